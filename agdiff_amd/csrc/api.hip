@@ -1,0 +1,58 @@
+// Whole-path entry points: ABI self-description, the score network (dualenc.py:142-251) and one
+// denoising step (dualenc.py:478-545), composed from the per-op launchers.
+#include "common.hpp"
+
+extern "C" int agdiff_abi_version(void) { return AGDIFF_ABI_VERSION; }
+
+extern "C" int agdiff_struct_sizes(int64_t* out) {
+  if (!out) return AGDIFF_ERR_ARG;
+  out[0] = sizeof(agdiff_conv_params_t);
+  out[1] = sizeof(agdiff_gin_params_t);
+  out[2] = sizeof(agdiff_head_params_t);
+  out[3] = sizeof(agdiff_params_t);
+  out[4] = sizeof(agdiff_topo_t);
+  out[5] = sizeof(agdiff_ws_t);
+  out[6] = sizeof(agdiff_step_args_t);
+  return AGDIFF_OK;
+}
+
+#define AG_TRY(call)            \
+  do {                          \
+    int _rc = (call);           \
+    if (_rc != AGDIFF_OK) return _rc; \
+  } while (0)
+
+extern "C" int agdiff_score_forward(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
+                                    const float* pos, int32_t with_global, void* stream) {
+  if (!p || !topo || !ws || !pos) return AGDIFF_ERR_ARG;
+  const int64_t ltiles = (topo->num_local + 31) / 32;
+  // local branch: lengths -> edge encoder -> GIN -> local head   (dualenc.py:214-239)
+  AG_TRY(agdiff_local_lengths(topo, ws, pos, stream));
+  if (topo->num_local > 0) {
+    AG_TRY(agdiff_edge_encoder(p, ws->num_local, ltiles, ws->l_len, topo->loc_type, ws->l_attr, stream));
+  }
+  AG_TRY(agdiff_gin_encoder(p, topo, ws, stream));
+  if (topo->num_local > 0) {
+    AG_TRY(agdiff_pair_head(&p->head_local, ws->num_local, ltiles, topo->loc_src, topo->loc_dst, ws->hl, ws->l_attr,
+                            ws->l_inv, stream));
+  }
+  if (!with_global) return AGDIFF_OK;
+  // global branch: radius graph -> edge encoder -> SchNet -> global head   (dualenc.py:167-211)
+  const int64_t etiles = (topo->max_edges + 31) / 32;
+  AG_TRY(agdiff_graph_build(topo, ws, pos, p->cutoff, stream));
+  AG_TRY(agdiff_edge_encoder(p, ws->num_edges, etiles, ws->e_len, ws->e_type, ws->e_attr, stream));
+  for (int k = 0; k <= p->num_convs; ++k) {
+    AG_TRY(agdiff_schnet_node_stage(p, topo, ws, k, stream));
+    if (k < p->num_convs) AG_TRY(agdiff_cfconv_fused(p, topo, ws, k, stream));
+  }
+  AG_TRY(agdiff_pair_head(&p->head_global, ws->num_edges, etiles, ws->e_src, ws->e_dst, ws->h, ws->e_attr,
+                          ws->e_inv_global, stream));
+  return AGDIFF_OK;
+}
+
+extern "C" int agdiff_langevin_step(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
+                                    const agdiff_step_args_t* a, void* stream) {
+  if (!a) return AGDIFF_ERR_ARG;
+  AG_TRY(agdiff_score_forward(p, topo, ws, a->pos_in, a->use_global, stream));
+  return agdiff_langevin_update(topo, ws, a, stream);
+}

@@ -1,0 +1,405 @@
+// Per-node kernels: SchNet node stages (everything of InteractionBlock / AdaptiveScaling that is not
+// per-edge), GIN layers, and the per-molecule Langevin update.  One wave = one tile of 32 nodes in
+// the MFMA accumulator layout (common.hpp): lane <-> node, registers <-> features.
+#include "common.hpp"
+#include <type_traits>
+
+namespace {
+
+// ------------------------------------------------------------------------------ SchNet node stage
+struct NodeStageArgs {
+  agdiff_conv_params_t prev;   // block k-1 (finish)   -- valid when finish != 0
+  agdiff_conv_params_t next;   // block k   (lin1)     -- valid when prep != 0
+  const float* emb;            // [100][128]
+  const int32_t* atom_type;
+  const int32_t* in_ptr;
+  const float* agg;
+  const float* agg_first;
+  float* h;
+  float* xs;
+  int64_t n;
+  int32_t finish;
+  int32_t prep;
+};
+
+// Stage k of SchNetEncoder.forward (schnet.py:268-282):
+//   finish: p1 = BN(lin2_1(agg1)), p2 = BN(lin2_2(agg2))         (schnet.py:157-158, BN folded)
+//           x  = lin(ssp(cat[p1,p2]));  x *= sigmoid(att(x))      (schnet.py:206-214)
+//           h += x * sigmoid(fc2(relu(fc1(x))))                   (schnet.py:230-234, 280)
+//   prep:   xs = LeakyReLU(BN(lin1(h))) for conv1 | conv2         (schnet.py:153-155)
+//   stage 0 (finish == 0): h = embedding[z]                       (schnet.py:271)
+__global__ void __launch_bounds__(AG_WG, 2) k_schnet_node_stage(NodeStageArgs a) {
+  const int lane = ag_lane(), h = lane >> 5;
+  const int64_t tile = (int64_t)blockIdx.x * 4 + ag_wave_in_wg();
+  if (tile * 32 >= a.n) return;
+  const int64_t node = tile * 32 + (lane & 31);
+  const bool valid = node < a.n;
+  const int64_t nd = valid ? node : 0;
+
+  f32x16 hv[4];
+  if (!a.finish) {
+    ag_load_row<4, 0>(hv, a.emb + (size_t)a.atom_type[nd] * 128, h);
+  } else {
+    f32x16 u[8];
+    {
+      // aggregates: agg[node] (+ the partial its last chunk kept separately, edge.hip k_cfconv_fused)
+      const int lo = a.in_ptr[nd], hi = a.in_ptr[nd + 1];
+      const int chunk_e = 32 * AGDIFF_CHUNK_TILES;
+      const bool has = hi > lo;
+      const int c_lo = lo / chunk_e, c_hi = has ? (hi - 1) / chunk_e : c_lo;
+      const float* ar = a.agg + (size_t)nd * 192;
+      const float* fr = a.agg_first + (size_t)c_hi * 192;
+      const bool split = has && (c_hi > c_lo);
+      ag_init_vec<8>(u, a.prev.lin2_b, h);
+      f32x16 g[2];
+      auto load_slice = [&](auto which, int k) {
+        constexpr int W = decltype(which)::value;
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const int f = 32 * k + 8 * rq + 4 * h;
+          f32x4 v = has ? ag_ld4(ar + f) : f32x4{0.f, 0.f, 0.f, 0.f};
+          if (split) v += ag_ld4(fr + f);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) g[W][4 * rq + q] = v[q];
+        }
+      };
+      load_slice(std::integral_constant<int, 0>{}, 0);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        if (k + 1 < 6) {
+          if (k & 1) load_slice(std::integral_constant<int, 0>{}, k + 1);
+          else load_slice(std::integral_constant<int, 1>{}, k + 1);
+        }
+        // conv1.lin2: slices 0..3 -> u[0..3]; conv2.lin2: slices 4..5 -> u[4..7]   (pkk blocks)
+        if (k < 4) {
+          if (k & 1) ag_dense_std_k<1, 4, 1, 0>(g, u, a.prev.lin2a_pk + (size_t)k * 4 * 1024, lane);
+          else ag_dense_std_k<1, 4, 0, 0>(g, u, a.prev.lin2a_pk + (size_t)k * 4 * 1024, lane);
+        } else {
+          if (k & 1) ag_dense_std_k<1, 4, 1, 4>(g, u, a.prev.lin2b_pk + (size_t)(k - 4) * 4 * 1024, lane);
+          else ag_dense_std_k<1, 4, 0, 4>(g, u, a.prev.lin2b_pk + (size_t)(k - 4) * 4 * 1024, lane);
+        }
+      }
+    }
+    {
+      const float beta = a.prev.act_beta;
+      AG_FOR_TILE(u, 8, ag_ssp(beta, v));
+    }
+    f32x16 xc[4];
+    ag_init_vec<4>(xc, a.prev.lin_b, h);
+    ag_dense_std<8, 4, 0, 0, 4>(u, xc, a.prev.lin_pk, lane);
+    {
+      f32x16 g1[2];
+      ag_init_vec<2>(g1, a.prev.gate1_b, h);
+      ag_dense_std<4, 2, 0, 0, 4>(xc, g1, a.prev.gate1_pk, lane);
+      AG_FOR_TILE(g1, 2, ag_relu(v));
+      const float gate = ag_sigmoid(ag_dot_vec<2>(g1, a.prev.gate2_w, h) + a.prev.gate2_b);
+      AG_FOR_TILE(xc, 4, v * gate);
+    }
+    {
+      f32x16 s1[1], s2[4];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s1[0][r] = 0.0f;
+      ag_dense_std<4, 1, 0, 0, 4>(xc, s1, a.prev.scale1_pk, lane);
+      AG_FOR_TILE(s1, 1, ag_relu(v));
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s2[t][r] = 0.0f;
+      ag_dense_std<1, 4, 0, 0, 1>(s1, s2, a.prev.scale2_pk, lane);
+      ag_load_row<4, 0>(hv, a.h + (size_t)nd * 128, h);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hv[t][r] = hv[t][r] + xc[t][r] * ag_sigmoid(s2[t][r]);
+    }
+  }
+  if (valid) ag_store_row<4, 0>(hv, a.h + (size_t)node * 128, h);
+  if (a.prep) {
+    f32x16 xo[6];
+    ag_init_vec<6>(xo, a.next.lin1_b, h);
+    ag_dense_std<4, 6, 0, 0, 4>(hv, xo, a.next.lin1_pk, lane);
+    AG_FOR_TILE(xo, 6, ag_lrelu(v));
+    if (valid) ag_store_row<6, 0>(xo, a.xs + (size_t)node * 192, h);
+  }
+}
+
+// ------------------------------------------------------------------------------ GIN layer
+struct GinArgs {
+  agdiff_gin_params_t gp;
+  const float* emb;            // non-null on layer 0: input = node_emb[z]
+  const int32_t* atom_type;
+  const int32_t* loc_in_ptr;
+  const int32_t* loc_in_eid;
+  const int32_t* loc_src;
+  const float* l_attr;         // fragment-major local edge attrs
+  const float* h_in;
+  float* h_out;
+  int64_t n;
+};
+
+// GINEConv + BN + relu + residual (gin.py:57-63, 131-138): m_i = sum relu(h_j + e_ji);
+// u = MLP(m_i + (1+eps) h_i); u = BN(u) (folded); relu except last layer; h = u + h.
+__global__ void __launch_bounds__(AG_WG, 2) k_gin_layer(GinArgs a) {
+  const int lane = ag_lane(), h = lane >> 5;
+  const int64_t tile = (int64_t)blockIdx.x * 4 + ag_wave_in_wg();
+  if (tile * 32 >= a.n) return;
+  const int64_t node = tile * 32 + (lane & 31);
+  const bool valid = node < a.n;
+  const int64_t nd = valid ? node : 0;
+  const float* hin_self = a.emb ? a.emb + (size_t)a.atom_type[nd] * 128 : a.h_in + (size_t)nd * 128;
+
+  f32x16 m[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m[t][r] = 0.0f;
+  const int lo = a.loc_in_ptr[nd], hi = valid ? a.loc_in_ptr[nd + 1] : lo;
+  int maxdeg = hi - lo;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, o));
+  for (int k = 0; k < maxdeg; ++k) {
+    const bool on = lo + k < hi;
+    const int eid = on ? a.loc_in_eid[lo + k] : 0;
+    const int src = on ? a.loc_src[eid] : 0;
+    const float* hs = a.emb ? a.emb + (size_t)a.atom_type[src] * 128 : a.h_in + (size_t)src * 128;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int f = 32 * t + 8 * rq + 4 * h;
+        const f32x4 hvv = ag_ld4(hs + f);
+        const f32x4 ev = ag_ld4(a.l_attr + ag_frag_off_ef(eid, f));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m[t][4 * rq + q] += on ? ag_relu(hvv[q] + ev[q]) : 0.0f;
+      }
+  }
+  f32x16 hs[4];
+  ag_load_row<4, 0>(hs, hin_self, h);
+  {
+    const float ope = a.gp.one_plus_eps;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m[t][r] = m[t][r] + ope * hs[t][r];
+  }
+  f32x16 y1[4];
+  ag_init_vec<4>(y1, a.gp.b1, h);
+  ag_dense_std<4, 4, 0, 0, 4>(m, y1, a.gp.w1_pk, lane);
+  AG_FOR_TILE(y1, 4, ag_relu(v));
+  ag_init_vec<4>(m, a.gp.b2, h);
+  ag_dense_std<4, 4, 0, 0, 4>(y1, m, a.gp.w2_pk, lane);
+  if (a.gp.relu_out) { AG_FOR_TILE(m, 4, ag_relu(v)); }
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m[t][r] += hs[t][r];
+  if (valid) ag_store_row<4, 0>(m, a.h_out + (size_t)node * 128, h);
+}
+
+// ------------------------------------------------------------------------------ Langevin update
+struct UpdateArgs {
+  agdiff_step_args_t s;
+  const int32_t* graph_ptr;
+  // local edges
+  const int32_t* loc_src;
+  const int32_t* loc_dst;
+  const int32_t* loc_out_ptr;
+  const int32_t* loc_in_ptr;
+  const int32_t* loc_in_eid;
+  const float* l_len;
+  const float* l_inv;
+  // dynamic edges
+  const int32_t* in_ptr;
+  const int32_t* out_ptr;
+  const int32_t* ref2dst;
+  const int32_t* e_src;
+  const int32_t* e_dst;
+  const int32_t* e_type;
+  const float* e_len;
+  const float* e_inv;
+  int32_t* nan_flag;
+};
+
+__device__ __forceinline__ void clip3(float& x, float& y, float& z, float limit) {  // dualenc.py:586-589
+  const float nrm = sqrtf(x * x + y * y + z * z);
+  if (nrm > limit) {
+    const float d = limit / nrm;
+    x *= d; y *= d; z *= d;
+  }
+}
+
+// One workgroup per molecule: eq_transform of the local and (optionally) global edge scores
+// (geometry.py:9-17), clip_norm, the Langevin move (dualenc.py:526-538), NaN flag, center_pos,
+// clamp, trajectory copy (dualenc.py:539-545).
+__global__ void __launch_bounds__(256) k_langevin_update(UpdateArgs a) {
+  const int g = blockIdx.x;
+  const int g0 = a.graph_ptr[g], n = a.graph_ptr[g + 1] - g0;
+  __shared__ float red[3][4];
+  __shared__ int nanw[4];
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  int bad = 0;
+  // pass 1: new (uncentred) positions into pos_out, per-thread partial sums for the centroid
+  for (int li = threadIdx.x; li < n; li += blockDim.x) {
+    const int i = g0 + li;
+    const float px = a.s.pos_in[3 * i], py = a.s.pos_in[3 * i + 1], pz = a.s.pos_in[3 * i + 2];
+    float ox = 0.f, oy = 0.f, oz = 0.f, ix = 0.f, iy = 0.f, iz = 0.f;
+    for (int e = a.loc_out_ptr[i]; e < a.loc_out_ptr[i + 1]; ++e) {   // row == i: + dd_dr * score
+      const int j = a.loc_dst[e];
+      const float w = (1.0f / a.l_len[e]), sc = a.l_inv[e];
+      ox += (w * (px - a.s.pos_in[3 * j])) * sc;
+      oy += (w * (py - a.s.pos_in[3 * j + 1])) * sc;
+      oz += (w * (pz - a.s.pos_in[3 * j + 2])) * sc;
+    }
+    for (int k = a.loc_in_ptr[i]; k < a.loc_in_ptr[i + 1]; ++k) {     // col == i: - dd_dr * score
+      const int e = a.loc_in_eid[k];
+      const int j = a.loc_src[e];
+      const float w = (1.0f / a.l_len[e]), sc = a.l_inv[e];
+      ix -= (w * (a.s.pos_in[3 * j] - px)) * sc;
+      iy -= (w * (a.s.pos_in[3 * j + 1] - py)) * sc;
+      iz -= (w * (a.s.pos_in[3 * j + 2] - pz)) * sc;
+    }
+    float lx = ox + ix, ly = oy + iy, lz = oz + iz;
+    if (a.s.clip_local >= 0.0f) clip3(lx, ly, lz, a.s.clip_local);
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    if (a.s.use_global) {
+      ox = oy = oz = ix = iy = iz = 0.f;
+      for (int q = a.out_ptr[i]; q < a.out_ptr[i + 1]; ++q) {
+        const int e = a.ref2dst[q];
+        if (a.e_type[e] != 0) continue;          // edge_inv_global * (1 - local_edge_mask), dualenc.py:516-518
+        const int j = a.e_dst[e];
+        const float w = (1.0f / a.e_len[e]), sc = a.e_inv[e];
+        ox += (w * (px - a.s.pos_in[3 * j])) * sc;
+        oy += (w * (py - a.s.pos_in[3 * j + 1])) * sc;
+        oz += (w * (pz - a.s.pos_in[3 * j + 2])) * sc;
+      }
+      for (int e = a.in_ptr[i]; e < a.in_ptr[i + 1]; ++e) {
+        if (a.e_type[e] != 0) continue;
+        const int j = a.e_src[e];
+        const float w = (1.0f / a.e_len[e]), sc = a.e_inv[e];
+        ix -= (w * (a.s.pos_in[3 * j] - px)) * sc;
+        iy -= (w * (a.s.pos_in[3 * j + 1] - py)) * sc;
+        iz -= (w * (a.s.pos_in[3 * j + 2] - pz)) * sc;
+      }
+      gx = ox + ix; gy = oy + iy; gz = oz + iz;
+      clip3(gx, gy, gz, a.s.clip);
+    }
+    const float ex = lx + gx * a.s.w_global, ey = ly + gy * a.s.w_global, ez = lz + gz * a.s.w_global;
+    const float nx = (px + (a.s.step_size * ex) / a.s.sigma) + a.s.noise[3 * i] * a.s.noise_scale;
+    const float ny = (py + (a.s.step_size * ey) / a.s.sigma) + a.s.noise[3 * i + 1] * a.s.noise_scale;
+    const float nz = (pz + (a.s.step_size * ez) / a.s.sigma) + a.s.noise[3 * i + 2] * a.s.noise_scale;
+    bad |= (nx != nx) | (ny != ny) | (nz != nz);
+    sx += nx; sy += ny; sz += nz;
+    a.s.scratch[3 * i] = nx; a.s.scratch[3 * i + 1] = ny; a.s.scratch[3 * i + 2] = nz;
+  }
+  // centroid
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sz += __shfl_xor(sz, o);
+    bad |= __shfl_xor(bad, o);
+  }
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wv] = sx; red[1][wv] = sy; red[2][wv] = sz; nanw[wv] = bad; }
+  __syncthreads();
+  const int nw = blockDim.x >> 6;
+  float cx = 0.f, cy = 0.f, cz = 0.f;
+  int anybad = 0;
+  for (int w = 0; w < nw; ++w) { cx += red[0][w]; cy += red[1][w]; cz += red[2][w]; anybad |= nanw[w]; }
+  const float inv_n = 1.0f / (float)(n > 0 ? n : 1);
+  cx *= inv_n; cy *= inv_n; cz *= inv_n;
+  if (anybad && threadIdx.x == 0) *a.nan_flag = 1;
+  for (int li = threadIdx.x; li < n; li += blockDim.x) {
+    const int i = g0 + li;
+    float x = a.s.scratch[3 * i] - cx, y = a.s.scratch[3 * i + 1] - cy, z = a.s.scratch[3 * i + 2] - cz;
+    if (a.s.clip_pos >= 0.0f) {
+      x = fminf(fmaxf(x, -a.s.clip_pos), a.s.clip_pos);
+      y = fminf(fmaxf(y, -a.s.clip_pos), a.s.clip_pos);
+      z = fminf(fmaxf(z, -a.s.clip_pos), a.s.clip_pos);
+    }
+    a.s.pos_out[3 * i] = x; a.s.pos_out[3 * i + 1] = y; a.s.pos_out[3 * i + 2] = z;
+    if (a.s.traj_out) { a.s.traj_out[3 * i] = x; a.s.traj_out[3 * i + 1] = y; a.s.traj_out[3 * i + 2] = z; }
+  }
+}
+
+}  // namespace
+
+extern "C" int agdiff_schnet_node_stage(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
+                                        int32_t k, void* stream) {
+  if (!p || !topo || !ws || k < 0 || k > p->num_convs || p->num_convs > AGDIFF_MAX_CONVS) return AGDIFF_ERR_ARG;
+  if (topo->num_nodes <= 0) return AGDIFF_OK;
+  NodeStageArgs a;
+  a.finish = k > 0;
+  a.prep = k < p->num_convs;
+  a.prev = p->conv[k > 0 ? k - 1 : 0];
+  a.next = p->conv[k < p->num_convs ? k : 0];
+  a.emb = p->schnet_emb;
+  a.atom_type = topo->atom_type;
+  a.in_ptr = ws->in_ptr;
+  a.agg = ws->agg;
+  a.agg_first = ws->agg_first;
+  a.h = ws->h;
+  a.xs = ws->xs;
+  a.n = topo->num_nodes;
+  const int64_t tiles = (a.n + 31) / 32;
+  k_schnet_node_stage<<<dim3((unsigned)((tiles + 3) / 4)), dim3(AG_WG), 0, (hipStream_t)stream>>>(a);
+  AG_CHECK_LAUNCH();
+  return AGDIFF_OK;
+}
+
+extern "C" int agdiff_gin_encoder(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, void* stream) {
+  if (!p || !topo || !ws || p->num_convs_local <= 0 || p->num_convs_local > AGDIFF_MAX_CONVS_LOCAL) return AGDIFF_ERR_ARG;
+  if (topo->num_nodes <= 0) return AGDIFF_OK;
+  const int64_t tiles = (topo->num_nodes + 31) / 32;
+  // ping-pong so that the final layer lands in ws->hl
+  float* bufs[2] = {ws->hl, ws->hl2};
+  int cur = (p->num_convs_local & 1) ? 0 : 1;   // layer 0 writes bufs[cur]; the last write must hit bufs[0]
+  const float* in = nullptr;
+  for (int k = 0; k < p->num_convs_local; ++k) {
+    GinArgs a;
+    a.gp = p->gin[k];
+    a.emb = (k == 0) ? p->gin_emb : nullptr;
+    a.atom_type = topo->atom_type;
+    a.loc_in_ptr = topo->loc_in_ptr;
+    a.loc_in_eid = topo->loc_in_eid;
+    a.loc_src = topo->loc_src;
+    a.l_attr = ws->l_attr;
+    a.h_in = in;
+    a.h_out = bufs[cur];
+    a.n = topo->num_nodes;
+    k_gin_layer<<<dim3((unsigned)((tiles + 3) / 4)), dim3(AG_WG), 0, (hipStream_t)stream>>>(a);
+    AG_CHECK_LAUNCH();
+    in = bufs[cur];
+    cur ^= 1;
+  }
+  return AGDIFF_OK;
+}
+
+extern "C" int agdiff_langevin_update(const agdiff_topo_t* topo, const agdiff_ws_t* ws, const agdiff_step_args_t* s,
+                                      void* stream) {
+  if (!topo || !ws || !s || !s->pos_in || !s->pos_out || !s->noise || !s->scratch || !ws->nan_flag) return AGDIFF_ERR_ARG;
+  if (topo->num_graphs <= 0) return AGDIFF_OK;
+  UpdateArgs a;
+  a.s = *s;
+  a.graph_ptr = topo->graph_ptr;
+  a.loc_src = topo->loc_src;
+  a.loc_dst = topo->loc_dst;
+  a.loc_out_ptr = topo->loc_out_ptr;
+  a.loc_in_ptr = topo->loc_in_ptr;
+  a.loc_in_eid = topo->loc_in_eid;
+  a.l_len = ws->l_len;
+  a.l_inv = ws->l_inv;
+  a.in_ptr = ws->in_ptr;
+  a.out_ptr = ws->out_ptr;
+  a.ref2dst = ws->ref2dst;
+  a.e_src = ws->e_src;
+  a.e_dst = ws->e_dst;
+  a.e_type = ws->e_type;
+  a.e_len = ws->e_len;
+  a.e_inv = ws->e_inv_global;
+  a.nan_flag = ws->nan_flag;
+  int bd = (int)(((topo->max_atoms_per_graph + 63) / 64) * 64);
+  if (bd > 256) bd = 256;
+  if (bd < 64) bd = 64;
+  k_langevin_update<<<dim3((unsigned)topo->num_graphs), dim3(bd), 0, (hipStream_t)stream>>>(a);
+  AG_CHECK_LAUNCH();
+  return AGDIFF_OK;
+}

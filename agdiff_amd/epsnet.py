@@ -1,0 +1,371 @@
+"""Host-side mirror of the reference's module API for the diffusion-sampling hot path.
+
+`get_model(config)` / `DualEncoderEpsNetwork` keep the reference's constructor argument, module
+tree, 854-key state_dict layout, `forward`, `langevin_dynamics_sample` and
+`langevin_dynamics_sample_diffusion` signatures (epsnet/__init__.py:7-11, epsnet/dualenc.py:54-547),
+so `scripts/test.py:111-164` runs against it unchanged.  The sub-modules below are parameter
+containers only: all arithmetic happens in libagdiff_hip.so (hand-written gfx950 kernels) through
+the C ABI of include/agdiff_hip.h.  There is no CPU / PyTorch fallback: calling the network
+without a GPU and the built library raises.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+from .packing import PackedParams
+from .topology import BatchTopology, Workspace
+
+H_FIXED = 128
+
+
+# ----------------------------------------------------------------------------------- schedule
+def get_beta_schedule(beta_schedule, *, beta_start, beta_end, num_diffusion_timesteps):
+    """epsnet/dualenc.py:21-51 (float64; the sigmoid branch's linspace has no dtype -> float64)."""
+    T = num_diffusion_timesteps
+    if beta_schedule == "quad":
+        betas = np.linspace(beta_start ** 0.5, beta_end ** 0.5, T, dtype=np.float64) ** 2
+    elif beta_schedule == "linear":
+        betas = np.linspace(beta_start, beta_end, T, dtype=np.float64)
+    elif beta_schedule == "const":
+        betas = beta_end * np.ones(T, dtype=np.float64)
+    elif beta_schedule == "jsd":
+        betas = 1.0 / np.linspace(T, 1, T, dtype=np.float64)
+    elif beta_schedule == "sigmoid":
+        betas = np.linspace(-6, 6, T)
+        betas = 1 / (np.exp(-betas) + 1) * (beta_end - beta_start) + beta_start
+    else:
+        raise NotImplementedError(beta_schedule)
+    assert betas.shape == (T,)
+    return betas
+
+
+# ----------------------------------------------------------------------------------- containers
+class _ShiftedSoftplus(nn.Module):          # schnet.py:71-75
+    def __init__(self):
+        super().__init__()
+        self.beta = nn.Parameter(torch.tensor(1.0))
+
+
+class _FilterAttention(nn.Module):          # schnet.py:103-106 (constructed, never called)
+    def __init__(self, f):
+        super().__init__()
+        self.attention_weights = nn.Parameter(torch.randn(f))
+
+
+class _DistanceWeighting(nn.Module):        # schnet.py:83-88
+    def __init__(self, hidden=32):
+        super().__init__()
+        self.layer1 = nn.Linear(1, hidden)
+        self.layer2 = nn.Linear(hidden, 1)
+
+
+class _CFConv(nn.Module):                   # schnet.py:113-134
+    def __init__(self, in_ch, out_ch, nf, filt):
+        super().__init__()
+        self.lin1 = nn.Linear(in_ch, nf, bias=True)
+        self.norm1 = nn.BatchNorm1d(nf)
+        self.lin2 = nn.Linear(nf, out_ch)
+        self.norm2 = nn.BatchNorm1d(out_ch)
+        self.nn = filt
+        self.attention = _FilterAttention(nf)
+        self.distance_weighting = _DistanceWeighting(32)
+        nn.init.xavier_uniform_(self.lin1.weight)
+        self.lin1.bias.data.fill_(0)
+        nn.init.xavier_uniform_(self.lin2.weight)
+        self.lin2.bias.data.fill_(0)
+
+
+class _InteractionBlock(nn.Module):         # schnet.py:165-199
+    def __init__(self, hidden, edge_ch, nf):
+        super().__init__()
+        mlp1 = nn.Sequential(nn.Linear(edge_ch, nf), _ShiftedSoftplus(), nn.Linear(nf, nf))
+        mlp2 = nn.Sequential(nn.Linear(edge_ch, nf // 2), _ShiftedSoftplus(), nn.Linear(nf // 2, nf // 2))
+        self.conv1 = _CFConv(hidden, hidden, nf, mlp1)
+        self.conv2 = _CFConv(hidden, hidden, nf // 2, mlp2)
+        self.act = _ShiftedSoftplus()
+        self.lin = nn.Linear(256, hidden)
+        self.attention = nn.Sequential(nn.Linear(hidden, hidden // 2), nn.ReLU(inplace=True),
+                                       nn.Linear(hidden // 2, 1), nn.Sigmoid())
+
+
+class _AdaptiveScaling(nn.Module):          # schnet.py:219-228
+    def __init__(self, ch, reduction=16):
+        super().__init__()
+        self.fc = nn.Sequential(nn.Linear(ch, ch // reduction, bias=False), nn.ReLU(inplace=True),
+                                nn.Linear(ch // reduction, ch, bias=False), nn.Sigmoid())
+
+
+class _SchNetEncoder(nn.Module):            # schnet.py:237-266
+    def __init__(self, hidden, nf, n_inter, edge_ch):
+        super().__init__()
+        self.embedding = nn.Embedding(100, hidden, max_norm=10.0)
+        self.interactions = nn.ModuleList([_InteractionBlock(hidden, edge_ch, nf) for _ in range(n_inter)])
+        self.scaling_modules = nn.ModuleList([_AdaptiveScaling(hidden) for _ in range(n_inter)])
+
+
+class _MLPEdgeEncoder(nn.Module):           # edge.py:45-82
+    def __init__(self, hidden):
+        super().__init__()
+        self.hidden_dim = hidden
+        self.bond_emb = nn.Embedding(100, embedding_dim=hidden)
+        self.feature_expansion = nn.Linear(1, hidden)
+        self.edge_feature_mlp = nn.Sequential(nn.Linear(hidden * 2, hidden), nn.GELU(), nn.Linear(hidden, hidden))
+        self.combination_mlp = nn.Sequential(nn.Linear(hidden * 2, hidden), nn.GELU(), nn.Linear(hidden, hidden))
+        self.attention = nn.Sequential(nn.Linear(hidden, hidden), nn.Tanh(), nn.Linear(hidden, 1), nn.Softmax(dim=1))
+
+    @property
+    def out_channels(self):
+        return self.hidden_dim
+
+
+class _MLP(nn.Module):                      # common.py:44-84
+    def __init__(self, input_dim, hidden_dims):
+        super().__init__()
+        dims = [input_dim] + list(hidden_dims)
+        self.layers = nn.ModuleList([nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1)])
+        self.attention_layers = nn.ModuleList()
+
+
+class _GINEConv(nn.Module):                 # gin.py:14-36
+    def __init__(self, mlp):
+        super().__init__()
+        self.nn = mlp
+        self.register_buffer("eps", torch.Tensor([0.0]))
+
+
+class _GINEncoder(nn.Module):               # gin.py:75-110
+    def __init__(self, hidden, num_convs):
+        super().__init__()
+        self.node_emb = nn.Embedding(100, hidden)
+        self.convs = nn.ModuleList([_GINEConv(_MLP(hidden, [hidden, hidden])) for _ in range(num_convs)])
+        self.batch_norms = nn.ModuleList([nn.BatchNorm1d(hidden) for _ in range(num_convs)])
+
+
+def get_edge_encoder(cfg):                  # edge.py:106-116
+    if cfg.edge_encoder == "mlp":
+        return _MLPEdgeEncoder(cfg.hidden_dim)
+    elif cfg.edge_encoder == "gaussian":
+        # The reference raises NameError here (GaussianSmearing is never imported, edge.py:24);
+        # this build does not implement the row either.
+        raise NotImplementedError("edge_encoder 'gaussian' is not implemented by the HIP path")
+    else:
+        raise NotImplementedError(f"Unknown edge encoder: {cfg.edge_encoder}")
+
+
+# ----------------------------------------------------------------------------------- the network
+class DualEncoderEpsNetwork(nn.Module):
+    """Drop-in for agdiff.models.epsnet.dualenc.DualEncoderEpsNetwork (sampling path only)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        if config.hidden_dim != H_FIXED:
+            raise NotImplementedError("hidden_dim must be 128: InteractionBlock.lin = Linear(256, hidden) (schnet.py:190)")
+        self.edge_encoder_global = get_edge_encoder(config)
+        self.edge_encoder_local = get_edge_encoder(config)
+        self.encoder_global = _SchNetEncoder(config.hidden_dim, config.hidden_dim, config.num_convs,
+                                             self.edge_encoder_global.out_channels)
+        self.encoder_local = _GINEncoder(config.hidden_dim, config.num_convs_local)
+        self.grad_global_dist_mlp = _MLP(2 * config.hidden_dim, [config.hidden_dim, config.hidden_dim // 2, 1])
+        self.grad_local_dist_mlp = _MLP(2 * config.hidden_dim, [config.hidden_dim, config.hidden_dim // 2, 1])
+        self.model_global = nn.ModuleList([self.edge_encoder_global, self.encoder_global, self.grad_global_dist_mlp])
+        self.model_local = nn.ModuleList([self.edge_encoder_local, self.encoder_local, self.grad_local_dist_mlp])
+        self.model_type = config.type
+        if self.model_type == "diffusion":
+            betas = get_beta_schedule(beta_schedule=config.beta_schedule, beta_start=config.beta_start,
+                                      beta_end=config.beta_end,
+                                      num_diffusion_timesteps=config.num_diffusion_timesteps)
+            betas = torch.from_numpy(betas).float()
+            self.betas = nn.Parameter(betas, requires_grad=False)
+            alphas = (1.0 - betas).cumprod(dim=0)
+            self.alphas = nn.Parameter(alphas, requires_grad=False)
+            self.num_timesteps = self.betas.size(0)
+        else:
+            raise NotImplementedError("model type %r: only 'diffusion' is on the HIP path" % (self.model_type,))
+        self._packed = None
+        self._packed_key = None
+        self._batch_cache = None
+
+    # ------------------------------------------------------------------ plumbing
+    def _device(self):
+        return self.betas.device
+
+    def _require_gpu(self):
+        dev = self._device()
+        if dev.type != "cuda":
+            raise _lib.AgdiffHipError(
+                "agdiff_amd.DualEncoderEpsNetwork computes on an MI355X only (module is on %s); "
+                "there is no CPU fallback -- call .to('cuda')" % dev)
+        return _lib.load()
+
+    def _weights_key(self):
+        return (str(self._device()),) + tuple(int(p._version) for p in self.state_dict(keep_vars=True).values())
+
+    def packed(self):
+        """Packed device weights, rebuilt when any parameter / buffer changed (load_state_dict, .to)."""
+        key = self._weights_key()
+        if self._packed is None or self._packed_key != key:
+            sd = {k: v for k, v in self.state_dict().items()}
+            self._packed = PackedParams(sd, self.config, self._device())
+            self._packed_key = key
+        return self._packed
+
+    def _renorm_embedding(self, atom_type):
+        # nn.Embedding(max_norm=10) renormalises looked-up rows in place on every forward, also in
+        # eval mode (schnet.py:254,271); same ATen op, same side effect on the state_dict.
+        w = self.encoder_global.embedding.weight
+        with torch.no_grad():
+            torch.embedding_renorm_(w, atom_type.reshape(-1).long().to(w.device), 10.0, 2.0)
+        pk = self.packed()
+        pk.update_schnet_embedding(w)
+        self._packed_key = self._weights_key()
+        return pk
+
+    def _batch(self, atom_type, bond_index, bond_type, batch, num_graphs, extend_order):
+        """Static topology + workspace, cached for repeated calls on the same batch tensors."""
+        key = (atom_type.data_ptr(), bond_index.data_ptr(), bond_type.data_ptr(), batch.data_ptr(),
+               int(atom_type.shape[0]), int(bond_index.shape[1]), bool(extend_order), num_graphs, str(self._device()))
+        if self._batch_cache is not None and self._batch_cache[0] == key:
+            return self._batch_cache[1], self._batch_cache[2]
+        topo = BatchTopology(atom_type, bond_index, bond_type, batch, num_graphs=num_graphs,
+                             extend_order=extend_order, order=self.config.edge_order, device=self._device())
+        ws = Workspace(topo)
+        self._batch_cache = (key, topo, ws)
+        return topo, ws
+
+    # ------------------------------------------------------------------ forward (dualenc.py:142-251)
+    def forward(self, atom_type, pos, bond_index, bond_type, batch, time_step, edge_index=None, edge_type=None,
+                edge_length=None, return_edges=False, extend_order=True, extend_radius=True):
+        lib = self._require_gpu()
+        if edge_index is not None and edge_type is not None and edge_length is not None:
+            raise NotImplementedError("caller-supplied edge_index/edge_type/edge_length are not supported by the HIP path")
+        if not extend_radius:
+            raise NotImplementedError("extend_radius=False is not supported by the HIP path")
+        with torch.no_grad():
+            pk = self._renorm_embedding(atom_type)
+            topo, ws = self._batch(atom_type, bond_index, bond_type, batch, None, extend_order)
+            posc = pos.detach().to(torch.float32).contiguous()
+            _lib.check(lib.agdiff_score_forward(ctypes.byref(pk.struct), ctypes.byref(topo.struct),
+                                                ctypes.byref(ws.struct), _lib.ptr(posc), 1, _lib.stream_ptr()),
+                       "agdiff_score_forward")
+            E = int(ws.num_edges.item())
+            perm = ws.ref2dst[:E].long()                     # reference (row, col)-sorted order
+            inv_g = ws.e_inv_global[:E][perm].unsqueeze(-1)
+            inv_l = ws.l_inv[:topo.L].clone().unsqueeze(-1)
+            if not return_edges:
+                return inv_g, inv_l
+            e_index = torch.stack([ws.e_src[:E][perm].long(), ws.e_dst[:E][perm].long()], dim=0)
+            e_type = ws.e_type[:E][perm].long()
+            e_len = ws.e_len[:E][perm].unsqueeze(-1)
+            return inv_g, inv_l, e_index, e_type, e_len, e_type > 0
+
+    # ------------------------------------------------------------------ samplers (dualenc.py:397-547)
+    def langevin_dynamics_sample(self, atom_type, pos_init, bond_index, bond_type, batch, num_graphs, extend_order,
+                                 extend_radius=True, n_steps=5000, step_lr=0.0000010, clip=1000, clip_local=None,
+                                 clip_pos=None, min_sigma=0, global_start_sigma=float("inf"), w_global=0.2,
+                                 w_reg=1.0, **kwargs):
+        if self.model_type == "diffusion":
+            kwargs.setdefault("sampling_type", "ddpm_noisy")
+            kwargs.setdefault("eta", 1.0)
+            return self.langevin_dynamics_sample_diffusion(
+                atom_type, pos_init, bond_index, bond_type, batch, num_graphs, extend_order, extend_radius, n_steps,
+                step_lr, clip, clip_local, clip_pos, min_sigma, global_start_sigma, w_global, w_reg, **kwargs)
+
+    def langevin_dynamics_sample_diffusion(self, atom_type, pos_init, bond_index, bond_type, batch, num_graphs,
+                                           extend_order, extend_radius=True, n_steps=5000, step_lr=0.0000010,
+                                           clip=1000, clip_local=None, clip_pos=None, min_sigma=0,
+                                           global_start_sigma=float("inf"), w_global=0.2, w_reg=1.0, **kwargs):
+        """Same contract as the reference; extra keyword-only hooks (all optional):
+          noise            [n_steps, N, 3] tensor replacing torch.randn_like (parity tests)
+          save_traj        False -> return an empty pos_traj and skip the per-step copy
+          skip_discarded_global  False -> also run the global encoder on steps whose result the
+                           reference discards (sigma >= global_start_sigma, dualenc.py:523-524)
+          nan_check_every  host polls the device NaN flag every this many steps (default 64)
+          step_indices     explicit list of schedule indices to visit instead of the last n_steps
+                           (bench.py's subsampled runs)
+          on_step          callback(k, i, pos) after each step is enqueued (data-parallel gather)
+        """
+        lib = self._require_gpu()
+        if not extend_radius:
+            raise NotImplementedError("extend_radius=False is not supported by the HIP path")
+        noise = kwargs.get("noise")
+        save_traj = kwargs.get("save_traj", True)
+        skip_discarded = kwargs.get("skip_discarded_global", True)
+        nan_every = int(kwargs.get("nan_check_every", 64))
+        on_step = kwargs.get("on_step")
+        dev = self._device()
+        sigmas = ((1.0 - self.alphas).sqrt() / self.alphas.sqrt()).detach().cpu()
+        self.eval()
+        with torch.no_grad():
+            pk = self._renorm_embedding(atom_type)
+            topo, ws = self._batch(atom_type, bond_index, bond_type, batch, num_graphs, extend_order)
+            N = topo.N
+            steps = kwargs.get("step_indices")
+            if steps is None:
+                steps = list(reversed(range(self.num_timesteps - n_steps, self.num_timesteps)))
+            n_run = len(steps)
+            pos = (pos_init.detach().to(dev, torch.float32) * sigmas[-1].to(dev)).contiguous()
+            traj = torch.empty((n_run, N, 3), dtype=torch.float32, device=dev) if save_traj else None
+            chunk = 128
+            ws.nan_flag.zero_()
+            stream = _lib.stream_ptr()
+            a = _lib.StepArgs()
+            a.pos_in = _lib.ptr(pos)
+            a.pos_out = _lib.ptr(pos)
+            a.scratch = _lib.ptr(ws.scratch)
+            a.w_global = float(w_global)
+            a.clip = float(clip)
+            a.clip_local = -1.0 if clip_local is None else float(clip_local)
+            a.clip_pos = -1.0 if clip_pos is None else float(clip_pos)
+            nz = None
+            for k, i in enumerate(steps):
+                if noise is not None:
+                    cur = noise[k].to(dev, torch.float32).contiguous()
+                else:
+                    if k % chunk == 0:
+                        nz = torch.randn((min(chunk, n_run - k), N, 3), dtype=torch.float32, device=dev)
+                    cur = nz[k % chunk]
+                sig = sigmas[i]
+                step_size = step_lr * (sig / 0.01) ** 2               # dualenc.py:532, fp32 tensor math
+                use_global = bool(sig < global_start_sigma)            # dualenc.py:515
+                a.noise = _lib.ptr(cur)
+                a.traj_out = ctypes.c_void_p(traj[k].data_ptr()) if save_traj else ctypes.c_void_p(0)
+                a.sigma = float(sig)
+                a.step_size = float(step_size)
+                a.noise_scale = float(torch.sqrt(step_size * 2))
+                a.use_global = 1 if use_global else 0
+                run_global = 1 if (use_global or not skip_discarded) else 0
+                _lib.check(lib.agdiff_score_forward(ctypes.byref(pk.struct), ctypes.byref(topo.struct),
+                                                    ctypes.byref(ws.struct), a.pos_in, run_global, stream),
+                           "agdiff_score_forward")
+                _lib.check(lib.agdiff_langevin_update(ctypes.byref(topo.struct), ctypes.byref(ws.struct),
+                                                      ctypes.byref(a), stream), "agdiff_langevin_update")
+                if on_step is not None:
+                    on_step(k, i, pos)
+                if (k + 1) % nan_every == 0 or k == n_run - 1:
+                    if int(ws.nan_flag.item()) != 0:
+                        print("NaN detected. Please restart.")
+                        raise FloatingPointError()
+            pos_traj = list(traj.cpu().unbind(0)) if save_traj else []
+        return pos, pos_traj
+
+
+def get_model(config):
+    """epsnet/__init__.py:7-11."""
+    if config.network == "dualenc":
+        return DualEncoderEpsNetwork(config)
+    else:
+        raise NotImplementedError("Unknown network: %s" % config.network)
+
+
+# helpers with the reference's names (dualenc.py:550-589) that drivers import
+def is_local_edge(edge_type):
+    return edge_type > 0
+
+
+def is_radius_edge(edge_type):
+    return edge_type == 0

@@ -1,0 +1,203 @@
+"""Weight pre-packing: reference state_dict (SURVEY.md §8b key layout) -> the device buffers and the
+agdiff_params_t struct the HIP kernels read (include/agdiff_hip.h).
+
+Output-preserving transformations applied here (each checked against the oracle in tests/):
+  * eval-mode BatchNorm folded into the adjacent Linear (schnet.py:153-158, gin.py:131-132);
+  * MLPEdgeEncoder: the bond-embedding halves of the two 256->128 layers become per-edge-type
+    tables; edge_feature_mlp.2 is folded into combination_mlp.0; the size-1 softmax attention
+    (== 1.0) is dropped (edge.py:84-103);
+  * conv1/conv2 first filter layers and lin1 layers are fused along the output dimension.
+All folding is done in float64 and rounded once to float32.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+H = 128
+
+
+def _np(sd, key):
+    return sd[key].detach().cpu().double().numpy()
+
+
+def pack_blocks(W, kouter=False):
+    """Linear weight W[out, in] -> MFMA-fragment-major blocks (see include/agdiff_hip.h):
+    block(mt, t)[rq][lane][q] = W[32*mt + (lane & 31)][32*t + 8*rq + 4*(lane >> 5) + q];
+    blocks ordered [MT][KT] ("pk") or [KT][MT] ("pkk")."""
+    W = np.asarray(W, dtype=np.float64)
+    out, inn = W.shape
+    MT, KT = (out + 31) // 32, (inn + 31) // 32
+    Wp = np.zeros((MT * 32, KT * 32), dtype=np.float64)
+    Wp[:out, :inn] = W
+    lane = np.arange(64)
+    rq = np.arange(4)
+    q = np.arange(4)
+    rows = (lane & 31)[None, :, None]                                   # [1,64,1]
+    cols = 8 * rq[:, None, None] + 4 * (lane >> 5)[None, :, None] + q[None, None, :]   # [4,64,4]
+    blocks = np.empty((MT, KT, 4, 64, 4), dtype=np.float64)
+    for mt in range(MT):
+        for t in range(KT):
+            blocks[mt, t] = Wp[32 * mt + rows, 32 * t + cols]
+    if kouter:
+        blocks = blocks.transpose(1, 0, 2, 3, 4)
+    return np.ascontiguousarray(blocks).astype(np.float32).reshape(-1)
+
+
+def fold_bn(W, b, sd, p, eps=1e-5):
+    """Linear(W, b) followed by eval BatchNorm1d `p` -> one Linear."""
+    s = _np(sd, p + ".weight") / np.sqrt(_np(sd, p + ".running_var") + eps)
+    return W * s[:, None], (b - _np(sd, p + ".running_mean")) * s + _np(sd, p + ".bias")
+
+
+class PackedParams:
+    """Owns the device copies of all packed weights and the agdiff_params_t that points at them."""
+
+    def __init__(self, sd, cfg, device):
+        import torch
+        self.device = device
+        if cfg.hidden_dim != H:
+            raise NotImplementedError("hidden_dim must be 128 (InteractionBlock.lin is Linear(256, hidden), schnet.py:190)")
+        if cfg.edge_encoder != "mlp":
+            raise NotImplementedError("Unknown edge encoder: %s" % cfg.edge_encoder)
+        if cfg.mlp_act != "relu":
+            raise NotImplementedError("mlp_act=%s (HIP heads implement relu, configs/*.yml:8)" % cfg.mlp_act)
+        if cfg.num_convs > _lib.DEFINES["AGDIFF_MAX_CONVS"] or cfg.num_convs_local > _lib.DEFINES["AGDIFF_MAX_CONVS_LOCAL"]:
+            raise NotImplementedError("too many conv layers for this build")
+        arrays = {}      # name -> np.float32 array
+        scalars = {}
+
+        # ---------------- edge encoder (edge.py:84-103)
+        e = "edge_encoder_global"
+        emb = _np(sd, e + ".bond_emb.weight")                           # [100,128]
+        W0, b0 = _np(sd, e + ".edge_feature_mlp.0.weight"), _np(sd, e + ".edge_feature_mlp.0.bias")
+        W2, b2 = _np(sd, e + ".edge_feature_mlp.2.weight"), _np(sd, e + ".edge_feature_mlp.2.bias")
+        C0, c0 = _np(sd, e + ".combination_mlp.0.weight"), _np(sd, e + ".combination_mlp.0.bias")
+        C2, c2 = _np(sd, e + ".combination_mlp.2.weight"), _np(sd, e + ".combination_mlp.2.bias")
+        arrays["ee_fe_w"] = _np(sd, e + ".feature_expansion.weight")[:, 0]
+        arrays["ee_fe_b"] = _np(sd, e + ".feature_expansion.bias")
+        arrays["ee_t1"] = emb @ W0[:, H:].T + b0[None, :]
+        arrays["ee_w1_pk"] = pack_blocks(W0[:, :H])
+        arrays["ee_t3"] = emb @ C0[:, H:].T + (c0 + C0[:, :H] @ b2)[None, :]
+        arrays["ee_w23_pk"] = pack_blocks(C0[:, :H] @ W2)
+        arrays["ee_w4_pk"] = pack_blocks(C2)
+        arrays["ee_b4"] = c2
+        arrays["schnet_emb"] = _np(sd, "encoder_global.embedding.weight")
+        arrays["gin_emb"] = _np(sd, "encoder_local.node_emb.weight")
+
+        # ---------------- SchNet blocks (schnet.py:113-234)
+        for k in range(cfg.num_convs):
+            p = "encoder_global.interactions.%d" % k
+            c1, c2_ = p + ".conv1", p + ".conv2"
+            n = "conv%d." % k
+            arrays[n + "filt_w1_pk"] = pack_blocks(
+                np.concatenate([_np(sd, c1 + ".nn.0.weight"), _np(sd, c2_ + ".nn.0.weight")], 0), kouter=True)
+            arrays[n + "filt_b1"] = np.concatenate([_np(sd, c1 + ".nn.0.bias"), _np(sd, c2_ + ".nn.0.bias")])
+            arrays[n + "filt_w2a_pk"] = pack_blocks(_np(sd, c1 + ".nn.2.weight"))
+            arrays[n + "filt_w2b_pk"] = pack_blocks(_np(sd, c2_ + ".nn.2.weight"))
+            arrays[n + "filt_b2"] = np.concatenate([_np(sd, c1 + ".nn.2.bias"), _np(sd, c2_ + ".nn.2.bias")])
+            dws = []
+            for c in (c1, c2_):
+                d = c + ".distance_weighting"
+                dws.append(np.concatenate([_np(sd, d + ".layer1.weight")[:, 0], _np(sd, d + ".layer1.bias"),
+                                           _np(sd, d + ".layer2.weight")[0], _np(sd, d + ".layer2.bias")]))
+            arrays[n + "dist_w"] = np.concatenate(dws)
+            scalars[n + "ssp_beta1"] = float(_np(sd, c1 + ".nn.1.beta"))
+            scalars[n + "ssp_beta2"] = float(_np(sd, c2_ + ".nn.1.beta"))
+            W1a, b1a = fold_bn(_np(sd, c1 + ".lin1.weight"), _np(sd, c1 + ".lin1.bias"), sd, c1 + ".norm1")
+            W1b, b1b = fold_bn(_np(sd, c2_ + ".lin1.weight"), _np(sd, c2_ + ".lin1.bias"), sd, c2_ + ".norm1")
+            arrays[n + "lin1_pk"] = pack_blocks(np.concatenate([W1a, W1b], 0))
+            arrays[n + "lin1_b"] = np.concatenate([b1a, b1b])
+            W2a, b2a = fold_bn(_np(sd, c1 + ".lin2.weight"), _np(sd, c1 + ".lin2.bias"), sd, c1 + ".norm2")
+            W2b, b2b = fold_bn(_np(sd, c2_ + ".lin2.weight"), _np(sd, c2_ + ".lin2.bias"), sd, c2_ + ".norm2")
+            arrays[n + "lin2a_pk"] = pack_blocks(W2a, kouter=True)
+            arrays[n + "lin2b_pk"] = pack_blocks(W2b, kouter=True)
+            arrays[n + "lin2_b"] = np.concatenate([b2a, b2b])
+            arrays[n + "lin_pk"] = pack_blocks(_np(sd, p + ".lin.weight"))
+            arrays[n + "lin_b"] = _np(sd, p + ".lin.bias")
+            arrays[n + "gate1_pk"] = pack_blocks(_np(sd, p + ".attention.0.weight"))
+            arrays[n + "gate1_b"] = _np(sd, p + ".attention.0.bias")
+            arrays[n + "gate2_w"] = _np(sd, p + ".attention.2.weight")[0]
+            scalars[n + "gate2_b"] = float(_np(sd, p + ".attention.2.bias")[0])
+            scalars[n + "act_beta"] = float(_np(sd, p + ".act.beta"))
+            s = "encoder_global.scaling_modules.%d" % k
+            arrays[n + "scale1_pk"] = pack_blocks(_np(sd, s + ".fc.0.weight"))
+            arrays[n + "scale2_pk"] = pack_blocks(_np(sd, s + ".fc.2.weight"))
+
+        # ---------------- GIN (gin.py:38-69, 112-148)
+        for k in range(cfg.num_convs_local):
+            p = "encoder_local.convs.%d" % k
+            n = "gin%d." % k
+            arrays[n + "w1_pk"] = pack_blocks(_np(sd, p + ".nn.layers.0.weight"))
+            arrays[n + "b1"] = _np(sd, p + ".nn.layers.0.bias")
+            W, b = fold_bn(_np(sd, p + ".nn.layers.1.weight"), _np(sd, p + ".nn.layers.1.bias"), sd,
+                           "encoder_local.batch_norms.%d" % k)
+            arrays[n + "w2_pk"] = pack_blocks(W)
+            arrays[n + "b2"] = b
+            scalars[n + "one_plus_eps"] = 1.0 + float(_np(sd, p + ".eps")[0])
+
+        # ---------------- heads (common.py:44-103; dualenc.py:88-98)
+        for name, p in (("head_global", "grad_global_dist_mlp"), ("head_local", "grad_local_dist_mlp")):
+            n = name + "."
+            arrays[n + "w1_pk"] = pack_blocks(_np(sd, p + ".layers.0.weight"), kouter=True)
+            arrays[n + "b1"] = _np(sd, p + ".layers.0.bias")
+            arrays[n + "w2_pk"] = pack_blocks(_np(sd, p + ".layers.1.weight"))
+            arrays[n + "b2"] = _np(sd, p + ".layers.1.bias")
+            arrays[n + "w3"] = _np(sd, p + ".layers.2.weight")[0]
+            scalars[n + "b3"] = float(_np(sd, p + ".layers.2.bias")[0])
+
+        # one flat device buffer, every section 256-byte aligned
+        offs, total = {}, 0
+        for k, v in arrays.items():
+            v = np.ascontiguousarray(np.asarray(v, dtype=np.float64).astype(np.float32).reshape(-1))
+            arrays[k] = v
+            offs[k] = total
+            total += (v.size + 63) // 64 * 64
+        flat = np.zeros(total, dtype=np.float32)
+        for k, v in arrays.items():
+            flat[offs[k]:offs[k] + v.size] = v
+        self.offsets = offs
+        self.sizes = {k: v.size for k, v in arrays.items()}
+        self.flat = torch.from_numpy(flat).to(device)
+        base = self.flat.data_ptr()
+
+        def P(name):
+            return ctypes.c_void_p(base + 4 * offs[name])
+
+        prm = _lib.Params()
+        for f in ("ee_fe_w", "ee_fe_b", "ee_t1", "ee_w1_pk", "ee_t3", "ee_w23_pk", "ee_w4_pk", "ee_b4",
+                  "schnet_emb", "gin_emb"):
+            setattr(prm, f, P(f))
+        for k in range(cfg.num_convs):
+            cp, n = prm.conv[k], "conv%d." % k
+            for f, _ in _lib.ConvParams._fields_:
+                if (n + f) in offs:
+                    setattr(cp, f, P(n + f))
+                else:
+                    setattr(cp, f, scalars[n + f])
+        for k in range(cfg.num_convs_local):
+            gp, n = prm.gin[k], "gin%d." % k
+            for f in ("w1_pk", "b1", "w2_pk", "b2"):
+                setattr(gp, f, P(n + f))
+            gp.one_plus_eps = scalars[n + "one_plus_eps"]
+            gp.relu_out = 1 if k < cfg.num_convs_local - 1 else 0
+        for name in ("head_global", "head_local"):
+            hp, n = getattr(prm, name), name + "."
+            for f in ("w1_pk", "b1", "w2_pk", "b2", "w3"):
+                setattr(hp, f, P(n + f))
+            hp.b3 = scalars[n + "b3"]
+            hp.act = 0
+        prm.num_convs = cfg.num_convs
+        prm.num_convs_local = cfg.num_convs_local
+        prm.cutoff = float(cfg.cutoff)
+        prm.smooth = 1 if cfg.smooth_conv else 0
+        self.struct = prm
+
+    def view(self, name):
+        o = self.offsets[name]
+        return self.flat[o:o + self.sizes[name]]
+
+    def update_schnet_embedding(self, weight):
+        """Re-upload encoder_global.embedding after the max_norm renorm touched it (schnet.py:254)."""
+        self.view("schnet_emb").copy_(weight.detach().reshape(-1).to(self.flat.dtype))

@@ -1,0 +1,146 @@
+"""Host-side static topology of one packed batch and the device workspace for it.
+
+The positions change every denoising step, the bond / 2-hop / 3-hop ("local", type > 0) edges never
+do (dualenc.py:566-567; utils/transforms.py:12-71).  Everything position-independent is built once
+per batch here with numpy and uploaded: graph offsets, the coalesced local edge list in the
+reference's (src, dst) order (models/common.py:215-231), its CSR views, and exact capacity bounds
+for the per-step radius graph.
+"""
+import numpy as np
+
+from . import _lib
+from .synth import extend_graph_order_np
+
+
+def _to_np(x):
+    if hasattr(x, "detach"):
+        x = x.detach().cpu().numpy()
+    return np.asarray(x)
+
+
+class BatchTopology:
+    def __init__(self, atom_type, bond_index, bond_type, batch, num_graphs=None, extend_order=False,
+                 order=3, device="cuda"):
+        import torch
+        at = _to_np(atom_type).astype(np.int64)
+        bi = _to_np(bond_index).astype(np.int64).reshape(2, -1)
+        bt = _to_np(bond_type).astype(np.int64).reshape(-1)
+        ba = _to_np(batch).astype(np.int64)
+        N = at.shape[0]
+        if ba.shape[0] != N:
+            raise ValueError("batch and atom_type disagree on the number of nodes")
+        if N == 0:
+            raise ValueError("empty batch")
+        if np.any(np.diff(ba) < 0):
+            raise ValueError("batch must be sorted (graph-contiguous nodes, PyG Batch.from_data_list)")
+        G = int(ba[-1]) + 1 if num_graphs is None else int(num_graphs)
+        counts = np.bincount(ba, minlength=G)
+        gptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        if at.min() < 0 or at.max() >= 100:
+            raise ValueError("atom_type out of the embedding range [0, 100)")
+        if bi.size and (bi.min() < 0 or bi.max() >= N):
+            raise ValueError("bond_index out of range")
+        if bi.size and np.any(ba[bi[0]] != ba[bi[1]]):
+            raise ValueError("bond between different graphs")
+
+        if extend_order:
+            # _extend_graph_order (common.py:135-205), per graph instead of one dense N x N matrix
+            rs, cs, ts = [], [], []
+            order_src = np.argsort(ba[bi[0]], kind="stable") if bi.size else np.zeros(0, dtype=np.int64)
+            gb = np.searchsorted(ba[bi[0]][order_src], np.arange(G + 1)) if bi.size else np.zeros(G + 1, dtype=np.int64)
+            for g in range(G):
+                sel = order_src[gb[g]:gb[g + 1]]
+                n = int(counts[g])
+                if n == 0:
+                    continue
+                r, c, t = extend_graph_order_np(n, bi[0][sel] - gptr[g], bi[1][sel] - gptr[g], bt[sel], order=order)
+                rs.append(r + gptr[g]); cs.append(c + gptr[g]); ts.append(t)
+            bi = np.stack([np.concatenate(rs), np.concatenate(cs)]) if rs else np.zeros((2, 0), dtype=np.int64)
+            bt = np.concatenate(ts) if ts else np.zeros(0, dtype=np.int64)
+
+        # coalesce: sort by (row, col), sum duplicate values (common.py:215,226)
+        key = bi[0] * N + bi[1]
+        uniq, inv = np.unique(key, return_inverse=True)
+        typ = np.zeros(uniq.shape[0], dtype=np.int64)
+        np.add.at(typ, inv, bt)
+        src, dst = uniq // N, uniq % N
+        if np.any(typ <= 0) or np.any(typ >= 100):
+            raise NotImplementedError("bond/edge types must lie in 1..99 after coalescing (type 0 marks radius edges)")
+        if np.any(src == dst):
+            raise NotImplementedError("self-loop bond edges are not supported")
+        L = int(uniq.shape[0])
+        out_ptr = np.concatenate([[0], np.cumsum(np.bincount(src, minlength=N))])
+        in_order = np.argsort(dst, kind="stable")               # grouped by dst, src ascending
+        in_ptr = np.concatenate([[0], np.cumsum(np.bincount(dst, minlength=N))])
+        locdeg = np.diff(in_ptr)
+
+        n_of_node = counts[ba]
+        cap = np.minimum(n_of_node - 1, np.minimum(_lib.RADIUS_CAP, n_of_node - 1) + locdeg)
+        cap = np.maximum(cap, 0)
+        self.N, self.G, self.L = N, G, L
+        self.max_edges = int(cap.sum())
+        self.max_in_degree = int(cap.max()) if N else 0
+        self.max_atoms = int(counts.max())
+        if self.max_atoms > _lib.MAX_ATOMS_PER_GRAPH:
+            raise NotImplementedError("graphs with more than %d atoms are not supported" % _lib.MAX_ATOMS_PER_GRAPH)
+        if self.max_in_degree > _lib.TILE * _lib.CHUNK_TILES:
+            raise NotImplementedError("in-degree bound %d exceeds the kernel's chunk size" % self.max_in_degree)
+        if N * 192 * 4 >= 2 ** 32 or self.max_edges >= 2 ** 31 - 64:
+            raise NotImplementedError("batch too large for 32-bit offsets; split it")
+
+        i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a).astype(np.int32)).to(device)
+        self.device = device
+        self.graph_ptr = i32(gptr)
+        self.atom_type = i32(at)
+        self.loc_src, self.loc_dst, self.loc_type = i32(src), i32(dst), i32(typ)
+        self.loc_out_ptr, self.loc_in_ptr, self.loc_in_eid = i32(out_ptr), i32(in_ptr), i32(in_order)
+        # int64 copies of the local edges for the API results (forward() returns int64 indices)
+        self.loc_index64 = torch.from_numpy(np.stack([src, dst])).to(device)
+        self.loc_type64 = torch.from_numpy(typ).to(device)
+        self.batch64 = torch.from_numpy(ba).to(device)
+        self.graph_sizes = counts
+
+        t = _lib.Topo()
+        t.num_nodes, t.num_graphs, t.num_local = N, G, L
+        t.max_edges, t.max_atoms_per_graph, t.max_in_degree = self.max_edges, self.max_atoms, self.max_in_degree
+        for f in ("graph_ptr", "atom_type", "loc_src", "loc_dst", "loc_type", "loc_out_ptr", "loc_in_ptr", "loc_in_eid"):
+            setattr(t, f, _lib.ptr(getattr(self, f)))
+        self.struct = t
+
+
+class Workspace:
+    """Device buffers for one BatchTopology (include/agdiff_hip.h: agdiff_ws_t)."""
+
+    def __init__(self, topo):
+        import torch
+        dev = topo.device
+        N, G, L, E = topo.N, topo.G, topo.L, topo.max_edges
+        etiles = (E + 31) // 32
+        ltiles = (L + 31) // 32
+        chunks = (etiles + _lib.CHUNK_TILES - 1) // _lib.CHUNK_TILES
+        i32 = lambda n: torch.zeros(max(int(n), 1), dtype=torch.int32, device=dev)
+        f32 = lambda n: torch.zeros(max(int(n), 1), dtype=torch.float32, device=dev)
+        self.num_edges = i32(1)
+        self.num_local = torch.tensor([L], dtype=torch.int32, device=dev)
+        self.graph_edge_cnt, self.graph_edge_ptr = i32(G), i32(G + 1)
+        self.in_ptr, self.out_ptr = i32(N + 1), i32(N + 1)
+        self.e_src, self.e_dst, self.e_type, self.ref2dst = i32(etiles * 32), i32(etiles * 32), i32(etiles * 32), i32(etiles * 32)
+        self.e_len = f32(etiles * 32)
+        self.e_attr = f32(etiles * 32 * 128)
+        self.e_inv_global = f32(etiles * 32)
+        self.l_len, self.l_inv = f32(ltiles * 32), f32(ltiles * 32)
+        self.l_attr = f32(ltiles * 32 * 128)
+        self.h, self.xs, self.agg = f32(N * 128), f32(N * 192), f32(N * 192)
+        self.agg_first = f32(chunks * 192)
+        self.hl, self.hl2 = f32(N * 128), f32(N * 128)
+        self.nan_flag = i32(1)
+        self.scratch = f32(N * 3)
+        w = _lib.Workspace()
+        for f, _ in _lib.Workspace._fields_:
+            setattr(w, f, _lib.ptr(getattr(self, f)))
+        self.struct = w
+        self.topo = topo
+
+    def bytes(self):
+        import torch
+        return sum(v.numel() * v.element_size() for v in vars(self).values() if isinstance(v, torch.Tensor))

@@ -1,0 +1,245 @@
+/*
+ * agdiff_hip.h -- C ABI of libagdiff_hip.so: the MI355X (gfx950) kernels behind the AGDIFF
+ * diffusion-sampling hot path.
+ *
+ * The reference (ADicksonLab/AGDIFF) is pure Python; the native work on this path is done by
+ * third-party packages it calls (torch_cluster / torch_scatter / torch_sparse / PyG) and by
+ * ATen.  Each entry point below names the reference call site(s) it replaces
+ * (paths relative to the reference tree).  All pointers are DEVICE pointers unless marked
+ * [host]; all tensors are dense, row-major; indices are int32 on this side of the boundary
+ * (the Python host converts from/to the reference's int64).  Every function enqueues work on
+ * `stream` (a hipStream_t passed as void*) and returns 0, or a negative agdiff_status code
+ * after validating its arguments on the host.  Nothing here allocates, frees or synchronises.
+ *
+ * Struct fields are only `void*`-sized pointers, int64_t, int32_t and float so that the
+ * Python binding (agdiff_amd/_lib.py) can mirror them mechanically by parsing this header.
+ */
+#ifndef AGDIFF_HIP_H
+#define AGDIFF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AGDIFF_ABI_VERSION 3
+#define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
+#define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
+#define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
+#define AGDIFF_NUM_EDGE_TYPES 100  /* rows of bond_emb (edge.py:49) */
+#define AGDIFF_MAX_ATOMS_PER_GRAPH 512
+#define AGDIFF_RADIUS_CAP 33       /* max_num_neighbors + 1 (torch_cluster.radius_graph, common.py:217) */
+#define AGDIFF_TILE 32             /* edges / nodes per MFMA tile */
+#define AGDIFF_CHUNK_TILES 4       /* tiles per wave in the fused CFConv kernel */
+
+enum agdiff_status {
+  AGDIFF_OK = 0,
+  AGDIFF_ERR_ARG = -1,       /* null pointer / negative size / inconsistent sizes */
+  AGDIFF_ERR_LIMIT = -2,     /* a compile-time limit above is exceeded */
+  AGDIFF_ERR_LAUNCH = -3     /* hipGetLastError() after a launch */
+};
+
+/* ---- packed network weights (built by agdiff_amd/packing.py from the reference state_dict) ---
+ * "pk" = MFMA-fragment-major packing [MT][KT][4][64][4] of a Linear weight W[out][in]
+ * (MT = ceil(out/32), KT = ceil(in/32)), one 16-byte load per lane per four MFMAs:
+ *   pk[((((mt*KT+t)*4+rq)*64+lane)*4)+q] = W[32*mt+(lane&31)][32*t+8*rq+4*(lane>>5)+q]
+ * (zero where out/in exceed the layer).  "pkk" = the same 1024-float blocks in k-tile-outer order
+ * [KT][MT][4][64][4], for layers whose input is streamed in 32-feature slices.  Vectors are in
+ * natural feature order. */
+typedef struct agdiff_conv_params {
+  /* CFConv filter networks of one InteractionBlock (schnet.py:169-186), conv1 (F=128) and conv2 (F=64) fused */
+  const float* filt_w1_pk;   /* pkk [4][6]: rows 0..127 conv1.nn.0, 128..191 conv2.nn.0 */
+  const float* filt_b1;      /* [192] */
+  const float* filt_w2a_pk;  /* [4][4]: conv1.nn.2 */
+  const float* filt_w2b_pk;  /* [2][2]: conv2.nn.2 */
+  const float* filt_b2;      /* [192] */
+  const float* dist_w;       /* [2][97]: DistanceWeightingNetwork (schnet.py:83-100): w1[32] b1[32] w2[32] b2 */
+  float ssp_beta1;           /* conv1.nn.1.beta */
+  float ssp_beta2;           /* conv2.nn.1.beta */
+  /* node side of the block (schnet.py:153-158, 201-216, 219-234) */
+  const float* lin1_pk;      /* [6][4]: BN-folded conv1.lin1 (rows 0..127) and conv2.lin1 (128..191) */
+  const float* lin1_b;       /* [192] */
+  const float* lin2a_pk;     /* pkk [4][4]: BN-folded conv1.lin2 */
+  const float* lin2b_pk;     /* pkk [2][4]: BN-folded conv2.lin2 */
+  const float* lin2_b;       /* [256] */
+  const float* lin_pk;       /* [4][8]: InteractionBlock.lin (256->128) */
+  const float* lin_b;        /* [128] */
+  const float* gate1_pk;     /* [2][4]: attention.0 (128->64) */
+  const float* gate1_b;      /* [64] */
+  const float* gate2_w;      /* [64]  attention.2 */
+  const float* scale1_pk;    /* [1][4]: scaling fc.0 (128->8, rows 8..31 zero) */
+  const float* scale2_pk;    /* [4][1]: scaling fc.2 (8->128, cols 8..31 zero) */
+  float gate2_b;
+  float act_beta;            /* InteractionBlock.act.beta */
+} agdiff_conv_params_t;
+
+typedef struct agdiff_gin_params {
+  const float* w1_pk;        /* [4][4] convs.k.nn.layers.0 */
+  const float* b1;           /* [128] */
+  const float* w2_pk;        /* [4][4] BN-folded convs.k.nn.layers.1 */
+  const float* b2;           /* [128] */
+  float one_plus_eps;
+  int32_t relu_out;          /* 1 for all but the last layer (gin.py:134) */
+} agdiff_gin_params_t;
+
+typedef struct agdiff_head_params {
+  const float* w1_pk;        /* pkk [8][4] layers.0 (256->128) */
+  const float* b1;           /* [128] */
+  const float* w2_pk;        /* [2][4] layers.1 (128->64) */
+  const float* b2;           /* [64] */
+  const float* w3;           /* [64]  layers.2 */
+  float b3;
+  int32_t act;               /* 0 relu (configs: mlp_act relu) */
+} agdiff_head_params_t;
+
+typedef struct agdiff_params {
+  /* MLPEdgeEncoder (edge.py:84-103), attention dropped (softmax over a size-1 axis == 1) and
+   * edge_feature_mlp.2 folded into combination_mlp.0 */
+  const float* ee_fe_w;      /* [128] feature_expansion.weight[:,0] */
+  const float* ee_fe_b;      /* [128] */
+  const float* ee_t1;        /* [100][128]: edge_feature_mlp.0.weight[:,128:] @ bond_emb[t] + bias */
+  const float* ee_w1_pk;     /* [4][4]: edge_feature_mlp.0.weight[:,:128] */
+  const float* ee_t3;        /* [100][128]: comb.0.weight[:,128:] @ bond_emb[t] + comb.0.bias + comb.0.weight[:,:128] @ efm.2.bias */
+  const float* ee_w23_pk;    /* [4][4]: comb.0.weight[:,:128] @ edge_feature_mlp.2.weight */
+  const float* ee_w4_pk;     /* [4][4]: combination_mlp.2 */
+  const float* ee_b4;        /* [128] */
+  const float* schnet_emb;   /* [100][128] encoder_global.embedding (max_norm renorm applied to used rows) */
+  const float* gin_emb;      /* [100][128] encoder_local.node_emb */
+  agdiff_conv_params_t conv[AGDIFF_MAX_CONVS];
+  agdiff_gin_params_t gin[AGDIFF_MAX_CONVS_LOCAL];
+  agdiff_head_params_t head_global;
+  agdiff_head_params_t head_local;
+  int32_t num_convs;
+  int32_t num_convs_local;
+  float cutoff;
+  int32_t smooth;            /* config.smooth_conv */
+} agdiff_params_t;
+
+/* ---- static topology of one packed batch (host builds it once per batch) ---------------------
+ * Graphs are contiguous node ranges (PyG Batch, utils/misc.py:88-90).  "Local" edges are the
+ * bond / 2-hop / 3-hop edges (type > 0, dualenc.py:566); they never depend on positions. */
+typedef struct agdiff_topo {
+  int64_t num_nodes;         /* N */
+  int64_t num_graphs;        /* G */
+  int64_t num_local;         /* L: local edges, in reference order (sorted by (src, dst)) */
+  int64_t max_edges;         /* capacity of the per-edge buffers: sum_i (33 + local in-degree_i) */
+  int64_t max_atoms_per_graph; /* <= AGDIFF_MAX_ATOMS_PER_GRAPH */
+  int64_t max_in_degree;     /* max_i (33 + local in-degree_i) <= AGDIFF_TILE * AGDIFF_CHUNK_TILES */
+  const int32_t* graph_ptr;  /* [G+1] node offsets */
+  const int32_t* atom_type;  /* [N] */
+  const int32_t* loc_src;    /* [L] */
+  const int32_t* loc_dst;    /* [L] */
+  const int32_t* loc_type;   /* [L] (1..99) */
+  const int32_t* loc_out_ptr;/* [N+1]: local edges with src == i are [loc_out_ptr[i], loc_out_ptr[i+1]) */
+  const int32_t* loc_in_ptr; /* [N+1] */
+  const int32_t* loc_in_eid; /* [L]: local edge ids grouped by dst (src ascending) */
+} agdiff_topo_t;
+
+/* ---- workspace (device buffers the host allocates once per batch) ------------------------- */
+typedef struct agdiff_ws {
+  /* dynamic graph, destination-sorted: edges of target i are [in_ptr[i], in_ptr[i+1]) with src ascending */
+  int32_t* num_edges;        /* [1]  E (device scalar, rewritten by every graph build) */
+  int32_t* num_local;        /* [1]  L as a device scalar (written once by the host) */
+  int32_t* graph_edge_cnt;   /* [G]  */
+  int32_t* graph_edge_ptr;   /* [G+1] */
+  int32_t* in_ptr;           /* [N+1] */
+  int32_t* out_ptr;          /* [N+1]: reference order (sorted by (src,dst)): edges with src == i */
+  int32_t* e_src;            /* [max_edges] */
+  int32_t* e_dst;            /* [max_edges] */
+  int32_t* e_type;           /* [max_edges] */
+  float*   e_len;            /* [max_edges] */
+  int32_t* ref2dst;          /* [max_edges]: reference position q -> destination-sorted id */
+  float*   e_attr;           /* [ceil(max_edges/32)][4][4][64][4] edge_attr, fragment-major */
+  float*   e_inv_global;     /* [max_edges] grad_global_dist_mlp output, destination-sorted */
+  /* local edges (reference order) */
+  float*   l_len;            /* [L] */
+  float*   l_attr;           /* [ceil(L/32)] tiles, fragment-major */
+  float*   l_inv;            /* [L] grad_local_dist_mlp output */
+  /* nodes */
+  float*   h;                /* [N][128] SchNet node state */
+  float*   xs;               /* [N][192] lin1/BN/LeakyReLU outputs feeding conv1 (0..127) and conv2 (128..191) */
+  float*   agg;              /* [N][192] CFConv aggregates */
+  float*   agg_first;        /* [ceil(tiles/CHUNK_TILES)][192] partial sums of a chunk's first target */
+  float*   hl;               /* [N][128] GIN node state (ping) */
+  float*   hl2;              /* [N][128] (pong) */
+  int32_t* nan_flag;         /* [1] set to 1 when a position becomes NaN */
+} agdiff_ws_t;
+
+typedef struct agdiff_step_args {
+  const float* pos_in;       /* [N][3] */
+  float*       pos_out;      /* [N][3] (may alias pos_in) */
+  float*       scratch;      /* [N][3] uncentred positions between the two passes of the update */
+  const float* noise;        /* [N][3] standard normal draws for this step (torch.randn_like, dualenc.py:529) */
+  float*       traj_out;     /* [N][3] or null: copy of the centred positions (pos_traj, dualenc.py:545) */
+  float sigma;               /* sigmas[i] */
+  float step_size;           /* step_lr * (sigmas[i] / 0.01) ** 2, evaluated by the host in fp32 (dualenc.py:532) */
+  float noise_scale;         /* sqrt(step_size * 2) (dualenc.py:536) */
+  float w_global;
+  float clip;                /* clip_norm limit of the global term (dualenc.py:522) */
+  float clip_local;          /* < 0: no local clipping (clip_local=None) */
+  float clip_pos;            /* < 0: no clamp */
+  int32_t use_global;        /* sigmas[i] < global_start_sigma (dualenc.py:515) */
+} agdiff_step_args_t;
+
+/* Build stamp / ABI check. */
+int agdiff_abi_version(void);
+/* sizeof() of every struct above, for the binding's self-check: out[0..6] =
+ * conv, gin, head, params, topo, ws, step_args. */
+int agdiff_struct_sizes(int64_t* out /* [host] */);
+
+/* torch_cluster.radius_graph + sparse add/coalesce (models/common.py:208-233) + get_distance
+ * (geometry.py:5-6): rebuilds the destination-sorted edge list, its reference-order permutation,
+ * edge types and lengths from `pos`. */
+int agdiff_graph_build(const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, float cutoff, void* stream);
+
+/* get_distance on the static local edges (geometry.py:5-6 applied to edge_index[:, local_edge_mask]). */
+int agdiff_local_lengths(const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, void* stream);
+
+/* MLPEdgeEncoder.forward (encoder/edge.py:84-103).  n_edges_dev: device scalar with the live edge
+ * count (<= max_tiles*32); writes fragment-major edge_attr tiles. */
+int agdiff_edge_encoder(const agdiff_params_t* p, const int32_t* n_edges_dev, int64_t max_tiles,
+                        const float* e_len, const int32_t* e_type, float* attr_frag, void* stream);
+
+/* Node-side stage k of SchNetEncoder.forward (encoder/schnet.py:268-282): k == 0 embeds atoms;
+ * k >= 1 finishes InteractionBlock k-1 (lin2/BN, act, lin, gate, AdaptiveScaling, residual);
+ * k < num_convs also applies block k's conv{1,2}.lin1/BN/LeakyReLU into ws->xs. */
+int agdiff_schnet_node_stage(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k, void* stream);
+
+/* CFConv filter generation + message + aggr='add' for both convs of block k
+ * (encoder/schnet.py:138-162; PyG MessagePassing.propagate): ws->agg / ws->agg_first. */
+int agdiff_cfconv_fused(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k, void* stream);
+
+/* assemble_atom_pair_feature + grad_*_dist_mlp (models/common.py:106-109, 86-103; dualenc.py:203-211,
+ * 226-239) over n edges given by (src, dst) and fragment-major attrs. */
+int agdiff_pair_head(const agdiff_head_params_t* hp, const int32_t* n_edges_dev, int64_t max_tiles,
+                     const int32_t* src, const int32_t* dst, const float* node_h, const float* attr_frag,
+                     float* out, void* stream);
+
+/* GINEncoder.forward (encoder/gin.py:112-148) on the static local edges; result in ws->hl. */
+int agdiff_gin_encoder(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, void* stream);
+
+/* PyG MessagePassing.propagate(aggr='add') with message x_j * W (encoder/schnet.py:156,161-162) as a
+ * stand-alone op on a destination-sorted CSR: out[i][:] = sum_{e in [in_ptr[i], in_ptr[i+1])} x[src[e]][:] * W[e][:].
+ * F must be 64 or 128. */
+int agdiff_cfconv_aggregate(const float* x, const float* W, const int32_t* in_ptr, const int32_t* src,
+                            int64_t num_nodes, int32_t F, float* out, void* stream);
+
+/* The whole score network, dualenc.py:142-251 with the graph rebuilt from `pos`
+ * (extend_order=False, extend_radius=True).  with_global = 0 skips everything whose result the
+ * sampler discards when sigma >= global_start_sigma (dualenc.py:523-524). */
+int agdiff_score_forward(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
+                         const float* pos, int32_t with_global, void* stream);
+
+/* eq_transform x2, clip_norm, Langevin update, NaN check, center_pos, clamp
+ * (geometry.py:9-17; dualenc.py:506-545, 581-589) from ws->l_inv / ws->e_inv_global. */
+int agdiff_langevin_update(const agdiff_topo_t* topo, const agdiff_ws_t* ws, const agdiff_step_args_t* a, void* stream);
+
+/* One denoising step = agdiff_score_forward + agdiff_langevin_update (dualenc.py:478-545). */
+int agdiff_langevin_step(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
+                         const agdiff_step_args_t* a, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGDIFF_HIP_H */

@@ -1,0 +1,175 @@
+"""CPU: host-side logic of the product (module tree / state_dict layout, weight packing and
+folding, topology building, C-ABI loading).  No GPU compute calls."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, load_golden, rel_err, t
+from agdiff_amd import _lib, get_model, qm9_model_config, drugs_model_config, synth
+from agdiff_amd.config import Config
+from agdiff_amd.packing import PackedParams, pack_blocks, fold_bn
+from agdiff_amd.topology import BatchTopology
+from oracle import agdiff_oracle as O
+
+
+def test_state_dict_layout_matches_reference_g7():
+    m = get_model(qm9_model_config())
+    sd = m.state_dict()
+    ref = [l.split() for l in open(os.path.join(GOLDEN, "g7_state_dict_keys.txt"))]
+    assert len(sd) == len(ref) == 854
+    for (k, v), (rk, rshape, rdt) in zip(sd.items(), ref):
+        assert k == rk
+        assert ("x".join(map(str, v.shape)) or "-") == rshape, k
+        assert str(v.dtype).replace("torch.", "") == rdt, k
+    # aliases share storage (dualenc.py:103-108)
+    assert sd["model_global.1.embedding.weight"].data_ptr() == sd["encoder_global.embedding.weight"].data_ptr()
+    # strict load of a reference-layout state_dict
+    m.load_state_dict(O.synth_state_dict_for(qm9_model_config()), strict=True)
+
+
+def test_factory_errors():
+    with pytest.raises(NotImplementedError):
+        get_model(qm9_model_config(network="nope"))
+    with pytest.raises(NotImplementedError):
+        get_model(qm9_model_config(edge_encoder="nope"))
+    with pytest.raises(NotImplementedError):
+        get_model(qm9_model_config(beta_schedule="nope"))
+
+
+def test_schedule_matches_golden():
+    m = get_model(qm9_model_config())
+    g = load_golden("g1_schedule")
+    sig = (1.0 - m.alphas).sqrt() / m.alphas.sqrt()
+    assert np.array_equal(m.betas.detach().numpy()[g["idx"]], g["betas"])
+    assert rel_err(sig.detach().numpy()[g["idx"]], g["sigmas"]) < 1e-6
+
+
+def test_no_cpu_fallback():
+    m = get_model(qm9_model_config())
+    b = synth.make_packed_batch("qm9", 1, 1, seed=1)
+    with pytest.raises(_lib.AgdiffHipError):
+        m(t(b["atom_type"]), torch.randn(b["atom_type"].shape[0], 3), t(b["bond_index"]), t(b["bond_type"]),
+          t(b["batch"]), None, extend_order=False)
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.load()
+    assert lib.agdiff_abi_version() == _lib.DEFINES["AGDIFF_ABI_VERSION"]
+    assert len(_lib.EXPORTS) >= 13
+    for name in _lib.EXPORTS:
+        assert hasattr(lib, name), name
+    # argument validation happens on the host before any launch
+    assert lib.agdiff_graph_build(None, None, None, ctypes.c_float(10.0), None) == -1
+    assert lib.agdiff_cfconv_aggregate(None, None, None, None, ctypes.c_int64(0), 128, None, None) == -1
+
+
+def _unpack_blocks(flat, out, inn, kouter=False):
+    MT, KT = (out + 31) // 32, (inn + 31) // 32
+    b = flat.reshape((KT, MT, 4, 64, 4) if kouter else (MT, KT, 4, 64, 4))
+    W = np.zeros((MT * 32, KT * 32), dtype=np.float32)
+    for mt in range(MT):
+        for k in range(KT):
+            blk = b[k, mt] if kouter else b[mt, k]
+            for rq in range(4):
+                for lane in range(64):
+                    for q in range(4):
+                        W[32 * mt + (lane & 31), 32 * k + 8 * rq + 4 * (lane >> 5) + q] = blk[rq, lane, q]
+    return W[:out, :inn]
+
+
+@pytest.mark.parametrize("shape,kouter", [((128, 128), False), ((192, 128), True), ((8, 128), False),
+                                          ((128, 8), False), ((64, 64), False), ((128, 256), True)])
+def test_pack_blocks_roundtrip(shape, kouter):
+    rng = np.random.default_rng(0)
+    W = rng.standard_normal(shape).astype(np.float32)
+    flat = pack_blocks(W, kouter=kouter)
+    assert flat.dtype == np.float32 and flat.size == ((shape[0] + 31) // 32) * ((shape[1] + 31) // 32) * 1024
+    assert np.array_equal(_unpack_blocks(flat, *shape, kouter=kouter), W)
+
+
+def test_folded_edge_encoder_equals_oracle():
+    """The table/fold form of MLPEdgeEncoder the kernels evaluate == edge.py:84-103 as executed."""
+    cfg = qm9_model_config()
+    sd = O.synth_state_dict_for(cfg)
+    pk = PackedParams(sd, cfg, "cpu")
+    g = load_golden("g3_forward_qm9_small")
+    d = g["edge_length"].astype(np.float64)[:, 0]
+    ty = g["edge_type"]
+    V = lambda n: pk.view(n).numpy().astype(np.float64)
+    W = lambda n, o, i: _unpack_blocks(pk.view(n).numpy(), o, i).astype(np.float64)
+    from scipy.special import erf
+    gelu = lambda x: 0.5 * x * (1 + erf(x / np.sqrt(2)))
+    x0 = gelu(d[:, None] * V("ee_fe_w")[None] + V("ee_fe_b")[None])
+    h1 = gelu(x0 @ W("ee_w1_pk", 128, 128).T + V("ee_t1").reshape(100, 128)[ty])
+    h2 = gelu(h1 @ W("ee_w23_pk", 128, 128).T + V("ee_t3").reshape(100, 128)[ty])
+    a = h2 @ W("ee_w4_pk", 128, 128).T + V("ee_b4")[None]
+    assert rel_err(a, g["edge_attr"]) < 5e-6
+
+
+def test_bn_fold_equals_eval_batchnorm():
+    cfg = qm9_model_config()
+    sd = O.synth_state_dict_for(cfg)
+    p = "encoder_global.interactions.2.conv1"
+    x = torch.randn(17, 128)
+    ref = O._bn_eval(sd, p + ".norm1", O._lin(sd, p + ".lin1", x))
+    W, b = fold_bn(sd[p + ".lin1.weight"].double().numpy(), sd[p + ".lin1.bias"].double().numpy(), sd, p + ".norm1")
+    got = x.double().numpy() @ W.T + b
+    assert rel_err(got, ref.numpy()) < 1e-6
+
+
+def test_erf_polynomial_mirror():
+    """numpy mirror of ag_erf (csrc/common.hpp) against scipy: < 1 ulp-ish absolute error."""
+    from scipy.special import erf
+    f = np.float32
+    a = np.linspace(-6, 6, 200001).astype(np.float32)
+    tt = np.abs(a); s = a * a
+    fma = lambda x, y, z: (x.astype(np.float64) * y.astype(np.float64) + z.astype(np.float64)).astype(np.float32)
+    c = lambda v: np.full_like(a, v)
+    r = fma(c(-1.72853470e-5), tt, c(3.83197126e-4)); u = fma(c(-3.88396438e-3), tt, c(2.42546219e-2))
+    r = fma(r, s, u)
+    for k in (-1.06777877e-1, -6.34846687e-1, -1.28717512e-1):
+        r = fma(r, tt, c(k))
+    r = fma(r, tt, -tt)
+    big = np.copysign(f(1.0) - np.exp(r.astype(np.float64)).astype(np.float32), a)
+    q = c(-5.96761703e-4)
+    for k in (4.99119423e-3, -2.67681349e-2, 1.12819925e-1, -3.76125336e-1, 1.28379166e-1):
+        q = fma(q, s, c(k))
+    small = fma(q, a, a)
+    got = np.where(tt > f(0.927734375), big, small)
+    assert np.abs(got.astype(np.float64) - erf(a.astype(np.float64))).max() < 1.2e-7
+
+
+def test_topology_matches_reference_local_edges():
+    g = load_golden("g3_forward_drugs_capped")
+    topo = BatchTopology(g["atom_type"], g["bond_index"], g["bond_type"], g["batch"], device="cpu")
+    lm = g["local_edge_mask"]
+    assert np.array_equal(topo.loc_index64.numpy(), g["edge_index"][:, lm])
+    assert np.array_equal(topo.loc_type64.numpy(), g["edge_type"][lm])
+    assert topo.max_edges >= g["edge_index"].shape[1]
+    indeg = np.bincount(g["edge_index"][1], minlength=topo.N)
+    assert topo.max_in_degree >= indeg.max()
+    # CSR views
+    src, dst = topo.loc_src.numpy(), topo.loc_dst.numpy()
+    ip, ie = topo.loc_in_ptr.numpy(), topo.loc_in_eid.numpy()
+    for i in (0, 5, topo.N - 1):
+        ids = ie[ip[i]:ip[i + 1]]
+        assert np.all(dst[ids] == i) and np.all(np.diff(src[ids]) > 0)
+    op = topo.loc_out_ptr.numpy()
+    assert np.all(src[op[7]:op[8]] == 7)
+
+
+def test_topology_extend_order_and_errors():
+    g = load_golden("g9_extend_order")
+    n = int(g["n1"])
+    topo = BatchTopology(np.ones(n, dtype=np.int64), g["bond_index1"], g["bond_type1"], np.zeros(n, dtype=np.int64),
+                         extend_order=True, device="cpu")
+    assert np.array_equal(topo.loc_index64.numpy(), g["ext_index1"])
+    assert np.array_equal(topo.loc_type64.numpy(), g["ext_type1"])
+    with pytest.raises(ValueError):
+        BatchTopology(np.ones(4, dtype=np.int64), np.zeros((2, 0), dtype=np.int64), np.zeros(0, dtype=np.int64),
+                      np.array([0, 1, 0, 1]), device="cpu")
+    with pytest.raises(ValueError):
+        BatchTopology(np.ones(4, dtype=np.int64), np.array([[0], [3]]), np.array([1]), np.array([0, 0, 1, 1]), device="cpu")
