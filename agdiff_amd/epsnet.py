@@ -226,11 +226,9 @@ class DualEncoderEpsNetwork(nn.Module):
         return pk
 
     def _batch(self, atom_type, bond_index, bond_type, batch, num_graphs, extend_order):
-        """Static topology + workspace, cached for repeated calls on the same batch tensors."""
-        key = (atom_type.data_ptr(), bond_index.data_ptr(), bond_type.data_ptr(), batch.data_ptr(),
-               int(atom_type.shape[0]), int(bond_index.shape[1]), bool(extend_order), num_graphs, str(self._device()))
-        if self._batch_cache is not None and self._batch_cache[0] == key:
-            return self._batch_cache[1], self._batch_cache[2]
+        """Static topology + workspace of this call's batch (kept on the module afterwards so that
+        tests and tools can inspect the device buffers; never reused across calls)."""
+        key = None
         topo = BatchTopology(atom_type, bond_index, bond_type, batch, num_graphs=num_graphs,
                              extend_order=extend_order, order=self.config.edge_order, device=self._device())
         ws = Workspace(topo)
@@ -313,9 +311,10 @@ class DualEncoderEpsNetwork(nn.Module):
             chunk = 128
             ws.nan_flag.zero_()
             stream = _lib.stream_ptr()
+            pos_p = _lib.ptr(pos)
             a = _lib.StepArgs()
-            a.pos_in = _lib.ptr(pos)
-            a.pos_out = _lib.ptr(pos)
+            a.pos_in = pos_p
+            a.pos_out = pos_p
             a.scratch = _lib.ptr(ws.scratch)
             a.w_global = float(w_global)
             a.clip = float(clip)
@@ -340,7 +339,7 @@ class DualEncoderEpsNetwork(nn.Module):
                 a.use_global = 1 if use_global else 0
                 run_global = 1 if (use_global or not skip_discarded) else 0
                 _lib.check(lib.agdiff_score_forward(ctypes.byref(pk.struct), ctypes.byref(topo.struct),
-                                                    ctypes.byref(ws.struct), a.pos_in, run_global, stream),
+                                                    ctypes.byref(ws.struct), pos_p, run_global, stream),
                            "agdiff_score_forward")
                 _lib.check(lib.agdiff_langevin_update(ctypes.byref(topo.struct), ctypes.byref(ws.struct),
                                                       ctypes.byref(a), stream), "agdiff_langevin_update")
