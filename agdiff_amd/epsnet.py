@@ -284,73 +284,116 @@ class DualEncoderEpsNetwork(nn.Module):
                            reference discards (sigma >= global_start_sigma, dualenc.py:523-524)
           nan_check_every  host polls the device NaN flag every this many steps (default 64)
           step_indices     explicit list of schedule indices to visit instead of the last n_steps
-                           (bench.py's subsampled runs)
           on_step          callback(k, i, pos) after each step is enqueued (data-parallel gather)
         """
-        lib = self._require_gpu()
+        run = self.begin_sampling(atom_type, pos_init, bond_index, bond_type, batch, num_graphs, extend_order,
+                                  extend_radius, n_steps, step_lr, clip, clip_local, clip_pos, global_start_sigma,
+                                  w_global, **kwargs)
+        run.advance(run.remaining())
+        return run.finish()
+
+    def begin_sampling(self, atom_type, pos_init, bond_index, bond_type, batch, num_graphs, extend_order,
+                       extend_radius=True, n_steps=5000, step_lr=0.0000010, clip=1000, clip_local=None,
+                       clip_pos=None, global_start_sigma=float("inf"), w_global=0.2, **kwargs):
+        """Set up one sampling job (dualenc.py:468-476) and return a LangevinRun that enqueues steps."""
+        self._require_gpu()
         if not extend_radius:
             raise NotImplementedError("extend_radius=False is not supported by the HIP path")
-        noise = kwargs.get("noise")
-        save_traj = kwargs.get("save_traj", True)
-        skip_discarded = kwargs.get("skip_discarded_global", True)
-        nan_every = int(kwargs.get("nan_check_every", 64))
-        on_step = kwargs.get("on_step")
-        dev = self._device()
-        sigmas = ((1.0 - self.alphas).sqrt() / self.alphas.sqrt()).detach().cpu()
-        self.eval()
+        return LangevinRun(self, atom_type, pos_init, bond_index, bond_type, batch, num_graphs, extend_order,
+                           n_steps, step_lr, clip, clip_local, clip_pos, global_start_sigma, w_global, **kwargs)
+
+
+class LangevinRun:
+    """The denoising loop of dualenc.py:478-545 as an object: `advance(m)` enqueues the next m steps on
+    the current stream with no host synchronisation except the periodic NaN-flag poll."""
+
+    def __init__(self, model, atom_type, pos_init, bond_index, bond_type, batch, num_graphs, extend_order,
+                 n_steps, step_lr, clip, clip_local, clip_pos, global_start_sigma, w_global, noise=None,
+                 save_traj=True, skip_discarded_global=True, nan_check_every=64, step_indices=None, on_step=None,
+                 **_ignored):
+        self.model, self.lib = model, _lib.load()
+        dev = model._device()
+        self.sigmas = ((1.0 - model.alphas).sqrt() / model.alphas.sqrt()).detach().cpu()
+        model.eval()
         with torch.no_grad():
-            pk = self._renorm_embedding(atom_type)
-            topo, ws = self._batch(atom_type, bond_index, bond_type, batch, num_graphs, extend_order)
-            N = topo.N
-            steps = kwargs.get("step_indices")
-            if steps is None:
-                steps = list(reversed(range(self.num_timesteps - n_steps, self.num_timesteps)))
-            n_run = len(steps)
-            pos = (pos_init.detach().to(dev, torch.float32) * sigmas[-1].to(dev)).contiguous()
-            traj = torch.empty((n_run, N, 3), dtype=torch.float32, device=dev) if save_traj else None
-            chunk = 128
-            ws.nan_flag.zero_()
-            stream = _lib.stream_ptr()
-            pos_p = _lib.ptr(pos)
-            a = _lib.StepArgs()
-            a.pos_in = pos_p
-            a.pos_out = pos_p
-            a.scratch = _lib.ptr(ws.scratch)
-            a.w_global = float(w_global)
-            a.clip = float(clip)
-            a.clip_local = -1.0 if clip_local is None else float(clip_local)
-            a.clip_pos = -1.0 if clip_pos is None else float(clip_pos)
-            nz = None
-            for k, i in enumerate(steps):
-                if noise is not None:
-                    cur = noise[k].to(dev, torch.float32).contiguous()
-                else:
-                    if k % chunk == 0:
-                        nz = torch.randn((min(chunk, n_run - k), N, 3), dtype=torch.float32, device=dev)
-                    cur = nz[k % chunk]
-                sig = sigmas[i]
-                step_size = step_lr * (sig / 0.01) ** 2               # dualenc.py:532, fp32 tensor math
-                use_global = bool(sig < global_start_sigma)            # dualenc.py:515
+            self.pk = model._renorm_embedding(atom_type)
+            self.topo, self.ws = model._batch(atom_type, bond_index, bond_type, batch, num_graphs, extend_order)
+            T = model.num_timesteps
+            self.steps = list(step_indices) if step_indices is not None else list(reversed(range(T - n_steps, T)))
+            self.pos = (pos_init.detach().to(dev, torch.float32) * self.sigmas[-1].to(dev)).contiguous()
+        N = self.topo.N
+        self.traj = torch.empty((len(self.steps), N, 3), dtype=torch.float32, device=dev) if save_traj else None
+        self.noise, self.on_step = noise, on_step
+        self.step_lr, self.global_start_sigma = step_lr, global_start_sigma
+        self.skip_discarded, self.nan_every = bool(skip_discarded_global), int(nan_check_every)
+        self.k = 0
+        self.ws.nan_flag.zero_()
+        self.pos_p = _lib.ptr(self.pos)
+        a = _lib.StepArgs()
+        a.pos_in = self.pos_p
+        a.pos_out = self.pos_p
+        a.scratch = _lib.ptr(self.ws.scratch)
+        a.w_global = float(w_global)
+        a.clip = float(clip)
+        a.clip_local = -1.0 if clip_local is None else float(clip_local)
+        a.clip_pos = -1.0 if clip_pos is None else float(clip_pos)
+        self.args = a
+        self._nz, self._nz_base = None, 0
+        self.global_steps = 0
+
+    def remaining(self):
+        return len(self.steps) - self.k
+
+    def _noise_for(self, k, dev, N):
+        if self.noise is not None:
+            return self.noise[k].to(dev, torch.float32).contiguous()
+        chunk = 128
+        if self._nz is None or k >= self._nz_base + self._nz.shape[0]:
+            self._nz = torch.randn((min(chunk, len(self.steps) - k), N, 3), dtype=torch.float32, device=dev)
+            self._nz_base = k
+        return self._nz[k - self._nz_base]
+
+    def advance(self, m):
+        lib, a, pk, topo, ws = self.lib, self.args, self.pk, self.topo, self.ws
+        dev, N = self.pos.device, topo.N
+        stream = _lib.stream_ptr()
+        end = min(self.k + int(m), len(self.steps))
+        with torch.no_grad():
+            while self.k < end:
+                k, i = self.k, self.steps[self.k]
+                cur = self._noise_for(k, dev, N)
+                sig = self.sigmas[i]
+                step_size = self.step_lr * (sig / 0.01) ** 2          # dualenc.py:532, fp32 tensor math
+                use_global = bool(sig < self.global_start_sigma)       # dualenc.py:515
                 a.noise = _lib.ptr(cur)
-                a.traj_out = ctypes.c_void_p(traj[k].data_ptr()) if save_traj else ctypes.c_void_p(0)
+                a.traj_out = ctypes.c_void_p(self.traj[k].data_ptr()) if self.traj is not None else ctypes.c_void_p(0)
                 a.sigma = float(sig)
                 a.step_size = float(step_size)
                 a.noise_scale = float(torch.sqrt(step_size * 2))
                 a.use_global = 1 if use_global else 0
-                run_global = 1 if (use_global or not skip_discarded) else 0
+                run_global = 1 if (use_global or not self.skip_discarded) else 0
+                self.global_steps += run_global
                 _lib.check(lib.agdiff_score_forward(ctypes.byref(pk.struct), ctypes.byref(topo.struct),
-                                                    ctypes.byref(ws.struct), pos_p, run_global, stream),
+                                                    ctypes.byref(ws.struct), self.pos_p, run_global, stream),
                            "agdiff_score_forward")
                 _lib.check(lib.agdiff_langevin_update(ctypes.byref(topo.struct), ctypes.byref(ws.struct),
                                                       ctypes.byref(a), stream), "agdiff_langevin_update")
-                if on_step is not None:
-                    on_step(k, i, pos)
-                if (k + 1) % nan_every == 0 or k == n_run - 1:
-                    if int(ws.nan_flag.item()) != 0:
-                        print("NaN detected. Please restart.")
-                        raise FloatingPointError()
-            pos_traj = list(traj.cpu().unbind(0)) if save_traj else []
-        return pos, pos_traj
+                self.k += 1
+                if self.on_step is not None:
+                    self.on_step(k, i, self.pos)
+                if self.k % self.nan_every == 0 or self.k == len(self.steps):
+                    self.check_nan()
+
+    def check_nan(self):
+        if int(self.ws.nan_flag.item()) != 0:
+            print("NaN detected. Please restart.")
+            raise FloatingPointError()
+
+    def finish(self):
+        """(pos on device, pos_traj list of CPU tensors) as dualenc.py:547 returns them."""
+        self.check_nan()
+        pos_traj = list(self.traj[:self.k].cpu().unbind(0)) if self.traj is not None else []
+        return self.pos, pos_traj
 
 
 def get_model(config):

@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py -- conformers/sec of the AGDIFF diffusion-sampling hot path on MI355X.
+
+A "step" is one Langevin denoising step (score-network forward + update, dualenc.py:478-545) over
+one packed batch of synthetic GEOM-Drugs-shaped conformers.  `value` = conformers generated per
+second by a 5000-step sampling job = G_total / (ms_per_step * 5000 / 1000), whole job over all ranks,
+inputs resident in HBM when the timed region starts.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload: `--mols` distinct synthetic molecules (atom count ~ clipped
+N(44, 11)) x `--copies` conformers each per GPU (weak scaling), synthetic closed-form checkpoint,
+"saturated" schedule (beta_end = 2e-5: sigma < 0.5 on every step, so the global SchNet branch runs
+on every step and the radius graph stays at the 32-neighbour cap -- the heaviest per-step work the
+path can see; the reference's default schedule is available with --schedule default).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+JOB_STEPS = 5000
+FLOP_PER_EDGE_CFCONV = 2 * (128 * 192 + 128 * 128 + 64 * 64)     # filter MLP of conv1+conv2, one block
+PEAK = {"f32": 157.3}                                              # dense MFMA TFLOP/s, MI355X_MICROARCH.md
+
+
+def build_batch(kind, mols, copies, seed):
+    from agdiff_amd import synth
+    return synth.make_packed_batch(kind, mols, copies, seed=seed)
+
+
+def make_cfg(kind, schedule):
+    from agdiff_amd import drugs_model_config, qm9_model_config
+    base = qm9_model_config if kind == "qm9" else drugs_model_config
+    return base(beta_end=2e-5) if schedule == "saturated" else base()
+
+
+def cpu_baseline(kind, schedule, seed, budget_s=20.0):
+    """The oracle (CPU port of the reference path) on a bounded sample of the same workload."""
+    from oracle import agdiff_oracle as O
+    cfg = make_cfg(kind, schedule)
+    sd = O.synth_state_dict_for(cfg)
+    mols, copies = 2, 8
+    b = build_batch(kind, mols, copies, seed)
+    T = lambda x: torch.from_numpy(np.ascontiguousarray(x))
+    at, bi, bt, ba = T(b["atom_type"]), T(b["bond_index"]), T(b["bond_type"]), T(b["batch"])
+    g = torch.Generator().manual_seed(seed)
+    pos = torch.randn(at.shape[0], 3, generator=g)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    kw = dict(extend_order=False, w_global=1.0, global_start_sigma=0.5, clip=1000.0)
+    O.langevin_dynamics_sample_diffusion(sd, cfg, at, pos, bi, bt, ba, b["num_graphs"], n_steps=1, **kw)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.langevin_dynamics_sample_diffusion(sd, cfg, at, pos, bi, bt, ba, b["num_graphs"], n_steps=2, **kw)
+        n += 2
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 40:
+            break
+    s_per_step = el / n
+    val = b["num_graphs"] / (s_per_step * JOB_STEPS)
+    return {"value": val, "unit": "conformers/s", "cores": cores, "kind": "port",
+            "sample": "%d %s-shaped molecules x %d conformers (%d atoms), %d steps timed, %.3f s/step, "
+                      "same synthetic checkpoint and schedule, extrapolated to %d steps"
+                      % (mols, kind, copies, at.shape[0], n, s_per_step, JOB_STEPS)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="drugs", choices=["drugs", "qm9", "large"])
+    ap.add_argument("--mols", type=int, default=8)
+    ap.add_argument("--copies", type=int, default=128)
+    ap.add_argument("--schedule", default="saturated", choices=["saturated", "default"])
+    ap.add_argument("--no-skip", action="store_true", help="run the global encoder even where its result is discarded")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traj", action="store_true")
+    ap.add_argument("--breakdown", default=None, help="write per-op timings (ms) to this JSON file")
+    ap.add_argument("--seed", type=int, default=2021)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from agdiff_amd import _lib, get_model
+    from oracle import agdiff_oracle as O     # only for the shared synthetic state_dict and the cpu_baseline leg
+    lib = _lib.load()
+
+    kind = args.workload
+    cfg = make_cfg(kind, args.schedule)
+    sd = O.synth_state_dict_for(cfg)
+    model = get_model(cfg)
+    model.load_state_dict({k: v.clone() for k, v in sd.items()})
+    model = model.to(dev).eval()
+
+    copies = args.copies if kind != "large" else 1
+    mols = args.mols if kind != "large" else args.mols * args.copies
+    b = build_batch(kind, mols, copies, args.seed + 1000 * rank)       # weak scaling: same shape per rank
+    T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    at, bi, bt, ba = T(b["atom_type"]), T(b["bond_index"]), T(b["bond_type"]), T(b["batch"])
+    G = b["num_graphs"]
+    g = torch.Generator(device="cpu").manual_seed(args.seed + rank)
+    pos_init = torch.randn(at.shape[0], 3, generator=g).to(dev)
+
+    W, K = args.warmup, args.steps
+    Tn = cfg.num_diffusion_timesteps
+    if args.schedule == "default" and W + K < Tn:
+        # visit the whole schedule evenly so that the share of global-active steps is the job's
+        idx = np.linspace(Tn - 1, 0, W + K).round().astype(int).tolist()
+    else:
+        idx = list(reversed(range(Tn - (W + K), Tn)))
+    on_step = None
+    gather = None
+    if world > 1:
+        from agdiff_amd.dist import StepAllGather
+        gather = StepAllGather(at.shape[0], dev)
+    run = model.begin_sampling(at, pos_init, bi, bt, ba, G, False, n_steps=W + K, step_lr=1e-6, clip=1000.0,
+                               global_start_sigma=0.5, w_global=1.0, step_indices=idx,
+                               save_traj=not args.no_traj, skip_discarded_global=not args.no_skip,
+                               nan_check_every=10 ** 9)
+    if gather is not None:
+        run.on_step = lambda k, i, pos: gather(k, i, pos, run.ws.nan_flag)
+
+    run.advance(W)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    g0 = run.global_steps
+    t0 = time.perf_counter()
+    run.advance(K)
+    if gather is not None:
+        gather.wait()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    global_frac = (run.global_steps - g0) / max(K, 1)
+    if world > 1:
+        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+        gt = torch.tensor([G], dtype=torch.int64, device=dev)
+        dist.all_reduce(gt)
+        G_total = int(gt.item())
+    else:
+        G_total = G
+    run.check_nan()
+    ms_per_step = el / K * 1e3
+    value = G_total / (ms_per_step * JOB_STEPS / 1e3)
+
+    # ---- dominant kernel (fused CFConv) timed with events on the launch stream, workspace as the run left it
+    ws, topo, pk = run.ws, run.topo, run.pk
+    stream = _lib.stream_ptr()
+    E = int(ws.num_edges.item())
+    roof = None
+    if E > 0:
+        reps, evs = 5, []
+        for _ in range(reps):
+            for k in range(cfg.num_convs):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                lib.agdiff_cfconv_fused(ctypes.byref(pk.struct), ctypes.byref(topo.struct), ctypes.byref(ws.struct), k, stream)
+                e1.record()
+                evs.append((e0, e1))
+        torch.cuda.synchronize()
+        avg_ms = sum(a.elapsed_time(bb) for a, bb in evs) / len(evs)
+        ach = E * FLOP_PER_EDGE_CFCONV / (avg_ms * 1e-3) / 1e12
+        roof = {"kernel": "k_cfconv_fused", "bound": "mfma", "achieved": ach, "peak": PEAK["f32"], "unit": "TFLOP/s",
+                "frac": ach / PEAK["f32"], "traffic": None, "avg_launch_ms": avg_ms, "edges_per_launch": E}
+
+    if args.breakdown and rank == 0:
+        ops = {}
+
+        def timeit(name, fn, reps=5):
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ops[name] = e0.elapsed_time(e1) / reps
+        P, Tp, Wp = ctypes.byref(pk.struct), ctypes.byref(topo.struct), ctypes.byref(ws.struct)
+        et, lt = (topo.max_edges + 31) // 32, (topo.L + 31) // 32
+        timeit("graph_build", lambda: lib.agdiff_graph_build(Tp, Wp, run.pos_p, ctypes.c_float(cfg.cutoff), stream))
+        timeit("edge_encoder", lambda: lib.agdiff_edge_encoder(P, _lib.ptr(ws.num_edges), et, _lib.ptr(ws.e_len), _lib.ptr(ws.e_type), _lib.ptr(ws.e_attr), stream))
+        timeit("node_stage_x%d" % (cfg.num_convs + 1), lambda: [lib.agdiff_schnet_node_stage(P, Tp, Wp, k, stream) for k in range(cfg.num_convs + 1)])
+        timeit("cfconv_fused_x%d" % cfg.num_convs, lambda: [lib.agdiff_cfconv_fused(P, Tp, Wp, k, stream) for k in range(cfg.num_convs)])
+        timeit("head_global", lambda: lib.agdiff_pair_head(ctypes.byref(pk.struct.head_global), _lib.ptr(ws.num_edges), et, _lib.ptr(ws.e_src), _lib.ptr(ws.e_dst), _lib.ptr(ws.h), _lib.ptr(ws.e_attr), _lib.ptr(ws.e_inv_global), stream))
+        timeit("local_branch", lambda: lib.agdiff_score_forward(P, Tp, Wp, run.pos_p, 0, stream))
+        timeit("score_forward_global", lambda: lib.agdiff_score_forward(P, Tp, Wp, run.pos_p, 1, stream))
+        ops.update(N=topo.N, E=E, L=topo.L, G=G, ms_per_step=ms_per_step)
+        with open(args.breakdown, "w") as f:
+            json.dump(ops, f, indent=1)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(kind, args.schedule, args.seed)
+
+    if rank == 0:
+        out = {
+            "metric": "conformers/sec (whole node), GEOM-Drugs 5000-step sampling",
+            "value": value, "unit": "conformers/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s-shaped synthetic molecules: %d molecules x %d conformers per GPU "
+                                   "(%d atoms, %d edges, %d local edges per GPU), %s schedule, "
+                                   "global branch active on %.0f%% of timed steps, %d-step job"
+                                   % (kind, mols, copies, topo.N, E, topo.L, args.schedule, 100 * global_frac, JOB_STEPS),
+                       "conformers_total": G_total, "parallelism": "dp%d" % world,
+                       "all_gather_per_step": world > 1, "trajectory_saved": not args.no_traj,
+                       "skip_discarded_global": not args.no_skip},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
