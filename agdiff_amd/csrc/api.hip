@@ -40,6 +40,7 @@ extern "C" int agdiff_score_forward(const agdiff_params_t* p, const agdiff_topo_
   // global branch: radius graph -> edge encoder -> SchNet -> global head   (dualenc.py:167-211)
   const int64_t etiles = (topo->max_edges + 31) / 32;
   AG_TRY(agdiff_graph_build(topo, ws, pos, p->cutoff, stream));
+  AG_TRY(agdiff_edge_scales(p, topo, ws, stream));
   AG_TRY(agdiff_edge_encoder(p, ws->num_edges, etiles, ws->e_len, ws->e_type, ws->e_attr, stream));
   for (int k = 0; k <= p->num_convs; ++k) {
     AG_TRY(agdiff_schnet_node_stage(p, topo, ws, k, stream));

@@ -1,8 +1,9 @@
-// Per-edge kernels: MLPEdgeEncoder, fused CFConv (filter MLP + message + destination-segmented
-// reduction), pair-feature heads.  One wave = one tile of 32 edges; activations stay in the MFMA
-// accumulator layout between layers (common.hpp).
+// Per-edge kernels: MLPEdgeEncoder, per-edge CFConv scales, fused CFConv (filter MLP + message +
+// destination-segmented reduction), pair-feature heads, and the stand-alone aggregate.
+// One wave = one tile of 32 edges; activations stay in the MFMA accumulator layout between layers
+// (common.hpp).  Every MFMA kernel is instantiated for both arithmetic modes (AG_F32 / AG_BF3).
 #include "common.hpp"
-#include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -26,6 +27,8 @@ struct EncArgs {
 // encoder/edge.py:84-103.  x0 = gelu(w*d+b); h1 = gelu(W1a x0 + T1[type]); h2 = gelu(W23 h1 + T3[type]);
 // a = W4 h2 + b4.  (T1/T3: per-edge-type tables holding the bond_emb halves of the two 256->128
 // layers; W23 = comb.0[:, :128] @ efm.2; the trailing attention factor is exactly 1.)
+// The result is stored in the operand form of the consuming mode (common.hpp: edge-attr storage).
+template <int MODE>
 __global__ void __launch_bounds__(AG_WG, 2) k_edge_encoder(EncArgs a) {
   const int lane = ag_lane(), h = lane >> 5;
   const int64_t tile = (int64_t)blockIdx.x * 4 + ag_wave_in_wg();
@@ -35,39 +38,33 @@ __global__ void __launch_bounds__(AG_WG, 2) k_edge_encoder(EncArgs a) {
   const bool valid = e < E;
   const float d = valid ? a.e_len[e] : 0.0f;
   const int ty = valid ? a.e_type[e] : 0;
+  constexpr int PF = (MODE == AG_F32) ? 1 : 4;
 
-  f32x16 x[4], y[4];
-  ag_init_vec<4>(x, a.fe_w, h);
-  ag_init_vec<4>(y, a.fe_b, h);
-  AG_FOR_TILE(x, 4, ag_gelu(fmaf(v, d, y[_t][_r])));
+  f32x16 y[4];
+  AgIn<MODE> x[4];
+  {
+    f32x16 w[4];
+    ag_init_vec<4>(w, a.fe_w, h);
+    ag_init_vec<4>(y, a.fe_b, h);
+    AG_FOR_TILE(y, 4, ag_gelu(fmaf(w[_t][_r], d, v)));
+  }
+  ag_cvt_tiles<MODE, 4, 0>(y, x);
   ag_init_vec<4>(y, a.t1 + (size_t)ty * 128, h);
-  ag_dense_std<4, 4, 0, 0, 4>(x, y, a.w1_pk, lane);
+  ag_dense_std<MODE, 4, 4, 0, 0, 4, PF>(x, y, a.w1_pk, lane);
   AG_FOR_TILE(y, 4, ag_gelu(v));
-  ag_init_vec<4>(x, a.t3 + (size_t)ty * 128, h);
-  ag_dense_std<4, 4, 0, 0, 4>(y, x, a.w23_pk, lane);
-  AG_FOR_TILE(x, 4, ag_gelu(v));
+  ag_cvt_tiles<MODE, 4, 0>(y, x);
+  ag_init_vec<4>(y, a.t3 + (size_t)ty * 128, h);
+  ag_dense_std<MODE, 4, 4, 0, 0, 4, PF>(x, y, a.w23_pk, lane);
+  AG_FOR_TILE(y, 4, ag_gelu(v));
+  ag_cvt_tiles<MODE, 4, 0>(y, x);
   ag_init_vec<4>(y, a.b4, h);
-  ag_dense_std<4, 4, 0, 0, 4>(x, y, a.w4_pk, lane);
-  ag_store_frag<4>(y, a.out_frag, tile, lane);
+  ag_dense_std<MODE, 4, 4, 0, 0, 4, PF>(x, y, a.w4_pk, lane);
+  ag_cvt_tiles<MODE, 4, 0>(y, x);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) ag_store_attr_slice(x[t], a.out_frag, tile, t, lane);
 }
 
-// ------------------------------------------------------------------------------ fused CFConv
-struct ConvArgs {
-  agdiff_conv_params_t cp;
-  const int32_t* n_dev;
-  const int32_t* in_ptr;
-  const int32_t* e_src;
-  const int32_t* e_dst;
-  const float* e_len;
-  const float* e_attr;
-  const float* xs;       // [N][192]
-  float* agg;            // [N][192]
-  float* agg_first;      // [chunks][192]
-  int64_t max_chunks;
-  float cutoff;
-  int32_t smooth;
-};
-
+// ------------------------------------------------------------------------------ per-edge conv scales
 // DistanceWeightingNetwork (schnet.py:83-100) times the cutoff envelope (schnet.py:140-146).
 __device__ __forceinline__ float cf_edge_scale(const float* __restrict__ dw, float d, float cutoff, int smooth) {
   float acc = dw[96];
@@ -86,146 +83,258 @@ __device__ __forceinline__ float cf_edge_scale(const float* __restrict__ dw, flo
   return lw * C;
 }
 
+struct ScaleArgs {
+  const float* dw[2 * AGDIFF_MAX_CONVS];
+  const int32_t* n_dev;
+  const float* e_len;
+  float* out;
+  int64_t epad;
+  int32_t n;
+  float cutoff;
+  int32_t smooth;
+};
+
+// lw(d) * C(d) for the 2*num_convs CFConvs (schnet.py:138-149), once per step instead of once per
+// block launch; accurate libm expf / cosf here, it is one thread per edge.
+__global__ void __launch_bounds__(256) k_edge_scales(ScaleArgs a) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= *a.n_dev) return;
+  const float d = a.e_len[e];
+  for (int c = 0; c < a.n; ++c) a.out[(size_t)c * a.epad + e] = cf_edge_scale(a.dw[c], d, a.cutoff, a.smooth);
+}
+
+// ------------------------------------------------------------------------------ fused CFConv
+struct ConvArgs {
+  agdiff_conv_params_t cp;
+  const int32_t* n_dev;
+  const int32_t* in_ptr;
+  const int32_t* e_src;
+  const int32_t* e_dst;
+  const float* scale1;   // [E] lw(d)*C(d) of conv1 of this block
+  const float* scale2;   // [E] ... conv2
+  const float* e_attr;
+  const float* xs;       // [N][192]
+  float* agg;            // [N][192]
+  float* agg_first;      // [chunks][192]
+  int64_t max_chunks;
+  int32_t ablate;        // timing experiments only (AGDIFF_ABLATE env): bit0 skip layer 1, bit1 skip ssp,
+                         // bit2 skip layer 2, bit3 skip x gather, bit4 skip reduction
+};
+
+#define AG_CONV_WAVES 8
+#define AG_CONV_LDS_BLOCKS 36   // resident 4-KiB weight blocks: filt_w1a (16) | filt_w2a (16) | filt_w2b (4)
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+
 // encoder/schnet.py:136-162 for conv1 (F=128) and conv2 (F=64) of one InteractionBlock:
 //   W_e = nn(edge_attr_e) * (lw(d_e) * C(d_e));  agg[dst] += x[src] * W_e   (aggr='add')
-// Each wave walks AGDIFF_CHUNK_TILES consecutive destination-sorted tiles and keeps the running sum
-// of the current target in registers; a target whose list started in an earlier chunk is written
-// to agg_first[chunk] and added by the node stage (fixed order -> bitwise reproducible).
-__global__ void __launch_bounds__(AG_WG, 2) k_cfconv_fused(ConvArgs a) {
+// Persistent launch, one 8-wave workgroup per CU.  Each wave walks AGDIFF_CHUNK_TILES consecutive
+// destination-sorted tiles per chunk and keeps the running sum of the open target in LDS; a target
+// whose list started in an earlier chunk is written to agg_first[chunk] and added by the node stage
+// (fixed order -> bitwise reproducible, no atomics).
+template <int MODE>
+__global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs a) {
+  // LDS (156 KiB of the CU's 160): 144 KiB of filter weights resident for the whole launch -- conv1's first
+  // layer and both second layers -- plus the carry rows (waves x 6 x 64 floats).  Only conv2's first layer
+  // (8 blocks per tile) is streamed from L2.
+  extern __shared__ u32x4 ag_conv_smem[];
+  lds_u32x4* w1a = (lds_u32x4*)ag_conv_smem;
+  lds_u32x4* w2 = w1a + 16 * 256;
+  {
+    const u32x4* g1 = reinterpret_cast<const u32x4*>(a.cp.filt_w1a_pk);
+    const u32x4* ga = reinterpret_cast<const u32x4*>(a.cp.filt_w2a_pk);
+    const u32x4* gb = reinterpret_cast<const u32x4*>(a.cp.filt_w2b_pk);
+    for (int i = threadIdx.x; i < 16 * 256; i += blockDim.x) w1a[i] = g1[i];
+    for (int i = threadIdx.x; i < 16 * 256; i += blockDim.x) w2[i] = ga[i];
+    for (int i = threadIdx.x; i < 4 * 256; i += blockDim.x) w2[16 * 256 + i] = gb[i];
+  }
+  __syncthreads();
   const int lane0 = ag_lane();
-  const int64_t chunk = (int64_t)blockIdx.x * 4 + ag_wave_in_wg();
+  const int wave = threadIdx.x >> 6;
   const int E = *a.n_dev;
-  const int64_t e_begin = chunk * (32 * AGDIFF_CHUNK_TILES);
-  if (chunk >= a.max_chunks || e_begin >= E) return;
   const int h0 = lane0 >> 5, col0 = lane0 & 31;
+  // running sums (6 channel tiles x 64 lanes) of target run_t, whose list is still open
+  float* carry = reinterpret_cast<float*>(ag_conv_smem + AG_CONV_LDS_BLOCKS * 256) + wave * (6 * 64);
+  const int64_t cstride = (int64_t)gridDim.x * AG_CONV_WAVES;
 
-  // running sums (6 channel tiles x 64 lanes) of target run_t, whose list is still open; kept in
-  // LDS so that the channel-tile loops need not be unrolled
-  __shared__ float carry_s[4][6 * 64];
-  float* carry = carry_s[ag_wave_in_wg()];
-  int run_t = -1;
+  for (int64_t chunk = (int64_t)blockIdx.x * AG_CONV_WAVES + wave; chunk < a.max_chunks; chunk += cstride) {
+    const int64_t e_begin = chunk * (32 * AGDIFF_CHUNK_TILES);
+    if (e_begin >= E) break;
+    int run_t = -1;
 
-  auto dest = [&](int t) -> float* {
-    const int lo = a.in_ptr[t];
-    return (lo >= e_begin) ? (a.agg + (size_t)t * 192) : (a.agg_first + (size_t)chunk * 192);
-  };
-
-  for (int tt = 0; tt < AGDIFF_CHUNK_TILES; ++tt) {
-    const int64_t tile = chunk * AGDIFF_CHUNK_TILES + tt;
-    const int64_t tbase = tile * 32;
-    if (tbase >= E) break;
-    // opaque copy of the lane id: keeps hipcc from hoisting every lane-derived weight / table address
-    // out of the tile loop (they would stay live across the whole body and spill)
-    int lane = lane0;
-    asm volatile("" : "+v"(lane));
-    const int h = lane >> 5, col = lane & 31;
-    const int64_t e = tbase + col;
-    const bool valid = e < E;
-    const float d = valid ? a.e_len[e] : 0.0f;
-    const int my_src = valid ? a.e_src[e] : 0;
-    const float s1 = valid ? cf_edge_scale(a.cp.dist_w, d, a.cutoff, a.smooth) : 0.0f;
-    const float s2 = valid ? cf_edge_scale(a.cp.dist_w + 97, d, a.cutoff, a.smooth) : 0.0f;
-
-    const int64_t last = (tbase + 31 < E) ? tbase + 31 : (int64_t)E - 1;
-    const int t0 = __builtin_amdgcn_readfirstlane(a.e_dst[tbase]);
-    const int t1 = __builtin_amdgcn_readfirstlane(a.e_dst[last]);
-    if (run_t >= 0 && run_t != t0) {   // previous tile ended exactly on a list boundary
-      float* dp = dest(run_t);
-      if (h == 0) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) dp[32 * i + col] = carry[i * 64 + lane];
-      }
-      run_t = -1;
-    }
-    const bool cont = (run_t == t0);
-
-    f32x16 hid[6];
-    {
-      // first filter layer, k-tile outer: only two 32-feature slices of edge_attr are live at a time
-      f32x16 ea[2];
-      ag_init_vec<6>(hid, a.cp.filt_b1, h);
-      ag_load_frag_tile<0>(ea, a.e_attr, tile, 0, lane);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        if (t + 1 < 4) {
-          if (t & 1) ag_load_frag_tile<0>(ea, a.e_attr, tile, t + 1, lane);
-          else ag_load_frag_tile<1>(ea, a.e_attr, tile, t + 1, lane);
-        }
-        if (t & 1) ag_dense_std_k<1, 6, 1, 0>(ea, hid, a.cp.filt_w1_pk + (size_t)t * 6 * 1024, lane);
-        else ag_dense_std_k<1, 6, 0, 0>(ea, hid, a.cp.filt_w1_pk + (size_t)t * 6 * 1024, lane);
-      }
-    }
-    // ssp, then fold the per-edge scale lw(d)*C(d) (a per-lane scalar here) into the hidden layer:
-    // (s.H)^T W2 + s.b2 == s.(H^T W2 + b2)
-#pragma unroll
-    for (int t = 0; t < 6; ++t) {
-      const float beta = (t < 4) ? a.cp.ssp_beta1 : a.cp.ssp_beta2;
-      const float sc = (t < 4) ? s1 : s2;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) hid[t][r] = ag_ssp(beta, hid[t][r]) * sc;
-    }
-    // gather row of every edge slot my half owns: slot (r,h) lives in lane ag_row(r,h)
-    uint32_t xoff[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) xoff[r] = (uint32_t)__shfl(my_src, ag_row(r, h)) * 192u + (uint32_t)col;
-
-    // second filter layer per 32-channel tile, flipped (rows = edges, lanes = channels), then
-    // message and destination-segmented reduction of that channel tile
-    auto channel_tile = [&](f32x16 (&z)[1], int nt) {
-      const float* xb = a.xs + 32 * nt;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) z[0][r] *= xb[xoff[r]];
-      float newcarry = 0.0f;
-      for (int t = t0; t <= t1; ++t) {
-        const int lo = __builtin_amdgcn_readfirstlane(a.in_ptr[t]);
-        const int hi = __builtin_amdgcn_readfirstlane(a.in_ptr[t + 1]);
-        float p = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t er = tbase + ag_row(r, h);
-          p += ((er >= lo) && (er < hi)) ? z[0][r] : 0.0f;
-        }
-        p += __shfl_xor(p, 32);
-        if (t == t0 && cont) p = carry[nt * 64 + lane] + p;
-        if (t < t1) {
-          float* dp = dest(t);
-          if (h == 0) dp[32 * nt + col] = p;
-        } else {
-          newcarry = p;
-        }
-      }
-      carry[nt * 64 + lane] = newcarry;
+    auto dest = [&](int t) -> float* {
+      const int lo = a.in_ptr[t];
+      return (lo >= e_begin) ? (a.agg + (size_t)t * 192) : (a.agg_first + (size_t)chunk * 192);
     };
-    // bias enters as one extra k-step: A = s_e on k-slot 0 (lane half 0), B = b2 on k-slot 0
+
+    for (int tt = 0; tt < AGDIFF_CHUNK_TILES; ++tt) {
+      const int64_t tile = chunk * AGDIFF_CHUNK_TILES + tt;
+      const int64_t tbase = tile * 32;
+      if (tbase >= E) break;
+      // opaque copy of the lane id: keeps hipcc from hoisting every lane-derived weight / table address
+      // out of the tile loop (they would stay live across the whole body and spill)
+      int lane = lane0;
+      asm volatile("" : "+v"(lane));
+      const int h = lane >> 5, col = lane & 31;
+      const int64_t e = tbase + col;
+      const bool valid = e < E;
+      const int my_src = valid ? a.e_src[e] : 0;
+      const float s1 = valid ? a.scale1[e] : 0.0f;
+      const float s2 = valid ? a.scale2[e] : 0.0f;
+
+      const int64_t last = (tbase + 31 < E) ? tbase + 31 : (int64_t)E - 1;
+      const int t0 = __builtin_amdgcn_readfirstlane(a.e_dst[tbase]);
+      const int t1 = __builtin_amdgcn_readfirstlane(a.e_dst[last]);
+      if (run_t >= 0 && run_t != t0) {   // previous tile ended exactly on a list boundary
+        float* dp = dest(run_t);
+        if (h == 0) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) dp[32 * i + col] = carry[i * 64 + lane];
+        }
+        run_t = -1;
+      }
+      const bool cont = (run_t == t0);
+
+      AgIn<MODE> hidb[6];
+      {
+        f32x16 hid[6];
+        {
+          // first filter layer, k-slice outer: per slice t, conv1's four output tiles from LDS-resident
+          // blocks, conv2's two from blocks streamed from L2; the streamed pair is refilled for the next
+          // slice right after its last use (4 LDS-fed steps of lookahead).  LDS-fed steps are
+          // double-buffered by hand: the sched_barriers that pin the global prefetches would otherwise
+          // also pin each ds_read right in front of its MFMAs.
+          AgIn<MODE> ea[4];
+          ag_init_vec<6>(hid, a.cp.filt_b1, h);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) ag_load_attr_slice(ea[t], a.e_attr, tile, t, lane);
+          if (!(a.ablate & 1)) {
+            const u32x4* gl = reinterpret_cast<const u32x4*>(a.cp.filt_w1b_pk) + lane;
+            u32x4 g[2][4];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+              for (int u = 0; u < 4; ++u) g[b][u] = gl[(b * 4 + u) * 64];
+            u32x4 wl[2][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) wl[0][u] = w1a[u * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+              for (int ot = 0; ot < 6; ++ot) {
+                if (ot < 4) {
+                  const int cur = t * 4 + ot;   // LDS block index, consumed in this order
+                  if (cur + 1 < 16) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) wl[(cur + 1) & 1][u] = w1a[((cur + 1) * 4 + u) * 64 + lane];
+                  }
+                  ag_block_mma<MODE, false>(hid[ot], ea[t], wl[cur & 1]);
+                } else {
+                  ag_block_mma<MODE, false>(hid[ot], ea[t], g[ot - 4]);
+                  if (t + 1 < 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) g[ot - 4][u] = gl[(((t + 1) * 2 + (ot - 4)) * 4 + u) * 64];
+                  }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+          }
+        }
+        // ssp, then fold the per-edge scale lw(d)*C(d) (a per-lane scalar here) into the hidden layer:
+        // (s.H)^T W2 + s.b2 == s.(H^T W2 + b2)
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+          const float beta = (t < 4) ? a.cp.ssp_beta1 : a.cp.ssp_beta2;
+          const float sc = (t < 4) ? s1 : s2;
+          if (!(a.ablate & 2)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hid[t][r] = ag_ssp(beta, hid[t][r]) * sc;
+          }
+        }
+        ag_cvt_tiles<MODE, 6, 0>(hid, hidb);
+      }
+      // gather row of every edge slot my half owns: slot (r,h) lives in lane ag_row(r,h)
+      uint32_t xoff[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xoff[r] = (uint32_t)__shfl(my_src, ag_row(r, h)) * 192u + (uint32_t)col;
+      // list boundaries of the targets present in this tile, one per lane (in_ptr[t0 + lane]); the
+      // reduction loops read them with readlane instead of dependent global loads
+      const int ntg = t1 - t0 + 1;
+      const int ipl = a.in_ptr[t0 + (lane <= ntg ? lane : ntg)];
+      auto bound = [&](int i) -> int {   // in_ptr[t0 + i], i <= ntg
+        return (i < 64) ? __builtin_amdgcn_readlane(ipl, i) : __builtin_amdgcn_readfirstlane(a.in_ptr[t0 + i]);
+      };
+      auto dest_lo = [&](int t, int lo) -> float* {
+        return (lo >= e_begin) ? (a.agg + (size_t)t * 192) : (a.agg_first + (size_t)chunk * 192);
+      };
+
+      // second filter layer per 32-channel tile, flipped (rows = edges, lanes = channels), then
+      // message and destination-segmented reduction of that channel tile.  The x[src] rows of the next
+      // channel tile are fetched before the current tile's reduction.
+      float xg[16];
+      auto fetch_x = [&](int nt) {
+        if (a.ablate & 8) return;
+        const float* xb = a.xs + 32 * nt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xg[r] = xb[xoff[r]];
+      };
+      auto channel_tile = [&](f32x16 (&z)[1], int nt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[0][r] *= xg[r];
+        if (nt + 1 < 6) fetch_x(nt + 1);
+        if (a.ablate & 16) { carry[nt * 64 + lane] = z[0][0]; return; }
+        float newcarry = 0.0f;
+        for (int i = 0; i < ntg; ++i) {
+          const int lo = bound(i), hi = bound(i + 1);
+          float p = 0.0f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int er = (int)tbase + ag_row(r, h);
+            p += ((er >= lo) && (er < hi)) ? z[0][r] : 0.0f;
+          }
+          p += __shfl_xor(p, 32);
+          if (i == 0 && cont) p = carry[nt * 64 + lane] + p;
+          if (i < ntg - 1) {
+            float* dp = dest_lo(t0 + i, lo);
+            if (h == 0) dp[32 * nt + col] = p;
+          } else {
+            newcarry = p;
+          }
+        }
+        carry[nt * 64 + lane] = newcarry;
+      };
+      fetch_x(0);
+      // the bias enters as one extra k-step (ag_rank1): A = s_e on k-slot 0, B = b2 on k-slot 0
 #pragma unroll 1
-    for (int nt = 0; nt < 4; ++nt) {
-      f32x16 z[1];
-      const float bb = (h == 0) ? a.cp.filt_b2[32 * nt + col] : 0.0f;
+      for (int nt = 0; nt < 4; ++nt) {
+        f32x16 z[1];
+        const float bb = a.cp.filt_b2[32 * nt + col];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) z[0][r] = 0.0f;
-      z[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((h == 0) ? s1 : 0.0f, bb, z[0], 0, 0, 0);
-      ag_dense_flip<4, 1, 0, 0>(hid, z, a.cp.filt_w2a_pk + (size_t)nt * 4 * 1024, lane);
-      channel_tile(z, nt);
-    }
+        for (int r = 0; r < 16; ++r) z[0][r] = 0.0f;
+        ag_rank1(z[0], s1, bb, h, (AgIn<MODE>*)nullptr);
+        if (!(a.ablate & 4)) ag_dense_flip_lds<MODE, 4, 1, 0, 0>(hidb, z, w2 + (nt * 4) * 256, lane);
+        channel_tile(z, nt);
+      }
 #pragma unroll 1
-    for (int nt = 4; nt < 6; ++nt) {
-      f32x16 z[1];
-      const float bb = (h == 0) ? a.cp.filt_b2[32 * nt + col] : 0.0f;
+      for (int nt = 4; nt < 6; ++nt) {
+        f32x16 z[1];
+        const float bb = a.cp.filt_b2[32 * nt + col];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) z[0][r] = 0.0f;
-      z[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((h == 0) ? s2 : 0.0f, bb, z[0], 0, 0, 0);
-      ag_dense_flip<2, 1, 4, 0>(hid, z, a.cp.filt_w2b_pk + (size_t)(nt - 4) * 2 * 1024, lane);
-      channel_tile(z, nt);
+        for (int r = 0; r < 16; ++r) z[0][r] = 0.0f;
+        ag_rank1(z[0], s2, bb, h, (AgIn<MODE>*)nullptr);
+        if (!(a.ablate & 4)) ag_dense_flip_lds<MODE, 2, 1, 4, 0>(hidb, z, w2 + (16 + (nt - 4) * 2) * 256, lane);
+        channel_tile(z, nt);
+      }
+      run_t = t1;
     }
-    run_t = t1;
-  }
-  if (run_t >= 0) {
-    float* dp = dest(run_t);
-    if (h0 == 0) {
+    if (run_t >= 0) {
+      float* dp = dest(run_t);
+      if (h0 == 0) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) dp[32 * i + col0] = carry[i * 64 + lane0];
+        for (int i = 0; i < 6; ++i) dp[32 * i + col0] = carry[i * 64 + lane0];
+      }
     }
-  }
+  }  // chunk loop
 }
 
 // ------------------------------------------------------------------------------ pair head
@@ -241,6 +350,7 @@ struct HeadArgs {
 };
 
 // assemble_atom_pair_feature (common.py:106-109) + MultiLayerPerceptron 256->128->64->1 (common.py:86-103)
+template <int MODE>
 __global__ void __launch_bounds__(AG_WG, 2) k_pair_head(HeadArgs a) {
   const int lane = ag_lane(), h = lane >> 5;
   const int64_t tile = (int64_t)blockIdx.x * 4 + ag_wave_in_wg();
@@ -256,35 +366,37 @@ __global__ void __launch_bounds__(AG_WG, 2) k_pair_head(HeadArgs a) {
   {
     const float* hs = a.node_h + (size_t)s * 128;
     const float* ht = a.node_h + (size_t)t * 128;
-    f32x16 sl[2];
-    auto load_slice = [&](auto which, int k) {
-      constexpr int W = decltype(which)::value;
+    AgIn<MODE> sl[2];
+    auto load_slice = [&](AgIn<MODE>& dst, int k) {
       if (k < 4) {
+        f32x16 pr;
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
           f32x4 u = ag_ld4(hs + 32 * k + 8 * rq + 4 * h), w = ag_ld4(ht + 32 * k + 8 * rq + 4 * h);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) sl[W][4 * rq + q] = u[q] * w[q];
+          for (int q = 0; q < 4; ++q) pr[4 * rq + q] = u[q] * w[q];
         }
+        ag_cvt(pr, dst);
       } else {
-        ag_load_frag_tile<W>(sl, a.attr_frag, tile, k - 4, lane);
+        ag_load_attr_slice(dst, a.attr_frag, tile, k - 4, lane);
       }
     };
-    load_slice(std::integral_constant<int, 0>{}, 0);
+    load_slice(sl[0], 0);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      if (k + 1 < 8) {
-        if (k & 1) load_slice(std::integral_constant<int, 0>{}, k + 1);
-        else load_slice(std::integral_constant<int, 1>{}, k + 1);
-      }
-      if (k & 1) ag_dense_std_k<1, 4, 1, 0>(sl, y1, a.hp.w1_pk + (size_t)k * 4 * 1024, lane);
-      else ag_dense_std_k<1, 4, 0, 0>(sl, y1, a.hp.w1_pk + (size_t)k * 4 * 1024, lane);
+      if (k + 1 < 8) load_slice(sl[(k + 1) & 1], k + 1);
+      if (k & 1) ag_dense_std_k<MODE, 1, 4, 1, 0>(sl, y1, ag_wblock(a.hp.w1_pk, k * 4), lane);
+      else ag_dense_std_k<MODE, 1, 4, 0, 0>(sl, y1, ag_wblock(a.hp.w1_pk, k * 4), lane);
     }
   }
   AG_FOR_TILE(y1, 4, ag_relu(v));
   f32x16 y2[2];
   ag_init_vec<2>(y2, a.hp.b2, h);
-  ag_dense_std<4, 2, 0, 0, 4>(y1, y2, a.hp.w2_pk, lane);
+  {
+    AgIn<MODE> y1b[4];
+    ag_cvt_tiles<MODE, 4, 0>(y1, y1b);
+    ag_dense_std<MODE, 4, 2, 0, 0, 4>(y1b, y2, a.hp.w2_pk, lane);
+  }
   AG_FOR_TILE(y2, 2, ag_relu(v));
   const float o = ag_dot_vec<2>(y2, a.hp.w3, h) + a.hp.b3;
   if (valid && h == 0) a.out[e] = o;
@@ -328,7 +440,31 @@ extern "C" int agdiff_edge_encoder(const agdiff_params_t* p, const int32_t* n_ed
   if (max_tiles == 0) return AGDIFF_OK;
   EncArgs a{p->ee_fe_w, p->ee_fe_b, p->ee_t1, p->ee_w1_pk, p->ee_t3, p->ee_w23_pk, p->ee_w4_pk, p->ee_b4,
             n_edges_dev, e_len, e_type, attr_frag, max_tiles};
-  k_edge_encoder<<<dim3((unsigned)((max_tiles + 3) / 4)), dim3(AG_WG), 0, (hipStream_t)stream>>>(a);
+  if (p->precision == AG_BF3)
+    k_edge_encoder<AG_BF3><<<dim3((unsigned)((max_tiles + 3) / 4)), dim3(AG_WG), 0, (hipStream_t)stream>>>(a);
+  else
+    k_edge_encoder<AG_F32><<<dim3((unsigned)((max_tiles + 3) / 4)), dim3(AG_WG), 0, (hipStream_t)stream>>>(a);
+  AG_CHECK_LAUNCH();
+  return AGDIFF_OK;
+}
+
+extern "C" int agdiff_edge_scales(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, void* stream) {
+  if (!p || !topo || !ws || !ws->e_scale || !ws->e_len || !ws->num_edges || p->num_convs > AGDIFF_MAX_CONVS)
+    return AGDIFF_ERR_ARG;
+  if (topo->max_edges == 0) return AGDIFF_OK;
+  ScaleArgs a;
+  for (int k = 0; k < p->num_convs; ++k) {
+    a.dw[2 * k] = p->conv[k].dist_w;
+    a.dw[2 * k + 1] = p->conv[k].dist_w + 97;
+  }
+  a.n_dev = ws->num_edges;
+  a.e_len = ws->e_len;
+  a.out = ws->e_scale;
+  a.epad = ((topo->max_edges + 31) / 32) * 32;
+  a.n = 2 * p->num_convs;
+  a.cutoff = p->cutoff;
+  a.smooth = p->smooth;
+  k_edge_scales<<<dim3((unsigned)((topo->max_edges + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(a);
   AG_CHECK_LAUNCH();
   return AGDIFF_OK;
 }
@@ -346,15 +482,39 @@ extern "C" int agdiff_cfconv_fused(const agdiff_params_t* p, const agdiff_topo_t
   a.in_ptr = ws->in_ptr;
   a.e_src = ws->e_src;
   a.e_dst = ws->e_dst;
-  a.e_len = ws->e_len;
+  {
+    const size_t epad = (size_t)max_tiles * 32;
+    a.scale1 = ws->e_scale + (size_t)(2 * k) * epad;
+    a.scale2 = ws->e_scale + (size_t)(2 * k + 1) * epad;
+  }
   a.e_attr = ws->e_attr;
   a.xs = ws->xs;
   a.agg = ws->agg;
   a.agg_first = ws->agg_first;
   a.max_chunks = max_chunks;
-  a.cutoff = p->cutoff;
-  a.smooth = p->smooth;
-  k_cfconv_fused<<<dim3((unsigned)((max_chunks + 3) / 4)), dim3(AG_WG), 0, (hipStream_t)stream>>>(a);
+  {
+    static int abl = -1;
+    if (abl < 0) {
+      const char* e = getenv("AGDIFF_ABLATE");
+      abl = e ? atoi(e) : 0;
+    }
+    a.ablate = abl;
+  }
+  // persistent launch: one 8-wave workgroup per CU keeps 144 KiB of filter weights in LDS
+  int64_t wgs = (max_chunks + AG_CONV_WAVES - 1) / AG_CONV_WAVES;
+  if (wgs > 256) wgs = 256;
+  const size_t smem = (size_t)AG_CONV_LDS_BLOCKS * 4096 + (size_t)AG_CONV_WAVES * 6 * 64 * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)k_cfconv_fused<AG_BF3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_cfconv_fused<AG_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return AGDIFF_ERR_LAUNCH;
+    attr_set = true;
+  }
+  if (p->precision == AG_BF3)
+    k_cfconv_fused<AG_BF3><<<dim3((unsigned)wgs), dim3(64 * AG_CONV_WAVES), smem, (hipStream_t)stream>>>(a);
+  else
+    k_cfconv_fused<AG_F32><<<dim3((unsigned)wgs), dim3(64 * AG_CONV_WAVES), smem, (hipStream_t)stream>>>(a);
   AG_CHECK_LAUNCH();
   return AGDIFF_OK;
 }
@@ -373,7 +533,10 @@ extern "C" int agdiff_pair_head(const agdiff_head_params_t* hp, const int32_t* n
   a.attr_frag = attr_frag;
   a.out = out;
   a.max_tiles = max_tiles;
-  k_pair_head<<<dim3((unsigned)((max_tiles + 3) / 4)), dim3(AG_WG), 0, (hipStream_t)stream>>>(a);
+  if (hp->precision == AG_BF3)
+    k_pair_head<AG_BF3><<<dim3((unsigned)((max_tiles + 3) / 4)), dim3(AG_WG), 0, (hipStream_t)stream>>>(a);
+  else
+    k_pair_head<AG_F32><<<dim3((unsigned)((max_tiles + 3) / 4)), dim3(AG_WG), 0, (hipStream_t)stream>>>(a);
   AG_CHECK_LAUNCH();
   return AGDIFF_OK;
 }

@@ -28,6 +28,7 @@ struct NodeStageArgs {
 //           h += x * sigmoid(fc2(relu(fc1(x))))                   (schnet.py:230-234, 280)
 //   prep:   xs = LeakyReLU(BN(lin1(h))) for conv1 | conv2         (schnet.py:153-155)
 //   stage 0 (finish == 0): h = embedding[z]                       (schnet.py:271)
+template <int MODE>
 __global__ void __launch_bounds__(AG_WG, 2) k_schnet_node_stage(NodeStageArgs a) {
   const int lane = ag_lane(), h = lane >> 5;
   const int64_t tile = (int64_t)blockIdx.x * 4 + ag_wave_in_wg();
@@ -51,32 +52,30 @@ __global__ void __launch_bounds__(AG_WG, 2) k_schnet_node_stage(NodeStageArgs a)
       const float* fr = a.agg_first + (size_t)c_hi * 192;
       const bool split = has && (c_hi > c_lo);
       ag_init_vec<8>(u, a.prev.lin2_b, h);
-      f32x16 g[2];
-      auto load_slice = [&](auto which, int k) {
-        constexpr int W = decltype(which)::value;
+      AgIn<MODE> g[2];
+      auto load_slice = [&](AgIn<MODE>& dst, int k) {
+        f32x16 raw;
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
           const int f = 32 * k + 8 * rq + 4 * h;
           f32x4 v = has ? ag_ld4(ar + f) : f32x4{0.f, 0.f, 0.f, 0.f};
           if (split) v += ag_ld4(fr + f);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) g[W][4 * rq + q] = v[q];
+          for (int q = 0; q < 4; ++q) raw[4 * rq + q] = v[q];
         }
+        ag_cvt(raw, dst);
       };
-      load_slice(std::integral_constant<int, 0>{}, 0);
+      load_slice(g[0], 0);
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
-        if (k + 1 < 6) {
-          if (k & 1) load_slice(std::integral_constant<int, 0>{}, k + 1);
-          else load_slice(std::integral_constant<int, 1>{}, k + 1);
-        }
+        if (k + 1 < 6) load_slice(g[(k + 1) & 1], k + 1);
         // conv1.lin2: slices 0..3 -> u[0..3]; conv2.lin2: slices 4..5 -> u[4..7]   (pkk blocks)
         if (k < 4) {
-          if (k & 1) ag_dense_std_k<1, 4, 1, 0>(g, u, a.prev.lin2a_pk + (size_t)k * 4 * 1024, lane);
-          else ag_dense_std_k<1, 4, 0, 0>(g, u, a.prev.lin2a_pk + (size_t)k * 4 * 1024, lane);
+          if (k & 1) ag_dense_std_k<MODE, 1, 4, 1, 0>(g, u, ag_wblock(a.prev.lin2a_pk, k * 4), lane);
+          else ag_dense_std_k<MODE, 1, 4, 0, 0>(g, u, ag_wblock(a.prev.lin2a_pk, k * 4), lane);
         } else {
-          if (k & 1) ag_dense_std_k<1, 4, 1, 4>(g, u, a.prev.lin2b_pk + (size_t)(k - 4) * 4 * 1024, lane);
-          else ag_dense_std_k<1, 4, 0, 4>(g, u, a.prev.lin2b_pk + (size_t)(k - 4) * 4 * 1024, lane);
+          if (k & 1) ag_dense_std_k<MODE, 1, 4, 1, 4>(g, u, ag_wblock(a.prev.lin2b_pk, (k - 4) * 4), lane);
+          else ag_dense_std_k<MODE, 1, 4, 0, 4>(g, u, ag_wblock(a.prev.lin2b_pk, (k - 4) * 4), lane);
         }
       }
     }
@@ -86,11 +85,19 @@ __global__ void __launch_bounds__(AG_WG, 2) k_schnet_node_stage(NodeStageArgs a)
     }
     f32x16 xc[4];
     ag_init_vec<4>(xc, a.prev.lin_b, h);
-    ag_dense_std<8, 4, 0, 0, 4>(u, xc, a.prev.lin_pk, lane);
+    {
+      AgIn<MODE> ub[8];
+      ag_cvt_tiles<MODE, 8, 0>(u, ub);
+      ag_dense_std<MODE, 8, 4, 0, 0, 4>(ub, xc, a.prev.lin_pk, lane);
+    }
     {
       f32x16 g1[2];
       ag_init_vec<2>(g1, a.prev.gate1_b, h);
-      ag_dense_std<4, 2, 0, 0, 4>(xc, g1, a.prev.gate1_pk, lane);
+      {
+        AgIn<MODE> xb[4];
+        ag_cvt_tiles<MODE, 4, 0>(xc, xb);
+        ag_dense_std<MODE, 4, 2, 0, 0, 4>(xb, g1, a.prev.gate1_pk, lane);
+      }
       AG_FOR_TILE(g1, 2, ag_relu(v));
       const float gate = ag_sigmoid(ag_dot_vec<2>(g1, a.prev.gate2_w, h) + a.prev.gate2_b);
       AG_FOR_TILE(xc, 4, v * gate);
@@ -99,13 +106,21 @@ __global__ void __launch_bounds__(AG_WG, 2) k_schnet_node_stage(NodeStageArgs a)
       f32x16 s1[1], s2[4];
 #pragma unroll
       for (int r = 0; r < 16; ++r) s1[0][r] = 0.0f;
-      ag_dense_std<4, 1, 0, 0, 4>(xc, s1, a.prev.scale1_pk, lane);
+      {
+        AgIn<MODE> xb[4];
+        ag_cvt_tiles<MODE, 4, 0>(xc, xb);
+        ag_dense_std<MODE, 4, 1, 0, 0, 4>(xb, s1, a.prev.scale1_pk, lane);
+      }
       AG_FOR_TILE(s1, 1, ag_relu(v));
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s2[t][r] = 0.0f;
-      ag_dense_std<1, 4, 0, 0, 1>(s1, s2, a.prev.scale2_pk, lane);
+      {
+        AgIn<MODE> sb[1];
+        ag_cvt_tiles<MODE, 1, 0>(s1, sb);
+        ag_dense_std<MODE, 1, 4, 0, 0, 1>(sb, s2, a.prev.scale2_pk, lane);
+      }
       ag_load_row<4, 0>(hv, a.h + (size_t)nd * 128, h);
 #pragma unroll
       for (int t = 0; t < 4; ++t)
@@ -117,7 +132,11 @@ __global__ void __launch_bounds__(AG_WG, 2) k_schnet_node_stage(NodeStageArgs a)
   if (a.prep) {
     f32x16 xo[6];
     ag_init_vec<6>(xo, a.next.lin1_b, h);
-    ag_dense_std<4, 6, 0, 0, 4>(hv, xo, a.next.lin1_pk, lane);
+    {
+      AgIn<MODE> hb[4];
+      ag_cvt_tiles<MODE, 4, 0>(hv, hb);
+      ag_dense_std<MODE, 4, 6, 0, 0, 4>(hb, xo, a.next.lin1_pk, lane);
+    }
     AG_FOR_TILE(xo, 6, ag_lrelu(v));
     if (valid) ag_store_row<6, 0>(xo, a.xs + (size_t)node * 192, h);
   }
@@ -139,6 +158,7 @@ struct GinArgs {
 
 // GINEConv + BN + relu + residual (gin.py:57-63, 131-138): m_i = sum relu(h_j + e_ji);
 // u = MLP(m_i + (1+eps) h_i); u = BN(u) (folded); relu except last layer; h = u + h.
+template <int MODE>
 __global__ void __launch_bounds__(AG_WG, 2) k_gin_layer(GinArgs a) {
   const int lane = ag_lane(), h = lane >> 5;
   const int64_t tile = (int64_t)blockIdx.x * 4 + ag_wave_in_wg();
@@ -168,7 +188,7 @@ __global__ void __launch_bounds__(AG_WG, 2) k_gin_layer(GinArgs a) {
       for (int rq = 0; rq < 4; ++rq) {
         const int f = 32 * t + 8 * rq + 4 * h;
         const f32x4 hvv = ag_ld4(hs + f);
-        const f32x4 ev = ag_ld4(a.l_attr + ag_frag_off_ef(eid, f));
+        const f32x4 ev = ag_attr_gather4<MODE>(a.l_attr, eid, f);
 #pragma unroll
         for (int q = 0; q < 4; ++q) m[t][4 * rq + q] += on ? ag_relu(hvv[q] + ev[q]) : 0.0f;
       }
@@ -184,10 +204,18 @@ __global__ void __launch_bounds__(AG_WG, 2) k_gin_layer(GinArgs a) {
   }
   f32x16 y1[4];
   ag_init_vec<4>(y1, a.gp.b1, h);
-  ag_dense_std<4, 4, 0, 0, 4>(m, y1, a.gp.w1_pk, lane);
+  {
+    AgIn<MODE> mb[4];
+    ag_cvt_tiles<MODE, 4, 0>(m, mb);
+    ag_dense_std<MODE, 4, 4, 0, 0, 4>(mb, y1, a.gp.w1_pk, lane);
+  }
   AG_FOR_TILE(y1, 4, ag_relu(v));
   ag_init_vec<4>(m, a.gp.b2, h);
-  ag_dense_std<4, 4, 0, 0, 4>(y1, m, a.gp.w2_pk, lane);
+  {
+    AgIn<MODE> yb[4];
+    ag_cvt_tiles<MODE, 4, 0>(y1, yb);
+    ag_dense_std<MODE, 4, 4, 0, 0, 4>(yb, m, a.gp.w2_pk, lane);
+  }
   if (a.gp.relu_out) { AG_FOR_TILE(m, 4, ag_relu(v)); }
 #pragma unroll
   for (int t = 0; t < 4; ++t)
@@ -340,7 +368,10 @@ extern "C" int agdiff_schnet_node_stage(const agdiff_params_t* p, const agdiff_t
   a.xs = ws->xs;
   a.n = topo->num_nodes;
   const int64_t tiles = (a.n + 31) / 32;
-  k_schnet_node_stage<<<dim3((unsigned)((tiles + 3) / 4)), dim3(AG_WG), 0, (hipStream_t)stream>>>(a);
+  if (p->precision == AG_BF3)
+    k_schnet_node_stage<AG_BF3><<<dim3((unsigned)((tiles + 3) / 4)), dim3(AG_WG), 0, (hipStream_t)stream>>>(a);
+  else
+    k_schnet_node_stage<AG_F32><<<dim3((unsigned)((tiles + 3) / 4)), dim3(AG_WG), 0, (hipStream_t)stream>>>(a);
   AG_CHECK_LAUNCH();
   return AGDIFF_OK;
 }
@@ -365,7 +396,10 @@ extern "C" int agdiff_gin_encoder(const agdiff_params_t* p, const agdiff_topo_t*
     a.h_in = in;
     a.h_out = bufs[cur];
     a.n = topo->num_nodes;
-    k_gin_layer<<<dim3((unsigned)((tiles + 3) / 4)), dim3(AG_WG), 0, (hipStream_t)stream>>>(a);
+    if (p->precision == AG_BF3)
+      k_gin_layer<AG_BF3><<<dim3((unsigned)((tiles + 3) / 4)), dim3(AG_WG), 0, (hipStream_t)stream>>>(a);
+    else
+      k_gin_layer<AG_F32><<<dim3((unsigned)((tiles + 3) / 4)), dim3(AG_WG), 0, (hipStream_t)stream>>>(a);
     AG_CHECK_LAUNCH();
     in = bufs[cur];
     cur ^= 1;

@@ -10,6 +10,7 @@ without a GPU and the built library raises.
 """
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -186,6 +187,9 @@ class DualEncoderEpsNetwork(nn.Module):
             self.num_timesteps = self.betas.size(0)
         else:
             raise NotImplementedError("model type %r: only 'diffusion' is on the HIP path" % (self.model_type,))
+        # arithmetic of the HIP kernels: "f32" = exact fp32 MFMA; "bf16x3" = split-bf16 MFMA (hi+lo operands,
+        # three passes, fp32 accumulation, ~2^-16 relative per product).  Both meet the 1e-4 parity bar.
+        self.precision = getattr(config, "precision", None) or os.environ.get("AGDIFF_PRECISION", "bf16x3")
         self._packed = None
         self._packed_key = None
         self._batch_cache = None
@@ -203,14 +207,14 @@ class DualEncoderEpsNetwork(nn.Module):
         return _lib.load()
 
     def _weights_key(self):
-        return (str(self._device()),) + tuple(int(p._version) for p in self.state_dict(keep_vars=True).values())
+        return (str(self._device()), self.precision) + tuple(int(p._version) for p in self.state_dict(keep_vars=True).values())
 
     def packed(self):
         """Packed device weights, rebuilt when any parameter / buffer changed (load_state_dict, .to)."""
         key = self._weights_key()
         if self._packed is None or self._packed_key != key:
             sd = {k: v for k, v in self.state_dict().items()}
-            self._packed = PackedParams(sd, self.config, self._device())
+            self._packed = PackedParams(sd, self.config, self._device(), self.precision)
             self._packed_key = key
         return self._packed
 

@@ -22,10 +22,47 @@ def _np(sd, key):
     return sd[key].detach().cpu().double().numpy()
 
 
-def pack_blocks(W, kouter=False):
+def bf16_round(x32):
+    """fp32 array -> (bf16 bits as uint16, the rounded value as fp32), round-to-nearest-even."""
+    u = np.ascontiguousarray(x32, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint32)
+    return r.astype(np.uint16), (r << 16).astype(np.uint32).view(np.float32)
+
+
+def pack_blocks_bf3(W, kouter=False):
+    """Split-bf16 packing (precision 1): block(mt, t)[s][part][lane][j], part 0 = hi = bf16(w), part 1 = lo =
+    bf16(w - hi), with w = W[32*mt + (lane & 31)][32*t + 16*s + 8*(j >> 2) + 4*(lane >> 5) + (j & 3)].
+    Same 4 KiB per block as the fp32 packing; returned as a float32 view of the bf16 bit patterns."""
+    W = np.asarray(W, dtype=np.float64)
+    out, inn = W.shape
+    MT, KT = (out + 31) // 32, (inn + 31) // 32
+    Wp = np.zeros((MT * 32, KT * 32), dtype=np.float32)
+    Wp[:out, :inn] = W.astype(np.float32)
+    lane = np.arange(64)
+    j = np.arange(8)
+    sidx = np.arange(2)
+    rows = (lane & 31)[None, :, None]                                                       # [1,64,1]
+    cols = (16 * sidx[:, None, None] + 8 * (j >> 2)[None, None, :] + 4 * (lane >> 5)[None, :, None]
+            + (j & 3)[None, None, :])                                                       # [2,64,8]
+    blocks = np.empty((MT, KT, 2, 2, 64, 8), dtype=np.uint16)
+    for mt in range(MT):
+        for t in range(KT):
+            w = Wp[32 * mt + rows, 32 * t + cols]                                           # [2,64,8] fp32
+            hb, hv = bf16_round(w)
+            lb, _ = bf16_round(w - hv)
+            blocks[mt, t, :, 0] = hb
+            blocks[mt, t, :, 1] = lb
+    if kouter:
+        blocks = blocks.transpose(1, 0, 2, 3, 4, 5)
+    return np.ascontiguousarray(blocks).reshape(-1).view(np.float32)
+
+
+def pack_blocks(W, kouter=False, mode=0):
     """Linear weight W[out, in] -> MFMA-fragment-major blocks (see include/agdiff_hip.h):
     block(mt, t)[rq][lane][q] = W[32*mt + (lane & 31)][32*t + 8*rq + 4*(lane >> 5) + q];
-    blocks ordered [MT][KT] ("pk") or [KT][MT] ("pkk")."""
+    blocks ordered [MT][KT] ("pk") or [KT][MT] ("pkk").  mode 1 -> pack_blocks_bf3."""
+    if mode == 1:
+        return pack_blocks_bf3(W, kouter)
     W = np.asarray(W, dtype=np.float64)
     out, inn = W.shape
     MT, KT = (out + 31) // 32, (inn + 31) // 32
@@ -51,12 +88,24 @@ def fold_bn(W, b, sd, p, eps=1e-5):
     return W * s[:, None], (b - _np(sd, p + ".running_mean")) * s + _np(sd, p + ".bias")
 
 
+PRECISIONS = {"f32": 0, "bf16x3": 1}
+
+
 class PackedParams:
     """Owns the device copies of all packed weights and the agdiff_params_t that points at them."""
 
-    def __init__(self, sd, cfg, device):
+    def __init__(self, sd, cfg, device, precision="f32"):
         import torch
         self.device = device
+        if precision not in PRECISIONS:
+            raise ValueError("precision must be one of %s" % (list(PRECISIONS),))
+        self.precision = precision
+        mode = PRECISIONS[precision]
+        _pack = globals()["pack_blocks"]
+
+        def pack_blocks(W, kouter=False):      # every matrix of this model is packed in the chosen mode
+            return _pack(W, kouter=kouter, mode=mode)
+
         if cfg.hidden_dim != H:
             raise NotImplementedError("hidden_dim must be 128 (InteractionBlock.lin is Linear(256, hidden), schnet.py:190)")
         if cfg.edge_encoder != "mlp":
@@ -91,8 +140,8 @@ class PackedParams:
             p = "encoder_global.interactions.%d" % k
             c1, c2_ = p + ".conv1", p + ".conv2"
             n = "conv%d." % k
-            arrays[n + "filt_w1_pk"] = pack_blocks(
-                np.concatenate([_np(sd, c1 + ".nn.0.weight"), _np(sd, c2_ + ".nn.0.weight")], 0), kouter=True)
+            arrays[n + "filt_w1a_pk"] = pack_blocks(_np(sd, c1 + ".nn.0.weight"), kouter=True)
+            arrays[n + "filt_w1b_pk"] = pack_blocks(_np(sd, c2_ + ".nn.0.weight"), kouter=True)
             arrays[n + "filt_b1"] = np.concatenate([_np(sd, c1 + ".nn.0.bias"), _np(sd, c2_ + ".nn.0.bias")])
             arrays[n + "filt_w2a_pk"] = pack_blocks(_np(sd, c1 + ".nn.2.weight"))
             arrays[n + "filt_w2b_pk"] = pack_blocks(_np(sd, c2_ + ".nn.2.weight"))
@@ -150,7 +199,10 @@ class PackedParams:
         # one flat device buffer, every section 256-byte aligned
         offs, total = {}, 0
         for k, v in arrays.items():
-            v = np.ascontiguousarray(np.asarray(v, dtype=np.float64).astype(np.float32).reshape(-1))
+            v = np.asarray(v)
+            if v.dtype != np.float32:          # packed matrices are float32 already (bf16 bit patterns in mode 1)
+                v = v.astype(np.float64).astype(np.float32)
+            v = np.ascontiguousarray(v.reshape(-1))
             arrays[k] = v
             offs[k] = total
             total += (v.size + 63) // 64 * 64
@@ -188,10 +240,12 @@ class PackedParams:
                 setattr(hp, f, P(n + f))
             hp.b3 = scalars[n + "b3"]
             hp.act = 0
+            hp.precision = mode
         prm.num_convs = cfg.num_convs
         prm.num_convs_local = cfg.num_convs_local
         prm.cutoff = float(cfg.cutoff)
         prm.smooth = 1 if cfg.smooth_conv else 0
+        prm.precision = mode
         self.struct = prm
 
     def view(self, name):

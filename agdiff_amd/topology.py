@@ -128,6 +128,7 @@ class Workspace:
         self.e_len = f32(etiles * 32)
         self.e_attr = f32(etiles * 32 * 128)
         self.e_inv_global = f32(etiles * 32)
+        self.e_scale = f32(2 * _lib.DEFINES["AGDIFF_MAX_CONVS"] * etiles * 32)
         self.l_len, self.l_inv = f32(ltiles * 32), f32(ltiles * 32)
         self.l_attr = f32(ltiles * 32 * 128)
         self.h, self.xs, self.agg = f32(N * 128), f32(N * 192), f32(N * 192)

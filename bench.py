@@ -31,7 +31,8 @@ sys.path.insert(0, ROOT)
 
 JOB_STEPS = 5000
 FLOP_PER_EDGE_CFCONV = 2 * (128 * 192 + 128 * 128 + 64 * 64)     # filter MLP of conv1+conv2, one block
-PEAK = {"f32": 157.3}                                              # dense MFMA TFLOP/s, MI355X_MICROARCH.md
+PEAK = {"f32": 157.3, "bf16x3": 2500.0}      # dense MFMA TFLOP/s (f32-input MFMA; bf16 MFMA), MI355X_MICROARCH.md
+MFMA_PASSES = {"f32": 1, "bf16x3": 3}        # MFMA FLOPs issued per algorithmic FLOP
 
 
 def build_batch(kind, mols, copies, seed):
@@ -103,6 +104,7 @@ def main():
     ap.add_argument("--no-traj", action="store_true")
     ap.add_argument("--breakdown", default=None, help="write per-op timings (ms) to this JSON file")
     ap.add_argument("--seed", type=int, default=2021)
+    ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"])
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -126,6 +128,7 @@ def main():
     cfg = make_cfg(kind, args.schedule)
     sd = O.synth_state_dict_for(cfg)
     model = get_model(cfg)
+    model.precision = args.precision
     model.load_state_dict({k: v.clone() for k, v in sd.items()})
     model = model.to(dev).eval()
 
@@ -203,8 +206,12 @@ def main():
         torch.cuda.synchronize()
         avg_ms = sum(a.elapsed_time(bb) for a, bb in evs) / len(evs)
         ach = E * FLOP_PER_EDGE_CFCONV / (avg_ms * 1e-3) / 1e12
-        roof = {"kernel": "k_cfconv_fused", "bound": "mfma", "achieved": ach, "peak": PEAK["f32"], "unit": "TFLOP/s",
-                "frac": ach / PEAK["f32"], "traffic": None, "avg_launch_ms": avg_ms, "edges_per_launch": E}
+        pk_ = PEAK[args.precision]
+        roof = {"kernel": "k_cfconv_fused", "bound": "mfma", "achieved": ach, "peak": pk_, "unit": "TFLOP/s",
+                "frac": ach / pk_, "traffic": None, "avg_launch_ms": avg_ms, "edges_per_launch": E,
+                "mfma_issued_tflops": ach * MFMA_PASSES[args.precision],
+                "note": "achieved = algorithmic FLOPs (E x 90,112) / launch time; bf16x3 issues 3 bf16 MFMA "
+                        "FLOPs per algorithmic FLOP (hi.hi + lo.hi + hi.lo), fp32 accumulate"}
 
     if args.breakdown and rank == 0:
         ops = {}
@@ -240,7 +247,7 @@ def main():
             "metric": "conformers/sec (whole node), GEOM-Drugs 5000-step sampling",
             "value": value, "unit": "conformers/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "%s-shaped synthetic molecules: %d molecules x %d conformers per GPU "
                                    "(%d atoms, %d edges, %d local edges per GPU), %s schedule, "
                                    "global branch active on %.0f%% of timed steps, %d-step job"

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 3
+#define AGDIFF_ABI_VERSION 5
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -49,7 +49,8 @@ enum agdiff_status {
  * natural feature order. */
 typedef struct agdiff_conv_params {
   /* CFConv filter networks of one InteractionBlock (schnet.py:169-186), conv1 (F=128) and conv2 (F=64) fused */
-  const float* filt_w1_pk;   /* pkk [4][6]: rows 0..127 conv1.nn.0, 128..191 conv2.nn.0 */
+  const float* filt_w1a_pk;  /* pkk [4][4]: conv1.nn.0 (128 -> 128) */
+  const float* filt_w1b_pk;  /* pkk [4][2]: conv2.nn.0 (128 -> 64) */
   const float* filt_b1;      /* [192] */
   const float* filt_w2a_pk;  /* [4][4]: conv1.nn.2 */
   const float* filt_w2b_pk;  /* [2][2]: conv2.nn.2 */
@@ -91,6 +92,8 @@ typedef struct agdiff_head_params {
   const float* w3;           /* [64]  layers.2 */
   float b3;
   int32_t act;               /* 0 relu (configs: mlp_act relu) */
+  int32_t precision;         /* as agdiff_params_t.precision */
+  int32_t pad0;
 } agdiff_head_params_t;
 
 typedef struct agdiff_params {
@@ -114,6 +117,9 @@ typedef struct agdiff_params {
   int32_t num_convs_local;
   float cutoff;
   int32_t smooth;            /* config.smooth_conv */
+  int32_t precision;         /* 0: exact fp32 MFMA; 1: split-bf16 (hi+lo, 3 MFMA passes, fp32 accumulate) -- selects
+                                both the kernels and the layout of every packed matrix and of e_attr / l_attr */
+  int32_t pad0;
 } agdiff_params_t;
 
 /* ---- static topology of one packed batch (host builds it once per batch) ---------------------
@@ -152,6 +158,7 @@ typedef struct agdiff_ws {
   int32_t* ref2dst;          /* [max_edges]: reference position q -> destination-sorted id */
   float*   e_attr;           /* [ceil(max_edges/32)][4][4][64][4] edge_attr, fragment-major */
   float*   e_inv_global;     /* [max_edges] grad_global_dist_mlp output, destination-sorted */
+  float*   e_scale;          /* [2*num_convs][ceil(max_edges/32)*32]: lw(d)*C(d) of conv1 / conv2 of every block (schnet.py:138-149) */
   /* local edges (reference order) */
   float*   l_len;            /* [L] */
   float*   l_attr;           /* [ceil(L/32)] tiles, fragment-major */
@@ -195,6 +202,10 @@ int agdiff_graph_build(const agdiff_topo_t* topo, const agdiff_ws_t* ws, const f
 
 /* get_distance on the static local edges (geometry.py:5-6 applied to edge_index[:, local_edge_mask]). */
 int agdiff_local_lengths(const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, void* stream);
+
+/* DistanceWeightingNetwork x cutoff envelope of all 2*num_convs CFConvs (encoder/schnet.py:83-100, 138-149):
+ * ws->e_scale from ws->e_len. */
+int agdiff_edge_scales(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, void* stream);
 
 /* MLPEdgeEncoder.forward (encoder/edge.py:84-103).  n_edges_dev: device scalar with the live edge
  * count (<= max_tiles*32); writes fragment-major edge_attr tiles. */

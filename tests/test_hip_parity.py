@@ -13,19 +13,30 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-def _gpu_model(cfg, head_scale=1e-3):
+PRECISIONS = ["f32", "bf16x3"]
+
+
+def _gpu_model(cfg, head_scale=1e-3, precision="bf16x3"):
     from agdiff_amd import get_model
     from oracle import agdiff_oracle as O
     sd = O.synth_state_dict_for(cfg, head_scale=head_scale)
     m = get_model(cfg)
+    m.precision = precision
     m.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
     return m.to("cuda:0").eval(), sd
 
 
-def unfrag(frag, n):
-    """fragment-major [tiles][4][4][64][4] -> row-major [n][128] (include/agdiff_hip.h: e_attr)."""
+def unfrag(frag, n, precision):
+    """operand-form edge-attr tiles -> row-major [n][128] fp32 (csrc/common.hpp: edge-attr storage)."""
     tiles = frag.numel() // (32 * 128)
-    x = frag.view(tiles, 4, 4, 2, 32, 4).permute(0, 4, 1, 2, 3, 5).reshape(tiles * 32, 128)
+    if precision == "f32":      # [tile][t][rq][h][edge][q], feature = 32t + 8rq + 4h + q
+        x = frag.view(tiles, 4, 4, 2, 32, 4).permute(0, 4, 1, 2, 3, 5).reshape(tiles * 32, 128)
+        return x[:n]
+    # bf16x3: [tile][t][s][part][h][edge][jq][q] bf16, feature = 32t + 16s + 8jq + 4h + q, value = hi + lo
+    u = frag.view(torch.int16).view(tiles, 4, 2, 2, 2, 32, 2, 4).to(torch.int32)
+    val = ((u & 0xFFFF) << 16).view(torch.float32)
+    val = val[:, :, :, 0] + val[:, :, :, 1]                     # [tile][t][s][h][edge][jq][q]
+    x = val.permute(0, 4, 1, 2, 5, 3, 6).reshape(tiles * 32, 128)
     return x[:n]
 
 
@@ -85,19 +96,20 @@ def test_graph_build_bit_exact(case):
     assert np.all(np.diff(src)[same] > 0)
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("case", ["g3_forward_qm9_small", "g3_forward_smooth_sparse"])
-def test_edge_encoder_and_stages(case):
+def test_edge_encoder_and_stages(case, precision):
     from agdiff_amd import _lib
     g = load_golden(case)
     cfg = FORWARD_CASES[case]()
-    m, sd = _gpu_model(cfg)
+    m, sd = _gpu_model(cfg, precision=precision)
     out = m(t(g["atom_type"]).cuda(), t(g["pos"]).cuda(), t(g["bond_index"]).cuda(), t(g["bond_type"]).cuda(),
             t(g["batch"]).cuda(), None, return_edges=True, extend_order=False)
     torch.cuda.synchronize()
     topo, ws = m._batch_cache[1], m._batch_cache[2]
     E = int(ws.num_edges.item())
     perm = ws.ref2dst[:E].long()
-    ea = unfrag(ws.e_attr, E)[perm].cpu().numpy()
+    ea = unfrag(ws.e_attr, E, precision)[perm].cpu().numpy()
     assert rel_err(ea, g["edge_attr"]) < TOL
     assert rel_err(ws.h.view(-1, 128).cpu().numpy(), g["schnet_out"]) < TOL
     assert rel_err(ws.hl.view(-1, 128).cpu().numpy(), g["gin_out"]) < TOL
@@ -105,11 +117,12 @@ def test_edge_encoder_and_stages(case):
     assert rel_err(m.encoder_global.embedding.weight[:20].detach().cpu().numpy(), g["emb_rows_after"]) < 1e-6
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("case", list(FORWARD_CASES))
-def test_forward_matches_reference_golden(case):
+def test_forward_matches_reference_golden(case, precision):
     g = load_golden(case)
     cfg = FORWARD_CASES[case]()
-    m, sd = _gpu_model(cfg)
+    m, sd = _gpu_model(cfg, precision=precision)
     out = m(t(g["atom_type"]).cuda(), t(g["pos"]).cuda(), t(g["bond_index"]).cuda(), t(g["bond_type"]).cuda(),
             t(g["batch"]).cuda(), None, return_edges=True, extend_order=False)
     inv_g, inv_l, ei, et, elen, lm = [o.cpu().numpy() for o in out]
@@ -126,11 +139,12 @@ def test_forward_matches_reference_golden(case):
     assert len(two) == 2 and np.array_equal(two[0].cpu().numpy(), inv_g)
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("case", ["g5_sampler_top", "g5_sampler_lowT_global", "g5_sampler_mixed_cliplocal"])
-def test_sampler_matches_reference_golden(case):
+def test_sampler_matches_reference_golden(case, precision):
     g = load_golden(case)
     cfg = sampler_case_cfg(g)
-    m, sd = _gpu_model(cfg, head_scale=float(g["head_scale"]))
+    m, sd = _gpu_model(cfg, head_scale=float(g["head_scale"]), precision=precision)
     kw = sampler_case_kwargs(g)
     pos, traj = m.langevin_dynamics_sample_diffusion(
         t(g["atom_type"]).cuda(), t(g["pos_init"]).cuda(), t(g["bond_index"]).cuda(), t(g["bond_type"]).cuda(),
