@@ -121,6 +121,19 @@ struct ConvArgs {
                          // bit2 skip layer 2, bit3 skip x gather, bit4 skip reduction
 };
 
+#ifdef AG_CONV_STAMPS
+// Diagnostic build only (make STAMPS=1): per-phase wave cycles of k_cfconv_fused, summed over waves.
+__device__ unsigned long long ag_conv_stamp_acc[8];
+#define AG_STAMP(var)                                  \
+  do {                                                 \
+    __builtin_amdgcn_sched_barrier(0);                 \
+    var = __builtin_readcyclecounter();                \
+    __builtin_amdgcn_sched_barrier(0);                 \
+  } while (0)
+#else
+#define AG_STAMP(var) do { } while (0)
+#endif
+
 #define AG_CONV_WAVES 8
 #define AG_CONV_LDS_BLOCKS 36   // resident 4-KiB weight blocks: filt_w1a (16) | filt_w2a (16) | filt_w2b (4)
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
@@ -155,6 +168,7 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
   // running sums (6 channel tiles x 64 lanes) of target run_t, whose list is still open
   float* carry = reinterpret_cast<float*>(ag_conv_smem + AG_CONV_LDS_BLOCKS * 256) + wave * (6 * 64);
   const int64_t cstride = (int64_t)gridDim.x * AG_CONV_WAVES;
+  [[maybe_unused]] unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c0 = 0, c1 = 0;
 
   for (int64_t chunk = (int64_t)blockIdx.x * AG_CONV_WAVES + wave; chunk < a.max_chunks; chunk += cstride) {
     const int64_t e_begin = chunk * (32 * AGDIFF_CHUNK_TILES);
@@ -172,6 +186,7 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
       if (tbase >= E) break;
       // opaque copy of the lane id: keeps hipcc from hoisting every lane-derived weight / table address
       // out of the tile loop (they would stay live across the whole body and spill)
+      AG_STAMP(c0);
       int lane = lane0;
       asm volatile("" : "+v"(lane));
       const int h = lane >> 5, col = lane & 31;
@@ -194,6 +209,7 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
       }
       const bool cont = (run_t == t0);
 
+      AG_STAMP(c1); st[0] += c1 - c0; c0 = c1;       // meta loads, carry flush
       AgIn<MODE> hidb[6];
       {
         f32x16 hid[6];
@@ -240,6 +256,7 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
             }
           }
         }
+        AG_STAMP(c1); st[1] += c1 - c0; c0 = c1;     // layer 1
         // ssp, then fold the per-edge scale lw(d)*C(d) (a per-lane scalar here) into the hidden layer:
         // (s.H)^T W2 + s.b2 == s.(H^T W2 + b2)
 #pragma unroll
@@ -253,6 +270,7 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
         }
         ag_cvt_tiles<MODE, 6, 0>(hid, hidb);
       }
+      AG_STAMP(c1); st[2] += c1 - c0; c0 = c1;       // ssp + split
       // gather row of every edge slot my half owns: slot (r,h) lives in lane ag_row(r,h)
       uint32_t xoff[16];
 #pragma unroll
@@ -304,6 +322,7 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
         carry[nt * 64 + lane] = newcarry;
       };
       fetch_x(0);
+      AG_STAMP(c1); st[3] += c1 - c0; c0 = c1;       // gather offsets, bounds
       // the bias enters as one extra k-step (ag_rank1): A = s_e on k-slot 0, B = b2 on k-slot 0
 #pragma unroll 1
       for (int nt = 0; nt < 4; ++nt) {
@@ -313,7 +332,9 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
         for (int r = 0; r < 16; ++r) z[0][r] = 0.0f;
         ag_rank1(z[0], s1, bb, h, (AgIn<MODE>*)nullptr);
         if (!(a.ablate & 4)) ag_dense_flip_lds<MODE, 4, 1, 0, 0>(hidb, z, w2 + (nt * 4) * 256, lane);
+        AG_STAMP(c1); st[4] += c1 - c0; c0 = c1;     // layer 2
         channel_tile(z, nt);
+        AG_STAMP(c1); st[5] += c1 - c0; c0 = c1;     // message + reduction
       }
 #pragma unroll 1
       for (int nt = 4; nt < 6; ++nt) {
@@ -323,7 +344,9 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
         for (int r = 0; r < 16; ++r) z[0][r] = 0.0f;
         ag_rank1(z[0], s2, bb, h, (AgIn<MODE>*)nullptr);
         if (!(a.ablate & 4)) ag_dense_flip_lds<MODE, 2, 1, 4, 0>(hidb, z, w2 + (16 + (nt - 4) * 2) * 256, lane);
+        AG_STAMP(c1); st[4] += c1 - c0; c0 = c1;
         channel_tile(z, nt);
+        AG_STAMP(c1); st[5] += c1 - c0; c0 = c1;
       }
       run_t = t1;
     }
@@ -335,6 +358,12 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
       }
     }
   }  // chunk loop
+#ifdef AG_CONV_STAMPS
+  if (lane0 == 0) {
+    for (int i = 0; i < 6; ++i) atomicAdd(&ag_conv_stamp_acc[i], st[i]);
+    atomicAdd(&ag_conv_stamp_acc[7], 1ull);
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------ pair head
@@ -433,6 +462,17 @@ __global__ void __launch_bounds__(AG_WG) k_cfconv_aggregate(const float* __restr
 }
 
 }  // namespace
+
+#ifdef AG_CONV_STAMPS
+extern "C" int agdiff_debug_conv_stamps(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ag_conv_stamp_acc), sizeof(ag_conv_stamp_acc)) != hipSuccess) return AGDIFF_ERR_LAUNCH;
+  if (reset) {
+    unsigned long long z[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(ag_conv_stamp_acc), z, sizeof(z)) != hipSuccess) return AGDIFF_ERR_LAUNCH;
+  }
+  return AGDIFF_OK;
+}
+#endif
 
 extern "C" int agdiff_edge_encoder(const agdiff_params_t* p, const int32_t* n_edges_dev, int64_t max_tiles,
                                    const float* e_len, const int32_t* e_type, float* attr_frag, void* stream) {

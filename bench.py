@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--breakdown", default=None, help="write per-op timings (ms) to this JSON file")
     ap.add_argument("--seed", type=int, default=2021)
     ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"])
+    ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL all-gather path even with one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -116,8 +117,10 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from agdiff_amd import _lib, get_model
@@ -150,7 +153,7 @@ def main():
         idx = list(reversed(range(Tn - (W + K), Tn)))
     on_step = None
     gather = None
-    if world > 1:
+    if use_dist:
         from agdiff_amd.dist import StepAllGather
         gather = StepAllGather(at.shape[0], dev)
     run = model.begin_sampling(at, pos_init, bi, bt, ba, G, False, n_steps=W + K, step_lr=1e-6, clip=1000.0,
@@ -162,7 +165,7 @@ def main():
 
     run.advance(W)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     g0 = run.global_steps
@@ -171,12 +174,12 @@ def main():
     if gather is not None:
         gather.wait()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     global_frac = (run.global_steps - g0) / max(K, 1)
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
@@ -242,6 +245,12 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(kind, args.schedule, args.seed)
 
+    if gather is not None:
+        parts, any_nan = gather.result()
+        assert len(parts) == world and parts[rank].shape[0] == at.shape[0] and not any_nan
+        assert torch.equal(parts[rank], run.pos), "all-gathered shard differs from the local positions"
+    if use_dist:
+        dist.destroy_process_group()
     if rank == 0:
         out = {
             "metric": "conformers/sec (whole node), GEOM-Drugs 5000-step sampling",
@@ -253,13 +262,12 @@ def main():
                                    "global branch active on %.0f%% of timed steps, %d-step job"
                                    % (kind, mols, copies, topo.N, E, topo.L, args.schedule, 100 * global_frac, JOB_STEPS),
                        "conformers_total": G_total, "parallelism": "dp%d" % world,
-                       "all_gather_per_step": world > 1, "trajectory_saved": not args.no_traj,
+                       "all_gather_per_step": use_dist, "trajectory_saved": not args.no_traj,
                        "skip_discarded_global": not args.no_skip},
             "roofline": roof, "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)     # last line of stdout (RCCL prints its banner earlier)
 
 
 if __name__ == "__main__":

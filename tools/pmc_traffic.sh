@@ -1,0 +1,25 @@
+#!/bin/bash
+# HBM traffic of the dominant kernel (MI355X_MICROARCH.md §HBM: separate --pmc passes; FETCH_SIZE x2 on gfx950 for
+# wide coalesced reads; both counters are in KiB).  Usage: bash tools/pmc_traffic.sh <outdir>
+out=${1:-gpurun_out/pmc_traffic}
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-traj > /dev/null 2>&1
+done
+python3 - <<PY
+import csv, glob, collections
+res = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob("$GRAFT_REPO_ROOT/$out/%s/*/*counter_collection.csv" % c)[0]
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == c:
+            for k in ("k_cfconv_fused", "k_edge_encoder", "k_pair_head", "k_gin_layer", "k_schnet_node_stage"):
+                if k in r["Kernel_Name"]:
+                    agg[k].append(float(r["Counter_Value"]))
+    res[c] = {k: sum(v) / len(v) for k, v in agg.items()}
+for k in res["FETCH_SIZE"]:
+    fk, wk = res["FETCH_SIZE"][k], res["WRITE_SIZE"].get(k, 0)
+    print("%-22s FETCH_SIZE %10.0f KiB (x2 = %8.1f MB)  WRITE_SIZE %10.0f KiB (%7.1f MB)" % (k, fk, 2 * fk * 1024 / 1e6, wk, wk * 1024 / 1e6))
+PY
