@@ -117,6 +117,7 @@ struct ConvArgs {
   float* agg;            // [N][192]
   float* agg_first;      // [chunks][192]
   int64_t max_chunks;
+  int32_t stagger;       // s_sleep units (64 cycles) the second wave of each SIMD waits before its first tile
   int32_t ablate;        // timing experiments only (AGDIFF_ABLATE env): bit0 skip layer 1, bit1 skip ssp,
                          // bit2 skip layer 2, bit3 skip x gather, bit4 skip reduction
 };
@@ -169,6 +170,12 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
   float* carry = reinterpret_cast<float*>(ag_conv_smem + AG_CONV_LDS_BLOCKS * 256) + wave * (6 * 64);
   const int64_t cstride = (int64_t)gridDim.x * AG_CONV_WAVES;
   [[maybe_unused]] unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c0 = 0, c1 = 0;
+  // The two waves that share a SIMD run the same program; started together they reach their MFMA
+  // phases together and their VALU phases together.  Delaying waves 4..7 once, by a fraction of a
+  // tile, lets one wave's MFMAs run beside the other's VALU work.
+  if (__builtin_amdgcn_readfirstlane(wave) >= 4) {
+    for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+  }
 
   for (int64_t chunk = (int64_t)blockIdx.x * AG_CONV_WAVES + wave; chunk < a.max_chunks; chunk += cstride) {
     const int64_t e_begin = chunk * (32 * AGDIFF_CHUNK_TILES);
@@ -539,6 +546,12 @@ extern "C" int agdiff_cfconv_fused(const agdiff_params_t* p, const agdiff_topo_t
       abl = e ? atoi(e) : 0;
     }
     a.ablate = abl;
+    static int stg = -1;
+    if (stg < 0) {
+      const char* e = getenv("AGDIFF_STAGGER");
+      stg = e ? atoi(e) : 0;
+    }
+    a.stagger = stg;
   }
   // persistent launch: one 8-wave workgroup per CU keeps 144 KiB of filter weights in LDS
   int64_t wgs = (max_chunks + AG_CONV_WAVES - 1) / AG_CONV_WAVES;

@@ -120,26 +120,22 @@ def test_bn_fold_equals_eval_batchnorm():
     assert rel_err(got, ref.numpy()) < 1e-6
 
 
-def test_erf_polynomial_mirror():
-    """numpy mirror of ag_erf (csrc/common.hpp) against scipy: < 1 ulp-ish absolute error."""
-    from scipy.special import erf
+def test_gelu_polynomial_mirror():
+    """numpy mirror of ag_gelu (csrc/common.hpp: one-range erfc fit) against torch's erf-form gelu."""
     f = np.float32
-    a = np.linspace(-6, 6, 200001).astype(np.float32)
-    tt = np.abs(a); s = a * a
-    fma = lambda x, y, z: (x.astype(np.float64) * y.astype(np.float64) + z.astype(np.float64)).astype(np.float32)
-    c = lambda v: np.full_like(a, v)
-    r = fma(c(-1.72853470e-5), tt, c(3.83197126e-4)); u = fma(c(-3.88396438e-3), tt, c(2.42546219e-2))
-    r = fma(r, s, u)
-    for k in (-1.06777877e-1, -6.34846687e-1, -1.28717512e-1):
-        r = fma(r, tt, c(k))
-    r = fma(r, tt, -tt)
-    big = np.copysign(f(1.0) - np.exp(r.astype(np.float64)).astype(np.float32), a)
-    q = c(-5.96761703e-4)
-    for k in (4.99119423e-3, -2.67681349e-2, 1.12819925e-1, -3.76125336e-1, 1.28379166e-1):
-        q = fma(q, s, c(k))
-    small = fma(q, a, a)
-    got = np.where(tt > f(0.927734375), big, small)
-    assert np.abs(got.astype(np.float64) - erf(a.astype(np.float64))).max() < 1.2e-7
+    cp = [f(c) for c in (-1.627908587e+00, -9.184163809e-01, -1.484816372e-01, 2.825373970e-02, -7.746984484e-04,
+                         -1.489399001e-03, 4.454943992e-04, -4.535698463e-05)]
+    x = np.concatenate([np.linspace(-12, 12, 400001), np.random.default_rng(0).standard_normal(50000) * 3]).astype(f)
+    tt = np.minimum(np.abs(x) * f(0.70710678118654752440), f(4.1))
+    p = np.full_like(tt, cp[7])
+    for k in range(6, -1, -1):
+        p = (p.astype(np.float64) * tt + cp[k]).astype(f)
+    p = (p.astype(np.float64) * tt - 1.0).astype(f)
+    q = np.exp2(p.astype(np.float64)).astype(f)
+    got = (x * np.where(x >= 0, f(1.0) - q, q)).astype(np.float64)
+    ref = torch.nn.functional.gelu(torch.from_numpy(x).double()).numpy()
+    err = np.abs(got - ref)
+    assert err.max() < 6e-7 and (err / np.maximum(np.abs(x), 1e-3)).max() < 2e-7
 
 
 def test_topology_matches_reference_local_edges():
