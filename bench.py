@@ -216,6 +216,30 @@ def main():
                 "note": "achieved = algorithmic FLOPs (E x 90,112) / launch time; bf16x3 issues 3 bf16 MFMA "
                         "FLOPs per algorithmic FLOP (hi.hi + lo.hi + hi.lo), fp32 accumulate"}
 
+    # ---- stand-alone CFConv aggregate (PyG propagate x_j * W, schnet.py:156-162) on the same graph: the HBM-bound
+    # "scatter" kernel BASELINE.json's north_star prices against the HBM roofline (unfused form: W[E,F] streamed)
+    agg_roof = None
+    if E > 0 and rank == 0:
+        F = 128
+        Wt = torch.randn(E, F, device=dev)
+        xin = torch.randn(topo.N, F, device=dev)
+        outt = torch.empty(topo.N, F, device=dev)
+        call = lambda: lib.agdiff_cfconv_aggregate(_lib.ptr(xin), _lib.ptr(Wt), _lib.ptr(ws.in_ptr), _lib.ptr(ws.e_src),
+                                                   topo.N, F, _lib.ptr(outt), stream)
+        call()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        nbytes = E * F * 4 + E * 4 + (topo.N + 1) * 4 + 2 * topo.N * F * 4      # fp32 516 B/edge + 1,028 B/node
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        agg_roof = {"kernel": "k_cfconv_aggregate<128>", "bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s",
+                    "frac": gbs / 8000.0, "traffic": None, "avg_launch_ms": ms, "algorithmic_bytes": nbytes}
+        del Wt, xin, outt
+
     if args.breakdown and rank == 0:
         ops = {}
 
@@ -264,7 +288,7 @@ def main():
                        "conformers_total": G_total, "parallelism": "dp%d" % world,
                        "all_gather_per_step": use_dist, "trajectory_saved": not args.no_traj,
                        "skip_discarded_global": not args.no_skip},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_cfconv_aggregate": agg_roof, "cpu_baseline": cpu,
         }
         sys.stdout.flush()
         print(json.dumps(out), flush=True)     # last line of stdout (RCCL prints its banner earlier)
