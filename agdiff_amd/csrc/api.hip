@@ -25,7 +25,7 @@ extern "C" int agdiff_struct_sizes(int64_t* out) {
 extern "C" int agdiff_score_forward(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
                                     const float* pos, int32_t with_global, void* stream) {
   if (!p || !topo || !ws || !pos) return AGDIFF_ERR_ARG;
-  const int64_t ltiles = (topo->num_local + 31) / 32;
+  const int64_t ltiles = (topo->num_local + AG_TW - 1) / AG_TW;
   // local branch: lengths -> edge encoder -> GIN -> local head   (dualenc.py:214-239)
   AG_TRY(agdiff_local_lengths(topo, ws, pos, stream));
   if (topo->num_local > 0) {
@@ -38,7 +38,7 @@ extern "C" int agdiff_score_forward(const agdiff_params_t* p, const agdiff_topo_
   }
   if (!with_global) return AGDIFF_OK;
   // global branch: radius graph -> edge encoder -> SchNet -> global head   (dualenc.py:167-211)
-  const int64_t etiles = (topo->max_edges + 31) / 32;
+  const int64_t etiles = (topo->max_edges + AG_TW - 1) / AG_TW;
   AG_TRY(agdiff_graph_build(topo, ws, pos, p->cutoff, stream));
   AG_TRY(agdiff_edge_scales(p, topo, ws, stream));
   AG_TRY(agdiff_edge_encoder(p, ws->num_edges, etiles, ws->e_len, ws->e_type, ws->e_attr, stream));

@@ -1,46 +1,45 @@
 // Device-side building blocks shared by all kernels (gfx950 / CDNA4 only).
 //
-// Register-resident MLP chains on v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fmaf chain):
-// a wave owns one tile of 32 edges (or nodes).  An activation vector of 32*KT features is kept
-// as KT accumulator tiles `f32x16 x[KT]` in the MFMA C/D layout:
-//     lane l  <->  edge  (l & 31),  half h = l >> 5
-//     x[t][r] <->  feature 32*t + (r&3) + 8*(r>>2) + 4*h
-// With weights pre-packed in the matching k-order ("pk", include/agdiff_hip.h) the accumulator
-// of one layer IS the B operand of the next one: no LDS, no shuffles between layers.
+// Register-resident MLP chains on 16x16 MFMA tiles: a wave owns one tile of AG_TW = 16 edges (or
+// nodes).  A 16-feature slice of an activation is one accumulator tile `f32x4` in the MFMA C/D layout
+//     lane l  <->  edge (l & 15),  quarter q = l >> 4
+//     y[r]    <->  feature 16*T + 4*q + r
+// so a 128-feature activation is 32 VGPRs per lane and a whole filter / encoder chain fits in <= 128
+// VGPRs: four waves per SIMD instead of the two a 32-edge tile allows, which is what lets one wave's
+// MFMAs run beside another wave's VALU work and hides LDS / L2 latency.
+// With weights pre-packed in the matching k-order ("pk", include/agdiff_hip.h) the accumulator of one
+// layer IS the operand of the next one: no LDS, no shuffles between layers.
 //   std  orientation: D[feature][edge] = W . X      (A = weights, B = activations)
 //   flip orientation: D[edge][feature] = X^T . W^T  (A = activations, B = weights)
-// The flipped result has edges on rows (registers) and features on lanes, which is what the
+// The flipped result has edges on rows (registers x quarters) and features on lanes, which is what the
 // destination-segmented reduction and coalesced row gathers want.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "agdiff_hip.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 
 #define AG_WAVE 64
-#define AG_WG 256  // 4 waves per workgroup, each wave an independent tile
+#define AG_WG 256                 // 4 waves per workgroup for the non-persistent kernels
+#define AG_TW AGDIFF_TILE         // 16 edges / nodes per tile
 
 __device__ __forceinline__ int ag_lane() { return threadIdx.x & 63; }
 __device__ __forceinline__ int ag_wave_in_wg() { return threadIdx.x >> 6; }
-
-// Row (edge slot) held in register r by lane half h of a flipped tile; also the feature offset
-// inside a std tile.
-__device__ __forceinline__ constexpr int ag_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 __device__ __forceinline__ f32x4 ag_ld4(const float* __restrict__ p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void ag_st4(float* __restrict__ p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
 // ---------------------------------------------------------------------------------- math
-// Per-element activations run 64..96 times per lane per layer, fully unrolled, so they are kept
-// branch-free and short: v_exp_f32 / v_log_f32 / v_rcp_f32 based (<= ~1e-6 relative).
-// raw v_exp_f32 / v_log_f32 (base 2, ~1 ulp, no denormal fix-up code): arguments are clamped by the
-// callers so that neither overflows; results below 2^-126 flush to zero, which every caller tolerates
-// (they are added to 1 or subtracted from 1).
+// Per-element activations run 32..48 times per lane per layer, fully unrolled, so they are kept
+// branch-free and short: raw v_exp_f32 / v_log_f32 / v_rcp_f32 (base 2, ~1 ulp, no denormal fix-up
+// code).  Arguments are clamped by the callers so that nothing overflows; results below 2^-126 flush
+// to zero, which every caller tolerates (they are added to 1 or subtracted from 1).
 __device__ __forceinline__ float ag_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float ag_log2(float x) { return __builtin_amdgcn_logf(x); }
-__device__ __forceinline__ float ag_exp(float x) { return ag_exp2(fmaxf(x, -125.0f * 0.69314718f) * 1.44269504088896340736f); }
 __device__ __forceinline__ float ag_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // torch F.gelu (erf form, edge.py:59,68,86): gelu(x) = x * Phi(x), Phi(x) = erfc(-x/sqrt2)/2.
@@ -76,374 +75,210 @@ __device__ __forceinline__ float ag_sigmoid(float x) {
 __device__ __forceinline__ float ag_relu(float x) { return x > 0.0f ? x : 0.0f; }
 __device__ __forceinline__ float ag_lrelu(float x) { return x > 0.0f ? x : 0.2f * x; }
 
-// ---------------------------------------------------------------------------------- tiles
-// Fill std-orientation tiles from a natural-order vector (bias init): y[t][r] = v[32t + row(r,h)].
-template <int MT>
-__device__ __forceinline__ void ag_init_vec(f32x16 (&y)[MT], const float* __restrict__ v, int h) {
+// ---------------------------------------------------------------------------------- fp32 tiles
+// Fill std-orientation tiles from a natural-order vector (bias init): y[T][r] = v[16T + 4q + r].
+template <int NT, int NY>
+__device__ __forceinline__ void ag_init_vec(f32x4 (&y)[NY], const float* __restrict__ v, int q) {
 #pragma unroll
-  for (int t = 0; t < MT; ++t)
+  for (int t = 0; t < NT; ++t) y[t] = ag_ld4(v + 16 * t + 4 * q);
+}
+// Row-major row (natural feature order) <-> std tiles T0 .. T0+NT-1.
+template <int NT, int T0, int NY>
+__device__ __forceinline__ void ag_load_row(f32x4 (&y)[NY], const float* __restrict__ row, int q) {
 #pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-      f32x4 b = ag_ld4(v + 32 * t + 8 * rq + 4 * h);
+  for (int t = 0; t < NT; ++t) y[T0 + t] = ag_ld4(row + 16 * t + 4 * q);
+}
+template <int NT, int T0, int NY>
+__device__ __forceinline__ void ag_store_row(const f32x4 (&y)[NY], float* __restrict__ row, int q) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) y[t][4 * rq + q] = b[q];
+  for (int t = 0; t < NT; ++t) ag_st4(row + 16 * t + 4 * q, y[T0 + t]);
+}
+// sum_f w[f] * y[f] over the first NT tiles for the lane's edge (all four quarters hold the total)
+template <int NT, int NY>
+__device__ __forceinline__ float ag_dot_vec(const f32x4 (&y)[NY], const float* __restrict__ w, int q) {
+  float s = 0.0f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const f32x4 b = ag_ld4(w + 16 * t + 4 * q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s = fmaf(b[r], y[t][r], s);
+  }
+  s += __shfl_xor(s, 16);
+  s += __shfl_xor(s, 32);
+  return s;
+}
+#define AG_FOR_TILE(y, NT, expr)                       \
+  _Pragma("unroll") for (int _t = 0; _t < (NT); ++_t)  \
+  _Pragma("unroll") for (int _r = 0; _r < 4; ++_r) { float v = (y)[_t][_r]; (y)[_t][_r] = (expr); }
+
+// ---------------------------------------------------------------------------------- MFMA operands
+// Two arithmetic modes share every kernel (template parameter MODE):
+//   AG_F32: v_mfma_f32_16x16x4_f32, exact fp32 (k-ordered fmaf chain).
+//   AG_BF3: "split bf16": every fp32 operand is hi + lo with hi = bf16(x), lo = bf16(x - hi); a product is
+//           hi.hi + lo.hi + hi.lo on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (~2^-16 relative per
+//           product; the dropped term is lo.lo).
+// The unit of input is a "k-tile" of 32 features = two consecutive accumulator tiles (2m, 2m+1):
+//   AG_F32: the two f32x4 as they are; MFMA (u, r) contracts feature 32m + 16u + 4q + r over the quarters q
+//   AG_BF3: one bf16x8 (hi) + one (lo); element j <-> feature 32m + 16*(j>>2) + 4q + (j&3), i.e. the two
+//           accumulator tiles' registers in order
+// One weight block = 16 outputs x 32 inputs = 2 x 16 B per lane in both modes (2 KiB):
+//   lane l holds W[16*ot + (l&15)][32*t + {4q..4q+3} U {16+4q..16+4q+3}], q = l>>4
+//   AG_F32: unit u = the four fp32 of half u;  AG_BF3: unit 0 = the eight bf16 hi, unit 1 = the eight lo.
+enum { AG_F32 = 0, AG_BF3 = 1 };
+
+template <int MODE> struct AgIn;
+template <> struct AgIn<AG_F32> { f32x4 v[2]; };
+template <> struct AgIn<AG_BF3> { bf16x8 hi, lo; };
+
+__device__ __forceinline__ void ag_cvt(const f32x4& a0, const f32x4& a1, AgIn<AG_F32>& o) { o.v[0] = a0; o.v[1] = a1; }
+__device__ __forceinline__ void ag_cvt(const f32x4& a0, const f32x4& a1, AgIn<AG_BF3>& o) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = (j < 4) ? a0[j & 3] : a1[j & 3];
+    const __bf16 hb = (__bf16)v;
+    o.hi[j] = hb;
+    o.lo[j] = (__bf16)(v - (float)hb);
+  }
+}
+// NK k-tiles from accumulator tiles A0, A0+1, ...
+template <int MODE, int NK, int A0, int NA, int NO>
+__device__ __forceinline__ void ag_cvt_tiles(const f32x4 (&a)[NA], AgIn<MODE> (&o)[NO]) {
+  static_assert(A0 + 2 * NK <= NA && NK <= NO, "tile range");
+#pragma unroll
+  for (int t = 0; t < NK; ++t) ag_cvt(a[A0 + 2 * t], a[A0 + 2 * t + 1], o[t]);
+}
+
+// one weight block (2 x 16 B per lane, already in registers) applied to one k-tile
+template <int MODE, bool FLIP>
+__device__ __forceinline__ void ag_block_mma(f32x4& o, const AgIn<MODE>& x, const u32x4 (&w)[2]) {
+  if constexpr (MODE == AG_F32) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const f32x4 wf = __builtin_bit_cast(f32x4, w[u]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        o = FLIP ? __builtin_amdgcn_mfma_f32_16x16x4f32(x.v[u][r], wf[r], o, 0, 0, 0)
+                 : __builtin_amdgcn_mfma_f32_16x16x4f32(wf[r], x.v[u][r], o, 0, 0, 0);
     }
-}
-
-// Load a row-major row (stride given by caller through `row`) into std tiles T0..T0+NTL-1 of y.
-template <int NTL, int T0, int MT>
-__device__ __forceinline__ void ag_load_row(f32x16 (&y)[MT], const float* __restrict__ row, int h) {
-#pragma unroll
-  for (int t = 0; t < NTL; ++t)
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-      f32x4 b = ag_ld4(row + 32 * t + 8 * rq + 4 * h);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) y[T0 + t][4 * rq + q] = b[q];
+  } else {
+    const bf16x8 whi = __builtin_bit_cast(bf16x8, w[0]), wlo = __builtin_bit_cast(bf16x8, w[1]);
+    if (FLIP) {
+      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x.hi, whi, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x.lo, whi, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x.hi, wlo, o, 0, 0, 0);
+    } else {
+      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, x.hi, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, x.lo, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, x.hi, o, 0, 0, 0);
     }
-}
-
-template <int NTL, int T0, int MT>
-__device__ __forceinline__ void ag_store_row(const f32x16 (&y)[MT], float* __restrict__ row, int h) {
-#pragma unroll
-  for (int t = 0; t < NTL; ++t)
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-      f32x4 b;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) b[q] = y[T0 + t][4 * rq + q];
-      ag_st4(row + 32 * t + 8 * rq + 4 * h, b);
-    }
-}
-
-// Fragment-major edge-attr tiles: [tile][4][4][64][4] floats (512 B per edge, coalesced 1 KiB per
-// wave instruction).
-__device__ __forceinline__ size_t ag_frag_off(int64_t tile, int t, int rq, int lane) {
-  return ((size_t)((tile * 4 + t) * 4 + rq) * 64 + lane) * 4;
-}
-// Same storage addressed by (edge e, feature f multiple of 4): used for gathers of single edges.
-__device__ __forceinline__ size_t ag_frag_off_ef(int64_t e, int f) {
-  int64_t tile = e >> 5;
-  int j = (int)(e & 31), t = f >> 5, w = f & 31;
-  int rq = w >> 3, hh = (w >> 2) & 1;
-  return ag_frag_off(tile, t, rq, j + 32 * hh);
-}
-
-template <int T0, int MT>
-__device__ __forceinline__ void ag_load_frag(f32x16 (&y)[MT], const float* __restrict__ frag, int64_t tile, int lane) {
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-      f32x4 b = ag_ld4(frag + ag_frag_off(tile, t, rq, lane));
-#pragma unroll
-      for (int q = 0; q < 4; ++q) y[T0 + t][4 * rq + q] = b[q];
-    }
-}
-
-// one 32-feature slice t of a fragment-major tile into y[T0]
-template <int T0, int MT>
-__device__ __forceinline__ void ag_load_frag_tile(f32x16 (&y)[MT], const float* __restrict__ frag, int64_t tile, int t, int lane) {
-#pragma unroll
-  for (int rq = 0; rq < 4; ++rq) {
-    f32x4 b = ag_ld4(frag + ag_frag_off(tile, t, rq, lane));
-#pragma unroll
-    for (int q = 0; q < 4; ++q) y[T0][4 * rq + q] = b[q];
   }
 }
 
-template <int MT>
-__device__ __forceinline__ void ag_store_frag(const f32x16 (&y)[MT], float* __restrict__ frag, int64_t tile, int lane) {
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-      f32x4 b;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) b[q] = y[t][4 * rq + q];
-      ag_st4(frag + ag_frag_off(tile, t, rq, lane), b);
-    }
-}
-
-// ---------------------------------------------------------------------------------- dense layers
-// Two arithmetic modes share every kernel (template parameter MODE):
-//   AG_F32: v_mfma_f32_32x32x2_f32, exact fp32 (k-ordered fmaf chain).  One weight block = 4 x 16 B per
-//           lane = 16 MFMAs (1024 SIMD cycles).
-//   AG_BF3: "split bf16": every fp32 operand is hi + lo with hi = bf16(x), lo = bf16(x - hi); a product is
-//           hi.hi + lo.hi + hi.lo on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (~2^-16 relative per
-//           product, the dropped term is lo.lo).  Same C/D layout, so the register-resident chaining is
-//           unchanged; k-slot (s, h, j) of tile t carries feature 32t + 16s + 8(j>>2) + 4h + (j&3), i.e.
-//           accumulator registers 8s..8s+7 in order.  One weight block = [s][hi,lo][64 lanes][8 bf16] =
-//           again 4 x 16 B per lane, 6 MFMAs (192 SIMD cycles).
-// Both run the same software pipeline: the loads of step s+PF are issued before the MFMAs of step s;
-// __builtin_amdgcn_sched_barrier(0) between steps keeps hipcc from hoisting every weight load of the
-// layer to its top (which costs > 256 VGPRs and spills).
-enum { AG_F32 = 0, AG_BF3 = 1 };
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-template <int MODE> struct AgIn;                       // one 32-feature input tile in MFMA-operand form
-template <> struct AgIn<AG_F32> { f32x16 v; };
-template <> struct AgIn<AG_BF3> { bf16x8 hi[2], lo[2]; };
-
-__device__ __forceinline__ void ag_cvt(const f32x16& a, AgIn<AG_F32>& o) { o.v = a; }
-__device__ __forceinline__ void ag_cvt(const f32x16& a, AgIn<AG_BF3>& o) {
-#pragma unroll
-  for (int s = 0; s < 2; ++s)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float v = a[8 * s + j];
-      const __bf16 hb = (__bf16)v;
-      o.hi[s][j] = hb;
-      o.lo[s][j] = (__bf16)(v - (float)hb);
-    }
-}
-template <int MODE, int NT, int A0, int NA, int NO>
-__device__ __forceinline__ void ag_cvt_tiles(const f32x16 (&a)[NA], AgIn<MODE> (&o)[NO]) {
-#pragma unroll
-  for (int t = 0; t < NT; ++t) ag_cvt(a[A0 + t], o[t]);
-}
-
-__device__ __forceinline__ u32x4 ag_ldu(const u32x4* p) { return *p; }
-
-// o[O0 + ot] += sum over k-tiles t of W-block(ot, t) x x[X0 + t]; FLIP selects the orientation (see top).
-// Blocks are contiguous in iteration order: output-tile-outer ("pk") or k-tile-outer ("pkk", KOUTER).
-// KPART = number of 8-feature groups used in the LAST k-tile (4 = all 32 features).
-template <int MODE, bool FLIP, bool KOUTER, int KT, int OT, int X0, int O0, int KPART, int PF, int NX, int NO>
-__device__ __forceinline__ void ag_dense_impl(const AgIn<MODE> (&x)[NX], f32x16 (&o)[NO], const void* wpk, int lane) {
+// Weight blocks are consumed in storage order: output-tile-outer ("pk": [OT][KT]) or k-tile-outer
+// ("pkk": [KT][OT]).  Global source: loads run PF blocks ahead of their MFMAs, with
+// __builtin_amdgcn_sched_barrier(0) between blocks so that hipcc cannot hoist every load of a layer to its
+// top (that costs hundreds of VGPRs).  LDS source: the compiler schedules the ds_reads itself.
+//   o[O0 + ot] += W-block(ot, t) . x[X0 + t]
+template <int MODE, bool FLIP, bool KOUTER, int KT, int OT, int X0, int O0, int PF, int NX, int NO>
+__device__ __forceinline__ void ag_dense(const AgIn<MODE> (&x)[NX], f32x4 (&o)[NO], const void* wpk, int lane) {
   static_assert(X0 + KT <= NX && O0 + OT <= NO, "tile range");
   constexpr int S = OT * KT;
   constexpr int R = PF + 1;
-  u32x4 w[R][4];
+  u32x4 w[R][2];
   const u32x4* wl = reinterpret_cast<const u32x4*>(wpk) + lane;
-  auto tile_of = [](int s) { return KOUTER ? s / OT : s % KT; };
-  auto units = [&](int s) {   // 16-byte units of block s that are actually used
-    const bool last = tile_of(s) == KT - 1;
-    return MODE == AG_F32 ? (last ? KPART : 4) : (last ? 2 * ((KPART + 1) / 2) : 4);
-  };
 #pragma unroll
-  for (int s = 0; s < (PF < S ? PF : S); ++s)
-#pragma unroll
-    for (int u = 0; u < units(s); ++u) w[s % R][u] = ag_ldu(wl + (s * 4 + u) * 64);
+  for (int s = 0; s < (PF < S ? PF : S); ++s) {
+    w[s % R][0] = wl[(s * 2) * 64];
+    w[s % R][1] = wl[(s * 2 + 1) * 64];
+  }
 #pragma unroll
   for (int s = 0; s < S; ++s) {
-    const int t = tile_of(s), ot = KOUTER ? s % OT : s / KT;
+    const int t = KOUTER ? s / OT : s % KT, ot = KOUTER ? s % OT : s / KT;
     if (s + PF < S) {
-#pragma unroll
-      for (int u = 0; u < units(s + PF); ++u) w[(s + PF) % R][u] = ag_ldu(wl + ((s + PF) * 4 + u) * 64);
+      w[(s + PF) % R][0] = wl[((s + PF) * 2) * 64];
+      w[(s + PF) % R][1] = wl[((s + PF) * 2 + 1) * 64];
     }
-    if constexpr (MODE == AG_F32) {
-#pragma unroll
-      for (int rq = 0; rq < units(s); ++rq) {
-        const f32x4 wf = __builtin_bit_cast(f32x4, w[s % R][rq]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (FLIP)
-            o[O0 + ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[X0 + t].v[4 * rq + q], wf[q], o[O0 + ot], 0, 0, 0);
-          else
-            o[O0 + ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q], x[X0 + t].v[4 * rq + q], o[O0 + ot], 0, 0, 0);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int ks = 0; ks < units(s) / 2; ++ks) {
-        const bf16x8 whi = __builtin_bit_cast(bf16x8, w[s % R][2 * ks]);
-        const bf16x8 wlo = __builtin_bit_cast(bf16x8, w[s % R][2 * ks + 1]);
-        const bf16x8 xhi = x[X0 + t].hi[ks], xlo = x[X0 + t].lo[ks];
-        if (FLIP) {
-          o[O0 + ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xhi, whi, o[O0 + ot], 0, 0, 0);
-          o[O0 + ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xlo, whi, o[O0 + ot], 0, 0, 0);
-          o[O0 + ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xhi, wlo, o[O0 + ot], 0, 0, 0);
-        } else {
-          o[O0 + ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, xhi, o[O0 + ot], 0, 0, 0);
-          o[O0 + ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, xlo, o[O0 + ot], 0, 0, 0);
-          o[O0 + ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, xhi, o[O0 + ot], 0, 0, 0);
-        }
-      }
-    }
+    ag_block_mma<MODE, FLIP>(o[O0 + ot], x[X0 + t], w[s % R]);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
-
-// one weight block (4 x 16 B per lane, already in registers) applied to one input tile
-template <int MODE, bool FLIP>
-__device__ __forceinline__ void ag_block_mma(f32x16& o, const AgIn<MODE>& x, const u32x4 (&w)[4]) {
-  if constexpr (MODE == AG_F32) {
+template <int MODE, bool FLIP, bool KOUTER, int KT, int OT, int X0, int O0, int NX, int NO>
+__device__ __forceinline__ void ag_dense_lds(const AgIn<MODE> (&x)[NX], f32x4 (&o)[NO], const lds_u32x4* wl, int lane) {
+  static_assert(X0 + KT <= NX && O0 + OT <= NO, "tile range");
 #pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-      const f32x4 wf = __builtin_bit_cast(f32x4, w[rq]);
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        o = FLIP ? __builtin_amdgcn_mfma_f32_32x32x2f32(x.v[4 * rq + q], wf[q], o, 0, 0, 0)
-                 : __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q], x.v[4 * rq + q], o, 0, 0, 0);
-    }
-  } else {
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8 whi = __builtin_bit_cast(bf16x8, w[2 * ks]), wlo = __builtin_bit_cast(bf16x8, w[2 * ks + 1]);
-      if (FLIP) {
-        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.hi[ks], whi, o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.lo[ks], whi, o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.hi[ks], wlo, o, 0, 0, 0);
-      } else {
-        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, x.hi[ks], o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, x.lo[ks], o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, x.hi[ks], o, 0, 0, 0);
-      }
-    }
+  for (int s = 0; s < OT * KT; ++s) {
+    const int t = KOUTER ? s / OT : s % KT, ot = KOUTER ? s % OT : s / KT;
+    u32x4 w[2];
+    w[0] = wl[(s * 2) * 64 + lane];
+    w[1] = wl[(s * 2 + 1) * 64 + lane];
+    ag_block_mma<MODE, FLIP>(o[O0 + ot], x[X0 + t], w);
   }
 }
-
-template <int MODE> struct AgPF { static constexpr int v = (MODE == AG_F32) ? 1 : 2; };
-
-// y[M0 + mt] += W . x   (std orientation: features on registers), "pk" blocks [MT][KT]
-template <int MODE, int KT, int MT, int X0, int M0, int KPART, int PF = AgPF<MODE>::v, int NX, int NY>
-__device__ __forceinline__ void ag_dense_std(const AgIn<MODE> (&x)[NX], f32x16 (&y)[NY], const void* wpk, int lane) {
-  ag_dense_impl<MODE, false, false, KT, MT, X0, M0, KPART, PF>(x, y, wpk, lane);
-}
-// same with "pkk" blocks [KT][MT]: a caller that streams its input in 32-feature slices passes KT = 1
-// and the slice's block offset (slice t starts at block t*MT)
-template <int MODE, int KT, int MT, int X0, int M0, int PF = AgPF<MODE>::v, int NX, int NY>
-__device__ __forceinline__ void ag_dense_std_k(const AgIn<MODE> (&x)[NX], f32x16 (&y)[NY], const void* wpk, int lane) {
-  ag_dense_impl<MODE, false, true, KT, MT, X0, M0, 4, PF>(x, y, wpk, lane);
-}
-// z[N0 + nt][row = edge] (lane = feature) += x^T . W^T   (flip orientation), "pk" blocks
-template <int MODE, int KT, int NT, int X0, int N0, int PF = AgPF<MODE>::v, int NX, int NZ>
-__device__ __forceinline__ void ag_dense_flip(const AgIn<MODE> (&x)[NX], f32x16 (&z)[NZ], const void* wpk, int lane) {
-  ag_dense_impl<MODE, true, false, KT, NT, X0, N0, 4, PF>(x, z, wpk, lane);
-}
-// The same from LDS-resident weight blocks (address space known to the compiler: ds_read_b128).
-template <int MODE, int KT, int NT, int X0, int N0, int NX, int NZ>
-__device__ __forceinline__ void ag_dense_flip_lds(const AgIn<MODE> (&x)[NX], f32x16 (&z)[NZ],
-                                                  const __attribute__((address_space(3))) u32x4* wl, int lane) {
-  static_assert(X0 + KT <= NX && N0 + NT <= NZ, "tile range");
-#pragma unroll
-  for (int s = 0; s < NT * KT; ++s) {
-    const int t = s % KT, ot = s / KT;
-    u32x4 w[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) w[u] = wl[(s * 4 + u) * 64 + lane];
-    if constexpr (MODE == AG_F32) {
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const f32x4 wf = __builtin_bit_cast(f32x4, w[rq]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          z[N0 + ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[X0 + t].v[4 * rq + q], wf[q], z[N0 + ot], 0, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 whi = __builtin_bit_cast(bf16x8, w[2 * ks]), wlo = __builtin_bit_cast(bf16x8, w[2 * ks + 1]);
-        z[N0 + ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[X0 + t].hi[ks], whi, z[N0 + ot], 0, 0, 0);
-        z[N0 + ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[X0 + t].lo[ks], whi, z[N0 + ot], 0, 0, 0);
-        z[N0 + ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[X0 + t].hi[ks], wlo, z[N0 + ot], 0, 0, 0);
-      }
-    }
-  }
-}
-// weight block b of a packed matrix (both modes: 4 KiB per block)
-__device__ __forceinline__ const void* ag_wblock(const float* wpk, int b) { return wpk + (size_t)b * 1024; }
+// default prefetch depth for weights streamed from L2 (blocks of 48 / 256 MFMA cycles)
+template <int MODE> struct AgPF { static constexpr int v = (MODE == AG_F32) ? 2 : 4; };
+// weight block b of a packed matrix (both modes: 2 KiB = 512 floats per block)
+__device__ __forceinline__ const void* ag_wblock(const float* wpk, int b) { return wpk + (size_t)b * 512; }
 
 // z (flip orientation: rows = edges, lanes = features) += s (per edge, on its lane) (x) b (per feature, on
-// its lane): the outer product as one extra k-step whose only non-zero k-slot is (lane half 0, element 0).
-__device__ __forceinline__ void ag_rank1(f32x16& z, float s_edge, float b_feat, int h, AgIn<AG_F32>*) {
-  z = __builtin_amdgcn_mfma_f32_32x32x2f32(h == 0 ? s_edge : 0.0f, h == 0 ? b_feat : 0.0f, z, 0, 0, 0);
+// its lane): the outer product as one extra k-step whose only non-zero k-slot is (quarter 0, element 0).
+__device__ __forceinline__ void ag_rank1(f32x4& z, float s_edge, float b_feat, int q, AgIn<AG_F32>*) {
+  z = __builtin_amdgcn_mfma_f32_16x16x4f32(q == 0 ? s_edge : 0.0f, q == 0 ? b_feat : 0.0f, z, 0, 0, 0);
 }
-__device__ __forceinline__ void ag_rank1(f32x16& z, float s_edge, float b_feat, int h, AgIn<AG_BF3>*) {
-  const float sv = h == 0 ? s_edge : 0.0f, bv = h == 0 ? b_feat : 0.0f;
+__device__ __forceinline__ void ag_rank1(f32x4& z, float s_edge, float b_feat, int q, AgIn<AG_BF3>*) {
+  const float sv = q == 0 ? s_edge : 0.0f, bv = q == 0 ? b_feat : 0.0f;
   const __bf16 sh = (__bf16)sv, bh = (__bf16)bv;
   const __bf16 sl = (__bf16)(sv - (float)sh), bl = (__bf16)(bv - (float)bh);
   bf16x8 ah = {}, al = {}, bhv = {}, blv = {};
   ah[0] = sh; al[0] = sl; bhv[0] = bh; blv[0] = bl;
-  z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bhv, z, 0, 0, 0);
-  z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bhv, z, 0, 0, 0);
-  z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, blv, z, 0, 0, 0);
+  z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bhv, z, 0, 0, 0);
+  z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bhv, z, 0, 0, 0);
+  z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, blv, z, 0, 0, 0);
 }
 
 // ---------------------------------------------------------------------------------- edge-attr storage
-// e_attr / l_attr tiles are stored in the operand form of the mode that consumes them, 4 x 16 B per lane
-// per 32-feature slice, unit index ((tile*4 + t)*4 + u)*64 + lane:
-//   AG_F32: unit u = register group rq (the accumulator dumped as-is)
-//   AG_BF3: unit u = 2*s + part (part 0 = hi, 1 = lo) of k-step s
-__device__ __forceinline__ void ag_store_attr_slice(const AgIn<AG_F32>& x, float* frag, int64_t tile, int t, int lane) {
-  u32x4* p = reinterpret_cast<u32x4*>(frag) + ((tile * 4 + t) * 4) * 64 + lane;
-#pragma unroll
-  for (int rq = 0; rq < 4; ++rq) {
-    f32x4 b;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) b[q] = x.v[4 * rq + q];
-    p[rq * 64] = __builtin_bit_cast(u32x4, b);
-  }
+// e_attr / l_attr tiles (16 edges x 128 features) are stored in the operand form of the mode that consumes
+// them: per k-tile t two 16-byte units per lane, unit index ((tile*4 + t)*2 + u)*64 + lane -- 1 KiB
+// coalesced per wave instruction for the producer's store and every consumer's load, 512 B per edge.
+__device__ __forceinline__ void ag_store_attr(const AgIn<AG_F32>& x, float* frag, int64_t tile, int t, int lane) {
+  u32x4* p = reinterpret_cast<u32x4*>(frag) + ((tile * 4 + t) * 2) * 64 + lane;
+  p[0] = __builtin_bit_cast(u32x4, x.v[0]);
+  p[64] = __builtin_bit_cast(u32x4, x.v[1]);
 }
-__device__ __forceinline__ void ag_store_attr_slice(const AgIn<AG_BF3>& x, float* frag, int64_t tile, int t, int lane) {
-  u32x4* p = reinterpret_cast<u32x4*>(frag) + ((tile * 4 + t) * 4) * 64 + lane;
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    p[(2 * s) * 64] = __builtin_bit_cast(u32x4, x.hi[s]);
-    p[(2 * s + 1) * 64] = __builtin_bit_cast(u32x4, x.lo[s]);
-  }
+__device__ __forceinline__ void ag_store_attr(const AgIn<AG_BF3>& x, float* frag, int64_t tile, int t, int lane) {
+  u32x4* p = reinterpret_cast<u32x4*>(frag) + ((tile * 4 + t) * 2) * 64 + lane;
+  p[0] = __builtin_bit_cast(u32x4, x.hi);
+  p[64] = __builtin_bit_cast(u32x4, x.lo);
 }
-__device__ __forceinline__ void ag_load_attr_slice(AgIn<AG_F32>& x, const float* frag, int64_t tile, int t, int lane) {
-  const u32x4* p = reinterpret_cast<const u32x4*>(frag) + ((tile * 4 + t) * 4) * 64 + lane;
-#pragma unroll
-  for (int rq = 0; rq < 4; ++rq) {
-    const f32x4 b = __builtin_bit_cast(f32x4, p[rq * 64]);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) x.v[4 * rq + q] = b[q];
-  }
+__device__ __forceinline__ void ag_load_attr(AgIn<AG_F32>& x, const float* frag, int64_t tile, int t, int lane) {
+  const u32x4* p = reinterpret_cast<const u32x4*>(frag) + ((tile * 4 + t) * 2) * 64 + lane;
+  x.v[0] = __builtin_bit_cast(f32x4, p[0]);
+  x.v[1] = __builtin_bit_cast(f32x4, p[64]);
 }
-__device__ __forceinline__ void ag_load_attr_slice(AgIn<AG_BF3>& x, const float* frag, int64_t tile, int t, int lane) {
-  const u32x4* p = reinterpret_cast<const u32x4*>(frag) + ((tile * 4 + t) * 4) * 64 + lane;
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    x.hi[s] = __builtin_bit_cast(bf16x8, p[(2 * s) * 64]);
-    x.lo[s] = __builtin_bit_cast(bf16x8, p[(2 * s + 1) * 64]);
-  }
+__device__ __forceinline__ void ag_load_attr(AgIn<AG_BF3>& x, const float* frag, int64_t tile, int t, int lane) {
+  const u32x4* p = reinterpret_cast<const u32x4*>(frag) + ((tile * 4 + t) * 2) * 64 + lane;
+  x.hi = __builtin_bit_cast(bf16x8, p[0]);
+  x.lo = __builtin_bit_cast(bf16x8, p[64]);
 }
 // four consecutive features f..f+3 (f % 4 == 0) of edge e as fp32 (GIN message gather)
 template <int MODE>
 __device__ __forceinline__ f32x4 ag_attr_gather4(const float* frag, int64_t e, int f) {
-  const int64_t tile = e >> 5;
-  const int j = (int)(e & 31), t = f >> 5, w = f & 31;
+  const int64_t tile = e >> 4;
+  const int t = f >> 5, w = f & 31, u = w >> 4, q = (w & 15) >> 2;
+  const int64_t unit0 = ((tile * 4 + t) * 2) * 64 + (int)(e & 15) + 16 * q;
   if constexpr (MODE == AG_F32) {
-    const int rq = w >> 3, hh = (w >> 2) & 1;
-    return ag_ld4(frag + (((tile * 4 + t) * 4 + rq) * 64 + j + 32 * hh) * 4);
+    return ag_ld4(frag + (unit0 + 64 * u) * 4);
   } else {
-    const int s = w >> 4, jq = (w >> 3) & 1, hh = (w >> 2) & 1;
-    const unsigned short* base = reinterpret_cast<const unsigned short*>(frag) +
-                                 ((((tile * 4 + t) * 4 + 2 * s) * 64 + j + 32 * hh) * 8 + 4 * jq);
     typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+    const unsigned short* base = reinterpret_cast<const unsigned short*>(frag) + unit0 * 8 + 4 * u;
     const u16x4 hi = *reinterpret_cast<const u16x4*>(base);
     const u16x4 lo = *reinterpret_cast<const u16x4*>(base + 64 * 8);
     f32x4 r;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      r[q] = __uint_as_float((unsigned)hi[q] << 16) + __uint_as_float((unsigned)lo[q] << 16);
+    for (int k = 0; k < 4; ++k)
+      r[k] = __uint_as_float((unsigned)hi[k] << 16) + __uint_as_float((unsigned)lo[k] << 16);
     return r;
   }
 }
-
-// dot product over the features of std tiles [0, MT) with a natural-order weight vector:
-// returns sum_f w[f] * y[f] for the lane's edge (both halves hold the total).
-template <int MT, int NY>
-__device__ __forceinline__ float ag_dot_vec(const f32x16 (&y)[NY], const float* __restrict__ w, int h) {
-  float s = 0.0f;
-#pragma unroll
-  for (int t = 0; t < MT; ++t)
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-      f32x4 b = ag_ld4(w + 32 * t + 8 * rq + 4 * h);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) s = fmaf(b[q], y[t][4 * rq + q], s);
-    }
-  s += __shfl_xor(s, 32);
-  return s;
-}
-
-#define AG_FOR_TILE(y, MT, expr)                 \
-  _Pragma("unroll") for (int _t = 0; _t < (MT); ++_t) \
-  _Pragma("unroll") for (int _r = 0; _r < 16; ++_r) { float v = (y)[_t][_r]; (y)[_t][_r] = (expr); }
 
 // Host-side launch check
 #define AG_CHECK_LAUNCH()                                         \

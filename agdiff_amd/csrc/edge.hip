@@ -1,6 +1,6 @@
 // Per-edge kernels: MLPEdgeEncoder, per-edge CFConv scales, fused CFConv (filter MLP + message +
 // destination-segmented reduction), pair-feature heads, and the stand-alone aggregate.
-// One wave = one tile of 32 edges; activations stay in the MFMA accumulator layout between layers
+// One wave = one tile of 16 edges; activations stay in the MFMA accumulator layout between layers
 // (common.hpp).  Every MFMA kernel is instantiated for both arithmetic modes (AG_F32 / AG_BF3).
 #include "common.hpp"
 #include <cstdlib>
@@ -29,39 +29,39 @@ struct EncArgs {
 // layers; W23 = comb.0[:, :128] @ efm.2; the trailing attention factor is exactly 1.)
 // The result is stored in the operand form of the consuming mode (common.hpp: edge-attr storage).
 template <int MODE>
-__global__ void __launch_bounds__(AG_WG, 2) k_edge_encoder(EncArgs a) {
-  const int lane = ag_lane(), h = lane >> 5;
+__global__ void __launch_bounds__(AG_WG, 4) k_edge_encoder(EncArgs a) {
+  const int lane = ag_lane(), q = lane >> 4;
   const int64_t tile = (int64_t)blockIdx.x * 4 + ag_wave_in_wg();
   const int E = *a.n_dev;
-  if (tile >= a.max_tiles || tile * 32 >= E) return;
-  const int64_t e = tile * 32 + (lane & 31);
+  if (tile >= a.max_tiles || tile * AG_TW >= E) return;
+  const int64_t e = tile * AG_TW + (lane & 15);
   const bool valid = e < E;
   const float d = valid ? a.e_len[e] : 0.0f;
   const int ty = valid ? a.e_type[e] : 0;
-  constexpr int PF = (MODE == AG_F32) ? 1 : 4;
+  constexpr int PF = AgPF<MODE>::v;
 
-  f32x16 y[4];
+  f32x4 y[8];
   AgIn<MODE> x[4];
   {
-    f32x16 w[4];
-    ag_init_vec<4>(w, a.fe_w, h);
-    ag_init_vec<4>(y, a.fe_b, h);
-    AG_FOR_TILE(y, 4, ag_gelu(fmaf(w[_t][_r], d, v)));
+    f32x4 w[8];
+    ag_init_vec<8>(w, a.fe_w, q);
+    ag_init_vec<8>(y, a.fe_b, q);
+    AG_FOR_TILE(y, 8, ag_gelu(fmaf(w[_t][_r], d, v)));
   }
   ag_cvt_tiles<MODE, 4, 0>(y, x);
-  ag_init_vec<4>(y, a.t1 + (size_t)ty * 128, h);
-  ag_dense_std<MODE, 4, 4, 0, 0, 4, PF>(x, y, a.w1_pk, lane);
-  AG_FOR_TILE(y, 4, ag_gelu(v));
+  ag_init_vec<8>(y, a.t1 + (size_t)ty * 128, q);
+  ag_dense<MODE, false, false, 4, 8, 0, 0, PF>(x, y, a.w1_pk, lane);
+  AG_FOR_TILE(y, 8, ag_gelu(v));
   ag_cvt_tiles<MODE, 4, 0>(y, x);
-  ag_init_vec<4>(y, a.t3 + (size_t)ty * 128, h);
-  ag_dense_std<MODE, 4, 4, 0, 0, 4, PF>(x, y, a.w23_pk, lane);
-  AG_FOR_TILE(y, 4, ag_gelu(v));
+  ag_init_vec<8>(y, a.t3 + (size_t)ty * 128, q);
+  ag_dense<MODE, false, false, 4, 8, 0, 0, PF>(x, y, a.w23_pk, lane);
+  AG_FOR_TILE(y, 8, ag_gelu(v));
   ag_cvt_tiles<MODE, 4, 0>(y, x);
-  ag_init_vec<4>(y, a.b4, h);
-  ag_dense_std<MODE, 4, 4, 0, 0, 4, PF>(x, y, a.w4_pk, lane);
+  ag_init_vec<8>(y, a.b4, q);
+  ag_dense<MODE, false, false, 4, 8, 0, 0, PF>(x, y, a.w4_pk, lane);
   ag_cvt_tiles<MODE, 4, 0>(y, x);
 #pragma unroll
-  for (int t = 0; t < 4; ++t) ag_store_attr_slice(x[t], a.out_frag, tile, t, lane);
+  for (int t = 0; t < 4; ++t) ag_store_attr(x[t], a.out_frag, tile, t, lane);
 }
 
 // ------------------------------------------------------------------------------ per-edge conv scales
@@ -123,7 +123,7 @@ struct ConvArgs {
 };
 
 #ifdef AG_CONV_STAMPS
-// Diagnostic build only (make STAMPS=1): per-phase wave cycles of k_cfconv_fused, summed over waves.
+// Diagnostic build only (make EXTRA=-DAG_CONV_STAMPS): per-phase wave cycles of k_cfconv_fused, summed over waves.
 __device__ unsigned long long ag_conv_stamp_acc[8];
 #define AG_STAMP(var)                                  \
   do {                                                 \
@@ -135,50 +135,43 @@ __device__ unsigned long long ag_conv_stamp_acc[8];
 #define AG_STAMP(var) do { } while (0)
 #endif
 
-#define AG_CONV_WAVES 8
-#define AG_CONV_LDS_BLOCKS 36   // resident 4-KiB weight blocks: filt_w1a (16) | filt_w2a (16) | filt_w2b (4)
-typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+#define AG_CONV_WAVES 16
+#define AG_CONV_LDS_BLOCKS 72   // resident 2-KiB weight blocks: filt_w1a (32) | filt_w2a (32) | filt_w2b (8)
+#define AG_CONV_NCH 12          // 16-channel tiles of the 192 filter channels (conv1: 0..7, conv2: 8..11)
 
 // encoder/schnet.py:136-162 for conv1 (F=128) and conv2 (F=64) of one InteractionBlock:
 //   W_e = nn(edge_attr_e) * (lw(d_e) * C(d_e));  agg[dst] += x[src] * W_e   (aggr='add')
-// Persistent launch, one 8-wave workgroup per CU.  Each wave walks AGDIFF_CHUNK_TILES consecutive
-// destination-sorted tiles per chunk and keeps the running sum of the open target in LDS; a target
-// whose list started in an earlier chunk is written to agg_first[chunk] and added by the node stage
-// (fixed order -> bitwise reproducible, no atomics).
+// Persistent launch, one 16-wave workgroup per CU (4 waves per SIMD).  Each wave walks AGDIFF_CHUNK_TILES
+// consecutive destination-sorted 16-edge tiles per chunk and keeps the running sum of the open target in
+// LDS; a target whose list started in an earlier chunk is written to agg_first[chunk] and added by the node
+// stage (fixed order -> bitwise reproducible, no atomics).
 template <int MODE>
-__global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs a) {
+__global__ void __launch_bounds__(64 * AG_CONV_WAVES, 4) k_cfconv_fused(ConvArgs a) {
   // LDS (156 KiB of the CU's 160): 144 KiB of filter weights resident for the whole launch -- conv1's first
-  // layer and both second layers -- plus the carry rows (waves x 6 x 64 floats).  Only conv2's first layer
-  // (8 blocks per tile) is streamed from L2.
+  // layer and both second layers -- plus the carry rows (waves x 192 floats).  Only conv2's first layer
+  // (16 blocks per tile) is streamed from L2.
   extern __shared__ u32x4 ag_conv_smem[];
   lds_u32x4* w1a = (lds_u32x4*)ag_conv_smem;
-  lds_u32x4* w2 = w1a + 16 * 256;
+  lds_u32x4* w2 = w1a + 32 * 128;
   {
     const u32x4* g1 = reinterpret_cast<const u32x4*>(a.cp.filt_w1a_pk);
     const u32x4* ga = reinterpret_cast<const u32x4*>(a.cp.filt_w2a_pk);
     const u32x4* gb = reinterpret_cast<const u32x4*>(a.cp.filt_w2b_pk);
-    for (int i = threadIdx.x; i < 16 * 256; i += blockDim.x) w1a[i] = g1[i];
-    for (int i = threadIdx.x; i < 16 * 256; i += blockDim.x) w2[i] = ga[i];
-    for (int i = threadIdx.x; i < 4 * 256; i += blockDim.x) w2[16 * 256 + i] = gb[i];
+    for (int i = threadIdx.x; i < 32 * 128; i += blockDim.x) w1a[i] = g1[i];
+    for (int i = threadIdx.x; i < 32 * 128; i += blockDim.x) w2[i] = ga[i];
+    for (int i = threadIdx.x; i < 8 * 128; i += blockDim.x) w2[32 * 128 + i] = gb[i];
   }
   __syncthreads();
   const int lane0 = ag_lane();
   const int wave = threadIdx.x >> 6;
   const int E = *a.n_dev;
-  const int h0 = lane0 >> 5, col0 = lane0 & 31;
-  // running sums (6 channel tiles x 64 lanes) of target run_t, whose list is still open
-  float* carry = reinterpret_cast<float*>(ag_conv_smem + AG_CONV_LDS_BLOCKS * 256) + wave * (6 * 64);
+  // running sums (192 channels) of target run_t, whose list is still open
+  float* carry = reinterpret_cast<float*>(ag_conv_smem + AG_CONV_LDS_BLOCKS * 128) + wave * 192;
   const int64_t cstride = (int64_t)gridDim.x * AG_CONV_WAVES;
   [[maybe_unused]] unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c0 = 0, c1 = 0;
-  // The two waves that share a SIMD run the same program; started together they reach their MFMA
-  // phases together and their VALU phases together.  Delaying waves 4..7 once, by a fraction of a
-  // tile, lets one wave's MFMAs run beside the other's VALU work.
-  if (__builtin_amdgcn_readfirstlane(wave) >= 4) {
-    for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(1);
-  }
 
   for (int64_t chunk = (int64_t)blockIdx.x * AG_CONV_WAVES + wave; chunk < a.max_chunks; chunk += cstride) {
-    const int64_t e_begin = chunk * (32 * AGDIFF_CHUNK_TILES);
+    const int64_t e_begin = chunk * (AG_TW * AGDIFF_CHUNK_TILES);
     if (e_begin >= E) break;
     int run_t = -1;
 
@@ -189,74 +182,71 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
 
     for (int tt = 0; tt < AGDIFF_CHUNK_TILES; ++tt) {
       const int64_t tile = chunk * AGDIFF_CHUNK_TILES + tt;
-      const int64_t tbase = tile * 32;
+      const int64_t tbase = tile * AG_TW;
       if (tbase >= E) break;
+      AG_STAMP(c0);
       // opaque copy of the lane id: keeps hipcc from hoisting every lane-derived weight / table address
       // out of the tile loop (they would stay live across the whole body and spill)
-      AG_STAMP(c0);
       int lane = lane0;
       asm volatile("" : "+v"(lane));
-      const int h = lane >> 5, col = lane & 31;
+      const int q = lane >> 4, col = lane & 15;
       const int64_t e = tbase + col;
       const bool valid = e < E;
       const int my_src = valid ? a.e_src[e] : 0;
       const float s1 = valid ? a.scale1[e] : 0.0f;
       const float s2 = valid ? a.scale2[e] : 0.0f;
 
-      const int64_t last = (tbase + 31 < E) ? tbase + 31 : (int64_t)E - 1;
+      const int64_t last = (tbase + AG_TW - 1 < E) ? tbase + AG_TW - 1 : (int64_t)E - 1;
       const int t0 = __builtin_amdgcn_readfirstlane(a.e_dst[tbase]);
       const int t1 = __builtin_amdgcn_readfirstlane(a.e_dst[last]);
       if (run_t >= 0 && run_t != t0) {   // previous tile ended exactly on a list boundary
         float* dp = dest(run_t);
-        if (h == 0) {
+        if (lane < 16) {
 #pragma unroll
-          for (int i = 0; i < 6; ++i) dp[32 * i + col] = carry[i * 64 + lane];
+          for (int i = 0; i < AG_CONV_NCH; ++i) dp[16 * i + col] = carry[16 * i + col];
         }
         run_t = -1;
       }
       const bool cont = (run_t == t0);
-
       AG_STAMP(c1); st[0] += c1 - c0; c0 = c1;       // meta loads, carry flush
+
       AgIn<MODE> hidb[6];
       {
-        f32x16 hid[6];
+        f32x4 hid[AG_CONV_NCH];
         {
-          // first filter layer, k-slice outer: per slice t, conv1's four output tiles from LDS-resident
-          // blocks, conv2's two from blocks streamed from L2; the streamed pair is refilled for the next
-          // slice right after its last use (4 LDS-fed steps of lookahead).  LDS-fed steps are
-          // double-buffered by hand: the sched_barriers that pin the global prefetches would otherwise
-          // also pin each ds_read right in front of its MFMAs.
+          // first filter layer, k-tile outer: per k-tile t, conv1's eight output tiles from LDS-resident
+          // blocks, conv2's four from blocks streamed from L2; the streamed set is refilled for the next
+          // k-tile right after its last use (8 LDS-fed blocks of lookahead).
           AgIn<MODE> ea[4];
-          ag_init_vec<6>(hid, a.cp.filt_b1, h);
+          ag_init_vec<AG_CONV_NCH>(hid, a.cp.filt_b1, q);
 #pragma unroll
-          for (int t = 0; t < 4; ++t) ag_load_attr_slice(ea[t], a.e_attr, tile, t, lane);
+          for (int t = 0; t < 4; ++t) ag_load_attr(ea[t], a.e_attr, tile, t, lane);
           if (!(a.ablate & 1)) {
+            // Streamed blocks are consumed in storage order (pkk: [t][b]), one after every two LDS-fed
+            // blocks; a 2-block register ring keeps the loads two streamed blocks (six MFMA blocks) ahead.
             const u32x4* gl = reinterpret_cast<const u32x4*>(a.cp.filt_w1b_pk) + lane;
-            u32x4 g[2][4];
+            u32x4 g[2][2];
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-              for (int u = 0; u < 4; ++u) g[b][u] = gl[(b * 4 + u) * 64];
-            u32x4 wl[2][4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) wl[0][u] = w1a[u * 64 + lane];
+            for (int b = 0; b < 2; ++b) {
+              g[b][0] = gl[(b * 2) * 64];
+              g[b][1] = gl[(b * 2 + 1) * 64];
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
 #pragma unroll
-              for (int ot = 0; ot < 6; ++ot) {
-                if (ot < 4) {
-                  const int cur = t * 4 + ot;   // LDS block index, consumed in this order
-                  if (cur + 1 < 16) {
+              for (int b = 0; b < 4; ++b) {
+                const int n = t * 4 + b;             // streamed block index
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) wl[(cur + 1) & 1][u] = w1a[((cur + 1) * 4 + u) * 64 + lane];
-                  }
-                  ag_block_mma<MODE, false>(hid[ot], ea[t], wl[cur & 1]);
-                } else {
-                  ag_block_mma<MODE, false>(hid[ot], ea[t], g[ot - 4]);
-                  if (t + 1 < 4) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) g[ot - 4][u] = gl[(((t + 1) * 2 + (ot - 4)) * 4 + u) * 64];
-                  }
+                for (int o = 0; o < 2; ++o) {
+                  u32x4 w[2];
+                  w[0] = w1a[((t * 8 + 2 * b + o) * 2) * 64 + lane];
+                  w[1] = w1a[((t * 8 + 2 * b + o) * 2 + 1) * 64 + lane];
+                  ag_block_mma<MODE, false>(hid[2 * b + o], ea[t], w);
+                }
+                ag_block_mma<MODE, false>(hid[8 + b], ea[t], g[n & 1]);
+                if (n + 2 < 16) {
+                  g[n & 1][0] = gl[((n + 2) * 2) * 64];
+                  g[n & 1][1] = gl[((n + 2) * 2 + 1) * 64];
                 }
                 __builtin_amdgcn_sched_barrier(0);
               }
@@ -267,21 +257,21 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
         // ssp, then fold the per-edge scale lw(d)*C(d) (a per-lane scalar here) into the hidden layer:
         // (s.H)^T W2 + s.b2 == s.(H^T W2 + b2)
 #pragma unroll
-        for (int t = 0; t < 6; ++t) {
-          const float beta = (t < 4) ? a.cp.ssp_beta1 : a.cp.ssp_beta2;
-          const float sc = (t < 4) ? s1 : s2;
+        for (int t = 0; t < AG_CONV_NCH; ++t) {
+          const float beta = (t < 8) ? a.cp.ssp_beta1 : a.cp.ssp_beta2;
+          const float sc = (t < 8) ? s1 : s2;
           if (!(a.ablate & 2)) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) hid[t][r] = ag_ssp(beta, hid[t][r]) * sc;
+            for (int r = 0; r < 4; ++r) hid[t][r] = ag_ssp(beta, hid[t][r]) * sc;
           }
         }
         ag_cvt_tiles<MODE, 6, 0>(hid, hidb);
       }
       AG_STAMP(c1); st[2] += c1 - c0; c0 = c1;       // ssp + split
-      // gather row of every edge slot my half owns: slot (r,h) lives in lane ag_row(r,h)
-      uint32_t xoff[16];
+      // gather row of every edge slot my quarter owns: slot 4q + r lives in lane 4q + r
+      uint32_t xoff[4];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) xoff[r] = (uint32_t)__shfl(my_src, ag_row(r, h)) * 192u + (uint32_t)col;
+      for (int r = 0; r < 4; ++r) xoff[r] = (uint32_t)__shfl(my_src, 4 * q + r) * 192u + (uint32_t)col;
       // list boundaries of the targets present in this tile, one per lane (in_ptr[t0 + lane]); the
       // reduction loops read them with readlane instead of dependent global loads
       const int ntg = t1 - t0 + 1;
@@ -293,75 +283,69 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
         return (lo >= e_begin) ? (a.agg + (size_t)t * 192) : (a.agg_first + (size_t)chunk * 192);
       };
 
-      // second filter layer per 32-channel tile, flipped (rows = edges, lanes = channels), then
-      // message and destination-segmented reduction of that channel tile.  The x[src] rows of the next
-      // channel tile are fetched before the current tile's reduction.
-      float xg[16];
+      // second filter layer per 16-channel tile, flipped (rows = edges, lanes = channels), then message and
+      // destination-segmented reduction of that channel tile.  The x[src] rows of the next channel tile are
+      // fetched before the current tile's reduction.
+      f32x4 xg;
       auto fetch_x = [&](int nt) {
         if (a.ablate & 8) return;
-        const float* xb = a.xs + 32 * nt;
+        const float* xb = a.xs + 16 * nt;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) xg[r] = xb[xoff[r]];
+        for (int r = 0; r < 4; ++r) xg[r] = xb[xoff[r]];
       };
-      auto channel_tile = [&](f32x16 (&z)[1], int nt) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) z[0][r] *= xg[r];
-        if (nt + 1 < 6) fetch_x(nt + 1);
-        if (a.ablate & 16) { carry[nt * 64 + lane] = z[0][0]; return; }
+      auto channel_tile = [&](f32x4& z, int nt) {
+        z *= xg;
+        if (nt + 1 < AG_CONV_NCH) fetch_x(nt + 1);
+        if (a.ablate & 16) { carry[16 * nt + col] = z[0]; return; }
         float newcarry = 0.0f;
         for (int i = 0; i < ntg; ++i) {
           const int lo = bound(i), hi = bound(i + 1);
           float p = 0.0f;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int er = (int)tbase + ag_row(r, h);
-            p += ((er >= lo) && (er < hi)) ? z[0][r] : 0.0f;
+          for (int r = 0; r < 4; ++r) {
+            const int er = (int)tbase + 4 * q + r;
+            p += ((er >= lo) && (er < hi)) ? z[r] : 0.0f;
           }
+          p += __shfl_xor(p, 16);
           p += __shfl_xor(p, 32);
-          if (i == 0 && cont) p = carry[nt * 64 + lane] + p;
+          if (i == 0 && cont) p = carry[16 * nt + col] + p;
           if (i < ntg - 1) {
             float* dp = dest_lo(t0 + i, lo);
-            if (h == 0) dp[32 * nt + col] = p;
+            if (lane < 16) dp[16 * nt + col] = p;
           } else {
             newcarry = p;
           }
         }
-        carry[nt * 64 + lane] = newcarry;
+        if (lane < 16) carry[16 * nt + col] = newcarry;
       };
       fetch_x(0);
       AG_STAMP(c1); st[3] += c1 - c0; c0 = c1;       // gather offsets, bounds
       // the bias enters as one extra k-step (ag_rank1): A = s_e on k-slot 0, B = b2 on k-slot 0
 #pragma unroll 1
-      for (int nt = 0; nt < 4; ++nt) {
-        f32x16 z[1];
-        const float bb = a.cp.filt_b2[32 * nt + col];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) z[0][r] = 0.0f;
-        ag_rank1(z[0], s1, bb, h, (AgIn<MODE>*)nullptr);
-        if (!(a.ablate & 4)) ag_dense_flip_lds<MODE, 4, 1, 0, 0>(hidb, z, w2 + (nt * 4) * 256, lane);
+      for (int nt = 0; nt < 8; ++nt) {
+        f32x4 z[1] = {{0.f, 0.f, 0.f, 0.f}};
+        ag_rank1(z[0], s1, a.cp.filt_b2[16 * nt + col], q, (AgIn<MODE>*)nullptr);
+        if (!(a.ablate & 4)) ag_dense_lds<MODE, true, false, 4, 1, 0, 0>(hidb, z, w2 + (nt * 4) * 128, lane);
         AG_STAMP(c1); st[4] += c1 - c0; c0 = c1;     // layer 2
-        channel_tile(z, nt);
+        channel_tile(z[0], nt);
         AG_STAMP(c1); st[5] += c1 - c0; c0 = c1;     // message + reduction
       }
 #pragma unroll 1
-      for (int nt = 4; nt < 6; ++nt) {
-        f32x16 z[1];
-        const float bb = a.cp.filt_b2[32 * nt + col];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) z[0][r] = 0.0f;
-        ag_rank1(z[0], s2, bb, h, (AgIn<MODE>*)nullptr);
-        if (!(a.ablate & 4)) ag_dense_flip_lds<MODE, 2, 1, 4, 0>(hidb, z, w2 + (16 + (nt - 4) * 2) * 256, lane);
+      for (int nt = 8; nt < AG_CONV_NCH; ++nt) {
+        f32x4 z[1] = {{0.f, 0.f, 0.f, 0.f}};
+        ag_rank1(z[0], s2, a.cp.filt_b2[16 * nt + col], q, (AgIn<MODE>*)nullptr);
+        if (!(a.ablate & 4)) ag_dense_lds<MODE, true, false, 2, 1, 4, 0>(hidb, z, w2 + (32 + (nt - 8) * 2) * 128, lane);
         AG_STAMP(c1); st[4] += c1 - c0; c0 = c1;
-        channel_tile(z, nt);
+        channel_tile(z[0], nt);
         AG_STAMP(c1); st[5] += c1 - c0; c0 = c1;
       }
       run_t = t1;
     }
     if (run_t >= 0) {
       float* dp = dest(run_t);
-      if (h0 == 0) {
+      if (lane0 < 16) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) dp[32 * i + col0] = carry[i * 64 + lane0];
+        for (int i = 0; i < AG_CONV_NCH; ++i) dp[16 * i + lane0] = carry[16 * i + lane0];
       }
     }
   }  // chunk loop
@@ -387,55 +371,51 @@ struct HeadArgs {
 
 // assemble_atom_pair_feature (common.py:106-109) + MultiLayerPerceptron 256->128->64->1 (common.py:86-103)
 template <int MODE>
-__global__ void __launch_bounds__(AG_WG, 2) k_pair_head(HeadArgs a) {
-  const int lane = ag_lane(), h = lane >> 5;
+__global__ void __launch_bounds__(AG_WG, 4) k_pair_head(HeadArgs a) {
+  const int lane = ag_lane(), q = lane >> 4;
   const int64_t tile = (int64_t)blockIdx.x * 4 + ag_wave_in_wg();
   const int E = *a.n_dev;
-  if (tile >= a.max_tiles || tile * 32 >= E) return;
-  const int64_t e = tile * 32 + (lane & 31);
+  if (tile >= a.max_tiles || tile * AG_TW >= E) return;
+  const int64_t e = tile * AG_TW + (lane & 15);
   const bool valid = e < E;
   const int s = valid ? a.src[e] : 0, t = valid ? a.dst[e] : 0;
+  constexpr int PF = AgPF<MODE>::v;
 
-  // first layer streamed over eight 32-feature slices of [h_src * h_dst || edge_attr] (pkk weights)
-  f32x16 y1[4];
-  ag_init_vec<4>(y1, a.hp.b1, h);
+  // first layer streamed over eight 32-feature k-tiles of [h_src * h_dst || edge_attr] (pkk weights)
+  f32x4 y1[8];
+  ag_init_vec<8>(y1, a.hp.b1, q);
   {
     const float* hs = a.node_h + (size_t)s * 128;
     const float* ht = a.node_h + (size_t)t * 128;
     AgIn<MODE> sl[2];
     auto load_slice = [&](AgIn<MODE>& dst, int k) {
       if (k < 4) {
-        f32x16 pr;
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-          f32x4 u = ag_ld4(hs + 32 * k + 8 * rq + 4 * h), w = ag_ld4(ht + 32 * k + 8 * rq + 4 * h);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) pr[4 * rq + q] = u[q] * w[q];
-        }
-        ag_cvt(pr, dst);
+        const f32x4 p0 = ag_ld4(hs + 32 * k + 4 * q) * ag_ld4(ht + 32 * k + 4 * q);
+        const f32x4 p1 = ag_ld4(hs + 32 * k + 16 + 4 * q) * ag_ld4(ht + 32 * k + 16 + 4 * q);
+        ag_cvt(p0, p1, dst);
       } else {
-        ag_load_attr_slice(dst, a.attr_frag, tile, k - 4, lane);
+        ag_load_attr(dst, a.attr_frag, tile, k - 4, lane);
       }
     };
     load_slice(sl[0], 0);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       if (k + 1 < 8) load_slice(sl[(k + 1) & 1], k + 1);
-      if (k & 1) ag_dense_std_k<MODE, 1, 4, 1, 0>(sl, y1, ag_wblock(a.hp.w1_pk, k * 4), lane);
-      else ag_dense_std_k<MODE, 1, 4, 0, 0>(sl, y1, ag_wblock(a.hp.w1_pk, k * 4), lane);
+      if (k & 1) ag_dense<MODE, false, true, 1, 8, 1, 0, PF>(sl, y1, ag_wblock(a.hp.w1_pk, k * 8), lane);
+      else ag_dense<MODE, false, true, 1, 8, 0, 0, PF>(sl, y1, ag_wblock(a.hp.w1_pk, k * 8), lane);
     }
   }
-  AG_FOR_TILE(y1, 4, ag_relu(v));
-  f32x16 y2[2];
-  ag_init_vec<2>(y2, a.hp.b2, h);
+  AG_FOR_TILE(y1, 8, ag_relu(v));
+  f32x4 y2[4];
+  ag_init_vec<4>(y2, a.hp.b2, q);
   {
     AgIn<MODE> y1b[4];
     ag_cvt_tiles<MODE, 4, 0>(y1, y1b);
-    ag_dense_std<MODE, 4, 2, 0, 0, 4>(y1b, y2, a.hp.w2_pk, lane);
+    ag_dense<MODE, false, false, 4, 4, 0, 0, PF>(y1b, y2, a.hp.w2_pk, lane);
   }
-  AG_FOR_TILE(y2, 2, ag_relu(v));
-  const float o = ag_dot_vec<2>(y2, a.hp.w3, h) + a.hp.b3;
-  if (valid && h == 0) a.out[e] = o;
+  AG_FOR_TILE(y2, 4, ag_relu(v));
+  const float o = ag_dot_vec<4>(y2, a.hp.w3, q) + a.hp.b3;
+  if (valid && q == 0) a.out[e] = o;
 }
 
 // ------------------------------------------------------------------------------ stand-alone aggregate
@@ -507,7 +487,7 @@ extern "C" int agdiff_edge_scales(const agdiff_params_t* p, const agdiff_topo_t*
   a.n_dev = ws->num_edges;
   a.e_len = ws->e_len;
   a.out = ws->e_scale;
-  a.epad = ((topo->max_edges + 31) / 32) * 32;
+  a.epad = ((topo->max_edges + AG_TW - 1) / AG_TW) * AG_TW;
   a.n = 2 * p->num_convs;
   a.cutoff = p->cutoff;
   a.smooth = p->smooth;
@@ -520,7 +500,7 @@ extern "C" int agdiff_cfconv_fused(const agdiff_params_t* p, const agdiff_topo_t
                                    void* stream) {
   if (!p || !topo || !ws || k < 0 || k >= p->num_convs) return AGDIFF_ERR_ARG;
   if (topo->max_in_degree > AGDIFF_TILE * AGDIFF_CHUNK_TILES) return AGDIFF_ERR_LIMIT;
-  const int64_t max_tiles = (topo->max_edges + 31) / 32;
+  const int64_t max_tiles = (topo->max_edges + AG_TW - 1) / AG_TW;
   const int64_t max_chunks = (max_tiles + AGDIFF_CHUNK_TILES - 1) / AGDIFF_CHUNK_TILES;
   if (max_chunks == 0) return AGDIFF_OK;
   ConvArgs a;
@@ -530,7 +510,7 @@ extern "C" int agdiff_cfconv_fused(const agdiff_params_t* p, const agdiff_topo_t
   a.e_src = ws->e_src;
   a.e_dst = ws->e_dst;
   {
-    const size_t epad = (size_t)max_tiles * 32;
+    const size_t epad = (size_t)max_tiles * AG_TW;
     a.scale1 = ws->e_scale + (size_t)(2 * k) * epad;
     a.scale2 = ws->e_scale + (size_t)(2 * k + 1) * epad;
   }
@@ -553,10 +533,10 @@ extern "C" int agdiff_cfconv_fused(const agdiff_params_t* p, const agdiff_topo_t
     }
     a.stagger = stg;
   }
-  // persistent launch: one 8-wave workgroup per CU keeps 144 KiB of filter weights in LDS
+  // persistent launch: one 16-wave workgroup per CU keeps 144 KiB of filter weights in LDS
   int64_t wgs = (max_chunks + AG_CONV_WAVES - 1) / AG_CONV_WAVES;
   if (wgs > 256) wgs = 256;
-  const size_t smem = (size_t)AG_CONV_LDS_BLOCKS * 4096 + (size_t)AG_CONV_WAVES * 6 * 64 * 4;
+  const size_t smem = (size_t)AG_CONV_LDS_BLOCKS * 2048 + (size_t)AG_CONV_WAVES * 192 * 4;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)k_cfconv_fused<AG_BF3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||

@@ -1,8 +1,7 @@
 // Per-node kernels: SchNet node stages (everything of InteractionBlock / AdaptiveScaling that is not
-// per-edge), GIN layers, and the per-molecule Langevin update.  One wave = one tile of 32 nodes in
+// per-edge), GIN layers, and the per-molecule Langevin update.  One wave = one tile of 16 nodes in
 // the MFMA accumulator layout (common.hpp): lane <-> node, registers <-> features.
 #include "common.hpp"
-#include <type_traits>
 
 namespace {
 
@@ -30,115 +29,112 @@ struct NodeStageArgs {
 //   stage 0 (finish == 0): h = embedding[z]                       (schnet.py:271)
 template <int MODE>
 __global__ void __launch_bounds__(AG_WG, 2) k_schnet_node_stage(NodeStageArgs a) {
-  const int lane = ag_lane(), h = lane >> 5;
+  const int lane = ag_lane(), q = lane >> 4;
   const int64_t tile = (int64_t)blockIdx.x * 4 + ag_wave_in_wg();
-  if (tile * 32 >= a.n) return;
-  const int64_t node = tile * 32 + (lane & 31);
+  if (tile * AG_TW >= a.n) return;
+  const int64_t node = tile * AG_TW + (lane & 15);
   const bool valid = node < a.n;
   const int64_t nd = valid ? node : 0;
+  constexpr int PF = AgPF<MODE>::v;
 
-  f32x16 hv[4];
+  f32x4 hv[8];
   if (!a.finish) {
-    ag_load_row<4, 0>(hv, a.emb + (size_t)a.atom_type[nd] * 128, h);
+    ag_load_row<8, 0>(hv, a.emb + (size_t)a.atom_type[nd] * 128, q);
   } else {
-    f32x16 u[8];
+    f32x4 xc[8];
+    ag_init_vec<8>(xc, a.prev.lin_b, q);
     {
-      // aggregates: agg[node] (+ the partial its last chunk kept separately, edge.hip k_cfconv_fused)
-      const int lo = a.in_ptr[nd], hi = a.in_ptr[nd + 1];
-      const int chunk_e = 32 * AGDIFF_CHUNK_TILES;
-      const bool has = hi > lo;
-      const int c_lo = lo / chunk_e, c_hi = has ? (hi - 1) / chunk_e : c_lo;
-      const float* ar = a.agg + (size_t)nd * 192;
-      const float* fr = a.agg_first + (size_t)c_hi * 192;
-      const bool split = has && (c_hi > c_lo);
-      ag_init_vec<8>(u, a.prev.lin2_b, h);
-      AgIn<MODE> g[2];
-      auto load_slice = [&](AgIn<MODE>& dst, int k) {
-        f32x16 raw;
+      f32x4 u[16];
+      {
+        // aggregates: agg[node] (+ the partial its last chunk kept separately, edge.hip k_cfconv_fused)
+        const int lo = a.in_ptr[nd], hi = a.in_ptr[nd + 1];
+        const int chunk_e = AG_TW * AGDIFF_CHUNK_TILES;
+        const bool has = hi > lo;
+        const int c_lo = lo / chunk_e, c_hi = has ? (hi - 1) / chunk_e : c_lo;
+        const float* ar = a.agg + (size_t)nd * 192;
+        const float* fr = a.agg_first + (size_t)c_hi * 192;
+        const bool split = has && (c_hi > c_lo);
+        ag_init_vec<16>(u, a.prev.lin2_b, q);
+        AgIn<MODE> g[2];
+        auto load_slice = [&](AgIn<MODE>& dst, int k) {
+          f32x4 v0 = has ? ag_ld4(ar + 32 * k + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+          f32x4 v1 = has ? ag_ld4(ar + 32 * k + 16 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+          if (split) {
+            v0 += ag_ld4(fr + 32 * k + 4 * q);
+            v1 += ag_ld4(fr + 32 * k + 16 + 4 * q);
+          }
+          ag_cvt(v0, v1, dst);
+        };
+        load_slice(g[0], 0);
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-          const int f = 32 * k + 8 * rq + 4 * h;
-          f32x4 v = has ? ag_ld4(ar + f) : f32x4{0.f, 0.f, 0.f, 0.f};
-          if (split) v += ag_ld4(fr + f);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) raw[4 * rq + q] = v[q];
-        }
-        ag_cvt(raw, dst);
-      };
-      load_slice(g[0], 0);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        if (k + 1 < 6) load_slice(g[(k + 1) & 1], k + 1);
-        // conv1.lin2: slices 0..3 -> u[0..3]; conv2.lin2: slices 4..5 -> u[4..7]   (pkk blocks)
-        if (k < 4) {
-          if (k & 1) ag_dense_std_k<MODE, 1, 4, 1, 0>(g, u, ag_wblock(a.prev.lin2a_pk, k * 4), lane);
-          else ag_dense_std_k<MODE, 1, 4, 0, 0>(g, u, ag_wblock(a.prev.lin2a_pk, k * 4), lane);
-        } else {
-          if (k & 1) ag_dense_std_k<MODE, 1, 4, 1, 4>(g, u, ag_wblock(a.prev.lin2b_pk, (k - 4) * 4), lane);
-          else ag_dense_std_k<MODE, 1, 4, 0, 4>(g, u, ag_wblock(a.prev.lin2b_pk, (k - 4) * 4), lane);
+        for (int k = 0; k < 6; ++k) {
+          if (k + 1 < 6) load_slice(g[(k + 1) & 1], k + 1);
+          // conv1.lin2: k-tiles 0..3 -> u[0..7]; conv2.lin2: k-tiles 4..5 -> u[8..15]   (pkk blocks)
+          if (k < 4) {
+            if (k & 1) ag_dense<MODE, false, true, 1, 8, 1, 0, PF>(g, u, ag_wblock(a.prev.lin2a_pk, k * 8), lane);
+            else ag_dense<MODE, false, true, 1, 8, 0, 0, PF>(g, u, ag_wblock(a.prev.lin2a_pk, k * 8), lane);
+          } else {
+            if (k & 1) ag_dense<MODE, false, true, 1, 8, 1, 8, PF>(g, u, ag_wblock(a.prev.lin2b_pk, (k - 4) * 8), lane);
+            else ag_dense<MODE, false, true, 1, 8, 0, 8, PF>(g, u, ag_wblock(a.prev.lin2b_pk, (k - 4) * 8), lane);
+          }
         }
       }
-    }
-    {
-      const float beta = a.prev.act_beta;
-      AG_FOR_TILE(u, 8, ag_ssp(beta, v));
-    }
-    f32x16 xc[4];
-    ag_init_vec<4>(xc, a.prev.lin_b, h);
-    {
+      {
+        const float beta = a.prev.act_beta;
+        AG_FOR_TILE(u, 16, ag_ssp(beta, v));
+      }
       AgIn<MODE> ub[8];
       ag_cvt_tiles<MODE, 8, 0>(u, ub);
-      ag_dense_std<MODE, 8, 4, 0, 0, 4>(ub, xc, a.prev.lin_pk, lane);
+      ag_dense<MODE, false, false, 8, 8, 0, 0, PF>(ub, xc, a.prev.lin_pk, lane);
     }
     {
-      f32x16 g1[2];
-      ag_init_vec<2>(g1, a.prev.gate1_b, h);
+      f32x4 g1[4];
+      ag_init_vec<4>(g1, a.prev.gate1_b, q);
       {
         AgIn<MODE> xb[4];
         ag_cvt_tiles<MODE, 4, 0>(xc, xb);
-        ag_dense_std<MODE, 4, 2, 0, 0, 4>(xb, g1, a.prev.gate1_pk, lane);
+        ag_dense<MODE, false, false, 4, 4, 0, 0, PF>(xb, g1, a.prev.gate1_pk, lane);
       }
-      AG_FOR_TILE(g1, 2, ag_relu(v));
-      const float gate = ag_sigmoid(ag_dot_vec<2>(g1, a.prev.gate2_w, h) + a.prev.gate2_b);
-      AG_FOR_TILE(xc, 4, v * gate);
+      AG_FOR_TILE(g1, 4, ag_relu(v));
+      const float gate = ag_sigmoid(ag_dot_vec<4>(g1, a.prev.gate2_w, q) + a.prev.gate2_b);
+      AG_FOR_TILE(xc, 8, v * gate);
     }
     {
-      f32x16 s1[1], s2[4];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s1[0][r] = 0.0f;
+      // AdaptiveScaling: 128 -> 8 (one 16-row output tile, rows 8..15 zero) -> relu -> 8 -> 128 (one k-tile,
+      // input features 8..31 zero)
+      f32x4 s1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      f32x4 s2[8];
       {
         AgIn<MODE> xb[4];
         ag_cvt_tiles<MODE, 4, 0>(xc, xb);
-        ag_dense_std<MODE, 4, 1, 0, 0, 4>(xb, s1, a.prev.scale1_pk, lane);
+        ag_dense<MODE, false, false, 4, 1, 0, 0, PF>(xb, s1, a.prev.scale1_pk, lane);
       }
       AG_FOR_TILE(s1, 1, ag_relu(v));
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s2[t][r] = 0.0f;
+      for (int t = 0; t < 8; ++t) s2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       {
         AgIn<MODE> sb[1];
         ag_cvt_tiles<MODE, 1, 0>(s1, sb);
-        ag_dense_std<MODE, 1, 4, 0, 0, 1>(sb, s2, a.prev.scale2_pk, lane);
+        ag_dense<MODE, false, false, 1, 8, 0, 0, PF>(sb, s2, a.prev.scale2_pk, lane);
       }
-      ag_load_row<4, 0>(hv, a.h + (size_t)nd * 128, h);
+      ag_load_row<8, 0>(hv, a.h + (size_t)nd * 128, q);
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 8; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) hv[t][r] = hv[t][r] + xc[t][r] * ag_sigmoid(s2[t][r]);
+        for (int r = 0; r < 4; ++r) hv[t][r] = hv[t][r] + xc[t][r] * ag_sigmoid(s2[t][r]);
     }
   }
-  if (valid) ag_store_row<4, 0>(hv, a.h + (size_t)node * 128, h);
+  if (valid) ag_store_row<8, 0>(hv, a.h + (size_t)node * 128, q);
   if (a.prep) {
-    f32x16 xo[6];
-    ag_init_vec<6>(xo, a.next.lin1_b, h);
+    f32x4 xo[12];
+    ag_init_vec<12>(xo, a.next.lin1_b, q);
     {
       AgIn<MODE> hb[4];
       ag_cvt_tiles<MODE, 4, 0>(hv, hb);
-      ag_dense_std<MODE, 4, 6, 0, 0, 4>(hb, xo, a.next.lin1_pk, lane);
+      ag_dense<MODE, false, false, 4, 12, 0, 0, PF>(hb, xo, a.next.lin1_pk, lane);
     }
-    AG_FOR_TILE(xo, 6, ag_lrelu(v));
-    if (valid) ag_store_row<6, 0>(xo, a.xs + (size_t)node * 192, h);
+    AG_FOR_TILE(xo, 12, ag_lrelu(v));
+    if (valid) ag_store_row<12, 0>(xo, a.xs + (size_t)node * 192, q);
   }
 }
 
@@ -160,19 +156,18 @@ struct GinArgs {
 // u = MLP(m_i + (1+eps) h_i); u = BN(u) (folded); relu except last layer; h = u + h.
 template <int MODE>
 __global__ void __launch_bounds__(AG_WG, 2) k_gin_layer(GinArgs a) {
-  const int lane = ag_lane(), h = lane >> 5;
+  const int lane = ag_lane(), q = lane >> 4;
   const int64_t tile = (int64_t)blockIdx.x * 4 + ag_wave_in_wg();
-  if (tile * 32 >= a.n) return;
-  const int64_t node = tile * 32 + (lane & 31);
+  if (tile * AG_TW >= a.n) return;
+  const int64_t node = tile * AG_TW + (lane & 15);
   const bool valid = node < a.n;
   const int64_t nd = valid ? node : 0;
   const float* hin_self = a.emb ? a.emb + (size_t)a.atom_type[nd] * 128 : a.h_in + (size_t)nd * 128;
+  constexpr int PF = AgPF<MODE>::v;
 
-  f32x16 m[4];
+  f32x4 m[8];
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) m[t][r] = 0.0f;
+  for (int t = 0; t < 8; ++t) m[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int lo = a.loc_in_ptr[nd], hi = valid ? a.loc_in_ptr[nd + 1] : lo;
   int maxdeg = hi - lo;
 #pragma unroll
@@ -181,47 +176,41 @@ __global__ void __launch_bounds__(AG_WG, 2) k_gin_layer(GinArgs a) {
     const bool on = lo + k < hi;
     const int eid = on ? a.loc_in_eid[lo + k] : 0;
     const int src = on ? a.loc_src[eid] : 0;
-    const float* hs = a.emb ? a.emb + (size_t)a.atom_type[src] * 128 : a.h_in + (size_t)src * 128;
+    const float* hsrc = a.emb ? a.emb + (size_t)a.atom_type[src] * 128 : a.h_in + (size_t)src * 128;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 8; ++t) {
+      const int f = 16 * t + 4 * q;
+      const f32x4 hvv = ag_ld4(hsrc + f);
+      const f32x4 ev = ag_attr_gather4<MODE>(a.l_attr, eid, f);
 #pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const int f = 32 * t + 8 * rq + 4 * h;
-        const f32x4 hvv = ag_ld4(hs + f);
-        const f32x4 ev = ag_attr_gather4<MODE>(a.l_attr, eid, f);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) m[t][4 * rq + q] += on ? ag_relu(hvv[q] + ev[q]) : 0.0f;
-      }
+      for (int r = 0; r < 4; ++r) m[t][r] += on ? ag_relu(hvv[r] + ev[r]) : 0.0f;
+    }
   }
-  f32x16 hs[4];
-  ag_load_row<4, 0>(hs, hin_self, h);
+  f32x4 hself[8];
+  ag_load_row<8, 0>(hself, hin_self, q);
   {
     const float ope = a.gp.one_plus_eps;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) m[t][r] = m[t][r] + ope * hs[t][r];
+    for (int t = 0; t < 8; ++t) m[t] = m[t] + ope * hself[t];
   }
-  f32x16 y1[4];
-  ag_init_vec<4>(y1, a.gp.b1, h);
+  f32x4 y1[8];
+  ag_init_vec<8>(y1, a.gp.b1, q);
   {
     AgIn<MODE> mb[4];
     ag_cvt_tiles<MODE, 4, 0>(m, mb);
-    ag_dense_std<MODE, 4, 4, 0, 0, 4>(mb, y1, a.gp.w1_pk, lane);
+    ag_dense<MODE, false, false, 4, 8, 0, 0, PF>(mb, y1, a.gp.w1_pk, lane);
   }
-  AG_FOR_TILE(y1, 4, ag_relu(v));
-  ag_init_vec<4>(m, a.gp.b2, h);
+  AG_FOR_TILE(y1, 8, ag_relu(v));
+  ag_init_vec<8>(m, a.gp.b2, q);
   {
     AgIn<MODE> yb[4];
     ag_cvt_tiles<MODE, 4, 0>(y1, yb);
-    ag_dense_std<MODE, 4, 4, 0, 0, 4>(yb, m, a.gp.w2_pk, lane);
+    ag_dense<MODE, false, false, 4, 8, 0, 0, PF>(yb, m, a.gp.w2_pk, lane);
   }
-  if (a.gp.relu_out) { AG_FOR_TILE(m, 4, ag_relu(v)); }
+  if (a.gp.relu_out) { AG_FOR_TILE(m, 8, ag_relu(v)); }
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) m[t][r] += hs[t][r];
-  if (valid) ag_store_row<4, 0>(m, a.h_out + (size_t)node * 128, h);
+  for (int t = 0; t < 8; ++t) m[t] += hself[t];
+  if (valid) ag_store_row<8, 0>(m, a.h_out + (size_t)node * 128, q);
 }
 
 // ------------------------------------------------------------------------------ Langevin update
@@ -367,7 +356,7 @@ extern "C" int agdiff_schnet_node_stage(const agdiff_params_t* p, const agdiff_t
   a.h = ws->h;
   a.xs = ws->xs;
   a.n = topo->num_nodes;
-  const int64_t tiles = (a.n + 31) / 32;
+  const int64_t tiles = (a.n + AG_TW - 1) / AG_TW;
   if (p->precision == AG_BF3)
     k_schnet_node_stage<AG_BF3><<<dim3((unsigned)((tiles + 3) / 4)), dim3(AG_WG), 0, (hipStream_t)stream>>>(a);
   else
@@ -379,7 +368,7 @@ extern "C" int agdiff_schnet_node_stage(const agdiff_params_t* p, const agdiff_t
 extern "C" int agdiff_gin_encoder(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, void* stream) {
   if (!p || !topo || !ws || p->num_convs_local <= 0 || p->num_convs_local > AGDIFF_MAX_CONVS_LOCAL) return AGDIFF_ERR_ARG;
   if (topo->num_nodes <= 0) return AGDIFF_OK;
-  const int64_t tiles = (topo->num_nodes + 31) / 32;
+  const int64_t tiles = (topo->num_nodes + AG_TW - 1) / AG_TW;
   // ping-pong so that the final layer lands in ws->hl
   float* bufs[2] = {ws->hl, ws->hl2};
   int cur = (p->num_convs_local & 1) ? 0 : 1;   // layer 0 writes bufs[cur]; the last write must hit bufs[0]

@@ -29,57 +29,65 @@ def bf16_round(x32):
     return r.astype(np.uint16), (r << 16).astype(np.uint32).view(np.float32)
 
 
-def pack_blocks_bf3(W, kouter=False):
-    """Split-bf16 packing (precision 1): block(mt, t)[s][part][lane][j], part 0 = hi = bf16(w), part 1 = lo =
-    bf16(w - hi), with w = W[32*mt + (lane & 31)][32*t + 16*s + 8*(j >> 2) + 4*(lane >> 5) + (j & 3)].
-    Same 4 KiB per block as the fp32 packing; returned as a float32 view of the bf16 bit patterns."""
-    W = np.asarray(W, dtype=np.float64)
-    out, inn = W.shape
-    MT, KT = (out + 31) // 32, (inn + 31) // 32
-    Wp = np.zeros((MT * 32, KT * 32), dtype=np.float32)
-    Wp[:out, :inn] = W.astype(np.float32)
+def _block_columns():
+    """Input-feature offsets (within a 32-feature k-tile) held by each lane of a weight block:
+    cols[lane][j], j = 0..7: {4q..4q+3} then {16+4q..16+4q+3}, q = lane >> 4 (csrc/common.hpp)."""
     lane = np.arange(64)
     j = np.arange(8)
-    sidx = np.arange(2)
-    rows = (lane & 31)[None, :, None]                                                       # [1,64,1]
-    cols = (16 * sidx[:, None, None] + 8 * (j >> 2)[None, None, :] + 4 * (lane >> 5)[None, :, None]
-            + (j & 3)[None, None, :])                                                       # [2,64,8]
-    blocks = np.empty((MT, KT, 2, 2, 64, 8), dtype=np.uint16)
-    for mt in range(MT):
-        for t in range(KT):
-            w = Wp[32 * mt + rows, 32 * t + cols]                                           # [2,64,8] fp32
-            hb, hv = bf16_round(w)
-            lb, _ = bf16_round(w - hv)
-            blocks[mt, t, :, 0] = hb
-            blocks[mt, t, :, 1] = lb
-    if kouter:
-        blocks = blocks.transpose(1, 0, 2, 3, 4, 5)
-    return np.ascontiguousarray(blocks).reshape(-1).view(np.float32)
+    return 16 * (j >> 2)[None, :] + 4 * (lane >> 4)[:, None] + (j & 3)[None, :]      # [64, 8]
 
 
 def pack_blocks(W, kouter=False, mode=0):
-    """Linear weight W[out, in] -> MFMA-fragment-major blocks (see include/agdiff_hip.h):
-    block(mt, t)[rq][lane][q] = W[32*mt + (lane & 31)][32*t + 8*rq + 4*(lane >> 5) + q];
-    blocks ordered [MT][KT] ("pk") or [KT][MT] ("pkk").  mode 1 -> pack_blocks_bf3."""
-    if mode == 1:
-        return pack_blocks_bf3(W, kouter)
+    """Linear weight W[out, in] -> MFMA-operand-major 2-KiB blocks of 16 outputs x 32 inputs
+    (include/agdiff_hip.h): lane l of block (ot, t) holds W[16*ot + (l & 15)][32*t + cols[l][0..7]].
+      mode 0 (fp32):   unit u = fp32 of elements 4u..4u+3                      -> [2][64][4] floats
+      mode 1 (bf16x3): unit 0 = bf16(w) of the 8 elements, unit 1 = bf16(w - hi) -> [2][64][8] bf16
+    Blocks are ordered [OT][KT] ("pk") or [KT][OT] ("pkk", kouter).  Returned as a float32 array
+    (bf16 bit patterns viewed as float32 in mode 1)."""
     W = np.asarray(W, dtype=np.float64)
     out, inn = W.shape
-    MT, KT = (out + 31) // 32, (inn + 31) // 32
-    Wp = np.zeros((MT * 32, KT * 32), dtype=np.float64)
+    OT, KT = (out + 15) // 16, (inn + 31) // 32
+    Wp = np.zeros((OT * 16, KT * 32), dtype=np.float64)
     Wp[:out, :inn] = W
-    lane = np.arange(64)
-    rq = np.arange(4)
-    q = np.arange(4)
-    rows = (lane & 31)[None, :, None]                                   # [1,64,1]
-    cols = 8 * rq[:, None, None] + 4 * (lane >> 5)[None, :, None] + q[None, None, :]   # [4,64,4]
-    blocks = np.empty((MT, KT, 4, 64, 4), dtype=np.float64)
-    for mt in range(MT):
+    rows = (np.arange(64) & 15)[:, None]                   # [64, 1]
+    cols = _block_columns()                                # [64, 8]
+    vals = np.empty((OT, KT, 64, 8), dtype=np.float32)
+    for ot in range(OT):
         for t in range(KT):
-            blocks[mt, t] = Wp[32 * mt + rows, 32 * t + cols]
+            vals[ot, t] = Wp[16 * ot + rows, 32 * t + cols].astype(np.float32)
     if kouter:
-        blocks = blocks.transpose(1, 0, 2, 3, 4)
-    return np.ascontiguousarray(blocks).astype(np.float32).reshape(-1)
+        vals = vals.transpose(1, 0, 2, 3)
+    vals = np.ascontiguousarray(vals)
+    nb = OT * KT
+    if mode == 0:
+        # [block][lane][u][4] -> [block][u][lane][4]
+        return np.ascontiguousarray(vals.reshape(nb, 64, 2, 4).transpose(0, 2, 1, 3)).reshape(-1)
+    hb, hv = bf16_round(vals)
+    lb, _ = bf16_round(vals - hv)
+    blk = np.stack([hb.reshape(nb, 64, 8), lb.reshape(nb, 64, 8)], axis=1)      # [block][part][lane][8]
+    return np.ascontiguousarray(blk).reshape(-1).view(np.float32)
+
+
+def unpack_blocks(flat, out, inn, kouter=False, mode=0):
+    """Inverse of pack_blocks (tests): fp32 W[out, in] (hi + lo in mode 1)."""
+    OT, KT = (out + 15) // 16, (inn + 31) // 32
+    nb = OT * KT
+    if mode == 0:
+        vals = np.asarray(flat, dtype=np.float32).reshape(nb, 2, 64, 4).transpose(0, 2, 1, 3).reshape(nb, 64, 8)
+    else:
+        u = np.ascontiguousarray(flat).view(np.uint16).reshape(nb, 2, 64, 8).astype(np.uint32)
+        v = (u << 16).view(np.float32)
+        vals = v[:, 0] + v[:, 1]
+    vals = vals.reshape((KT, OT, 64, 8) if kouter else (OT, KT, 64, 8))
+    if kouter:
+        vals = vals.transpose(1, 0, 2, 3)
+    W = np.zeros((OT * 16, KT * 32), dtype=np.float32)
+    rows = (np.arange(64) & 15)[:, None]
+    cols = _block_columns()
+    for ot in range(OT):
+        for t in range(KT):
+            W[16 * ot + rows, 32 * t + cols] = vals[ot, t]
+    return W[:out, :inn]
 
 
 def fold_bn(W, b, sd, p, eps=1e-5):

@@ -115,8 +115,9 @@ class Workspace:
         import torch
         dev = topo.device
         N, G, L, E = topo.N, topo.G, topo.L, topo.max_edges
-        etiles = (E + 31) // 32
-        ltiles = (L + 31) // 32
+        TW = _lib.TILE
+        etiles = (E + TW - 1) // TW
+        ltiles = (L + TW - 1) // TW
         chunks = (etiles + _lib.CHUNK_TILES - 1) // _lib.CHUNK_TILES
         i32 = lambda n: torch.zeros(max(int(n), 1), dtype=torch.int32, device=dev)
         f32 = lambda n: torch.zeros(max(int(n), 1), dtype=torch.float32, device=dev)
@@ -124,13 +125,13 @@ class Workspace:
         self.num_local = torch.tensor([L], dtype=torch.int32, device=dev)
         self.graph_edge_cnt, self.graph_edge_ptr = i32(G), i32(G + 1)
         self.in_ptr, self.out_ptr = i32(N + 1), i32(N + 1)
-        self.e_src, self.e_dst, self.e_type, self.ref2dst = i32(etiles * 32), i32(etiles * 32), i32(etiles * 32), i32(etiles * 32)
-        self.e_len = f32(etiles * 32)
-        self.e_attr = f32(etiles * 32 * 128)
-        self.e_inv_global = f32(etiles * 32)
-        self.e_scale = f32(2 * _lib.DEFINES["AGDIFF_MAX_CONVS"] * etiles * 32)
-        self.l_len, self.l_inv = f32(ltiles * 32), f32(ltiles * 32)
-        self.l_attr = f32(ltiles * 32 * 128)
+        self.e_src, self.e_dst, self.e_type, self.ref2dst = i32(etiles * TW), i32(etiles * TW), i32(etiles * TW), i32(etiles * TW)
+        self.e_len = f32(etiles * TW)
+        self.e_attr = f32(etiles * TW * 128)
+        self.e_inv_global = f32(etiles * TW)
+        self.e_scale = f32(2 * _lib.DEFINES["AGDIFF_MAX_CONVS"] * etiles * TW)
+        self.l_len, self.l_inv = f32(ltiles * TW), f32(ltiles * TW)
+        self.l_attr = f32(ltiles * TW * 128)
         self.h, self.xs, self.agg = f32(N * 128), f32(N * 192), f32(N * 192)
         self.agg_first = f32(chunks * 192)
         self.hl, self.hl2 = f32(N * 128), f32(N * 128)

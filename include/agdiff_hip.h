@@ -23,15 +23,15 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 5
+#define AGDIFF_ABI_VERSION 6
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
 #define AGDIFF_NUM_EDGE_TYPES 100  /* rows of bond_emb (edge.py:49) */
 #define AGDIFF_MAX_ATOMS_PER_GRAPH 512
 #define AGDIFF_RADIUS_CAP 33       /* max_num_neighbors + 1 (torch_cluster.radius_graph, common.py:217) */
-#define AGDIFF_TILE 32             /* edges / nodes per MFMA tile */
-#define AGDIFF_CHUNK_TILES 4       /* tiles per wave in the fused CFConv kernel */
+#define AGDIFF_TILE 16             /* edges / nodes per MFMA tile */
+#define AGDIFF_CHUNK_TILES 8       /* tiles per wave-chunk in the fused CFConv kernel (128 edges) */
 
 enum agdiff_status {
   AGDIFF_OK = 0,
@@ -41,53 +41,54 @@ enum agdiff_status {
 };
 
 /* ---- packed network weights (built by agdiff_amd/packing.py from the reference state_dict) ---
- * "pk" = MFMA-fragment-major packing [MT][KT][4][64][4] of a Linear weight W[out][in]
- * (MT = ceil(out/32), KT = ceil(in/32)), one 16-byte load per lane per four MFMAs:
- *   pk[((((mt*KT+t)*4+rq)*64+lane)*4)+q] = W[32*mt+(lane&31)][32*t+8*rq+4*(lane>>5)+q]
- * (zero where out/in exceed the layer).  "pkk" = the same 1024-float blocks in k-tile-outer order
- * [KT][MT][4][64][4], for layers whose input is streamed in 32-feature slices.  Vectors are in
- * natural feature order. */
+ * "pk" = MFMA-operand-major packing of a Linear weight W[out][in] in 2-KiB blocks of 16 outputs x 32 inputs
+ * (OT = ceil(out/16), KT = ceil(in/32), zero padded), blocks ordered [OT][KT]; "pkk" = the same blocks in
+ * k-tile-outer order [KT][OT], for layers whose input is streamed in 32-feature k-tiles.  Lane l of block
+ * (ot, t) holds the eight weights W[16*ot + (l&15)][32*t + c], c in {4q..4q+3, 16+4q..16+4q+3}, q = l>>4:
+ *   precision 0: two 16-byte units [u][lane][4 fp32] (elements 4u..4u+3)
+ *   precision 1: two 16-byte units [part][lane][8 bf16], part 0 = bf16(w), part 1 = bf16(w - hi)
+ * Dimensions in the field comments below are [OT][KT] block counts.  Vectors are in natural feature order. */
 typedef struct agdiff_conv_params {
   /* CFConv filter networks of one InteractionBlock (schnet.py:169-186), conv1 (F=128) and conv2 (F=64) fused */
-  const float* filt_w1a_pk;  /* pkk [4][4]: conv1.nn.0 (128 -> 128) */
-  const float* filt_w1b_pk;  /* pkk [4][2]: conv2.nn.0 (128 -> 64) */
+  const float* filt_w1a_pk;  /* pkk [4][8]: conv1.nn.0 (128 -> 128) */
+  const float* filt_w1b_pk;  /* pkk [4][4]: conv2.nn.0 (128 -> 64) */
   const float* filt_b1;      /* [192] */
-  const float* filt_w2a_pk;  /* [4][4]: conv1.nn.2 */
-  const float* filt_w2b_pk;  /* [2][2]: conv2.nn.2 */
+  const float* filt_w2a_pk;  /* pk [8][4]: conv1.nn.2 */
+  const float* filt_w2b_pk;  /* pk [4][2]: conv2.nn.2 */
   const float* filt_b2;      /* [192] */
   const float* dist_w;       /* [2][97]: DistanceWeightingNetwork (schnet.py:83-100): w1[32] b1[32] w2[32] b2 */
   float ssp_beta1;           /* conv1.nn.1.beta */
   float ssp_beta2;           /* conv2.nn.1.beta */
   /* node side of the block (schnet.py:153-158, 201-216, 219-234) */
-  const float* lin1_pk;      /* [6][4]: BN-folded conv1.lin1 (rows 0..127) and conv2.lin1 (128..191) */
+  const float* lin1_pk;      /* pk [12][4]: BN-folded conv1.lin1 (rows 0..127) and conv2.lin1 (128..191) */
   const float* lin1_b;       /* [192] */
-  const float* lin2a_pk;     /* pkk [4][4]: BN-folded conv1.lin2 */
-  const float* lin2b_pk;     /* pkk [2][4]: BN-folded conv2.lin2 */
+  const float* lin2a_pk;     /* pkk [4][8]: BN-folded conv1.lin2 */
+  const float* lin2b_pk;     /* pkk [2][8]: BN-folded conv2.lin2 */
   const float* lin2_b;       /* [256] */
-  const float* lin_pk;       /* [4][8]: InteractionBlock.lin (256->128) */
+  const float* lin_pk;       /* pk [8][8]: InteractionBlock.lin (256->128) */
   const float* lin_b;        /* [128] */
-  const float* gate1_pk;     /* [2][4]: attention.0 (128->64) */
+  const float* gate1_pk;     /* pk [4][4]: attention.0 (128->64) */
   const float* gate1_b;      /* [64] */
   const float* gate2_w;      /* [64]  attention.2 */
-  const float* scale1_pk;    /* [1][4]: scaling fc.0 (128->8, rows 8..31 zero) */
-  const float* scale2_pk;    /* [4][1]: scaling fc.2 (8->128, cols 8..31 zero) */
+  const float* scale1_pk;    /* pk [1][4]: scaling fc.0 (128->8, rows 8..15 zero) */
+  const float* scale2_pk;    /* pk [8][1]: scaling fc.2 (8->128, cols 8..31 zero) */
   float gate2_b;
   float act_beta;            /* InteractionBlock.act.beta */
 } agdiff_conv_params_t;
 
 typedef struct agdiff_gin_params {
-  const float* w1_pk;        /* [4][4] convs.k.nn.layers.0 */
+  const float* w1_pk;        /* pk [8][4] convs.k.nn.layers.0 */
   const float* b1;           /* [128] */
-  const float* w2_pk;        /* [4][4] BN-folded convs.k.nn.layers.1 */
+  const float* w2_pk;        /* pk [8][4] BN-folded convs.k.nn.layers.1 */
   const float* b2;           /* [128] */
   float one_plus_eps;
   int32_t relu_out;          /* 1 for all but the last layer (gin.py:134) */
 } agdiff_gin_params_t;
 
 typedef struct agdiff_head_params {
-  const float* w1_pk;        /* pkk [8][4] layers.0 (256->128) */
+  const float* w1_pk;        /* pkk [8][8] layers.0 (256->128) */
   const float* b1;           /* [128] */
-  const float* w2_pk;        /* [2][4] layers.1 (128->64) */
+  const float* w2_pk;        /* pk [4][4] layers.1 (128->64) */
   const float* b2;           /* [64] */
   const float* w3;           /* [64]  layers.2 */
   float b3;
@@ -102,10 +103,10 @@ typedef struct agdiff_params {
   const float* ee_fe_w;      /* [128] feature_expansion.weight[:,0] */
   const float* ee_fe_b;      /* [128] */
   const float* ee_t1;        /* [100][128]: edge_feature_mlp.0.weight[:,128:] @ bond_emb[t] + bias */
-  const float* ee_w1_pk;     /* [4][4]: edge_feature_mlp.0.weight[:,:128] */
+  const float* ee_w1_pk;     /* pk [8][4]: edge_feature_mlp.0.weight[:,:128] */
   const float* ee_t3;        /* [100][128]: comb.0.weight[:,128:] @ bond_emb[t] + comb.0.bias + comb.0.weight[:,:128] @ efm.2.bias */
-  const float* ee_w23_pk;    /* [4][4]: comb.0.weight[:,:128] @ edge_feature_mlp.2.weight */
-  const float* ee_w4_pk;     /* [4][4]: combination_mlp.2 */
+  const float* ee_w23_pk;    /* pk [8][4]: comb.0.weight[:,:128] @ edge_feature_mlp.2.weight */
+  const float* ee_w4_pk;     /* pk [8][4]: combination_mlp.2 */
   const float* ee_b4;        /* [128] */
   const float* schnet_emb;   /* [100][128] encoder_global.embedding (max_norm renorm applied to used rows) */
   const float* gin_emb;      /* [100][128] encoder_local.node_emb */
@@ -131,7 +132,7 @@ typedef struct agdiff_topo {
   int64_t num_local;         /* L: local edges, in reference order (sorted by (src, dst)) */
   int64_t max_edges;         /* capacity of the per-edge buffers: sum_i (33 + local in-degree_i) */
   int64_t max_atoms_per_graph; /* <= AGDIFF_MAX_ATOMS_PER_GRAPH */
-  int64_t max_in_degree;     /* max_i (33 + local in-degree_i) <= AGDIFF_TILE * AGDIFF_CHUNK_TILES */
+  int64_t max_in_degree;     /* max_i (33 + local in-degree_i) <= AGDIFF_TILE * AGDIFF_CHUNK_TILES = 128 */
   const int32_t* graph_ptr;  /* [G+1] node offsets */
   const int32_t* atom_type;  /* [N] */
   const int32_t* loc_src;    /* [L] */
@@ -156,12 +157,12 @@ typedef struct agdiff_ws {
   int32_t* e_type;           /* [max_edges] */
   float*   e_len;            /* [max_edges] */
   int32_t* ref2dst;          /* [max_edges]: reference position q -> destination-sorted id */
-  float*   e_attr;           /* [ceil(max_edges/32)][4][4][64][4] edge_attr, fragment-major */
+  float*   e_attr;           /* [ceil(max_edges/16)] tiles x 2048 floats: edge_attr in operand form (csrc/common.hpp) */
   float*   e_inv_global;     /* [max_edges] grad_global_dist_mlp output, destination-sorted */
-  float*   e_scale;          /* [2*num_convs][ceil(max_edges/32)*32]: lw(d)*C(d) of conv1 / conv2 of every block (schnet.py:138-149) */
+  float*   e_scale;          /* [2*num_convs][ceil(max_edges/16)*16]: lw(d)*C(d) of conv1 / conv2 of every block (schnet.py:138-149) */
   /* local edges (reference order) */
   float*   l_len;            /* [L] */
-  float*   l_attr;           /* [ceil(L/32)] tiles, fragment-major */
+  float*   l_attr;           /* [ceil(L/16)] tiles, operand form */
   float*   l_inv;            /* [L] grad_local_dist_mlp output */
   /* nodes */
   float*   h;                /* [N][128] SchNet node state */
@@ -208,7 +209,7 @@ int agdiff_local_lengths(const agdiff_topo_t* topo, const agdiff_ws_t* ws, const
 int agdiff_edge_scales(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, void* stream);
 
 /* MLPEdgeEncoder.forward (encoder/edge.py:84-103).  n_edges_dev: device scalar with the live edge
- * count (<= max_tiles*32); writes fragment-major edge_attr tiles. */
+ * count (<= max_tiles*16); writes operand-form edge_attr tiles. */
 int agdiff_edge_encoder(const agdiff_params_t* p, const int32_t* n_edges_dev, int64_t max_tiles,
                         const float* e_len, const int32_t* e_type, float* attr_frag, void* stream);
 

@@ -27,16 +27,16 @@ def _gpu_model(cfg, head_scale=1e-3, precision="bf16x3"):
 
 
 def unfrag(frag, n, precision):
-    """operand-form edge-attr tiles -> row-major [n][128] fp32 (csrc/common.hpp: edge-attr storage)."""
-    tiles = frag.numel() // (32 * 128)
-    if precision == "f32":      # [tile][t][rq][h][edge][q], feature = 32t + 8rq + 4h + q
-        x = frag.view(tiles, 4, 4, 2, 32, 4).permute(0, 4, 1, 2, 3, 5).reshape(tiles * 32, 128)
+    """operand-form edge-attr tiles (16 edges x 128 features, csrc/common.hpp) -> row-major [n][128] fp32."""
+    tiles = frag.numel() // (16 * 128)
+    if precision == "f32":      # [tile][t][u][q][edge][r], feature = 32t + 16u + 4q + r
+        x = frag.view(tiles, 4, 2, 4, 16, 4).permute(0, 4, 1, 2, 3, 5).reshape(tiles * 16, 128)
         return x[:n]
-    # bf16x3: [tile][t][s][part][h][edge][jq][q] bf16, feature = 32t + 16s + 8jq + 4h + q, value = hi + lo
-    u = frag.view(torch.int16).view(tiles, 4, 2, 2, 2, 32, 2, 4).to(torch.int32)
+    # bf16x3: [tile][t][part][q][edge][u][r] bf16, feature = 32t + 16u + 4q + r, value = hi + lo
+    u = frag.view(torch.int16).view(tiles, 4, 2, 4, 16, 2, 4).to(torch.int32)
     val = ((u & 0xFFFF) << 16).view(torch.float32)
-    val = val[:, :, :, 0] + val[:, :, :, 1]                     # [tile][t][s][h][edge][jq][q]
-    x = val.permute(0, 4, 1, 2, 5, 3, 6).reshape(tiles * 32, 128)
+    val = val[:, :, 0] + val[:, :, 1]                           # [tile][t][q][edge][u][r]
+    x = val.permute(0, 3, 1, 4, 2, 5).reshape(tiles * 16, 128)
     return x[:n]
 
 

@@ -10,7 +10,7 @@ import torch
 from helpers import GOLDEN, load_golden, rel_err, t
 from agdiff_amd import _lib, get_model, qm9_model_config, drugs_model_config, synth
 from agdiff_amd.config import Config
-from agdiff_amd.packing import PackedParams, pack_blocks, fold_bn
+from agdiff_amd.packing import PackedParams, pack_blocks, unpack_blocks, fold_bn
 from agdiff_amd.topology import BatchTopology
 from oracle import agdiff_oracle as O
 
@@ -66,28 +66,28 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.agdiff_cfconv_aggregate(None, None, None, None, ctypes.c_int64(0), 128, None, None) == -1
 
 
-def _unpack_blocks(flat, out, inn, kouter=False):
-    MT, KT = (out + 31) // 32, (inn + 31) // 32
-    b = flat.reshape((KT, MT, 4, 64, 4) if kouter else (MT, KT, 4, 64, 4))
-    W = np.zeros((MT * 32, KT * 32), dtype=np.float32)
-    for mt in range(MT):
-        for k in range(KT):
-            blk = b[k, mt] if kouter else b[mt, k]
-            for rq in range(4):
-                for lane in range(64):
-                    for q in range(4):
-                        W[32 * mt + (lane & 31), 32 * k + 8 * rq + 4 * (lane >> 5) + q] = blk[rq, lane, q]
-    return W[:out, :inn]
-
-
+@pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("shape,kouter", [((128, 128), False), ((192, 128), True), ((8, 128), False),
                                           ((128, 8), False), ((64, 64), False), ((128, 256), True)])
-def test_pack_blocks_roundtrip(shape, kouter):
+def test_pack_blocks_roundtrip(shape, kouter, mode):
     rng = np.random.default_rng(0)
     W = rng.standard_normal(shape).astype(np.float32)
-    flat = pack_blocks(W, kouter=kouter)
-    assert flat.dtype == np.float32 and flat.size == ((shape[0] + 31) // 32) * ((shape[1] + 31) // 32) * 1024
-    assert np.array_equal(_unpack_blocks(flat, *shape, kouter=kouter), W)
+    flat = pack_blocks(W, kouter=kouter, mode=mode)
+    assert flat.dtype == np.float32 and flat.size == ((shape[0] + 15) // 16) * ((shape[1] + 31) // 32) * 512
+    R = unpack_blocks(flat, *shape, kouter=kouter, mode=mode)
+    if mode == 0:
+        assert np.array_equal(R, W)
+    else:
+        assert np.abs(R - W).max() < 2.0 ** -15 * np.abs(W).max()      # hi + lo keeps ~16 bits
+
+
+def test_pack_blocks_lane_map():
+    """Spot-check the documented lane map (include/agdiff_hip.h) independently of unpack_blocks."""
+    W = np.arange(32 * 64, dtype=np.float32).reshape(32, 64)
+    flat = pack_blocks(W, mode=0).reshape(2, 2, 2, 64, 4)             # [ot][t][u][lane][4]
+    for (ot, t, u, lane, r) in [(0, 0, 0, 0, 0), (1, 1, 1, 37, 2), (0, 1, 0, 63, 3), (1, 0, 1, 16, 1)]:
+        q = lane >> 4
+        assert flat[ot, t, u, lane, r] == W[16 * ot + (lane & 15), 32 * t + 16 * u + 4 * q + r]
 
 
 def test_folded_edge_encoder_equals_oracle():
@@ -99,7 +99,7 @@ def test_folded_edge_encoder_equals_oracle():
     d = g["edge_length"].astype(np.float64)[:, 0]
     ty = g["edge_type"]
     V = lambda n: pk.view(n).numpy().astype(np.float64)
-    W = lambda n, o, i: _unpack_blocks(pk.view(n).numpy(), o, i).astype(np.float64)
+    W = lambda n, o, i: unpack_blocks(pk.view(n).numpy(), o, i).astype(np.float64)
     from scipy.special import erf
     gelu = lambda x: 0.5 * x * (1 + erf(x / np.sqrt(2)))
     x0 = gelu(d[:, None] * V("ee_fe_w")[None] + V("ee_fe_b")[None])
