@@ -136,37 +136,33 @@ __device__ unsigned long long ag_conv_stamp_acc[8];
 #endif
 
 #define AG_CONV_WAVES 16
-#define AG_CONV_LDS_BLOCKS 72   // resident 2-KiB weight blocks: filt_w1a (32) | filt_w2a (32) | filt_w2b (8)
+#define AG_CONV_LDS_BLOCKS 80   // resident 2-KiB weight blocks: filt_w1 (48: both convs' first layer) | filt_w2a (32)
 #define AG_CONV_NCH 12          // 16-channel tiles of the 192 filter channels (conv1: 0..7, conv2: 8..11)
 
 // encoder/schnet.py:136-162 for conv1 (F=128) and conv2 (F=64) of one InteractionBlock:
 //   W_e = nn(edge_attr_e) * (lw(d_e) * C(d_e));  agg[dst] += x[src] * W_e   (aggr='add')
 // Persistent launch, one 16-wave workgroup per CU (4 waves per SIMD).  Each wave walks AGDIFF_CHUNK_TILES
 // consecutive destination-sorted 16-edge tiles per chunk and keeps the running sum of the open target in
-// LDS; a target whose list started in an earlier chunk is written to agg_first[chunk] and added by the node
-// stage (fixed order -> bitwise reproducible, no atomics).
+// registers; a target whose list started in an earlier chunk is written to agg_first[chunk] and added by
+// the node stage (fixed order -> bitwise reproducible, no atomics).
 template <int MODE>
 __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 4) k_cfconv_fused(ConvArgs a) {
-  // LDS (156 KiB of the CU's 160): 144 KiB of filter weights resident for the whole launch -- conv1's first
-  // layer and both second layers -- plus the carry rows (waves x 192 floats).  Only conv2's first layer
-  // (16 blocks per tile) is streamed from L2.
+  // LDS: all 160 KiB hold filter weights for the whole launch -- the fused first layer of both convs (96 KiB)
+  // and conv1's second layer (64 KiB).  Only conv2's second layer (8 blocks = 16 KiB per tile) is streamed
+  // from L2, fetched two channel tiles ahead of its use.
   extern __shared__ u32x4 ag_conv_smem[];
-  lds_u32x4* w1a = (lds_u32x4*)ag_conv_smem;
-  lds_u32x4* w2 = w1a + 32 * 128;
+  lds_u32x4* w1 = (lds_u32x4*)ag_conv_smem;
+  lds_u32x4* w2a = w1 + 48 * 128;
   {
-    const u32x4* g1 = reinterpret_cast<const u32x4*>(a.cp.filt_w1a_pk);
+    const u32x4* g1 = reinterpret_cast<const u32x4*>(a.cp.filt_w1_pk);
     const u32x4* ga = reinterpret_cast<const u32x4*>(a.cp.filt_w2a_pk);
-    const u32x4* gb = reinterpret_cast<const u32x4*>(a.cp.filt_w2b_pk);
-    for (int i = threadIdx.x; i < 32 * 128; i += blockDim.x) w1a[i] = g1[i];
-    for (int i = threadIdx.x; i < 32 * 128; i += blockDim.x) w2[i] = ga[i];
-    for (int i = threadIdx.x; i < 8 * 128; i += blockDim.x) w2[32 * 128 + i] = gb[i];
+    for (int i = threadIdx.x; i < 48 * 128; i += blockDim.x) w1[i] = g1[i];
+    for (int i = threadIdx.x; i < 32 * 128; i += blockDim.x) w2a[i] = ga[i];
   }
   __syncthreads();
   const int lane0 = ag_lane();
   const int wave = threadIdx.x >> 6;
   const int E = *a.n_dev;
-  // running sums (192 channels) of target run_t, whose list is still open
-  float* carry = reinterpret_cast<float*>(ag_conv_smem + AG_CONV_LDS_BLOCKS * 128) + wave * 192;
   const int64_t cstride = (int64_t)gridDim.x * AG_CONV_WAVES;
   [[maybe_unused]] unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c0 = 0, c1 = 0;
 
@@ -174,6 +170,9 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 4) k_cfconv_fused(ConvArgs
     const int64_t e_begin = chunk * (AG_TW * AGDIFF_CHUNK_TILES);
     if (e_begin >= E) break;
     int run_t = -1;
+    // running sums (192 channels: entry i = channel 16 i + (lane & 15), replicated over the quarters) of
+    // target run_t, whose list is still open
+    float carry[AG_CONV_NCH];
 
     auto dest = [&](int t) -> float* {
       const int lo = a.in_ptr[t];
@@ -203,7 +202,7 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 4) k_cfconv_fused(ConvArgs
         float* dp = dest(run_t);
         if (lane < 16) {
 #pragma unroll
-          for (int i = 0; i < AG_CONV_NCH; ++i) dp[16 * i + col] = carry[16 * i + col];
+          for (int i = 0; i < AG_CONV_NCH; ++i) dp[16 * i + col] = carry[i];
         }
         run_t = -1;
       }
@@ -214,64 +213,35 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 4) k_cfconv_fused(ConvArgs
       {
         f32x4 hid[AG_CONV_NCH];
         {
-          // first filter layer, k-tile outer: per k-tile t, conv1's eight output tiles from LDS-resident
-          // blocks, conv2's four from blocks streamed from L2; the streamed set is refilled for the next
-          // k-tile right after its last use (8 LDS-fed blocks of lookahead).
+          // first filter layer of both convs (128 -> 192), k-tile outer, all 48 weight blocks from LDS
           AgIn<MODE> ea[4];
           ag_init_vec<AG_CONV_NCH>(hid, a.cp.filt_b1, q);
 #pragma unroll
           for (int t = 0; t < 4; ++t) ag_load_attr(ea[t], a.e_attr, tile, t, lane);
-          if (!(a.ablate & 1)) {
-            // Streamed blocks are consumed in storage order (pkk: [t][b]), one after every two LDS-fed
-            // blocks; a 2-block register ring keeps the loads two streamed blocks (six MFMA blocks) ahead.
-            const u32x4* gl = reinterpret_cast<const u32x4*>(a.cp.filt_w1b_pk) + lane;
-            u32x4 g[2][2];
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-              g[b][0] = gl[(b * 2) * 64];
-              g[b][1] = gl[(b * 2 + 1) * 64];
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-#pragma unroll
-              for (int b = 0; b < 4; ++b) {
-                const int n = t * 4 + b;             // streamed block index
-#pragma unroll
-                for (int o = 0; o < 2; ++o) {
-                  u32x4 w[2];
-                  w[0] = w1a[((t * 8 + 2 * b + o) * 2) * 64 + lane];
-                  w[1] = w1a[((t * 8 + 2 * b + o) * 2 + 1) * 64 + lane];
-                  ag_block_mma<MODE, false>(hid[2 * b + o], ea[t], w);
-                }
-                ag_block_mma<MODE, false>(hid[8 + b], ea[t], g[n & 1]);
-                if (n + 2 < 16) {
-                  g[n & 1][0] = gl[((n + 2) * 2) * 64];
-                  g[n & 1][1] = gl[((n + 2) * 2 + 1) * 64];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-              }
-            }
-          }
+          if (!(a.ablate & 1)) ag_dense_lds<MODE, false, true, 4, AG_CONV_NCH, 0, 0>(ea, hid, w1, lane);
         }
         AG_STAMP(c1); st[1] += c1 - c0; c0 = c1;     // layer 1
-        // ssp, then fold the per-edge scale lw(d)*C(d) (a per-lane scalar here) into the hidden layer:
-        // (s.H)^T W2 + s.b2 == s.(H^T W2 + b2)
+        if (!(a.ablate & 2)) {
 #pragma unroll
-        for (int t = 0; t < AG_CONV_NCH; ++t) {
-          const float beta = (t < 8) ? a.cp.ssp_beta1 : a.cp.ssp_beta2;
-          const float sc = (t < 8) ? s1 : s2;
-          if (!(a.ablate & 2)) {
+          for (int t = 0; t < AG_CONV_NCH; ++t) {
+            const float beta = (t < 8) ? a.cp.ssp_beta1 : a.cp.ssp_beta2;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) hid[t][r] = ag_ssp(beta, hid[t][r]) * sc;
+            for (int r = 0; r < 4; ++r) hid[t][r] = ag_ssp(beta, hid[t][r]);
           }
         }
         ag_cvt_tiles<MODE, 6, 0>(hid, hidb);
       }
       AG_STAMP(c1); st[2] += c1 - c0; c0 = c1;       // ssp + split
-      // gather row of every edge slot my quarter owns: slot 4q + r lives in lane 4q + r
+      // per edge slot of my quarter (slot 4q + r lives in lane 4q + r): gather row of x, and the scales
+      // lw(d)*C(d) of the two convs, which multiply the message: (H^T W2 + b2) . s . x[src]
       uint32_t xoff[4];
+      f32x4 sr1, sr2;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) xoff[r] = (uint32_t)__shfl(my_src, 4 * q + r) * 192u + (uint32_t)col;
+      for (int r = 0; r < 4; ++r) {
+        xoff[r] = (uint32_t)__shfl(my_src, 4 * q + r) * 192u + (uint32_t)col;
+        sr1[r] = __shfl(s1, 4 * q + r);
+        sr2[r] = __shfl(s2, 4 * q + r);
+      }
       // list boundaries of the targets present in this tile, one per lane (in_ptr[t0 + lane]); the
       // reduction loops read them with readlane instead of dependent global loads
       const int ntg = t1 - t0 + 1;
@@ -293,10 +263,8 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 4) k_cfconv_fused(ConvArgs
 #pragma unroll
         for (int r = 0; r < 4; ++r) xg[r] = xb[xoff[r]];
       };
-      auto channel_tile = [&](f32x4& z, int nt) {
-        z *= xg;
-        if (nt + 1 < AG_CONV_NCH) fetch_x(nt + 1);
-        if (a.ablate & 16) { carry[16 * nt + col] = z[0]; return; }
+      auto reduce_tile = [&](f32x4 z, int nt, float& cr) {
+        if (a.ablate & 16) { cr = z[0]; return; }
         float newcarry = 0.0f;
         for (int i = 0; i < ntg; ++i) {
           const int lo = bound(i), hi = bound(i + 1);
@@ -308,7 +276,7 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 4) k_cfconv_fused(ConvArgs
           }
           p += __shfl_xor(p, 16);
           p += __shfl_xor(p, 32);
-          if (i == 0 && cont) p = carry[16 * nt + col] + p;
+          if (i == 0 && cont) p = cr + p;
           if (i < ntg - 1) {
             float* dp = dest_lo(t0 + i, lo);
             if (lane < 16) dp[16 * nt + col] = p;
@@ -316,28 +284,42 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 4) k_cfconv_fused(ConvArgs
             newcarry = p;
           }
         }
-        if (lane < 16) carry[16 * nt + col] = newcarry;
+        cr = newcarry;
+      };
+      // conv2's second-layer blocks (pk [4][2]) stream through a two-pair register ring
+      const u32x4* gl = reinterpret_cast<const u32x4*>(a.cp.filt_w2b_pk) + lane;
+      u32x4 g[2][2][2];
+      auto fetch_g = [&](int pair) {   // blocks 2*pair, 2*pair+1 -> ring slot pair & 1
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          g[pair & 1][b][0] = gl[((2 * pair + b) * 2) * 64];
+          g[pair & 1][b][1] = gl[((2 * pair + b) * 2 + 1) * 64];
+        }
       };
       fetch_x(0);
       AG_STAMP(c1); st[3] += c1 - c0; c0 = c1;       // gather offsets, bounds
-      // the bias enters as one extra k-step (ag_rank1): A = s_e on k-slot 0, B = b2 on k-slot 0
-#pragma unroll 1
-      for (int nt = 0; nt < 8; ++nt) {
+#pragma unroll
+      for (int nt = 0; nt < AG_CONV_NCH; ++nt) {
         f32x4 z[1] = {{0.f, 0.f, 0.f, 0.f}};
-        ag_rank1(z[0], s1, a.cp.filt_b2[16 * nt + col], q, (AgIn<MODE>*)nullptr);
-        if (!(a.ablate & 4)) ag_dense_lds<MODE, true, false, 4, 1, 0, 0>(hidb, z, w2 + (nt * 4) * 128, lane);
-        AG_STAMP(c1); st[4] += c1 - c0; c0 = c1;     // layer 2
-        channel_tile(z[0], nt);
-        AG_STAMP(c1); st[5] += c1 - c0; c0 = c1;     // message + reduction
-      }
-#pragma unroll 1
-      for (int nt = 8; nt < AG_CONV_NCH; ++nt) {
-        f32x4 z[1] = {{0.f, 0.f, 0.f, 0.f}};
-        ag_rank1(z[0], s2, a.cp.filt_b2[16 * nt + col], q, (AgIn<MODE>*)nullptr);
-        if (!(a.ablate & 4)) ag_dense_lds<MODE, true, false, 2, 1, 4, 0>(hidb, z, w2 + (32 + (nt - 8) * 2) * 128, lane);
-        AG_STAMP(c1); st[4] += c1 - c0; c0 = c1;
-        channel_tile(z[0], nt);
-        AG_STAMP(c1); st[5] += c1 - c0; c0 = c1;
+        if (nt == 5) fetch_g(0);
+        if (nt == 6) fetch_g(1);
+        if (!(a.ablate & 4)) {
+          if (nt < 8) {
+            ag_dense_lds<MODE, true, false, 4, 1, 0, 0>(hidb, z, w2a + (nt * 4) * 128, lane);
+          } else {
+            ag_block_mma<MODE, true>(z[0], hidb[4], g[(nt - 8) & 1][0]);
+            ag_block_mma<MODE, true>(z[0], hidb[5], g[(nt - 8) & 1][1]);
+            if (nt + 2 < AG_CONV_NCH) fetch_g(nt + 2 - 8);
+          }
+        }
+        const float bb = a.cp.filt_b2[16 * nt + col];
+        const f32x4 m = (nt < 8 ? sr1 : sr2) * xg;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z[0][r] = (z[0][r] + bb) * m[r];
+        if (nt + 1 < AG_CONV_NCH) fetch_x(nt + 1);
+        AG_STAMP(c1); st[4] += c1 - c0; c0 = c1;     // layer 2 + message
+        reduce_tile(z[0], nt, carry[nt]);
+        AG_STAMP(c1); st[5] += c1 - c0; c0 = c1;     // reduction
       }
       run_t = t1;
     }
@@ -345,7 +327,7 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 4) k_cfconv_fused(ConvArgs
       float* dp = dest(run_t);
       if (lane0 < 16) {
 #pragma unroll
-        for (int i = 0; i < AG_CONV_NCH; ++i) dp[16 * i + lane0] = carry[16 * i + lane0];
+        for (int i = 0; i < AG_CONV_NCH; ++i) dp[16 * i + lane0] = carry[i];
       }
     }
   }  // chunk loop
@@ -536,7 +518,7 @@ extern "C" int agdiff_cfconv_fused(const agdiff_params_t* p, const agdiff_topo_t
   // persistent launch: one 16-wave workgroup per CU keeps 144 KiB of filter weights in LDS
   int64_t wgs = (max_chunks + AG_CONV_WAVES - 1) / AG_CONV_WAVES;
   if (wgs > 256) wgs = 256;
-  const size_t smem = (size_t)AG_CONV_LDS_BLOCKS * 2048 + (size_t)AG_CONV_WAVES * 192 * 4;
+  const size_t smem = (size_t)AG_CONV_LDS_BLOCKS * 2048;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)k_cfconv_fused<AG_BF3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||

@@ -148,8 +148,8 @@ class PackedParams:
             p = "encoder_global.interactions.%d" % k
             c1, c2_ = p + ".conv1", p + ".conv2"
             n = "conv%d." % k
-            arrays[n + "filt_w1a_pk"] = pack_blocks(_np(sd, c1 + ".nn.0.weight"), kouter=True)
-            arrays[n + "filt_w1b_pk"] = pack_blocks(_np(sd, c2_ + ".nn.0.weight"), kouter=True)
+            arrays[n + "filt_w1_pk"] = pack_blocks(
+                np.concatenate([_np(sd, c1 + ".nn.0.weight"), _np(sd, c2_ + ".nn.0.weight")], 0), kouter=True)
             arrays[n + "filt_b1"] = np.concatenate([_np(sd, c1 + ".nn.0.bias"), _np(sd, c2_ + ".nn.0.bias")])
             arrays[n + "filt_w2a_pk"] = pack_blocks(_np(sd, c1 + ".nn.2.weight"))
             arrays[n + "filt_w2b_pk"] = pack_blocks(_np(sd, c2_ + ".nn.2.weight"))

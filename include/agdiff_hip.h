@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 6
+#define AGDIFF_ABI_VERSION 7
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -50,8 +50,7 @@ enum agdiff_status {
  * Dimensions in the field comments below are [OT][KT] block counts.  Vectors are in natural feature order. */
 typedef struct agdiff_conv_params {
   /* CFConv filter networks of one InteractionBlock (schnet.py:169-186), conv1 (F=128) and conv2 (F=64) fused */
-  const float* filt_w1a_pk;  /* pkk [4][8]: conv1.nn.0 (128 -> 128) */
-  const float* filt_w1b_pk;  /* pkk [4][4]: conv2.nn.0 (128 -> 64) */
+  const float* filt_w1_pk;   /* pkk [4][12]: rows 0..127 conv1.nn.0, 128..191 conv2.nn.0 */
   const float* filt_b1;      /* [192] */
   const float* filt_w2a_pk;  /* pk [8][4]: conv1.nn.2 */
   const float* filt_w2b_pk;  /* pk [4][2]: conv2.nn.2 */
