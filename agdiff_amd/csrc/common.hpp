@@ -214,6 +214,30 @@ __device__ __forceinline__ void ag_dense_lds(const AgIn<MODE> (&x)[NX], f32x4 (&
     ag_block_mma<MODE, FLIP>(o[O0 + ot], x[X0 + t], w);
   }
 }
+// Mixed source: unit 0 of every block (hi halves in AG_BF3, first k-half in AG_F32) from an LDS array that holds
+// only those units (64 u32x4 per block), unit 1 streamed from the full packed matrix in global memory PF blocks
+// ahead.  Halves the L2 traffic of a layer that does not fit in LDS next to the others.
+template <int MODE, bool FLIP, bool KOUTER, int KT, int OT, int X0, int O0, int PF, int NX, int NO>
+__device__ __forceinline__ void ag_dense_split(const AgIn<MODE> (&x)[NX], f32x4 (&o)[NO], const lds_u32x4* w0,
+                                               const void* wpk, int lane) {
+  static_assert(X0 + KT <= NX && O0 + OT <= NO, "tile range");
+  constexpr int S = OT * KT;
+  constexpr int R = PF + 1;
+  u32x4 w1[R];
+  const u32x4* wl = reinterpret_cast<const u32x4*>(wpk) + 64 + lane;     // unit 1 of block 0
+#pragma unroll
+  for (int s = 0; s < (PF < S ? PF : S); ++s) w1[s % R] = wl[(s * 2) * 64];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int t = KOUTER ? s / OT : s % KT, ot = KOUTER ? s % OT : s / KT;
+    if (s + PF < S) w1[(s + PF) % R] = wl[((s + PF) * 2) * 64];
+    u32x4 w[2];
+    w[0] = w0[s * 64 + lane];
+    w[1] = w1[s % R];
+    ag_block_mma<MODE, FLIP>(o[O0 + ot], x[X0 + t], w);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
 // default prefetch depth for weights streamed from L2 (blocks of 48 / 256 MFMA cycles)
 template <int MODE> struct AgPF { static constexpr int v = (MODE == AG_F32) ? 2 : 4; };
 // weight block b of a packed matrix (both modes: 2 KiB = 512 floats per block)

@@ -28,40 +28,61 @@ struct EncArgs {
 // a = W4 h2 + b4.  (T1/T3: per-edge-type tables holding the bond_emb halves of the two 256->128
 // layers; W23 = comb.0[:, :128] @ efm.2; the trailing attention factor is exactly 1.)
 // The result is stored in the operand form of the consuming mode (common.hpp: edge-attr storage).
+#define AG_PERSIST_WAVES 16
+// Persistent launch, one 16-wave workgroup per CU: w1 and w23 (64 KiB each) and the first unit of every w4
+// block (32 KiB) stay in LDS for the whole launch; only w4's second units (32 KiB per tile) stream from L2.
+// (Streaming all three matrices made the kernel L2-bandwidth-bound: 192 KiB per 16-edge tile.)
 template <int MODE>
-__global__ void __launch_bounds__(AG_WG, 4) k_edge_encoder(EncArgs a) {
-  const int lane = ag_lane(), q = lane >> 4;
-  const int64_t tile = (int64_t)blockIdx.x * 4 + ag_wave_in_wg();
-  const int E = *a.n_dev;
-  if (tile >= a.max_tiles || tile * AG_TW >= E) return;
-  const int64_t e = tile * AG_TW + (lane & 15);
-  const bool valid = e < E;
-  const float d = valid ? a.e_len[e] : 0.0f;
-  const int ty = valid ? a.e_type[e] : 0;
-  constexpr int PF = AgPF<MODE>::v;
-
-  f32x4 y[8];
-  AgIn<MODE> x[4];
+__global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_edge_encoder(EncArgs a) {
+  extern __shared__ u32x4 ag_enc_smem[];
+  lds_u32x4* lw1 = (lds_u32x4*)ag_enc_smem;
+  lds_u32x4* lw23 = lw1 + 32 * 128;
+  lds_u32x4* lw4 = lw23 + 32 * 128;           // 32 blocks x 64 (unit 0 only)
   {
-    f32x4 w[8];
-    ag_init_vec<8>(w, a.fe_w, q);
-    ag_init_vec<8>(y, a.fe_b, q);
-    AG_FOR_TILE(y, 8, ag_gelu(fmaf(w[_t][_r], d, v)));
+    const u32x4* g1 = reinterpret_cast<const u32x4*>(a.w1_pk);
+    const u32x4* g2 = reinterpret_cast<const u32x4*>(a.w23_pk);
+    const u32x4* g4 = reinterpret_cast<const u32x4*>(a.w4_pk);
+    for (int i = threadIdx.x; i < 32 * 128; i += blockDim.x) lw1[i] = g1[i];
+    for (int i = threadIdx.x; i < 32 * 128; i += blockDim.x) lw23[i] = g2[i];
+    for (int i = threadIdx.x; i < 32 * 64; i += blockDim.x) lw4[i] = g4[(i >> 6) * 128 + (i & 63)];
   }
-  ag_cvt_tiles<MODE, 4, 0>(y, x);
-  ag_init_vec<8>(y, a.t1 + (size_t)ty * 128, q);
-  ag_dense<MODE, false, false, 4, 8, 0, 0, PF>(x, y, a.w1_pk, lane);
-  AG_FOR_TILE(y, 8, ag_gelu(v));
-  ag_cvt_tiles<MODE, 4, 0>(y, x);
-  ag_init_vec<8>(y, a.t3 + (size_t)ty * 128, q);
-  ag_dense<MODE, false, false, 4, 8, 0, 0, PF>(x, y, a.w23_pk, lane);
-  AG_FOR_TILE(y, 8, ag_gelu(v));
-  ag_cvt_tiles<MODE, 4, 0>(y, x);
-  ag_init_vec<8>(y, a.b4, q);
-  ag_dense<MODE, false, false, 4, 8, 0, 0, PF>(x, y, a.w4_pk, lane);
-  ag_cvt_tiles<MODE, 4, 0>(y, x);
+  __syncthreads();
+  const int lane0 = ag_lane();
+  const int E = *a.n_dev;
+  const int64_t stride = (int64_t)gridDim.x * AG_PERSIST_WAVES;
+  for (int64_t tile = (int64_t)blockIdx.x * AG_PERSIST_WAVES + (threadIdx.x >> 6); tile < a.max_tiles; tile += stride) {
+    if (tile * AG_TW >= E) break;
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));      // keep lane-derived addresses out of the loop-invariant set
+    const int q = lane >> 4;
+    const int64_t e = tile * AG_TW + (lane & 15);
+    const bool valid = e < E;
+    const float d = valid ? a.e_len[e] : 0.0f;
+    const int ty = valid ? a.e_type[e] : 0;
+
+    f32x4 y[8];
+    AgIn<MODE> x[4];
+    {
+      f32x4 w[8];
+      ag_init_vec<8>(w, a.fe_w, q);
+      ag_init_vec<8>(y, a.fe_b, q);
+      AG_FOR_TILE(y, 8, ag_gelu(fmaf(w[_t][_r], d, v)));
+    }
+    ag_cvt_tiles<MODE, 4, 0>(y, x);
+    ag_init_vec<8>(y, a.t1 + (size_t)ty * 128, q);
+    ag_dense_lds<MODE, false, false, 4, 8, 0, 0>(x, y, lw1, lane);
+    AG_FOR_TILE(y, 8, ag_gelu(v));
+    ag_cvt_tiles<MODE, 4, 0>(y, x);
+    ag_init_vec<8>(y, a.t3 + (size_t)ty * 128, q);
+    ag_dense_lds<MODE, false, false, 4, 8, 0, 0>(x, y, lw23, lane);
+    AG_FOR_TILE(y, 8, ag_gelu(v));
+    ag_cvt_tiles<MODE, 4, 0>(y, x);
+    ag_init_vec<8>(y, a.b4, q);
+    ag_dense_split<MODE, false, false, 4, 8, 0, 0, 6>(x, y, lw4, a.w4_pk, lane);
+    ag_cvt_tiles<MODE, 4, 0>(y, x);
 #pragma unroll
-  for (int t = 0; t < 4; ++t) ag_store_attr(x[t], a.out_frag, tile, t, lane);
+    for (int t = 0; t < 4; ++t) ag_store_attr(x[t], a.out_frag, tile, t, lane);
+  }
 }
 
 // ------------------------------------------------------------------------------ per-edge conv scales
@@ -352,52 +373,67 @@ struct HeadArgs {
 };
 
 // assemble_atom_pair_feature (common.py:106-109) + MultiLayerPerceptron 256->128->64->1 (common.py:86-103)
+// Persistent launch, one 16-wave workgroup per CU; both weight matrices (128 + 32 KiB) stay in LDS.
 template <int MODE>
-__global__ void __launch_bounds__(AG_WG, 4) k_pair_head(HeadArgs a) {
-  const int lane = ag_lane(), q = lane >> 4;
-  const int64_t tile = (int64_t)blockIdx.x * 4 + ag_wave_in_wg();
+__global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_pair_head(HeadArgs a) {
+  extern __shared__ u32x4 ag_head_smem[];
+  lds_u32x4* lw1 = (lds_u32x4*)ag_head_smem;      // pkk [8][8] = 64 blocks
+  lds_u32x4* lw2 = lw1 + 64 * 128;                // pk  [4][4] = 16 blocks
+  {
+    const u32x4* g1 = reinterpret_cast<const u32x4*>(a.hp.w1_pk);
+    const u32x4* g2 = reinterpret_cast<const u32x4*>(a.hp.w2_pk);
+    for (int i = threadIdx.x; i < 64 * 128; i += blockDim.x) lw1[i] = g1[i];
+    for (int i = threadIdx.x; i < 16 * 128; i += blockDim.x) lw2[i] = g2[i];
+  }
+  __syncthreads();
+  const int lane0 = ag_lane();
   const int E = *a.n_dev;
-  if (tile >= a.max_tiles || tile * AG_TW >= E) return;
-  const int64_t e = tile * AG_TW + (lane & 15);
-  const bool valid = e < E;
-  const int s = valid ? a.src[e] : 0, t = valid ? a.dst[e] : 0;
-  constexpr int PF = AgPF<MODE>::v;
+  const int64_t stride = (int64_t)gridDim.x * AG_PERSIST_WAVES;
+  for (int64_t tile = (int64_t)blockIdx.x * AG_PERSIST_WAVES + (threadIdx.x >> 6); tile < a.max_tiles; tile += stride) {
+    if (tile * AG_TW >= E) break;
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int q = lane >> 4;
+    const int64_t e = tile * AG_TW + (lane & 15);
+    const bool valid = e < E;
+    const int s = valid ? a.src[e] : 0, t = valid ? a.dst[e] : 0;
 
-  // first layer streamed over eight 32-feature k-tiles of [h_src * h_dst || edge_attr] (pkk weights)
-  f32x4 y1[8];
-  ag_init_vec<8>(y1, a.hp.b1, q);
-  {
-    const float* hs = a.node_h + (size_t)s * 128;
-    const float* ht = a.node_h + (size_t)t * 128;
-    AgIn<MODE> sl[2];
-    auto load_slice = [&](AgIn<MODE>& dst, int k) {
-      if (k < 4) {
-        const f32x4 p0 = ag_ld4(hs + 32 * k + 4 * q) * ag_ld4(ht + 32 * k + 4 * q);
-        const f32x4 p1 = ag_ld4(hs + 32 * k + 16 + 4 * q) * ag_ld4(ht + 32 * k + 16 + 4 * q);
-        ag_cvt(p0, p1, dst);
-      } else {
-        ag_load_attr(dst, a.attr_frag, tile, k - 4, lane);
-      }
-    };
-    load_slice(sl[0], 0);
+    // first layer over eight 32-feature k-tiles of [h_src * h_dst || edge_attr] (pkk weights)
+    f32x4 y1[8];
+    ag_init_vec<8>(y1, a.hp.b1, q);
+    {
+      const float* hs = a.node_h + (size_t)s * 128;
+      const float* ht = a.node_h + (size_t)t * 128;
+      AgIn<MODE> sl[2];
+      auto load_slice = [&](AgIn<MODE>& dst, int k) {
+        if (k < 4) {
+          const f32x4 p0 = ag_ld4(hs + 32 * k + 4 * q) * ag_ld4(ht + 32 * k + 4 * q);
+          const f32x4 p1 = ag_ld4(hs + 32 * k + 16 + 4 * q) * ag_ld4(ht + 32 * k + 16 + 4 * q);
+          ag_cvt(p0, p1, dst);
+        } else {
+          ag_load_attr(dst, a.attr_frag, tile, k - 4, lane);
+        }
+      };
+      load_slice(sl[0], 0);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      if (k + 1 < 8) load_slice(sl[(k + 1) & 1], k + 1);
-      if (k & 1) ag_dense<MODE, false, true, 1, 8, 1, 0, PF>(sl, y1, ag_wblock(a.hp.w1_pk, k * 8), lane);
-      else ag_dense<MODE, false, true, 1, 8, 0, 0, PF>(sl, y1, ag_wblock(a.hp.w1_pk, k * 8), lane);
+      for (int k = 0; k < 8; ++k) {
+        if (k + 1 < 8) load_slice(sl[(k + 1) & 1], k + 1);
+        if (k & 1) ag_dense_lds<MODE, false, true, 1, 8, 1, 0>(sl, y1, lw1 + (k * 8) * 128, lane);
+        else ag_dense_lds<MODE, false, true, 1, 8, 0, 0>(sl, y1, lw1 + (k * 8) * 128, lane);
+      }
     }
+    AG_FOR_TILE(y1, 8, ag_relu(v));
+    f32x4 y2[4];
+    ag_init_vec<4>(y2, a.hp.b2, q);
+    {
+      AgIn<MODE> y1b[4];
+      ag_cvt_tiles<MODE, 4, 0>(y1, y1b);
+      ag_dense_lds<MODE, false, false, 4, 4, 0, 0>(y1b, y2, lw2, lane);
+    }
+    AG_FOR_TILE(y2, 4, ag_relu(v));
+    const float o = ag_dot_vec<4>(y2, a.hp.w3, q) + a.hp.b3;
+    if (valid && q == 0) a.out[e] = o;
   }
-  AG_FOR_TILE(y1, 8, ag_relu(v));
-  f32x4 y2[4];
-  ag_init_vec<4>(y2, a.hp.b2, q);
-  {
-    AgIn<MODE> y1b[4];
-    ag_cvt_tiles<MODE, 4, 0>(y1, y1b);
-    ag_dense<MODE, false, false, 4, 4, 0, 0, PF>(y1b, y2, a.hp.w2_pk, lane);
-  }
-  AG_FOR_TILE(y2, 4, ag_relu(v));
-  const float o = ag_dot_vec<4>(y2, a.hp.w3, q) + a.hp.b3;
-  if (valid && q == 0) a.out[e] = o;
 }
 
 // ------------------------------------------------------------------------------ stand-alone aggregate
@@ -449,10 +485,20 @@ extern "C" int agdiff_edge_encoder(const agdiff_params_t* p, const int32_t* n_ed
   if (max_tiles == 0) return AGDIFF_OK;
   EncArgs a{p->ee_fe_w, p->ee_fe_b, p->ee_t1, p->ee_w1_pk, p->ee_t3, p->ee_w23_pk, p->ee_w4_pk, p->ee_b4,
             n_edges_dev, e_len, e_type, attr_frag, max_tiles};
+  int64_t wgs = (max_tiles + AG_PERSIST_WAVES - 1) / AG_PERSIST_WAVES;
+  if (wgs > 256) wgs = 256;
+  const size_t smem = (size_t)80 * 2048;     // w1 (32 blocks) + w23 (32) + unit 0 of w4's 32 blocks
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)k_edge_encoder<AG_BF3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_edge_encoder<AG_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return AGDIFF_ERR_LAUNCH;
+    attr_set = true;
+  }
   if (p->precision == AG_BF3)
-    k_edge_encoder<AG_BF3><<<dim3((unsigned)((max_tiles + 3) / 4)), dim3(AG_WG), 0, (hipStream_t)stream>>>(a);
+    k_edge_encoder<AG_BF3><<<dim3((unsigned)wgs), dim3(64 * AG_PERSIST_WAVES), smem, (hipStream_t)stream>>>(a);
   else
-    k_edge_encoder<AG_F32><<<dim3((unsigned)((max_tiles + 3) / 4)), dim3(AG_WG), 0, (hipStream_t)stream>>>(a);
+    k_edge_encoder<AG_F32><<<dim3((unsigned)wgs), dim3(64 * AG_PERSIST_WAVES), smem, (hipStream_t)stream>>>(a);
   AG_CHECK_LAUNCH();
   return AGDIFF_OK;
 }
@@ -548,10 +594,20 @@ extern "C" int agdiff_pair_head(const agdiff_head_params_t* hp, const int32_t* n
   a.attr_frag = attr_frag;
   a.out = out;
   a.max_tiles = max_tiles;
+  int64_t wgs = (max_tiles + AG_PERSIST_WAVES - 1) / AG_PERSIST_WAVES;
+  if (wgs > 256) wgs = 256;
+  const size_t smem = (size_t)80 * 2048;     // w1 (64 blocks) + w2 (16 blocks)
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)k_pair_head<AG_BF3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_pair_head<AG_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return AGDIFF_ERR_LAUNCH;
+    attr_set = true;
+  }
   if (hp->precision == AG_BF3)
-    k_pair_head<AG_BF3><<<dim3((unsigned)((max_tiles + 3) / 4)), dim3(AG_WG), 0, (hipStream_t)stream>>>(a);
+    k_pair_head<AG_BF3><<<dim3((unsigned)wgs), dim3(64 * AG_PERSIST_WAVES), smem, (hipStream_t)stream>>>(a);
   else
-    k_pair_head<AG_F32><<<dim3((unsigned)((max_tiles + 3) / 4)), dim3(AG_WG), 0, (hipStream_t)stream>>>(a);
+    k_pair_head<AG_F32><<<dim3((unsigned)wgs), dim3(64 * AG_PERSIST_WAVES), smem, (hipStream_t)stream>>>(a);
   AG_CHECK_LAUNCH();
   return AGDIFF_OK;
 }
