@@ -29,7 +29,7 @@ extern "C" int agdiff_score_forward(const agdiff_params_t* p, const agdiff_topo_
   // local branch: lengths -> edge encoder -> GIN -> local head   (dualenc.py:214-239)
   AG_TRY(agdiff_local_lengths(topo, ws, pos, stream));
   if (topo->num_local > 0) {
-    AG_TRY(agdiff_edge_encoder(p, ws->num_local, ltiles, ws->l_len, topo->loc_type, ws->l_attr, stream));
+    AG_TRY(agdiff_edge_encoder(p, ws->num_local, ltiles, ws->l_len, topo->loc_type, ws->l_attr, ws->l_attr_rows, stream));
   }
   AG_TRY(agdiff_gin_encoder(p, topo, ws, stream));
   if (topo->num_local > 0) {
@@ -41,7 +41,7 @@ extern "C" int agdiff_score_forward(const agdiff_params_t* p, const agdiff_topo_
   const int64_t etiles = (topo->max_edges + AG_TW - 1) / AG_TW;
   AG_TRY(agdiff_graph_build(topo, ws, pos, p->cutoff, stream));
   AG_TRY(agdiff_edge_scales(p, topo, ws, stream));
-  AG_TRY(agdiff_edge_encoder(p, ws->num_edges, etiles, ws->e_len, ws->e_type, ws->e_attr, stream));
+  AG_TRY(agdiff_edge_encoder(p, ws->num_edges, etiles, ws->e_len, ws->e_type, ws->e_attr, nullptr, stream));
   for (int k = 0; k <= p->num_convs; ++k) {
     AG_TRY(agdiff_schnet_node_stage(p, topo, ws, k, stream));
     if (k < p->num_convs) AG_TRY(agdiff_cfconv_fused(p, topo, ws, k, stream));

@@ -21,6 +21,7 @@ struct EncArgs {
   const float* e_len;
   const int32_t* e_type;
   float* out_frag;
+  float* out_rows;       // optional [E][128] fp32 row-major copy
   int64_t max_tiles;
 };
 
@@ -79,6 +80,7 @@ __global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_edge_encoder(EncAr
     ag_cvt_tiles<MODE, 4, 0>(y, x);
     ag_init_vec<8>(y, a.b4, q);
     ag_dense_split<MODE, false, false, 4, 8, 0, 0, 6>(x, y, lw4, a.w4_pk, lane);
+    if (a.out_rows && valid) ag_store_row<8, 0>(y, a.out_rows + (size_t)e * 128, q);
     ag_cvt_tiles<MODE, 4, 0>(y, x);
 #pragma unroll
     for (int t = 0; t < 4; ++t) ag_store_attr(x[t], a.out_frag, tile, t, lane);
@@ -258,12 +260,11 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 4) k_cfconv_fused(ConvArgs
       // per edge slot of my quarter (slot 4q + r lives in lane 4q + r): gather row of x, and the scales
       // lw(d)*C(d) of the two convs, which multiply the message: (H^T W2 + b2) . s . x[src]
       uint32_t xoff[4];
-      f32x4 sr1, sr2;
+      f32x4 sr;                          // scale of the conv being processed, per edge slot
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         xoff[r] = (uint32_t)__shfl(my_src, 4 * q + r) * 192u + (uint32_t)col;
-        sr1[r] = __shfl(s1, 4 * q + r);
-        sr2[r] = __shfl(s2, 4 * q + r);
+        sr[r] = __shfl(s1, 4 * q + r);
       }
       // list boundaries of the targets present in this tile, one per lane (in_ptr[t0 + lane]); the
       // reduction loops read them with readlane instead of dependent global loads
@@ -309,14 +310,15 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 4) k_cfconv_fused(ConvArgs
         }
         cr = newcarry;
       };
-      // conv2's second-layer blocks (pk [4][2]) stream through a two-pair register ring
+      // conv2's second-layer blocks (pk [4][2]: one pair per channel tile) stream from L2; the pair of the
+      // next channel tile is requested right after the current pair's MFMAs
       const u32x4* gl = reinterpret_cast<const u32x4*>(a.cp.filt_w2b_pk) + lane;
-      u32x4 g[2][2][2];
-      auto fetch_g = [&](int pair) {   // blocks 2*pair, 2*pair+1 -> ring slot pair & 1
+      u32x4 g[2][2];
+      auto fetch_g = [&](int pair) {   // blocks 2*pair, 2*pair+1
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-          g[pair & 1][b][0] = gl[((2 * pair + b) * 2) * 64];
-          g[pair & 1][b][1] = gl[((2 * pair + b) * 2 + 1) * 64];
+          g[b][0] = gl[((2 * pair + b) * 2) * 64];
+          g[b][1] = gl[((2 * pair + b) * 2 + 1) * 64];
         }
       };
       fetch_x(0);
@@ -324,19 +326,22 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 4) k_cfconv_fused(ConvArgs
 #pragma unroll
       for (int nt = 0; nt < AG_CONV_NCH; ++nt) {
         f32x4 z[1] = {{0.f, 0.f, 0.f, 0.f}};
-        if (nt == 5) fetch_g(0);
-        if (nt == 6) fetch_g(1);
+        if (nt == 7) fetch_g(0);
+        if (nt == 8) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sr[r] = __shfl(s2, 4 * q + r);
+        }
         if (!(a.ablate & 4)) {
           if (nt < 8) {
             ag_dense_lds<MODE, true, false, 4, 1, 0, 0>(hidb, z, w2a + (nt * 4) * 128, lane);
           } else {
-            ag_block_mma<MODE, true>(z[0], hidb[4], g[(nt - 8) & 1][0]);
-            ag_block_mma<MODE, true>(z[0], hidb[5], g[(nt - 8) & 1][1]);
-            if (nt + 2 < AG_CONV_NCH) fetch_g(nt + 2 - 8);
+            ag_block_mma<MODE, true>(z[0], hidb[4], g[0]);
+            ag_block_mma<MODE, true>(z[0], hidb[5], g[1]);
+            if (nt + 1 < AG_CONV_NCH) fetch_g(nt + 1 - 8);
           }
         }
         const float bb = a.cp.filt_b2[16 * nt + col];
-        const f32x4 m = (nt < 8 ? sr1 : sr2) * xg;
+        const f32x4 m = sr * xg;
 #pragma unroll
         for (int r = 0; r < 4; ++r) z[0][r] = (z[0][r] + bb) * m[r];
         if (nt + 1 < AG_CONV_NCH) fetch_x(nt + 1);
@@ -482,11 +487,12 @@ extern "C" int agdiff_debug_conv_stamps(unsigned long long* out, int reset) {
 #endif
 
 extern "C" int agdiff_edge_encoder(const agdiff_params_t* p, const int32_t* n_edges_dev, int64_t max_tiles,
-                                   const float* e_len, const int32_t* e_type, float* attr_frag, void* stream) {
+                                   const float* e_len, const int32_t* e_type, float* attr_frag, float* attr_rows,
+                                   void* stream) {
   if (!p || !n_edges_dev || !e_len || !e_type || !attr_frag || max_tiles < 0) return AGDIFF_ERR_ARG;
   if (max_tiles == 0) return AGDIFF_OK;
   EncArgs a{p->ee_fe_w, p->ee_fe_b, p->ee_t1, p->ee_w1_pk, p->ee_t3, p->ee_w23_pk, p->ee_w4_pk, p->ee_b4,
-            n_edges_dev, e_len, e_type, attr_frag, max_tiles};
+            n_edges_dev, e_len, e_type, attr_frag, attr_rows, max_tiles};
   int64_t wgs = (max_tiles + AG_PERSIST_WAVES - 1) / AG_PERSIST_WAVES;
   if (wgs > 256) wgs = 256;
   const size_t smem = (size_t)80 * 2048;     // w1 (32 blocks) + w23 (32) + unit 0 of w4's 32 blocks

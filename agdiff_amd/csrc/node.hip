@@ -146,7 +146,7 @@ struct GinArgs {
   const int32_t* loc_in_ptr;
   const int32_t* loc_in_eid;
   const int32_t* loc_src;
-  const float* l_attr;         // fragment-major local edge attrs
+  const float* l_attr_rows;    // [L][128] fp32 local edge attrs, row-major
   const float* h_in;
   float* h_out;
   int64_t n;
@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(AG_WG, 2) k_gin_layer(GinArgs a) {
     for (int t = 0; t < 8; ++t) {
       const int f = 16 * t + 4 * q;
       const f32x4 hvv = ag_ld4(hsrc + f);
-      const f32x4 ev = ag_attr_gather4<MODE>(a.l_attr, eid, f);
+      const f32x4 ev = ag_ld4(a.l_attr_rows + (size_t)eid * 128 + f);
 #pragma unroll
       for (int r = 0; r < 4; ++r) m[t][r] += on ? ag_relu(hvv[r] + ev[r]) : 0.0f;
     }
@@ -381,7 +381,7 @@ extern "C" int agdiff_gin_encoder(const agdiff_params_t* p, const agdiff_topo_t*
     a.loc_in_ptr = topo->loc_in_ptr;
     a.loc_in_eid = topo->loc_in_eid;
     a.loc_src = topo->loc_src;
-    a.l_attr = ws->l_attr;
+    a.l_attr_rows = ws->l_attr_rows;
     a.h_in = in;
     a.h_out = bufs[cur];
     a.n = topo->num_nodes;

@@ -132,6 +132,7 @@ class Workspace:
         self.e_scale = f32(2 * _lib.DEFINES["AGDIFF_MAX_CONVS"] * etiles * TW)
         self.l_len, self.l_inv = f32(ltiles * TW), f32(ltiles * TW)
         self.l_attr = f32(ltiles * TW * 128)
+        self.l_attr_rows = f32(ltiles * TW * 128)
         self.h, self.xs, self.agg = f32(N * 128), f32(N * 192), f32(N * 192)
         self.agg_first = f32(chunks * 192)
         self.hl, self.hl2 = f32(N * 128), f32(N * 128)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 7
+#define AGDIFF_ABI_VERSION 8
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -162,6 +162,7 @@ typedef struct agdiff_ws {
   /* local edges (reference order) */
   float*   l_len;            /* [L] */
   float*   l_attr;           /* [ceil(L/16)] tiles, operand form */
+  float*   l_attr_rows;      /* [L][128] fp32 row-major copy of l_attr for the GIN message gather */
   float*   l_inv;            /* [L] grad_local_dist_mlp output */
   /* nodes */
   float*   h;                /* [N][128] SchNet node state */
@@ -210,7 +211,8 @@ int agdiff_edge_scales(const agdiff_params_t* p, const agdiff_topo_t* topo, cons
 /* MLPEdgeEncoder.forward (encoder/edge.py:84-103).  n_edges_dev: device scalar with the live edge
  * count (<= max_tiles*16); writes operand-form edge_attr tiles. */
 int agdiff_edge_encoder(const agdiff_params_t* p, const int32_t* n_edges_dev, int64_t max_tiles,
-                        const float* e_len, const int32_t* e_type, float* attr_frag, void* stream);
+                        const float* e_len, const int32_t* e_type, float* attr_frag, float* attr_rows /* optional [E][128] */,
+                        void* stream);
 
 /* Node-side stage k of SchNetEncoder.forward (encoder/schnet.py:268-282): k == 0 embeds atoms;
  * k >= 1 finishes InteractionBlock k-1 (lin2/BN, act, lin, gate, AdaptiveScaling, residual);
