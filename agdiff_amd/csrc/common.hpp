@@ -283,27 +283,6 @@ __device__ __forceinline__ void ag_load_attr(AgIn<AG_BF3>& x, const float* frag,
   x.hi = __builtin_bit_cast(bf16x8, p[0]);
   x.lo = __builtin_bit_cast(bf16x8, p[64]);
 }
-// four consecutive features f..f+3 (f % 4 == 0) of edge e as fp32 (GIN message gather)
-template <int MODE>
-__device__ __forceinline__ f32x4 ag_attr_gather4(const float* frag, int64_t e, int f) {
-  const int64_t tile = e >> 4;
-  const int t = f >> 5, w = f & 31, u = w >> 4, q = (w & 15) >> 2;
-  const int64_t unit0 = ((tile * 4 + t) * 2) * 64 + (int)(e & 15) + 16 * q;
-  if constexpr (MODE == AG_F32) {
-    return ag_ld4(frag + (unit0 + 64 * u) * 4);
-  } else {
-    typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
-    const unsigned short* base = reinterpret_cast<const unsigned short*>(frag) + unit0 * 8 + 4 * u;
-    const u16x4 hi = *reinterpret_cast<const u16x4*>(base);
-    const u16x4 lo = *reinterpret_cast<const u16x4*>(base + 64 * 8);
-    f32x4 r;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      r[k] = __uint_as_float((unsigned)hi[k] << 16) + __uint_as_float((unsigned)lo[k] << 16);
-    return r;
-  }
-}
-
 // Host-side launch check
 #define AG_CHECK_LAUNCH()                                         \
   do {                                                            \

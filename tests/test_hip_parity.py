@@ -225,3 +225,28 @@ def test_full_size_properties():
     cen = torch.zeros(b["num_graphs"], 3, device="cuda").index_add_(0, ba, p1)
     assert float(cen.abs().max()) < 1e-3
     assert torch.isfinite(p1).all()
+
+
+def test_driver_end_to_end(tmp_path):
+    """scripts/test.py counterpart on a reference-layout checkpoint file and an .npz test set."""
+    from agdiff_amd import Config, driver, qm9_model_config, synth
+    from oracle import agdiff_oracle as O
+    cfg = qm9_model_config(num_diffusion_timesteps=30)
+    ckpt = str(tmp_path / "ckpt.pt")
+    torch.save({"config": Config(model=cfg), "model": O.synth_state_dict_for(cfg), "iteration": 0}, ckpt)
+    rng = np.random.default_rng(5)
+    mols = []
+    for i in range(4):
+        at, r, c, ty = synth.random_molecule(rng, int(rng.integers(10, 25)))
+        mols.append(dict(atom_type=at, edge_index=np.stack([r, c]), edge_type=ty, num_refs=2 + i, name="mol%d" % i))
+    ts = str(tmp_path / "test.npz")
+    driver.save_testset(ts, mols)
+    out = str(tmp_path / "out")
+    driver.main(["--ckpt", ckpt, "--testset", ts, "--out", out, "--n-steps", "6", "--max-atoms", "120", "--save-traj"])
+    z = np.load(out + "/samples_all.npz")
+    for i, m in enumerate(mols):
+        p = z["pos_gen_%d" % i]
+        assert p.shape == (2 * m["num_refs"], m["atom_type"].shape[0], 3) and np.isfinite(p).all()
+        assert np.abs(p.mean(axis=1)).max() < 1e-3            # every conformer is centred (dualenc.py:542)
+        assert z["traj_%d" % i].shape == (6,) + p.shape
+    driver.main(["--ckpt", ckpt, "--testset", ts, "--out", out, "--n-steps", "6", "--resume"])   # nothing left to do
