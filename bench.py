@@ -210,8 +210,16 @@ def main():
         avg_ms = sum(a.elapsed_time(bb) for a, bb in evs) / len(evs)
         ach = E * FLOP_PER_EDGE_CFCONV / (avg_ms * 1e-3) / 1e12
         pk_ = PEAK[args.precision]
+        # HBM bytes per launch come from a separate rocprofv3 --pmc pass (tools/pmc_traffic.sh); the committed
+        # figure applies to the workload it was taken on (same edge count within 1%), otherwise null
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r01_%s_pmc_traffic.json" % args.precision)
+        if os.path.exists(tf):
+            tj = json.load(open(tf))
+            if abs(tj.get("workload_edges", 0) - E) <= 0.01 * E:
+                traffic = tj["kernels"]["k_cfconv_fused"]["hbm_bytes_per_launch"]
         roof = {"kernel": "k_cfconv_fused", "bound": "mfma", "achieved": ach, "peak": pk_, "unit": "TFLOP/s",
-                "frac": ach / pk_, "traffic": None, "avg_launch_ms": avg_ms, "edges_per_launch": E,
+                "frac": ach / pk_, "traffic": traffic, "avg_launch_ms": avg_ms, "edges_per_launch": E,
                 "mfma_issued_tflops": ach * MFMA_PASSES[args.precision],
                 "note": "achieved = algorithmic FLOPs (E x 90,112) / launch time; bf16x3 issues 3 bf16 MFMA "
                         "FLOPs per algorithmic FLOP (hi.hi + lo.hi + hi.lo), fp32 accumulate"}
