@@ -1,6 +1,7 @@
 // Whole-path entry points: ABI self-description, the score network (dualenc.py:142-251) and one
 // denoising step (dualenc.py:478-545), composed from the per-op launchers.
 #include "common.hpp"
+#include <cstdlib>
 
 extern "C" int agdiff_abi_version(void) { return AGDIFF_ABI_VERSION; }
 
@@ -22,11 +23,33 @@ extern "C" int agdiff_struct_sizes(int64_t* out) {
     if (_rc != AGDIFF_OK) return _rc; \
   } while (0)
 
-extern "C" int agdiff_score_forward(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
-                                    const float* pos, int32_t with_global, void* stream) {
-  if (!p || !topo || !ws || !pos) return AGDIFF_ERR_ARG;
+namespace {
+// The local branch (bond graph: lengths -> encoder -> GIN -> local head) and the global branch (radius graph ->
+// encoder -> SchNet -> global head) only share `pos`, so they are forked onto two HIP streams and joined before
+// returning: the local branch's small, latency-bound launches fill the gaps the global branch's node stages and
+// graph kernels leave.  One side stream and two events per device, created on first use (HIP objects only; no
+// device memory).  The fork/join is event-based, hence also capturable into a hipGraph.
+struct ForkJoin {
+  hipStream_t side = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool ok = false;
+};
+ForkJoin& fork_join_for_current_device() {
+  static ForkJoin fj[16];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  ForkJoin& f = fj[dev & 15];
+  if (!f.ok) {
+    f.ok = hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&f.fork, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&f.join, hipEventDisableTiming) == hipSuccess;
+  }
+  return f;
+}
+
+int local_branch(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, void* stream) {
   const int64_t ltiles = (topo->num_local + AG_TW - 1) / AG_TW;
-  // local branch: lengths -> edge encoder -> GIN -> local head   (dualenc.py:214-239)
+  // lengths -> edge encoder -> GIN -> local head   (dualenc.py:214-239)
   AG_TRY(agdiff_local_lengths(topo, ws, pos, stream));
   if (topo->num_local > 0) {
     AG_TRY(agdiff_edge_encoder(p, ws->num_local, ltiles, ws->l_len, topo->loc_type, ws->l_attr, ws->l_attr_rows, stream));
@@ -36,8 +59,11 @@ extern "C" int agdiff_score_forward(const agdiff_params_t* p, const agdiff_topo_
     AG_TRY(agdiff_pair_head(&p->head_local, ws->num_local, ltiles, topo->loc_src, topo->loc_dst, ws->hl, ws->l_attr,
                             ws->l_inv, stream));
   }
-  if (!with_global) return AGDIFF_OK;
-  // global branch: radius graph -> edge encoder -> SchNet -> global head   (dualenc.py:167-211)
+  return AGDIFF_OK;
+}
+
+int global_branch(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, void* stream) {
+  // radius graph -> scales -> edge encoder -> SchNet -> global head   (dualenc.py:167-211)
   const int64_t etiles = (topo->max_edges + AG_TW - 1) / AG_TW;
   AG_TRY(agdiff_graph_build(topo, ws, pos, p->cutoff, stream));
   AG_TRY(agdiff_edge_scales(p, topo, ws, stream));
@@ -48,6 +74,27 @@ extern "C" int agdiff_score_forward(const agdiff_params_t* p, const agdiff_topo_
   }
   AG_TRY(agdiff_pair_head(&p->head_global, ws->num_edges, etiles, ws->e_src, ws->e_dst, ws->h, ws->e_attr,
                           ws->e_inv_global, stream));
+  return AGDIFF_OK;
+}
+}  // namespace
+
+extern "C" int agdiff_score_forward(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
+                                    const float* pos, int32_t with_global, void* stream) {
+  if (!p || !topo || !ws || !pos) return AGDIFF_ERR_ARG;
+  if (!with_global) return local_branch(p, topo, ws, pos, stream);
+  static const bool serial = getenv("AGDIFF_SERIAL_BRANCHES") != nullptr;
+  ForkJoin& fj = fork_join_for_current_device();
+  if (serial || !fj.ok) {
+    AG_TRY(local_branch(p, topo, ws, pos, stream));
+    return global_branch(p, topo, ws, pos, stream);
+  }
+  hipStream_t main = (hipStream_t)stream;
+  if (hipEventRecord(fj.fork, main) != hipSuccess || hipStreamWaitEvent(fj.side, fj.fork, 0) != hipSuccess)
+    return AGDIFF_ERR_LAUNCH;
+  AG_TRY(local_branch(p, topo, ws, pos, (void*)fj.side));
+  if (hipEventRecord(fj.join, fj.side) != hipSuccess) return AGDIFF_ERR_LAUNCH;
+  AG_TRY(global_branch(p, topo, ws, pos, stream));
+  if (hipStreamWaitEvent(main, fj.join, 0) != hipSuccess) return AGDIFF_ERR_LAUNCH;
   return AGDIFF_OK;
 }
 

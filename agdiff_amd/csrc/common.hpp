@@ -75,6 +75,18 @@ __device__ __forceinline__ float ag_sigmoid(float x) {
 __device__ __forceinline__ float ag_relu(float x) { return x > 0.0f ? x : 0.0f; }
 __device__ __forceinline__ float ag_lrelu(float x) { return x > 0.0f ? x : 0.2f * x; }
 
+// Sum of a value over the four quarters of the wave (lanes l, l^16, l^32, l^48), result in every lane:
+// two VALU lane-swap instructions (gfx950 v_permlane16_swap / v_permlane32_swap) instead of two trips
+// through the LDS crossbar (ds_bpermute).  Association: (q0 + q1) + (q2 + q3).
+__device__ __forceinline__ float ag_quarter_sum(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const unsigned w = __float_as_uint(s);
+  const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 // ---------------------------------------------------------------------------------- fp32 tiles
 // Fill std-orientation tiles from a natural-order vector (bias init): y[T][r] = v[16T + 4q + r].
 template <int NT, int NY>
@@ -103,9 +115,7 @@ __device__ __forceinline__ float ag_dot_vec(const f32x4 (&y)[NY], const float* _
 #pragma unroll
     for (int r = 0; r < 4; ++r) s = fmaf(b[r], y[t][r], s);
   }
-  s += __shfl_xor(s, 16);
-  s += __shfl_xor(s, 32);
-  return s;
+  return ag_quarter_sum(s);
 }
 #define AG_FOR_TILE(y, NT, expr)                       \
   _Pragma("unroll") for (int _t = 0; _t < (NT); ++_t)  \

@@ -298,8 +298,7 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 4) k_cfconv_fused(ConvArgs
             const int er = (int)tbase + 4 * q + r;
             p += ((er >= lo) && (er < hi)) ? z[r] : 0.0f;
           }
-          p += __shfl_xor(p, 16);
-          p += __shfl_xor(p, 32);
+          p = ag_quarter_sum(p);
           if (i == 0 && cont) p = cr + p;
           if (i < ntg - 1) {
             float* dp = dest_lo(t0 + i, lo);
