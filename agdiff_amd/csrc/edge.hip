@@ -287,8 +287,40 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 4) k_cfconv_fused(ConvArgs
 #pragma unroll
         for (int r = 0; r < 4; ++r) xg[r] = xb[xoff[r]];
       };
+      // Row masks of the first two targets of the tile, built once per tile: almost every 16-edge tile holds
+      // the in-lists of one or two targets (in-degree >= 8), so the per-channel-tile reduction is 8 FMAs and two
+      // quarter sums; tiles with more targets take the general loop.
+      f32x4 m0, m1;
+      {
+        const int b0 = bound(0), b1 = bound(1), b2 = bound(ntg >= 2 ? 2 : 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int er = (int)tbase + 4 * q + r;
+          m0[r] = (er >= b0 && er < b1) ? 1.0f : 0.0f;
+          m1[r] = (ntg >= 2 && er >= b1 && er < b2) ? 1.0f : 0.0f;
+        }
+      }
+      float* const dp0 = dest_lo(t0, bound(0));
       auto reduce_tile = [&](f32x4 z, int nt, float& cr) {
         if (a.ablate & 16) { cr = z[0]; return; }
+        if (ntg <= 2 && !(a.ablate & 32)) {
+          float p0 = z[0] * m0[0], p1 = z[0] * m1[0];
+#pragma unroll
+          for (int r = 1; r < 4; ++r) {
+            p0 = fmaf(z[r], m0[r], p0);
+            p1 = fmaf(z[r], m1[r], p1);
+          }
+          p0 = ag_quarter_sum(p0);
+          if (cont) p0 = cr + p0;
+          if (ntg == 2) {
+            p1 = ag_quarter_sum(p1);
+            if (lane < 16) dp0[16 * nt + col] = p0;
+            cr = p1;
+          } else {
+            cr = p0;
+          }
+          return;
+        }
         float newcarry = 0.0f;
         for (int i = 0; i < ntg; ++i) {
           const int lo = bound(i), hi = bound(i + 1);
