@@ -250,3 +250,43 @@ def test_driver_end_to_end(tmp_path):
         assert np.abs(p.mean(axis=1)).max() < 1e-3            # every conformer is centred (dualenc.py:542)
         assert z["traj_%d" % i].shape == (6,) + p.shape
     driver.main(["--ckpt", ckpt, "--testset", ts, "--out", out, "--n-steps", "6", "--resume"])   # nothing left to do
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_ragged_and_degenerate_graphs(precision):
+    """Edge cases the path must survive: a single-atom graph (no edges at all), a two-atom graph, isolated atoms far
+    beyond the cutoff (zero in-degree nodes between lists), a graph larger than the 32-neighbour cap, and a
+    batch whose edge count is not a multiple of the tile size."""
+    from agdiff_amd import drugs_model_config
+    from oracle import agdiff_oracle as O
+    cfg = drugs_model_config(num_diffusion_timesteps=10)
+    m, sd = _gpu_model(cfg, precision=precision)
+    rng = np.random.default_rng(9)
+    from agdiff_amd import synth
+    at3, r3, c3, t3 = synth.random_molecule(rng, 47)
+    atoms = [np.array([6]), np.array([6, 8]), at3, np.array([1, 1, 1])]
+    bonds = [(np.zeros((2, 0), dtype=np.int64), np.zeros(0, dtype=np.int64)),
+             (np.array([[0, 1], [1, 0]]), np.array([1, 1])),
+             (np.stack([r3, c3]), t3),
+             (np.array([[0, 1], [1, 0]]), np.array([2, 2]))]          # third atom of the last graph has no bond
+    at_l, bi_l, bt_l, ba_l, off = [], [], [], [], 0
+    for g, (a, (bi, bt)) in enumerate(zip(atoms, bonds)):
+        at_l.append(a); bi_l.append(bi + off); bt_l.append(bt); ba_l.append(np.full(a.shape[0], g)); off += a.shape[0]
+    at, bi, bt, ba = (t(np.concatenate(at_l)), t(np.concatenate(bi_l, axis=1)), t(np.concatenate(bt_l)),
+                      t(np.concatenate(ba_l)))
+    gen = torch.Generator().manual_seed(4)
+    pos = torch.randn(at.shape[0], 3, generator=gen) * 1.3
+    pos[-1] += 40.0                                   # isolated atom: beyond the cutoff of its graph mates
+    ref = O.forward(sd, cfg, at, pos, bi, bt, ba, extend_order=False)
+    got = m(at.cuda(), pos.cuda(), bi.cuda(), bt.cuda(), ba.cuda(), None, return_edges=True, extend_order=False)
+    assert np.array_equal(got[2].cpu().numpy(), ref[2].numpy())
+    assert np.array_equal(got[3].cpu().numpy(), ref[3].numpy())
+    assert rel_err(got[0].cpu().numpy(), ref[0].numpy()) < TOL
+    assert rel_err(got[1].cpu().numpy(), ref[1].numpy()) < TOL
+    noise = torch.randn(3, at.shape[0], 3, generator=gen)
+    rpos, _ = O.langevin_dynamics_sample_diffusion(sd, cfg, at, pos, bi, bt, ba, 4, False, n_steps=3, noise=noise,
+                                                   w_global=1.0, global_start_sigma=float("inf"))
+    gpos, _ = m.langevin_dynamics_sample_diffusion(at.cuda(), pos.cuda(), bi.cuda(), bt.cuda(), ba.cuda(), 4, False,
+                                                   n_steps=3, noise=noise.cuda(), w_global=1.0,
+                                                   global_start_sigma=float("inf"))
+    assert rel_err(gpos.cpu().numpy(), rpos.numpy()) < TOL
