@@ -5,6 +5,14 @@
 
 extern "C" int agdiff_abi_version(void) { return AGDIFF_ABI_VERSION; }
 
+// One chunk per wave slot at least twice over (256 CUs x 16 waves), at most AGDIFF_MAX_CHUNK_TILES tiles.
+extern "C" int agdiff_conv_chunk_tiles(int64_t max_edges) {
+  const int64_t tiles = (max_edges + AG_TW - 1) / AG_TW;
+  int c = 1;
+  while (c < AGDIFF_MAX_CHUNK_TILES && tiles / (2 * c) >= 2 * 4096) c *= 2;
+  return c;
+}
+
 extern "C" int agdiff_struct_sizes(int64_t* out) {
   if (!out) return AGDIFF_ERR_ARG;
   out[0] = sizeof(agdiff_conv_params_t);

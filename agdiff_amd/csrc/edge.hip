@@ -142,6 +142,7 @@ struct ConvArgs {
   float* agg;            // [N][192]
   float* agg_first;      // [chunks][192]
   int64_t max_chunks;
+  int32_t chunk_tiles;   // tiles per chunk (agdiff_conv_chunk_tiles)
   int32_t stagger;       // s_sleep units (64 cycles) the second wave of each SIMD waits before its first tile
   int32_t ablate;        // timing experiments only (AGDIFF_ABLATE env): bit0 skip layer 1, bit1 skip ssp,
                          // bit2 skip layer 2, bit3 skip x gather, bit4 skip reduction
@@ -167,7 +168,7 @@ __device__ unsigned long long ag_conv_stamp_acc[8];
 // encoder/schnet.py:136-162 for conv1 (F=128) and conv2 (F=64) of one InteractionBlock:
 //   W_e = nn(edge_attr_e) * (lw(d_e) * C(d_e));  agg[dst] += x[src] * W_e   (aggr='add')
 // Persistent launch, one 16-wave workgroup per CU (4 waves per SIMD).  Each wave walks AGDIFF_CHUNK_TILES
-// consecutive destination-sorted 16-edge tiles per chunk and keeps the running sum of the open target in
+// consecutive destination-sorted 16-edge tiles per chunk (chunk_tiles = 1..8, fewer for small batches) and keeps the running sum of the open target in
 // registers; a target whose list started in an earlier chunk is written to agg_first[chunk] and added by
 // the node stage (fixed order -> bitwise reproducible, no atomics).
 template <int MODE>
@@ -192,7 +193,7 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 4) k_cfconv_fused(ConvArgs
   [[maybe_unused]] unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c0 = 0, c1 = 0;
 
   for (int64_t chunk = (int64_t)blockIdx.x * AG_CONV_WAVES + wave; chunk < a.max_chunks; chunk += cstride) {
-    const int64_t e_begin = chunk * (AG_TW * AGDIFF_CHUNK_TILES);
+    const int64_t e_begin = chunk * (AG_TW * a.chunk_tiles);
     if (e_begin >= E) break;
     int run_t = -1;
     // running sums (192 channels: entry i = channel 16 i + (lane & 15), replicated over the quarters) of
@@ -204,8 +205,8 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 4) k_cfconv_fused(ConvArgs
       return (lo >= e_begin) ? (a.agg + (size_t)t * 192) : (a.agg_first + (size_t)chunk * 192);
     };
 
-    for (int tt = 0; tt < AGDIFF_CHUNK_TILES; ++tt) {
-      const int64_t tile = chunk * AGDIFF_CHUNK_TILES + tt;
+    for (int tt = 0; tt < a.chunk_tiles; ++tt) {
+      const int64_t tile = chunk * a.chunk_tiles + tt;
       const int64_t tbase = tile * AG_TW;
       if (tbase >= E) break;
       AG_STAMP(c0);
@@ -566,9 +567,9 @@ extern "C" int agdiff_edge_scales(const agdiff_params_t* p, const agdiff_topo_t*
 extern "C" int agdiff_cfconv_fused(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k,
                                    void* stream) {
   if (!p || !topo || !ws || k < 0 || k >= p->num_convs) return AGDIFF_ERR_ARG;
-  if (topo->max_in_degree > AGDIFF_TILE * AGDIFF_CHUNK_TILES) return AGDIFF_ERR_LIMIT;
   const int64_t max_tiles = (topo->max_edges + AG_TW - 1) / AG_TW;
-  const int64_t max_chunks = (max_tiles + AGDIFF_CHUNK_TILES - 1) / AGDIFF_CHUNK_TILES;
+  const int chunk_tiles = agdiff_conv_chunk_tiles(topo->max_edges);
+  const int64_t max_chunks = (max_tiles + chunk_tiles - 1) / chunk_tiles;
   if (max_chunks == 0) return AGDIFF_OK;
   ConvArgs a;
   a.cp = p->conv[k];
@@ -586,6 +587,7 @@ extern "C" int agdiff_cfconv_fused(const agdiff_params_t* p, const agdiff_topo_t
   a.agg = ws->agg;
   a.agg_first = ws->agg_first;
   a.max_chunks = max_chunks;
+  a.chunk_tiles = chunk_tiles;
   {
     static int abl = -1;
     if (abl < 0) {

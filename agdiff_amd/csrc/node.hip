@@ -19,6 +19,7 @@ struct NodeStageArgs {
   int64_t n;
   int32_t finish;
   int32_t prep;
+  int32_t chunk_edges;         // AG_TW * agdiff_conv_chunk_tiles(max_edges)
 };
 
 // Stage k of SchNetEncoder.forward (schnet.py:268-282):
@@ -48,18 +49,19 @@ __global__ void __launch_bounds__(AG_WG, 2) k_schnet_node_stage(NodeStageArgs a)
       {
         // aggregates: agg[node] (+ the partial its last chunk kept separately, edge.hip k_cfconv_fused)
         const int lo = a.in_ptr[nd], hi = a.in_ptr[nd + 1];
-        const int chunk_e = AG_TW * AGDIFF_CHUNK_TILES;
+        // A list that spans chunks c_lo..c_hi: chunk c_lo wrote its part to agg[node], every later chunk to
+        // agg_first[c]; they are added in chunk order.
+        const int chunk_e = a.chunk_edges;
         const bool has = hi > lo;
         const int c_lo = lo / chunk_e, c_hi = has ? (hi - 1) / chunk_e : c_lo;
         const float* ar = a.agg + (size_t)nd * 192;
-        const float* fr = a.agg_first + (size_t)c_hi * 192;
-        const bool split = has && (c_hi > c_lo);
         ag_init_vec<16>(u, a.prev.lin2_b, q);
         AgIn<MODE> g[2];
         auto load_slice = [&](AgIn<MODE>& dst, int k) {
           f32x4 v0 = has ? ag_ld4(ar + 32 * k + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
           f32x4 v1 = has ? ag_ld4(ar + 32 * k + 16 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
-          if (split) {
+          for (int c = c_lo + 1; c <= c_hi; ++c) {
+            const float* fr = a.agg_first + (size_t)c * 192;
             v0 += ag_ld4(fr + 32 * k + 4 * q);
             v1 += ag_ld4(fr + 32 * k + 16 + 4 * q);
           }
@@ -356,6 +358,7 @@ extern "C" int agdiff_schnet_node_stage(const agdiff_params_t* p, const agdiff_t
   a.h = ws->h;
   a.xs = ws->xs;
   a.n = topo->num_nodes;
+  a.chunk_edges = AG_TW * agdiff_conv_chunk_tiles(topo->max_edges);
   const int64_t tiles = (a.n + AG_TW - 1) / AG_TW;
   if (p->precision == AG_BF3)
     k_schnet_node_stage<AG_BF3><<<dim3((unsigned)((tiles + 3) / 4)), dim3(AG_WG), 0, (hipStream_t)stream>>>(a);

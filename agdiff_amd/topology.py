@@ -83,8 +83,6 @@ class BatchTopology:
         self.max_atoms = int(counts.max())
         if self.max_atoms > _lib.MAX_ATOMS_PER_GRAPH:
             raise NotImplementedError("graphs with more than %d atoms are not supported" % _lib.MAX_ATOMS_PER_GRAPH)
-        if self.max_in_degree > _lib.TILE * _lib.CHUNK_TILES:
-            raise NotImplementedError("in-degree bound %d exceeds the kernel's chunk size" % self.max_in_degree)
         if N * 192 * 4 >= 2 ** 32 or self.max_edges >= 2 ** 31 - 64:
             raise NotImplementedError("batch too large for 32-bit offsets; split it")
 
@@ -118,7 +116,8 @@ class Workspace:
         TW = _lib.TILE
         etiles = (E + TW - 1) // TW
         ltiles = (L + TW - 1) // TW
-        chunks = (etiles + _lib.CHUNK_TILES - 1) // _lib.CHUNK_TILES
+        chunk_tiles = _lib.load().agdiff_conv_chunk_tiles(E)
+        chunks = (etiles + chunk_tiles - 1) // chunk_tiles
         i32 = lambda n: torch.zeros(max(int(n), 1), dtype=torch.int32, device=dev)
         f32 = lambda n: torch.zeros(max(int(n), 1), dtype=torch.float32, device=dev)
         self.num_edges = i32(1)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 8
+#define AGDIFF_ABI_VERSION 9
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -31,7 +31,7 @@ extern "C" {
 #define AGDIFF_MAX_ATOMS_PER_GRAPH 512
 #define AGDIFF_RADIUS_CAP 33       /* max_num_neighbors + 1 (torch_cluster.radius_graph, common.py:217) */
 #define AGDIFF_TILE 16             /* edges / nodes per MFMA tile */
-#define AGDIFF_CHUNK_TILES 8       /* tiles per wave-chunk in the fused CFConv kernel (128 edges) */
+#define AGDIFF_MAX_CHUNK_TILES 8   /* most tiles one wave walks per chunk in the fused CFConv kernel (128 edges) */
 
 enum agdiff_status {
   AGDIFF_OK = 0,
@@ -131,7 +131,7 @@ typedef struct agdiff_topo {
   int64_t num_local;         /* L: local edges, in reference order (sorted by (src, dst)) */
   int64_t max_edges;         /* capacity of the per-edge buffers: sum_i (33 + local in-degree_i) */
   int64_t max_atoms_per_graph; /* <= AGDIFF_MAX_ATOMS_PER_GRAPH */
-  int64_t max_in_degree;     /* max_i (33 + local in-degree_i) <= AGDIFF_TILE * AGDIFF_CHUNK_TILES = 128 */
+  int64_t max_in_degree;     /* max_i (33 + local in-degree_i); any value (a list may span several chunks) */
   const int32_t* graph_ptr;  /* [G+1] node offsets */
   const int32_t* atom_type;  /* [N] */
   const int32_t* loc_src;    /* [L] */
@@ -168,7 +168,8 @@ typedef struct agdiff_ws {
   float*   h;                /* [N][128] SchNet node state */
   float*   xs;               /* [N][192] lin1/BN/LeakyReLU outputs feeding conv1 (0..127) and conv2 (128..191) */
   float*   agg;              /* [N][192] CFConv aggregates */
-  float*   agg_first;        /* [ceil(tiles/CHUNK_TILES)][192] partial sums of a chunk's first target */
+  float*   agg_first;        /* [ceil(tiles / agdiff_conv_chunk_tiles(max_edges))][192]: partial sum of the target whose list was
+                                already open when the chunk started; the node stage adds them in chunk order */
   float*   hl;               /* [N][128] GIN node state (ping) */
   float*   hl2;              /* [N][128] (pong) */
   int32_t* nan_flag;         /* [1] set to 1 when a position becomes NaN */
@@ -189,6 +190,10 @@ typedef struct agdiff_step_args {
   float clip_pos;            /* < 0: no clamp */
   int32_t use_global;        /* sigmas[i] < global_start_sigma (dualenc.py:515) */
 } agdiff_step_args_t;
+
+/* Tiles per chunk the fused CFConv kernel and the node stage use for a workspace of `max_edges` edges (1..8):
+ * small batches get short chunks so that every wave slot of the chip has work. */
+int agdiff_conv_chunk_tiles(int64_t max_edges);
 
 /* Build stamp / ABI check. */
 int agdiff_abi_version(void);
