@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(AG_WG, 2) k_schnet_node_stage(NodeStageArgs a)
   const int64_t node = tile * AG_TW + (lane & 15);
   const bool valid = node < a.n;
   const int64_t nd = valid ? node : 0;
-  constexpr int PF = AgPF<MODE>::v;
+  constexpr int PF = (MODE == AG_F32) ? 3 : 10;   // few waves per SIMD here: hide the L2 latency of the weight stream in registers
 
   f32x4 hv[8];
   if (!a.finish) {
@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(AG_WG, 2) k_gin_layer(GinArgs a) {
   const bool valid = node < a.n;
   const int64_t nd = valid ? node : 0;
   const float* hin_self = a.emb ? a.emb + (size_t)a.atom_type[nd] * 128 : a.h_in + (size_t)nd * 128;
-  constexpr int PF = AgPF<MODE>::v;
+  constexpr int PF = (MODE == AG_F32) ? 3 : 10;   // few waves per SIMD here: hide the L2 latency of the weight stream in registers
 
   f32x4 m[8];
 #pragma unroll
