@@ -87,6 +87,43 @@ __global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_edge_encoder(EncAr
   }
 }
 
+// ------------------------------------------------------------------------------ gaussian edge encoder
+// encoder/edge.py:17-42 + GaussianSmearing (schnet.py:18-27): a[e] = [exp(coeff (d - offset_k)^2), k < 64 |
+// bond_emb[type] (64)].  No GEMM: one 16-edge tile per wave, written straight in operand form.
+struct GaussArgs {
+  const float* offset;
+  const float* emb;
+  const int32_t* n_dev;
+  const float* e_len;
+  const int32_t* e_type;
+  float* out_frag;
+  float* out_rows;
+  int64_t max_tiles;
+  float coeff_log2e;
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k_edge_gaussian(GaussArgs a) {
+  const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int E = *a.n_dev;
+  if (tile >= a.max_tiles || tile * AG_TW >= E) return;
+  const int lane = ag_lane();
+  const int q = lane >> 4;
+  const int64_t e = tile * AG_TW + (lane & 15);
+  const bool valid = e < E;
+  const float d = valid ? a.e_len[e] : 0.0f;
+  const int ty = valid ? a.e_type[e] : 0;
+  f32x4 y[8];
+  ag_load_row<4, 0>(y, a.offset, q);
+  AG_FOR_TILE(y, 4, ag_exp2(a.coeff_log2e * ((d - v) * (d - v))));
+  ag_load_row<4, 4>(y, a.emb + (size_t)ty * 64, q);
+  if (a.out_rows && valid) ag_store_row<8, 0>(y, a.out_rows + (size_t)e * 128, q);
+  AgIn<MODE> x[4];
+  ag_cvt_tiles<MODE, 4, 0>(y, x);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) ag_store_attr(x[t], a.out_frag, tile, t, lane);
+}
+
 // ------------------------------------------------------------------------------ per-edge conv scales
 // DistanceWeightingNetwork (schnet.py:83-100) times the cutoff envelope (schnet.py:140-146).
 // cos via v_cos_f32 on the half angle (0.5 (cos x + 1) = cos^2(x/2), argument <= 1/4 revolution inside the
@@ -523,6 +560,19 @@ extern "C" int agdiff_edge_encoder(const agdiff_params_t* p, const int32_t* n_ed
                                    void* stream) {
   if (!p || !n_edges_dev || !e_len || !e_type || !attr_frag || max_tiles < 0) return AGDIFF_ERR_ARG;
   if (max_tiles == 0) return AGDIFF_OK;
+  if (p->edge_encoder == 1) {
+    if (!p->ge_offset || !p->ge_emb) return AGDIFF_ERR_ARG;
+    GaussArgs g{p->ge_offset, p->ge_emb, n_edges_dev, e_len, e_type, attr_frag, attr_rows, max_tiles,
+                p->ge_coeff * 1.44269504088896340736f};
+    const dim3 grid((unsigned)((max_tiles + 3) / 4));
+    if (p->precision == AG_BF3)
+      k_edge_gaussian<AG_BF3><<<grid, dim3(256), 0, (hipStream_t)stream>>>(g);
+    else
+      k_edge_gaussian<AG_F32><<<grid, dim3(256), 0, (hipStream_t)stream>>>(g);
+    AG_CHECK_LAUNCH();
+    return AGDIFF_OK;
+  }
+  if (p->edge_encoder != 0) return AGDIFF_ERR_ARG;
   EncArgs a{p->ee_fe_w, p->ee_fe_b, p->ee_t1, p->ee_w1_pk, p->ee_t3, p->ee_w23_pk, p->ee_w4_pk, p->ee_b4,
             n_edges_dev, e_len, e_type, attr_frag, attr_rows, max_tiles};
   int64_t wgs = (max_tiles + AG_PERSIST_WAVES - 1) / AG_PERSIST_WAVES;

@@ -97,6 +97,7 @@ def fold_bn(W, b, sd, p, eps=1e-5):
 
 
 PRECISIONS = {"f32": 0, "bf16x3": 1}
+EDGE_ENCODERS = {"mlp": 0, "gaussian": 1}       # agdiff_params_t.edge_encoder
 
 
 class PackedParams:
@@ -116,7 +117,7 @@ class PackedParams:
 
         if cfg.hidden_dim != H:
             raise NotImplementedError("hidden_dim must be 128 (InteractionBlock.lin is Linear(256, hidden), schnet.py:190)")
-        if cfg.edge_encoder != "mlp":
+        if cfg.edge_encoder not in EDGE_ENCODERS:
             raise NotImplementedError("Unknown edge encoder: %s" % cfg.edge_encoder)
         if cfg.mlp_act != "relu":
             raise NotImplementedError("mlp_act=%s (HIP heads implement relu, configs/*.yml:8)" % cfg.mlp_act)
@@ -127,6 +128,22 @@ class PackedParams:
 
         # ---------------- edge encoder (edge.py:84-103)
         e = "edge_encoder_global"
+        scalars["ge_coeff"] = 0.0
+        if cfg.edge_encoder == "gaussian":     # edge.py:17-42; schnet.py:18-27
+            off = _np(sd, e + ".rbf.offset")
+            arrays["ge_offset"] = off
+            arrays["ge_emb"] = _np(sd, e + ".bond_emb.weight")          # [100,64]
+            if off.shape != (H // 2,) or arrays["ge_emb"].shape != (100, H // 2):
+                raise ValueError("gaussian edge encoder: expected 64 offsets and a [100,64] bond_emb")
+            scalars["ge_coeff"] = -0.5 / float(off[1] - off[0]) ** 2    # (offset[1]-offset[0]).item() ** 2
+        else:
+            self._pack_mlp_edge_encoder(sd, e, arrays, pack_blocks)
+        arrays["schnet_emb"] = _np(sd, "encoder_global.embedding.weight")
+        arrays["gin_emb"] = _np(sd, "encoder_local.node_emb.weight")
+        self._pack_rest(sd, cfg, device, mode, arrays, scalars, pack_blocks)
+
+    @staticmethod
+    def _pack_mlp_edge_encoder(sd, e, arrays, pack_blocks):
         emb = _np(sd, e + ".bond_emb.weight")                           # [100,128]
         W0, b0 = _np(sd, e + ".edge_feature_mlp.0.weight"), _np(sd, e + ".edge_feature_mlp.0.bias")
         W2, b2 = _np(sd, e + ".edge_feature_mlp.2.weight"), _np(sd, e + ".edge_feature_mlp.2.bias")
@@ -140,9 +157,9 @@ class PackedParams:
         arrays["ee_w23_pk"] = pack_blocks(C0[:, :H] @ W2)
         arrays["ee_w4_pk"] = pack_blocks(C2)
         arrays["ee_b4"] = c2
-        arrays["schnet_emb"] = _np(sd, "encoder_global.embedding.weight")
-        arrays["gin_emb"] = _np(sd, "encoder_local.node_emb.weight")
 
+    def _pack_rest(self, sd, cfg, device, mode, arrays, scalars, pack_blocks):
+        import torch
         # ---------------- SchNet blocks (schnet.py:113-234)
         for k in range(cfg.num_convs):
             p = "encoder_global.interactions.%d" % k
@@ -227,8 +244,11 @@ class PackedParams:
 
         prm = _lib.Params()
         for f in ("ee_fe_w", "ee_fe_b", "ee_t1", "ee_w1_pk", "ee_t3", "ee_w23_pk", "ee_w4_pk", "ee_b4",
-                  "schnet_emb", "gin_emb"):
-            setattr(prm, f, P(f))
+                  "ge_offset", "ge_emb", "schnet_emb", "gin_emb"):
+            if f in offs:
+                setattr(prm, f, P(f))
+        prm.edge_encoder = EDGE_ENCODERS[cfg.edge_encoder]
+        prm.ge_coeff = scalars["ge_coeff"]
         for k in range(cfg.num_convs):
             cp, n = prm.conv[k], "conv%d." % k
             for f, _ in _lib.ConvParams._fields_:

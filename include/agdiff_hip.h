@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 9
+#define AGDIFF_ABI_VERSION 10
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -107,6 +107,10 @@ typedef struct agdiff_params {
   const float* ee_w23_pk;    /* pk [8][4]: comb.0.weight[:,:128] @ edge_feature_mlp.2.weight */
   const float* ee_w4_pk;     /* pk [8][4]: combination_mlp.2 */
   const float* ee_b4;        /* [128] */
+  /* GaussianSmearingEdgeEncoder (edge.py:17-42 with GaussianSmearing, schnet.py:18-27): used instead of the
+   * ee_* fields when edge_encoder == 1; out = [exp(coeff (d - offset_k)^2), k < 64 | bond_emb[type]] */
+  const float* ge_offset;    /* [64] rbf.offset buffer = linspace(0, 2 cutoff, 64) */
+  const float* ge_emb;       /* [100][64] bond_emb.weight */
   const float* schnet_emb;   /* [100][128] encoder_global.embedding (max_norm renorm applied to used rows) */
   const float* gin_emb;      /* [100][128] encoder_local.node_emb */
   agdiff_conv_params_t conv[AGDIFF_MAX_CONVS];
@@ -119,6 +123,8 @@ typedef struct agdiff_params {
   int32_t smooth;            /* config.smooth_conv */
   int32_t precision;         /* 0: exact fp32 MFMA; 1: split-bf16 (hi+lo, 3 MFMA passes, fp32 accumulate) -- selects
                                 both the kernels and the layout of every packed matrix and of e_attr / l_attr */
+  int32_t edge_encoder;      /* config.edge_encoder: 0 'mlp' (edge.py:45-103), 1 'gaussian' (edge.py:17-42) */
+  float ge_coeff;            /* -0.5 / (offset[1] - offset[0])^2 (schnet.py:22) */
   int32_t pad0;
 } agdiff_params_t;
 
@@ -213,7 +219,9 @@ int agdiff_local_lengths(const agdiff_topo_t* topo, const agdiff_ws_t* ws, const
  * ws->e_scale from ws->e_len. */
 int agdiff_edge_scales(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, void* stream);
 
-/* MLPEdgeEncoder.forward (encoder/edge.py:84-103).  n_edges_dev: device scalar with the live edge
+/* get_edge_encoder(cfg)(edge_length, edge_type) (encoder/edge.py:106-116): MLPEdgeEncoder.forward
+ * (edge.py:84-103) when p->edge_encoder == 0, GaussianSmearingEdgeEncoder.forward (edge.py:34-42) when 1.
+ * n_edges_dev: device scalar with the live edge
  * count (<= max_tiles*16); writes operand-form edge_attr tiles. */
 int agdiff_edge_encoder(const agdiff_params_t* p, const int32_t* n_edges_dev, int64_t max_tiles,
                         const float* e_len, const int32_t* e_type, float* attr_frag, float* attr_rows /* optional [E][128] */,

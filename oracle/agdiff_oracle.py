@@ -370,7 +370,8 @@ def synth_state_dict_for(cfg, head_scale=1e-3):
     from agdiff_amd import synth  # pure-numpy helper shared by tests/bench (not a compute path)
     import os
     keys = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden",
-                        "g7_state_dict_keys.txt")
+                        "g7_state_dict_keys_gaussian.txt" if cfg.edge_encoder == "gaussian"
+                        else "g7_state_dict_keys.txt")             # 802 / 854 keys
     sd = {}
     betas, alphas, _ = schedule_tensors(cfg)
     for line in open(keys):
@@ -383,7 +384,9 @@ def synth_state_dict_for(cfg, head_scale=1e-3):
         else:
             dtype = getattr(torch, dt)
             v = synth.synth_tensor(k, shape, head_scale)
-            if v is None:
+            if v is None and k.endswith("rbf.offset"):         # GaussianSmearing buffer, schnet.py:21
+                sd[k] = torch.linspace(0.0, cfg.cutoff * 2, shape[0])
+            elif v is None:
                 sd[k] = torch.zeros(shape, dtype=dtype)
             else:
                 sd[k] = torch.from_numpy(v.copy()).reshape(shape).to(dtype)

@@ -217,7 +217,28 @@ def g_extend_order():
     save("g9_extend_order", **recs)
 
 
+def g_gaussian():
+    """Row a6b: edge_encoder='gaussian'.  The reference's edge.py uses GaussianSmearing without importing it
+    (NameError at edge.py:24); the class exists in encoder/schnet.py:18-27, so it is put into edge's namespace
+    here -- the one-line import the reference lacks -- and everything else runs unmodified."""
+    from agdiff.models.encoder import edge as ref_edge, schnet as ref_schnet
+    ref_edge.GaussianSmearing = ref_schnet.GaussianSmearing
+    cfg = qm9_model_config(edge_encoder="gaussian")
+    m, _ = g_forward("g3_forward_gaussian", cfg, "qm9", 5, 3, 1, 1.6, stages=True)
+    with open(os.path.join(HERE, "g7_state_dict_keys_gaussian.txt"), "w") as f:
+        for k, v in m.state_dict().items():
+            f.write("%s %s %s\n" % (k, "x".join(map(str, v.shape)) or "-", str(v.dtype).replace("torch.", "")))
+    print("wrote g7_state_dict_keys_gaussian.txt  (%d keys)" % len(m.state_dict()))
+    g_forward("g3_forward_gaussian_drugs", drugs_model_config(edge_encoder="gaussian"), "drugs", 9, 2, 2, 1.5,
+              stages=False)
+    g_sampler("g5_sampler_gaussian", drugs_model_config(edge_encoder="gaussian", num_diffusion_timesteps=10),
+              "qm9", 24, 2, 2, n_steps=10, step_lr=1e-6, w_global=1.0, global_start_sigma=0.5, clip=1000.0)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["gaussian"]:          # add the a6b fixtures without touching the others
+        g_gaussian()
+        sys.exit(0)
     g_schedule_and_keys()
     # G2+G3 uncapped QM9-shaped batch with per-stage outputs (small: 3 molecules x 1 copy)
     g_forward("g3_forward_qm9_small", qm9_model_config(), "qm9", 3, 3, 1, 1.6, stages=True)
@@ -235,3 +256,4 @@ if __name__ == "__main__":
               global_start_sigma=0.5, clip=0.05, clip_local=0.02, clip_pos=30.0)
     g_nan()
     g_extend_order()
+    g_gaussian()

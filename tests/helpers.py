@@ -32,12 +32,17 @@ FORWARD_CASES = {
     "g3_forward_qm9_small": lambda: qm9_model_config(),
     "g3_forward_smooth_sparse": lambda: drugs_model_config(),
     "g3_forward_drugs_capped": lambda: drugs_model_config(),
+    "g3_forward_gaussian": lambda: qm9_model_config(edge_encoder="gaussian"),
+    "g3_forward_gaussian_drugs": lambda: drugs_model_config(edge_encoder="gaussian"),
 }
+STAGE_CASES = ["g3_forward_qm9_small", "g3_forward_smooth_sparse", "g3_forward_gaussian"]
+SAMPLER_CASES = ["g5_sampler_top", "g5_sampler_lowT_global", "g5_sampler_mixed_cliplocal", "g5_sampler_gaussian"]
 
 
-def sampler_case_cfg(g):
+def sampler_case_cfg(g, case=""):
     base = drugs_model_config if int(g["cfg_smooth"]) else qm9_model_config
-    return base(num_diffusion_timesteps=int(g["cfg_T"]), beta_end=float(g["cfg_beta_end"]))
+    return base(num_diffusion_timesteps=int(g["cfg_T"]), beta_end=float(g["cfg_beta_end"]),
+                edge_encoder="gaussian" if "gaussian" in case else "mlp")
 
 
 def sampler_case_kwargs(g):

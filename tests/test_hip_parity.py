@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (FORWARD_CASES, load_golden, rel_err, sampler_case_cfg, sampler_case_kwargs, t)
+from helpers import (FORWARD_CASES, SAMPLER_CASES, STAGE_CASES, load_golden, rel_err, sampler_case_cfg, sampler_case_kwargs, t)
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -97,7 +97,7 @@ def test_graph_build_bit_exact(case):
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
-@pytest.mark.parametrize("case", ["g3_forward_qm9_small", "g3_forward_smooth_sparse"])
+@pytest.mark.parametrize("case", STAGE_CASES)
 def test_edge_encoder_and_stages(case, precision):
     from agdiff_amd import _lib
     g = load_golden(case)
@@ -140,10 +140,10 @@ def test_forward_matches_reference_golden(case, precision):
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
-@pytest.mark.parametrize("case", ["g5_sampler_top", "g5_sampler_lowT_global", "g5_sampler_mixed_cliplocal"])
+@pytest.mark.parametrize("case", SAMPLER_CASES)
 def test_sampler_matches_reference_golden(case, precision):
     g = load_golden(case)
-    cfg = sampler_case_cfg(g)
+    cfg = sampler_case_cfg(g, case)
     m, sd = _gpu_model(cfg, head_scale=float(g["head_scale"]), precision=precision)
     kw = sampler_case_kwargs(g)
     pos, traj = m.langevin_dynamics_sample_diffusion(

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (FORWARD_CASES, load_golden, rel_err, sampler_case_cfg, sampler_case_kwargs, t)
+from helpers import (FORWARD_CASES, SAMPLER_CASES, STAGE_CASES, load_golden, rel_err, sampler_case_cfg, sampler_case_kwargs, t)
 from oracle import agdiff_oracle as O
 
 TOL = 1e-6 * 5
@@ -87,10 +87,10 @@ def test_forward_stage_modules_g2():
     assert rel_err(sc.numpy(), g["scaled_b0"]) < TOL
 
 
-@pytest.mark.parametrize("case", ["g5_sampler_top", "g5_sampler_lowT_global", "g5_sampler_mixed_cliplocal"])
+@pytest.mark.parametrize("case", SAMPLER_CASES)
 def test_sampler_g5(case):
     g = load_golden(case)
-    cfg = sampler_case_cfg(g)
+    cfg = sampler_case_cfg(g, case)
     sd = O.synth_state_dict_for(cfg, head_scale=float(g["head_scale"]))
     kw = sampler_case_kwargs(g)
     pos, traj = O.langevin_dynamics_sample_diffusion(
