@@ -177,6 +177,26 @@ def repeat_molecule(atom_type, row, col, typ, num_samples, node_offset=0, graph_
     return at, r, c, t, batch
 
 
+def alanine_dipeptide(num_samples=250):
+    """BASELINE.json configs[0]: the molecule of examples/alanine_dipeptide.pdb (ACE-ALA-NME, 22 atoms in file
+    order) with its 21 covalent bonds by standard peptide topology (both C=O double, the rest single; rdkit's
+    own perception is unpinned), extended to order 3 and replicated `num_samples` times the way
+    examples/test_alanine_dipeptide.py:292-298 does (250 copies).  Same dict as make_packed_batch."""
+    elements = "H C H H C O N H C H C H H H C O N H C H H H".split()
+    z = {"H": 1, "C": 6, "N": 7, "O": 8}
+    atom_type = np.array([z[e] for e in elements], dtype=np.int64)
+    # 1-based serials of the pdb: (i, j, bond type)
+    bonds = [(2, 1, 1), (2, 3, 1), (2, 4, 1), (2, 5, 1), (5, 6, 2), (5, 7, 1),              # ACE
+             (7, 8, 1), (7, 9, 1), (9, 10, 1), (9, 11, 1), (11, 12, 1), (11, 13, 1), (11, 14, 1),
+             (9, 15, 1), (15, 16, 2), (15, 17, 1),                                            # ALA
+             (17, 18, 1), (17, 19, 1), (19, 20, 1), (19, 21, 1), (19, 22, 1)]                 # NME
+    i = np.array([b[0] - 1 for b in bonds]); j = np.array([b[1] - 1 for b in bonds]); t = np.array([b[2] for b in bonds])
+    r, c, ty = extend_graph_order_np(22, np.concatenate([i, j]), np.concatenate([j, i]), np.concatenate([t, t]), order=3)
+    at, r2, c2, t2, b2 = repeat_molecule(atom_type, r, c, ty, num_samples)
+    return dict(atom_type=at, bond_index=np.stack([r2, c2]), bond_type=t2, batch=b2, num_graphs=int(num_samples),
+                mol_id=np.zeros(num_samples, dtype=np.int64))
+
+
 def sample_n_atoms(rng, kind):
     if kind == "qm9":
         return int(rng.integers(10, 30))

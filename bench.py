@@ -37,12 +37,14 @@ MFMA_PASSES = {"f32": 1, "bf16x3": 3}        # MFMA FLOPs issued per algorithmic
 
 def build_batch(kind, mols, copies, seed):
     from agdiff_amd import synth
+    if kind == "alanine":          # BASELINE.json configs[0]: one molecule, `copies` conformers (250 in the example)
+        return synth.alanine_dipeptide(mols * copies)
     return synth.make_packed_batch(kind, mols, copies, seed=seed)
 
 
 def make_cfg(kind, schedule):
     from agdiff_amd import drugs_model_config, qm9_model_config
-    base = qm9_model_config if kind == "qm9" else drugs_model_config
+    base = qm9_model_config if kind in ("qm9", "alanine") else drugs_model_config
     return base(beta_end=2e-5) if schedule == "saturated" else base()
 
 
@@ -91,11 +93,12 @@ def cpu_baseline(kind, schedule, seed, budget_s=20.0):
 
 
 def main():
+    global JOB_STEPS
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="drugs", choices=["drugs", "qm9", "large"])
+    ap.add_argument("--workload", default="drugs", choices=["drugs", "qm9", "large", "alanine"])
     ap.add_argument("--mols", type=int, default=8)
     ap.add_argument("--copies", type=int, default=128)
     ap.add_argument("--schedule", default="saturated", choices=["saturated", "default"])
@@ -106,7 +109,10 @@ def main():
     ap.add_argument("--seed", type=int, default=2021)
     ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"])
     ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL all-gather path even with one rank")
+    ap.add_argument("--job-steps", type=int, default=JOB_STEPS, help="denoising steps of one sampling job (5000; the "
+                    "alanine dipeptide example runs 100)")
     args = ap.parse_args()
+    JOB_STEPS = args.job_steps
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -176,6 +176,26 @@ def g_sampler(name, cfg, kind, seed, nmol, copies, n_steps, head_scale=1e-3, **k
          cfg_T=cfg.num_diffusion_timesteps, cfg_beta_end=cfg.beta_end, cfg_smooth=int(cfg.smooth_conv), **kwn)
 
 
+def g_alanine():
+    """BASELINE.json configs[0]: alanine dipeptide, 100 steps through the langevin_dynamics_sample wrapper as
+    examples/test_alanine_dipeptide.py:303-320 calls it (qm9 config, w_global 1.0, global_start_sigma 0.5)."""
+    m = build_ref(qm9_model_config())
+    b = synth.alanine_dipeptide(3)
+    at, bi, bt, ba = T(b["atom_type"]), T(b["bond_index"]), T(b["bond_type"]), T(b["batch"])
+    g = torch.Generator().manual_seed(2021)
+    n, n_steps = at.shape[0], 100
+    pos_init = torch.randn(n, 3, generator=g)
+    noise = torch.randn(n_steps, n, 3, generator=g)
+    ref_dualenc.tqdm = lambda it, **k: it
+    with NoiseInjector(noise):
+        pos, traj = m.langevin_dynamics_sample(
+            atom_type=at, pos_init=pos_init, bond_index=bi, bond_type=bt, batch=ba, num_graphs=3,
+            extend_order=False, n_steps=n_steps, step_lr=1e-6, w_global=1.0, global_start_sigma=0.5, clip=1000.0,
+            clip_local=None, sampling_type="ld", eta=1.0)
+    save("g5_sampler_alanine", atom_type=at, bond_index=bi, bond_type=bt, batch=ba, num_graphs=3,
+         pos_init=pos_init, noise=noise, pos_final=pos, traj=torch.stack(traj)[::10], n_steps=n_steps)
+
+
 def g_nan():
     """G6: NaN in positions -> FloatingPointError (dualenc.py:539-541)."""
     cfg = qm9_model_config(num_diffusion_timesteps=20)
@@ -236,8 +256,9 @@ def g_gaussian():
 
 
 if __name__ == "__main__":
-    if sys.argv[1:] == ["gaussian"]:          # add the a6b fixtures without touching the others
-        g_gaussian()
+    if sys.argv[1:] and all(a in ("gaussian", "alanine") for a in sys.argv[1:]):   # add without touching the others
+        for a in sys.argv[1:]:
+            {"gaussian": g_gaussian, "alanine": g_alanine}[a]()
         sys.exit(0)
     g_schedule_and_keys()
     # G2+G3 uncapped QM9-shaped batch with per-stage outputs (small: 3 molecules x 1 copy)
@@ -257,3 +278,4 @@ if __name__ == "__main__":
     g_nan()
     g_extend_order()
     g_gaussian()
+    g_alanine()

@@ -161,6 +161,23 @@ def test_sampler_matches_reference_golden(case, precision):
     assert torch.equal(pos2, pos)
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_alanine_dipeptide_config0(precision):
+    """BASELINE.json configs[0] through the langevin_dynamics_sample wrapper, as
+    examples/test_alanine_dipeptide.py:303-320 calls it, against the reference's own trajectory."""
+    from agdiff_amd import qm9_model_config
+    g = load_golden("g5_sampler_alanine")
+    m, _ = _gpu_model(qm9_model_config(), precision=precision)
+    pos, traj = m.langevin_dynamics_sample(
+        atom_type=t(g["atom_type"]).cuda(), pos_init=t(g["pos_init"]).cuda(), bond_index=t(g["bond_index"]).cuda(),
+        bond_type=t(g["bond_type"]).cuda(), batch=t(g["batch"]).cuda(), num_graphs=3, extend_order=False,
+        n_steps=100, step_lr=1e-6, w_global=1.0, global_start_sigma=0.5, clip=1000.0, clip_local=None,
+        sampling_type="ld", eta=1.0, noise=t(g["noise"]).cuda())
+    assert len(traj) == 100
+    assert rel_err(torch.stack(traj)[::10].numpy(), g["traj"]) < TOL
+    assert rel_err(pos.cpu().numpy(), g["pos_final"]) < TOL
+
+
 def test_nan_raises_floating_point_error():
     from agdiff_amd import qm9_model_config, synth
     cfg = qm9_model_config(num_diffusion_timesteps=20)

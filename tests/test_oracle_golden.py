@@ -101,6 +101,26 @@ def test_sampler_g5(case):
     assert rel_err(pos.numpy(), g["pos_final"]) < 2e-5
 
 
+def test_alanine_dipeptide_config0():
+    """BASELINE.json configs[0]: 22-atom alanine dipeptide, 100 steps, qm9 config (the reference's example call)."""
+    from agdiff_amd import synth
+    from agdiff_amd.config import qm9_model_config
+    g = load_golden("g5_sampler_alanine")
+    b = synth.alanine_dipeptide(3)
+    assert b["atom_type"].shape == (66,) and sorted(set(b["atom_type"].tolist())) == [1, 6, 7, 8]
+    assert int((b["bond_type"] < 22).sum()) == 3 * 2 * 21            # 21 covalent bonds, both directions
+    for k in ("atom_type", "bond_index", "bond_type", "batch"):
+        assert np.array_equal(b[k], g[k]), k
+    cfg = qm9_model_config()
+    sd = O.synth_state_dict_for(cfg)
+    pos, traj = O.langevin_dynamics_sample_diffusion(
+        sd, cfg, t(g["atom_type"]), t(g["pos_init"]), t(g["bond_index"]), t(g["bond_type"]), t(g["batch"]), 3,
+        extend_order=False, n_steps=100, step_lr=1e-6, w_global=1.0, global_start_sigma=0.5, clip=1000.0,
+        noise=t(g["noise"]))
+    assert rel_err(torch.stack(traj)[::10].numpy(), g["traj"]) < 2e-5
+    assert rel_err(pos.numpy(), g["pos_final"]) < 2e-5
+
+
 def test_nan_raises_g6():
     from agdiff_amd.config import qm9_model_config
     from agdiff_amd import synth
