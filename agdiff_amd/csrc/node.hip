@@ -339,6 +339,132 @@ __global__ void __launch_bounds__(256) k_langevin_update(UpdateArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------ diffusion loss (forward only)
+// get_loss_diffusion, dualenc.py:284-395, as scripts/train.py:160-170 evaluates it under no_grad.
+struct PerturbArgs {
+  const int32_t* graph_ptr;
+  const float* pos;
+  const float* noise;
+  const float* alpha_graph;
+  float* out;
+};
+
+// pos_perturbed = pos + pos_noise * sqrt(1 - a) / sqrt(a), a = alphas[time_step[graph]]  (dualenc.py:308-312)
+__global__ void __launch_bounds__(256) k_perturb_positions(PerturbArgs a) {
+  const int g = blockIdx.x;
+  const int g0 = a.graph_ptr[g], n = a.graph_ptr[g + 1] - g0;
+  const float al = a.alpha_graph[g];
+  const float s1 = sqrtf(1.0f - al), s2 = sqrtf(al);
+  for (int k = threadIdx.x; k < 3 * n; k += blockDim.x) {
+    const int idx = 3 * g0 + k;
+    a.out[idx] = a.pos[idx] + (a.noise[idx] * s1) / s2;
+  }
+}
+
+struct LossArgs {
+  const int32_t* graph_ptr;
+  const float* pos_gt;
+  const float* pos;          // perturbed positions the score network was evaluated on
+  const float* alpha_graph;
+  float* loss;               // [3][N]: total, global, local
+  int64_t n_total;
+  float cutoff;
+  const int32_t* loc_src;
+  const int32_t* loc_dst;
+  const int32_t* loc_out_ptr;
+  const int32_t* loc_in_ptr;
+  const int32_t* loc_in_eid;
+  const float* l_len;
+  const float* l_inv;
+  const int32_t* in_ptr;
+  const int32_t* out_ptr;
+  const int32_t* ref2dst;
+  const int32_t* e_src;
+  const int32_t* e_dst;
+  const int32_t* e_type;
+  const float* e_len;
+  const float* e_inv;
+};
+
+__device__ __forceinline__ float ag_dist3(const float* __restrict__ p, int i, int j) {   // geometry.py:5-6
+  const float dx = p[3 * i] - p[3 * j], dy = p[3 * i + 1] - p[3 * j + 1], dz = p[3 * i + 2] - p[3 * j + 2];
+  return sqrtf(dx * dx + dy * dy + dz * dz);
+}
+
+// One workgroup per molecule, one thread per atom: the four eq_transforms (target / prediction x global / local,
+// geometry.py:9-17) gathered over the atom's out- and in-edges, then the squared differences
+// (dualenc.py:337-385).  d_target = (d_gt - d_perturbed) / sqrt(1 - a) * sqrt(a) per edge.
+__global__ void __launch_bounds__(256) k_diffusion_loss(LossArgs a) {
+  const int g = blockIdx.x;
+  const int g0 = a.graph_ptr[g], n = a.graph_ptr[g + 1] - g0;
+  const float al = a.alpha_graph[g];
+  const float s1 = sqrtf(1.0f - al), s2 = sqrtf(al);
+  for (int li = threadIdx.x; li < n; li += blockDim.x) {
+    const int i = g0 + li;
+    const float px = a.pos[3 * i], py = a.pos[3 * i + 1], pz = a.pos[3 * i + 2];
+    float t[3] = {0.f, 0.f, 0.f}, p[3] = {0.f, 0.f, 0.f};      // target / predicted, accumulated over both roles
+    float ti[3] = {0.f, 0.f, 0.f}, pi[3] = {0.f, 0.f, 0.f};
+    // ---- local edges (type > 0)
+    for (int e = a.loc_out_ptr[i]; e < a.loc_out_ptr[i + 1]; ++e) {
+      const int j = a.loc_dst[e];
+      const float dp = a.l_len[e], w = 1.0f / dp;
+      const float dt = ((ag_dist3(a.pos_gt, i, j) - dp) / s1) * s2, sc = a.l_inv[e];
+      const float ux = w * (px - a.pos[3 * j]), uy = w * (py - a.pos[3 * j + 1]), uz = w * (pz - a.pos[3 * j + 2]);
+      t[0] += ux * dt; t[1] += uy * dt; t[2] += uz * dt;
+      p[0] += ux * sc; p[1] += uy * sc; p[2] += uz * sc;
+    }
+    for (int k = a.loc_in_ptr[i]; k < a.loc_in_ptr[i + 1]; ++k) {
+      const int e = a.loc_in_eid[k];
+      const int j = a.loc_src[e];
+      const float dp = a.l_len[e], w = 1.0f / dp;
+      const float dt = ((ag_dist3(a.pos_gt, j, i) - dp) / s1) * s2, sc = a.l_inv[e];
+      const float ux = w * (a.pos[3 * j] - px), uy = w * (a.pos[3 * j + 1] - py), uz = w * (a.pos[3 * j + 2] - pz);
+      ti[0] -= ux * dt; ti[1] -= uy * dt; ti[2] -= uz * dt;
+      pi[0] -= ux * sc; pi[1] -= uy * sc; pi[2] -= uz * sc;
+    }
+    float ll = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float d = (p[c] + pi[c]) - (t[c] + ti[c]);
+      ll += d * d;
+      t[c] = p[c] = ti[c] = pi[c] = 0.f;
+    }
+    ll *= 5.0f;
+    // ---- global: edges with global_mask = (d_perturbed <= cutoff | local) & ~local  (dualenc.py:346-356)
+    for (int q = a.out_ptr[i]; q < a.out_ptr[i + 1]; ++q) {
+      const int e = a.ref2dst[q];
+      const float dp = a.e_len[e];
+      if (a.e_type[e] != 0 || !(dp <= a.cutoff)) continue;
+      const int j = a.e_dst[e];
+      const float w = 1.0f / dp;
+      const float dt = ((ag_dist3(a.pos_gt, i, j) - dp) / s1) * s2, sc = a.e_inv[e];
+      const float ux = w * (px - a.pos[3 * j]), uy = w * (py - a.pos[3 * j + 1]), uz = w * (pz - a.pos[3 * j + 2]);
+      t[0] += ux * dt; t[1] += uy * dt; t[2] += uz * dt;
+      p[0] += ux * sc; p[1] += uy * sc; p[2] += uz * sc;
+    }
+    for (int e = a.in_ptr[i]; e < a.in_ptr[i + 1]; ++e) {
+      const float dp = a.e_len[e];
+      if (a.e_type[e] != 0 || !(dp <= a.cutoff)) continue;
+      const int j = a.e_src[e];
+      const float w = 1.0f / dp;
+      const float dt = ((ag_dist3(a.pos_gt, j, i) - dp) / s1) * s2, sc = a.e_inv[e];
+      const float ux = w * (a.pos[3 * j] - px), uy = w * (a.pos[3 * j + 1] - py), uz = w * (a.pos[3 * j + 2] - pz);
+      ti[0] -= ux * dt; ti[1] -= uy * dt; ti[2] -= uz * dt;
+      pi[0] -= ux * sc; pi[1] -= uy * sc; pi[2] -= uz * sc;
+    }
+    float lg = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float d = (p[c] + pi[c]) - (t[c] + ti[c]);
+      lg += d * d;
+    }
+    lg *= 2.0f;
+    a.loss[i] = lg + ll;
+    a.loss[a.n_total + i] = lg;
+    a.loss[2 * a.n_total + i] = ll;
+  }
+}
+
 }  // namespace
 
 extern "C" int agdiff_schnet_node_stage(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
@@ -426,6 +552,52 @@ extern "C" int agdiff_langevin_update(const agdiff_topo_t* topo, const agdiff_ws
   if (bd > 256) bd = 256;
   if (bd < 64) bd = 64;
   k_langevin_update<<<dim3((unsigned)topo->num_graphs), dim3(bd), 0, (hipStream_t)stream>>>(a);
+  AG_CHECK_LAUNCH();
+  return AGDIFF_OK;
+}
+
+extern "C" int agdiff_perturb_positions(const agdiff_topo_t* topo, const float* pos, const float* noise,
+                                        const float* alpha_graph, float* pos_out, void* stream) {
+  if (!topo || !pos || !noise || !alpha_graph || !pos_out) return AGDIFF_ERR_ARG;
+  if (topo->num_graphs <= 0) return AGDIFF_OK;
+  PerturbArgs a{topo->graph_ptr, pos, noise, alpha_graph, pos_out};
+  k_perturb_positions<<<dim3((unsigned)topo->num_graphs), dim3(256), 0, (hipStream_t)stream>>>(a);
+  AG_CHECK_LAUNCH();
+  return AGDIFF_OK;
+}
+
+extern "C" int agdiff_diffusion_loss(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
+                                     const float* pos_gt, const float* pos_perturbed, const float* alpha_graph,
+                                     float* loss, void* stream) {
+  if (!p || !topo || !ws || !pos_gt || !pos_perturbed || !alpha_graph || !loss) return AGDIFF_ERR_ARG;
+  if (topo->num_graphs <= 0) return AGDIFF_OK;
+  LossArgs a;
+  a.graph_ptr = topo->graph_ptr;
+  a.pos_gt = pos_gt;
+  a.pos = pos_perturbed;
+  a.alpha_graph = alpha_graph;
+  a.loss = loss;
+  a.n_total = topo->num_nodes;
+  a.cutoff = p->cutoff;
+  a.loc_src = topo->loc_src;
+  a.loc_dst = topo->loc_dst;
+  a.loc_out_ptr = topo->loc_out_ptr;
+  a.loc_in_ptr = topo->loc_in_ptr;
+  a.loc_in_eid = topo->loc_in_eid;
+  a.l_len = ws->l_len;
+  a.l_inv = ws->l_inv;
+  a.in_ptr = ws->in_ptr;
+  a.out_ptr = ws->out_ptr;
+  a.ref2dst = ws->ref2dst;
+  a.e_src = ws->e_src;
+  a.e_dst = ws->e_dst;
+  a.e_type = ws->e_type;
+  a.e_len = ws->e_len;
+  a.e_inv = ws->e_inv_global;
+  int bd = (int)(((topo->max_atoms_per_graph + 63) / 64) * 64);
+  if (bd > 256) bd = 256;
+  if (bd < 64) bd = 64;
+  k_diffusion_loss<<<dim3((unsigned)topo->num_graphs), dim3(bd), 0, (hipStream_t)stream>>>(a);
   AG_CHECK_LAUNCH();
   return AGDIFF_OK;
 }

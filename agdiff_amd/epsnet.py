@@ -286,6 +286,57 @@ class DualEncoderEpsNetwork(nn.Module):
             e_len = ws.e_len[:E][perm].unsqueeze(-1)
             return inv_g, inv_l, e_index, e_type, e_len, e_type > 0
 
+    # ------------------------------------------------------------------ loss value (dualenc.py:253-395)
+    def get_loss(self, atom_type, pos, bond_index, bond_type, batch, num_nodes_per_graph, num_graphs,
+                 anneal_power=2.0, return_unreduced_loss=False, return_unreduced_edge_loss=False,
+                 extend_order=True, extend_radius=True, **kwargs):
+        if self.model_type == "diffusion":
+            return self.get_loss_diffusion(atom_type, pos, bond_index, bond_type, batch, num_nodes_per_graph,
+                                           num_graphs, anneal_power, return_unreduced_loss,
+                                           return_unreduced_edge_loss, extend_order, extend_radius, **kwargs)
+
+    def get_loss_diffusion(self, atom_type, pos, bond_index, bond_type, batch, num_nodes_per_graph, num_graphs,
+                           anneal_power=2.0, return_unreduced_loss=False, return_unreduced_edge_loss=False,
+                           extend_order=True, extend_radius=True, *, time_step=None, pos_noise=None):
+        """Forward VALUE of the training loss (what scripts/train.py:160-170 `validate` computes under no_grad):
+        per-atom `loss [N,1]`, or `(loss, loss_global, loss_local)` with return_unreduced_loss.  No autograd graph
+        is built -- backward kernels are out of scope.  Keyword-only `time_step [G]` / `pos_noise
+        [N,3]` replace the torch.randint / normal_ draws of dualenc.py:299-311 (parity tests)."""
+        lib = self._require_gpu()
+        if not extend_radius:
+            raise NotImplementedError("extend_radius=False is not supported by the HIP path")
+        dev = self._device()
+        with torch.no_grad():
+            if time_step is None:
+                ts = torch.randint(0, self.num_timesteps, size=(num_graphs // 2 + 1,), device=dev)
+                time_step = torch.cat([ts, self.num_timesteps - ts - 1], dim=0)[:num_graphs]
+            time_step = time_step.to(dev).long()
+            a = self.alphas.index_select(0, time_step).to(torch.float32).contiguous()          # (G,)
+            posc = pos.detach().to(dev, torch.float32).contiguous()
+            if pos_noise is None:
+                pos_noise = torch.zeros(size=posc.size(), device=dev)
+                pos_noise.normal_()
+            noise = pos_noise.detach().to(dev, torch.float32).contiguous()
+            pk = self._renorm_embedding(atom_type)
+            topo, ws = self._batch(atom_type, bond_index, bond_type, batch, num_graphs, extend_order)
+            if a.numel() != topo.G:
+                raise ValueError("time_step must have one entry per graph")
+            pert = torch.empty_like(posc)
+            loss = torch.empty(3, topo.N, device=dev, dtype=torch.float32)
+            st = _lib.stream_ptr()
+            _lib.check(lib.agdiff_perturb_positions(ctypes.byref(topo.struct), _lib.ptr(posc), _lib.ptr(noise),
+                                                    _lib.ptr(a), _lib.ptr(pert), st), "agdiff_perturb_positions")
+            _lib.check(lib.agdiff_score_forward(ctypes.byref(pk.struct), ctypes.byref(topo.struct),
+                                                ctypes.byref(ws.struct), _lib.ptr(pert), 1, st), "agdiff_score_forward")
+            _lib.check(lib.agdiff_diffusion_loss(ctypes.byref(pk.struct), ctypes.byref(topo.struct),
+                                                 ctypes.byref(ws.struct), _lib.ptr(posc), _lib.ptr(pert), _lib.ptr(a),
+                                                 _lib.ptr(loss), st), "agdiff_diffusion_loss")
+            if return_unreduced_edge_loss:
+                return None                      # the reference's branch is `pass` and falls off the end (dualenc.py:390-391)
+            if return_unreduced_loss:
+                return loss[0].unsqueeze(-1), loss[1].unsqueeze(-1), loss[2].unsqueeze(-1)
+            return loss[0].unsqueeze(-1)
+
     # ------------------------------------------------------------------ samplers (dualenc.py:397-547)
     def langevin_dynamics_sample(self, atom_type, pos_init, bond_index, bond_type, batch, num_graphs, extend_order,
                                  extend_radius=True, n_steps=5000, step_lr=0.0000010, clip=1000, clip_local=None,

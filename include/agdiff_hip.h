@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 10
+#define AGDIFF_ABI_VERSION 11
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -260,6 +260,18 @@ int agdiff_score_forward(const agdiff_params_t* p, const agdiff_topo_t* topo, co
 /* eq_transform x2, clip_norm, Langevin update, NaN check, center_pos, clamp
  * (geometry.py:9-17; dualenc.py:506-545, 581-589) from ws->l_inv / ws->e_inv_global. */
 int agdiff_langevin_update(const agdiff_topo_t* topo, const agdiff_ws_t* ws, const agdiff_step_args_t* a, void* stream);
+
+/* pos_perturbed = pos + pos_noise * sqrt(1 - a) / sqrt(a) with a = alpha_graph[graph of the atom]
+ * (get_loss_diffusion, dualenc.py:306-312; alpha_graph[G] = alphas.index_select(0, time_step)). */
+int agdiff_perturb_positions(const agdiff_topo_t* topo, const float* pos, const float* noise,
+                             const float* alpha_graph, float* pos_out, void* stream);
+
+/* Forward value of get_loss_diffusion (dualenc.py:329-395; evaluated under no_grad by scripts/train.py:160-170)
+ * after agdiff_score_forward(pos_perturbed, need_global = 1): d_gt / d_target per edge, global_mask, the four
+ * eq_transforms and the per-atom squared errors.  loss: [3][N] = total, 2*global, 5*local. */
+int agdiff_diffusion_loss(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
+                          const float* pos_gt, const float* pos_perturbed, const float* alpha_graph,
+                          float* loss, void* stream);
 
 /* One denoising step = agdiff_score_forward + agdiff_langevin_update (dualenc.py:478-545). */
 int agdiff_langevin_step(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,

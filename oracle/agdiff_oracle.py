@@ -328,6 +328,34 @@ def forward(sd, cfg, atom_type, pos, bond_index, bond_type, batch, extend_order=
     return inv_g, inv_l, edge_index, edge_type, edge_length, local_mask
 
 
+def get_loss_diffusion(sd, cfg, atom_type, pos, bond_index, bond_type, batch, num_graphs, time_step, pos_noise,
+                       extend_order=True, extend_radius=True):
+    """epsnet/dualenc.py:284-395, forward value only, with the two random draws (time_step: :299-304,
+    pos_noise: :310-311) passed in.  Returns (loss, loss_global, loss_local), each [N,1]."""
+    _, alphas, _ = schedule_tensors(cfg)
+    a = alphas.index_select(0, time_step)
+    a_pos = a.index_select(0, batch).unsqueeze(-1)
+    pos_perturbed = pos + pos_noise * (1.0 - a_pos).sqrt() / a_pos.sqrt()
+    inv_g, inv_l, edge_index, edge_type, edge_length, lmask = forward(
+        sd, cfg, atom_type, pos_perturbed, bond_index, bond_type, batch, extend_order=extend_order,
+        extend_radius=extend_radius)
+    a_edge = a.index_select(0, batch.index_select(0, edge_index[0])).unsqueeze(-1)
+    d_gt = get_distance(pos, edge_index).unsqueeze(-1)
+    d_perturbed = edge_length                                  # is_train_edge == all True (dualenc.py:570-572)
+    d_target = (d_gt - d_perturbed) / (1.0 - a_edge).sqrt() * a_edge.sqrt()
+    lm = lmask.unsqueeze(-1)
+    global_mask = torch.logical_and(torch.logical_or(d_perturbed <= cfg.cutoff, lm), ~lm)
+    target_d_global = torch.where(global_mask, d_target, torch.zeros_like(d_target))
+    inv_g = torch.where(global_mask, inv_g, torch.zeros_like(inv_g))
+    target_pos_global = eq_transform(target_d_global, pos_perturbed, edge_index, edge_length)
+    node_eq_global = eq_transform(inv_g, pos_perturbed, edge_index, edge_length)
+    loss_global = 2 * torch.sum((node_eq_global - target_pos_global) ** 2, dim=-1, keepdim=True)
+    target_pos_local = eq_transform(d_target[lmask], pos_perturbed, edge_index[:, lmask], edge_length[lmask])
+    node_eq_local = eq_transform(inv_l, pos_perturbed, edge_index[:, lmask], edge_length[lmask])
+    loss_local = 5 * torch.sum((node_eq_local - target_pos_local) ** 2, dim=-1, keepdim=True)
+    return loss_global + loss_local, loss_global, loss_local
+
+
 def langevin_dynamics_sample_diffusion(sd, cfg, atom_type, pos_init, bond_index, bond_type, batch,
                                        num_graphs, extend_order, extend_radius=True, n_steps=5000,
                                        step_lr=0.0000010, clip=1000, clip_local=None, clip_pos=None,

@@ -196,6 +196,28 @@ def g_alanine():
          pos_init=pos_init, noise=noise, pos_final=pos, traj=torch.stack(traj)[::10], n_steps=n_steps)
 
 
+def g_loss(name, cfg, kind, seed, nmol, copies, pos_scale):
+    """§8f-3: get_loss (dualenc.py:253-395) forward value; the two random draws are replaced by stored tensors."""
+    m = build_ref(cfg, head_scale=1.0)
+    b, pos = small_batch(kind, seed, nmol, copies, pos_scale)
+    at, bi, bt, ba = T(b["atom_type"]), T(b["bond_index"]), T(b["bond_type"]), T(b["batch"])
+    G = b["num_graphs"]
+    g = torch.Generator().manual_seed(seed + 3)
+    ts_half = torch.randint(0, m.num_timesteps, (G // 2 + 1,), generator=g)
+    noise = torch.randn(at.shape[0], 3, generator=g)
+    orig_randint, orig_normal = torch.randint, torch.Tensor.normal_
+    torch.randint = lambda *a, **k: ts_half.clone()
+    torch.Tensor.normal_ = lambda self, *a, **k: self.copy_(noise)
+    try:
+        with torch.no_grad():
+            loss, lg, ll = m.get_loss(at, pos, bi, bt, ba, None, G, return_unreduced_loss=True, extend_order=False)
+    finally:
+        torch.randint, torch.Tensor.normal_ = orig_randint, orig_normal
+    time_step = torch.cat([ts_half, m.num_timesteps - ts_half - 1], dim=0)[:G]
+    save(name, atom_type=at, pos=pos, bond_index=bi, bond_type=bt, batch=ba, num_graphs=G, time_step=time_step,
+         pos_noise=noise, loss=loss, loss_global=lg, loss_local=ll, cfg_smooth=int(cfg.smooth_conv))
+
+
 def g_nan():
     """G6: NaN in positions -> FloatingPointError (dualenc.py:539-541)."""
     cfg = qm9_model_config(num_diffusion_timesteps=20)
@@ -255,10 +277,15 @@ def g_gaussian():
               "qm9", 24, 2, 2, n_steps=10, step_lr=1e-6, w_global=1.0, global_start_sigma=0.5, clip=1000.0)
 
 
+def g_losses():
+    g_loss("g10_loss_qm9", qm9_model_config(), "qm9", 31, 3, 2, 1.6)
+    g_loss("g10_loss_drugs", drugs_model_config(), "drugs", 32, 2, 2, 2.5)
+
+
 if __name__ == "__main__":
-    if sys.argv[1:] and all(a in ("gaussian", "alanine") for a in sys.argv[1:]):   # add without touching the others
+    if sys.argv[1:] and all(a in ("gaussian", "alanine", "loss") for a in sys.argv[1:]):   # add without touching the others
         for a in sys.argv[1:]:
-            {"gaussian": g_gaussian, "alanine": g_alanine}[a]()
+            {"gaussian": g_gaussian, "alanine": g_alanine, "loss": g_losses}[a]()
         sys.exit(0)
     g_schedule_and_keys()
     # G2+G3 uncapped QM9-shaped batch with per-stage outputs (small: 3 molecules x 1 copy)
@@ -279,3 +306,4 @@ if __name__ == "__main__":
     g_extend_order()
     g_gaussian()
     g_alanine()
+    g_losses()

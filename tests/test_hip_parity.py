@@ -178,6 +178,31 @@ def test_alanine_dipeptide_config0(precision):
     assert rel_err(pos.cpu().numpy(), g["pos_final"]) < TOL
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("case", ["g10_loss_qm9", "g10_loss_drugs"])
+def test_loss_matches_reference_golden(case, precision):
+    """get_loss (dualenc.py:253-395) forward value, as scripts/train.py:160-170 `validate` calls it."""
+    from agdiff_amd import drugs_model_config, qm9_model_config
+    g = load_golden(case)
+    cfg = (drugs_model_config if int(g["cfg_smooth"]) else qm9_model_config)()
+    m, _ = _gpu_model(cfg, head_scale=1.0, precision=precision)
+    args = (t(g["atom_type"]).cuda(), t(g["pos"]).cuda(), t(g["bond_index"]).cuda(), t(g["bond_type"]).cuda(),
+            t(g["batch"]).cuda(), None, int(g["num_graphs"]))
+    kw = dict(extend_order=False, time_step=t(g["time_step"]).cuda(), pos_noise=t(g["pos_noise"]).cuda())
+    loss, lg, ll = m.get_loss(*args, return_unreduced_loss=True, **kw)
+    assert loss.shape == lg.shape == ll.shape == (g["atom_type"].shape[0], 1) and loss.is_cuda
+    assert rel_err(lg.cpu().numpy(), g["loss_global"]) < TOL
+    assert rel_err(ll.cpu().numpy(), g["loss_local"]) < TOL
+    assert rel_err(loss.cpu().numpy(), g["loss"]) < TOL
+    only = m.get_loss(*args, **kw)
+    assert torch.equal(only, loss)
+    assert m.get_loss(*args, return_unreduced_edge_loss=True, **kw) is None       # dualenc.py:390-391 falls through
+    # own random draws: finite, right shape, different each call
+    r1 = m.get_loss(*args, extend_order=False)
+    r2 = m.get_loss(*args, extend_order=False)
+    assert r1.shape == loss.shape and torch.isfinite(r1).all() and not torch.equal(r1, r2)
+
+
 def test_nan_raises_floating_point_error():
     from agdiff_amd import qm9_model_config, synth
     cfg = qm9_model_config(num_diffusion_timesteps=20)

@@ -121,6 +121,21 @@ def test_alanine_dipeptide_config0():
     assert rel_err(pos.numpy(), g["pos_final"]) < 2e-5
 
 
+@pytest.mark.parametrize("case", ["g10_loss_qm9", "g10_loss_drugs"])
+def test_loss_g10(case):
+    """get_loss forward value (dualenc.py:253-395) with the reference's random draws replayed."""
+    from agdiff_amd.config import drugs_model_config, qm9_model_config
+    g = load_golden(case)
+    cfg = (drugs_model_config if int(g["cfg_smooth"]) else qm9_model_config)()
+    sd = O.synth_state_dict_for(cfg, head_scale=1.0)
+    loss, lg, ll = O.get_loss_diffusion(sd, cfg, t(g["atom_type"]), t(g["pos"]), t(g["bond_index"]), t(g["bond_type"]),
+                                        t(g["batch"]), int(g["num_graphs"]), t(g["time_step"]), t(g["pos_noise"]),
+                                        extend_order=False)
+    assert rel_err(lg.numpy(), g["loss_global"]) < 2e-5
+    assert rel_err(ll.numpy(), g["loss_local"]) < 2e-5
+    assert rel_err(loss.numpy(), g["loss"]) < 2e-5
+
+
 def test_nan_raises_g6():
     from agdiff_amd.config import qm9_model_config
     from agdiff_amd import synth
