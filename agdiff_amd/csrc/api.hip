@@ -55,10 +55,11 @@ ForkJoin& fork_join_for_current_device() {
   return f;
 }
 
-int local_branch(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, void* stream) {
+int local_branch(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, int flags,
+                 void* stream) {
   const int64_t ltiles = (topo->num_local + AG_TW - 1) / AG_TW;
   // lengths -> edge encoder -> GIN -> local head   (dualenc.py:214-239)
-  AG_TRY(agdiff_local_lengths(topo, ws, pos, stream));
+  if (!(flags & AGDIFF_FWD_GRAPH_GIVEN)) AG_TRY(agdiff_local_lengths(topo, ws, pos, stream));
   if (topo->num_local > 0) {
     AG_TRY(agdiff_edge_encoder(p, ws->num_local, ltiles, ws->l_len, topo->loc_type, ws->l_attr, ws->l_attr_rows, stream));
   }
@@ -70,10 +71,12 @@ int local_branch(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdi
   return AGDIFF_OK;
 }
 
-int global_branch(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, void* stream) {
+int global_branch(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, int flags,
+                  void* stream) {
   // radius graph -> scales -> edge encoder -> SchNet -> global head   (dualenc.py:167-211)
   const int64_t etiles = (topo->max_edges + AG_TW - 1) / AG_TW;
-  AG_TRY(agdiff_graph_build(topo, ws, pos, p->cutoff, stream));
+  if (!(flags & AGDIFF_FWD_GRAPH_GIVEN))     // cutoff 0 admits no radius edge: the bond graph alone (extend_radius=False)
+    AG_TRY(agdiff_graph_build(topo, ws, pos, (flags & AGDIFF_FWD_NO_RADIUS) ? 0.0f : p->cutoff, stream));
   AG_TRY(agdiff_edge_scales(p, topo, ws, stream));
   AG_TRY(agdiff_edge_encoder(p, ws->num_edges, etiles, ws->e_len, ws->e_type, ws->e_attr, nullptr, stream));
   for (int k = 0; k <= p->num_convs; ++k) {
@@ -87,21 +90,21 @@ int global_branch(const agdiff_params_t* p, const agdiff_topo_t* topo, const agd
 }  // namespace
 
 extern "C" int agdiff_score_forward(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
-                                    const float* pos, int32_t with_global, void* stream) {
+                                    const float* pos, int32_t flags, void* stream) {
   if (!p || !topo || !ws || !pos) return AGDIFF_ERR_ARG;
-  if (!with_global) return local_branch(p, topo, ws, pos, stream);
+  if (!(flags & AGDIFF_FWD_GLOBAL)) return local_branch(p, topo, ws, pos, flags, stream);
   static const bool serial = getenv("AGDIFF_SERIAL_BRANCHES") != nullptr;
   ForkJoin& fj = fork_join_for_current_device();
   if (serial || !fj.ok) {
-    AG_TRY(local_branch(p, topo, ws, pos, stream));
-    return global_branch(p, topo, ws, pos, stream);
+    AG_TRY(local_branch(p, topo, ws, pos, flags, stream));
+    return global_branch(p, topo, ws, pos, flags, stream);
   }
   hipStream_t main = (hipStream_t)stream;
   if (hipEventRecord(fj.fork, main) != hipSuccess || hipStreamWaitEvent(fj.side, fj.fork, 0) != hipSuccess)
     return AGDIFF_ERR_LAUNCH;
-  AG_TRY(local_branch(p, topo, ws, pos, (void*)fj.side));
+  AG_TRY(local_branch(p, topo, ws, pos, flags, (void*)fj.side));
   if (hipEventRecord(fj.join, fj.side) != hipSuccess) return AGDIFF_ERR_LAUNCH;
-  AG_TRY(global_branch(p, topo, ws, pos, stream));
+  AG_TRY(global_branch(p, topo, ws, pos, flags, stream));
   if (hipStreamWaitEvent(main, fj.join, 0) != hipSuccess) return AGDIFF_ERR_LAUNCH;
   return AGDIFF_OK;
 }
@@ -109,6 +112,6 @@ extern "C" int agdiff_score_forward(const agdiff_params_t* p, const agdiff_topo_
 extern "C" int agdiff_langevin_step(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
                                     const agdiff_step_args_t* a, void* stream) {
   if (!a) return AGDIFF_ERR_ARG;
-  AG_TRY(agdiff_score_forward(p, topo, ws, a->pos_in, a->use_global, stream));
+  AG_TRY(agdiff_score_forward(p, topo, ws, a->pos_in, a->use_global ? AGDIFF_FWD_GLOBAL : 0, stream));
   return agdiff_langevin_update(topo, ws, a, stream);
 }

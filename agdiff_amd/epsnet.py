@@ -265,15 +265,14 @@ class DualEncoderEpsNetwork(nn.Module):
                 edge_length=None, return_edges=False, extend_order=True, extend_radius=True):
         lib = self._require_gpu()
         if edge_index is not None and edge_type is not None and edge_length is not None:
-            raise NotImplementedError("caller-supplied edge_index/edge_type/edge_length are not supported by the HIP path")
-        if not extend_radius:
-            raise NotImplementedError("extend_radius=False is not supported by the HIP path")
+            return self._forward_given_graph(lib, atom_type, pos, batch, edge_index, edge_type, edge_length, return_edges)
         with torch.no_grad():
             pk = self._renorm_embedding(atom_type)
             topo, ws = self._batch(atom_type, bond_index, bond_type, batch, None, extend_order)
             posc = pos.detach().to(torch.float32).contiguous()
             _lib.check(lib.agdiff_score_forward(ctypes.byref(pk.struct), ctypes.byref(topo.struct),
-                                                ctypes.byref(ws.struct), _lib.ptr(posc), 1, _lib.stream_ptr()),
+                                                ctypes.byref(ws.struct), _lib.ptr(posc),
+                                                self._fwd_flags(topo, extend_radius), _lib.stream_ptr()),
                        "agdiff_score_forward")
             E = int(ws.num_edges.item())
             perm = ws.ref2dst[:E].long()                     # reference (row, col)-sorted order
@@ -285,6 +284,66 @@ class DualEncoderEpsNetwork(nn.Module):
             e_type = ws.e_type[:E][perm].long()
             e_len = ws.e_len[:E][perm].unsqueeze(-1)
             return inv_g, inv_l, e_index, e_type, e_len, e_type > 0
+
+    @staticmethod
+    def _fwd_flags(topo, extend_radius, with_global=True):
+        flags = _lib.DEFINES["AGDIFF_FWD_GLOBAL"] if with_global else 0
+        if not extend_radius:
+            # dualenc.py:166-176 with extend_radius=False leaves the bond list as it was passed; the device graph
+            # is always in coalesced (row, col) order, so the two agree only for an already-coalesced list
+            if not topo.bond_list_coalesced:
+                raise NotImplementedError("extend_radius=False needs a (row, col)-sorted duplicate-free bond list")
+            flags |= _lib.DEFINES["AGDIFF_FWD_NO_RADIUS"]
+        return flags
+
+    def _forward_given_graph(self, lib, atom_type, pos, batch, edge_index, edge_type, edge_length, return_edges):
+        """forward(..., edge_index, edge_type, edge_length) (dualenc.py:165 skips the graph construction): the
+        caller's edges, in the caller's order.  The host sorts them by destination once and uploads them."""
+        import numpy as np
+        dev = self._device()
+        ei = edge_index.detach().cpu().numpy().astype(np.int64).reshape(2, -1)
+        et = edge_type.detach().cpu().numpy().astype(np.int64).reshape(-1)
+        el = edge_length.detach().to(torch.float32).cpu().numpy().reshape(-1)
+        E = et.shape[0]
+        if ei.shape[1] != E or el.shape[0] != E:
+            raise ValueError("edge_index, edge_type and edge_length disagree on the number of edges")
+        if E and (et.min() < 0 or et.max() >= 100):
+            raise ValueError("edge_type out of the embedding range [0, 100)")
+        loc = np.nonzero(et > 0)[0]                                    # is_local_edge, dualenc.py:566-567
+        with torch.no_grad():
+            pk = self._renorm_embedding(atom_type)
+            topo = BatchTopology(atom_type, ei[:, loc], et[loc], batch, num_graphs=None, extend_order=False,
+                                 device=dev)
+            if topo.L != loc.shape[0]:
+                raise NotImplementedError("duplicate local edges in a caller-supplied edge list")
+            ws = Workspace(topo, max_edges=E)
+            self._batch_cache = (None, topo, ws)
+            order = np.lexsort((ei[0], ei[1]))                          # by destination, sources ascending
+            where = np.empty(E, dtype=np.int64)
+            where[order] = np.arange(E)
+            by_src = np.lexsort((ei[1], ei[0]))
+            N = topo.N
+            up_i = lambda a: torch.from_numpy(np.ascontiguousarray(a).astype(np.int32)).to(dev)
+            ws.e_src[:E].copy_(up_i(ei[0][order])); ws.e_dst[:E].copy_(up_i(ei[1][order]))
+            ws.e_type[:E].copy_(up_i(et[order]))
+            ws.e_len[:E].copy_(torch.from_numpy(np.ascontiguousarray(el[order])).to(dev))
+            ws.in_ptr.copy_(up_i(np.concatenate([[0], np.cumsum(np.bincount(ei[1], minlength=N))])))
+            ws.out_ptr.copy_(up_i(np.concatenate([[0], np.cumsum(np.bincount(ei[0], minlength=N))])))
+            ws.ref2dst[:E].copy_(up_i(where[by_src]))
+            ws.num_edges.fill_(E)
+            l_len = np.empty(topo.L, dtype=np.float32)
+            l_len[topo.loc_pos_of_input] = el[loc]
+            ws.l_len[:topo.L].copy_(torch.from_numpy(l_len).to(dev))
+            posc = pos.detach().to(dev, torch.float32).contiguous()
+            flags = _lib.DEFINES["AGDIFF_FWD_GLOBAL"] | _lib.DEFINES["AGDIFF_FWD_GRAPH_GIVEN"]
+            _lib.check(lib.agdiff_score_forward(ctypes.byref(pk.struct), ctypes.byref(topo.struct),
+                                                ctypes.byref(ws.struct), _lib.ptr(posc), flags, _lib.stream_ptr()),
+                       "agdiff_score_forward")
+            inv_g = ws.e_inv_global[:E][torch.from_numpy(where).to(dev)].unsqueeze(-1)
+            inv_l = ws.l_inv[:topo.L][torch.from_numpy(topo.loc_pos_of_input).to(dev)].unsqueeze(-1)
+            if not return_edges:
+                return inv_g, inv_l
+            return inv_g, inv_l, edge_index, edge_type, edge_length, edge_type > 0       # dualenc.py:241-249
 
     # ------------------------------------------------------------------ loss value (dualenc.py:253-395)
     def get_loss(self, atom_type, pos, bond_index, bond_type, batch, num_nodes_per_graph, num_graphs,
@@ -303,8 +362,6 @@ class DualEncoderEpsNetwork(nn.Module):
         is built -- backward kernels are out of scope.  Keyword-only `time_step [G]` / `pos_noise
         [N,3]` replace the torch.randint / normal_ draws of dualenc.py:299-311 (parity tests)."""
         lib = self._require_gpu()
-        if not extend_radius:
-            raise NotImplementedError("extend_radius=False is not supported by the HIP path")
         dev = self._device()
         with torch.no_grad():
             if time_step is None:
@@ -327,7 +384,8 @@ class DualEncoderEpsNetwork(nn.Module):
             _lib.check(lib.agdiff_perturb_positions(ctypes.byref(topo.struct), _lib.ptr(posc), _lib.ptr(noise),
                                                     _lib.ptr(a), _lib.ptr(pert), st), "agdiff_perturb_positions")
             _lib.check(lib.agdiff_score_forward(ctypes.byref(pk.struct), ctypes.byref(topo.struct),
-                                                ctypes.byref(ws.struct), _lib.ptr(pert), 1, st), "agdiff_score_forward")
+                                                ctypes.byref(ws.struct), _lib.ptr(pert),
+                                                self._fwd_flags(topo, extend_radius), st), "agdiff_score_forward")
             _lib.check(lib.agdiff_diffusion_loss(ctypes.byref(pk.struct), ctypes.byref(topo.struct),
                                                  ctypes.byref(ws.struct), _lib.ptr(posc), _lib.ptr(pert), _lib.ptr(a),
                                                  _lib.ptr(loss), st), "agdiff_diffusion_loss")
@@ -373,10 +431,9 @@ class DualEncoderEpsNetwork(nn.Module):
                        clip_pos=None, global_start_sigma=float("inf"), w_global=0.2, **kwargs):
         """Set up one sampling job (dualenc.py:468-476) and return a LangevinRun that enqueues steps."""
         self._require_gpu()
-        if not extend_radius:
-            raise NotImplementedError("extend_radius=False is not supported by the HIP path")
         return LangevinRun(self, atom_type, pos_init, bond_index, bond_type, batch, num_graphs, extend_order,
-                           n_steps, step_lr, clip, clip_local, clip_pos, global_start_sigma, w_global, **kwargs)
+                           n_steps, step_lr, clip, clip_local, clip_pos, global_start_sigma, w_global,
+                           extend_radius=extend_radius, **kwargs)
 
 
 class LangevinRun:
@@ -386,7 +443,7 @@ class LangevinRun:
     def __init__(self, model, atom_type, pos_init, bond_index, bond_type, batch, num_graphs, extend_order,
                  n_steps, step_lr, clip, clip_local, clip_pos, global_start_sigma, w_global, noise=None,
                  save_traj=True, skip_discarded_global=True, nan_check_every=64, step_indices=None, on_step=None,
-                 **_ignored):
+                 extend_radius=True, **_ignored):
         self.model, self.lib = model, _lib.load()
         dev = model._device()
         self.sigmas = ((1.0 - model.alphas).sqrt() / model.alphas.sqrt()).detach().cpu()
@@ -394,6 +451,7 @@ class LangevinRun:
         with torch.no_grad():
             self.pk = model._renorm_embedding(atom_type)
             self.topo, self.ws = model._batch(atom_type, bond_index, bond_type, batch, num_graphs, extend_order)
+            self.radius_flags = model._fwd_flags(self.topo, extend_radius, with_global=False)
             T = model.num_timesteps
             self.steps = list(step_indices) if step_indices is not None else list(reversed(range(T - n_steps, T)))
             self.pos = (pos_init.detach().to(dev, torch.float32) * self.sigmas[-1].to(dev)).contiguous()
@@ -450,7 +508,8 @@ class LangevinRun:
                 run_global = 1 if (use_global or not self.skip_discarded) else 0
                 self.global_steps += run_global
                 _lib.check(lib.agdiff_score_forward(ctypes.byref(pk.struct), ctypes.byref(topo.struct),
-                                                    ctypes.byref(ws.struct), self.pos_p, run_global, stream),
+                                                    ctypes.byref(ws.struct), self.pos_p,
+                                                    run_global | self.radius_flags, stream),
                            "agdiff_score_forward")
                 _lib.check(lib.agdiff_langevin_update(ctypes.byref(topo.struct), ctypes.byref(ws.struct),
                                                       ctypes.byref(a), stream), "agdiff_langevin_update")

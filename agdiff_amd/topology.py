@@ -60,7 +60,9 @@ class BatchTopology:
 
         # coalesce: sort by (row, col), sum duplicate values (common.py:215,226)
         key = bi[0] * N + bi[1]
+        self.bond_list_coalesced = bool(np.all(np.diff(key) > 0))     # already (row, col)-sorted and unique
         uniq, inv = np.unique(key, return_inverse=True)
+        self.loc_pos_of_input = inv.reshape(-1)                        # input bond edge -> index in the coalesced list
         typ = np.zeros(uniq.shape[0], dtype=np.int64)
         np.add.at(typ, inv, bt)
         src, dst = uniq // N, uniq % N
@@ -109,9 +111,12 @@ class BatchTopology:
 class Workspace:
     """Device buffers for one BatchTopology (include/agdiff_hip.h: agdiff_ws_t)."""
 
-    def __init__(self, topo):
+    def __init__(self, topo, max_edges=None):
         import torch
         dev = topo.device
+        if max_edges is not None:          # caller-supplied graph (forward(edge_index=...)): capacity = its size
+            topo.max_edges = int(max_edges)
+            topo.struct.max_edges = int(max_edges)
         N, G, L, E = topo.N, topo.G, topo.L, topo.max_edges
         TW = _lib.TILE
         etiles = (E + TW - 1) // TW

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 11
+#define AGDIFF_ABI_VERSION 12
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -251,11 +251,18 @@ int agdiff_gin_encoder(const agdiff_params_t* p, const agdiff_topo_t* topo, cons
 int agdiff_cfconv_aggregate(const float* x, const float* W, const int32_t* in_ptr, const int32_t* src,
                             int64_t num_nodes, int32_t F, float* out, void* stream);
 
-/* The whole score network, dualenc.py:142-251 with the graph rebuilt from `pos`
- * (extend_order=False, extend_radius=True).  with_global = 0 skips everything whose result the
- * sampler discards when sigma >= global_start_sigma (dualenc.py:523-524). */
+/* The whole score network, dualenc.py:142-251.  flags:
+ *   AGDIFF_FWD_GLOBAL       run the global branch; without it everything whose result the sampler discards
+ *                           when sigma >= global_start_sigma (dualenc.py:523-524) is skipped
+ *   AGDIFF_FWD_NO_RADIUS    extend_radius=False (dualenc.py:166-176): the graph is the bond graph only
+ *   AGDIFF_FWD_GRAPH_GIVEN  caller-supplied edge_index / edge_type / edge_length (dualenc.py:165): ws already
+ *                           holds the destination-sorted graph (num_edges, in_ptr, e_src/e_dst/e_type/e_len)
+ *                           and l_len; neither is rebuilt from `pos` */
+#define AGDIFF_FWD_GLOBAL 1
+#define AGDIFF_FWD_NO_RADIUS 2
+#define AGDIFF_FWD_GRAPH_GIVEN 4
 int agdiff_score_forward(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
-                         const float* pos, int32_t with_global, void* stream);
+                         const float* pos, int32_t flags, void* stream);
 
 /* eq_transform x2, clip_norm, Langevin update, NaN check, center_pos, clamp
  * (geometry.py:9-17; dualenc.py:506-545, 581-589) from ws->l_inv / ws->e_inv_global. */
@@ -267,7 +274,7 @@ int agdiff_perturb_positions(const agdiff_topo_t* topo, const float* pos, const 
                              const float* alpha_graph, float* pos_out, void* stream);
 
 /* Forward value of get_loss_diffusion (dualenc.py:329-395; evaluated under no_grad by scripts/train.py:160-170)
- * after agdiff_score_forward(pos_perturbed, need_global = 1): d_gt / d_target per edge, global_mask, the four
+ * after agdiff_score_forward(pos_perturbed, AGDIFF_FWD_GLOBAL): d_gt / d_target per edge, global_mask, the four
  * eq_transforms and the per-atom squared errors.  loss: [3][N] = total, 2*global, 5*local. */
 int agdiff_diffusion_loss(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
                           const float* pos_gt, const float* pos_perturbed, const float* alpha_graph,

@@ -297,14 +297,15 @@ def head_mlp(sd, p, x, act):
 
 
 def forward(sd, cfg, atom_type, pos, bond_index, bond_type, batch, extend_order=True,
-            extend_radius=True, stages=None):
+            extend_radius=True, stages=None, edge_index=None, edge_type=None, edge_length=None):
     """epsnet/dualenc.py:142-251 (return_edges=True form).  `sd` embedding rows are renormalised
     in place exactly like the reference module's weights are."""
     n = atom_type.size(0)
-    edge_index, edge_type = extend_graph_order_radius(
-        n, pos, bond_index, bond_type, batch, order=cfg.edge_order, cutoff=cfg.cutoff,
-        extend_order=extend_order, extend_radius=extend_radius)
-    edge_length = get_distance(pos, edge_index).unsqueeze(-1)
+    if edge_index is None or edge_type is None or edge_length is None:          # dualenc.py:165-178
+        edge_index, edge_type = extend_graph_order_radius(
+            n, pos, bond_index, bond_type, batch, order=cfg.edge_order, cutoff=cfg.cutoff,
+            extend_order=extend_order, extend_radius=extend_radius)
+        edge_length = get_distance(pos, edge_index).unsqueeze(-1)
     local_mask = edge_type > 0                                         # dualenc.py:566-567
     act = getattr(F, cfg.mlp_act)
     if cfg.edge_encoder == "mlp":

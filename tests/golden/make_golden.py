@@ -277,15 +277,39 @@ def g_gaussian():
               "qm9", 24, 2, 2, n_steps=10, step_lr=1e-6, w_global=1.0, global_start_sigma=0.5, clip=1000.0)
 
 
+def g_forward_variants():
+    """forward() argument variants of dualenc.py:142-178: extend_radius=False (bond graph only) and
+    caller-supplied edge_index / edge_type / edge_length (shuffled order, lengths that are NOT |pos_i - pos_j|)."""
+    cfg = qm9_model_config()
+    m = build_ref(cfg)
+    b, pos = small_batch("qm9", 41, 3, 2, 1.6)
+    at, bi, bt, ba = T(b["atom_type"]), T(b["bond_index"]), T(b["bond_type"]), T(b["batch"])
+    rec = dict(atom_type=at, pos=pos, bond_index=bi, bond_type=bt, batch=ba)
+    with torch.no_grad():
+        out = m(at, pos, bi, bt, ba, None, return_edges=True, extend_order=False, extend_radius=False)
+        for k, v in zip(("inv_g", "inv_l", "edge_index", "edge_type", "edge_length", "mask"), out):
+            rec["nr_" + k] = v
+        full = m(at, pos, bi, bt, ba, None, return_edges=True, extend_order=False, extend_radius=True)
+        g = torch.Generator().manual_seed(5)
+        perm = torch.randperm(full[2].shape[1], generator=g)
+        ei, et = full[2][:, perm], full[3][perm]
+        el = full[4][perm] * (0.9 + 0.2 * torch.rand(perm.shape[0], 1, generator=g))
+        out = m(at, pos, None, None, ba, None, edge_index=ei, edge_type=et, edge_length=el, return_edges=True)
+        rec.update(given_edge_index=ei, given_edge_type=et, given_edge_length=el, given_inv_g=out[0],
+                   given_inv_l=out[1])
+        assert out[2] is ei and out[4] is el
+    save("g11_forward_variants", **rec)
+
+
 def g_losses():
     g_loss("g10_loss_qm9", qm9_model_config(), "qm9", 31, 3, 2, 1.6)
     g_loss("g10_loss_drugs", drugs_model_config(), "drugs", 32, 2, 2, 2.5)
 
 
 if __name__ == "__main__":
-    if sys.argv[1:] and all(a in ("gaussian", "alanine", "loss") for a in sys.argv[1:]):   # add without touching the others
+    if sys.argv[1:] and all(a in ("gaussian", "alanine", "loss", "variants") for a in sys.argv[1:]):   # add without touching the others
         for a in sys.argv[1:]:
-            {"gaussian": g_gaussian, "alanine": g_alanine, "loss": g_losses}[a]()
+            {"gaussian": g_gaussian, "alanine": g_alanine, "loss": g_losses, "variants": g_forward_variants}[a]()
         sys.exit(0)
     g_schedule_and_keys()
     # G2+G3 uncapped QM9-shaped batch with per-stage outputs (small: 3 molecules x 1 copy)
@@ -307,3 +331,4 @@ if __name__ == "__main__":
     g_gaussian()
     g_alanine()
     g_losses()
+    g_forward_variants()

@@ -203,6 +203,32 @@ def test_loss_matches_reference_golden(case, precision):
     assert r1.shape == loss.shape and torch.isfinite(r1).all() and not torch.equal(r1, r2)
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_forward_variants_match_reference_golden(precision):
+    """forward(extend_radius=False) and forward(edge_index=, edge_type=, edge_length=) -- dualenc.py:165-178."""
+    from agdiff_amd import qm9_model_config
+    g = load_golden("g11_forward_variants")
+    m, _ = _gpu_model(qm9_model_config(), precision=precision)
+    a = (t(g["atom_type"]).cuda(), t(g["pos"]).cuda(), t(g["bond_index"]).cuda(), t(g["bond_type"]).cuda(),
+         t(g["batch"]).cuda(), None)
+    out = m(*a, return_edges=True, extend_order=False, extend_radius=False)
+    assert np.array_equal(out[2].cpu().numpy(), g["nr_edge_index"])
+    assert np.array_equal(out[3].cpu().numpy(), g["nr_edge_type"]) and bool(out[5].all())
+    assert rel_err(out[4].cpu().numpy(), g["nr_edge_length"]) < 1e-6
+    assert rel_err(out[0].cpu().numpy(), g["nr_inv_g"]) < TOL
+    assert rel_err(out[1].cpu().numpy(), g["nr_inv_l"]) < TOL
+    ei, et, el = t(g["given_edge_index"]).cuda(), t(g["given_edge_type"]).cuda(), t(g["given_edge_length"]).cuda()
+    out = m(a[0], a[1], None, None, a[4], None, edge_index=ei, edge_type=et, edge_length=el, return_edges=True)
+    assert out[2] is ei and out[3] is et and out[4] is el
+    assert np.array_equal(out[5].cpu().numpy(), g["given_edge_type"] > 0)
+    assert rel_err(out[0].cpu().numpy(), g["given_inv_g"]) < TOL
+    assert rel_err(out[1].cpu().numpy(), g["given_inv_l"]) < TOL
+    # the sampler with extend_radius=False keeps working (local edges only; nothing for the global term to act on)
+    pos, _ = m.langevin_dynamics_sample_diffusion(a[0], a[1], a[2], a[3], a[4], int(g["batch"].max()) + 1, False,
+                                                  extend_radius=False, n_steps=3, w_global=1.0, global_start_sigma=1e9)
+    assert torch.isfinite(pos).all()
+
+
 def test_nan_raises_floating_point_error():
     from agdiff_amd import qm9_model_config, synth
     cfg = qm9_model_config(num_diffusion_timesteps=20)

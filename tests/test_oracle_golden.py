@@ -136,6 +136,21 @@ def test_loss_g10(case):
     assert rel_err(loss.numpy(), g["loss"]) < 2e-5
 
 
+def test_forward_variants_g11():
+    """extend_radius=False and caller-supplied edges (dualenc.py:165-178)."""
+    from agdiff_amd.config import qm9_model_config
+    g = load_golden("g11_forward_variants")
+    cfg = qm9_model_config()
+    sd = O.synth_state_dict_for(cfg)
+    a = (t(g["atom_type"]), t(g["pos"]), t(g["bond_index"]), t(g["bond_type"]), t(g["batch"]))
+    out = O.forward(sd, cfg, *a, extend_order=False, extend_radius=False)
+    assert np.array_equal(out[2].numpy(), g["nr_edge_index"]) and np.array_equal(out[3].numpy(), g["nr_edge_type"])
+    assert out[5].all() and rel_err(out[0].numpy(), g["nr_inv_g"]) < TOL and rel_err(out[1].numpy(), g["nr_inv_l"]) < TOL
+    out = O.forward(sd, cfg, *a, edge_index=t(g["given_edge_index"]), edge_type=t(g["given_edge_type"]),
+                    edge_length=t(g["given_edge_length"]))
+    assert rel_err(out[0].numpy(), g["given_inv_g"]) < TOL and rel_err(out[1].numpy(), g["given_inv_l"]) < TOL
+
+
 def test_nan_raises_g6():
     from agdiff_amd.config import qm9_model_config
     from agdiff_amd import synth
