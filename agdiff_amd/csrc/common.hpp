@@ -69,6 +69,11 @@ __device__ __forceinline__ float ag_ssp(float beta, float x) {
   const float l = ag_log2(1.0f + ag_exp2(t)) * 0.69314718055994530942f;
   return fmaxf(z, l) - 0.69314718055994530942f;
 }
+// The same in base 2 for callers whose surrounding linear layers carry the constants (agdiff_conv_params_t):
+// u = beta x log2(e)  ->  max(u, log2(1 + 2^u)) = (softplus(beta x)) / ln 2.
+__device__ __forceinline__ float ag_ssp_base2(float u) {
+  return fmaxf(u, ag_log2(1.0f + ag_exp2(fminf(u, 126.0f))));
+}
 __device__ __forceinline__ float ag_sigmoid(float x) {
   return ag_rcp(1.0f + ag_exp2(fminf(-x * 1.44269504088896340736f, 126.0f)));
 }

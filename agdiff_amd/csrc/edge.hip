@@ -285,12 +285,7 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 4) k_cfconv_fused(ConvArgs
         }
         AG_STAMP(c1); st[1] += c1 - c0; c0 = c1;     // layer 1
         if (!(a.ablate & 2)) {
-#pragma unroll
-          for (int t = 0; t < AG_CONV_NCH; ++t) {
-            const float beta = (t < 8) ? a.cp.ssp_beta1 : a.cp.ssp_beta2;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) hid[t][r] = ag_ssp(beta, hid[t][r]);
-          }
+          AG_FOR_TILE(hid, AG_CONV_NCH, ag_ssp_base2(v));
         }
         ag_cvt_tiles<MODE, 6, 0>(hid, hidb);
       }

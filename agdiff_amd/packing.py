@@ -165,20 +165,24 @@ class PackedParams:
             p = "encoder_global.interactions.%d" % k
             c1, c2_ = p + ".conv1", p + ".conv2"
             n = "conv%d." % k
+            # ShiftedSoftplus in base 2, constants folded into the linear layers (include/agdiff_hip.h)
+            LN2 = np.log(2.0)
+            k1 = float(_np(sd, c1 + ".nn.1.beta")) / LN2
+            k2 = float(_np(sd, c2_ + ".nn.1.beta")) / LN2
+            f64 = lambda key: _np(sd, key).astype(np.float64)
             arrays[n + "filt_w1_pk"] = pack_blocks(
-                np.concatenate([_np(sd, c1 + ".nn.0.weight"), _np(sd, c2_ + ".nn.0.weight")], 0), kouter=True)
-            arrays[n + "filt_b1"] = np.concatenate([_np(sd, c1 + ".nn.0.bias"), _np(sd, c2_ + ".nn.0.bias")])
-            arrays[n + "filt_w2a_pk"] = pack_blocks(_np(sd, c1 + ".nn.2.weight"))
-            arrays[n + "filt_w2b_pk"] = pack_blocks(_np(sd, c2_ + ".nn.2.weight"))
-            arrays[n + "filt_b2"] = np.concatenate([_np(sd, c1 + ".nn.2.bias"), _np(sd, c2_ + ".nn.2.bias")])
+                np.concatenate([k1 * f64(c1 + ".nn.0.weight"), k2 * f64(c2_ + ".nn.0.weight")], 0), kouter=True)
+            arrays[n + "filt_b1"] = np.concatenate([k1 * f64(c1 + ".nn.0.bias"), k2 * f64(c2_ + ".nn.0.bias")])
+            arrays[n + "filt_w2a_pk"] = pack_blocks(LN2 * f64(c1 + ".nn.2.weight"))
+            arrays[n + "filt_w2b_pk"] = pack_blocks(LN2 * f64(c2_ + ".nn.2.weight"))
+            arrays[n + "filt_b2"] = np.concatenate([f64(c1 + ".nn.2.bias") - LN2 * f64(c1 + ".nn.2.weight").sum(1),
+                                                    f64(c2_ + ".nn.2.bias") - LN2 * f64(c2_ + ".nn.2.weight").sum(1)])
             dws = []
             for c in (c1, c2_):
                 d = c + ".distance_weighting"
                 dws.append(np.concatenate([_np(sd, d + ".layer1.weight")[:, 0], _np(sd, d + ".layer1.bias"),
                                            _np(sd, d + ".layer2.weight")[0], _np(sd, d + ".layer2.bias")]))
             arrays[n + "dist_w"] = np.concatenate(dws)
-            scalars[n + "ssp_beta1"] = float(_np(sd, c1 + ".nn.1.beta"))
-            scalars[n + "ssp_beta2"] = float(_np(sd, c2_ + ".nn.1.beta"))
             W1a, b1a = fold_bn(_np(sd, c1 + ".lin1.weight"), _np(sd, c1 + ".lin1.bias"), sd, c1 + ".norm1")
             W1b, b1b = fold_bn(_np(sd, c2_ + ".lin1.weight"), _np(sd, c2_ + ".lin1.bias"), sd, c2_ + ".norm1")
             arrays[n + "lin1_pk"] = pack_blocks(np.concatenate([W1a, W1b], 0))

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 12
+#define AGDIFF_ABI_VERSION 13
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -49,15 +49,17 @@ enum agdiff_status {
  *   precision 1: two 16-byte units [part][lane][8 bf16], part 0 = bf16(w), part 1 = bf16(w - hi)
  * Dimensions in the field comments below are [OT][KT] block counts.  Vectors are in natural feature order. */
 typedef struct agdiff_conv_params {
-  /* CFConv filter networks of one InteractionBlock (schnet.py:169-186), conv1 (F=128) and conv2 (F=64) fused */
-  const float* filt_w1_pk;   /* pkk [4][12]: rows 0..127 conv1.nn.0, 128..191 conv2.nn.0 */
-  const float* filt_b1;      /* [192] */
-  const float* filt_w2a_pk;  /* pk [8][4]: conv1.nn.2 */
-  const float* filt_w2b_pk;  /* pk [4][2]: conv2.nn.2 */
-  const float* filt_b2;      /* [192] */
+  /* CFConv filter networks of one InteractionBlock (schnet.py:169-186), conv1 (F=128) and conv2 (F=64) fused.
+   * ShiftedSoftplus (schnet.py:71-80) is evaluated in base 2 with its constants folded into the two linear
+   * layers by the host: with c = beta * log2(e) per conv, layer 1 yields u = c (W1 a + b1); the kernel forms
+   * s = max(u, log2(1 + 2^u)); since softplus(beta x) - ln 2 = ln 2 (s - 1), layer 2 uses ln 2 * W2 and
+   * b2 - ln 2 * W2 1. */
+  const float* filt_w1_pk;   /* pkk [4][12]: rows 0..127 c1 * conv1.nn.0.weight, 128..191 c2 * conv2.nn.0.weight */
+  const float* filt_b1;      /* [192] c * nn.0.bias */
+  const float* filt_w2a_pk;  /* pk [8][4]: ln2 * conv1.nn.2.weight */
+  const float* filt_w2b_pk;  /* pk [4][2]: ln2 * conv2.nn.2.weight */
+  const float* filt_b2;      /* [192] nn.2.bias - ln2 * rowsum(nn.2.weight) */
   const float* dist_w;       /* [2][97]: DistanceWeightingNetwork (schnet.py:83-100): w1[32] b1[32] w2[32] b2 */
-  float ssp_beta1;           /* conv1.nn.1.beta */
-  float ssp_beta2;           /* conv2.nn.1.beta */
   /* node side of the block (schnet.py:153-158, 201-216, 219-234) */
   const float* lin1_pk;      /* pk [12][4]: BN-folded conv1.lin1 (rows 0..127) and conv2.lin1 (128..191) */
   const float* lin1_b;       /* [192] */
