@@ -2,6 +2,7 @@
 // per-edge), GIN layers, and the per-molecule Langevin update.  One wave = one tile of 16 nodes in
 // the MFMA accumulator layout (common.hpp): lane <-> node, registers <-> features.
 #include "common.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -28,23 +29,57 @@ struct NodeStageArgs {
 //           h += x * sigmoid(fc2(relu(fc1(x))))                   (schnet.py:230-234, 280)
 //   prep:   xs = LeakyReLU(BN(lin1(h))) for conv1 | conv2         (schnet.py:153-155)
 //   stage 0 (finish == 0): h = embedding[z]                       (schnet.py:271)
-template <int MODE>
-__global__ void __launch_bounds__(AG_WG, 2) k_schnet_node_stage(NodeStageArgs a) {
+//
+// One wave = one 16-node tile; a workgroup of W waves (W = 4..16, chosen by the launcher so that the grid is about
+// one workgroup per CU) shares every weight matrix through LDS: the 188 weight blocks (376 KiB) of a stage are
+// copied global -> LDS once per WORKGROUP in three steps instead of being streamed from L2 once per WAVE
+// (1.1 GB of L2 reads per launch at 2,928 tiles, which is what bounded the first version of this kernel).
+//   step A: [0,48) lin2a | lin2b     [48,80) lin blocks 0..31 (output tiles 0..3)
+//   step B: [0,32) lin blocks 32..63 [32,48) gate1
+//   step C: [0,4) scale1  [4,12) scale2  [12,60) lin1 of the next block
+// Waves without a tile (tail of the grid) still take part in the copies and barriers.
+// Small batches (fewer tiles than keep every CU busy that way) use LDSW = false: 4-wave workgroups, every wave
+// streams the weights from L2 through a register ring (no copies, no barriers).
+#define AG_NODE_LDS_BLOCKS 80
+#define AG_NODE_DENSE(KOUTER, KT, OT, X0, O0, x, o, gsrc, lblock)                                   \
+  do {                                                                                              \
+    if constexpr (LDSW) ag_dense_lds<MODE, false, KOUTER, KT, OT, X0, O0>(x, o, L + (lblock) * 128, lane); \
+    else ag_dense<MODE, false, KOUTER, KT, OT, X0, O0, PF>(x, o, gsrc, lane);                       \
+  } while (0)
+template <int MODE, bool LDSW>
+__global__ void __launch_bounds__(LDSW ? 1024 : 256, LDSW ? 1 : 2) k_schnet_node_stage(NodeStageArgs a) {
+  extern __shared__ u32x4 ag_node_smem[];
+  lds_u32x4* L = (lds_u32x4*)ag_node_smem;
+  constexpr int PF = (MODE == AG_F32) ? 3 : 10;   // LDSW = false, few waves per SIMD: hide the L2 latency in registers
+  auto stage_in = [&](int dst_block, const float* src, int nblocks) {
+    if constexpr (LDSW) {
+      const u32x4* g = reinterpret_cast<const u32x4*>(src);
+      for (int i = threadIdx.x; i < nblocks * 128; i += blockDim.x) L[dst_block * 128 + i] = g[i];
+    }
+  };
+  auto sync = [&]() {
+    if constexpr (LDSW) __syncthreads();
+  };
   const int lane = ag_lane(), q = lane >> 4;
-  const int64_t tile = (int64_t)blockIdx.x * 4 + ag_wave_in_wg();
-  if (tile * AG_TW >= a.n) return;
+  const int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const bool active = tile * AG_TW < a.n;
   const int64_t node = tile * AG_TW + (lane & 15);
-  const bool valid = node < a.n;
+  const bool valid = active && node < a.n;
   const int64_t nd = valid ? node : 0;
-  constexpr int PF = (MODE == AG_F32) ? 3 : 10;   // few waves per SIMD here: hide the L2 latency of the weight stream in registers
 
   f32x4 hv[8];
   if (!a.finish) {
-    ag_load_row<8, 0>(hv, a.emb + (size_t)a.atom_type[nd] * 128, q);
+    if (a.prep) stage_in(12, a.next.lin1_pk, 48);
+    if (active) ag_load_row<8, 0>(hv, a.emb + (size_t)a.atom_type[nd] * 128, q);
+    sync();
   } else {
+    stage_in(0, a.prev.lin2a_pk, 32);
+    stage_in(32, a.prev.lin2b_pk, 16);
+    stage_in(48, a.prev.lin_pk, 32);
+    sync();
     f32x4 xc[8];
-    ag_init_vec<8>(xc, a.prev.lin_b, q);
-    {
+    AgIn<MODE> ub[8];
+    if (active) {
       f32x4 u[16];
       {
         // aggregates: agg[node] (+ the partial its last chunk kept separately, edge.hip k_cfconv_fused)
@@ -73,11 +108,11 @@ __global__ void __launch_bounds__(AG_WG, 2) k_schnet_node_stage(NodeStageArgs a)
           if (k + 1 < 6) load_slice(g[(k + 1) & 1], k + 1);
           // conv1.lin2: k-tiles 0..3 -> u[0..7]; conv2.lin2: k-tiles 4..5 -> u[8..15]   (pkk blocks)
           if (k < 4) {
-            if (k & 1) ag_dense<MODE, false, true, 1, 8, 1, 0, PF>(g, u, ag_wblock(a.prev.lin2a_pk, k * 8), lane);
-            else ag_dense<MODE, false, true, 1, 8, 0, 0, PF>(g, u, ag_wblock(a.prev.lin2a_pk, k * 8), lane);
+            if (k & 1) AG_NODE_DENSE(true, 1, 8, 1, 0, g, u, ag_wblock(a.prev.lin2a_pk, k * 8), k * 8);
+            else AG_NODE_DENSE(true, 1, 8, 0, 0, g, u, ag_wblock(a.prev.lin2a_pk, k * 8), k * 8);
           } else {
-            if (k & 1) ag_dense<MODE, false, true, 1, 8, 1, 8, PF>(g, u, ag_wblock(a.prev.lin2b_pk, (k - 4) * 8), lane);
-            else ag_dense<MODE, false, true, 1, 8, 0, 8, PF>(g, u, ag_wblock(a.prev.lin2b_pk, (k - 4) * 8), lane);
+            if (k & 1) AG_NODE_DENSE(true, 1, 8, 1, 8, g, u, ag_wblock(a.prev.lin2b_pk, (k - 4) * 8), 32 + (k - 4) * 8);
+            else AG_NODE_DENSE(true, 1, 8, 0, 8, g, u, ag_wblock(a.prev.lin2b_pk, (k - 4) * 8), 32 + (k - 4) * 8);
           }
         }
       }
@@ -85,23 +120,33 @@ __global__ void __launch_bounds__(AG_WG, 2) k_schnet_node_stage(NodeStageArgs a)
         const float beta = a.prev.act_beta;
         AG_FOR_TILE(u, 16, ag_ssp(beta, v));
       }
-      AgIn<MODE> ub[8];
       ag_cvt_tiles<MODE, 8, 0>(u, ub);
-      ag_dense<MODE, false, false, 8, 8, 0, 0, PF>(ub, xc, a.prev.lin_pk, lane);
+      ag_init_vec<8>(xc, a.prev.lin_b, q);
+      AG_NODE_DENSE(false, 8, 4, 0, 0, ub, xc, a.prev.lin_pk, 48);                             // output tiles 0..3
     }
-    {
+    sync();
+    stage_in(0, a.prev.lin_pk + (size_t)32 * 512, 32);
+    stage_in(32, a.prev.gate1_pk, 16);
+    sync();
+    if (active) {
+      AG_NODE_DENSE(false, 8, 4, 0, 4, ub, xc, ag_wblock(a.prev.lin_pk, 32), 0);               // output tiles 4..7
       f32x4 g1[4];
       ag_init_vec<4>(g1, a.prev.gate1_b, q);
       {
         AgIn<MODE> xb[4];
         ag_cvt_tiles<MODE, 4, 0>(xc, xb);
-        ag_dense<MODE, false, false, 4, 4, 0, 0, PF>(xb, g1, a.prev.gate1_pk, lane);
+        AG_NODE_DENSE(false, 4, 4, 0, 0, xb, g1, a.prev.gate1_pk, 32);
       }
       AG_FOR_TILE(g1, 4, ag_relu(v));
       const float gate = ag_sigmoid(ag_dot_vec<4>(g1, a.prev.gate2_w, q) + a.prev.gate2_b);
       AG_FOR_TILE(xc, 8, v * gate);
     }
-    {
+    sync();
+    stage_in(0, a.prev.scale1_pk, 4);
+    stage_in(4, a.prev.scale2_pk, 8);
+    if (a.prep) stage_in(12, a.next.lin1_pk, 48);
+    sync();
+    if (active) {
       // AdaptiveScaling: 128 -> 8 (one 16-row output tile, rows 8..15 zero) -> relu -> 8 -> 128 (one k-tile,
       // input features 8..31 zero)
       f32x4 s1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -109,7 +154,7 @@ __global__ void __launch_bounds__(AG_WG, 2) k_schnet_node_stage(NodeStageArgs a)
       {
         AgIn<MODE> xb[4];
         ag_cvt_tiles<MODE, 4, 0>(xc, xb);
-        ag_dense<MODE, false, false, 4, 1, 0, 0, PF>(xb, s1, a.prev.scale1_pk, lane);
+        AG_NODE_DENSE(false, 4, 1, 0, 0, xb, s1, a.prev.scale1_pk, 0);
       }
       AG_FOR_TILE(s1, 1, ag_relu(v));
 #pragma unroll
@@ -117,7 +162,7 @@ __global__ void __launch_bounds__(AG_WG, 2) k_schnet_node_stage(NodeStageArgs a)
       {
         AgIn<MODE> sb[1];
         ag_cvt_tiles<MODE, 1, 0>(s1, sb);
-        ag_dense<MODE, false, false, 1, 8, 0, 0, PF>(sb, s2, a.prev.scale2_pk, lane);
+        AG_NODE_DENSE(false, 1, 8, 0, 0, sb, s2, a.prev.scale2_pk, 4);
       }
       ag_load_row<8, 0>(hv, a.h + (size_t)nd * 128, q);
 #pragma unroll
@@ -126,6 +171,7 @@ __global__ void __launch_bounds__(AG_WG, 2) k_schnet_node_stage(NodeStageArgs a)
         for (int r = 0; r < 4; ++r) hv[t][r] = hv[t][r] + xc[t][r] * ag_sigmoid(s2[t][r]);
     }
   }
+  if (!active) return;                     // no barrier below this point
   if (valid) ag_store_row<8, 0>(hv, a.h + (size_t)node * 128, q);
   if (a.prep) {
     f32x4 xo[12];
@@ -133,7 +179,7 @@ __global__ void __launch_bounds__(AG_WG, 2) k_schnet_node_stage(NodeStageArgs a)
     {
       AgIn<MODE> hb[4];
       ag_cvt_tiles<MODE, 4, 0>(hv, hb);
-      ag_dense<MODE, false, false, 4, 12, 0, 0, PF>(hb, xo, a.next.lin1_pk, lane);
+      AG_NODE_DENSE(false, 4, 12, 0, 0, hb, xo, a.next.lin1_pk, 12);
     }
     AG_FOR_TILE(xo, 12, ag_lrelu(v));
     if (valid) ag_store_row<12, 0>(xo, a.xs + (size_t)node * 192, q);
@@ -156,58 +202,70 @@ struct GinArgs {
 
 // GINEConv + BN + relu + residual (gin.py:57-63, 131-138): m_i = sum relu(h_j + e_ji);
 // u = MLP(m_i + (1+eps) h_i); u = BN(u) (folded); relu except last layer; h = u + h.
-template <int MODE>
-__global__ void __launch_bounds__(AG_WG, 2) k_gin_layer(GinArgs a) {
+// Like the SchNet node stage, a workgroup of W one-tile waves shares the layer's two weight matrices (64 blocks,
+// 128 KiB) through LDS; the copy is issued first and lands while the waves gather their messages.
+template <int MODE, bool LDSW>
+__global__ void __launch_bounds__(LDSW ? 1024 : 256, LDSW ? 1 : 2) k_gin_layer(GinArgs a) {
+  extern __shared__ u32x4 ag_gin_smem[];
+  lds_u32x4* L = (lds_u32x4*)ag_gin_smem;
+  constexpr int PF = (MODE == AG_F32) ? 3 : 10;
+  if constexpr (LDSW) {
+    const u32x4* g1 = reinterpret_cast<const u32x4*>(a.gp.w1_pk);
+    const u32x4* g2 = reinterpret_cast<const u32x4*>(a.gp.w2_pk);
+    for (int i = threadIdx.x; i < 32 * 128; i += blockDim.x) L[i] = g1[i];
+    for (int i = threadIdx.x; i < 32 * 128; i += blockDim.x) L[32 * 128 + i] = g2[i];
+  }
   const int lane = ag_lane(), q = lane >> 4;
-  const int64_t tile = (int64_t)blockIdx.x * 4 + ag_wave_in_wg();
-  if (tile * AG_TW >= a.n) return;
+  const int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const bool active = tile * AG_TW < a.n;
   const int64_t node = tile * AG_TW + (lane & 15);
-  const bool valid = node < a.n;
+  const bool valid = active && node < a.n;
   const int64_t nd = valid ? node : 0;
   const float* hin_self = a.emb ? a.emb + (size_t)a.atom_type[nd] * 128 : a.h_in + (size_t)nd * 128;
-  constexpr int PF = (MODE == AG_F32) ? 3 : 10;   // few waves per SIMD here: hide the L2 latency of the weight stream in registers
 
   f32x4 m[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) m[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int lo = a.loc_in_ptr[nd], hi = valid ? a.loc_in_ptr[nd + 1] : lo;
-  int maxdeg = hi - lo;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, o));
-  for (int k = 0; k < maxdeg; ++k) {
-    const bool on = lo + k < hi;
-    const int eid = on ? a.loc_in_eid[lo + k] : 0;
-    const int src = on ? a.loc_src[eid] : 0;
-    const float* hsrc = a.emb ? a.emb + (size_t)a.atom_type[src] * 128 : a.h_in + (size_t)src * 128;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const int f = 16 * t + 4 * q;
-      const f32x4 hvv = ag_ld4(hsrc + f);
-      const f32x4 ev = ag_ld4(a.l_attr_rows + (size_t)eid * 128 + f);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) m[t][r] += on ? ag_relu(hvv[r] + ev[r]) : 0.0f;
-    }
-  }
   f32x4 hself[8];
-  ag_load_row<8, 0>(hself, hin_self, q);
-  {
+  if (active) {
+    const int lo = a.loc_in_ptr[nd], hi = valid ? a.loc_in_ptr[nd + 1] : lo;
+    int maxdeg = hi - lo;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, o));
+    for (int k = 0; k < maxdeg; ++k) {
+      const bool on = lo + k < hi;
+      const int eid = on ? a.loc_in_eid[lo + k] : 0;
+      const int src = on ? a.loc_src[eid] : 0;
+      const float* hsrc = a.emb ? a.emb + (size_t)a.atom_type[src] * 128 : a.h_in + (size_t)src * 128;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int f = 16 * t + 4 * q;
+        const f32x4 hvv = ag_ld4(hsrc + f);
+        const f32x4 ev = ag_ld4(a.l_attr_rows + (size_t)eid * 128 + f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m[t][r] += on ? ag_relu(hvv[r] + ev[r]) : 0.0f;
+      }
+    }
+    ag_load_row<8, 0>(hself, hin_self, q);
     const float ope = a.gp.one_plus_eps;
 #pragma unroll
     for (int t = 0; t < 8; ++t) m[t] = m[t] + ope * hself[t];
   }
+  if constexpr (LDSW) __syncthreads();
+  if (!active) return;
   f32x4 y1[8];
   ag_init_vec<8>(y1, a.gp.b1, q);
   {
     AgIn<MODE> mb[4];
     ag_cvt_tiles<MODE, 4, 0>(m, mb);
-    ag_dense<MODE, false, false, 4, 8, 0, 0, PF>(mb, y1, a.gp.w1_pk, lane);
+    AG_NODE_DENSE(false, 4, 8, 0, 0, mb, y1, a.gp.w1_pk, 0);
   }
   AG_FOR_TILE(y1, 8, ag_relu(v));
   ag_init_vec<8>(m, a.gp.b2, q);
   {
     AgIn<MODE> yb[4];
     ag_cvt_tiles<MODE, 4, 0>(y1, yb);
-    ag_dense<MODE, false, false, 4, 8, 0, 0, PF>(yb, m, a.gp.w2_pk, lane);
+    AG_NODE_DENSE(false, 4, 8, 0, 0, yb, m, a.gp.w2_pk, 32);
   }
   if (a.gp.relu_out) { AG_FOR_TILE(m, 8, ag_relu(v)); }
 #pragma unroll
@@ -467,6 +525,25 @@ __global__ void __launch_bounds__(256) k_diffusion_loss(LossArgs a) {
 
 }  // namespace
 
+// Waves (= 16-node tiles) per workgroup for the LDS-sharing node kernels: about one workgroup per CU.
+// Below AG_NODE_LDSW_MIN_TILES the 4-wave streaming variants are faster (measured crossover between 275 and
+// 2,928 tiles: 24 vs 43 us and 75 vs 56 us per node stage).
+// AGDIFF_NODE_LDSW_MIN_TILES overrides the threshold (tests run both variants on the same small batch).
+static int64_t ag_node_ldsw_min_tiles() {
+  const char* e = getenv("AGDIFF_NODE_LDSW_MIN_TILES");
+  return e ? atoll(e) : 1536;
+}
+static int ag_node_waves_per_wg(int64_t tiles) {
+  if (tiles < ag_node_ldsw_min_tiles()) return 4;
+  int64_t w = (tiles + 255) / 256;
+  if (w > 16) w = 16;
+  return (int)w;
+}
+template <typename K>
+static int ag_allow_lds(K kern, size_t smem) {
+  return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess;
+}
+
 extern "C" int agdiff_schnet_node_stage(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
                                         int32_t k, void* stream) {
   if (!p || !topo || !ws || k < 0 || k > p->num_convs || p->num_convs > AGDIFF_MAX_CONVS) return AGDIFF_ERR_ARG;
@@ -486,10 +563,25 @@ extern "C" int agdiff_schnet_node_stage(const agdiff_params_t* p, const agdiff_t
   a.n = topo->num_nodes;
   a.chunk_edges = AG_TW * agdiff_conv_chunk_tiles(topo->max_edges);
   const int64_t tiles = (a.n + AG_TW - 1) / AG_TW;
-  if (p->precision == AG_BF3)
-    k_schnet_node_stage<AG_BF3><<<dim3((unsigned)((tiles + 3) / 4)), dim3(AG_WG), 0, (hipStream_t)stream>>>(a);
-  else
-    k_schnet_node_stage<AG_F32><<<dim3((unsigned)((tiles + 3) / 4)), dim3(AG_WG), 0, (hipStream_t)stream>>>(a);
+  const int waves = ag_node_waves_per_wg(tiles);
+  const bool ldsw = tiles >= ag_node_ldsw_min_tiles();
+  const size_t smem = ldsw ? (size_t)AG_NODE_LDS_BLOCKS * 2048 : 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (!ag_allow_lds(k_schnet_node_stage<AG_BF3, true>, (size_t)AG_NODE_LDS_BLOCKS * 2048) ||
+        !ag_allow_lds(k_schnet_node_stage<AG_F32, true>, (size_t)AG_NODE_LDS_BLOCKS * 2048))
+      return AGDIFF_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const dim3 grid((unsigned)((tiles + waves - 1) / waves)), block(64 * waves);
+  hipStream_t st = (hipStream_t)stream;
+  if (p->precision == AG_BF3) {
+    if (ldsw) k_schnet_node_stage<AG_BF3, true><<<grid, block, smem, st>>>(a);
+    else k_schnet_node_stage<AG_BF3, false><<<grid, block, 0, st>>>(a);
+  } else {
+    if (ldsw) k_schnet_node_stage<AG_F32, true><<<grid, block, smem, st>>>(a);
+    else k_schnet_node_stage<AG_F32, false><<<grid, block, 0, st>>>(a);
+  }
   AG_CHECK_LAUNCH();
   return AGDIFF_OK;
 }
@@ -498,6 +590,16 @@ extern "C" int agdiff_gin_encoder(const agdiff_params_t* p, const agdiff_topo_t*
   if (!p || !topo || !ws || p->num_convs_local <= 0 || p->num_convs_local > AGDIFF_MAX_CONVS_LOCAL) return AGDIFF_ERR_ARG;
   if (topo->num_nodes <= 0) return AGDIFF_OK;
   const int64_t tiles = (topo->num_nodes + AG_TW - 1) / AG_TW;
+  const int waves = ag_node_waves_per_wg(tiles);
+  const bool ldsw = tiles >= ag_node_ldsw_min_tiles();
+  const size_t smem = ldsw ? (size_t)64 * 2048 : 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (!ag_allow_lds(k_gin_layer<AG_BF3, true>, (size_t)64 * 2048) || !ag_allow_lds(k_gin_layer<AG_F32, true>, (size_t)64 * 2048))
+      return AGDIFF_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const dim3 grid((unsigned)((tiles + waves - 1) / waves)), block(64 * waves);
   // ping-pong so that the final layer lands in ws->hl
   float* bufs[2] = {ws->hl, ws->hl2};
   int cur = (p->num_convs_local & 1) ? 0 : 1;   // layer 0 writes bufs[cur]; the last write must hit bufs[0]
@@ -514,10 +616,14 @@ extern "C" int agdiff_gin_encoder(const agdiff_params_t* p, const agdiff_topo_t*
     a.h_in = in;
     a.h_out = bufs[cur];
     a.n = topo->num_nodes;
-    if (p->precision == AG_BF3)
-      k_gin_layer<AG_BF3><<<dim3((unsigned)((tiles + 3) / 4)), dim3(AG_WG), 0, (hipStream_t)stream>>>(a);
-    else
-      k_gin_layer<AG_F32><<<dim3((unsigned)((tiles + 3) / 4)), dim3(AG_WG), 0, (hipStream_t)stream>>>(a);
+    hipStream_t st = (hipStream_t)stream;
+    if (p->precision == AG_BF3) {
+      if (ldsw) k_gin_layer<AG_BF3, true><<<grid, block, smem, st>>>(a);
+      else k_gin_layer<AG_BF3, false><<<grid, block, 0, st>>>(a);
+    } else {
+      if (ldsw) k_gin_layer<AG_F32, true><<<grid, block, smem, st>>>(a);
+      else k_gin_layer<AG_F32, false><<<grid, block, 0, st>>>(a);
+    }
     AG_CHECK_LAUNCH();
     in = bufs[cur];
     cur ^= 1;

@@ -229,6 +229,29 @@ def test_forward_variants_match_reference_golden(precision):
     assert torch.isfinite(pos).all()
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_node_kernels_lds_shared_variant(precision, monkeypatch):
+    """The SchNet node stage and the GIN layer have two weight-delivery variants (per-wave streaming for small
+    batches, workgroup-shared LDS copies for large ones, csrc/node.hip) with the same MFMA order: fp32 mode is
+    bitwise equal, the split-bf16 mode differs only by FMA contraction around the hi/lo split (two template
+    instantiations), and both must match the reference fixture."""
+    case = "g3_forward_drugs_capped"
+    g = load_golden(case)
+    m, _ = _gpu_model(FORWARD_CASES[case](), precision=precision)
+    a = (t(g["atom_type"]).cuda(), t(g["pos"]).cuda(), t(g["bond_index"]).cuda(), t(g["bond_type"]).cuda(),
+         t(g["batch"]).cuda(), None)
+    base = m(*a, return_edges=True, extend_order=False)
+    monkeypatch.setenv("AGDIFF_NODE_LDSW_MIN_TILES", "1")
+    shared = m(*a, return_edges=True, extend_order=False)
+    monkeypatch.delenv("AGDIFF_NODE_LDSW_MIN_TILES")
+    if precision == "f32":
+        assert torch.equal(base[0], shared[0]) and torch.equal(base[1], shared[1])
+    assert rel_err(shared[0].cpu().numpy(), base[0].cpu().numpy()) < 1e-5
+    assert rel_err(shared[1].cpu().numpy(), base[1].cpu().numpy()) < 1e-5
+    assert rel_err(shared[0].cpu().numpy(), g["edge_inv_global"]) < TOL
+    assert rel_err(shared[1].cpu().numpy(), g["edge_inv_local"]) < TOL
+
+
 def test_nan_raises_floating_point_error():
     from agdiff_amd import qm9_model_config, synth
     cfg = qm9_model_config(num_diffusion_timesteps=20)
