@@ -198,6 +198,14 @@ __device__ unsigned long long ag_conv_stamp_acc[8];
 #define AG_STAMP(var) do { } while (0)
 #endif
 
+// Timing experiments (AGDIFF_ABLATE env) exist only in the diagnostic build (make EXTRA=-DAG_CONV_ABLATE): in the
+// product build the tile body has no uniform branches around its phases, which also gives the scheduler one region.
+#ifdef AG_CONV_ABLATE
+#define AG_ABL(bit) (a.ablate & (bit))
+#else
+#define AG_ABL(bit) false
+#endif
+
 #define AG_CONV_WAVES 16
 #define AG_CONV_LDS_BLOCKS 80   // resident 2-KiB weight blocks: filt_w1 (48: both convs' first layer) | filt_w2a (32)
 #define AG_CONV_NCH 12          // 16-channel tiles of the 192 filter channels (conv1: 0..7, conv2: 8..11)
@@ -274,21 +282,35 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 4) k_cfconv_fused(ConvArgs
 
       AgIn<MODE> hidb[6];
       {
-        f32x4 hid[AG_CONV_NCH];
-        {
-          // first filter layer of both convs (128 -> 192), k-tile outer, all 48 weight blocks from LDS
-          AgIn<MODE> ea[4];
-          ag_init_vec<AG_CONV_NCH>(hid, a.cp.filt_b1, q);
+        // First filter layer of both convs (128 -> 192), all 48 weight blocks from LDS (block (t, ot) at
+        // t * 12 + ot), two output tiles (= one k-tile of the second layer) at a time, so that the softplus
+        // and the operand split of one pair can issue between the MFMAs of the next.
+        AgIn<MODE> ea[4];
 #pragma unroll
-          for (int t = 0; t < 4; ++t) ag_load_attr(ea[t], a.e_attr, tile, t, lane);
-          if (!(a.ablate & 1)) ag_dense_lds<MODE, false, true, 4, AG_CONV_NCH, 0, 0>(ea, hid, w1, lane);
+        for (int t = 0; t < 4; ++t) ag_load_attr(ea[t], a.e_attr, tile, t, lane);
+#pragma unroll
+        for (int m = 0; m < AG_CONV_NCH / 2; ++m) {
+          f32x4 h0 = ag_ld4(a.cp.filt_b1 + 32 * m + 4 * q), h1 = ag_ld4(a.cp.filt_b1 + 32 * m + 16 + 4 * q);
+          if (!(AG_ABL(1))) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              u32x4 wa[2], wb[2];
+              wa[0] = w1[((t * AG_CONV_NCH + 2 * m) * 2) * 64 + lane];
+              wa[1] = w1[((t * AG_CONV_NCH + 2 * m) * 2 + 1) * 64 + lane];
+              wb[0] = w1[((t * AG_CONV_NCH + 2 * m + 1) * 2) * 64 + lane];
+              wb[1] = w1[((t * AG_CONV_NCH + 2 * m + 1) * 2 + 1) * 64 + lane];
+              ag_block_mma<MODE, false>(h0, ea[t], wa);
+              ag_block_mma<MODE, false>(h1, ea[t], wb);
+            }
+          }
+          if (!(AG_ABL(2))) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { h0[r] = ag_ssp_base2(h0[r]); h1[r] = ag_ssp_base2(h1[r]); }
+          }
+          ag_cvt(h0, h1, hidb[m]);
         }
-        AG_STAMP(c1); st[1] += c1 - c0; c0 = c1;     // layer 1
-        if (!(a.ablate & 2)) {
-          AG_FOR_TILE(hid, AG_CONV_NCH, ag_ssp_base2(v));
-        }
-        ag_cvt_tiles<MODE, 6, 0>(hid, hidb);
       }
+      AG_STAMP(c1); st[1] += c1 - c0; c0 = c1;       // layer 1 + ssp + split
       AG_STAMP(c1); st[2] += c1 - c0; c0 = c1;       // ssp + split
       // per edge slot of my quarter (slot 4q + r lives in lane 4q + r): gather row of x, and the scales
       // lw(d)*C(d) of the two convs, which multiply the message: (H^T W2 + b2) . s . x[src]
@@ -315,7 +337,7 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 4) k_cfconv_fused(ConvArgs
       // fetched before the current tile's reduction.
       f32x4 xg;
       auto fetch_x = [&](int nt) {
-        if (a.ablate & 8) return;
+        if (AG_ABL(8)) return;
         const float* xb = a.xs + 16 * nt;
 #pragma unroll
         for (int r = 0; r < 4; ++r) xg[r] = xb[xoff[r]];
@@ -335,8 +357,8 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 4) k_cfconv_fused(ConvArgs
       }
       float* const dp0 = dest_lo(t0, bound(0));
       auto reduce_tile = [&](f32x4 z, int nt, float& cr) {
-        if (a.ablate & 16) { cr = z[0]; return; }
-        if (ntg <= 2 && !(a.ablate & 32)) {
+        if (AG_ABL(16)) { cr = z[0]; return; }
+        if (ntg <= 2 && !(AG_ABL(32))) {
           float p0 = z[0] * m0[0], p1 = z[0] * m1[0];
 #pragma unroll
           for (int r = 1; r < 4; ++r) {
@@ -395,7 +417,7 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 4) k_cfconv_fused(ConvArgs
 #pragma unroll
           for (int r = 0; r < 4; ++r) sr[r] = __shfl(s2, 4 * q + r);
         }
-        if (!(a.ablate & 4)) {
+        if (!(AG_ABL(4))) {
           if (nt < 8) {
             ag_dense_lds<MODE, true, false, 4, 1, 0, 0>(hidb, z, w2a + (nt * 4) * 128, lane);
           } else {
