@@ -155,6 +155,19 @@ __device__ __forceinline__ void ag_cvt(const f32x4& a0, const f32x4& a1, AgIn<AG
     o.lo[j] = (__bf16)(v - (float)hb);
   }
 }
+// Elements j, j + 1 (j even) of a k-tile from two fp32 values: the piecewise form of ag_cvt, for callers that
+// spread the conversion between other work.
+__device__ __forceinline__ void ag_cvt_pair(AgIn<AG_F32>& o, int j, float v0, float v1) {
+  o.v[j >> 2][j & 3] = v0;
+  o.v[j >> 2][(j & 3) + 1] = v1;
+}
+__device__ __forceinline__ void ag_cvt_pair(AgIn<AG_BF3>& o, int j, float v0, float v1) {
+  const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
+  o.hi[j] = h0;
+  o.hi[j + 1] = h1;
+  o.lo[j] = (__bf16)(v0 - (float)h0);
+  o.lo[j + 1] = (__bf16)(v1 - (float)h1);
+}
 // NK k-tiles from accumulator tiles A0, A0+1, ...
 template <int MODE, int NK, int A0, int NA, int NO>
 __device__ __forceinline__ void ag_cvt_tiles(const f32x4 (&a)[NA], AgIn<MODE> (&o)[NO]) {

@@ -206,7 +206,7 @@ __device__ unsigned long long ag_conv_stamp_acc[8];
 #define AG_ABL(bit) false
 #endif
 
-#define AG_CONV_WAVES 16
+#define AG_CONV_WAVES 8
 #define AG_CONV_LDS_BLOCKS 80   // resident 2-KiB weight blocks: filt_w1 (48: both convs' first layer) | filt_w2a (32)
 #define AG_CONV_NCH 12          // 16-channel tiles of the 192 filter channels (conv1: 0..7, conv2: 8..11)
 
@@ -217,7 +217,7 @@ __device__ unsigned long long ag_conv_stamp_acc[8];
 // registers; a target whose list started in an earlier chunk is written to agg_first[chunk] and added by
 // the node stage (fixed order -> bitwise reproducible, no atomics).
 template <int MODE>
-__global__ void __launch_bounds__(64 * AG_CONV_WAVES, 4) k_cfconv_fused(ConvArgs a) {
+__global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs a) {
   // LDS: all 160 KiB hold filter weights for the whole launch -- the fused first layer of both convs (96 KiB)
   // and conv1's second layer (64 KiB).  Only conv2's second layer (8 blocks = 16 KiB per tile) is streamed
   // from L2, fetched two channel tiles ahead of its use.
@@ -237,6 +237,16 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 4) k_cfconv_fused(ConvArgs
   const int64_t cstride = (int64_t)gridDim.x * AG_CONV_WAVES;
   [[maybe_unused]] unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c0 = 0, c1 = 0;
 
+  // edge attributes of the wave's NEXT tile are requested as soon as the current tile's first layer has consumed
+  // its own (they land during the rest of the tile)
+  AgIn<MODE> ea[4];
+  {
+    const int64_t first = ((int64_t)blockIdx.x * AG_CONV_WAVES + wave) * a.chunk_tiles;
+    if (first * AG_TW < E) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) ag_load_attr(ea[t], a.e_attr, first, t, lane0);
+    }
+  }
   for (int64_t chunk = (int64_t)blockIdx.x * AG_CONV_WAVES + wave; chunk < a.max_chunks; chunk += cstride) {
     const int64_t e_begin = chunk * (AG_TW * a.chunk_tiles);
     if (e_begin >= E) break;
@@ -285,29 +295,54 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 4) k_cfconv_fused(ConvArgs
         // First filter layer of both convs (128 -> 192), all 48 weight blocks from LDS (block (t, ot) at
         // t * 12 + ot), two output tiles (= one k-tile of the second layer) at a time, so that the softplus
         // and the operand split of one pair can issue between the MFMAs of the next.
-        AgIn<MODE> ea[4];
+        // weight blocks are read from LDS one step (two blocks) ahead of the MFMAs that use them
+        u32x4 wq[2][2][2];
+        auto fetch_w = [&](u32x4 (&dst)[2][2], int step) {     // step = m * 4 + t
+          const int m = step >> 2, t = step & 3;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) ag_load_attr(ea[t], a.e_attr, tile, t, lane);
+          for (int b = 0; b < 2; ++b) {
+            dst[b][0] = w1[((t * AG_CONV_NCH + 2 * m + b) * 2) * 64 + lane];
+            dst[b][1] = w1[((t * AG_CONV_NCH + 2 * m + b) * 2 + 1) * 64 + lane];
+          }
+        };
+        fetch_w(wq[0], 0);
+        // Software pipeline, fenced per step: the six MFMAs of pair m's step t run beside a quarter of pair
+        // m-1's softplus + operand split (two of its eight values per lane).
+        f32x4 hp0 = {0.f, 0.f, 0.f, 0.f}, hp1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int m = 0; m < AG_CONV_NCH / 2; ++m) {
-          f32x4 h0 = ag_ld4(a.cp.filt_b1 + 32 * m + 4 * q), h1 = ag_ld4(a.cp.filt_b1 + 32 * m + 16 + 4 * q);
-          if (!(AG_ABL(1))) {
+        for (int m = 0; m <= AG_CONV_NCH / 2; ++m) {
+          f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = {0.f, 0.f, 0.f, 0.f};
+          if (m < AG_CONV_NCH / 2) {
+            h0 = ag_ld4(a.cp.filt_b1 + 32 * m + 4 * q);
+            h1 = ag_ld4(a.cp.filt_b1 + 32 * m + 16 + 4 * q);
+          }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              u32x4 wa[2], wb[2];
-              wa[0] = w1[((t * AG_CONV_NCH + 2 * m) * 2) * 64 + lane];
-              wa[1] = w1[((t * AG_CONV_NCH + 2 * m) * 2 + 1) * 64 + lane];
-              wb[0] = w1[((t * AG_CONV_NCH + 2 * m + 1) * 2) * 64 + lane];
-              wb[1] = w1[((t * AG_CONV_NCH + 2 * m + 1) * 2 + 1) * 64 + lane];
-              ag_block_mma<MODE, false>(h0, ea[t], wa);
-              ag_block_mma<MODE, false>(h1, ea[t], wb);
+          for (int t = 0; t < 4; ++t) {
+            const int step = m * 4 + t;
+            if (m < AG_CONV_NCH / 2) {
+              if (step + 1 < 4 * (AG_CONV_NCH / 2)) fetch_w(wq[(step + 1) & 1], step + 1);
+              if (!(AG_ABL(1))) {
+                ag_block_mma<MODE, false>(h0, ea[t], wq[step & 1][0]);
+                ag_block_mma<MODE, false>(h1, ea[t], wq[step & 1][1]);
+              }
             }
+            if (m > 0) {
+              float v0 = (t < 2) ? hp0[2 * t] : hp1[2 * t - 4], v1 = (t < 2) ? hp0[2 * t + 1] : hp1[2 * t - 3];
+              if (!(AG_ABL(2))) { v0 = ag_ssp_base2(v0); v1 = ag_ssp_base2(v1); }
+              asm volatile("" : "+v"(v0), "+v"(v1));      // keep the softplus here (the IR sinks it to its use otherwise)
+              ag_cvt_pair(hidb[m - 1], 2 * t, v0, v1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
           }
-          if (!(AG_ABL(2))) {
+          hp0 = h0; hp1 = h1;
+        }
+        {
+          int64_t nxt = tile + 1;
+          if (tt + 1 >= a.chunk_tiles) nxt = (chunk + cstride) * a.chunk_tiles;
+          if (nxt * AG_TW < E && nxt < a.max_chunks * a.chunk_tiles) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { h0[r] = ag_ssp_base2(h0[r]); h1[r] = ag_ssp_base2(h1[r]); }
+            for (int t = 0; t < 4; ++t) ag_load_attr(ea[t], a.e_attr, nxt, t, lane);
           }
-          ag_cvt(h0, h1, hidb[m]);
         }
       }
       AG_STAMP(c1); st[1] += c1 - c0; c0 = c1;       // layer 1 + ssp + split
