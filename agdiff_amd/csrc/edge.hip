@@ -254,6 +254,8 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
     // running sums (192 channels: entry i = channel 16 i + (lane & 15), replicated over the quarters) of
     // target run_t, whose list is still open
     float carry[AG_CONV_NCH];
+#pragma unroll
+    for (int i = 0; i < AG_CONV_NCH; ++i) carry[i] = 0.0f;
 
     auto dest = [&](int t) -> float* {
       const int lo = a.in_ptr[t];
@@ -285,9 +287,10 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
 #pragma unroll
           for (int i = 0; i < AG_CONV_NCH; ++i) dp[16 * i + col] = carry[i];
         }
+#pragma unroll
+        for (int i = 0; i < AG_CONV_NCH; ++i) carry[i] = 0.0f;
         run_t = -1;
       }
-      const bool cont = (run_t == t0);
       AG_STAMP(c1); st[0] += c1 - c0; c0 = c1;       // meta loads, carry flush
 
       AgIn<MODE> hidb[6];
@@ -391,26 +394,27 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
         }
       }
       float* const dp0 = dest_lo(t0, bound(0));
-      auto reduce_tile = [&](f32x4 z, int nt, float& cr) {
-        if (AG_ABL(16)) { cr = z[0]; return; }
-        if (ntg <= 2 && !(AG_ABL(32))) {
-          float p0 = z[0] * m0[0], p1 = z[0] * m1[0];
+      const bool fast = ntg <= 2 && !(AG_ABL(32));
+      const bool two = ntg == 2;
+      // Fast reduction (one or two targets in the tile), free of branches so that it can be issued in the shadow
+      // of the next channel tile's MFMAs: both masked sums are always formed; the first target's running sum is
+      // always stored (all lanes, the quarters hold the same value -- when its list goes on, a later tile or the
+      // flush repeats the store with the final value); the open list's sum stays in `cr`.  carry[] is zero
+      // whenever no list is open, so adding it needs no condition.
+      auto reduce_fast = [&](f32x4 z, int nt, float& cr) {
+        float p0 = z[0] * m0[0], p1 = z[0] * m1[0];
 #pragma unroll
-          for (int r = 1; r < 4; ++r) {
-            p0 = fmaf(z[r], m0[r], p0);
-            p1 = fmaf(z[r], m1[r], p1);
-          }
-          p0 = ag_quarter_sum(p0);
-          if (cont) p0 = cr + p0;
-          if (ntg == 2) {
-            p1 = ag_quarter_sum(p1);
-            if (lane < 16) dp0[16 * nt + col] = p0;
-            cr = p1;
-          } else {
-            cr = p0;
-          }
-          return;
+        for (int r = 1; r < 4; ++r) {
+          p0 = fmaf(z[r], m0[r], p0);
+          p1 = fmaf(z[r], m1[r], p1);
         }
+        p0 = cr + ag_quarter_sum(p0);
+        p1 = ag_quarter_sum(p1);
+        dp0[16 * nt + col] = p0;
+        cr = two ? p1 : p0;
+      };
+      // General reduction (three or more targets in the tile): one masked sum per target.
+      auto reduce_general = [&](f32x4 z, int nt, float& cr) {
         float newcarry = 0.0f;
         for (int i = 0; i < ntg; ++i) {
           const int lo = bound(i), hi = bound(i + 1);
@@ -421,7 +425,7 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
             p += ((er >= lo) && (er < hi)) ? z[r] : 0.0f;
           }
           p = ag_quarter_sum(p);
-          if (i == 0 && cont) p = cr + p;
+          if (i == 0) p = cr + p;
           if (i < ntg - 1) {
             float* dp = dest_lo(t0 + i, lo);
             if (lane < 16) dp[16 * nt + col] = p;
@@ -444,14 +448,10 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
       };
       fetch_x(0);
       AG_STAMP(c1); st[3] += c1 - c0; c0 = c1;       // gather offsets, bounds
-#pragma unroll
-      for (int nt = 0; nt < AG_CONV_NCH; ++nt) {
+      // second-layer MFMAs of channel tile nt (flipped: rows = edges, lanes = channels), raw accumulators
+      auto dense2 = [&](int nt) -> f32x4 {
         f32x4 z[1] = {{0.f, 0.f, 0.f, 0.f}};
         if (nt == 7) fetch_g(0);
-        if (nt == 8) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) sr[r] = __shfl(s2, 4 * q + r);
-        }
         if (!(AG_ABL(4))) {
           if (nt < 8) {
             ag_dense_lds<MODE, true, false, 4, 1, 0, 0>(hidb, z, w2a + (nt * 4) * 128, lane);
@@ -461,14 +461,50 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
             if (nt + 1 < AG_CONV_NCH) fetch_g(nt + 1 - 8);
           }
         }
-        const float bb = a.cp.filt_b2[16 * nt + col];
-        const f32x4 m = sr * xg;
+        return z[0];
+      };
+      // message factors of channel tile nt: bias (per channel = per lane) and scale . x[src] per edge row
+      auto factors = [&](int nt, float& bb, f32x4& m) {
+        if (nt == 8) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) z[0][r] = (z[0][r] + bb) * m[r];
+          for (int r = 0; r < 4; ++r) sr[r] = __shfl(s2, 4 * q + r);
+        }
+        bb = a.cp.filt_b2[16 * nt + col];
+        m = sr * xg;
         if (nt + 1 < AG_CONV_NCH) fetch_x(nt + 1);
-        AG_STAMP(c1); st[4] += c1 - c0; c0 = c1;     // layer 2 + message
-        reduce_tile(z[0], nt, carry[nt]);
-        AG_STAMP(c1); st[5] += c1 - c0; c0 = c1;     // reduction
+      };
+      if (fast) {
+        // software pipeline, fenced per channel tile: the MFMAs of tile nt beside message + reduction of tile nt-1
+        f32x4 zp = {0.f, 0.f, 0.f, 0.f}, mp = {0.f, 0.f, 0.f, 0.f};
+        float bp = 0.0f;
+#pragma unroll
+        for (int nt = 0; nt <= AG_CONV_NCH; ++nt) {
+          f32x4 z = {0.f, 0.f, 0.f, 0.f}, m = {0.f, 0.f, 0.f, 0.f};
+          float bb = 0.0f;
+          if (nt < AG_CONV_NCH) {
+            z = dense2(nt);
+            factors(nt, bb, m);
+          }
+          if (nt > 0) {
+            f32x4 t;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r] = (zp[r] + bp) * mp[r];
+            if (AG_ABL(16)) carry[nt - 1] = t[0];
+            else reduce_fast(t, nt - 1, carry[nt - 1]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          zp = z; mp = m; bp = bb;
+        }
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < AG_CONV_NCH; ++nt) {
+          f32x4 z = dense2(nt), m;
+          float bb;
+          factors(nt, bb, m);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) z[r] = (z[r] + bb) * m[r];
+          reduce_general(z, nt, carry[nt]);
+        }
       }
       run_t = t1;
     }
