@@ -92,6 +92,20 @@ __device__ __forceinline__ float ag_quarter_sum(float v) {
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// Reduce-scatter of four values over the quarters: returns, in the lanes of quarter j, the sum of v[j] over the
+// four quarters (same lane & 15); three lane-swap instructions for four values instead of two per value.
+// v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of the second,
+// v_permlane32_swap the upper half of the first with the lower half of the second.  Association per value:
+// (q0 + q1) + (q2 + q3), as ag_quarter_sum.
+__device__ __forceinline__ float ag_quarter_reduce_scatter4(float v0, float v1, float v2, float v3) {
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v2), __float_as_uint(v3), false, false);
+  const float s01 = __uint_as_float(a[0]) + __uint_as_float(a[1]);   // rows: v0(q0+q1) v1(q0+q1) v0(q2+q3) v1(q2+q3)
+  const float s23 = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+  const auto c = __builtin_amdgcn_permlane32_swap(__float_as_uint(s01), __float_as_uint(s23), false, false);
+  return __uint_as_float(c[0]) + __uint_as_float(c[1]);              // rows: v0 v1 v2 v3
+}
+
 // ---------------------------------------------------------------------------------- fp32 tiles
 // Fill std-orientation tiles from a natural-order vector (bias init): y[T][r] = v[16T + 4q + r].
 template <int NT, int NY>

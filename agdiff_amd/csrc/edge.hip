@@ -251,11 +251,11 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
     const int64_t e_begin = chunk * (AG_TW * a.chunk_tiles);
     if (e_begin >= E) break;
     int run_t = -1;
-    // running sums (192 channels: entry i = channel 16 i + (lane & 15), replicated over the quarters) of
-    // target run_t, whose list is still open
-    float carry[AG_CONV_NCH];
+    // running sums of target run_t, whose list is still open: 192 channels spread over the wave, entry g of
+    // lane (col, q) = channel 16 (4 g + q) + col; zero while no list is open
+    float carry[AG_CONV_NCH / 4];
 #pragma unroll
-    for (int i = 0; i < AG_CONV_NCH; ++i) carry[i] = 0.0f;
+    for (int i = 0; i < AG_CONV_NCH / 4; ++i) carry[i] = 0.0f;
 
     auto dest = [&](int t) -> float* {
       const int lo = a.in_ptr[t];
@@ -283,12 +283,11 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
       const int t1 = __builtin_amdgcn_readfirstlane(a.e_dst[last]);
       if (run_t >= 0 && run_t != t0) {   // previous tile ended exactly on a list boundary
         float* dp = dest(run_t);
-        if (lane < 16) {
 #pragma unroll
-          for (int i = 0; i < AG_CONV_NCH; ++i) dp[16 * i + col] = carry[i];
+        for (int i = 0; i < AG_CONV_NCH / 4; ++i) {
+          dp[16 * (4 * i + q) + col] = carry[i];
+          carry[i] = 0.0f;
         }
-#pragma unroll
-        for (int i = 0; i < AG_CONV_NCH; ++i) carry[i] = 0.0f;
         run_t = -1;
       }
       AG_STAMP(c1); st[0] += c1 - c0; c0 = c1;       // meta loads, carry flush
@@ -398,23 +397,28 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
       const bool two = ntg == 2;
       // Fast reduction (one or two targets in the tile), free of branches so that it can be issued in the shadow
       // of the next channel tile's MFMAs: both masked sums are always formed; the first target's running sum is
-      // always stored (all lanes, the quarters hold the same value -- when its list goes on, a later tile or the
-      // flush repeats the store with the final value); the open list's sum stays in `cr`.  carry[] is zero
-      // whenever no list is open, so adding it needs no condition.
-      auto reduce_fast = [&](f32x4 z, int nt, float& cr) {
-        float p0 = z[0] * m0[0], p1 = z[0] * m1[0];
+      // always stored (when its list goes on, a later tile or the flush repeats the store with the final value);
+      // the open list's sum stays in carry[].  carry[] is zero whenever no list is open, so adding it needs no
+      // condition.  The sums over the four quarters are taken four channel tiles at a time (reduce-scatter).
+      auto partial_fast = [&](f32x4 z, float& p0, float& p1) {     // this lane's four edge rows, per target
+        p0 = z[0] * m0[0]; p1 = z[0] * m1[0];
 #pragma unroll
         for (int r = 1; r < 4; ++r) {
           p0 = fmaf(z[r], m0[r], p0);
           p1 = fmaf(z[r], m1[r], p1);
         }
-        p0 = cr + ag_quarter_sum(p0);
-        p1 = ag_quarter_sum(p1);
-        dp0[16 * nt + col] = p0;
-        cr = two ? p1 : p0;
       };
-      // General reduction (three or more targets in the tile): one masked sum per target.
+      // four channel tiles 4 g4 .. 4 g4 + 3 at once: quarter q ends up with the sums of tile 4 g4 + q
+      auto finish_fast = [&](const float (&p0)[4], const float (&p1)[4], int g4) {
+        const float r0 = carry[g4] + ag_quarter_reduce_scatter4(p0[0], p0[1], p0[2], p0[3]);
+        const float r1 = ag_quarter_reduce_scatter4(p1[0], p1[1], p1[2], p1[3]);
+        dp0[16 * (4 * g4 + q) + col] = r0;
+        carry[g4] = two ? r1 : r0;
+      };
+      // General reduction (three or more targets in the tile): one masked sum per target, replicated over the
+      // quarters; quarter nt & 3 keeps / stores it (the fast path's distribution).
       auto reduce_general = [&](f32x4 z, int nt, float& cr) {
+        const bool mine = q == (nt & 3);
         float newcarry = 0.0f;
         for (int i = 0; i < ntg; ++i) {
           const int lo = bound(i), hi = bound(i + 1);
@@ -428,12 +432,12 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
           if (i == 0) p = cr + p;
           if (i < ntg - 1) {
             float* dp = dest_lo(t0 + i, lo);
-            if (lane < 16) dp[16 * nt + col] = p;
+            if (mine) dp[16 * nt + col] = p;
           } else {
             newcarry = p;
           }
         }
-        cr = newcarry;
+        cr = mine ? newcarry : cr;
       };
       // conv2's second-layer blocks (pk [4][2]: one pair per channel tile) stream from L2; the pair of the
       // next channel tile is requested right after the current pair's MFMAs
@@ -477,6 +481,7 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
         // software pipeline, fenced per channel tile: the MFMAs of tile nt beside message + reduction of tile nt-1
         f32x4 zp = {0.f, 0.f, 0.f, 0.f}, mp = {0.f, 0.f, 0.f, 0.f};
         float bp = 0.0f;
+        float p0[4], p1[4];
 #pragma unroll
         for (int nt = 0; nt <= AG_CONV_NCH; ++nt) {
           f32x4 z = {0.f, 0.f, 0.f, 0.f}, m = {0.f, 0.f, 0.f, 0.f};
@@ -489,8 +494,9 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
             f32x4 t;
 #pragma unroll
             for (int r = 0; r < 4; ++r) t[r] = (zp[r] + bp) * mp[r];
-            if (AG_ABL(16)) carry[nt - 1] = t[0];
-            else reduce_fast(t, nt - 1, carry[nt - 1]);
+            if (AG_ABL(16)) { p0[(nt - 1) & 3] = t[0]; p1[(nt - 1) & 3] = 0.0f; }
+            else partial_fast(t, p0[(nt - 1) & 3], p1[(nt - 1) & 3]);
+            if (((nt - 1) & 3) == 3) finish_fast(p0, p1, (nt - 1) >> 2);
           }
           __builtin_amdgcn_sched_barrier(0);
           zp = z; mp = m; bp = bb;
@@ -503,17 +509,15 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
           factors(nt, bb, m);
 #pragma unroll
           for (int r = 0; r < 4; ++r) z[r] = (z[r] + bb) * m[r];
-          reduce_general(z, nt, carry[nt]);
+          reduce_general(z, nt, carry[nt >> 2]);
         }
       }
       run_t = t1;
     }
     if (run_t >= 0) {
       float* dp = dest(run_t);
-      if (lane0 < 16) {
 #pragma unroll
-        for (int i = 0; i < AG_CONV_NCH; ++i) dp[16 * i + lane0] = carry[i];
-      }
+      for (int i = 0; i < AG_CONV_NCH / 4; ++i) dp[16 * (4 * i + (lane0 >> 4)) + (lane0 & 15)] = carry[i];
     }
   }  // chunk loop
 #ifdef AG_CONV_STAMPS
