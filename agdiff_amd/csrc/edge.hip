@@ -400,12 +400,13 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
       // always stored (when its list goes on, a later tile or the flush repeats the store with the final value);
       // the open list's sum stays in carry[].  carry[] is zero whenever no list is open, so adding it needs no
       // condition.  The sums over the four quarters are taken four channel tiles at a time (reduce-scatter).
-      auto partial_fast = [&](f32x4 z, float& p0, float& p1) {     // this lane's four edge rows, per target
-        p0 = z[0] * m0[0]; p1 = z[0] * m1[0];
+      // this lane's four edge rows, per target; w0 / w1 = row masks times the conv's per-edge scale
+      auto partial_fast = [&](f32x4 z, const f32x4& w0, const f32x4& w1, float& p0, float& p1) {
+        p0 = z[0] * w0[0]; p1 = z[0] * w1[0];
 #pragma unroll
         for (int r = 1; r < 4; ++r) {
-          p0 = fmaf(z[r], m0[r], p0);
-          p1 = fmaf(z[r], m1[r], p1);
+          p0 = fmaf(z[r], w0[r], p0);
+          p1 = fmaf(z[r], w1[r], p1);
         }
       };
       // four channel tiles 4 g4 .. 4 g4 + 3 at once: quarter q ends up with the sums of tile 4 g4 + q
@@ -468,13 +469,15 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
         return z[0];
       };
       // message factors of channel tile nt: bias (per channel = per lane) and scale . x[src] per edge row
-      auto factors = [&](int nt, float& bb, f32x4& m) {
+      // message factors of channel tile nt: bias (per channel = per lane) and x[src] per edge row (times the
+      // conv's per-edge scale unless the caller folds that into its row masks)
+      auto factors = [&](int nt, float& bb, f32x4& m, bool with_scale) {
         if (nt == 8) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) sr[r] = __shfl(s2, 4 * q + r);
         }
         bb = a.cp.filt_b2[16 * nt + col];
-        m = sr * xg;
+        m = with_scale ? sr * xg : xg;
         if (nt + 1 < AG_CONV_NCH) fetch_x(nt + 1);
       };
       if (fast) {
@@ -482,20 +485,22 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
         f32x4 zp = {0.f, 0.f, 0.f, 0.f}, mp = {0.f, 0.f, 0.f, 0.f};
         float bp = 0.0f;
         float p0[4], p1[4];
+        f32x4 w0 = m0 * sr, w1 = m1 * sr;          // conv1's scale folded into the row masks
 #pragma unroll
         for (int nt = 0; nt <= AG_CONV_NCH; ++nt) {
           f32x4 z = {0.f, 0.f, 0.f, 0.f}, m = {0.f, 0.f, 0.f, 0.f};
           float bb = 0.0f;
           if (nt < AG_CONV_NCH) {
             z = dense2(nt);
-            factors(nt, bb, m);
+            factors(nt, bb, m, false);
           }
+          if (nt == 9) { w0 = m0 * sr; w1 = m1 * sr; }   // tile 8 (reduced in this step) starts conv2: sr is its scale now
           if (nt > 0) {
             f32x4 t;
 #pragma unroll
             for (int r = 0; r < 4; ++r) t[r] = (zp[r] + bp) * mp[r];
             if (AG_ABL(16)) { p0[(nt - 1) & 3] = t[0]; p1[(nt - 1) & 3] = 0.0f; }
-            else partial_fast(t, p0[(nt - 1) & 3], p1[(nt - 1) & 3]);
+            else partial_fast(t, w0, w1, p0[(nt - 1) & 3], p1[(nt - 1) & 3]);
             if (((nt - 1) & 3) == 3) finish_fast(p0, p1, (nt - 1) >> 2);
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -506,7 +511,7 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
         for (int nt = 0; nt < AG_CONV_NCH; ++nt) {
           f32x4 z = dense2(nt), m;
           float bb;
-          factors(nt, bb, m);
+          factors(nt, bb, m, true);
 #pragma unroll
           for (int r = 0; r < 4; ++r) z[r] = (z[r] + bb) * m[r];
           reduce_general(z, nt, carry[nt >> 2]);
