@@ -4,6 +4,7 @@
 // (common.hpp).  Every MFMA kernel is instantiated for both arithmetic modes (AG_F32 / AG_BF3).
 #include "common.hpp"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -400,22 +401,6 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
       // always stored (when its list goes on, a later tile or the flush repeats the store with the final value);
       // the open list's sum stays in carry[].  carry[] is zero whenever no list is open, so adding it needs no
       // condition.  The sums over the four quarters are taken four channel tiles at a time (reduce-scatter).
-      // this lane's four edge rows, per target; w0 / w1 = row masks times the conv's per-edge scale
-      auto partial_fast = [&](f32x4 z, const f32x4& w0, const f32x4& w1, float& p0, float& p1) {
-        p0 = z[0] * w0[0]; p1 = z[0] * w1[0];
-#pragma unroll
-        for (int r = 1; r < 4; ++r) {
-          p0 = fmaf(z[r], w0[r], p0);
-          p1 = fmaf(z[r], w1[r], p1);
-        }
-      };
-      // four channel tiles 4 g4 .. 4 g4 + 3 at once: quarter q ends up with the sums of tile 4 g4 + q
-      auto finish_fast = [&](const float (&p0)[4], const float (&p1)[4], int g4) {
-        const float r0 = carry[g4] + ag_quarter_reduce_scatter4(p0[0], p0[1], p0[2], p0[3]);
-        const float r1 = ag_quarter_reduce_scatter4(p1[0], p1[1], p1[2], p1[3]);
-        dp0[16 * (4 * g4 + q) + col] = r0;
-        carry[g4] = two ? r1 : r0;
-      };
       // General reduction (three or more targets in the tile): one masked sum per target, replicated over the
       // quarters; quarter nt & 3 keeps / stores it (the fast path's distribution).
       auto reduce_general = [&](f32x4 z, int nt, float& cr) {
@@ -480,11 +465,14 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
         m = with_scale ? sr * xg : xg;
         if (nt + 1 < AG_CONV_NCH) fetch_x(nt + 1);
       };
-      if (fast) {
-        // software pipeline, fenced per channel tile: the MFMAs of tile nt beside message + reduction of tile nt-1
+      // software pipeline, fenced per channel tile: the MFMAs of tile nt beside message + reduction of tile nt-1.
+      // TWO = the tile holds two targets; with one, the second masked sum, its quarter sums and the store are
+      // not needed at all (the sum stays in carry[] until the list ends).
+      auto run_fast = [&](auto TWO) {
+        constexpr bool kTwo = decltype(TWO)::value;
         f32x4 zp = {0.f, 0.f, 0.f, 0.f}, mp = {0.f, 0.f, 0.f, 0.f};
         float bp = 0.0f;
-        float p0[4], p1[4];
+        float p0[4], p1[4] = {0.f, 0.f, 0.f, 0.f};
         f32x4 w0 = m0 * sr, w1 = m1 * sr;          // conv1's scale folded into the row masks
 #pragma unroll
         for (int nt = 0; nt <= AG_CONV_NCH; ++nt) {
@@ -496,16 +484,39 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
           }
           if (nt == 9) { w0 = m0 * sr; w1 = m1 * sr; }   // tile 8 (reduced in this step) starts conv2: sr is its scale now
           if (nt > 0) {
+            const int j = (nt - 1) & 3, g4 = (nt - 1) >> 2;
             f32x4 t;
 #pragma unroll
             for (int r = 0; r < 4; ++r) t[r] = (zp[r] + bp) * mp[r];
-            if (AG_ABL(16)) { p0[(nt - 1) & 3] = t[0]; p1[(nt - 1) & 3] = 0.0f; }
-            else partial_fast(t, w0, w1, p0[(nt - 1) & 3], p1[(nt - 1) & 3]);
-            if (((nt - 1) & 3) == 3) finish_fast(p0, p1, (nt - 1) >> 2);
+            if (AG_ABL(16)) {
+              p0[j] = t[0];
+            } else {
+              p0[j] = t[0] * w0[0];
+#pragma unroll
+              for (int r = 1; r < 4; ++r) p0[j] = fmaf(t[r], w0[r], p0[j]);
+              if constexpr (kTwo) {
+                p1[j] = t[0] * w1[0];
+#pragma unroll
+                for (int r = 1; r < 4; ++r) p1[j] = fmaf(t[r], w1[r], p1[j]);
+              }
+            }
+            if (j == 3) {      // quarter q ends up with the sums of channel tile 4 g4 + q
+              const float r0 = carry[g4] + ag_quarter_reduce_scatter4(p0[0], p0[1], p0[2], p0[3]);
+              if constexpr (kTwo) {
+                dp0[16 * (4 * g4 + q) + col] = r0;
+                carry[g4] = ag_quarter_reduce_scatter4(p1[0], p1[1], p1[2], p1[3]);
+              } else {
+                carry[g4] = r0;
+              }
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
           zp = z; mp = m; bp = bb;
         }
+      };
+      if (fast) {
+        if (two) run_fast(std::true_type{});
+        else run_fast(std::false_type{});
       } else {
 #pragma unroll
         for (int nt = 0; nt < AG_CONV_NCH; ++nt) {
