@@ -295,6 +295,7 @@ struct UpdateArgs {
   const float* e_len;
   const float* e_inv;
   int32_t* nan_flag;
+  int32_t parts;         // lanes per atom (power of two, 1..16)
 };
 
 __device__ __forceinline__ void clip3(float& x, float& y, float& z, float limit) {  // dualenc.py:586-589
@@ -307,7 +308,8 @@ __device__ __forceinline__ void clip3(float& x, float& y, float& z, float limit)
 
 // One workgroup per molecule: eq_transform of the local and (optionally) global edge scores
 // (geometry.py:9-17), clip_norm, the Langevin move (dualenc.py:526-538), NaN flag, center_pos,
-// clamp, trajectory copy (dualenc.py:539-545).
+// clamp, trajectory copy (dualenc.py:539-545).  P = a.parts lanes share one atom's edge lists (strided) and
+// combine their partial forces with xor-shuffles (P is a power of two <= 16, so the lanes of an atom sit in one wave).
 __global__ void __launch_bounds__(256) k_langevin_update(UpdateArgs a) {
   const int g = blockIdx.x;
   const int g0 = a.graph_ptr[g], n = a.graph_ptr[g + 1] - g0;
@@ -315,59 +317,69 @@ __global__ void __launch_bounds__(256) k_langevin_update(UpdateArgs a) {
   __shared__ int nanw[4];
   float sx = 0.f, sy = 0.f, sz = 0.f;
   int bad = 0;
-  // pass 1: new (uncentred) positions into pos_out, per-thread partial sums for the centroid
-  for (int li = threadIdx.x; li < n; li += blockDim.x) {
-    const int i = g0 + li;
+  const int P = a.parts, part = threadIdx.x & (P - 1);
+  const int per_pass = blockDim.x / P;
+  // pass 1: new (uncentred) positions into scratch, per-thread partial sums for the centroid
+  for (int base = 0; base < n; base += per_pass) {
+    const int li = base + (int)(threadIdx.x / P);
+    const bool on = li < n;
+    const int i = g0 + (on ? li : 0);
     const float px = a.s.pos_in[3 * i], py = a.s.pos_in[3 * i + 1], pz = a.s.pos_in[3 * i + 2];
-    float ox = 0.f, oy = 0.f, oz = 0.f, ix = 0.f, iy = 0.f, iz = 0.f;
-    for (int e = a.loc_out_ptr[i]; e < a.loc_out_ptr[i + 1]; ++e) {   // row == i: + dd_dr * score
-      const int j = a.loc_dst[e];
-      const float w = (1.0f / a.l_len[e]), sc = a.l_inv[e];
-      ox += (w * (px - a.s.pos_in[3 * j])) * sc;
-      oy += (w * (py - a.s.pos_in[3 * j + 1])) * sc;
-      oz += (w * (pz - a.s.pos_in[3 * j + 2])) * sc;
+    float lx = 0.f, ly = 0.f, lz = 0.f;
+    if (on) {
+      for (int e = a.loc_out_ptr[i] + part; e < a.loc_out_ptr[i + 1]; e += P) {   // row == i: + dd_dr * score
+        const int j = a.loc_dst[e];
+        const float w = (1.0f / a.l_len[e]), sc = a.l_inv[e];
+        lx += (w * (px - a.s.pos_in[3 * j])) * sc;
+        ly += (w * (py - a.s.pos_in[3 * j + 1])) * sc;
+        lz += (w * (pz - a.s.pos_in[3 * j + 2])) * sc;
+      }
+      for (int k = a.loc_in_ptr[i] + part; k < a.loc_in_ptr[i + 1]; k += P) {     // col == i: - dd_dr * score
+        const int e = a.loc_in_eid[k];
+        const int j = a.loc_src[e];
+        const float w = (1.0f / a.l_len[e]), sc = a.l_inv[e];
+        lx -= (w * (a.s.pos_in[3 * j] - px)) * sc;
+        ly -= (w * (a.s.pos_in[3 * j + 1] - py)) * sc;
+        lz -= (w * (a.s.pos_in[3 * j + 2] - pz)) * sc;
+      }
     }
-    for (int k = a.loc_in_ptr[i]; k < a.loc_in_ptr[i + 1]; ++k) {     // col == i: - dd_dr * score
-      const int e = a.loc_in_eid[k];
-      const int j = a.loc_src[e];
-      const float w = (1.0f / a.l_len[e]), sc = a.l_inv[e];
-      ix -= (w * (a.s.pos_in[3 * j] - px)) * sc;
-      iy -= (w * (a.s.pos_in[3 * j + 1] - py)) * sc;
-      iz -= (w * (a.s.pos_in[3 * j + 2] - pz)) * sc;
-    }
-    float lx = ox + ix, ly = oy + iy, lz = oz + iz;
+    for (int o = P >> 1; o > 0; o >>= 1) { lx += __shfl_xor(lx, o); ly += __shfl_xor(ly, o); lz += __shfl_xor(lz, o); }
     if (a.s.clip_local >= 0.0f) clip3(lx, ly, lz, a.s.clip_local);
     float gx = 0.f, gy = 0.f, gz = 0.f;
     if (a.s.use_global) {
-      ox = oy = oz = ix = iy = iz = 0.f;
-      for (int q = a.out_ptr[i]; q < a.out_ptr[i + 1]; ++q) {
-        const int e = a.ref2dst[q];
-        if (a.e_type[e] != 0) continue;          // edge_inv_global * (1 - local_edge_mask), dualenc.py:516-518
-        const int j = a.e_dst[e];
-        const float w = (1.0f / a.e_len[e]), sc = a.e_inv[e];
-        ox += (w * (px - a.s.pos_in[3 * j])) * sc;
-        oy += (w * (py - a.s.pos_in[3 * j + 1])) * sc;
-        oz += (w * (pz - a.s.pos_in[3 * j + 2])) * sc;
+      if (on) {
+        for (int q = a.out_ptr[i] + part; q < a.out_ptr[i + 1]; q += P) {
+          const int e = a.ref2dst[q];
+          if (a.e_type[e] != 0) continue;          // edge_inv_global * (1 - local_edge_mask), dualenc.py:516-518
+          const int j = a.e_dst[e];
+          const float w = (1.0f / a.e_len[e]), sc = a.e_inv[e];
+          gx += (w * (px - a.s.pos_in[3 * j])) * sc;
+          gy += (w * (py - a.s.pos_in[3 * j + 1])) * sc;
+          gz += (w * (pz - a.s.pos_in[3 * j + 2])) * sc;
+        }
+        for (int e = a.in_ptr[i] + part; e < a.in_ptr[i + 1]; e += P) {
+          if (a.e_type[e] != 0) continue;
+          const int j = a.e_src[e];
+          const float w = (1.0f / a.e_len[e]), sc = a.e_inv[e];
+          gx -= (w * (a.s.pos_in[3 * j] - px)) * sc;
+          gy -= (w * (a.s.pos_in[3 * j + 1] - py)) * sc;
+          gz -= (w * (a.s.pos_in[3 * j + 2] - pz)) * sc;
+        }
       }
-      for (int e = a.in_ptr[i]; e < a.in_ptr[i + 1]; ++e) {
-        if (a.e_type[e] != 0) continue;
-        const int j = a.e_src[e];
-        const float w = (1.0f / a.e_len[e]), sc = a.e_inv[e];
-        ix -= (w * (a.s.pos_in[3 * j] - px)) * sc;
-        iy -= (w * (a.s.pos_in[3 * j + 1] - py)) * sc;
-        iz -= (w * (a.s.pos_in[3 * j + 2] - pz)) * sc;
-      }
-      gx = ox + ix; gy = oy + iy; gz = oz + iz;
+      for (int o = P >> 1; o > 0; o >>= 1) { gx += __shfl_xor(gx, o); gy += __shfl_xor(gy, o); gz += __shfl_xor(gz, o); }
       clip3(gx, gy, gz, a.s.clip);
     }
-    const float ex = lx + gx * a.s.w_global, ey = ly + gy * a.s.w_global, ez = lz + gz * a.s.w_global;
-    const float nx = (px + (a.s.step_size * ex) / a.s.sigma) + a.s.noise[3 * i] * a.s.noise_scale;
-    const float ny = (py + (a.s.step_size * ey) / a.s.sigma) + a.s.noise[3 * i + 1] * a.s.noise_scale;
-    const float nz = (pz + (a.s.step_size * ez) / a.s.sigma) + a.s.noise[3 * i + 2] * a.s.noise_scale;
-    bad |= (nx != nx) | (ny != ny) | (nz != nz);
-    sx += nx; sy += ny; sz += nz;
-    a.s.scratch[3 * i] = nx; a.s.scratch[3 * i + 1] = ny; a.s.scratch[3 * i + 2] = nz;
+    if (on && part == 0) {
+      const float ex = lx + gx * a.s.w_global, ey = ly + gy * a.s.w_global, ez = lz + gz * a.s.w_global;
+      const float nx = (px + (a.s.step_size * ex) / a.s.sigma) + a.s.noise[3 * i] * a.s.noise_scale;
+      const float ny = (py + (a.s.step_size * ey) / a.s.sigma) + a.s.noise[3 * i + 1] * a.s.noise_scale;
+      const float nz = (pz + (a.s.step_size * ez) / a.s.sigma) + a.s.noise[3 * i + 2] * a.s.noise_scale;
+      bad |= (nx != nx) | (ny != ny) | (nz != nz);
+      sx += nx; sy += ny; sz += nz;
+      a.s.scratch[3 * i] = nx; a.s.scratch[3 * i + 1] = ny; a.s.scratch[3 * i + 2] = nz;
+    }
   }
+  __syncthreads();     // scratch[] of this molecule is complete (pass 2 reads other threads' rows)
   // centroid
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -654,10 +666,11 @@ extern "C" int agdiff_langevin_update(const agdiff_topo_t* topo, const agdiff_ws
   a.e_len = ws->e_len;
   a.e_inv = ws->e_inv_global;
   a.nan_flag = ws->nan_flag;
-  int bd = (int)(((topo->max_atoms_per_graph + 63) / 64) * 64);
-  if (bd > 256) bd = 256;
-  if (bd < 64) bd = 64;
-  k_langevin_update<<<dim3((unsigned)topo->num_graphs), dim3(bd), 0, (hipStream_t)stream>>>(a);
+  // lanes per atom: as many as a 256-thread workgroup offers for the largest molecule of the batch, at most 16
+  int parts = 16;
+  while (parts > 1 && (int64_t)parts * topo->max_atoms_per_graph > 256) parts >>= 1;
+  a.parts = parts;
+  k_langevin_update<<<dim3((unsigned)topo->num_graphs), dim3(256), 0, (hipStream_t)stream>>>(a);
   AG_CHECK_LAUNCH();
   return AGDIFF_OK;
 }
