@@ -40,92 +40,91 @@ __device__ __forceinline__ float dist2_nofma(float ax, float ay, float az, float
   return s;
 }
 
-// Enumerate the merged in-list of target i (graph-local index) in ascending source order and call
-// emit(k, j, type, d2) for the k-th in-edge j -> i.  Returns the in-degree.
-template <class Emit>
-__device__ __forceinline__ int enumerate_in_edges(const GraphArgs& a, const float* spos, int n, int g0, int i, Emit emit) {
-  const float xi = spos[3 * i], yi = spos[3 * i + 1], zi = spos[3 * i + 2];
-  int lk = a.loc_in_ptr[g0 + i];
-  const int lend = a.loc_in_ptr[g0 + i + 1];
-  int lsrc = (lk < lend) ? a.loc_src[a.loc_in_eid[lk]] - g0 : n;
-  int cnt_r = 0, k = 0;
-  for (int j = 0; j < n; ++j) {
-    float d2 = dist2_nofma(xi, yi, zi, spos[3 * j], spos[3 * j + 1], spos[3 * j + 2]);
-    bool within = false;
-    if (cnt_r < AGDIFF_RADIUS_CAP && d2 < a.r2) {  // first 33 in-radius candidates, self included
-      within = true;
-      ++cnt_r;
-    }
-    const bool rad = within && (j != i);
-    const bool loc = (j == lsrc);
-    if (rad || loc) {
-      int ty = 0;
-      if (loc) ty = a.loc_type[a.loc_in_eid[lk]];
-      emit(k, j, ty, d2);
-      ++k;
-    }
-    if (loc) {
-      ++lk;
-      lsrc = (lk < lend) ? a.loc_src[a.loc_in_eid[lk]] - g0 : n;
-    }
-  }
-  return k;
-}
-
 extern __shared__ uint32_t ag_graph_smem[];
 
+// One workgroup per molecule, one WAVE per target atom at a time: the 64 lanes test 64 candidate sources at once,
+// wave ballots replace the serial scan of the reference rule --
+//   radius_graph: source j is kept for target i if d2(i, j) < r^2 and fewer than 33 such candidates (self
+//   included) precede it in ascending j; self is then dropped; bond / 2-hop / 3-hop edges are always present
+// -- and the position of an edge inside the target's list is the population count of the kept mask below its
+// lane, so all per-edge stores are contiguous.  The in-adjacency masks stay in LDS (row i, bit j <=> edge j -> i);
+// out-degrees and the (src, dst)-order permutation ref2dst come from their columns.
 template <bool FILL>
-__global__ void __launch_bounds__(512) k_graph(GraphArgs a) {
+__global__ void __launch_bounds__(256) k_graph(GraphArgs a) {
   const int g = blockIdx.x;
   const int g0 = a.graph_ptr[g];
   const int n = a.graph_ptr[g + 1] - g0;
-  const int words = a.words;
-  // LDS carve: pos[3n] | indeg[n] | outdeg[n] | bits[n][words]
+  const int words = a.words;          // 32-bit words per mask row, even (whole 64-lane chunks)
   const int nmax = words * 32;
+  // LDS carve: pos[3 nmax] | indeg[nmax] | outdeg[nmax] | inbits[nmax][words] | locbits[nmax][words]
   float* spos = reinterpret_cast<float*>(ag_graph_smem);
   int* sin = reinterpret_cast<int*>(ag_graph_smem + 3 * nmax);
   int* sout = sin + nmax;
-  uint32_t* bits = reinterpret_cast<uint32_t*>(sout + nmax);
+  uint32_t* inbits = reinterpret_cast<uint32_t*>(sout + nmax);
+  uint32_t* locbits = inbits + nmax * words;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));     // lanes below mine
 
   for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) spos[i] = a.pos[3 * (size_t)g0 + i];
-  for (int i = threadIdx.x; i < n * words; i += blockDim.x) bits[i] = 0u;
+  // static local in-adjacency of the molecule: the thread that owns target i sets its row
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    for (int w = 0; w < words; ++w) locbits[i * words + w] = 0u;
+    for (int k = a.loc_in_ptr[g0 + i]; k < a.loc_in_ptr[g0 + i + 1]; ++k) {
+      const int j = a.loc_src[a.loc_in_eid[k]] - g0;
+      locbits[i * words + (j >> 5)] |= 1u << (j & 31);
+    }
+  }
   __syncthreads();
 
-  // pass 1: in-degree and out-adjacency bits (bit i of row j <=> edge j -> i exists)
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    int deg = enumerate_in_edges(a, spos, n, g0, i, [&](int, int j, int, float) {
-      atomicOr(&bits[j * words + (i >> 5)], 1u << (i & 31));
-    });
-    sin[i] = deg;
+  // pass 1: kept masks and in-degrees
+  int wave_total = 0;
+  for (int i = wave; i < n; i += nwaves) {
+    const float xi = spos[3 * i], yi = spos[3 * i + 1], zi = spos[3 * i + 2];
+    int cnt_r = 0, deg = 0;
+    for (int c = 0; 64 * c < n; ++c) {
+      const int j = 64 * c + lane;
+      const bool valid = j < n;
+      const int jj = valid ? j : 0;
+      const float d2 = dist2_nofma(xi, yi, zi, spos[3 * jj], spos[3 * jj + 1], spos[3 * jj + 2]);
+      const bool within = valid && d2 < a.r2;
+      const uint64_t wmask = __ballot(within);
+      const bool rad = within && (cnt_r + __popcll(wmask & lt) < AGDIFF_RADIUS_CAP) && j != i;
+      cnt_r += __popcll(wmask);
+      const bool loc = valid && ((locbits[i * words + 2 * c + (lane >> 5)] >> (lane & 31)) & 1u);
+      const uint64_t emask = __ballot(rad || loc);
+      if (lane == 0) {
+        inbits[i * words + 2 * c] = (uint32_t)emask;
+        inbits[i * words + 2 * c + 1] = (uint32_t)(emask >> 32);
+      }
+      deg += __popcll(emask);
+    }
+    if (lane == 0) sin[i] = deg;
+    wave_total += deg;
   }
   __syncthreads();
 
   if (!FILL) {
-    // per-graph edge count = sum of in-degrees
-    int s = 0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) s += sin[i];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-    __shared__ int wsum[8];
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __shared__ int wsum[4];
+    if (lane == 0) wsum[wave] = wave_total;
     __syncthreads();
     if (threadIdx.x == 0) {
       int tot = 0;
-      for (int w = 0; w < (int)((blockDim.x + 63) >> 6); ++w) tot += wsum[w];
+      for (int w = 0; w < nwaves; ++w) tot += wsum[w];
       a.graph_edge_cnt[g] = tot;
     }
     return;
   }
 
-  // out-degrees from the bit rows
+  // out-degrees = column counts of the in-adjacency
   for (int j = threadIdx.x; j < n; j += blockDim.x) {
     int c = 0;
-    for (int w = 0; w < words; ++w) c += __popc(bits[j * words + w]);
+    for (int i = 0; i < n; ++i) c += (inbits[i * words + (j >> 5)] >> (j & 31)) & 1u;
     sout[j] = c;
   }
   __syncthreads();
-  // exclusive scans of sin / sout (n <= 512): Hillis-Steele in place, two arrays together
+  // inclusive scans of sin / sout (n <= 512): Hillis-Steele in place, two arrays together
   for (int off = 1; off < n; off <<= 1) {
-    int vi[4], vo[4], cnt = 0;
+    int vi[2], vo[2], cnt = 0;
     for (int i = threadIdx.x; i < n; i += blockDim.x, ++cnt) {
       vi[cnt] = sin[i] + (i >= off ? sin[i - off] : 0);
       vo[cnt] = sout[i] + (i >= off ? sout[i - off] : 0);
@@ -138,34 +137,51 @@ __global__ void __launch_bounds__(512) k_graph(GraphArgs a) {
     }
     __syncthreads();
   }
-  // sin/sout now hold INCLUSIVE sums
   const int base = a.graph_edge_ptr[g];
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const int in_excl = (i ? sin[i - 1] : 0), out_excl = (i ? sout[i - 1] : 0);
-    a.in_ptr[g0 + i] = base + in_excl;
-    a.out_ptr[g0 + i] = base + out_excl;
+    a.in_ptr[g0 + i] = base + (i ? sin[i - 1] : 0);
+    a.out_ptr[g0 + i] = base + (i ? sout[i - 1] : 0);
   }
   if (g == a.num_graphs - 1 && threadIdx.x == 0) {
     a.in_ptr[g0 + n] = base + (n ? sin[n - 1] : 0);
     a.out_ptr[g0 + n] = base + (n ? sout[n - 1] : 0);
   }
-  // pass 2: emit
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const int pbase = base + (i ? sin[i - 1] : 0);
-    enumerate_in_edges(a, spos, n, g0, i, [&](int k, int j, int ty, float d2) {
-      const int p = pbase + k;
-      a.e_src[p] = g0 + j;
-      a.e_dst[p] = g0 + i;
-      a.e_type[p] = ty;
-      a.e_len[p] = sqrtf(d2);
-      // rank of target i among the out-edges of j (targets ascending) = set bits below i in row j
-      int rank = 0;
-      const uint32_t* row = bits + j * words;
-      for (int w = 0; w < (i >> 5); ++w) rank += __popc(row[w]);
-      rank += __popc(row[i >> 5] & ((1u << (i & 31)) - 1u));
-      const int q = base + (j ? sout[j - 1] : 0) + rank;
-      a.ref2dst[q] = p;
-    });
+  // pass 2: emit the lists, one wave per target, contiguous stores
+  for (int i = wave; i < n; i += nwaves) {
+    const float xi = spos[3 * i], yi = spos[3 * i + 1], zi = spos[3 * i + 2];
+    int p0 = base + (i ? sin[i - 1] : 0);
+    int lk = a.loc_in_ptr[g0 + i];
+    for (int c = 0; 64 * c < n; ++c) {
+      const int j = 64 * c + lane;
+      const int jj = (j < n) ? j : 0;
+      const uint64_t emask = (uint64_t)inbits[i * words + 2 * c] | ((uint64_t)inbits[i * words + 2 * c + 1] << 32);
+      const uint64_t lmask = (uint64_t)locbits[i * words + 2 * c] | ((uint64_t)locbits[i * words + 2 * c + 1] << 32);
+      if ((emask >> lane) & 1ull) {
+        const int p = p0 + __popcll(emask & lt);
+        int ty = 0;
+        if ((lmask >> lane) & 1ull) ty = a.loc_type[a.loc_in_eid[lk + __popcll(lmask & lt)]];
+        a.e_src[p] = g0 + j;
+        a.e_dst[p] = g0 + i;
+        a.e_type[p] = ty;
+        a.e_len[p] = sqrtf(dist2_nofma(xi, yi, zi, spos[3 * jj], spos[3 * jj + 1], spos[3 * jj + 2]));
+      }
+      p0 += __popcll(emask);
+      lk += __popcll(lmask);
+    }
+  }
+  // pass 3: ref2dst, one thread per source walking its column (targets ascending = the (src, dst) order)
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    int q = base + (j ? sout[j - 1] : 0);
+    const int wj = j >> 5;
+    const uint32_t below = (1u << (j & 31)) - 1u;
+    for (int i = 0; i < n; ++i) {
+      const uint32_t* row = inbits + i * words;
+      if ((row[wj] >> (j & 31)) & 1u) {
+        int rank = __popc(row[wj] & below);
+        for (int w = 0; w < wj; ++w) rank += __popc(row[w]);
+        a.ref2dst[q++] = base + (i ? sin[i - 1] : 0) + rank;
+      }
+    }
   }
 }
 
@@ -242,11 +258,19 @@ extern "C" int agdiff_graph_build(const agdiff_topo_t* topo, const agdiff_ws_t* 
   a.num_graphs = (int32_t)topo->num_graphs;
   const int max_atoms = (int)topo->max_atoms_per_graph;
   if (max_atoms <= 0 || max_atoms > AGDIFF_MAX_ATOMS_PER_GRAPH) return AGDIFF_ERR_LIMIT;
-  a.words = (max_atoms + 31) / 32;
+  a.words = 2 * ((max_atoms + 63) / 64);
   const int nmax = a.words * 32;
-  int bd = ((max_atoms + 63) / 64) * 64;
-  if (bd > 512) bd = 512;
-  const size_t smem = (size_t)(3 * nmax + 2 * nmax + nmax * a.words) * 4;
+  const int bd = 256;
+  const size_t smem = (size_t)(3 * nmax + 2 * nmax + 2 * nmax * a.words) * 4;
+  if (smem > 48 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)k_graph<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+          hipFuncSetAttribute((const void*)k_graph<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return AGDIFF_ERR_LAUNCH;
+      attr_set = true;
+    }
+  }
   k_graph<false><<<dim3((unsigned)topo->num_graphs), dim3(bd), smem, st>>>(a);
   AG_CHECK_LAUNCH();
   k_scan_graphs<<<1, 1024, 0, st>>>(ws->graph_edge_cnt, ws->graph_edge_ptr, ws->num_edges, (int)topo->num_graphs);
