@@ -343,6 +343,41 @@ def test_driver_end_to_end(tmp_path):
     driver.main(["--ckpt", ckpt, "--testset", ts, "--out", out, "--n-steps", "6", "--resume"])   # nothing left to do
 
 
+def test_graph_build_molecules_beyond_one_wave():
+    """Molecules of 200 atoms (four 64-source chunks per target in csrc/graph.hip) next to small ones: edge set,
+    order, types and lengths bit-exact against the oracle's radius graph, cap active (compact coordinates)."""
+    from agdiff_amd import _lib, synth
+    from agdiff_amd.topology import BatchTopology, Workspace
+    from oracle import agdiff_oracle as O
+    lib = _lib.load()
+    big = synth.make_packed_batch("large", 2, 1, seed=3)
+    small = synth.make_packed_batch("drugs", 2, 2, seed=4)
+    n_big = big["atom_type"].shape[0]
+    at = np.concatenate([big["atom_type"], small["atom_type"]])
+    bi = np.concatenate([big["bond_index"], small["bond_index"] + n_big], axis=1)
+    bt = np.concatenate([big["bond_type"], small["bond_type"]])
+    ba = np.concatenate([big["batch"], small["batch"] + big["num_graphs"]])
+    gen = torch.Generator().manual_seed(12)
+    pos = torch.randn(at.shape[0], 3, generator=gen) * 3.0
+    ei, et = O.extend_graph_order_radius(at.shape[0], pos, t(bi), t(bt), t(ba), cutoff=10.0, extend_order=False)
+    elen = O.get_distance(pos, ei)
+    topo = BatchTopology(at, bi, bt, ba, device="cuda")
+    ws = Workspace(topo)
+    posd = pos.cuda().contiguous()
+    assert lib.agdiff_graph_build(ctypes.byref(topo.struct), ctypes.byref(ws.struct), _lib.ptr(posd),
+                                  ctypes.c_float(10.0), _lib.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    E = int(ws.num_edges.item())
+    assert E == ei.shape[1] and E <= topo.max_edges
+    perm = ws.ref2dst[:E].long()
+    got = torch.stack([ws.e_src[:E][perm], ws.e_dst[:E][perm]]).cpu().numpy()
+    assert np.array_equal(got, ei.numpy())
+    assert np.array_equal(ws.e_type[:E][perm].cpu().numpy(), et.numpy())
+    assert rel_err(ws.e_len[:E][perm].cpu().numpy(), elen.numpy()) < 1e-6
+    indeg = np.diff(ws.in_ptr.cpu().numpy())
+    assert indeg.max() > 33            # cap + bonded neighbours beyond it
+
+
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_ragged_and_degenerate_graphs(precision):
     """Edge cases the path must survive: a single-atom graph (no edges at all), a two-atom graph, isolated atoms far
