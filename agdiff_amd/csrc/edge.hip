@@ -241,11 +241,25 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
   // edge attributes of the wave's NEXT tile are requested as soon as the current tile's first layer has consumed
   // its own (they land during the rest of the tile)
   AgIn<MODE> ea[4];
+  // ... and so are its per-edge scalars (source, the two conv scales) and its first / last target
+  int pf_src = 0, pf_t0 = 0, pf_t1 = 0;
+  float pf_s1 = 0.0f, pf_s2 = 0.0f;
+  auto prefetch_meta = [&](int64_t tl, int ln) {
+    const int64_t tb = tl * AG_TW, e = tb + (ln & 15);
+    const bool valid = e < E;
+    pf_src = valid ? a.e_src[e] : 0;
+    pf_s1 = valid ? a.scale1[e] : 0.0f;
+    pf_s2 = valid ? a.scale2[e] : 0.0f;
+    const int64_t last = (tb + AG_TW - 1 < E) ? tb + AG_TW - 1 : (int64_t)E - 1;
+    pf_t0 = a.e_dst[tb];
+    pf_t1 = a.e_dst[last];
+  };
   {
     const int64_t first = ((int64_t)blockIdx.x * AG_CONV_WAVES + wave) * a.chunk_tiles;
     if (first * AG_TW < E) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) ag_load_attr(ea[t], a.e_attr, first, t, lane0);
+      prefetch_meta(first, lane0);
     }
   }
   for (int64_t chunk = (int64_t)blockIdx.x * AG_CONV_WAVES + wave; chunk < a.max_chunks; chunk += cstride) {
@@ -273,15 +287,10 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
       int lane = lane0;
       asm volatile("" : "+v"(lane));
       const int q = lane >> 4, col = lane & 15;
-      const int64_t e = tbase + col;
-      const bool valid = e < E;
-      const int my_src = valid ? a.e_src[e] : 0;
-      const float s1 = valid ? a.scale1[e] : 0.0f;
-      const float s2 = valid ? a.scale2[e] : 0.0f;
-
-      const int64_t last = (tbase + AG_TW - 1 < E) ? tbase + AG_TW - 1 : (int64_t)E - 1;
-      const int t0 = __builtin_amdgcn_readfirstlane(a.e_dst[tbase]);
-      const int t1 = __builtin_amdgcn_readfirstlane(a.e_dst[last]);
+      const int my_src = pf_src;
+      const float s1 = pf_s1, s2 = pf_s2;
+      const int t0 = __builtin_amdgcn_readfirstlane(pf_t0);
+      const int t1 = __builtin_amdgcn_readfirstlane(pf_t1);
       if (run_t >= 0 && run_t != t0) {   // previous tile ended exactly on a list boundary
         float* dp = dest(run_t);
 #pragma unroll
@@ -345,6 +354,7 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
           if (nxt * AG_TW < E && nxt < a.max_chunks * a.chunk_tiles) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) ag_load_attr(ea[t], a.e_attr, nxt, t, lane);
+            prefetch_meta(nxt, lane);
           }
         }
       }
