@@ -302,6 +302,37 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
       }
       AG_STAMP(c1); st[0] += c1 - c0; c0 = c1;       // meta loads, carry flush
 
+      // per edge slot of my quarter (slot 4q + r lives in lane 4q + r): gather row of x, and the scales
+      // lw(d)*C(d) of the two convs, which multiply the message: (H^T W2 + b2) . s . x[src]
+      uint32_t xoff[4];
+      f32x4 sr;                          // scale of the conv being processed, per edge slot
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        xoff[r] = (uint32_t)__shfl(my_src, 4 * q + r) * 192u + (uint32_t)col;
+        sr[r] = __shfl(s1, 4 * q + r);
+      }
+      // list boundaries of the targets present in this tile, one per lane (in_ptr[t0 + lane]); the
+      // reduction loops read them with readlane instead of dependent global loads
+      const int ntg = t1 - t0 + 1;
+      const int ipl = a.in_ptr[t0 + (lane <= ntg ? lane : ntg)];
+      auto bound = [&](int i) -> int {   // in_ptr[t0 + i], i <= ntg
+        return (i < 64) ? __builtin_amdgcn_readlane(ipl, i) : __builtin_amdgcn_readfirstlane(a.in_ptr[t0 + i]);
+      };
+      auto dest_lo = [&](int t, int lo) -> float* {
+        return (lo >= e_begin) ? (a.agg + (size_t)t * 192) : (a.agg_first + (size_t)chunk * 192);
+      };
+
+      // second filter layer per 16-channel tile, flipped (rows = edges, lanes = channels), then message and
+      // destination-segmented reduction of that channel tile.  The x[src] rows of the next channel tile are
+      // fetched before the current tile's reduction.
+      f32x4 xg;
+      auto fetch_x = [&](int nt) {
+        if (AG_ABL(8)) return;
+        const float* xb = a.xs + 16 * nt;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xg[r] = xb[xoff[r]];
+      };
+      fetch_x(0);          // requested here, before the first layer: lands while its MFMAs run
       AgIn<MODE> hidb[6];
       {
         // First filter layer of both convs (128 -> 192), all 48 weight blocks from LDS (block (t, ot) at
@@ -360,36 +391,6 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
       }
       AG_STAMP(c1); st[1] += c1 - c0; c0 = c1;       // layer 1 + ssp + split
       AG_STAMP(c1); st[2] += c1 - c0; c0 = c1;       // ssp + split
-      // per edge slot of my quarter (slot 4q + r lives in lane 4q + r): gather row of x, and the scales
-      // lw(d)*C(d) of the two convs, which multiply the message: (H^T W2 + b2) . s . x[src]
-      uint32_t xoff[4];
-      f32x4 sr;                          // scale of the conv being processed, per edge slot
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        xoff[r] = (uint32_t)__shfl(my_src, 4 * q + r) * 192u + (uint32_t)col;
-        sr[r] = __shfl(s1, 4 * q + r);
-      }
-      // list boundaries of the targets present in this tile, one per lane (in_ptr[t0 + lane]); the
-      // reduction loops read them with readlane instead of dependent global loads
-      const int ntg = t1 - t0 + 1;
-      const int ipl = a.in_ptr[t0 + (lane <= ntg ? lane : ntg)];
-      auto bound = [&](int i) -> int {   // in_ptr[t0 + i], i <= ntg
-        return (i < 64) ? __builtin_amdgcn_readlane(ipl, i) : __builtin_amdgcn_readfirstlane(a.in_ptr[t0 + i]);
-      };
-      auto dest_lo = [&](int t, int lo) -> float* {
-        return (lo >= e_begin) ? (a.agg + (size_t)t * 192) : (a.agg_first + (size_t)chunk * 192);
-      };
-
-      // second filter layer per 16-channel tile, flipped (rows = edges, lanes = channels), then message and
-      // destination-segmented reduction of that channel tile.  The x[src] rows of the next channel tile are
-      // fetched before the current tile's reduction.
-      f32x4 xg;
-      auto fetch_x = [&](int nt) {
-        if (AG_ABL(8)) return;
-        const float* xb = a.xs + 16 * nt;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xg[r] = xb[xoff[r]];
-      };
       // Row masks of the first two targets of the tile, built once per tile: almost every 16-edge tile holds
       // the in-lists of one or two targets (in-degree >= 8), so the per-channel-tile reduction is 8 FMAs and two
       // quarter sums; tiles with more targets take the general loop.
@@ -446,8 +447,7 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
           g[b][1] = gl[((2 * pair + b) * 2 + 1) * 64];
         }
       };
-      fetch_x(0);
-      AG_STAMP(c1); st[3] += c1 - c0; c0 = c1;       // gather offsets, bounds
+      AG_STAMP(c1); st[3] += c1 - c0; c0 = c1;       // bounds, masks
       // second-layer MFMAs of channel tile nt (flipped: rows = edges, lanes = channels), raw accumulators
       auto dense2 = [&](int nt) -> f32x4 {
         f32x4 z[1] = {{0.f, 0.f, 0.f, 0.f}};
