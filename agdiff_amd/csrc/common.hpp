@@ -58,7 +58,8 @@ __device__ __forceinline__ float ag_gelu(float x) {
   p = fmaf(p, t, -1.627908587e+00f);
   p = fmaf(p, t, -1.0f);
   const float q = ag_exp2(p);                 // erfc(t) / 2
-  return x * (x >= 0.0f ? 1.0f - q : q);
+  // x * (x >= 0 ? 1 - q : q)  ==  max(x, 0) - |x| q   (two instructions instead of four)
+  return fmaf(-fabsf(x), q, fmaxf(x, 0.0f));
 }
 // schnet.py:71-80: softplus(beta*x) - log 2 with torch's threshold 20 (softplus(z) = z for z > 20).
 // softplus(z) >= z and equals z to fp32 precision beyond ~17, so max(z, log(1 + e^z)) reproduces the
