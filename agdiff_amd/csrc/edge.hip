@@ -520,7 +520,7 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
               }
             }
           }
-          __builtin_amdgcn_sched_barrier(0);
+          // (no fence here: experiment)
           zp = z; mp = m; bp = bb;
         }
       };
