@@ -305,7 +305,8 @@ def main():
             "roofline": roof, "roofline_cfconv_aggregate": agg_roof, "cpu_baseline": cpu,
         }
         sys.stdout.flush()
-        print(json.dumps(out), flush=True)     # last line of stdout (RCCL prints its banner earlier)
+        ctypes.CDLL(None).fflush(None)         # RCCL writes its banner through C stdio (block-buffered on a pipe):
+        print(json.dumps(out), flush=True)     # push it out first, so that the JSON is the last line of stdout
 
 
 if __name__ == "__main__":
