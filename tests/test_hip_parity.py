@@ -378,6 +378,41 @@ def test_graph_build_molecules_beyond_one_wave():
     assert indeg.max() > 33            # cap + bonded neighbours beyond it
 
 
+def test_molecule_larger_than_a_workgroup():
+    """A 300-atom molecule (more atoms than the 256 threads of the per-molecule kernels: graph build, Langevin
+    update, loss) next to a small one: forward and three sampler steps against the oracle."""
+    from agdiff_amd import drugs_model_config, synth
+    from oracle import agdiff_oracle as O
+    cfg = drugs_model_config(num_diffusion_timesteps=10)
+    m, sd = _gpu_model(cfg)
+    rng = np.random.default_rng(21)
+    a1, r1, c1, t1 = synth.random_molecule(rng, 300)
+    a2, r2, c2, t2 = synth.random_molecule(rng, 23)
+    at = t(np.concatenate([a1, a2]))
+    bi = t(np.concatenate([np.stack([r1, c1]), np.stack([r2, c2]) + 300], axis=1))
+    bt = t(np.concatenate([t1, t2]))
+    ba = t(np.concatenate([np.zeros(300, dtype=np.int64), np.ones(23, dtype=np.int64)]))
+    gen = torch.Generator().manual_seed(8)
+    pos = torch.randn(323, 3, generator=gen) * 4.0
+    ref = O.forward(sd, cfg, at, pos, bi, bt, ba, extend_order=False)
+    got = m(at.cuda(), pos.cuda(), bi.cuda(), bt.cuda(), ba.cuda(), None, return_edges=True, extend_order=False)
+    assert np.array_equal(got[2].cpu().numpy(), ref[2].numpy()) and np.array_equal(got[3].cpu().numpy(), ref[3].numpy())
+    assert rel_err(got[0].cpu().numpy(), ref[0].numpy()) < TOL and rel_err(got[1].cpu().numpy(), ref[1].numpy()) < TOL
+    noise = torch.randn(3, 323, 3, generator=gen)
+    kw = dict(n_steps=3, w_global=1.0, global_start_sigma=float("inf"), clip=1000.0)
+    rpos, _ = O.langevin_dynamics_sample_diffusion(sd, cfg, at, pos, bi, bt, ba, 2, False, noise=noise, **kw)
+    gpos, _ = m.langevin_dynamics_sample_diffusion(at.cuda(), pos.cuda(), bi.cuda(), bt.cuda(), ba.cuda(), 2, False,
+                                                   noise=noise.cuda(), **kw)
+    assert rel_err(gpos.cpu().numpy(), rpos.numpy()) < TOL
+    ts = torch.tensor([3, 7])
+    pn = torch.randn(323, 3, generator=gen)
+    rl = O.get_loss_diffusion(sd, cfg, at, pos, bi, bt, ba, 2, ts, pn, extend_order=False)
+    gl = m.get_loss(at.cuda(), pos.cuda(), bi.cuda(), bt.cuda(), ba.cuda(), None, 2, return_unreduced_loss=True,
+                    extend_order=False, time_step=ts.cuda(), pos_noise=pn.cuda())
+    for a_, b_ in zip(gl, rl):
+        assert rel_err(a_.cpu().numpy(), b_.numpy()) < TOL
+
+
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_ragged_and_degenerate_graphs(precision):
     """Edge cases the path must survive: a single-atom graph (no edges at all), a two-atom graph, isolated atoms far
