@@ -286,21 +286,6 @@ template <int MODE> struct AgPF { static constexpr int v = (MODE == AG_F32) ? 2 
 // weight block b of a packed matrix (both modes: 2 KiB = 512 floats per block)
 __device__ __forceinline__ const void* ag_wblock(const float* wpk, int b) { return wpk + (size_t)b * 512; }
 
-// z (flip orientation: rows = edges, lanes = features) += s (per edge, on its lane) (x) b (per feature, on
-// its lane): the outer product as one extra k-step whose only non-zero k-slot is (quarter 0, element 0).
-__device__ __forceinline__ void ag_rank1(f32x4& z, float s_edge, float b_feat, int q, AgIn<AG_F32>*) {
-  z = __builtin_amdgcn_mfma_f32_16x16x4f32(q == 0 ? s_edge : 0.0f, q == 0 ? b_feat : 0.0f, z, 0, 0, 0);
-}
-__device__ __forceinline__ void ag_rank1(f32x4& z, float s_edge, float b_feat, int q, AgIn<AG_BF3>*) {
-  const float sv = q == 0 ? s_edge : 0.0f, bv = q == 0 ? b_feat : 0.0f;
-  const __bf16 sh = (__bf16)sv, bh = (__bf16)bv;
-  const __bf16 sl = (__bf16)(sv - (float)sh), bl = (__bf16)(bv - (float)bh);
-  bf16x8 ah = {}, al = {}, bhv = {}, blv = {};
-  ah[0] = sh; al[0] = sl; bhv[0] = bh; blv[0] = bl;
-  z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bhv, z, 0, 0, 0);
-  z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bhv, z, 0, 0, 0);
-  z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, blv, z, 0, 0, 0);
-}
 
 // ---------------------------------------------------------------------------------- edge-attr storage
 // e_attr / l_attr tiles (16 edges x 128 features) are stored in the operand form of the mode that consumes

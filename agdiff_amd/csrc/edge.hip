@@ -181,7 +181,6 @@ struct ConvArgs {
   float* agg_first;      // [chunks][192]
   int64_t max_chunks;
   int32_t chunk_tiles;   // tiles per chunk (agdiff_conv_chunk_tiles)
-  int32_t stagger;       // s_sleep units (64 cycles) the second wave of each SIMD waits before its first tile
   int32_t ablate;        // timing experiments only (AGDIFF_ABLATE env): bit0 skip layer 1, bit1 skip ssp,
                          // bit2 skip layer 2, bit3 skip x gather, bit4 skip reduction
 };
@@ -213,10 +212,11 @@ __device__ unsigned long long ag_conv_stamp_acc[8];
 
 // encoder/schnet.py:136-162 for conv1 (F=128) and conv2 (F=64) of one InteractionBlock:
 //   W_e = nn(edge_attr_e) * (lw(d_e) * C(d_e));  agg[dst] += x[src] * W_e   (aggr='add')
-// Persistent launch, one 16-wave workgroup per CU (4 waves per SIMD).  Each wave walks AGDIFF_CHUNK_TILES
-// consecutive destination-sorted 16-edge tiles per chunk (chunk_tiles = 1..8, fewer for small batches) and keeps the running sum of the open target in
-// registers; a target whose list started in an earlier chunk is written to agg_first[chunk] and added by
-// the node stage (fixed order -> bitwise reproducible, no atomics).
+// Persistent launch, one 8-wave workgroup per CU (2 waves per SIMD, ~240 VGPRs: the tile body is a software
+// pipeline).  Each wave walks chunk_tiles (1..8, fewer for small batches) consecutive
+// destination-sorted 16-edge tiles per chunk and keeps the running sum of the open target in registers; a target
+// whose list started in an earlier chunk is written to agg_first[chunk] and added by the node stage (fixed
+// order -> bitwise reproducible, no atomics).
 template <int MODE>
 __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs a) {
   // LDS: all 160 KiB hold filter weights for the whole launch -- the fused first layer of both convs (96 KiB)
@@ -756,6 +756,8 @@ extern "C" int agdiff_cfconv_fused(const agdiff_params_t* p, const agdiff_topo_t
   a.agg_first = ws->agg_first;
   a.max_chunks = max_chunks;
   a.chunk_tiles = chunk_tiles;
+  a.ablate = 0;
+#ifdef AG_CONV_ABLATE
   {
     static int abl = -1;
     if (abl < 0) {
@@ -763,14 +765,9 @@ extern "C" int agdiff_cfconv_fused(const agdiff_params_t* p, const agdiff_topo_t
       abl = e ? atoi(e) : 0;
     }
     a.ablate = abl;
-    static int stg = -1;
-    if (stg < 0) {
-      const char* e = getenv("AGDIFF_STAGGER");
-      stg = e ? atoi(e) : 0;
-    }
-    a.stagger = stg;
   }
-  // persistent launch: one 16-wave workgroup per CU keeps 144 KiB of filter weights in LDS
+#endif
+  // persistent launch: one 8-wave workgroup per CU keeps 160 KiB of filter weights in LDS
   int64_t wgs = (max_chunks + AG_CONV_WAVES - 1) / AG_CONV_WAVES;
   if (wgs > 256) wgs = 256;
   const size_t smem = (size_t)AG_CONV_LDS_BLOCKS * 2048;
