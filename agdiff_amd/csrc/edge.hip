@@ -236,6 +236,9 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
   const int wave = threadIdx.x >> 6;
   const int E = *a.n_dev;
   const int64_t cstride = (int64_t)gridDim.x * AG_CONV_WAVES;
+  // Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8); give each XCD a contiguous range of the
+  // destination-sorted edge list per round, so that the x rows and list bounds of a molecule stay in ONE L2.
+  const int wg = (gridDim.x % 8 == 0) ? (int)((blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8) : (int)blockIdx.x;
   [[maybe_unused]] unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c0 = 0, c1 = 0;
 
   // edge attributes of the wave's NEXT tile are requested as soon as the current tile's first layer has consumed
@@ -255,14 +258,14 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
     pf_t1 = a.e_dst[last];
   };
   {
-    const int64_t first = ((int64_t)blockIdx.x * AG_CONV_WAVES + wave) * a.chunk_tiles;
+    const int64_t first = ((int64_t)wg * AG_CONV_WAVES + wave) * a.chunk_tiles;
     if (first * AG_TW < E) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) ag_load_attr(ea[t], a.e_attr, first, t, lane0);
       prefetch_meta(first, lane0);
     }
   }
-  for (int64_t chunk = (int64_t)blockIdx.x * AG_CONV_WAVES + wave; chunk < a.max_chunks; chunk += cstride) {
+  for (int64_t chunk = (int64_t)wg * AG_CONV_WAVES + wave; chunk < a.max_chunks; chunk += cstride) {
     const int64_t e_begin = chunk * (AG_TW * a.chunk_tiles);
     if (e_begin >= E) break;
     int run_t = -1;
