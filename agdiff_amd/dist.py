@@ -3,8 +3,9 @@
 Graphs are independent everywhere on the path (radius graph per `batch` id, eval-mode BatchNorm,
 per-graph centring, i.i.d. noise: SURVEY.md §8e), so the only exchange is the one BASELINE.json's
 north_star asks for: an all-gather of the shard positions (+ NaN flag) at the end of each
-denoising step.  It is issued on a side stream from a staging copy, because no rank needs remote
-positions for its next step: compute never waits for it.  `backend="nccl"` is RCCL on ROCm;
+denoising step.  It is issued on a side stream from a snapshot taken on the compute stream, because no
+rank needs remote positions for its next step: compute never waits for it (only, in principle, for the
+previous step's collective to release the snapshot buffer).  `backend="nccl"` is RCCL on ROCm;
 message sizes are tens of KB to ~0.6 MB per rank -> latency-bound, one collective per step.
 """
 import numpy as np
@@ -56,24 +57,32 @@ class StepAllGather:
         self.is_cuda = torch.device(device).type == "cuda"
         self.side = torch.cuda.Stream(device=device) if self.is_cuda else None
         self.calls = 0
+        self.prev_done = None
 
     def __call__(self, k, i, pos, nan_flag=None):
-        """on_step hook of LangevinRun: snapshot `pos` and launch the collective off the compute stream."""
+        """on_step hook of LangevinRun: snapshot `pos` on the compute stream (the next step updates it in place),
+        then launch the collective from the snapshot on the side stream."""
         if self.is_cuda:
+            cur = torch.cuda.current_stream()
+            if self.prev_done is not None:
+                cur.wait_event(self.prev_done)        # the previous collective has finished reading `stage`
+            self._snapshot(pos, nan_flag)
             ev = torch.cuda.Event()
-            ev.record()
+            ev.record(cur)
             with torch.cuda.stream(self.side):
                 self.side.wait_event(ev)
-                self._gather(pos, nan_flag)
+                dist.all_gather_into_tensor(self.gathered, self.stage, group=self.group)
+                self.prev_done = torch.cuda.Event()
+                self.prev_done.record(self.side)
         else:
-            self._gather(pos, nan_flag)
+            self._snapshot(pos, nan_flag)
+            dist.all_gather_into_tensor(self.gathered, self.stage, group=self.group)
         self.calls += 1
 
-    def _gather(self, pos, nan_flag):
+    def _snapshot(self, pos, nan_flag):
         self.stage[: self.n_local * 3].copy_(pos.reshape(-1), non_blocking=True)
         if nan_flag is not None:
             self.stage[-1:].copy_(nan_flag.to(torch.float32), non_blocking=True)
-        dist.all_gather_into_tensor(self.gathered, self.stage, group=self.group)
 
     def wait(self):
         if self.is_cuda:
