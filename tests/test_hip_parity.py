@@ -378,6 +378,30 @@ def test_graph_build_molecules_beyond_one_wave():
     assert indeg.max() > 33            # cap + bonded neighbours beyond it
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_default_initialised_weights(precision):
+    """torch's own parameter initialisation instead of the synthetic filler (other magnitudes: SchNet embedding rows
+    of norm ~11 > max_norm, kaiming-uniform linears, BatchNorm at identity): one forward against the oracle."""
+    from agdiff_amd import drugs_model_config, get_model, synth
+    from oracle import agdiff_oracle as O
+    torch.manual_seed(1234)
+    cfg = drugs_model_config()
+    m = get_model(cfg)
+    m.precision = precision
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to("cuda:0").eval()
+    b = synth.make_packed_batch("drugs", 2, 2, seed=77)
+    at, bi, bt, ba = t(b["atom_type"]), t(b["bond_index"]), t(b["bond_type"]), t(b["batch"])
+    pos = torch.randn(at.shape[0], 3, generator=torch.Generator().manual_seed(5)) * 2.0
+    ref = O.forward(sd, cfg, at, pos, bi, bt, ba, extend_order=False)
+    got = m(at.cuda(), pos.cuda(), bi.cuda(), bt.cuda(), ba.cuda(), None, return_edges=True, extend_order=False)
+    assert np.array_equal(got[2].cpu().numpy(), ref[2].numpy())
+    assert rel_err(got[0].cpu().numpy(), ref[0].numpy()) < TOL
+    assert rel_err(got[1].cpu().numpy(), ref[1].numpy()) < TOL
+    # the max_norm renormalisation touched the module's own embedding exactly as the oracle's copy
+    assert rel_err(m.encoder_global.embedding.weight.detach().cpu().numpy(), sd["encoder_global.embedding.weight"].numpy()) < 1e-6
+
+
 def test_molecule_larger_than_a_workgroup():
     """A 300-atom molecule (more atoms than the 256 threads of the per-molecule kernels: graph build, Langevin
     update, loss) next to a small one: forward and three sampler steps against the oracle."""
