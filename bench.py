@@ -129,16 +129,16 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from agdiff_amd import _lib, get_model
-    from oracle import agdiff_oracle as O     # only for the shared synthetic state_dict and the cpu_baseline leg
+    from agdiff_amd import _lib, get_model, synth
     lib = _lib.load()
 
+    # The measured path never touches oracle/: the synthetic checkpoint comes from the product-side closed-form
+    # filler (agdiff_amd/synth.py; the oracle fills its own copy with the same function in the cpu_baseline leg).
     kind = args.workload
     cfg = make_cfg(kind, args.schedule)
-    sd = O.synth_state_dict_for(cfg)
     model = get_model(cfg)
     model.precision = args.precision
-    model.load_state_dict({k: v.clone() for k, v in sd.items()})
+    model.load_state_dict(synth.synth_state_dict(model.state_dict()))
     model = model.to(dev).eval()
 
     copies = args.copies if kind != "large" else 1
