@@ -39,7 +39,7 @@ namespace {
 // device memory).  The fork/join is event-based, hence also capturable into a hipGraph.
 struct ForkJoin {
   hipStream_t side = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr, rows = nullptr;
   bool ok = false;
 };
 ForkJoin& fork_join_for_current_device() {
@@ -50,40 +50,53 @@ ForkJoin& fork_join_for_current_device() {
   if (!f.ok) {
     f.ok = hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) == hipSuccess &&
            hipEventCreateWithFlags(&f.fork, hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&f.join, hipEventDisableTiming) == hipSuccess;
+           hipEventCreateWithFlags(&f.join, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&f.rows, hipEventDisableTiming) == hipSuccess;
   }
   return f;
 }
 
+// Local branch = lengths -> edge encoder (local rows) -> GIN -> local head   (dualenc.py:214-239).
+// `rows_from_global`: the global branch's encoder pass writes ws->l_attr_rows itself (the local edges are a subset of
+// the edge set it walks and dualenc.py:214-216 evaluates the SAME encoder on them), so the pass over the local list is
+// skipped and everything after it waits for `rows_ready`.
 int local_branch(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, int flags,
-                 void* stream) {
+                 bool rows_from_global, hipEvent_t rows_ready, void* stream) {
   const int64_t ltiles = (topo->num_local + AG_TW - 1) / AG_TW;
-  // lengths -> edge encoder -> GIN -> local head   (dualenc.py:214-239)
   if (!(flags & AGDIFF_FWD_GRAPH_GIVEN)) AG_TRY(agdiff_local_lengths(topo, ws, pos, stream));
-  if (topo->num_local > 0) {
-    AG_TRY(agdiff_edge_encoder(p, ws->num_local, ltiles, ws->l_len, topo->loc_type, ws->l_attr, ws->l_attr_rows, stream));
+  if (rows_from_global) {
+    if (hipStreamWaitEvent((hipStream_t)stream, rows_ready, 0) != hipSuccess) return AGDIFF_ERR_LAUNCH;
+  } else if (topo->num_local > 0) {
+    AG_TRY(agdiff_edge_encoder(p, ws->num_local, ltiles, ws->l_len, topo->loc_type, nullptr, ws->l_attr_rows, nullptr, stream));
   }
   AG_TRY(agdiff_gin_encoder(p, topo, ws, stream));
   if (topo->num_local > 0) {
-    AG_TRY(agdiff_pair_head(&p->head_local, ws->num_local, ltiles, topo->loc_src, topo->loc_dst, ws->hl, ws->l_attr,
-                            ws->l_inv, stream));
+    AG_TRY(agdiff_pair_head(&p->head_local, ws->num_local, ltiles, topo->loc_src, topo->loc_dst, ws->hl, nullptr,
+                            ws->l_attr_rows, ws->l_inv, stream));
   }
   return AGDIFF_OK;
 }
 
-int global_branch(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, int flags,
-                  void* stream) {
-  // radius graph -> scales -> edge encoder -> SchNet -> global head   (dualenc.py:167-211)
+// radius graph -> scales -> edge encoder   (dualenc.py:167-191)
+int global_front(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, int flags,
+                 bool rows_for_local, void* stream) {
   const int64_t etiles = (topo->max_edges + AG_TW - 1) / AG_TW;
   if (!(flags & AGDIFF_FWD_GRAPH_GIVEN))     // cutoff 0 admits no radius edge: the bond graph alone (extend_radius=False)
     AG_TRY(agdiff_graph_build(topo, ws, pos, (flags & AGDIFF_FWD_NO_RADIUS) ? 0.0f : p->cutoff, stream));
   AG_TRY(agdiff_edge_scales(p, topo, ws, stream));
-  AG_TRY(agdiff_edge_encoder(p, ws->num_edges, etiles, ws->e_len, ws->e_type, ws->e_attr, nullptr, stream));
+  AG_TRY(agdiff_edge_encoder(p, ws->num_edges, etiles, ws->e_len, ws->e_type, ws->e_attr,
+                             rows_for_local ? ws->l_attr_rows : nullptr, rows_for_local ? ws->e_loc : nullptr, stream));
+  return AGDIFF_OK;
+}
+
+// SchNet -> global head   (dualenc.py:193-211)
+int global_back(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, void* stream) {
+  const int64_t etiles = (topo->max_edges + AG_TW - 1) / AG_TW;
   for (int k = 0; k <= p->num_convs; ++k) {
     AG_TRY(agdiff_schnet_node_stage(p, topo, ws, k, stream));
     if (k < p->num_convs) AG_TRY(agdiff_cfconv_fused(p, topo, ws, k, stream));
   }
-  AG_TRY(agdiff_pair_head(&p->head_global, ws->num_edges, etiles, ws->e_src, ws->e_dst, ws->h, ws->e_attr,
+  AG_TRY(agdiff_pair_head(&p->head_global, ws->num_edges, etiles, ws->e_src, ws->e_dst, ws->h, ws->e_attr, nullptr,
                           ws->e_inv_global, stream));
   return AGDIFF_OK;
 }
@@ -92,19 +105,25 @@ int global_branch(const agdiff_params_t* p, const agdiff_topo_t* topo, const agd
 extern "C" int agdiff_score_forward(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
                                     const float* pos, int32_t flags, void* stream) {
   if (!p || !topo || !ws || !pos) return AGDIFF_ERR_ARG;
-  if (!(flags & AGDIFF_FWD_GLOBAL)) return local_branch(p, topo, ws, pos, flags, stream);
+  if (!(flags & AGDIFF_FWD_GLOBAL)) return local_branch(p, topo, ws, pos, flags, false, nullptr, stream);
+  // the encoder pass over all edges also fills the local rows when the graph came from agdiff_graph_build (e_loc)
+  const bool share_rows = !(flags & AGDIFF_FWD_GRAPH_GIVEN) && topo->num_local > 0 && ws->e_loc;
   static const bool serial = getenv("AGDIFF_SERIAL_BRANCHES") != nullptr;
   ForkJoin& fj = fork_join_for_current_device();
-  if (serial || !fj.ok) {
-    AG_TRY(local_branch(p, topo, ws, pos, flags, stream));
-    return global_branch(p, topo, ws, pos, flags, stream);
-  }
   hipStream_t main = (hipStream_t)stream;
+  if (serial || !fj.ok) {
+    AG_TRY(global_front(p, topo, ws, pos, flags, share_rows, stream));
+    if (share_rows && fj.ok && hipEventRecord(fj.rows, main) != hipSuccess) return AGDIFF_ERR_LAUNCH;
+    AG_TRY(local_branch(p, topo, ws, pos, flags, share_rows && fj.ok, fj.rows, stream));
+    return global_back(p, topo, ws, stream);
+  }
   if (hipEventRecord(fj.fork, main) != hipSuccess || hipStreamWaitEvent(fj.side, fj.fork, 0) != hipSuccess)
     return AGDIFF_ERR_LAUNCH;
-  AG_TRY(local_branch(p, topo, ws, pos, flags, (void*)fj.side));
+  AG_TRY(global_front(p, topo, ws, pos, flags, share_rows, stream));
+  if (share_rows && hipEventRecord(fj.rows, main) != hipSuccess) return AGDIFF_ERR_LAUNCH;
+  AG_TRY(local_branch(p, topo, ws, pos, flags, share_rows, fj.rows, (void*)fj.side));
   if (hipEventRecord(fj.join, fj.side) != hipSuccess) return AGDIFF_ERR_LAUNCH;
-  AG_TRY(global_branch(p, topo, ws, pos, flags, stream));
+  AG_TRY(global_back(p, topo, ws, stream));
   if (hipStreamWaitEvent(main, fj.join, 0) != hipSuccess) return AGDIFF_ERR_LAUNCH;
   return AGDIFF_OK;
 }

@@ -21,8 +21,9 @@ struct EncArgs {
   const int32_t* n_dev;
   const float* e_len;
   const int32_t* e_type;
-  float* out_frag;
-  float* out_rows;       // optional [E][128] fp32 row-major copy
+  float* out_frag;       // optional: operand-form tiles
+  float* out_rows;       // optional: fp32 rows, row e or row row_index[e] (< 0: none)
+  const int32_t* row_index;
   int64_t max_tiles;
 };
 
@@ -81,10 +82,15 @@ __global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_edge_encoder(EncAr
     ag_cvt_tiles<MODE, 4, 0>(y, x);
     ag_init_vec<8>(y, a.b4, q);
     ag_dense_split<MODE, false, false, 4, 8, 0, 0, 6>(x, y, lw4, a.w4_pk, lane);
-    if (a.out_rows && valid) ag_store_row<8, 0>(y, a.out_rows + (size_t)e * 128, q);
-    ag_cvt_tiles<MODE, 4, 0>(y, x);
+    if (a.out_rows && valid) {
+      const int64_t row = a.row_index ? (int64_t)a.row_index[e] : e;
+      if (row >= 0) ag_store_row<8, 0>(y, a.out_rows + (size_t)row * 128, q);
+    }
+    if (a.out_frag) {
+      ag_cvt_tiles<MODE, 4, 0>(y, x);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) ag_store_attr(x[t], a.out_frag, tile, t, lane);
+      for (int t = 0; t < 4; ++t) ag_store_attr(x[t], a.out_frag, tile, t, lane);
+    }
   }
 }
 
@@ -99,6 +105,7 @@ struct GaussArgs {
   const int32_t* e_type;
   float* out_frag;
   float* out_rows;
+  const int32_t* row_index;
   int64_t max_tiles;
   float coeff_log2e;
 };
@@ -118,11 +125,16 @@ __global__ void __launch_bounds__(256) k_edge_gaussian(GaussArgs a) {
   ag_load_row<4, 0>(y, a.offset, q);
   AG_FOR_TILE(y, 4, ag_exp2(a.coeff_log2e * ((d - v) * (d - v))));
   ag_load_row<4, 4>(y, a.emb + (size_t)ty * 64, q);
-  if (a.out_rows && valid) ag_store_row<8, 0>(y, a.out_rows + (size_t)e * 128, q);
-  AgIn<MODE> x[4];
-  ag_cvt_tiles<MODE, 4, 0>(y, x);
+  if (a.out_rows && valid) {
+    const int64_t row = a.row_index ? (int64_t)a.row_index[e] : e;
+    if (row >= 0) ag_store_row<8, 0>(y, a.out_rows + (size_t)row * 128, q);
+  }
+  if (a.out_frag) {
+    AgIn<MODE> x[4];
+    ag_cvt_tiles<MODE, 4, 0>(y, x);
 #pragma unroll
-  for (int t = 0; t < 4; ++t) ag_store_attr(x[t], a.out_frag, tile, t, lane);
+    for (int t = 0; t < 4; ++t) ag_store_attr(x[t], a.out_frag, tile, t, lane);
+  }
 }
 
 // ------------------------------------------------------------------------------ per-edge conv scales
@@ -564,7 +576,8 @@ struct HeadArgs {
   const int32_t* src;
   const int32_t* dst;
   const float* node_h;   // [N][128]
-  const float* attr_frag;
+  const float* attr_frag;   // operand-form edge_attr tiles, or
+  const float* attr_rows;   // fp32 rows [E][128] (exactly one of the two)
   float* out;            // [E]
   int64_t max_tiles;
 };
@@ -607,8 +620,11 @@ __global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_pair_head(HeadArgs
           const f32x4 p0 = ag_ld4(hs + 32 * k + 4 * q) * ag_ld4(ht + 32 * k + 4 * q);
           const f32x4 p1 = ag_ld4(hs + 32 * k + 16 + 4 * q) * ag_ld4(ht + 32 * k + 16 + 4 * q);
           ag_cvt(p0, p1, dst);
-        } else {
+        } else if (a.attr_frag) {
           ag_load_attr(dst, a.attr_frag, tile, k - 4, lane);
+        } else {
+          const float* ar = a.attr_rows + (size_t)(valid ? e : 0) * 128 + 32 * (k - 4) + 4 * q;
+          ag_cvt(ag_ld4(ar), ag_ld4(ar + 16), dst);
         }
       };
       load_slice(sl[0], 0);
@@ -678,12 +694,12 @@ extern "C" int agdiff_debug_conv_stamps(unsigned long long* out, int reset) {
 
 extern "C" int agdiff_edge_encoder(const agdiff_params_t* p, const int32_t* n_edges_dev, int64_t max_tiles,
                                    const float* e_len, const int32_t* e_type, float* attr_frag, float* attr_rows,
-                                   void* stream) {
-  if (!p || !n_edges_dev || !e_len || !e_type || !attr_frag || max_tiles < 0) return AGDIFF_ERR_ARG;
+                                   const int32_t* row_index, void* stream) {
+  if (!p || !n_edges_dev || !e_len || !e_type || (!attr_frag && !attr_rows) || max_tiles < 0) return AGDIFF_ERR_ARG;
   if (max_tiles == 0) return AGDIFF_OK;
   if (p->edge_encoder == 1) {
     if (!p->ge_offset || !p->ge_emb) return AGDIFF_ERR_ARG;
-    GaussArgs g{p->ge_offset, p->ge_emb, n_edges_dev, e_len, e_type, attr_frag, attr_rows, max_tiles,
+    GaussArgs g{p->ge_offset, p->ge_emb, n_edges_dev, e_len, e_type, attr_frag, attr_rows, row_index, max_tiles,
                 p->ge_coeff * 1.44269504088896340736f};
     const dim3 grid((unsigned)((max_tiles + 3) / 4));
     if (p->precision == AG_BF3)
@@ -695,7 +711,7 @@ extern "C" int agdiff_edge_encoder(const agdiff_params_t* p, const int32_t* n_ed
   }
   if (p->edge_encoder != 0) return AGDIFF_ERR_ARG;
   EncArgs a{p->ee_fe_w, p->ee_fe_b, p->ee_t1, p->ee_w1_pk, p->ee_t3, p->ee_w23_pk, p->ee_w4_pk, p->ee_b4,
-            n_edges_dev, e_len, e_type, attr_frag, attr_rows, max_tiles};
+            n_edges_dev, e_len, e_type, attr_frag, attr_rows, row_index, max_tiles};
   int64_t wgs = (max_tiles + AG_PERSIST_WAVES - 1) / AG_PERSIST_WAVES;
   if (wgs > 256) wgs = 256;
   const size_t smem = (size_t)80 * 2048;     // w1 (32 blocks) + w23 (32) + unit 0 of w4's 32 blocks
@@ -791,8 +807,9 @@ extern "C" int agdiff_cfconv_fused(const agdiff_params_t* p, const agdiff_topo_t
 
 extern "C" int agdiff_pair_head(const agdiff_head_params_t* hp, const int32_t* n_edges_dev, int64_t max_tiles,
                                 const int32_t* src, const int32_t* dst, const float* node_h, const float* attr_frag,
-                                float* out, void* stream) {
-  if (!hp || !n_edges_dev || !src || !dst || !node_h || !attr_frag || !out || max_tiles < 0) return AGDIFF_ERR_ARG;
+                                const float* attr_rows, float* out, void* stream) {
+  if (!hp || !n_edges_dev || !src || !dst || !node_h || (!attr_frag == !attr_rows) || !out || max_tiles < 0)
+    return AGDIFF_ERR_ARG;
   if (max_tiles == 0) return AGDIFF_OK;
   HeadArgs a;
   a.hp = *hp;
@@ -801,6 +818,7 @@ extern "C" int agdiff_pair_head(const agdiff_head_params_t* hp, const int32_t* n
   a.dst = dst;
   a.node_h = node_h;
   a.attr_frag = attr_frag;
+  a.attr_rows = attr_rows;
   a.out = out;
   a.max_tiles = max_tiles;
   int64_t wgs = (max_tiles + AG_PERSIST_WAVES - 1) / AG_PERSIST_WAVES;

@@ -28,6 +28,7 @@ struct GraphArgs {
   int32_t* e_type;
   float* e_len;
   int32_t* ref2dst;
+  int32_t* e_loc;
   int32_t num_graphs;
 };
 
@@ -158,8 +159,12 @@ __global__ void __launch_bounds__(256) k_graph(GraphArgs a) {
       const uint64_t lmask = (uint64_t)locbits[i * words + 2 * c] | ((uint64_t)locbits[i * words + 2 * c + 1] << 32);
       if ((emask >> lane) & 1ull) {
         const int p = p0 + __popcll(emask & lt);
-        int ty = 0;
-        if ((lmask >> lane) & 1ull) ty = a.loc_type[a.loc_in_eid[lk + __popcll(lmask & lt)]];
+        int ty = 0, eid = -1;
+        if ((lmask >> lane) & 1ull) {
+          eid = a.loc_in_eid[lk + __popcll(lmask & lt)];
+          ty = a.loc_type[eid];
+        }
+        a.e_loc[p] = eid;
         a.e_src[p] = g0 + j;
         a.e_dst[p] = g0 + i;
         a.e_type[p] = ty;
@@ -232,7 +237,7 @@ extern "C" int agdiff_graph_build(const agdiff_topo_t* topo, const agdiff_ws_t* 
                                   void* stream) {
   if (!topo || !ws || !pos || topo->num_graphs <= 0 || topo->num_nodes <= 0) return AGDIFF_ERR_ARG;
   if (!ws->graph_edge_cnt || !ws->graph_edge_ptr || !ws->in_ptr || !ws->out_ptr || !ws->e_src || !ws->e_dst ||
-      !ws->e_type || !ws->e_len || !ws->ref2dst || !ws->num_edges)
+      !ws->e_type || !ws->e_len || !ws->ref2dst || !ws->e_loc || !ws->num_edges)
     return AGDIFF_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   // The host (agdiff_amd/topology.py) guarantees max atoms per graph <= AGDIFF_MAX_ATOMS_PER_GRAPH and
@@ -255,6 +260,7 @@ extern "C" int agdiff_graph_build(const agdiff_topo_t* topo, const agdiff_ws_t* 
   a.e_type = ws->e_type;
   a.e_len = ws->e_len;
   a.ref2dst = ws->ref2dst;
+  a.e_loc = ws->e_loc;
   a.num_graphs = (int32_t)topo->num_graphs;
   const int max_atoms = (int)topo->max_atoms_per_graph;
   if (max_atoms <= 0 || max_atoms > AGDIFF_MAX_ATOMS_PER_GRAPH) return AGDIFF_ERR_LIMIT;

@@ -130,12 +130,12 @@ class Workspace:
         self.graph_edge_cnt, self.graph_edge_ptr = i32(G), i32(G + 1)
         self.in_ptr, self.out_ptr = i32(N + 1), i32(N + 1)
         self.e_src, self.e_dst, self.e_type, self.ref2dst = i32(etiles * TW), i32(etiles * TW), i32(etiles * TW), i32(etiles * TW)
+        self.e_loc = i32(etiles * TW)
         self.e_len = f32(etiles * TW)
         self.e_attr = f32(etiles * TW * 128)
         self.e_inv_global = f32(etiles * TW)
         self.e_scale = f32(2 * _lib.DEFINES["AGDIFF_MAX_CONVS"] * etiles * TW)
         self.l_len, self.l_inv = f32(ltiles * TW), f32(ltiles * TW)
-        self.l_attr = f32(ltiles * TW * 128)
         self.l_attr_rows = f32(ltiles * TW * 128)
         self.h, self.xs, self.agg = f32(N * 128), f32(N * 192), f32(N * 192)
         self.agg_first = f32(chunks * 192)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 13
+#define AGDIFF_ABI_VERSION 14
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -164,13 +164,15 @@ typedef struct agdiff_ws {
   int32_t* e_type;           /* [max_edges] */
   float*   e_len;            /* [max_edges] */
   int32_t* ref2dst;          /* [max_edges]: reference position q -> destination-sorted id */
+  int32_t* e_loc;            /* [max_edges]: id of the edge in the local (type > 0) list, -1 for radius-only edges */
   float*   e_attr;           /* [ceil(max_edges/16)] tiles x 2048 floats: edge_attr in operand form (csrc/common.hpp) */
   float*   e_inv_global;     /* [max_edges] grad_global_dist_mlp output, destination-sorted */
   float*   e_scale;          /* [2*num_convs][ceil(max_edges/16)*16]: lw(d)*C(d) of conv1 / conv2 of every block (schnet.py:138-149) */
   /* local edges (reference order) */
   float*   l_len;            /* [L] */
-  float*   l_attr;           /* [ceil(L/16)] tiles, operand form */
-  float*   l_attr_rows;      /* [L][128] fp32 row-major copy of l_attr for the GIN message gather */
+  float*   l_attr_rows;      /* [L][128] fp32 row-major edge_attr of the local edges (GIN message gather, local head);
+                                written by the global encoder pass through e_loc when that pass runs, else by a
+                                pass over the local list */
   float*   l_inv;            /* [L] grad_local_dist_mlp output */
   /* nodes */
   float*   h;                /* [N][128] SchNet node state */
@@ -223,11 +225,13 @@ int agdiff_edge_scales(const agdiff_params_t* p, const agdiff_topo_t* topo, cons
 
 /* get_edge_encoder(cfg)(edge_length, edge_type) (encoder/edge.py:106-116): MLPEdgeEncoder.forward
  * (edge.py:84-103) when p->edge_encoder == 0, GaussianSmearingEdgeEncoder.forward (edge.py:34-42) when 1.
- * n_edges_dev: device scalar with the live edge
- * count (<= max_tiles*16); writes operand-form edge_attr tiles. */
+ * n_edges_dev: device scalar with the live edge count (<= max_tiles*16).  Outputs, each optional:
+ *   attr_frag  operand-form edge_attr tiles;
+ *   attr_rows  fp32 rows [.][128]: row e of edge e, or row row_index[e] when row_index is given (edges with
+ *              row_index[e] < 0 write no row) -- how the pass over all edges also serves the local edge list. */
 int agdiff_edge_encoder(const agdiff_params_t* p, const int32_t* n_edges_dev, int64_t max_tiles,
-                        const float* e_len, const int32_t* e_type, float* attr_frag, float* attr_rows /* optional [E][128] */,
-                        void* stream);
+                        const float* e_len, const int32_t* e_type, float* attr_frag, float* attr_rows,
+                        const int32_t* row_index, void* stream);
 
 /* Node-side stage k of SchNetEncoder.forward (encoder/schnet.py:268-282): k == 0 embeds atoms;
  * k >= 1 finishes InteractionBlock k-1 (lin2/BN, act, lin, gate, AdaptiveScaling, residual);
@@ -239,10 +243,11 @@ int agdiff_schnet_node_stage(const agdiff_params_t* p, const agdiff_topo_t* topo
 int agdiff_cfconv_fused(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k, void* stream);
 
 /* assemble_atom_pair_feature + grad_*_dist_mlp (models/common.py:106-109, 86-103; dualenc.py:203-211,
- * 226-239) over n edges given by (src, dst) and fragment-major attrs. */
+ * 226-239) over n edges given by (src, dst); edge_attr either as operand-form tiles (attr_frag) or as fp32
+ * rows [n][128] (attr_rows) -- exactly one of the two. */
 int agdiff_pair_head(const agdiff_head_params_t* hp, const int32_t* n_edges_dev, int64_t max_tiles,
                      const int32_t* src, const int32_t* dst, const float* node_h, const float* attr_frag,
-                     float* out, void* stream);
+                     const float* attr_rows, float* out, void* stream);
 
 /* GINEncoder.forward (encoder/gin.py:112-148) on the static local edges; result in ws->hl. */
 int agdiff_gin_encoder(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, void* stream);
