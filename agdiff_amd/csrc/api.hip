@@ -67,12 +67,13 @@ int local_branch(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdi
   if (rows_from_global) {
     if (hipStreamWaitEvent((hipStream_t)stream, rows_ready, 0) != hipSuccess) return AGDIFF_ERR_LAUNCH;
   } else if (topo->num_local > 0) {
-    AG_TRY(agdiff_edge_encoder(p, ws->num_local, ltiles, ws->l_len, topo->loc_type, nullptr, ws->l_attr_rows, nullptr, stream));
+    AG_TRY(agdiff_edge_encoder(p, ws->num_local, ltiles, ws->l_len, topo->loc_type, nullptr, ws->l_attr_rows, nullptr,
+                               nullptr, nullptr, stream));
   }
   AG_TRY(agdiff_gin_encoder(p, topo, ws, stream));
   if (topo->num_local > 0) {
     AG_TRY(agdiff_pair_head(&p->head_local, ws->num_local, ltiles, topo->loc_src, topo->loc_dst, ws->hl, nullptr,
-                            ws->l_attr_rows, ws->l_inv, stream));
+                            ws->l_attr_rows, nullptr, nullptr, ws->l_inv, stream));
   }
   return AGDIFF_OK;
 }
@@ -84,20 +85,33 @@ int global_front(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdi
   if (!(flags & AGDIFF_FWD_GRAPH_GIVEN))     // cutoff 0 admits no radius edge: the bond graph alone (extend_radius=False)
     AG_TRY(agdiff_graph_build(topo, ws, pos, (flags & AGDIFF_FWD_NO_RADIUS) ? 0.0f : p->cutoff, stream));
   AG_TRY(agdiff_edge_scales(p, topo, ws, stream));
-  AG_TRY(agdiff_edge_encoder(p, ws->num_edges, etiles, ws->e_len, ws->e_type, ws->e_attr,
-                             rows_for_local ? ws->l_attr_rows : nullptr, rows_for_local ? ws->e_loc : nullptr, stream));
+  if (flags & AGDIFF_FWD_GRAPH_GIVEN) {       // caller's edge list: no canonical list, one encoder evaluation per edge
+    AG_TRY(agdiff_edge_encoder(p, ws->num_edges, etiles, ws->e_len, ws->e_type, ws->e_attr, nullptr, nullptr, nullptr,
+                               nullptr, stream));
+  } else {
+    // one evaluation per canonical edge, written to its own and its mirror's slot of e_attr (and, for local edges,
+    // to their rows of l_attr_rows)
+    AG_TRY(agdiff_edge_encoder(p, ws->num_canon, etiles, ws->c_len, ws->c_type, ws->e_attr,
+                               rows_for_local ? ws->l_attr_rows : nullptr, rows_for_local ? ws->e_loc : nullptr, ws->c_pos,
+                               ws->c_mir, stream));
+  }
   return AGDIFF_OK;
 }
 
 // SchNet -> global head   (dualenc.py:193-211)
-int global_back(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, void* stream) {
+int global_back(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int flags, void* stream) {
   const int64_t etiles = (topo->max_edges + AG_TW - 1) / AG_TW;
   for (int k = 0; k <= p->num_convs; ++k) {
     AG_TRY(agdiff_schnet_node_stage(p, topo, ws, k, stream));
     if (k < p->num_convs) AG_TRY(agdiff_cfconv_fused(p, topo, ws, k, stream));
   }
-  AG_TRY(agdiff_pair_head(&p->head_global, ws->num_edges, etiles, ws->e_src, ws->e_dst, ws->h, ws->e_attr, nullptr,
-                          ws->e_inv_global, stream));
+  if (flags & AGDIFF_FWD_GRAPH_GIVEN) {
+    AG_TRY(agdiff_pair_head(&p->head_global, ws->num_edges, etiles, ws->e_src, ws->e_dst, ws->h, ws->e_attr, nullptr,
+                            nullptr, nullptr, ws->e_inv_global, stream));
+  } else {
+    AG_TRY(agdiff_pair_head(&p->head_global, ws->num_canon, etiles, ws->c_src, ws->c_dst, ws->h, ws->e_attr, nullptr,
+                            ws->c_pos, ws->c_mir, ws->e_inv_global, stream));
+  }
   return AGDIFF_OK;
 }
 }  // namespace
@@ -115,7 +129,7 @@ extern "C" int agdiff_score_forward(const agdiff_params_t* p, const agdiff_topo_
     AG_TRY(global_front(p, topo, ws, pos, flags, share_rows, stream));
     if (share_rows && fj.ok && hipEventRecord(fj.rows, main) != hipSuccess) return AGDIFF_ERR_LAUNCH;
     AG_TRY(local_branch(p, topo, ws, pos, flags, share_rows && fj.ok, fj.rows, stream));
-    return global_back(p, topo, ws, stream);
+    return global_back(p, topo, ws, flags, stream);
   }
   if (hipEventRecord(fj.fork, main) != hipSuccess || hipStreamWaitEvent(fj.side, fj.fork, 0) != hipSuccess)
     return AGDIFF_ERR_LAUNCH;
@@ -123,7 +137,7 @@ extern "C" int agdiff_score_forward(const agdiff_params_t* p, const agdiff_topo_
   if (share_rows && hipEventRecord(fj.rows, main) != hipSuccess) return AGDIFF_ERR_LAUNCH;
   AG_TRY(local_branch(p, topo, ws, pos, flags, share_rows, fj.rows, (void*)fj.side));
   if (hipEventRecord(fj.join, fj.side) != hipSuccess) return AGDIFF_ERR_LAUNCH;
-  AG_TRY(global_back(p, topo, ws, stream));
+  AG_TRY(global_back(p, topo, ws, flags, stream));
   if (hipStreamWaitEvent(main, fj.join, 0) != hipSuccess) return AGDIFF_ERR_LAUNCH;
   return AGDIFF_OK;
 }

@@ -288,28 +288,34 @@ __device__ __forceinline__ const void* ag_wblock(const float* wpk, int b) { retu
 
 
 // ---------------------------------------------------------------------------------- edge-attr storage
-// e_attr / l_attr tiles (16 edges x 128 features) are stored in the operand form of the mode that consumes
-// them: per k-tile t two 16-byte units per lane, unit index ((tile*4 + t)*2 + u)*64 + lane -- 1 KiB
-// coalesced per wave instruction for the producer's store and every consumer's load, 512 B per edge.
+// e_attr (128 features per edge) is stored in the operand form of the mode that consumes it: per k-tile t two
+// 16-byte units per lane, loaded straight into MFMA operands, 512 B per edge.
+// 16-byte unit index of (tile, k-tile t, unit u, edge column col = lane & 15, quarter q = lane >> 4):
+// ((tile * 4 + t) * 2 + u) * 64 + col * 4 + q.  A tile-wise producer / consumer moves 1 KiB contiguous per wave
+// instruction (all 64 slots of one (tile, t, u)); the four quarters of ONE edge are adjacent, so a writer that places
+// single edges (canonical edge -> its own and its mirror's slot) writes whole 64-byte sectors.
+__device__ __forceinline__ int64_t ag_attr_unit(int64_t tile, int t, int u, int lane) {
+  return ((tile * 4 + t) * 2 + u) * 64 + (lane & 15) * 4 + (lane >> 4);
+}
 __device__ __forceinline__ void ag_store_attr(const AgIn<AG_F32>& x, float* frag, int64_t tile, int t, int lane) {
-  u32x4* p = reinterpret_cast<u32x4*>(frag) + ((tile * 4 + t) * 2) * 64 + lane;
-  p[0] = __builtin_bit_cast(u32x4, x.v[0]);
-  p[64] = __builtin_bit_cast(u32x4, x.v[1]);
+  u32x4* p = reinterpret_cast<u32x4*>(frag);
+  p[ag_attr_unit(tile, t, 0, lane)] = __builtin_bit_cast(u32x4, x.v[0]);
+  p[ag_attr_unit(tile, t, 1, lane)] = __builtin_bit_cast(u32x4, x.v[1]);
 }
 __device__ __forceinline__ void ag_store_attr(const AgIn<AG_BF3>& x, float* frag, int64_t tile, int t, int lane) {
-  u32x4* p = reinterpret_cast<u32x4*>(frag) + ((tile * 4 + t) * 2) * 64 + lane;
-  p[0] = __builtin_bit_cast(u32x4, x.hi);
-  p[64] = __builtin_bit_cast(u32x4, x.lo);
+  u32x4* p = reinterpret_cast<u32x4*>(frag);
+  p[ag_attr_unit(tile, t, 0, lane)] = __builtin_bit_cast(u32x4, x.hi);
+  p[ag_attr_unit(tile, t, 1, lane)] = __builtin_bit_cast(u32x4, x.lo);
 }
 __device__ __forceinline__ void ag_load_attr(AgIn<AG_F32>& x, const float* frag, int64_t tile, int t, int lane) {
-  const u32x4* p = reinterpret_cast<const u32x4*>(frag) + ((tile * 4 + t) * 2) * 64 + lane;
-  x.v[0] = __builtin_bit_cast(f32x4, p[0]);
-  x.v[1] = __builtin_bit_cast(f32x4, p[64]);
+  const u32x4* p = reinterpret_cast<const u32x4*>(frag);
+  x.v[0] = __builtin_bit_cast(f32x4, p[ag_attr_unit(tile, t, 0, lane)]);
+  x.v[1] = __builtin_bit_cast(f32x4, p[ag_attr_unit(tile, t, 1, lane)]);
 }
 __device__ __forceinline__ void ag_load_attr(AgIn<AG_BF3>& x, const float* frag, int64_t tile, int t, int lane) {
-  const u32x4* p = reinterpret_cast<const u32x4*>(frag) + ((tile * 4 + t) * 2) * 64 + lane;
-  x.hi = __builtin_bit_cast(bf16x8, p[0]);
-  x.lo = __builtin_bit_cast(bf16x8, p[64]);
+  const u32x4* p = reinterpret_cast<const u32x4*>(frag);
+  x.hi = __builtin_bit_cast(bf16x8, p[ag_attr_unit(tile, t, 0, lane)]);
+  x.lo = __builtin_bit_cast(bf16x8, p[ag_attr_unit(tile, t, 1, lane)]);
 }
 // Host-side launch check
 #define AG_CHECK_LAUNCH()                                         \

@@ -24,8 +24,48 @@ struct EncArgs {
   float* out_frag;       // optional: operand-form tiles
   float* out_rows;       // optional: fp32 rows, row e or row row_index[e] (< 0: none)
   const int32_t* row_index;
+  const int32_t* pos_index;   // optional (with mir_index): edge e's results go to positions pos_index[e] and, if
+  const int32_t* mir_index;   // >= 0, mir_index[e] of out_frag / row_index instead of position e
   int64_t max_tiles;
 };
+
+// Where one edge's results go (shared by the encoder kernels).
+struct AgEdgeOut {
+  int64_t p, pm;      // output positions (pm < 0: none)
+};
+__device__ __forceinline__ AgEdgeOut ag_edge_out(const int32_t* pos_index, const int32_t* mir_index, int64_t e, bool valid) {
+  if (!pos_index) return AgEdgeOut{valid ? e : (int64_t)-1, -1};
+  return AgEdgeOut{valid ? (int64_t)pos_index[e] : (int64_t)-1, valid ? (int64_t)mir_index[e] : (int64_t)-1};
+}
+template <int MODE>
+__device__ __forceinline__ void ag_emit_edge_attr(const f32x4 (&y)[8], const AgEdgeOut& o, float* out_frag, float* out_rows,
+                                                  const int32_t* row_index, bool scattered, int64_t tile, int lane) {
+  const int q = lane >> 4;
+  if (out_rows) {
+    if (o.p >= 0) {
+      const int64_t row = row_index ? (int64_t)row_index[o.p] : o.p;
+      if (row >= 0) ag_store_row<8, 0>(y, out_rows + (size_t)row * 128, q);
+    }
+    if (o.pm >= 0) {
+      const int64_t row = row_index ? (int64_t)row_index[o.pm] : o.pm;
+      if (row >= 0) ag_store_row<8, 0>(y, out_rows + (size_t)row * 128, q);
+    }
+  }
+  if (out_frag) {
+    AgIn<MODE> x[4];
+    ag_cvt_tiles<MODE, 4, 0>(y, x);
+    if (!scattered) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) ag_store_attr(x[t], out_frag, tile, t, lane);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (o.p >= 0) ag_store_attr(x[t], out_frag, o.p >> 4, t, q * 16 + (int)(o.p & 15));
+        if (o.pm >= 0) ag_store_attr(x[t], out_frag, o.pm >> 4, t, q * 16 + (int)(o.pm & 15));
+      }
+    }
+  }
+}
 
 // encoder/edge.py:84-103.  x0 = gelu(w*d+b); h1 = gelu(W1a x0 + T1[type]); h2 = gelu(W23 h1 + T3[type]);
 // a = W4 h2 + b4.  (T1/T3: per-edge-type tables holding the bond_emb halves of the two 256->128
@@ -82,15 +122,8 @@ __global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_edge_encoder(EncAr
     ag_cvt_tiles<MODE, 4, 0>(y, x);
     ag_init_vec<8>(y, a.b4, q);
     ag_dense_split<MODE, false, false, 4, 8, 0, 0, 6>(x, y, lw4, a.w4_pk, lane);
-    if (a.out_rows && valid) {
-      const int64_t row = a.row_index ? (int64_t)a.row_index[e] : e;
-      if (row >= 0) ag_store_row<8, 0>(y, a.out_rows + (size_t)row * 128, q);
-    }
-    if (a.out_frag) {
-      ag_cvt_tiles<MODE, 4, 0>(y, x);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) ag_store_attr(x[t], a.out_frag, tile, t, lane);
-    }
+    ag_emit_edge_attr<MODE>(y, ag_edge_out(a.pos_index, a.mir_index, e, valid), a.out_frag, a.out_rows, a.row_index,
+                            a.pos_index != nullptr, tile, lane);
   }
 }
 
@@ -106,6 +139,8 @@ struct GaussArgs {
   float* out_frag;
   float* out_rows;
   const int32_t* row_index;
+  const int32_t* pos_index;
+  const int32_t* mir_index;
   int64_t max_tiles;
   float coeff_log2e;
 };
@@ -125,16 +160,8 @@ __global__ void __launch_bounds__(256) k_edge_gaussian(GaussArgs a) {
   ag_load_row<4, 0>(y, a.offset, q);
   AG_FOR_TILE(y, 4, ag_exp2(a.coeff_log2e * ((d - v) * (d - v))));
   ag_load_row<4, 4>(y, a.emb + (size_t)ty * 64, q);
-  if (a.out_rows && valid) {
-    const int64_t row = a.row_index ? (int64_t)a.row_index[e] : e;
-    if (row >= 0) ag_store_row<8, 0>(y, a.out_rows + (size_t)row * 128, q);
-  }
-  if (a.out_frag) {
-    AgIn<MODE> x[4];
-    ag_cvt_tiles<MODE, 4, 0>(y, x);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) ag_store_attr(x[t], a.out_frag, tile, t, lane);
-  }
+  ag_emit_edge_attr<MODE>(y, ag_edge_out(a.pos_index, a.mir_index, e, valid), a.out_frag, a.out_rows, a.row_index,
+                          a.pos_index != nullptr, tile, lane);
 }
 
 // ------------------------------------------------------------------------------ per-edge conv scales
@@ -578,6 +605,8 @@ struct HeadArgs {
   const float* node_h;   // [N][128]
   const float* attr_frag;   // operand-form edge_attr tiles, or
   const float* attr_rows;   // fp32 rows [E][128] (exactly one of the two)
+  const int32_t* pos_index; // optional (with mir_index): edge e is position pos_index[e] of attr_frag / out, and its
+  const int32_t* mir_index; // result is also written to position mir_index[e] when that is >= 0
   float* out;            // [E]
   int64_t max_tiles;
 };
@@ -607,6 +636,8 @@ __global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_pair_head(HeadArgs
     const int64_t e = tile * AG_TW + (lane & 15);
     const bool valid = e < E;
     const int s = valid ? a.src[e] : 0, t = valid ? a.dst[e] : 0;
+    const int64_t pe = a.pos_index ? (valid ? (int64_t)a.pos_index[e] : 0) : e;     // where the edge's attrs / result live
+    const int64_t pm = (a.pos_index && valid) ? (int64_t)a.mir_index[e] : -1;
 
     // first layer over eight 32-feature k-tiles of [h_src * h_dst || edge_attr] (pkk weights)
     f32x4 y1[8];
@@ -620,6 +651,8 @@ __global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_pair_head(HeadArgs
           const f32x4 p0 = ag_ld4(hs + 32 * k + 4 * q) * ag_ld4(ht + 32 * k + 4 * q);
           const f32x4 p1 = ag_ld4(hs + 32 * k + 16 + 4 * q) * ag_ld4(ht + 32 * k + 16 + 4 * q);
           ag_cvt(p0, p1, dst);
+        } else if (a.attr_frag && a.pos_index) {
+          ag_load_attr(dst, a.attr_frag, pe >> 4, k - 4, q * 16 + (int)(pe & 15));
         } else if (a.attr_frag) {
           ag_load_attr(dst, a.attr_frag, tile, k - 4, lane);
         } else {
@@ -645,7 +678,10 @@ __global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_pair_head(HeadArgs
     }
     AG_FOR_TILE(y2, 4, ag_relu(v));
     const float o = ag_dot_vec<4>(y2, a.hp.w3, q) + a.hp.b3;
-    if (valid && q == 0) a.out[e] = o;
+    if (valid && q == 0) {
+      a.out[pe] = o;
+      if (pm >= 0) a.out[pm] = o;
+    }
   }
 }
 
@@ -694,13 +730,15 @@ extern "C" int agdiff_debug_conv_stamps(unsigned long long* out, int reset) {
 
 extern "C" int agdiff_edge_encoder(const agdiff_params_t* p, const int32_t* n_edges_dev, int64_t max_tiles,
                                    const float* e_len, const int32_t* e_type, float* attr_frag, float* attr_rows,
-                                   const int32_t* row_index, void* stream) {
-  if (!p || !n_edges_dev || !e_len || !e_type || (!attr_frag && !attr_rows) || max_tiles < 0) return AGDIFF_ERR_ARG;
+                                   const int32_t* row_index, const int32_t* pos_index, const int32_t* mir_index,
+                                   void* stream) {
+  if (!p || !n_edges_dev || !e_len || !e_type || (!attr_frag && !attr_rows) || max_tiles < 0 || (!pos_index != !mir_index))
+    return AGDIFF_ERR_ARG;
   if (max_tiles == 0) return AGDIFF_OK;
   if (p->edge_encoder == 1) {
     if (!p->ge_offset || !p->ge_emb) return AGDIFF_ERR_ARG;
-    GaussArgs g{p->ge_offset, p->ge_emb, n_edges_dev, e_len, e_type, attr_frag, attr_rows, row_index, max_tiles,
-                p->ge_coeff * 1.44269504088896340736f};
+    GaussArgs g{p->ge_offset, p->ge_emb, n_edges_dev, e_len, e_type, attr_frag, attr_rows, row_index, pos_index, mir_index,
+                max_tiles, p->ge_coeff * 1.44269504088896340736f};
     const dim3 grid((unsigned)((max_tiles + 3) / 4));
     if (p->precision == AG_BF3)
       k_edge_gaussian<AG_BF3><<<grid, dim3(256), 0, (hipStream_t)stream>>>(g);
@@ -711,7 +749,7 @@ extern "C" int agdiff_edge_encoder(const agdiff_params_t* p, const int32_t* n_ed
   }
   if (p->edge_encoder != 0) return AGDIFF_ERR_ARG;
   EncArgs a{p->ee_fe_w, p->ee_fe_b, p->ee_t1, p->ee_w1_pk, p->ee_t3, p->ee_w23_pk, p->ee_w4_pk, p->ee_b4,
-            n_edges_dev, e_len, e_type, attr_frag, attr_rows, row_index, max_tiles};
+            n_edges_dev, e_len, e_type, attr_frag, attr_rows, row_index, pos_index, mir_index, max_tiles};
   int64_t wgs = (max_tiles + AG_PERSIST_WAVES - 1) / AG_PERSIST_WAVES;
   if (wgs > 256) wgs = 256;
   const size_t smem = (size_t)80 * 2048;     // w1 (32 blocks) + w23 (32) + unit 0 of w4's 32 blocks
@@ -807,8 +845,10 @@ extern "C" int agdiff_cfconv_fused(const agdiff_params_t* p, const agdiff_topo_t
 
 extern "C" int agdiff_pair_head(const agdiff_head_params_t* hp, const int32_t* n_edges_dev, int64_t max_tiles,
                                 const int32_t* src, const int32_t* dst, const float* node_h, const float* attr_frag,
-                                const float* attr_rows, float* out, void* stream) {
-  if (!hp || !n_edges_dev || !src || !dst || !node_h || (!attr_frag == !attr_rows) || !out || max_tiles < 0)
+                                const float* attr_rows, const int32_t* pos_index, const int32_t* mir_index, float* out,
+                                void* stream) {
+  if (!hp || !n_edges_dev || !src || !dst || !node_h || (!attr_frag == !attr_rows) || !out || max_tiles < 0 ||
+      (!pos_index != !mir_index) || (pos_index && !attr_frag))
     return AGDIFF_ERR_ARG;
   if (max_tiles == 0) return AGDIFF_OK;
   HeadArgs a;
@@ -819,6 +859,8 @@ extern "C" int agdiff_pair_head(const agdiff_head_params_t* hp, const int32_t* n
   a.node_h = node_h;
   a.attr_frag = attr_frag;
   a.attr_rows = attr_rows;
+  a.pos_index = pos_index;
+  a.mir_index = mir_index;
   a.out = out;
   a.max_tiles = max_tiles;
   int64_t wgs = (max_tiles + AG_PERSIST_WAVES - 1) / AG_PERSIST_WAVES;

@@ -29,16 +29,29 @@ struct GraphArgs {
   float* e_len;
   int32_t* ref2dst;
   int32_t* e_loc;
+  // canonical edges (one per undirected pair whose two directions carry the same type, plus every unpaired edge)
+  int32_t* graph_canon_cnt;
+  const int32_t* graph_canon_ptr;
+  float* c_len;
+  int32_t* c_type;
+  int32_t* c_src;
+  int32_t* c_dst;
+  int32_t* c_pos;
+  int32_t* c_mir;
   int32_t num_graphs;
 };
 
+// Edge lengths must come out bit-identical wherever they are computed (the per-step graph build and the local-edge
+// pass feed the same encoder): hipcc lowers sqrtf differently from kernel to kernel (1 ulp apart), so the root is
+// taken in double and rounded once -- correctly rounded for every float input.
+__device__ __forceinline__ float ag_sqrt_rn(float x) { return (float)sqrt((double)x); }
+
 // d^2 exactly as the restated rule: ((dx*dx + dy*dy) + dz*dz), no FMA contraction.
 __device__ __forceinline__ float dist2_nofma(float ax, float ay, float az, float bx, float by, float bz) {
-  float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
-  float s = __fmul_rn(dx, dx);
-  s = __fadd_rn(s, __fmul_rn(dy, dy));
-  s = __fadd_rn(s, __fmul_rn(dz, dz));
-  return s;
+#pragma clang fp contract(off)
+  const float dx = ax - bx, dy = ay - by, dz = az - bz;
+  const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+  return (xx + yy) + zz;
 }
 
 extern __shared__ uint32_t ag_graph_smem[];
@@ -57,14 +70,34 @@ __global__ void __launch_bounds__(256) k_graph(GraphArgs a) {
   const int n = a.graph_ptr[g + 1] - g0;
   const int words = a.words;          // 32-bit words per mask row, even (whole 64-lane chunks)
   const int nmax = words * 32;
-  // LDS carve: pos[3 nmax] | indeg[nmax] | outdeg[nmax] | inbits[nmax][words] | locbits[nmax][words]
+  // LDS carve: pos[3 nmax] | indeg[nmax] | outdeg[nmax] | canonical indeg[nmax] | inbits[nmax][words] | locbits[nmax][words]
   float* spos = reinterpret_cast<float*>(ag_graph_smem);
   int* sin = reinterpret_cast<int*>(ag_graph_smem + 3 * nmax);
   int* sout = sin + nmax;
-  uint32_t* inbits = reinterpret_cast<uint32_t*>(sout + nmax);
+  int* scan_c = sout + nmax;
+  uint32_t* inbits = reinterpret_cast<uint32_t*>(scan_c + nmax);
   uint32_t* locbits = inbits + nmax * words;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));     // lanes below mine
+  auto bit = [&](const uint32_t* rows, int r, int c) -> bool { return (rows[r * words + (c >> 5)] >> (c & 31)) & 1u; };
+  auto rank_below = [&](const uint32_t* rows, int r, int c) -> int {   // set bits of row r below column c
+    const uint32_t* row = rows + r * words;
+    int k = __popc(row[c >> 5] & ((1u << (c & 31)) - 1u));
+    for (int w = 0; w < (c >> 5); ++w) k += __popc(row[w]);
+    return k;
+  };
+  auto local_type = [&](int i, int j) -> int {      // type of the local edge j -> i (caller checked its locbits bit)
+    return a.loc_type[a.loc_in_eid[a.loc_in_ptr[g0 + i] + rank_below(locbits, i, j)]];
+  };
+  // The directed edges j -> i and i -> j are mirrors when both exist with the same type: same length, same type,
+  // hence bit-identical edge_attr, filter and pair-head output (dualenc.py:189-211).  Canonical = the one with
+  // src < dst, or any edge without a mirror.
+  auto has_mirror = [&](int i, int j) -> bool {     // for an existing edge j -> i
+    if (!bit(inbits, j, i)) return false;
+    const bool li = bit(locbits, i, j), lj = bit(locbits, j, i);
+    if (li != lj) return false;
+    return !li || local_type(i, j) == local_type(j, i);
+  };
 
   for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) spos[i] = a.pos[3 * (size_t)g0 + i];
   // static local in-adjacency of the molecule: the thread that owns target i sets its row
@@ -104,14 +137,30 @@ __global__ void __launch_bounds__(256) k_graph(GraphArgs a) {
   }
   __syncthreads();
 
+  // canonical in-degrees (needs every row of inbits: after the barrier)
+  int wave_ctotal = 0;
+  for (int i = wave; i < n; i += nwaves) {
+    int cdeg = 0;
+    for (int c = 0; 64 * c < n; ++c) {
+      const int j = 64 * c + lane;
+      const bool e = j < n && bit(inbits, i, j);
+      const bool canon = e && (j < i || !has_mirror(i, j));
+      cdeg += __popcll(__ballot(canon));
+    }
+    if (lane == 0) scan_c[i] = cdeg;
+    wave_ctotal += cdeg;
+  }
+  __syncthreads();
+
   if (!FILL) {
-    __shared__ int wsum[4];
-    if (lane == 0) wsum[wave] = wave_total;
+    __shared__ int wsum[2][4];
+    if (lane == 0) { wsum[0][wave] = wave_total; wsum[1][wave] = wave_ctotal; }
     __syncthreads();
     if (threadIdx.x == 0) {
-      int tot = 0;
-      for (int w = 0; w < nwaves; ++w) tot += wsum[w];
+      int tot = 0, ctot = 0;
+      for (int w = 0; w < nwaves; ++w) { tot += wsum[0][w]; ctot += wsum[1][w]; }
       a.graph_edge_cnt[g] = tot;
+      a.graph_canon_cnt[g] = ctot;
     }
     return;
   }
@@ -123,18 +172,20 @@ __global__ void __launch_bounds__(256) k_graph(GraphArgs a) {
     sout[j] = c;
   }
   __syncthreads();
-  // inclusive scans of sin / sout (n <= 512): Hillis-Steele in place, two arrays together
+  // inclusive scans of sin / sout / scan_c (n <= 512): Hillis-Steele in place, three arrays together
   for (int off = 1; off < n; off <<= 1) {
-    int vi[2], vo[2], cnt = 0;
+    int vi[2], vo[2], vc[2], cnt = 0;
     for (int i = threadIdx.x; i < n; i += blockDim.x, ++cnt) {
       vi[cnt] = sin[i] + (i >= off ? sin[i - off] : 0);
       vo[cnt] = sout[i] + (i >= off ? sout[i - off] : 0);
+      vc[cnt] = scan_c[i] + (i >= off ? scan_c[i - off] : 0);
     }
     __syncthreads();
     cnt = 0;
     for (int i = threadIdx.x; i < n; i += blockDim.x, ++cnt) {
       sin[i] = vi[cnt];
       sout[i] = vo[cnt];
+      scan_c[i] = vc[cnt];
     }
     __syncthreads();
   }
@@ -151,26 +202,42 @@ __global__ void __launch_bounds__(256) k_graph(GraphArgs a) {
   for (int i = wave; i < n; i += nwaves) {
     const float xi = spos[3 * i], yi = spos[3 * i + 1], zi = spos[3 * i + 2];
     int p0 = base + (i ? sin[i - 1] : 0);
+    int cp0 = a.graph_canon_ptr[g] + (i ? scan_c[i - 1] : 0);
     int lk = a.loc_in_ptr[g0 + i];
     for (int c = 0; 64 * c < n; ++c) {
       const int j = 64 * c + lane;
       const int jj = (j < n) ? j : 0;
       const uint64_t emask = (uint64_t)inbits[i * words + 2 * c] | ((uint64_t)inbits[i * words + 2 * c + 1] << 32);
       const uint64_t lmask = (uint64_t)locbits[i * words + 2 * c] | ((uint64_t)locbits[i * words + 2 * c + 1] << 32);
-      if ((emask >> lane) & 1ull) {
+      const bool e = (emask >> lane) & 1ull;
+      const bool mir = e && has_mirror(i, j);
+      const bool canon = e && (j < i || !mir);
+      const uint64_t cmask = __ballot(canon);
+      if (e) {
         const int p = p0 + __popcll(emask & lt);
         int ty = 0, eid = -1;
         if ((lmask >> lane) & 1ull) {
           eid = a.loc_in_eid[lk + __popcll(lmask & lt)];
           ty = a.loc_type[eid];
         }
+        const float len = ag_sqrt_rn(dist2_nofma(xi, yi, zi, spos[3 * jj], spos[3 * jj + 1], spos[3 * jj + 2]));
         a.e_loc[p] = eid;
         a.e_src[p] = g0 + j;
         a.e_dst[p] = g0 + i;
         a.e_type[p] = ty;
-        a.e_len[p] = sqrtf(dist2_nofma(xi, yi, zi, spos[3 * jj], spos[3 * jj + 1], spos[3 * jj + 2]));
+        a.e_len[p] = len;
+        if (canon) {
+          const int cp = cp0 + __popcll(cmask & lt);
+          a.c_len[cp] = len;
+          a.c_type[cp] = ty;
+          a.c_src[cp] = g0 + j;
+          a.c_dst[cp] = g0 + i;
+          a.c_pos[cp] = p;
+          a.c_mir[cp] = mir ? base + (j ? sin[j - 1] : 0) + rank_below(inbits, j, i) : -1;
+        }
       }
       p0 += __popcll(emask);
+      cp0 += __popcll(cmask);
       lk += __popcll(lmask);
     }
   }
@@ -191,8 +258,13 @@ __global__ void __launch_bounds__(256) k_graph(GraphArgs a) {
 }
 
 // exclusive scan of graph_edge_cnt[G] -> graph_edge_ptr[G+1]; total -> num_edges. One workgroup.
-__global__ void __launch_bounds__(1024) k_scan_graphs(const int32_t* __restrict__ cnt, int32_t* __restrict__ ptr,
-                                                      int32_t* __restrict__ total, int G) {
+// Block 1 (if launched) does the same for the canonical counts.
+__global__ void __launch_bounds__(1024) k_scan_graphs(const int32_t* __restrict__ cnt0, int32_t* __restrict__ ptr0,
+                                                      int32_t* __restrict__ total0, const int32_t* __restrict__ cnt1,
+                                                      int32_t* __restrict__ ptr1, int32_t* __restrict__ total1, int G) {
+  const int32_t* cnt = blockIdx.x ? cnt1 : cnt0;
+  int32_t* ptr = blockIdx.x ? ptr1 : ptr0;
+  int32_t* total = blockIdx.x ? total1 : total0;
   __shared__ int wtot[16];
   __shared__ int carry_s;
   if (threadIdx.x == 0) carry_s = 0;
@@ -227,8 +299,7 @@ __global__ void k_local_lengths(const int32_t* __restrict__ src, const int32_t* 
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= L) return;
   int s = src[e], d = dst[e];
-  float dx = pos[3 * s] - pos[3 * d], dy = pos[3 * s + 1] - pos[3 * d + 1], dz = pos[3 * s + 2] - pos[3 * d + 2];
-  len[e] = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+  len[e] = ag_sqrt_rn(dist2_nofma(pos[3 * s], pos[3 * s + 1], pos[3 * s + 2], pos[3 * d], pos[3 * d + 1], pos[3 * d + 2]));
 }
 
 }  // namespace
@@ -237,7 +308,9 @@ extern "C" int agdiff_graph_build(const agdiff_topo_t* topo, const agdiff_ws_t* 
                                   void* stream) {
   if (!topo || !ws || !pos || topo->num_graphs <= 0 || topo->num_nodes <= 0) return AGDIFF_ERR_ARG;
   if (!ws->graph_edge_cnt || !ws->graph_edge_ptr || !ws->in_ptr || !ws->out_ptr || !ws->e_src || !ws->e_dst ||
-      !ws->e_type || !ws->e_len || !ws->ref2dst || !ws->e_loc || !ws->num_edges)
+      !ws->e_type || !ws->e_len || !ws->ref2dst || !ws->e_loc || !ws->num_edges || !ws->num_canon ||
+      !ws->graph_canon_cnt || !ws->graph_canon_ptr || !ws->c_len || !ws->c_type || !ws->c_src || !ws->c_dst ||
+      !ws->c_pos || !ws->c_mir)
     return AGDIFF_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   // The host (agdiff_amd/topology.py) guarantees max atoms per graph <= AGDIFF_MAX_ATOMS_PER_GRAPH and
@@ -261,13 +334,21 @@ extern "C" int agdiff_graph_build(const agdiff_topo_t* topo, const agdiff_ws_t* 
   a.e_len = ws->e_len;
   a.ref2dst = ws->ref2dst;
   a.e_loc = ws->e_loc;
+  a.graph_canon_cnt = ws->graph_canon_cnt;
+  a.graph_canon_ptr = ws->graph_canon_ptr;
+  a.c_len = ws->c_len;
+  a.c_type = ws->c_type;
+  a.c_src = ws->c_src;
+  a.c_dst = ws->c_dst;
+  a.c_pos = ws->c_pos;
+  a.c_mir = ws->c_mir;
   a.num_graphs = (int32_t)topo->num_graphs;
   const int max_atoms = (int)topo->max_atoms_per_graph;
   if (max_atoms <= 0 || max_atoms > AGDIFF_MAX_ATOMS_PER_GRAPH) return AGDIFF_ERR_LIMIT;
   a.words = 2 * ((max_atoms + 63) / 64);
   const int nmax = a.words * 32;
   const int bd = 256;
-  const size_t smem = (size_t)(3 * nmax + 2 * nmax + 2 * nmax * a.words) * 4;
+  const size_t smem = (size_t)(3 * nmax + 3 * nmax + 2 * nmax * a.words) * 4;
   if (smem > 48 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -279,7 +360,8 @@ extern "C" int agdiff_graph_build(const agdiff_topo_t* topo, const agdiff_ws_t* 
   }
   k_graph<false><<<dim3((unsigned)topo->num_graphs), dim3(bd), smem, st>>>(a);
   AG_CHECK_LAUNCH();
-  k_scan_graphs<<<1, 1024, 0, st>>>(ws->graph_edge_cnt, ws->graph_edge_ptr, ws->num_edges, (int)topo->num_graphs);
+  k_scan_graphs<<<2, 1024, 0, st>>>(ws->graph_edge_cnt, ws->graph_edge_ptr, ws->num_edges, ws->graph_canon_cnt,
+                                    ws->graph_canon_ptr, ws->num_canon, (int)topo->num_graphs);
   AG_CHECK_LAUNCH();
   k_graph<true><<<dim3((unsigned)topo->num_graphs), dim3(bd), smem, st>>>(a);
   AG_CHECK_LAUNCH();

@@ -131,6 +131,11 @@ class Workspace:
         self.in_ptr, self.out_ptr = i32(N + 1), i32(N + 1)
         self.e_src, self.e_dst, self.e_type, self.ref2dst = i32(etiles * TW), i32(etiles * TW), i32(etiles * TW), i32(etiles * TW)
         self.e_loc = i32(etiles * TW)
+        self.num_canon = i32(1)
+        self.graph_canon_cnt, self.graph_canon_ptr = i32(G), i32(G + 1)
+        self.c_len = f32(etiles * TW)
+        self.c_type, self.c_src, self.c_dst = i32(etiles * TW), i32(etiles * TW), i32(etiles * TW)
+        self.c_pos, self.c_mir = i32(etiles * TW), i32(etiles * TW)
         self.e_len = f32(etiles * TW)
         self.e_attr = f32(etiles * TW * 128)
         self.e_inv_global = f32(etiles * TW)

@@ -269,10 +269,10 @@ def main():
         P, Tp, Wp = ctypes.byref(pk.struct), ctypes.byref(topo.struct), ctypes.byref(ws.struct)
         et, lt = (topo.max_edges + 31) // 32, (topo.L + 31) // 32
         timeit("graph_build", lambda: lib.agdiff_graph_build(Tp, Wp, run.pos_p, ctypes.c_float(cfg.cutoff), stream))
-        timeit("edge_encoder", lambda: lib.agdiff_edge_encoder(P, _lib.ptr(ws.num_edges), et, _lib.ptr(ws.e_len), _lib.ptr(ws.e_type), _lib.ptr(ws.e_attr), None, None, stream))
+        timeit("edge_encoder", lambda: lib.agdiff_edge_encoder(P, _lib.ptr(ws.num_canon), et, _lib.ptr(ws.c_len), _lib.ptr(ws.c_type), _lib.ptr(ws.e_attr), _lib.ptr(ws.l_attr_rows), _lib.ptr(ws.e_loc), _lib.ptr(ws.c_pos), _lib.ptr(ws.c_mir), stream))
         timeit("node_stage_x%d" % (cfg.num_convs + 1), lambda: [lib.agdiff_schnet_node_stage(P, Tp, Wp, k, stream) for k in range(cfg.num_convs + 1)])
         timeit("cfconv_fused_x%d" % cfg.num_convs, lambda: [lib.agdiff_cfconv_fused(P, Tp, Wp, k, stream) for k in range(cfg.num_convs)])
-        timeit("head_global", lambda: lib.agdiff_pair_head(ctypes.byref(pk.struct.head_global), _lib.ptr(ws.num_edges), et, _lib.ptr(ws.e_src), _lib.ptr(ws.e_dst), _lib.ptr(ws.h), _lib.ptr(ws.e_attr), None, _lib.ptr(ws.e_inv_global), stream))
+        timeit("head_global", lambda: lib.agdiff_pair_head(ctypes.byref(pk.struct.head_global), _lib.ptr(ws.num_canon), et, _lib.ptr(ws.c_src), _lib.ptr(ws.c_dst), _lib.ptr(ws.h), _lib.ptr(ws.e_attr), None, _lib.ptr(ws.c_pos), _lib.ptr(ws.c_mir), _lib.ptr(ws.e_inv_global), stream))
         timeit("local_branch", lambda: lib.agdiff_score_forward(P, Tp, Wp, run.pos_p, 0, stream))
         timeit("score_forward_global", lambda: lib.agdiff_score_forward(P, Tp, Wp, run.pos_p, 1, stream))
         ops.update(N=topo.N, E=E, L=topo.L, G=G, ms_per_step=ms_per_step)

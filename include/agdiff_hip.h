@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 14
+#define AGDIFF_ABI_VERSION 15
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -165,6 +165,18 @@ typedef struct agdiff_ws {
   float*   e_len;            /* [max_edges] */
   int32_t* ref2dst;          /* [max_edges]: reference position q -> destination-sorted id */
   int32_t* e_loc;            /* [max_edges]: id of the edge in the local (type > 0) list, -1 for radius-only edges */
+  /* canonical edges: j -> i and i -> j with equal type have the same length and type, hence bit-identical
+   * edge_attr and pair-head output (dualenc.py:189-211); one of the two (src < dst) is canonical, as is every edge
+   * without such a mirror.  Destination-sorted like the full list; the encoder and the global head walk this list. */
+  int32_t* num_canon;        /* [1]  device scalar */
+  int32_t* graph_canon_cnt;  /* [G]  */
+  int32_t* graph_canon_ptr;  /* [G+1] */
+  float*   c_len;            /* [max_edges] */
+  int32_t* c_type;           /* [max_edges] */
+  int32_t* c_src;            /* [max_edges] */
+  int32_t* c_dst;            /* [max_edges] */
+  int32_t* c_pos;            /* [max_edges]: the canonical edge's own id in the destination-sorted list */
+  int32_t* c_mir;            /* [max_edges]: its mirror's id there, or -1 */
   float*   e_attr;           /* [ceil(max_edges/16)] tiles x 2048 floats: edge_attr in operand form (csrc/common.hpp) */
   float*   e_inv_global;     /* [max_edges] grad_global_dist_mlp output, destination-sorted */
   float*   e_scale;          /* [2*num_convs][ceil(max_edges/16)*16]: lw(d)*C(d) of conv1 / conv2 of every block (schnet.py:138-149) */
@@ -227,11 +239,13 @@ int agdiff_edge_scales(const agdiff_params_t* p, const agdiff_topo_t* topo, cons
  * (edge.py:84-103) when p->edge_encoder == 0, GaussianSmearingEdgeEncoder.forward (edge.py:34-42) when 1.
  * n_edges_dev: device scalar with the live edge count (<= max_tiles*16).  Outputs, each optional:
  *   attr_frag  operand-form edge_attr tiles;
- *   attr_rows  fp32 rows [.][128]: row e of edge e, or row row_index[e] when row_index is given (edges with
- *              row_index[e] < 0 write no row) -- how the pass over all edges also serves the local edge list. */
+ *   attr_rows  fp32 rows [.][128]: row e of edge e, or row row_index[e] when row_index is given (negative: no
+ *              row) -- how the pass over all edges also serves the local edge list.
+ * pos_index / mir_index (both or neither): the n edges are a canonical list (agdiff_ws_t.c_*); edge e's results go
+ * to position pos_index[e] and, when >= 0, mir_index[e] of attr_frag / row_index instead of position e. */
 int agdiff_edge_encoder(const agdiff_params_t* p, const int32_t* n_edges_dev, int64_t max_tiles,
                         const float* e_len, const int32_t* e_type, float* attr_frag, float* attr_rows,
-                        const int32_t* row_index, void* stream);
+                        const int32_t* row_index, const int32_t* pos_index, const int32_t* mir_index, void* stream);
 
 /* Node-side stage k of SchNetEncoder.forward (encoder/schnet.py:268-282): k == 0 embeds atoms;
  * k >= 1 finishes InteractionBlock k-1 (lin2/BN, act, lin, gate, AdaptiveScaling, residual);
@@ -244,10 +258,13 @@ int agdiff_cfconv_fused(const agdiff_params_t* p, const agdiff_topo_t* topo, con
 
 /* assemble_atom_pair_feature + grad_*_dist_mlp (models/common.py:106-109, 86-103; dualenc.py:203-211,
  * 226-239) over n edges given by (src, dst); edge_attr either as operand-form tiles (attr_frag) or as fp32
- * rows [n][128] (attr_rows) -- exactly one of the two. */
+ * rows [n][128] (attr_rows) -- exactly one of the two.  pos_index / mir_index (both or neither, with attr_frag):
+ * the n edges are a canonical list; edge e reads its attrs at position pos_index[e] and writes its result to
+ * out[pos_index[e]] and, when >= 0, out[mir_index[e]] (h_i * h_j is symmetric, so the mirror's value is the same). */
 int agdiff_pair_head(const agdiff_head_params_t* hp, const int32_t* n_edges_dev, int64_t max_tiles,
                      const int32_t* src, const int32_t* dst, const float* node_h, const float* attr_frag,
-                     const float* attr_rows, float* out, void* stream);
+                     const float* attr_rows, const int32_t* pos_index, const int32_t* mir_index, float* out,
+                     void* stream);
 
 /* GINEncoder.forward (encoder/gin.py:112-148) on the static local edges; result in ws->hl. */
 int agdiff_gin_encoder(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, void* stream);

@@ -27,16 +27,17 @@ def _gpu_model(cfg, head_scale=1e-3, precision="bf16x3"):
 
 
 def unfrag(frag, n, precision):
-    """operand-form edge-attr tiles (16 edges x 128 features, csrc/common.hpp) -> row-major [n][128] fp32."""
+    """operand-form edge attrs (csrc/common.hpp: [tile][t][u][edge column][quarter] 16-byte units) -> row-major
+    [n][128] fp32."""
     tiles = frag.numel() // (16 * 128)
-    if precision == "f32":      # [tile][t][u][q][edge][r], feature = 32t + 16u + 4q + r
-        x = frag.view(tiles, 4, 2, 4, 16, 4).permute(0, 4, 1, 2, 3, 5).reshape(tiles * 16, 128)
+    if precision == "f32":      # [tile][t][u][edge][q][r], feature = 32t + 16u + 4q + r
+        x = frag.view(tiles, 4, 2, 16, 4, 4).permute(0, 3, 1, 2, 4, 5).reshape(tiles * 16, 128)
         return x[:n]
-    # bf16x3: [tile][t][part][q][edge][u][r] bf16, feature = 32t + 16u + 4q + r, value = hi + lo
-    u = frag.view(torch.int16).view(tiles, 4, 2, 4, 16, 2, 4).to(torch.int32)
+    # bf16x3: [tile][t][part][edge][q][u][r] bf16, feature = 32t + 16u + 4q + r, value = hi + lo
+    u = frag.view(torch.int16).view(tiles, 4, 2, 16, 4, 2, 4).to(torch.int32)
     val = ((u & 0xFFFF) << 16).view(torch.float32)
-    val = val[:, :, 0] + val[:, :, 1]                           # [tile][t][q][edge][u][r]
-    x = val.permute(0, 3, 1, 4, 2, 5).reshape(tiles * 16, 128)
+    val = val[:, :, 0] + val[:, :, 1]                           # [tile][t][edge][q][u][r]
+    x = val.permute(0, 2, 1, 4, 3, 5).reshape(tiles * 16, 128)
     return x[:n]
 
 
@@ -341,6 +342,58 @@ def test_driver_end_to_end(tmp_path):
         assert np.abs(p.mean(axis=1)).max() < 1e-3            # every conformer is centred (dualenc.py:542)
         assert z["traj_%d" % i].shape == (6,) + p.shape
     driver.main(["--ckpt", ckpt, "--testset", ts, "--out", out, "--n-steps", "6", "--resume"])   # nothing left to do
+
+
+@pytest.mark.parametrize("case", ["g3_forward_qm9_small", "g3_forward_drugs_capped", "big"])
+def test_canonical_edge_list(case):
+    """agdiff_ws_t.c_*: every directed edge is either canonical or the mirror of exactly one canonical edge; a
+    mirror pair has swapped end points, equal type and bitwise equal length; unpaired edges (asymmetric 32-cap) are
+    canonical; the canonical list keeps the destination-sorted order."""
+    from agdiff_amd import _lib, synth
+    from agdiff_amd.topology import BatchTopology, Workspace
+    lib = _lib.load()
+    if case == "big":
+        b = synth.make_packed_batch("large", 1, 1, seed=5)
+        s2 = synth.make_packed_batch("drugs", 3, 2, seed=6)
+        n0 = b["atom_type"].shape[0]
+        at = np.concatenate([b["atom_type"], s2["atom_type"]])
+        bi = np.concatenate([b["bond_index"], s2["bond_index"] + n0], axis=1)
+        bt = np.concatenate([b["bond_type"], s2["bond_type"]])
+        ba = np.concatenate([b["batch"], s2["batch"] + 1])
+        pos = torch.randn(at.shape[0], 3, generator=torch.Generator().manual_seed(3)) * 2.5
+    else:
+        g = load_golden(case)
+        at, bi, bt, ba, pos = g["atom_type"], g["bond_index"], g["bond_type"], g["batch"], t(g["pos"])
+    topo = BatchTopology(at, bi, bt, ba, device="cuda")
+    ws = Workspace(topo)
+    posd = pos.cuda().contiguous()
+    assert lib.agdiff_graph_build(ctypes.byref(topo.struct), ctypes.byref(ws.struct), _lib.ptr(posd),
+                                  ctypes.c_float(10.0), _lib.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    E, C = int(ws.num_edges.item()), int(ws.num_canon.item())
+    src, dst = ws.e_src[:E].cpu().numpy(), ws.e_dst[:E].cpu().numpy()
+    ty, ln = ws.e_type[:E].cpu().numpy(), ws.e_len[:E].cpu().numpy()
+    cp, cm = ws.c_pos[:C].cpu().numpy(), ws.c_mir[:C].cpu().numpy()
+    assert 0 < C <= E and np.all(np.diff(cp) > 0)
+    assert np.array_equal(ws.c_src[:C].cpu().numpy(), src[cp]) and np.array_equal(ws.c_dst[:C].cpu().numpy(), dst[cp])
+    assert np.array_equal(ws.c_type[:C].cpu().numpy(), ty[cp]) and np.array_equal(ws.c_len[:C].cpu().numpy(), ln[cp])
+    has = cm >= 0
+    m = cm[has]
+    assert np.array_equal(src[m], dst[cp[has]]) and np.array_equal(dst[m], src[cp[has]])
+    assert np.array_equal(ty[m], ty[cp[has]]) and np.array_equal(ln[m].view(np.int32), ln[cp[has]].view(np.int32))
+    assert np.all(src[cp[has]] < dst[cp[has]])
+    cover = np.zeros(E, dtype=np.int64)
+    np.add.at(cover, cp, 1)
+    np.add.at(cover, m, 1)
+    assert np.all(cover == 1)
+    # an edge without mirror really has none: its reverse is absent or carries another type
+    key = {(int(a_), int(b_)): int(t_) for a_, b_, t_ in zip(src, dst, ty)}
+    for e in cp[~has][:2000]:
+        assert key.get((int(dst[e]), int(src[e])), -1) != int(ty[e])
+    if case != "g3_forward_qm9_small":
+        assert (~has).any()                # the 32-cap leaves unpaired edges
+    else:
+        assert C * 2 == E                  # uncapped, symmetric: exactly half
 
 
 def test_graph_build_molecules_beyond_one_wave():
