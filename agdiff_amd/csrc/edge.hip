@@ -260,7 +260,7 @@ template <int MODE>
 __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs a) {
   // LDS: all 160 KiB hold filter weights for the whole launch -- the fused first layer of both convs (96 KiB)
   // and conv1's second layer (64 KiB).  Only conv2's second layer (8 blocks = 16 KiB per tile) is streamed
-  // from L2, fetched two channel tiles ahead of its use.
+  // from L2, each pair of blocks requested one channel tile ahead of its use.
   extern __shared__ u32x4 ag_conv_smem[];
   lds_u32x4* w1 = (lds_u32x4*)ag_conv_smem;
   lds_u32x4* w2a = w1 + 48 * 128;
@@ -431,8 +431,7 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
           }
         }
       }
-      AG_STAMP(c1); st[1] += c1 - c0; c0 = c1;       // layer 1 + ssp + split
-      AG_STAMP(c1); st[2] += c1 - c0; c0 = c1;       // ssp + split
+      AG_STAMP(c1); st[1] += c1 - c0; c0 = c1;       // layer 1 + softplus + split (one pipeline)
       // Row masks of the first two targets of the tile, built once per tile: almost every 16-edge tile holds
       // the in-lists of one or two targets (in-degree >= 8), so the per-channel-tile reduction is 8 FMAs and two
       // quarter sums; tiles with more targets take the general loop.
@@ -489,7 +488,7 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
           g[b][1] = gl[((2 * pair + b) * 2 + 1) * 64];
         }
       };
-      AG_STAMP(c1); st[3] += c1 - c0; c0 = c1;       // bounds, masks
+      AG_STAMP(c1); st[2] += c1 - c0; c0 = c1;       // bounds, masks
       // second-layer MFMAs of channel tile nt (flipped: rows = edges, lanes = channels), raw accumulators
       auto dense2 = [&](int nt) -> f32x4 {
         f32x4 z[1] = {{0.f, 0.f, 0.f, 0.f}};
@@ -580,6 +579,7 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
           reduce_general(z, nt, carry[nt >> 2]);
         }
       }
+      AG_STAMP(c1); st[3] += c1 - c0; c0 = c1;       // layer 2 + message + reduction (one pipeline)
       run_t = t1;
     }
     if (run_t >= 0) {
@@ -590,7 +590,7 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs
   }  // chunk loop
 #ifdef AG_CONV_STAMPS
   if (lane0 == 0) {
-    for (int i = 0; i < 6; ++i) atomicAdd(&ag_conv_stamp_acc[i], st[i]);
+    for (int i = 0; i < 4; ++i) atomicAdd(&ag_conv_stamp_acc[i], st[i]);
     atomicAdd(&ag_conv_stamp_acc[7], 1ull);
   }
 #endif

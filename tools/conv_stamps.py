@@ -12,8 +12,8 @@ try:
 finally:
     lib.agdiff_debug_conv_stamps(buf, 1)
     v = list(buf)
-    tot = sum(v[:6])
-    names = ["meta+flush", "layer1", "ssp+split", "offsets+bounds", "layer2", "message+reduce"]
+    tot = sum(v[:4])
+    names = ["meta+flush", "layer1+softplus+split", "bounds+masks", "layer2+message+reduce"]
     print("waves", v[7])
-    for n, x in zip(names, v[:6]):
+    for n, x in zip(names, v[:4]):
         print("%-16s %6.2f %%   %.0f cycles/wave-launch" % (n, 100.0 * x / max(tot, 1), x / max(v[7], 1)))
