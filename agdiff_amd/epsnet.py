@@ -474,6 +474,12 @@ class LangevinRun:
         self.args = a
         self._nz, self._nz_base = None, 0
         self.global_steps = 0
+        # per-step scalars of dualenc.py:515,532,536 for every step of the run, evaluated once in the reference's
+        # fp32 tensor arithmetic (the loop then only touches Python floats)
+        sig = self.sigmas[torch.as_tensor(self.steps, dtype=torch.long)] if len(self.steps) else self.sigmas[:0]
+        step = self.step_lr * (sig / 0.01) ** 2
+        self._sched = list(zip(sig.tolist(), step.tolist(), torch.sqrt(step * 2).tolist(),
+                               (sig < self.global_start_sigma).tolist()))
 
     def remaining(self):
         return len(self.steps) - self.k
@@ -496,14 +502,12 @@ class LangevinRun:
             while self.k < end:
                 k, i = self.k, self.steps[self.k]
                 cur = self._noise_for(k, dev, N)
-                sig = self.sigmas[i]
-                step_size = self.step_lr * (sig / 0.01) ** 2          # dualenc.py:532, fp32 tensor math
-                use_global = bool(sig < self.global_start_sigma)       # dualenc.py:515
+                sig, step_size, noise_scale, use_global = self._sched[k]
                 a.noise = _lib.ptr(cur)
                 a.traj_out = ctypes.c_void_p(self.traj[k].data_ptr()) if self.traj is not None else ctypes.c_void_p(0)
-                a.sigma = float(sig)
-                a.step_size = float(step_size)
-                a.noise_scale = float(torch.sqrt(step_size * 2))
+                a.sigma = sig
+                a.step_size = step_size
+                a.noise_scale = noise_scale
                 a.use_global = 1 if use_global else 0
                 run_global = 1 if (use_global or not self.skip_discarded) else 0
                 self.global_steps += run_global
