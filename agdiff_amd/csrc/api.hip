@@ -2,6 +2,7 @@
 // denoising step (dualenc.py:478-545), composed from the per-op launchers.
 #include "common.hpp"
 #include <cstdlib>
+#include <mutex>
 
 extern "C" int agdiff_abi_version(void) { return AGDIFF_ABI_VERSION; }
 
@@ -49,9 +50,11 @@ struct ForkJoin {
 };
 ForkJoin& fork_join_for_current_device() {
   static ForkJoin fj[16];
+  static std::mutex mu;                      // first use may come from several host threads
   int dev = 0;
   (void)hipGetDevice(&dev);
   ForkJoin& f = fj[dev & 15];
+  std::lock_guard<std::mutex> lock(mu);
   if (!f.ok) {
     f.ok = hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) == hipSuccess &&
            hipEventCreateWithFlags(&f.fork, hipEventDisableTiming) == hipSuccess &&

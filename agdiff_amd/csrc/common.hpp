@@ -315,6 +315,20 @@ __device__ __forceinline__ void ag_load_attr(AgIn<AG_BF3>& x, const float* frag,
   x.hi = __builtin_bit_cast(bf16x8, p[ag_attr_unit(tile, t, 0, lane)]);
   x.lo = __builtin_bit_cast(bf16x8, p[ag_attr_unit(tile, t, 1, lane)]);
 }
+// Kernels that declare more than 64 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize, and HIP keeps
+// function attributes PER DEVICE: `done` has one bit per device id, so a process that drives several GPUs sets the
+// attribute on each of them (setting it twice from two threads is harmless, hence no lock).
+#include <atomic>
+template <typename... K>
+static inline bool ag_allow_big_lds(std::atomic<uint64_t>& done, size_t smem, K... kernels) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return true;
+  const bool ok = ((hipFuncSetAttribute((const void*)kernels, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess) && ...);
+  if (ok) done.fetch_or(bit, std::memory_order_release);
+  return ok;
+}
 // Host-side launch check
 #define AG_CHECK_LAUNCH()                                         \
   do {                                                            \

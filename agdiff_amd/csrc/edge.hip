@@ -753,13 +753,8 @@ extern "C" int agdiff_edge_encoder(const agdiff_params_t* p, const int32_t* n_ed
   int64_t wgs = (max_tiles + AG_PERSIST_WAVES - 1) / AG_PERSIST_WAVES;
   if (wgs > 256) wgs = 256;
   const size_t smem = (size_t)80 * 2048;     // w1 (32 blocks) + w23 (32) + unit 0 of w4's 32 blocks
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_edge_encoder<AG_BF3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_edge_encoder<AG_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-      return AGDIFF_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  if (!ag_allow_big_lds(attr_done, smem, k_edge_encoder<AG_BF3>, k_edge_encoder<AG_F32>)) return AGDIFF_ERR_LAUNCH;
   if (p->precision == AG_BF3)
     k_edge_encoder<AG_BF3><<<dim3((unsigned)wgs), dim3(64 * AG_PERSIST_WAVES), smem, (hipStream_t)stream>>>(a);
   else
@@ -828,13 +823,8 @@ extern "C" int agdiff_cfconv_fused(const agdiff_params_t* p, const agdiff_topo_t
   int64_t wgs = (max_chunks + AG_CONV_WAVES - 1) / AG_CONV_WAVES;
   if (wgs > 256) wgs = 256;
   const size_t smem = (size_t)AG_CONV_LDS_BLOCKS * 2048;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_cfconv_fused<AG_BF3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_cfconv_fused<AG_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-      return AGDIFF_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  if (!ag_allow_big_lds(attr_done, smem, k_cfconv_fused<AG_BF3>, k_cfconv_fused<AG_F32>)) return AGDIFF_ERR_LAUNCH;
   if (p->precision == AG_BF3)
     k_cfconv_fused<AG_BF3><<<dim3((unsigned)wgs), dim3(64 * AG_CONV_WAVES), smem, (hipStream_t)stream>>>(a);
   else
@@ -866,13 +856,8 @@ extern "C" int agdiff_pair_head(const agdiff_head_params_t* hp, const int32_t* n
   int64_t wgs = (max_tiles + AG_PERSIST_WAVES - 1) / AG_PERSIST_WAVES;
   if (wgs > 256) wgs = 256;
   const size_t smem = (size_t)80 * 2048;     // w1 (64 blocks) + w2 (16 blocks)
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_pair_head<AG_BF3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_pair_head<AG_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-      return AGDIFF_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  if (!ag_allow_big_lds(attr_done, smem, k_pair_head<AG_BF3>, k_pair_head<AG_F32>)) return AGDIFF_ERR_LAUNCH;
   if (hp->precision == AG_BF3)
     k_pair_head<AG_BF3><<<dim3((unsigned)wgs), dim3(64 * AG_PERSIST_WAVES), smem, (hipStream_t)stream>>>(a);
   else

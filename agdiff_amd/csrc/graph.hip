@@ -350,13 +350,8 @@ extern "C" int agdiff_graph_build(const agdiff_topo_t* topo, const agdiff_ws_t* 
   const int bd = 256;
   const size_t smem = (size_t)(3 * nmax + 3 * nmax + 2 * nmax * a.words) * 4;
   if (smem > 48 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)k_graph<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-          hipFuncSetAttribute((const void*)k_graph<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-        return AGDIFF_ERR_LAUNCH;
-      attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (!ag_allow_big_lds(attr_done, (size_t)160 * 1024, k_graph<false>, k_graph<true>)) return AGDIFF_ERR_LAUNCH;
   }
   k_graph<false><<<dim3((unsigned)topo->num_graphs), dim3(bd), smem, st>>>(a);
   AG_CHECK_LAUNCH();

@@ -395,7 +395,10 @@ __global__ void __launch_bounds__(256) k_langevin_update(UpdateArgs a) {
   for (int w = 0; w < nw; ++w) { cx += red[0][w]; cy += red[1][w]; cz += red[2][w]; anybad |= nanw[w]; }
   const float inv_n = 1.0f / (float)(n > 0 ? n : 1);
   cx *= inv_n; cy *= inv_n; cz *= inv_n;
-  if (anybad && threadIdx.x == 0) *a.nan_flag = 1;
+  if (anybad && threadIdx.x == 0) {
+    a.nan_flag[0] = 1;
+    a.nan_flag[1 + g] = 1;       // per graph: the driver re-samples only the molecules that diverged (test.py:143-181)
+  }
   for (int li = threadIdx.x; li < n; li += blockDim.x) {
     const int i = g0 + li;
     float x = a.s.scratch[3 * i] - cx, y = a.s.scratch[3 * i + 1] - cy, z = a.s.scratch[3 * i + 2] - cz;
@@ -551,10 +554,6 @@ static int ag_node_waves_per_wg(int64_t tiles) {
   if (w > 16) w = 16;
   return (int)w;
 }
-template <typename K>
-static int ag_allow_lds(K kern, size_t smem) {
-  return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess;
-}
 
 extern "C" int agdiff_schnet_node_stage(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
                                         int32_t k, void* stream) {
@@ -578,13 +577,10 @@ extern "C" int agdiff_schnet_node_stage(const agdiff_params_t* p, const agdiff_t
   const int waves = ag_node_waves_per_wg(tiles);
   const bool ldsw = tiles >= ag_node_ldsw_min_tiles();
   const size_t smem = ldsw ? (size_t)AG_NODE_LDS_BLOCKS * 2048 : 0;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (!ag_allow_lds(k_schnet_node_stage<AG_BF3, true>, (size_t)AG_NODE_LDS_BLOCKS * 2048) ||
-        !ag_allow_lds(k_schnet_node_stage<AG_F32, true>, (size_t)AG_NODE_LDS_BLOCKS * 2048))
-      return AGDIFF_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  if (!ag_allow_big_lds(attr_done, (size_t)AG_NODE_LDS_BLOCKS * 2048, k_schnet_node_stage<AG_BF3, true>,
+                        k_schnet_node_stage<AG_F32, true>))
+    return AGDIFF_ERR_LAUNCH;
   const dim3 grid((unsigned)((tiles + waves - 1) / waves)), block(64 * waves);
   hipStream_t st = (hipStream_t)stream;
   if (p->precision == AG_BF3) {
@@ -605,12 +601,9 @@ extern "C" int agdiff_gin_encoder(const agdiff_params_t* p, const agdiff_topo_t*
   const int waves = ag_node_waves_per_wg(tiles);
   const bool ldsw = tiles >= ag_node_ldsw_min_tiles();
   const size_t smem = ldsw ? (size_t)64 * 2048 : 0;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (!ag_allow_lds(k_gin_layer<AG_BF3, true>, (size_t)64 * 2048) || !ag_allow_lds(k_gin_layer<AG_F32, true>, (size_t)64 * 2048))
-      return AGDIFF_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  if (!ag_allow_big_lds(attr_done, (size_t)64 * 2048, k_gin_layer<AG_BF3, true>, k_gin_layer<AG_F32, true>))
+    return AGDIFF_ERR_LAUNCH;
   const dim3 grid((unsigned)((tiles + waves - 1) / waves)), block(64 * waves);
   // ping-pong so that the final layer lands in ws->hl
   float* bufs[2] = {ws->hl, ws->hl2};

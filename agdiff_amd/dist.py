@@ -81,8 +81,8 @@ class StepAllGather:
 
     def _snapshot(self, pos, nan_flag):
         self.stage[: self.n_local * 3].copy_(pos.reshape(-1), non_blocking=True)
-        if nan_flag is not None:
-            self.stage[-1:].copy_(nan_flag.to(torch.float32), non_blocking=True)
+        if nan_flag is not None:       # agdiff_ws_t.nan_flag: element 0 is the "any graph" flag
+            self.stage[-1:].copy_(nan_flag.reshape(-1)[:1].to(torch.float32), non_blocking=True)
 
     def wait(self):
         if self.is_cuda:
@@ -93,3 +93,94 @@ class StepAllGather:
         self.wait()
         g = self.gathered.view(self.world, self.pad)
         return [g[r, : self.sizes[r] * 3].view(-1, 3) for r in range(self.world)], bool((g[:, -1] != 0).any())
+
+
+def graph_weights(packed):
+    """(graph_sizes [G], local edges per graph [G]) of a packed batch: the inputs of shard_graphs."""
+    ba = np.asarray(packed["batch"], dtype=np.int64)
+    G = int(packed["num_graphs"])
+    sizes = np.bincount(ba, minlength=G)
+    loc = np.bincount(ba[np.asarray(packed["bond_index"])[0]], minlength=G) if np.asarray(packed["bond_type"]).size else np.zeros(G, dtype=np.int64)
+    return sizes, loc
+
+
+def shard_of(packed, rank, world):
+    """This rank's contiguous graph range of one packed batch: (dict like `packed` for the range or None when the
+    range is empty, (g0, g1), (node_lo, node_hi))."""
+    sizes, loc = graph_weights(packed)
+    g0, g1 = shard_graphs(sizes, loc, world)[rank]
+    if g1 <= g0:
+        return None, (g0, g1), (0, 0)
+    at, bi, bt, ba, lo, hi = take_graph_range(np.asarray(packed["atom_type"]), np.asarray(packed["bond_index"]),
+                                              np.asarray(packed["bond_type"]), np.asarray(packed["batch"]), g0, g1)
+    return dict(atom_type=at, bond_index=bi, bond_type=bt, batch=ba, num_graphs=g1 - g0), (g0, g1), (lo, hi)
+
+
+def sample_batch_sharded(model, packed, device, sampler_kwargs, save_traj=False, max_retry=2, log=print, group=None,
+                         pos_init=None, noise=None):
+    """driver.sample_batch for one packed batch sharded over the ranks of `group` by contiguous graph ranges
+    (SURVEY §8e): every rank samples its range, the shards' positions (+ NaN flag) are all-gathered after every
+    denoising step (StepAllGather), and the last gather is the job's result on every rank.  Molecules in which a NaN
+    appeared (on any rank) are re-sampled, sharded again, with clip_local=20 (test.py:143-181).
+    `pos_init` [N,3] / `noise` [steps,N,3] for the WHOLE batch replace the first attempt's draws (tests).
+    Returns (pos [N,3] cpu, traj or None, ok [num molecules]) like driver.sample_batch, identical on all ranks."""
+    from .driver import subset_batch
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)
+    spans = packed["spans"]
+    n_mol, N = len(spans), packed["atom_type"].shape[0]
+    pos_out = torch.full((N, 3), float("nan"))
+    traj_out = None
+    ok = np.zeros(n_mol, dtype=bool)
+    todo, clip_local = list(range(n_mol)), None
+    n_steps = int(sampler_kwargs.get("n_steps", 5000))
+    for attempt in range(max_retry):
+        sub = packed if len(todo) == n_mol else subset_batch(packed, todo)
+        mine, (g0, g1), (lo, hi) = shard_of(sub, rank, world)
+        first = attempt == 0
+        gather = StepAllGather(hi - lo, device, group)
+        if mine is None:                      # more ranks than graphs: take part in the collectives only
+            empty, zero = torch.zeros(0, 3, device=device), torch.zeros(1, dtype=torch.int32, device=device)
+            for k in range(n_steps):
+                gather(k, k, empty, zero)
+            bad_local, traj = np.zeros(0, dtype=bool), None
+        else:
+            p0 = pos_init[lo:hi].to(device) if (first and pos_init is not None) else torch.randn(hi - lo, 3).to(device)
+            run = model.begin_sampling(T(mine["atom_type"]), p0, T(mine["bond_index"]), T(mine["bond_type"]),
+                                       T(mine["batch"]), mine["num_graphs"], False, clip_local=clip_local,
+                                       save_traj=save_traj, raise_on_nan=False,
+                                       noise=(noise[:, lo:hi] if (first and noise is not None) else None),
+                                       **sampler_kwargs)
+            run.on_step = lambda k, i, pos: gather(k, i, pos, run.ws.nan_flag)
+            run.advance(run.remaining())
+            _, traj = run.finish()
+            bad_local = run.nan_graphs().numpy()
+        parts, _ = gather.result()
+        pos = torch.cat([p.cpu() for p in parts], dim=0)            # rank order == graph order
+        bad_all = [None] * world
+        dist.all_gather_object(bad_all, bad_local.tolist(), group=group)
+        bad_graph = np.array([b for part in bad_all for b in part], dtype=bool)
+        if save_traj:
+            trajs = [None] * world
+            dist.all_gather_object(trajs, None if traj is None else torch.stack(traj).numpy(), group=group)
+            traj = torch.from_numpy(np.concatenate([x for x in trajs if x is not None], axis=1))
+            if traj_out is None:
+                traj_out = torch.full((traj.shape[0], N, 3), float("nan"))
+        failed, g_off = [], 0
+        for slot, (off_s, n, g) in zip(todo, sub["spans"]):
+            off, _, _ = spans[slot]
+            if bad_graph[g_off:g_off + g].any():
+                failed.append(slot)
+            else:
+                ok[slot] = True
+                pos_out[off:off + n * g] = pos[off_s:off_s + n * g]
+                if save_traj:
+                    traj_out[:, off:off + n * g] = traj[:, off_s:off_s + n * g]
+            g_off += g
+        todo = failed
+        if not todo:
+            break
+        clip_local = 20
+        if attempt + 1 < max_retry and rank == 0:
+            log("NaN in %d of %d molecules: retrying those with local clipping." % (len(todo), len(sub["spans"])))
+    return pos_out, traj_out, ok

@@ -4,16 +4,18 @@ scripts/test.py needs PyG `Data` pickles, rdkit and easydict and samples ONE mol
 (`repeat_data(data, 2 * num_refs)`, 100-1000 conformers, test.py:135-141), which leaves an MI355X
 mostly idle.  This driver keeps its contract -- per molecule `num_confs(num_refs)` conformers,
 5000-step Langevin sampling with the same arguments, at most one retry with `clip_local=20` when a NaN
-appears (test.py:143-181), results saved after every batch, `--resume` skips finished molecules --
+appears in a molecule (test.py:143-181; only that molecule is re-sampled), results saved after every batch, `--resume` skips finished molecules --
 but reads/writes PyG-free `.npz` files and packs many molecules into each batch.
 
 Input .npz (see `save_testset`): for molecule i: `atom_type_i` [n], `edge_index_i` [2, e] and `edge_type_i` [e]
 (bond graph; already extended to order 3 like `AddHigherOrderEdges` does unless --extend-order),
-`num_refs_i` scalar, `name_i` string.  Output: `samples_<batch>.npz` with `pos_gen_<i>` [num_samples, n, 3]
-(+ `traj_<i>` [steps, num_samples, n, 3] with --save-traj) and `samples_all.npz`.
+`num_refs_i` scalar, `name_i` string.  Output: `samples_<first>_<last>.npz` per batch (named by the molecule
+indices it holds) with `pos_gen_<i>` [num_samples, n, 3] (+ `traj_<i>` [steps, num_samples, n, 3] with
+--save-traj) and the merged `samples_all.npz`, written by rank 0 after a barrier.
 
     python -m agdiff_amd.driver --ckpt ckpt.pt --testset test.npz --out out_dir [--n-steps 5000]
-    torchrun --nproc-per-node 8 -m agdiff_amd.driver ...      (molecule batches are dealt round-robin to ranks)
+    torchrun --nproc-per-node 8 -m agdiff_amd.driver ...      (each packed batch is sharded over the ranks by graph
+                                                               ranges; one RCCL all-gather of positions per step)
 """
 import argparse
 import glob
@@ -87,24 +89,178 @@ def pack_batch(mols, confs_of):
                 bond_type=np.concatenate(ts), batch=np.concatenate(bs), num_graphs=g_off, spans=spans)
 
 
-def sample_batch(model, packed, device, sampler_kwargs, save_traj=False, max_retry=2, log=print):
-    """test.py:143-181: up to `max_retry` attempts, the second one with clip_local=20."""
+def sample_batch(model, packed, device, sampler_kwargs, save_traj=False, max_retry=2, log=print, pos_init=None,
+                 noise=None):
+    """test.py:143-181 for every molecule of a packed batch: a molecule in which a NaN appeared is sampled again
+    (fresh pos_init) with clip_local=20, at most `max_retry` attempts in all, and dropped after that; the molecules
+    packed with it keep their first result -- graphs are independent on the whole path, and the update kernel flags
+    NaNs per graph (agdiff_ws_t.nan_flag).  Returns (pos [N,3] cpu, traj [steps,N,3] cpu or None, ok [num molecules]
+    bool); rows of failed molecules are NaN.  `pos_init` [N,3] / `noise` [steps,N,3] replace the first attempt's
+    random draws (parity tests).  Models without begin_sampling (test stubs) take the reference's whole-batch retry."""
     import torch
     T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)
-    at, bi, bt, ba = T(packed["atom_type"]), T(packed["bond_index"]), T(packed["bond_type"]), T(packed["batch"])
+    spans = packed["spans"]
+    n_mol = len(spans)
+    if not hasattr(model, "begin_sampling"):
+        at, bi, bt, ba = T(packed["atom_type"]), T(packed["bond_index"]), T(packed["bond_type"]), T(packed["batch"])
+        clip_local = None
+        for _ in range(max_retry):
+            try:
+                p0 = torch.randn(at.shape[0], 3).to(device) if pos_init is None else pos_init.to(device)
+                pos_gen, traj = model.langevin_dynamics_sample_diffusion(
+                    atom_type=at, pos_init=p0, bond_index=bi, bond_type=bt, batch=ba,
+                    num_graphs=packed["num_graphs"], extend_order=False, clip_local=clip_local,
+                    save_traj=save_traj, **sampler_kwargs)
+                return pos_gen.cpu(), (torch.stack(traj) if save_traj else None), np.ones(n_mol, dtype=bool)
+            except FloatingPointError:
+                clip_local = 20
+                log("Retrying with local clipping.")
+        return None, None, np.zeros(n_mol, dtype=bool)
+
+    N = packed["atom_type"].shape[0]
+    pos_out = torch.full((N, 3), float("nan"))
+    traj_out = None
+    ok = np.zeros(n_mol, dtype=bool)
+    todo = list(range(n_mol))                      # molecule slots of `packed` still to be sampled
     clip_local = None
-    for _ in range(max_retry):
-        try:
-            pos_init = torch.randn(at.shape[0], 3).to(device)
-            pos_gen, traj = model.langevin_dynamics_sample_diffusion(
-                atom_type=at, pos_init=pos_init, bond_index=bi, bond_type=bt, batch=ba,
-                num_graphs=packed["num_graphs"], extend_order=False, clip_local=clip_local,
-                save_traj=save_traj, **sampler_kwargs)
-            return pos_gen.cpu(), (torch.stack(traj) if save_traj else None)
-        except FloatingPointError:
-            clip_local = 20
-            log("Retrying with local clipping.")
-    return None, None
+    for attempt in range(max_retry):
+        sub = packed if len(todo) == n_mol else subset_batch(packed, todo)
+        at, bi, bt, ba = T(sub["atom_type"]), T(sub["bond_index"]), T(sub["bond_type"]), T(sub["batch"])
+        first = attempt == 0
+        p0 = pos_init.to(device) if (first and pos_init is not None) else torch.randn(at.shape[0], 3).to(device)
+        run = model.begin_sampling(at, p0, bi, bt, ba, sub["num_graphs"], False, clip_local=clip_local,
+                                   save_traj=save_traj, raise_on_nan=False,
+                                   noise=(noise if first else None), **sampler_kwargs)
+        run.advance(run.remaining())
+        pos, traj = run.finish()
+        pos = pos.cpu()
+        bad_graph = run.nan_graphs().numpy()
+        if save_traj:
+            traj = torch.stack(traj)
+            if traj_out is None:
+                traj_out = torch.full((traj.shape[0], N, 3), float("nan"))
+        failed, g_off = [], 0
+        for slot, (off_s, n, g) in zip(todo, sub["spans"]):
+            off, _, _ = spans[slot]
+            if bad_graph[g_off:g_off + g].any():
+                failed.append(slot)
+            else:
+                ok[slot] = True
+                pos_out[off:off + n * g] = pos[off_s:off_s + n * g]
+                if save_traj:
+                    traj_out[:, off:off + n * g] = traj[:, off_s:off_s + n * g]
+            g_off += g
+        todo = failed
+        if not todo:
+            break
+        clip_local = 20
+        if attempt + 1 < max_retry:
+            log("NaN in %d of %d molecules: retrying those with local clipping." % (len(todo), len(sub["spans"])))
+    return pos_out, traj_out, ok
+
+
+def subset_batch(packed, slots):
+    """The packed batch restricted to the molecule slots `slots` (re-based node / graph ids)."""
+    keep_nodes, spans, batch = [], [], []
+    node_off = g_off = 0
+    shift = np.zeros(packed["atom_type"].shape[0], dtype=np.int64)
+    gfirst = np.concatenate([[0], np.cumsum([g for (_, _, g) in packed["spans"]])])
+    for s in slots:
+        off, n, g = packed["spans"][s]
+        idx = np.arange(off, off + n * g)
+        keep_nodes.append(idx)
+        shift[idx] = node_off - off
+        batch.append(packed["batch"][idx] - gfirst[s] + g_off)
+        spans.append((node_off, n, g))
+        node_off += n * g
+        g_off += g
+    keep = np.concatenate(keep_nodes)
+    mask = np.zeros(packed["atom_type"].shape[0], dtype=bool)
+    mask[keep] = True
+    bi = packed["bond_index"]
+    esel = mask[bi[0]]
+    return dict(atom_type=packed["atom_type"][keep], bond_index=bi[:, esel] + shift[bi[0][esel]][None, :],
+                bond_type=packed["bond_type"][esel], batch=np.concatenate(batch), num_graphs=g_off, spans=spans)
+
+
+def _done_indices(out_dir):
+    done = set()
+    for f in glob.glob(os.path.join(out_dir, "samples_[0-9]*.npz")):
+        done.update(int(k.split("_")[-1]) for k in np.load(f).files if k.startswith("pos_gen_"))
+    return done
+
+
+def _batch_path(out_dir, bmols):
+    """Output file of one batch, named by what it holds (first / last molecule index of the batch), never by a
+    batch counter: a --resume run plans its batches over the molecules still missing, and a counter restarting at 0
+    would overwrite files of the earlier run that hold other, finished molecules."""
+    base = os.path.join(out_dir, "samples_%05d_%05d" % (bmols[0]["index"], bmols[-1]["index"]))
+    path, k = base + ".npz", 0
+    while os.path.exists(path):
+        k += 1
+        path = "%s_r%d.npz" % (base, k)
+    return path
+
+
+def _save_npz_atomic(path, arrays):
+    tmp = path[:-4] + ".tmp.npz"
+    np.savez_compressed(tmp, **arrays)
+    os.replace(tmp, path)
+
+
+def merge_outputs(out_dir):
+    merged = {}
+    for f in sorted(glob.glob(os.path.join(out_dir, "samples_[0-9]*.npz"))):
+        z = np.load(f)
+        merged.update({k: z[k] for k in z.files})
+    _save_npz_atomic(os.path.join(out_dir, "samples_all.npz"), merged)
+    return merged
+
+
+def run_job(model, mols, out_dir, confs_of, max_atoms, sampler_kwargs, device, save_traj=False, resume=False,
+            rank=0, world=1, shard=False, log=print):
+    """Plan, sample and save (the loop of scripts/test.py:128-181 over packed batches).  Returns the merged result
+    dict on rank 0 (None elsewhere)."""
+    import torch.distributed as dist
+    os.makedirs(out_dir, exist_ok=True)
+    done = set()
+    if resume:
+        # every rank must plan the same batches: rank 0 lists the finished molecules, the others take its list
+        box = [sorted(_done_indices(out_dir)) if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        done = set(box[0])
+    mols = [m for m in mols if m["index"] not in done]
+    batches = plan_batches(mols, confs_of, max_atoms * (world if shard else 1))
+    for bidx, bmols in enumerate(batches):
+        if not shard and bidx % world != rank:
+            continue
+        packed = pack_batch(bmols, confs_of)
+        if shard:
+            from .dist import sample_batch_sharded
+            pos, traj, ok = sample_batch_sharded(model, packed, device, sampler_kwargs, save_traj=save_traj, log=log)
+            if rank != 0:
+                continue
+        else:
+            pos, traj, ok = sample_batch(model, packed, device, sampler_kwargs, save_traj=save_traj, log=log)
+        if not ok.any():
+            log("batch %d: every molecule failed twice (NaN); skipped: %s" % (bidx, [m["name"] for m in bmols]))
+            continue
+        out = {}
+        for m, (off, n, g), good in zip(bmols, packed["spans"], ok):
+            if not good:
+                log("molecule %s failed twice (NaN); skipped" % m["name"])
+                continue
+            out["pos_gen_%d" % m["index"]] = pos[off:off + n * g].numpy().reshape(g, n, 3)
+            out["name_%d" % m["index"]] = np.str_(m["name"])
+            if traj is not None:
+                out["traj_%d" % m["index"]] = traj[:, off:off + n * g].numpy().reshape(traj.shape[0], g, n, 3)
+        _save_npz_atomic(_batch_path(out_dir, bmols), out)
+        log("rank %d: batch %d/%d (%d of %d molecules, %d conformers) saved" % (rank, bidx + 1, len(batches),
+                                                                               int(ok.sum()), len(bmols), packed["num_graphs"]))
+    if world > 1:
+        dist.barrier()                       # every rank's batch files are on disk
+    return merge_outputs(out_dir) if rank == 0 else None
 
 
 def main(argv=None):
@@ -122,22 +278,34 @@ def main(argv=None):
     ap.add_argument("--save-traj", action="store_true")
     ap.add_argument("--resume", action="store_true")
     ap.add_argument("--extend-order", action="store_true", help="input holds raw bonds: extend to order 3 first")
-    ap.add_argument("--max-atoms", type=int, default=50000, help="atoms per packed batch")
+    ap.add_argument("--max-atoms", type=int, default=50000, help="atoms per packed batch and GPU")
     ap.add_argument("--seed", type=int, default=2021)
     ap.add_argument("--precision", default=None, choices=[None, "f32", "bf16x3"])
+    ap.add_argument("--dist-mode", default="shard", choices=["shard", "batches"],
+                    help="with several ranks: 'shard' = every packed batch (max-atoms x world atoms) is split into "
+                         "contiguous graph ranges, one per rank, with an RCCL all-gather of the positions after each "
+                         "denoising step (BASELINE.json north_star); 'batches' = whole batches dealt round-robin")
+    ap.add_argument("--trust-ckpt", action="store_true", help="unpickle arbitrary classes from the checkpoint")
     args = ap.parse_args(argv)
 
     import torch
-    from . import get_model
+    import torch.distributed as dist
+    from . import compat, get_model
     from .synth import extend_graph_order_np
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(device)
+    own_pg = False
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        own_pg = True
     torch.manual_seed(args.seed + rank)
     np.random.seed(args.seed + rank)
-    ckpt = torch.load(args.ckpt, map_location="cpu", weights_only=False)
-    cfg = ckpt["config"].model if hasattr(ckpt["config"], "model") else ckpt["config"]["model"]
+    ckpt = compat.load_checkpoint(args.ckpt, trust=args.trust_ckpt)
+    cfg = compat.model_config(ckpt)
     model = get_model(cfg)
     if args.precision:
         model.precision = args.precision
@@ -150,39 +318,12 @@ def main(argv=None):
             r, c, t = extend_graph_order_np(m["atom_type"].shape[0], m["edge_index"][0], m["edge_index"][1],
                                             m["edge_type"], order=cfg.edge_order)
             m["edge_index"], m["edge_type"] = np.stack([r, c]), t
-    os.makedirs(args.out, exist_ok=True)
-    done = set()
-    if args.resume:
-        for f in glob.glob(os.path.join(args.out, "samples_*.npz")):
-            done.update(int(k.split("_")[-1]) for k in np.load(f).files if k.startswith("pos_gen_"))
-    mols = [m for m in mols if m["index"] not in done]
-    confs_of = num_confs(args.num_confs)
-    batches = plan_batches(mols, confs_of, args.max_atoms)
     kw = dict(n_steps=args.n_steps, step_lr=1e-6, w_global=args.w_global, global_start_sigma=args.global_start_sigma,
               clip=args.clip)
-    for bidx, bmols in enumerate(batches):
-        if bidx % world != rank:
-            continue
-        packed = pack_batch(bmols, confs_of)
-        pos, traj = sample_batch(model, packed, device, kw, save_traj=args.save_traj)
-        if pos is None:
-            print("batch %d failed twice (NaN); skipped: %s" % (bidx, [m["name"] for m in bmols]))
-            continue
-        out = {}
-        for m, (off, n, g) in zip(bmols, packed["spans"]):
-            out["pos_gen_%d" % m["index"]] = pos[off:off + n * g].numpy().reshape(g, n, 3)
-            out["name_%d" % m["index"]] = np.str_(m["name"])
-            if traj is not None:
-                out["traj_%d" % m["index"]] = traj[:, off:off + n * g].numpy().reshape(traj.shape[0], g, n, 3)
-        np.savez_compressed(os.path.join(args.out, "samples_%05d.npz" % bidx), **out)
-        print("rank %d: batch %d/%d (%d molecules, %d conformers) saved" % (rank, bidx + 1, len(batches), len(bmols),
-                                                                            packed["num_graphs"]))
-    if world == 1:
-        merged = {}
-        for f in sorted(glob.glob(os.path.join(args.out, "samples_[0-9]*.npz"))):
-            z = np.load(f)
-            merged.update({k: z[k] for k in z.files})
-        np.savez_compressed(os.path.join(args.out, "samples_all.npz"), **merged)
+    run_job(model, mols, args.out, num_confs(args.num_confs), args.max_atoms, kw, device, save_traj=args.save_traj,
+            resume=args.resume, rank=rank, world=world, shard=(world > 1 and args.dist_mode == "shard"))
+    if own_pg:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

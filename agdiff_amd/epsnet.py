@@ -242,10 +242,13 @@ class DualEncoderEpsNetwork(nn.Module):
     def _renorm_embedding(self, atom_type):
         # nn.Embedding(max_norm=10) renormalises looked-up rows in place on every forward, also in
         # eval mode (schnet.py:254,271); same ATen op, same side effect on the state_dict.
+        # embedding_renorm_ bumps the weight's version counter even when no row changes, so the packed weights are
+        # looked up BEFORE it (a validation loop calling forward() per batch must not repack 854 tensors every
+        # call); the renormed rows are then pushed into the packed copy and the key refreshed.
+        pk = self.packed()
         w = self.encoder_global.embedding.weight
         with torch.no_grad():
             torch.embedding_renorm_(w, atom_type.reshape(-1).long().to(w.device), 10.0, 2.0)
-        pk = self.packed()
         pk.update_schnet_embedding(w)
         self._packed_key = self._weights_key()
         return pk
@@ -419,6 +422,12 @@ class DualEncoderEpsNetwork(nn.Module):
           nan_check_every  host polls the device NaN flag every this many steps (default 64)
           step_indices     explicit list of schedule indices to visit instead of the last n_steps
           on_step          callback(k, i, pos) after each step is enqueued (data-parallel gather)
+          raise_on_nan     False -> never raise FloatingPointError; the caller reads LangevinRun.nan_graphs()
+                           (graphs are independent, so the others' results stay valid: agdiff_amd/driver.py)
+        Random draws: without `noise`, standard normals come from torch.randn on the module's device generator in
+        chunks of 128 steps ([128, N, 3] per call) instead of one torch.randn_like(pos) per step (dualenc.py:529);
+        same distribution, but a different consumption of the Philox stream -- runs with equal seeds are not
+        sample-for-sample comparable with the reference (parity tests inject `noise` on both sides).
         """
         run = self.begin_sampling(atom_type, pos_init, bond_index, bond_type, batch, num_graphs, extend_order,
                                   extend_radius, n_steps, step_lr, clip, clip_local, clip_pos, global_start_sigma,
@@ -443,7 +452,7 @@ class LangevinRun:
     def __init__(self, model, atom_type, pos_init, bond_index, bond_type, batch, num_graphs, extend_order,
                  n_steps, step_lr, clip, clip_local, clip_pos, global_start_sigma, w_global, noise=None,
                  save_traj=True, skip_discarded_global=True, nan_check_every=64, step_indices=None, on_step=None,
-                 extend_radius=True, **_ignored):
+                 extend_radius=True, raise_on_nan=True, **_ignored):
         self.model, self.lib = model, _lib.load()
         dev = model._device()
         self.sigmas = ((1.0 - model.alphas).sqrt() / model.alphas.sqrt()).detach().cpu()
@@ -460,6 +469,7 @@ class LangevinRun:
         self.noise, self.on_step = noise, on_step
         self.step_lr, self.global_start_sigma = step_lr, global_start_sigma
         self.skip_discarded, self.nan_every = bool(skip_discarded_global), int(nan_check_every)
+        self.raise_on_nan = bool(raise_on_nan)
         self.k = 0
         self.ws.nan_flag.zero_()
         self.pos_p = _lib.ptr(self.pos)
@@ -520,13 +530,18 @@ class LangevinRun:
                 self.k += 1
                 if self.on_step is not None:
                     self.on_step(k, i, self.pos)
-                if self.k % self.nan_every == 0 or self.k == len(self.steps):
+                if self.raise_on_nan and (self.k % self.nan_every == 0 or self.k == len(self.steps)):
                     self.check_nan()
 
     def check_nan(self):
-        if int(self.ws.nan_flag.item()) != 0:
+        """dualenc.py:539-541.  ws.nan_flag[0] is set by the update kernel as soon as any position is NaN."""
+        if self.raise_on_nan and int(self.ws.nan_flag[0].item()) != 0:
             print("NaN detected. Please restart.")
             raise FloatingPointError()
+
+    def nan_graphs(self):
+        """Bool tensor [G] (host): graphs in which a position became NaN so far (ws.nan_flag[1 + g])."""
+        return self.ws.nan_flag[1:1 + self.topo.G].cpu() != 0
 
     def finish(self):
         """(pos on device, pos_traj list of CPU tensors) as dualenc.py:547 returns them."""

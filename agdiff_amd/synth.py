@@ -140,10 +140,10 @@ def extend_graph_order_np(n, bond_src, bond_dst, bond_type, order=3, num_types=N
     return r.astype(np.int64), c.astype(np.int64), tnew[r, c].astype(np.int64)
 
 
-def random_molecule(rng, n):
+def random_bonds(rng, n):
     """Random tree over n atoms (parent uniform among the previous 3 indices) plus n//10 ring
-    closures between atoms <= 6 apart. Returns atom_type[n], and the symmetric
-    order-3-extended edge list (row, col, type) sorted by (row, col)."""
+    closures between atoms <= 6 apart. Returns atom_type[n] and the raw symmetric
+    bond list (row, col, type), both directions of every bond, in generation order."""
     atom_type = rng.choice(_ATOM_CHOICES, size=n, p=_ATOM_P).astype(np.int64)
     pairs = set()
     for a in range(1, n):
@@ -159,6 +159,16 @@ def random_molecule(rng, n):
     src = np.array([p[0] for p in pairs] + [p[1] for p in pairs], dtype=np.int64)
     dst = np.array([p[1] for p in pairs] + [p[0] for p in pairs], dtype=np.int64)
     typ = np.concatenate([bt, bt])
+    return atom_type, src, dst, typ
+
+
+def random_molecule(rng, n, raw_bonds=False):
+    """random_bonds + the order-3 extension AddHigherOrderEdges applies to every data set item
+    (utils/transforms.py:12-71): atom_type[n] and the symmetric edge list (row, col, type) sorted by
+    (row, col).  raw_bonds=True returns the bond list as it is (for forward(extend_order=True))."""
+    atom_type, src, dst, typ = random_bonds(rng, n)
+    if raw_bonds:
+        return atom_type, src, dst, typ
     r, c, t = extend_graph_order_np(n, src, dst, typ, order=3)
     return atom_type, r, c, t
 
@@ -207,7 +217,7 @@ def sample_n_atoms(rng, kind):
     raise ValueError(kind)
 
 
-def make_packed_batch(kind, num_molecules, copies, seed=2021):
+def make_packed_batch(kind, num_molecules, copies, seed=2021, raw_bonds=False):
     """Pack `num_molecules` distinct synthetic molecules, each replicated copies(rng) times,
     into one batch the way scripts/test.py builds a per-molecule batch (but many molecules per
     batch so that one GPU is filled). `copies` is an int or a callable rng -> int.
@@ -218,7 +228,7 @@ def make_packed_batch(kind, num_molecules, copies, seed=2021):
     node_off, g_off = 0, 0
     for m in range(num_molecules):
         n = sample_n_atoms(rng, kind)
-        at, r, c, t = random_molecule(rng, n)
+        at, r, c, t = random_molecule(rng, n, raw_bonds=raw_bonds)
         g = copies(rng) if callable(copies) else int(copies)
         a2, r2, c2, t2, b2 = repeat_molecule(at, r, c, t, g, node_off, g_off)
         ats.append(a2); rs.append(r2); cs.append(c2); ts.append(t2); bs.append(b2)

@@ -145,7 +145,7 @@ class Workspace:
         self.h, self.xs, self.agg = f32(N * 128), f32(N * 192), f32(N * 192)
         self.agg_first = f32(chunks * 192)
         self.hl, self.hl2 = f32(N * 128), f32(N * 128)
-        self.nan_flag = i32(1)
+        self.nan_flag = i32(1 + G)
         self.scratch = f32(N * 3)
         w = _lib.Workspace()
         for f, _ in _lib.Workspace._fields_:

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 15
+#define AGDIFF_ABI_VERSION 16
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -194,7 +194,8 @@ typedef struct agdiff_ws {
                                 already open when the chunk started; the node stage adds them in chunk order */
   float*   hl;               /* [N][128] GIN node state (ping) */
   float*   hl2;              /* [N][128] (pong) */
-  int32_t* nan_flag;         /* [1] set to 1 when a position becomes NaN */
+  int32_t* nan_flag;         /* [1 + G]: [0] set to 1 when any position becomes NaN, [1 + g] when one of graph g does
+                                (sticky: the host clears them when a sampling job starts) */
 } agdiff_ws_t;
 
 typedef struct agdiff_step_args {

@@ -16,3 +16,18 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Parity figures measured by this session (tests/helpers.py:check_close) -> gpurun_out/parity_errors.json."""
+    import json
+    try:
+        import helpers
+    except Exception:
+        return
+    if not helpers._RECORDS:
+        return
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_errors.json"), "w") as f:
+        json.dump(helpers._RECORDS, f, indent=1)

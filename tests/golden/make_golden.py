@@ -301,15 +301,42 @@ def g_forward_variants():
     save("g11_forward_variants", **rec)
 
 
+def g_extend_order_forward():
+    """§8f-1 on the model path: RAW bonds + extend_order=True (forward's default, dualenc.py:153,167-177 ->
+    _extend_graph_order, common.py:135-205, applied to the whole batch) for one forward and one sampler run."""
+    cfg = drugs_model_config(num_diffusion_timesteps=12)
+    m = build_ref(cfg)
+    b = synth.make_packed_batch("qm9", 3, 2, seed=51, raw_bonds=True)
+    at, bi, bt, ba = T(b["atom_type"]), T(b["bond_index"]), T(b["bond_type"]), T(b["batch"])
+    g = torch.Generator().manual_seed(51)
+    pos = torch.randn(at.shape[0], 3, generator=g) * 1.7
+    with torch.no_grad():
+        out = m(at, pos, bi, bt, ba, None, return_edges=True, extend_order=True, extend_radius=True)
+    rec = dict(atom_type=at, pos=pos, bond_index=bi, bond_type=bt, batch=ba, num_graphs=b["num_graphs"])
+    for k, v in zip(("edge_inv_global", "edge_inv_local", "edge_index", "edge_type", "edge_length", "local_edge_mask"), out):
+        rec[k] = v
+    n_steps = 12
+    pos_init = torch.randn(at.shape[0], 3, generator=g)
+    noise = torch.randn(n_steps, at.shape[0], 3, generator=g)
+    ref_dualenc.tqdm = lambda it, **k: it
+    with NoiseInjector(noise):
+        p, traj = m.langevin_dynamics_sample_diffusion(at, pos_init, bi, bt, ba, b["num_graphs"], extend_order=True,
+                                                       n_steps=n_steps, step_lr=1e-6, w_global=1.0,
+                                                       global_start_sigma=0.5, clip=1000.0)
+    rec.update(pos_init=pos_init, noise=noise, pos_final=p, traj=torch.stack(traj), n_steps=n_steps)
+    save("g12_extend_order_forward", **rec)
+
+
 def g_losses():
     g_loss("g10_loss_qm9", qm9_model_config(), "qm9", 31, 3, 2, 1.6)
     g_loss("g10_loss_drugs", drugs_model_config(), "drugs", 32, 2, 2, 2.5)
 
 
 if __name__ == "__main__":
-    if sys.argv[1:] and all(a in ("gaussian", "alanine", "loss", "variants") for a in sys.argv[1:]):   # add without touching the others
+    if sys.argv[1:] and all(a in ("gaussian", "alanine", "loss", "variants", "extend") for a in sys.argv[1:]):   # add without touching the others
         for a in sys.argv[1:]:
-            {"gaussian": g_gaussian, "alanine": g_alanine, "loss": g_losses, "variants": g_forward_variants}[a]()
+            {"gaussian": g_gaussian, "alanine": g_alanine, "loss": g_losses, "variants": g_forward_variants,
+             "extend": g_extend_order_forward}[a]()
         sys.exit(0)
     g_schedule_and_keys()
     # G2+G3 uncapped QM9-shaped batch with per-stage outputs (small: 3 molecules x 1 copy)
@@ -332,3 +359,4 @@ if __name__ == "__main__":
     g_alanine()
     g_losses()
     g_forward_variants()
+    g_extend_order_forward()

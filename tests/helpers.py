@@ -28,6 +28,47 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
+def elem_err(a, b, floor_frac=1e-3):
+    """Element-wise figure: max_i |a_i - b_i| / max(|b_i|, floor), floor = floor_frac * max|b| -- a value
+    much smaller than the tensor's scale is measured against the floor instead of against itself."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if a.size == 0 and b.size == 0:
+        return 0.0
+    floor = max(floor_frac * np.abs(b).max(), 1e-30)
+    return float((np.abs(a - b) / np.maximum(np.abs(b), floor)).max())
+
+
+# Parity gates of the HIP path per arithmetic mode (tests/test_hip_parity.py, tests/test_hip_kernels.py).
+# BASELINE.json's north_star asks for 1e-4 relative fp32; the two modes are gated a small factor above what they
+# measure on MI355X (profiles/r02_parity_errors.json: exact-fp32 MFMA ~1e-6 normwise on the fixtures, split-bf16
+# ~1.5e-5; element-wise with the 1e-3 floor 5e-4 / 1.2e-2), so that a regression of half an order of magnitude
+# turns the suite red.  A call site that needs more room says why and passes `scale`.
+TOL_NORM = {"f32": 5e-6, "bf16x3": 3e-5}
+TOL_ELEM = {"f32": 2e-3, "bf16x3": 3e-2}
+# measuring runs only: AGDIFF_PARITY_GATE_SCALE=100 records the figures without gating them at the product tolerances
+_GATE_SCALE = float(os.environ.get("AGDIFF_PARITY_GATE_SCALE", "1"))
+_RECORDS = []
+
+
+def check_close(name, got, ref, precision, scale=1.0):
+    """Assert both parity figures for `got` vs `ref` in mode `precision`, and record them (dumped to
+    gpurun_out/parity_errors.json at session end by conftest.py).  `scale` loosens both gates for quantities that
+    accumulate over several steps / layers (stated at the call site)."""
+    if hasattr(got, "detach"):
+        got = got.detach().cpu().numpy()
+    if hasattr(ref, "detach"):
+        ref = ref.detach().cpu().numpy()
+    scale = scale * _GATE_SCALE
+    rn, re_ = rel_err(got, ref), elem_err(got, ref)
+    _RECORDS.append({"name": name, "precision": precision, "normwise": rn, "elementwise": re_,
+                     "gate_norm": TOL_NORM[precision] * scale, "gate_elem": TOL_ELEM[precision] * scale})
+    print("parity %-48s %-7s normwise %.2e  elementwise %.2e" % (name, precision, rn, re_))
+    assert rn < TOL_NORM[precision] * scale, "%s (%s): normwise %.3e" % (name, precision, rn)
+    assert re_ < TOL_ELEM[precision] * scale, "%s (%s): element-wise %.3e" % (name, precision, re_)
+    return rn
+
+
 FORWARD_CASES = {
     "g3_forward_qm9_small": lambda: qm9_model_config(),
     "g3_forward_smooth_sparse": lambda: drugs_model_config(),

@@ -56,3 +56,75 @@ def test_step_all_gather_world2_gloo():
     out = mgr.dict()
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     assert out[0] == 1 and out[1] == 1
+
+
+def test_shards_reassemble_to_the_unsharded_topology():
+    """shard_graphs + take_graph_range on a real packed batch: the shards' static topologies (graph offsets, local
+    edge lists in reference order, their types, capacity bounds) concatenate to the unsharded batch's topology."""
+    from agdiff_amd.dist import shard_of
+    from agdiff_amd.topology import BatchTopology
+    b = synth.make_packed_batch("drugs", 5, lambda rng: int(rng.integers(1, 4)), seed=17)
+    full = BatchTopology(b["atom_type"], b["bond_index"], b["bond_type"], b["batch"], device="cpu")
+    for world in (2, 3, 8, 16):               # 16 > number of graphs for some seeds: empty shards are allowed
+        gp, src, dst, typ, at, me = [np.zeros(1, dtype=np.int64)], [], [], [], [], 0
+        covered = 0
+        for rank in range(world):
+            mine, (g0, g1), (lo, hi) = shard_of(b, rank, world)
+            assert g0 == covered
+            covered = g1
+            if mine is None:
+                assert g1 == g0
+                continue
+            tp = BatchTopology(mine["atom_type"], mine["bond_index"], mine["bond_type"], mine["batch"], device="cpu")
+            assert tp.G == g1 - g0 and tp.N == hi - lo
+            gp.append(tp.graph_ptr.numpy()[1:].astype(np.int64) + lo)
+            src.append(tp.loc_src.numpy().astype(np.int64) + lo); dst.append(tp.loc_dst.numpy().astype(np.int64) + lo)
+            typ.append(tp.loc_type.numpy()); at.append(tp.atom_type.numpy())
+            me += tp.max_edges
+        assert covered == b["num_graphs"]
+        assert np.array_equal(np.concatenate(gp), full.graph_ptr.numpy())
+        assert np.array_equal(np.concatenate(src), full.loc_src.numpy()) and np.array_equal(np.concatenate(dst), full.loc_dst.numpy())
+        assert np.array_equal(np.concatenate(typ), full.loc_type.numpy()) and np.array_equal(np.concatenate(at), full.atom_type.numpy())
+        assert me == full.max_edges
+
+
+def _shard_worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_driver_cpu import _FakeSampler, _mols
+    from agdiff_amd import driver
+    from agdiff_amd.dist import sample_batch_sharded
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mols = _mols(5)
+        mols[3]["atom_type"] = mols[3]["atom_type"].copy()
+        mols[3]["atom_type"][:] = 9
+        packed = driver.pack_batch(mols, driver.num_confs("3"))
+        N = packed["atom_type"].shape[0]
+        g = torch.Generator().manual_seed(5)
+        p0 = torch.randn(N, 3, generator=g)
+        model = _FakeSampler(nan_type=9)
+        pos, traj, ok = sample_batch_sharded(model, packed, "cpu", dict(n_steps=3), save_traj=True, log=lambda s: None,
+                                             pos_init=p0)
+        ref_model = _FakeSampler(nan_type=-1)                       # unsharded, nothing diverges
+        ref, _, _ = driver.sample_batch(ref_model, packed, "cpu", dict(n_steps=3), pos_init=p0, log=lambda s: None)
+        off, n, gg = packed["spans"][3]
+        keep = torch.ones(N, dtype=torch.bool)
+        keep[off:off + n * gg] = False
+        good = bool(ok.all()) and torch.equal(pos[keep], ref[keep]) and bool(torch.isfinite(pos).all())
+        good = good and traj.shape == (3, N, 3) and torch.equal(traj[-1][keep], ref[keep])
+        # first attempt: this rank's share of the 15 graphs; second: its share of molecule 3's three conformers
+        good = good and len(model.calls) == 2 and model.calls[0][1] is None and model.calls[1][1] == 20
+        out[rank] = (int(good), model.calls[0][0], model.calls[1][0])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_sampling_matches_unsharded_world2_gloo():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_shard_worker, args=(2, port, out), nprocs=2, join=True)
+    assert out[0][0] == 1 and out[1][0] == 1
+    assert out[0][1] + out[1][1] == 15 and out[0][2] + out[1][2] == 3      # graphs of both attempts, split over the ranks

@@ -1,6 +1,7 @@
 """CPU: host logic of the sampling driver (scripts/test.py counterpart): test-set file format, batch
 planning / packing, retry-on-NaN.  The model is a stub; nothing here computes on a GPU."""
 import numpy as np
+import pytest
 import torch
 
 from agdiff_amd import driver, synth
@@ -59,11 +60,181 @@ class _StubModel:
         return torch.zeros(n, 3), [torch.zeros(n, 3)] * 2
 
 
-def test_retry_with_local_clipping():
+def test_retry_with_local_clipping_whole_batch_models():
+    """A model without begin_sampling (the reference's own module would be one) gets test.py:143-181 as written."""
     packed = driver.pack_batch(_mols(2), driver.num_confs("1"))
     m = _StubModel(fail_first=True)
-    pos, traj = driver.sample_batch(m, packed, "cpu", dict(n_steps=2), save_traj=True, log=lambda s: None)
-    assert m.calls == [None, 20] and pos.shape == (packed["atom_type"].shape[0], 3) and traj.shape[0] == 2
+    pos, traj, ok = driver.sample_batch(m, packed, "cpu", dict(n_steps=2), save_traj=True, log=lambda s: None)
+    assert m.calls == [None, 20] and pos.shape == (packed["atom_type"].shape[0], 3) and traj.shape[0] == 2 and ok.all()
     m2 = _StubModel(fail_first=False)
     driver.sample_batch(m2, packed, "cpu", dict(n_steps=2))
     assert m2.calls == [None]
+
+
+class _FakeRun:
+    """Stands where epsnet.LangevinRun does: positions = 100 * (molecule fingerprint) + atom index; a graph is
+    flagged NaN when its first atom type equals `nan_type` and no local clipping is requested."""
+
+    def __init__(self, owner, at, pos_init, batch, G, clip_local, save_traj, n_steps, on_step=None):
+        self.owner, self.at, self.p0, self.batch, self.G = owner, at, pos_init, batch, G
+        self.clip_local, self.save_traj, self.n_steps, self.on_step = clip_local, save_traj, n_steps, on_step
+        self.ws = type("W", (), {"nan_flag": torch.zeros(1 + G, dtype=torch.int32)})()
+
+    def remaining(self):
+        return self.n_steps
+
+    def advance(self, m):
+        self.pos = self.p0 * 0.5 + self.at.to(torch.float32)[:, None]
+        for k in range(m):
+            if self.on_step is not None:
+                self.on_step(k, k, self.pos)
+
+    def finish(self):
+        return self.pos, ([self.pos.clone()] * self.n_steps if self.save_traj else [])
+
+    def nan_graphs(self):
+        first = torch.zeros(self.G, dtype=torch.long).scatter_reduce(0, self.batch, self.at, "amin", include_self=False)
+        return (first == self.owner.nan_type) & torch.tensor(self.clip_local is None)
+
+
+class _FakeSampler:
+    def __init__(self, nan_type=-1):
+        self.nan_type, self.calls = nan_type, []
+
+    def begin_sampling(self, at, pos_init, bi, bt, batch, G, extend_order, clip_local=None, save_traj=True,
+                       raise_on_nan=True, noise=None, n_steps=2, **kw):
+        assert raise_on_nan is False and extend_order is False
+        self.calls.append((int(G), clip_local))
+        return _FakeRun(self, at, pos_init, batch, G, clip_local, save_traj, n_steps)
+
+
+def test_only_the_diverging_molecule_is_resampled():
+    mols = _mols(4)
+    mols[2]["atom_type"] = mols[2]["atom_type"].copy()
+    mols[2]["atom_type"][:] = 9          # fingerprint of the molecule that "diverges"
+    packed = driver.pack_batch(mols, driver.num_confs("2"))
+    m = _FakeSampler(nan_type=9)
+    p0 = torch.randn(packed["atom_type"].shape[0], 3)
+    pos, traj, ok = driver.sample_batch(m, packed, "cpu", dict(n_steps=2), save_traj=True, log=lambda s: None, pos_init=p0)
+    # first attempt: all 8 graphs, no clipping; second: only molecule 2's two conformers, clip_local=20
+    assert m.calls == [(8, None), (2, 20)] and ok.all()
+    expect = p0 * 0.5 + torch.from_numpy(packed["atom_type"]).float()[:, None]
+    off, n, g = packed["spans"][2]
+    keep = torch.ones(pos.shape[0], dtype=torch.bool)
+    keep[off:off + n * g] = False
+    assert torch.equal(pos[keep], expect[keep])                 # the healthy molecules keep their FIRST result
+    assert torch.isfinite(pos).all() and not torch.equal(pos[~keep], expect[~keep])     # re-drawn pos_init
+    assert traj.shape == (2,) + tuple(pos.shape)
+    # a molecule that fails twice is dropped, the others stay
+    m3 = _FakeSampler(nan_type=9)
+    m3_run = m3.begin_sampling
+    m3.begin_sampling = lambda *a, **k: m3_run(*a, **dict(k, clip_local=None))      # clipping does not help
+    pos, _, ok = driver.sample_batch(m3, packed, "cpu", dict(n_steps=2), log=lambda s: None)
+    assert ok.tolist() == [True, True, False, True] and torch.isnan(pos[off:off + n * g]).all()
+
+
+def test_subset_batch_rebases():
+    mols = _mols(5)
+    confs = driver.num_confs("2x")
+    packed = driver.pack_batch(mols, confs)
+    sub = driver.subset_batch(packed, [1, 3])
+    ref = driver.pack_batch([mols[1], mols[3]], confs)
+    for k in ("atom_type", "bond_index", "bond_type", "batch"):
+        assert np.array_equal(sub[k], ref[k]), k
+    assert sub["num_graphs"] == ref["num_graphs"] and sub["spans"] == ref["spans"]
+
+
+def test_resume_keeps_every_finished_molecule(tmp_path):
+    """a resumed run plans batches over the remaining molecules; its files must not replace files of the
+    interrupted run that hold other molecules."""
+    mols = _mols(7)
+    for i, m in enumerate(mols):
+        m["index"] = i
+    confs, out = driver.num_confs("2"), str(tmp_path / "out")
+    model = _FakeSampler()
+    # "interrupted" run: only molecules 0..3 get sampled
+    first = driver.run_job(model, mols[:4], out, confs, 70, dict(n_steps=1), "cpu", log=lambda s: None)
+    assert sorted(k for k in first if k.startswith("pos_gen_")) == ["pos_gen_%d" % i for i in range(4)]
+    before = {k: first[k].copy() for k in first if k.startswith("pos_gen_")}
+    merged = driver.run_job(model, mols, out, confs, 70, dict(n_steps=1), "cpu", resume=True, log=lambda s: None)
+    assert sorted(int(k.split("_")[-1]) for k in merged if k.startswith("pos_gen_")) == list(range(7))
+    for k, v in before.items():
+        assert np.array_equal(merged[k], v), k                    # nothing of the first run was overwritten
+    z = np.load(out + "/samples_all.npz")
+    assert all(("pos_gen_%d" % i) in z.files for i in range(7))
+    # a third run with --resume has nothing left to do and changes nothing
+    again = driver.run_job(model, mols, out, confs, 70, dict(n_steps=1), "cpu", resume=True, log=lambda s: None)
+    assert all(np.array_equal(again[k], merged[k]) for k in merged)
+
+
+def test_reference_checkpoint_with_easydict_config(tmp_path):
+    """scripts/train.py:219-231 pickles `config` as easydict.EasyDict; the package is not installed here, so the
+    file is written against a stand-in module that exists only while saving."""
+    import sys
+    import types
+    from agdiff_amd import Config, compat, get_model, qm9_model_config
+
+    class EasyDict(dict):                    # behaviour of the PyPI package: attribute <-> item, nested dicts wrapped
+        def __init__(self, d=None, **kw):
+            super().__init__()
+            for k, v in dict(d or {}, **kw).items():
+                setattr(self, k, v)
+
+        def __setattr__(self, name, value):
+            if isinstance(value, dict) and not isinstance(value, EasyDict):
+                value = EasyDict(value)
+            super().__setattr__(name, value)
+            super().__setitem__(name, value)
+        __setitem__ = __setattr__
+    EasyDict.__module__, EasyDict.__qualname__ = "easydict", "EasyDict"
+    fake = types.ModuleType("easydict")
+    fake.EasyDict = EasyDict
+    cfg = qm9_model_config()
+    m = get_model(cfg)
+    path = str(tmp_path / "ckpt.pt")
+    had = sys.modules.get("easydict")
+    sys.modules["easydict"] = fake
+    try:
+        torch.save({"config": EasyDict({"model": dict(cfg), "train": {"seed": 2021, "optimizer": {"lr": 1e-3}}}),
+                    "model": m.state_dict(), "optimizer_global": {"state": {}, "param_groups": [{"lr": 1e-3}]},
+                    "iteration": 7, "avg_val_loss": 0.5}, path)
+    finally:
+        if had is None:
+            del sys.modules["easydict"]
+        else:
+            sys.modules["easydict"] = had
+    ckpt = compat.load_checkpoint(path)
+    assert type(ckpt["config"]) is Config and type(ckpt["config"].train.optimizer) is Config
+    mc = compat.model_config(ckpt)
+    assert mc.hidden_dim == 128 and mc.edge_encoder == "mlp" and mc["cutoff"] == 10.0 and ckpt["iteration"] == 7
+    m2 = get_model(mc)
+    m2.load_state_dict(ckpt["model"], strict=True)
+    assert compat.model_config({"config": {"model": dict(cfg)}}).num_convs == 6        # plain-dict configs too
+    # nothing but tensors / containers / EasyDict is admitted
+    import pickle
+    bad = str(tmp_path / "bad.pt")
+    torch.save({"config": Config(model=cfg), "model": {}, "x": __import__("pathlib").PurePosixPath("a")}, bad)
+    with pytest.raises(pickle.UnpicklingError):
+        compat.load_checkpoint(bad)
+    assert compat.load_checkpoint(bad, trust=True)["x"].name == "a"
+
+
+def test_compat_install_aliases_the_reference_import_path():
+    import importlib
+    import sys
+    from agdiff_amd import compat, epsnet
+    saved = {k: sys.modules.get(k) for k in ("agdiff", "agdiff.models", "agdiff.models.epsnet",
+                                             "agdiff.models.epsnet.dualenc", "easydict")}
+    try:
+        compat.install()
+        mod = importlib.import_module("agdiff.models.epsnet")             # scripts/test.py:21
+        assert mod.get_model is epsnet.get_model
+        from agdiff.models.epsnet import get_model as gm                  # noqa: F401
+        from agdiff.models.epsnet.dualenc import DualEncoderEpsNetwork as D
+        assert D is epsnet.DualEncoderEpsNetwork
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v

@@ -1,0 +1,180 @@
+"""GPU (MI355X): the sampling driver (scripts/test.py counterpart) against the oracle, the per-molecule NaN retry,
+the RCCL all-gather path on one GPU (world_size 1, backend nccl), and size-independent properties at the
+BASELINE.json config shapes that have no fixture (QM9-shaped test batch, 200-atom molecules)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import check_close, t
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu_model(cfg, head_scale=1e-3, precision="bf16x3"):
+    from agdiff_amd import get_model
+    from oracle import agdiff_oracle as O
+    sd = O.synth_state_dict_for(cfg, head_scale=head_scale)
+    m = get_model(cfg)
+    m.precision = precision
+    m.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+    return m.to("cuda:0").eval(), sd
+
+
+def _three_molecules(seed=5):
+    from agdiff_amd import synth
+    rng = np.random.default_rng(seed)
+    mols = []
+    for i in range(3):
+        at, r, c, ty = synth.random_molecule(rng, int(rng.integers(9, 22)))
+        mols.append(dict(atom_type=at, edge_index=np.stack([r, c]), edge_type=ty, num_refs=1 + i, name="mol%d" % i, index=i))
+    return mols
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_driver_sample_batch_matches_oracle_per_molecule(precision):
+    """every molecule's pos_gen out of driver.sample_batch (packed batch, injected pos_init / noise)
+    against the oracle's langevin_dynamics_sample_diffusion with scripts/test.py's arguments."""
+    from agdiff_amd import driver, qm9_model_config
+    from oracle import agdiff_oracle as O
+    cfg = qm9_model_config(num_diffusion_timesteps=14, beta_end=2e-3)
+    m, sd = _gpu_model(cfg, precision=precision)
+    mols = _three_molecules()
+    packed = driver.pack_batch(mols, driver.num_confs("2x"))
+    N, n_steps = packed["atom_type"].shape[0], 14
+    gen = torch.Generator().manual_seed(11)
+    pos_init, noise = torch.randn(N, 3, generator=gen), torch.randn(n_steps, N, 3, generator=gen)
+    kw = dict(n_steps=n_steps, step_lr=1e-6, w_global=1.0, global_start_sigma=0.5, clip=1000.0)
+    pos, traj, ok = driver.sample_batch(m, packed, "cuda:0", kw, save_traj=True, pos_init=pos_init, noise=noise)
+    assert ok.all() and traj.shape == (n_steps, N, 3)
+    ref, ref_traj = O.langevin_dynamics_sample_diffusion(
+        sd, cfg, t(packed["atom_type"]), pos_init, t(packed["bond_index"]), t(packed["bond_type"]), t(packed["batch"]),
+        packed["num_graphs"], False, noise=noise, **kw)
+    for mol, (off, n, g) in zip(mols, packed["spans"]):
+        check_close("driver pos_gen %s" % mol["name"], pos[off:off + n * g], ref[off:off + n * g], precision)
+    check_close("driver traj", traj, torch.stack(ref_traj), precision)
+
+
+def test_driver_resamples_only_the_diverging_molecule():
+    """One molecule's initial positions hold a NaN: its conformers are flagged per graph (agdiff_ws_t.nan_flag) and
+    re-sampled with clip_local=20; the molecules packed with it keep, bit for bit, what a clean run gives them."""
+    from agdiff_amd import driver, qm9_model_config
+    cfg = qm9_model_config(num_diffusion_timesteps=10)
+    m, _ = _gpu_model(cfg)
+    mols = _three_molecules(seed=6)
+    packed = driver.pack_batch(mols, driver.num_confs("2"))
+    N = packed["atom_type"].shape[0]
+    gen = torch.Generator().manual_seed(3)
+    pos_init, noise = torch.randn(N, 3, generator=gen), torch.randn(10, N, 3, generator=gen)
+    kw = dict(n_steps=10, step_lr=1e-6, w_global=1.0, global_start_sigma=0.5, clip=1000.0)
+    clean, _, ok0 = driver.sample_batch(m, packed, "cuda:0", kw, pos_init=pos_init, noise=noise)
+    assert ok0.all()
+    off, n, g = packed["spans"][1]
+    bad = pos_init.clone()
+    bad[off + n + 2, 0] = float("nan")                      # second conformer of molecule 1
+    logs = []
+    pos, _, ok = driver.sample_batch(m, packed, "cuda:0", kw, pos_init=bad, noise=noise, log=logs.append)
+    assert ok.all() and torch.isfinite(pos).all() and len(logs) == 1 and "1 of 3" in logs[0]
+    keep = torch.ones(N, dtype=torch.bool)
+    keep[off:off + n * g] = False
+    assert torch.equal(pos[keep], clean[keep])
+    assert not torch.equal(pos[~keep], clean[~keep])
+    # the module API keeps the reference's contract: the whole call raises (dualenc.py:539-541)
+    with pytest.raises(FloatingPointError):
+        m.langevin_dynamics_sample_diffusion(t(packed["atom_type"]).cuda(), bad.cuda(), t(packed["bond_index"]).cuda(),
+                                             t(packed["bond_type"]).cuda(), t(packed["batch"]).cuda(),
+                                             packed["num_graphs"], extend_order=False, n_steps=3)
+
+
+def test_all_gather_path_on_one_gpu_nccl_world1():
+    """SURVEY §8e on hardware: process group 'nccl' (= RCCL) with one rank; StepAllGather as the sampler's on_step.
+    Every step's gathered shard equals the positions of that step (the snapshot is taken on the compute stream before
+    the next step overwrites them), the NaN flag travels with it, and the sharded driver path gives the unsharded
+    result."""
+    import torch.distributed as dist
+    from agdiff_amd import driver, qm9_model_config, synth
+    from agdiff_amd.dist import StepAllGather, sample_batch_sharded
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        cfg = qm9_model_config(num_diffusion_timesteps=8)
+        m, _ = _gpu_model(cfg)
+        b = synth.make_packed_batch("qm9", 3, 2, seed=9)
+        at, bi, bt, ba = [t(b[k]).cuda() for k in ("atom_type", "bond_index", "bond_type", "batch")]
+        N = at.shape[0]
+        gen = torch.Generator().manual_seed(2)
+        pos_init, noise = torch.randn(N, 3, generator=gen).cuda(), torch.randn(6, N, 3, generator=gen).cuda()
+        gather = StepAllGather(N, dev)
+        seen = []
+
+        def on_step(k, i, pos):
+            gather(k, i, pos, run.ws.nan_flag)
+            parts, any_nan = gather.result()               # waits for the side stream; test only
+            seen.append((parts[0].clone(), any_nan))
+        run = m.begin_sampling(at, pos_init, bi, bt, ba, b["num_graphs"], False, n_steps=6, w_global=1.0,
+                               global_start_sigma=0.5, noise=noise, on_step=on_step)
+        run.advance(6)
+        pos, traj = run.finish()
+        assert gather.calls == 6 and len(seen) == 6
+        for k in range(6):
+            assert torch.equal(seen[k][0].cpu(), traj[k]) and not seen[k][1]
+        assert torch.equal(seen[-1][0], pos)
+        # NaN flag propagation
+        bad = pos_init.clone()
+        bad[1, 1] = float("nan")
+        g2 = StepAllGather(N, dev)
+        run2 = m.begin_sampling(at, bad, bi, bt, ba, b["num_graphs"], False, n_steps=2, raise_on_nan=False)
+        run2.on_step = lambda k, i, p: g2(k, i, p, run2.ws.nan_flag)
+        run2.advance(2)
+        assert g2.result()[1] and bool(run2.nan_graphs()[0]) and not bool(run2.nan_graphs()[1:].any())
+        # the sharded driver path (one shard = the whole batch here) equals the plain one
+        mols = _three_molecules(seed=8)
+        packed = driver.pack_batch(mols, driver.num_confs("2"))
+        n2 = packed["atom_type"].shape[0]
+        p0, nz = torch.randn(n2, 3, generator=gen), torch.randn(5, n2, 3, generator=gen)
+        kw = dict(n_steps=5, step_lr=1e-6, w_global=1.0, global_start_sigma=0.5, clip=1000.0)
+        a, _, oka = driver.sample_batch(m, packed, dev, kw, pos_init=p0, noise=nz)
+        bb, _, okb = sample_batch_sharded(m, packed, dev, kw, pos_init=p0, noise=nz)
+        assert oka.all() and okb.all() and torch.equal(a, bb)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,mols,copies,min_mean_deg", [("qm9", 40, 30, 14.0), ("large", 256, 1, 30.0)])
+def test_full_size_properties_other_configs(kind, mols, copies, min_mean_deg):
+    """BASELINE.json configs[1] (QM9-shaped, uncapped) and configs[4]'s per-GPU share (200-atom molecules x 256,
+    32-cap active) at sizes the oracle cannot check: bitwise run-to-run determinism, CSR invariants, mirror-pair
+    structure of the canonical list, centring, finiteness."""
+    from agdiff_amd import drugs_model_config, qm9_model_config, synth
+    cfg = (qm9_model_config if kind == "qm9" else drugs_model_config)(num_diffusion_timesteps=50, beta_end=2e-5)
+    m, _ = _gpu_model(cfg)
+    b = synth.make_packed_batch(kind, mols, copies, seed=91)
+    at, bi, bt, ba = [t(b[k]).cuda() for k in ("atom_type", "bond_index", "bond_type", "batch")]
+    gen = torch.Generator().manual_seed(4)
+    pos_init = torch.randn(at.shape[0], 3, generator=gen).cuda()
+    noise = torch.randn(3, at.shape[0], 3, generator=gen).cuda()
+    kw = dict(extend_order=False, n_steps=3, w_global=1.0, global_start_sigma=0.5, clip=1000.0, noise=noise)
+    p1, tr1 = m.langevin_dynamics_sample_diffusion(at, pos_init, bi, bt, ba, b["num_graphs"], **kw)
+    p2, tr2 = m.langevin_dynamics_sample_diffusion(at, pos_init, bi, bt, ba, b["num_graphs"], **kw)
+    assert torch.equal(p1, p2) and torch.equal(torch.stack(tr1), torch.stack(tr2))
+    ws, topo = m._batch_cache[2], m._batch_cache[1]
+    E, C = int(ws.num_edges.item()), int(ws.num_canon.item())
+    ip = ws.in_ptr.cpu().numpy()
+    indeg = np.diff(ip)
+    dst, src = ws.e_dst[:E].cpu().numpy(), ws.e_src[:E].cpu().numpy()
+    assert E <= topo.max_edges and ip[-1] == E and indeg.max() <= topo.max_in_degree
+    assert np.all(np.diff(dst) >= 0) and np.array_equal(np.bincount(dst, minlength=topo.N), indeg)
+    assert np.all(np.diff(src)[np.diff(dst) == 0] > 0)
+    assert indeg.mean() > min_mean_deg
+    batch = b["batch"]
+    assert np.array_equal(batch[src], batch[dst])                    # no edge crosses a molecule
+    if kind == "qm9":
+        assert 2 * C == E                                            # uncapped: every edge has its mirror
+    else:
+        assert E // 2 < C < E
+    cen = torch.zeros(b["num_graphs"], 3, device="cuda").index_add_(0, ba, p1)
+    assert float(cen.abs().max()) < 2e-3 and torch.isfinite(p1).all()

@@ -1,16 +1,19 @@
 """GPU (MI355X): the HIP path, called through the C ABI (include/agdiff_hip.h), against the oracle
-and the reference-generated golden fixtures.  Tolerance: 1e-4 relative fp32 (BASELINE.json north_star)
-for floating point; bit-exact for every index / integer output."""
+and the reference-generated golden fixtures.  Floating point: BASELINE.json's north_star asks for 1e-4 relative
+fp32; the gates here are per arithmetic mode and about ten times tighter (helpers.TOL_NORM: exact-fp32 MFMA 1e-5,
+split-bf16 5e-5 normwise = max|a-b| / max|b|) plus an element-wise figure with an absolute floor
+(helpers.TOL_ELEM); every comparison prints and records both figures (gpurun_out/parity_errors.json).
+Bit-exact for every index / integer output."""
 import ctypes
 
 import numpy as np
 import pytest
 import torch
 
-from helpers import (FORWARD_CASES, SAMPLER_CASES, STAGE_CASES, load_golden, rel_err, sampler_case_cfg, sampler_case_kwargs, t)
+from helpers import (FORWARD_CASES, SAMPLER_CASES, STAGE_CASES, check_close, load_golden, rel_err, sampler_case_cfg,
+                     sampler_case_kwargs, t)
 
 pytestmark = pytest.mark.gpu
-TOL = 1e-4
 
 
 PRECISIONS = ["f32", "bf16x3"]
@@ -111,9 +114,9 @@ def test_edge_encoder_and_stages(case, precision):
     E = int(ws.num_edges.item())
     perm = ws.ref2dst[:E].long()
     ea = unfrag(ws.e_attr, E, precision)[perm].cpu().numpy()
-    assert rel_err(ea, g["edge_attr"]) < TOL
-    assert rel_err(ws.h.view(-1, 128).cpu().numpy(), g["schnet_out"]) < TOL
-    assert rel_err(ws.hl.view(-1, 128).cpu().numpy(), g["gin_out"]) < TOL
+    check_close("edge_encoder_and_stages ea[%s]" % case, ea, g["edge_attr"], precision)
+    check_close("edge_encoder_and_stages ws.h.view1128[%s]" % case, ws.h.view(-1, 128).cpu().numpy(), g["schnet_out"], precision)
+    check_close("edge_encoder_and_stages ws.hl.view1128[%s]" % case, ws.hl.view(-1, 128).cpu().numpy(), g["gin_out"], precision)
     # embedding renorm side effect (G8)
     assert rel_err(m.encoder_global.embedding.weight[:20].detach().cpu().numpy(), g["emb_rows_after"]) < 1e-6
 
@@ -133,8 +136,8 @@ def test_forward_matches_reference_golden(case, precision):
     assert np.array_equal(lm, g["local_edge_mask"])
     assert inv_g.shape == g["edge_inv_global"].shape and inv_l.shape == g["edge_inv_local"].shape
     assert rel_err(elen, g["edge_length"]) < 1e-6
-    assert rel_err(inv_g, g["edge_inv_global"]) < TOL
-    assert rel_err(inv_l, g["edge_inv_local"]) < TOL
+    check_close("forward_matches_reference_golden inv_g[%s]" % case, inv_g, g["edge_inv_global"], precision)
+    check_close("forward_matches_reference_golden inv_l[%s]" % case, inv_l, g["edge_inv_local"], precision)
     two = m(t(g["atom_type"]).cuda(), t(g["pos"]).cuda(), t(g["bond_index"]).cuda(), t(g["bond_type"]).cuda(),
             t(g["batch"]).cuda(), None, extend_order=False)
     assert len(two) == 2 and np.array_equal(two[0].cpu().numpy(), inv_g)
@@ -152,8 +155,8 @@ def test_sampler_matches_reference_golden(case, precision):
         t(g["batch"]).cuda(), int(g["num_graphs"]), extend_order=False, n_steps=int(g["n_steps"]),
         noise=t(g["noise"]).cuda(), **kw)
     assert pos.is_cuda and len(traj) == int(g["n_steps"]) and not traj[0].is_cuda
-    assert rel_err(torch.stack(traj).numpy(), g["traj"]) < TOL
-    assert rel_err(pos.cpu().numpy(), g["pos_final"]) < TOL
+    check_close("sampler_matches_reference_golden traj[%s]" % case, torch.stack(traj).numpy(), g["traj"], precision)
+    check_close("sampler_matches_reference_golden pos[%s]" % case, pos.cpu().numpy(), g["pos_final"], precision)
     # running the global encoder on the steps whose result is discarded changes nothing
     pos2, _ = m.langevin_dynamics_sample_diffusion(
         t(g["atom_type"]).cuda(), t(g["pos_init"]).cuda(), t(g["bond_index"]).cuda(), t(g["bond_type"]).cuda(),
@@ -175,8 +178,8 @@ def test_alanine_dipeptide_config0(precision):
         n_steps=100, step_lr=1e-6, w_global=1.0, global_start_sigma=0.5, clip=1000.0, clip_local=None,
         sampling_type="ld", eta=1.0, noise=t(g["noise"]).cuda())
     assert len(traj) == 100
-    assert rel_err(torch.stack(traj)[::10].numpy(), g["traj"]) < TOL
-    assert rel_err(pos.cpu().numpy(), g["pos_final"]) < TOL
+    check_close("alanine_dipeptide_config0 traj[10]", torch.stack(traj)[::10].numpy(), g["traj"], precision)
+    check_close("alanine_dipeptide_config0 pos", pos.cpu().numpy(), g["pos_final"], precision)
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
@@ -192,9 +195,9 @@ def test_loss_matches_reference_golden(case, precision):
     kw = dict(extend_order=False, time_step=t(g["time_step"]).cuda(), pos_noise=t(g["pos_noise"]).cuda())
     loss, lg, ll = m.get_loss(*args, return_unreduced_loss=True, **kw)
     assert loss.shape == lg.shape == ll.shape == (g["atom_type"].shape[0], 1) and loss.is_cuda
-    assert rel_err(lg.cpu().numpy(), g["loss_global"]) < TOL
-    assert rel_err(ll.cpu().numpy(), g["loss_local"]) < TOL
-    assert rel_err(loss.cpu().numpy(), g["loss"]) < TOL
+    check_close("loss_matches_reference_golden lg[%s]" % case, lg.cpu().numpy(), g["loss_global"], precision)
+    check_close("loss_matches_reference_golden ll[%s]" % case, ll.cpu().numpy(), g["loss_local"], precision)
+    check_close("loss_matches_reference_golden loss[%s]" % case, loss.cpu().numpy(), g["loss"], precision)
     only = m.get_loss(*args, **kw)
     assert torch.equal(only, loss)
     assert m.get_loss(*args, return_unreduced_edge_loss=True, **kw) is None       # dualenc.py:390-391 falls through
@@ -216,18 +219,42 @@ def test_forward_variants_match_reference_golden(precision):
     assert np.array_equal(out[2].cpu().numpy(), g["nr_edge_index"])
     assert np.array_equal(out[3].cpu().numpy(), g["nr_edge_type"]) and bool(out[5].all())
     assert rel_err(out[4].cpu().numpy(), g["nr_edge_length"]) < 1e-6
-    assert rel_err(out[0].cpu().numpy(), g["nr_inv_g"]) < TOL
-    assert rel_err(out[1].cpu().numpy(), g["nr_inv_l"]) < TOL
+    check_close("forward_variants_match_reference_golden out[0]", out[0].cpu().numpy(), g["nr_inv_g"], precision)
+    check_close("forward_variants_match_reference_golden out[1]", out[1].cpu().numpy(), g["nr_inv_l"], precision)
     ei, et, el = t(g["given_edge_index"]).cuda(), t(g["given_edge_type"]).cuda(), t(g["given_edge_length"]).cuda()
     out = m(a[0], a[1], None, None, a[4], None, edge_index=ei, edge_type=et, edge_length=el, return_edges=True)
     assert out[2] is ei and out[3] is et and out[4] is el
     assert np.array_equal(out[5].cpu().numpy(), g["given_edge_type"] > 0)
-    assert rel_err(out[0].cpu().numpy(), g["given_inv_g"]) < TOL
-    assert rel_err(out[1].cpu().numpy(), g["given_inv_l"]) < TOL
+    check_close("forward_variants_match_reference_golden out[0]", out[0].cpu().numpy(), g["given_inv_g"], precision)
+    check_close("forward_variants_match_reference_golden out[1]", out[1].cpu().numpy(), g["given_inv_l"], precision)
     # the sampler with extend_radius=False keeps working (local edges only; nothing for the global term to act on)
     pos, _ = m.langevin_dynamics_sample_diffusion(a[0], a[1], a[2], a[3], a[4], int(g["batch"].max()) + 1, False,
                                                   extend_radius=False, n_steps=3, w_global=1.0, global_start_sigma=1e9)
     assert torch.isfinite(pos).all()
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_extend_order_true_matches_reference_golden(precision):
+    """SURVEY §8 f1 on the HIP path: RAW bonds, extend_order=True (forward's default, dualenc.py:153,167-177;
+    _extend_graph_order, common.py:135-205) -- forward with edges and a 12-step sampler run against the reference."""
+    from agdiff_amd import drugs_model_config
+    g = load_golden("g12_extend_order_forward")
+    m, _ = _gpu_model(drugs_model_config(num_diffusion_timesteps=12), precision=precision)
+    a = (t(g["atom_type"]).cuda(), t(g["pos"]).cuda(), t(g["bond_index"]).cuda(), t(g["bond_type"]).cuda(),
+         t(g["batch"]).cuda(), None)
+    out = m(*a, return_edges=True)                                   # extend_order defaults to True
+    assert np.array_equal(out[2].cpu().numpy(), g["edge_index"])
+    assert np.array_equal(out[3].cpu().numpy(), g["edge_type"]) and (g["edge_type"] >= 23).any()
+    assert np.array_equal(out[5].cpu().numpy(), g["local_edge_mask"])
+    assert rel_err(out[4].cpu().numpy(), g["edge_length"]) < 1e-6
+    check_close("extend_order inv_g", out[0], g["edge_inv_global"], precision)
+    check_close("extend_order inv_l", out[1], g["edge_inv_local"], precision)
+    pos, traj = m.langevin_dynamics_sample_diffusion(
+        a[0], t(g["pos_init"]).cuda(), a[2], a[3], a[4], int(g["num_graphs"]), extend_order=True,
+        n_steps=int(g["n_steps"]), step_lr=1e-6, w_global=1.0, global_start_sigma=0.5, clip=1000.0,
+        noise=t(g["noise"]).cuda())
+    check_close("extend_order traj", torch.stack(traj), g["traj"], precision)
+    check_close("extend_order pos", pos, g["pos_final"], precision)
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
@@ -249,8 +276,8 @@ def test_node_kernels_lds_shared_variant(precision, monkeypatch):
         assert torch.equal(base[0], shared[0]) and torch.equal(base[1], shared[1])
     assert rel_err(shared[0].cpu().numpy(), base[0].cpu().numpy()) < 1e-5
     assert rel_err(shared[1].cpu().numpy(), base[1].cpu().numpy()) < 1e-5
-    assert rel_err(shared[0].cpu().numpy(), g["edge_inv_global"]) < TOL
-    assert rel_err(shared[1].cpu().numpy(), g["edge_inv_local"]) < TOL
+    check_close("node_kernels_lds_shared_variant shared[0]", shared[0].cpu().numpy(), g["edge_inv_global"], precision)
+    check_close("node_kernels_lds_shared_variant shared[1]", shared[1].cpu().numpy(), g["edge_inv_local"], precision)
 
 
 def test_nan_raises_floating_point_error():
@@ -267,8 +294,9 @@ def test_nan_raises_floating_point_error():
 
 
 def test_oracle_parity_on_seeded_batches_and_wrapper_defaults():
-    """Fresh seeded inputs (not fixtures): HIP vs oracle, QM9- and Drugs-shaped, plus extend_order=True
-    and the langevin_dynamics_sample wrapper (dualenc.py:397-439)."""
+    """Fresh seeded inputs (not fixtures): HIP vs oracle, QM9- and Drugs-shaped, forward and the
+    langevin_dynamics_sample wrapper with its own defaults (dualenc.py:397-439).  (extend_order=True has its own
+    reference fixture: test_extend_order_true_matches_reference_golden.)"""
     from agdiff_amd import drugs_model_config, qm9_model_config, synth
     from oracle import agdiff_oracle as O
     for kind, cfgf, seed, scale in (("qm9", qm9_model_config, 31, 2.0), ("drugs", drugs_model_config, 32, 1.2)):
@@ -282,14 +310,15 @@ def test_oracle_parity_on_seeded_batches_and_wrapper_defaults():
         got = m(at.cuda(), pos.cuda(), bi.cuda(), bt.cuda(), ba.cuda(), None, return_edges=True, extend_order=False)
         assert np.array_equal(got[2].cpu().numpy(), ref[2].numpy())
         assert np.array_equal(got[3].cpu().numpy(), ref[3].numpy())
-        assert rel_err(got[0].cpu().numpy(), ref[0].numpy()) < TOL
-        assert rel_err(got[1].cpu().numpy(), ref[1].numpy()) < TOL
+        check_close("oracle_parity_on_seeded_batches_and_wrapper_defaults got[0]", got[0].cpu().numpy(), ref[0].numpy(), "bf16x3")
+        check_close("oracle_parity_on_seeded_batches_and_wrapper_defaults got[1]", got[1].cpu().numpy(), ref[1].numpy(), "bf16x3")
         noise = torch.randn(5, at.shape[0], 3, generator=gen)
         rpos, _ = O.langevin_dynamics_sample_diffusion(sd, cfg, at, pos, bi, bt, ba, b["num_graphs"], False,
                                                        n_steps=5, noise=noise)
         gpos, gtraj = m.langevin_dynamics_sample(at.cuda(), pos.cuda(), bi.cuda(), bt.cuda(), ba.cuda(),
                                                  b["num_graphs"], False, n_steps=5, noise=noise.cuda())
-        assert rel_err(gpos.cpu().numpy(), rpos.numpy()) < TOL and len(gtraj) == 5
+        check_close("oracle_parity_on_seeded_batches_and_wrapper_defaults gpos", gpos.cpu().numpy(), rpos.numpy(), "bf16x3")
+        assert len(gtraj) == 5
 
 
 def test_full_size_properties():
@@ -449,8 +478,10 @@ def test_default_initialised_weights(precision):
     ref = O.forward(sd, cfg, at, pos, bi, bt, ba, extend_order=False)
     got = m(at.cuda(), pos.cuda(), bi.cuda(), bt.cuda(), ba.cuda(), None, return_edges=True, extend_order=False)
     assert np.array_equal(got[2].cpu().numpy(), ref[2].numpy())
-    assert rel_err(got[0].cpu().numpy(), ref[0].numpy()) < TOL
-    assert rel_err(got[1].cpu().numpy(), ref[1].numpy()) < TOL
+    # kaiming-uniform heads without the synthetic filler's damping: the 64 -> 1 output layer cancels to ~1 % of its
+    # terms' size, which is where the relative figure loses a factor ~3 (still inside north_star's 1e-4)
+    check_close("default_initialised_weights got[0]", got[0].cpu().numpy(), ref[0].numpy(), precision, scale=3.0)
+    check_close("default_initialised_weights got[1]", got[1].cpu().numpy(), ref[1].numpy(), precision, scale=3.0)
     # the max_norm renormalisation touched the module's own embedding exactly as the oracle's copy
     assert rel_err(m.encoder_global.embedding.weight.detach().cpu().numpy(), sd["encoder_global.embedding.weight"].numpy()) < 1e-6
 
@@ -474,20 +505,21 @@ def test_molecule_larger_than_a_workgroup():
     ref = O.forward(sd, cfg, at, pos, bi, bt, ba, extend_order=False)
     got = m(at.cuda(), pos.cuda(), bi.cuda(), bt.cuda(), ba.cuda(), None, return_edges=True, extend_order=False)
     assert np.array_equal(got[2].cpu().numpy(), ref[2].numpy()) and np.array_equal(got[3].cpu().numpy(), ref[3].numpy())
-    assert rel_err(got[0].cpu().numpy(), ref[0].numpy()) < TOL and rel_err(got[1].cpu().numpy(), ref[1].numpy()) < TOL
+    check_close("molecule_larger_than_a_workgroup got[0]", got[0].cpu().numpy(), ref[0].numpy(), "bf16x3")
+    check_close("molecule_larger_than_a_workgroup got[1]", got[1].cpu().numpy(), ref[1].numpy(), "bf16x3")
     noise = torch.randn(3, 323, 3, generator=gen)
     kw = dict(n_steps=3, w_global=1.0, global_start_sigma=float("inf"), clip=1000.0)
     rpos, _ = O.langevin_dynamics_sample_diffusion(sd, cfg, at, pos, bi, bt, ba, 2, False, noise=noise, **kw)
     gpos, _ = m.langevin_dynamics_sample_diffusion(at.cuda(), pos.cuda(), bi.cuda(), bt.cuda(), ba.cuda(), 2, False,
                                                    noise=noise.cuda(), **kw)
-    assert rel_err(gpos.cpu().numpy(), rpos.numpy()) < TOL
+    check_close("molecule_larger_than_a_workgroup gpos", gpos.cpu().numpy(), rpos.numpy(), "bf16x3")
     ts = torch.tensor([3, 7])
     pn = torch.randn(323, 3, generator=gen)
     rl = O.get_loss_diffusion(sd, cfg, at, pos, bi, bt, ba, 2, ts, pn, extend_order=False)
     gl = m.get_loss(at.cuda(), pos.cuda(), bi.cuda(), bt.cuda(), ba.cuda(), None, 2, return_unreduced_loss=True,
                     extend_order=False, time_step=ts.cuda(), pos_noise=pn.cuda())
     for a_, b_ in zip(gl, rl):
-        assert rel_err(a_.cpu().numpy(), b_.numpy()) < TOL
+        check_close("molecule_larger_than_a_workgroup a_", a_.cpu().numpy(), b_.numpy(), "bf16x3")
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
@@ -519,12 +551,12 @@ def test_ragged_and_degenerate_graphs(precision):
     got = m(at.cuda(), pos.cuda(), bi.cuda(), bt.cuda(), ba.cuda(), None, return_edges=True, extend_order=False)
     assert np.array_equal(got[2].cpu().numpy(), ref[2].numpy())
     assert np.array_equal(got[3].cpu().numpy(), ref[3].numpy())
-    assert rel_err(got[0].cpu().numpy(), ref[0].numpy()) < TOL
-    assert rel_err(got[1].cpu().numpy(), ref[1].numpy()) < TOL
+    check_close("ragged_and_degenerate_graphs got[0]", got[0].cpu().numpy(), ref[0].numpy(), precision)
+    check_close("ragged_and_degenerate_graphs got[1]", got[1].cpu().numpy(), ref[1].numpy(), precision)
     noise = torch.randn(3, at.shape[0], 3, generator=gen)
     rpos, _ = O.langevin_dynamics_sample_diffusion(sd, cfg, at, pos, bi, bt, ba, 4, False, n_steps=3, noise=noise,
                                                    w_global=1.0, global_start_sigma=float("inf"))
     gpos, _ = m.langevin_dynamics_sample_diffusion(at.cuda(), pos.cuda(), bi.cuda(), bt.cuda(), ba.cuda(), 4, False,
                                                    n_steps=3, noise=noise.cuda(), w_global=1.0,
                                                    global_start_sigma=float("inf"))
-    assert rel_err(gpos.cpu().numpy(), rpos.numpy()) < TOL
+    check_close("ragged_and_degenerate_graphs gpos", gpos.cpu().numpy(), rpos.numpy(), precision)

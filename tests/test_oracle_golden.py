@@ -177,3 +177,21 @@ def test_extend_order_g9():
                                                g["bond_type%d" % i], order=3)
         assert np.array_equal(np.stack([r, c]), g["ext_index%d" % i])
         assert np.array_equal(ty, g["ext_type%d" % i])
+
+
+def test_forward_and_sampler_with_extend_order_g12():
+    """Raw bonds + extend_order=True (forward's default; dualenc.py:167-177 -> common.py:135-205) on the model path."""
+    from agdiff_amd.config import drugs_model_config
+    g = load_golden("g12_extend_order_forward")
+    cfg = drugs_model_config(num_diffusion_timesteps=12)
+    sd = O.synth_state_dict_for(cfg)
+    a = (t(g["atom_type"]), t(g["pos"]), t(g["bond_index"]), t(g["bond_type"]), t(g["batch"]))
+    out = O.forward(sd, cfg, *a, extend_order=True)
+    assert np.array_equal(out[2].numpy(), g["edge_index"]) and np.array_equal(out[3].numpy(), g["edge_type"])
+    assert (g["edge_type"] >= 23).any()                      # 2-/3-hop types really come from the extension
+    assert rel_err(out[0].numpy(), g["edge_inv_global"]) < TOL and rel_err(out[1].numpy(), g["edge_inv_local"]) < TOL
+    pos, traj = O.langevin_dynamics_sample_diffusion(
+        sd, cfg, a[0], t(g["pos_init"]), a[2], a[3], a[4], int(g["num_graphs"]), True, n_steps=int(g["n_steps"]),
+        step_lr=1e-6, w_global=1.0, global_start_sigma=0.5, clip=1000.0, noise=t(g["noise"]))
+    assert rel_err(torch.stack(traj).numpy(), g["traj"]) < TOL
+    assert rel_err(pos.numpy(), g["pos_final"]) < TOL
