@@ -245,7 +245,9 @@ __device__ unsigned long long ag_conv_stamp_acc[8];
 #define AG_ABL(bit) false
 #endif
 
-#define AG_CONV_WAVES 8
+#ifndef AG_CONV_WAVES
+#define AG_CONV_WAVES 8     // waves per workgroup (= per CU): 2 per SIMD
+#endif
 #define AG_CONV_LDS_BLOCKS 80   // resident 2-KiB weight blocks: filt_w1 (48: both convs' first layer) | filt_w2a (32)
 #define AG_CONV_NCH 12          // 16-channel tiles of the 192 filter channels (conv1: 0..7, conv2: 8..11)
 
@@ -257,7 +259,7 @@ __device__ unsigned long long ag_conv_stamp_acc[8];
 // whose list started in an earlier chunk is written to agg_first[chunk] and added by the node stage (fixed
 // order -> bitwise reproducible, no atomics).
 template <int MODE>
-__global__ void __launch_bounds__(64 * AG_CONV_WAVES, 2) k_cfconv_fused(ConvArgs a) {
+__global__ void __launch_bounds__(64 * AG_CONV_WAVES, AG_CONV_WAVES / 4) k_cfconv_fused(ConvArgs a) {
   // LDS: all 160 KiB hold filter weights for the whole launch -- the fused first layer of both convs (96 KiB)
   // and conv1's second layer (64 KiB).  Only conv2's second layer (8 blocks = 16 KiB per tile) is streamed
   // from L2, each pair of blocks requested one channel tile ahead of its use.

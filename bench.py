@@ -9,22 +9,29 @@ inputs resident in HBM when the timed region starts.
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Workload: `--mols` distinct synthetic molecules (atom count ~ clipped
-N(44, 11)) x `--copies` conformers each per GPU (weak scaling), synthetic closed-form checkpoint,
-"saturated" schedule (beta_end = 2e-5: sigma < 0.5 on every step, so the global SchNet branch runs
-on every step and the radius graph stays at the 32-neighbour cap -- the heaviest per-step work the
-path can see; the reference's default schedule is available with --schedule default).
-Rank 0 prints ONE JSON line.
+Workloads:
+  drugs (default)  `--mols` distinct synthetic molecules (atom count ~ clipped N(44, 11)) x `--copies` conformers each
+                   per GPU, synthetic closed-form checkpoint, "saturated" schedule (beta_end = 2e-5: sigma < 0.5 on
+                   every step, so the global SchNet branch runs on every step and the radius graph stays at the
+                   32-neighbour cap -- the heaviest per-step work the path can see).  The same run also measures the
+                   reference's default schedule with and without skipping the discarded global branch (`extra`).
+  drugs200         BASELINE.json configs[2] as SURVEY §8(d) restates it: 200 Drugs-shaped molecules, 2 x U{50..500}
+                   conformers each, packed by the driver's plan_batches (--max-atoms per batch); every batch runs
+                   --warmup + --steps steps, and value = all conformers / (sum over batches of its step time x 5000).
+  qm9 | large | alanine   QM9-shaped, 200-atom molecules (configs[4] shape), alanine dipeptide (configs[0]).
+Scaling: weak (default; every rank gets its own batch of the same shape) or `--scaling strong` (ONE global batch is
+cut into contiguous graph ranges by agdiff_amd.dist.shard_graphs, one per rank).  With more than one rank
+(or --force-dist) the shards' positions are all-gathered over RCCL after every step.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -48,127 +55,104 @@ def make_cfg(kind, schedule):
     return base(beta_end=2e-5) if schedule == "saturated" else base()
 
 
-def cpu_baseline(kind, schedule, seed, budget_s=20.0):
-    """The oracle (CPU port of the reference path) on a bounded sample of the same workload."""
+# ------------------------------------------------------------------------------------------ CPU baseline (oracle)
+def cpu_worker(kind, schedule, seed, mols, copies, threads, budget_s):
+    """One CPU process of the baseline: the oracle (CPU port of the reference path) on `mols` x `copies`
+    conformers with `threads` torch threads; prints one JSON line."""
+    import torch
     from oracle import agdiff_oracle as O
+    torch.set_num_threads(threads)
     cfg = make_cfg(kind, schedule)
     sd = O.synth_state_dict_for(cfg)
-    mols, copies = 2, 8
     b = build_batch(kind, mols, copies, seed)
     T = lambda x: torch.from_numpy(np.ascontiguousarray(x))
     at, bi, bt, ba = T(b["atom_type"]), T(b["bond_index"]), T(b["bond_type"]), T(b["batch"])
     g = torch.Generator().manual_seed(seed)
     pos = torch.randn(at.shape[0], 3, generator=g)
-    ncpu = os.cpu_count() or 1
     kw = dict(extend_order=False, w_global=1.0, global_start_sigma=0.5, clip=1000.0)
-    # torch's intra-op pool degrades badly when oversubscribed on small tensors (256 threads on this
-    # sample: 80 s/step); try a few pool sizes on one step each and keep the fastest
-    best = None
-    for thr in sorted({min(ncpu, 8), min(ncpu, 32), min(ncpu, 96)}):
-        torch.set_num_threads(thr)
-        O.langevin_dynamics_sample_diffusion(sd, cfg, at, pos, bi, bt, ba, b["num_graphs"], n_steps=1, **kw)
-        t0 = time.perf_counter()
-        O.langevin_dynamics_sample_diffusion(sd, cfg, at, pos, bi, bt, ba, b["num_graphs"], n_steps=1, **kw)
-        dt = time.perf_counter() - t0
-        if best is None or dt < best[0]:
-            best = (dt, thr)
-        if dt > 10.0:
-            break
-    cores = best[1]
-    torch.set_num_threads(cores)
+    O.langevin_dynamics_sample_diffusion(sd, cfg, at, pos, bi, bt, ba, b["num_graphs"], n_steps=1, **kw)     # warm-up
     n, t0 = 0, time.perf_counter()
     while True:
-        O.langevin_dynamics_sample_diffusion(sd, cfg, at, pos, bi, bt, ba, b["num_graphs"], n_steps=2, **kw)
-        n += 2
+        O.langevin_dynamics_sample_diffusion(sd, cfg, at, pos, bi, bt, ba, b["num_graphs"], n_steps=1, **kw)
+        n += 1
         el = time.perf_counter() - t0
         if el > budget_s or n >= 40:
             break
-    s_per_step = el / n
-    val = b["num_graphs"] / (s_per_step * JOB_STEPS)
-    return {"value": val, "unit": "conformers/s", "cores": cores, "kind": "port",
-            "sample": "%d %s-shaped molecules x %d conformers (%d atoms), %d steps timed, %.3f s/step, "
-                      "%d torch threads (best of a small sweep; host has %d logical CPUs), "
-                      "same synthetic checkpoint and schedule, extrapolated to %d steps"
-                      % (mols, kind, copies, at.shape[0], n, s_per_step, cores, ncpu, JOB_STEPS)}
+    print(json.dumps({"G": int(b["num_graphs"]), "atoms": int(at.shape[0]), "steps": n, "s_per_step": el / n,
+                      "threads": threads}), flush=True)
 
 
-def main():
-    global JOB_STEPS
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="drugs", choices=["drugs", "qm9", "large", "alanine"])
-    ap.add_argument("--mols", type=int, default=8)
-    ap.add_argument("--copies", type=int, default=128)
-    ap.add_argument("--schedule", default="saturated", choices=["saturated", "default"])
-    ap.add_argument("--no-skip", action="store_true", help="run the global encoder even where its result is discarded")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-traj", action="store_true")
-    ap.add_argument("--breakdown", default=None, help="write per-op timings (ms) to this JSON file")
-    ap.add_argument("--seed", type=int, default=2021)
-    ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"])
-    ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL all-gather path even with one rank")
-    ap.add_argument("--job-steps", type=int, default=JOB_STEPS, help="denoising steps of one sampling job (5000; the "
-                    "alanine dipeptide example runs 100)")
-    args = ap.parse_args()
-    JOB_STEPS = args.job_steps
+def _spawn_cpu_workers(kind, schedule, seed, mols, copies, threads, budget_s, procs):
+    """`procs` independent interpreter processes (disjoint molecules: seed + p), started BEFORE this process touches
+    the GPU.  Returns their JSON records."""
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads),
+               MKL_NUM_THREADS=str(threads))
+    ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker",
+                            json.dumps([kind, schedule, seed + 7919 * p, mols, copies, threads, budget_s])],
+                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, cwd=ROOT) for p in range(procs)]
+    recs = []
+    for p in ps:
+        out, _ = p.communicate()
+        lines = [l for l in out.decode().splitlines() if l.startswith("{")]
+        if p.returncode == 0 and lines:
+            recs.append(json.loads(lines[-1]))
+    return recs
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+
+def cpu_baseline(kind, schedule, seed):
+    """Two figures from the oracle (kind "port") on the host cores of this box, same synthetic checkpoint and
+    schedule as the GPU run:
+      single   ONE process x 8 torch threads on a >= 4,400-atom sample (SURVEY §6's size: one Drugs-shaped
+               molecule x 100 conformers) -- how the reference's own driver would run on this host;
+      value    the WHOLE HOST: P = logical CPUs / 16 processes x 8 threads over disjoint molecules (the path is
+               embarrassingly parallel over molecules; one process per 16 logical CPUs = 8 physical cores keeps the
+               torch intra-op pools off each other's hyper-threads), aggregate conformers/s.  `cores` = P x 8."""
+    ncpu = os.cpu_count() or 1
+    thr = min(8, ncpu)
+    mols, copies = (1, 250) if kind == "alanine" else (1, 100)
+    single = _spawn_cpu_workers(kind, schedule, seed, mols, copies, thr, 12.0, 1)
+    procs = max(1, min(32, ncpu // 16))
+    many = _spawn_cpu_workers(kind, schedule, seed + 1, mols, copies, thr, 12.0, procs)
+    if not single or not many:
+        return None
+    s = single[0]
+    val1 = s["G"] / (s["s_per_step"] * JOB_STEPS)
+    val = sum(r["G"] / (r["s_per_step"] * JOB_STEPS) for r in many)
+    return {"value": val, "unit": "conformers/s", "cores": len(many) * thr, "kind": "port",
+            "sample": "whole host: %d oracle processes x %d torch threads (host has %d logical CPUs), each one "
+                      "%s-shaped molecule x %d conformers (%d..%d atoms), %d..%d steps timed after one warm-up step, "
+                      "%.2f..%.2f s/step, same synthetic checkpoint and %s schedule, extrapolated to %d steps"
+                      % (len(many), thr, ncpu, kind, copies, min(r["atoms"] for r in many), max(r["atoms"] for r in many),
+                         min(r["steps"] for r in many), max(r["steps"] for r in many),
+                         min(r["s_per_step"] for r in many), max(r["s_per_step"] for r in many), schedule, JOB_STEPS),
+            "single_process": {"value": val1, "cores": thr, "atoms": s["atoms"], "s_per_step": s["s_per_step"],
+                               "steps": s["steps"]}}
+
+
+# ------------------------------------------------------------------------------------------ timed GPU runs
+def timed_run(model, dev, b, cfg, W, K, schedule, skip, save_traj, seed, rank, use_dist, on_gather=None):
+    """W untimed + K timed denoising steps of one packed batch; returns (seconds, run, global-branch share, gather)."""
+    import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or args.force_dist
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    from agdiff_amd import _lib, get_model, synth
-    lib = _lib.load()
-
-    # The measured path never touches oracle/: the synthetic checkpoint comes from the product-side closed-form
-    # filler (agdiff_amd/synth.py; the oracle fills its own copy with the same function in the cpu_baseline leg).
-    kind = args.workload
-    cfg = make_cfg(kind, args.schedule)
-    model = get_model(cfg)
-    model.precision = args.precision
-    model.load_state_dict(synth.synth_state_dict(model.state_dict()))
-    model = model.to(dev).eval()
-
-    copies = args.copies if kind != "large" else 1
-    mols = args.mols if kind != "large" else args.mols * args.copies
-    b = build_batch(kind, mols, copies, args.seed + 1000 * rank)       # weak scaling: same shape per rank
     T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
     at, bi, bt, ba = T(b["atom_type"]), T(b["bond_index"]), T(b["bond_type"]), T(b["batch"])
-    G = b["num_graphs"]
-    g = torch.Generator(device="cpu").manual_seed(args.seed + rank)
+    g = torch.Generator(device="cpu").manual_seed(seed + rank)
     pos_init = torch.randn(at.shape[0], 3, generator=g).to(dev)
-
-    W, K = args.warmup, args.steps
     Tn = cfg.num_diffusion_timesteps
-    if args.schedule == "default" and W + K < Tn:
+    if schedule == "default" and W + K < Tn:
         # visit the whole schedule evenly so that the share of global-active steps is the job's
         idx = np.linspace(Tn - 1, 0, W + K).round().astype(int).tolist()
     else:
         idx = list(reversed(range(Tn - (W + K), Tn)))
-    on_step = None
     gather = None
     if use_dist:
         from agdiff_amd.dist import StepAllGather
         gather = StepAllGather(at.shape[0], dev)
-    run = model.begin_sampling(at, pos_init, bi, bt, ba, G, False, n_steps=W + K, step_lr=1e-6, clip=1000.0,
-                               global_start_sigma=0.5, w_global=1.0, step_indices=idx,
-                               save_traj=not args.no_traj, skip_discarded_global=not args.no_skip,
-                               nan_check_every=10 ** 9)
+    run = model.begin_sampling(at, pos_init, bi, bt, ba, b["num_graphs"], False, n_steps=W + K, step_lr=1e-6,
+                               clip=1000.0, global_start_sigma=0.5, w_global=1.0, step_indices=idx,
+                               save_traj=save_traj, skip_discarded_global=skip, nan_check_every=10 ** 9)
     if gather is not None:
         run.on_step = lambda k, i, pos: gather(k, i, pos, run.ws.nan_flag)
-
     run.advance(W)
     torch.cuda.synchronize()
     if use_dist:
@@ -184,26 +168,170 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    global_frac = (run.global_steps - g0) / max(K, 1)
+    return el, run, (run.global_steps - g0) / max(K, 1), gather
+
+
+def main():
+    global JOB_STEPS
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 1000; 10 per batch for drugs200)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 20; 2 per batch for drugs200)")
+    ap.add_argument("--workload", default="drugs", choices=["drugs", "drugs200", "qm9", "large", "alanine"])
+    ap.add_argument("--mols", type=int, default=8)
+    ap.add_argument("--copies", type=int, default=128)
+    ap.add_argument("--max-atoms", type=int, default=50000, help="drugs200: atoms per packed batch (driver.plan_batches)")
+    ap.add_argument("--schedule", default="saturated", choices=["saturated", "default"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--no-skip", action="store_true", help="run the global encoder even where its result is discarded")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the default-schedule runs reported under `extra`")
+    ap.add_argument("--no-traj", action="store_true")
+    ap.add_argument("--breakdown", default=None, help="write per-op timings (ms) to this JSON file")
+    ap.add_argument("--seed", type=int, default=2021)
+    ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"])
+    ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL all-gather path even with one rank")
+    ap.add_argument("--job-steps", type=int, default=JOB_STEPS, help="denoising steps of one sampling job (5000; the "
+                    "alanine dipeptide example runs 100)")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    if args.cpu_worker:
+        cpu_worker(*json.loads(args.cpu_worker))
+        return
+    JOB_STEPS = args.job_steps
+    d200 = args.workload == "drugs200"
+    K = args.steps if args.steps is not None else (10 if d200 else 1000)
+    W = args.warmup if args.warmup is not None else (2 if d200 else 20)
+    kind = "drugs" if d200 else args.workload
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+
+    # The CPU leg runs first, in separate interpreter processes, before this process initialises the GPU.
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(kind, args.schedule, args.seed)
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    use_dist = world > 1 or args.force_dist
     if use_dist:
-        tt = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
-        gt = torch.tensor([G], dtype=torch.int64, device=dev)
-        dist.all_reduce(gt)
-        G_total = int(gt.item())
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from agdiff_amd import _lib, driver, get_model, synth
+    from agdiff_amd.dist import shard_of
+    lib = _lib.load()
+
+    # The measured path never touches oracle/: the synthetic checkpoint comes from the product-side closed-form
+    # filler (agdiff_amd/synth.py; the oracle fills its own copy with the same function in the cpu_baseline leg).
+    def make_model(schedule):
+        cfg = make_cfg(kind, schedule)
+        m = get_model(cfg)
+        m.precision = args.precision
+        m.load_state_dict(synth.synth_state_dict(m.state_dict()))
+        return m.to(dev).eval(), cfg
+    model, cfg = make_model(args.schedule)
+
+    save_traj, skip = not args.no_traj, not args.no_skip
+    per_batch = None
+    if d200:
+        # configs[2]: 200 molecules, G = 2 x U{50..500} conformers each (utils/datasets.py:720-721,763), packed into
+        # batches of <= max_atoms atoms per GPU the way the driver does; ranks take whole batches round-robin (weak)
+        # or a graph range of every batch (strong)
+        rng = np.random.default_rng(args.seed)
+        mols200 = []
+        for i in range(200):
+            at_, r_, c_, t_ = synth.random_molecule(rng, synth.sample_n_atoms(rng, "drugs"))
+            mols200.append(dict(atom_type=at_, edge_index=np.stack([r_, c_]), edge_type=t_,
+                                num_refs=int(rng.integers(50, 501)), name="m%d" % i, index=i))
+        confs_of = driver.num_confs("2x")
+        strong = args.scaling == "strong"
+        batches = driver.plan_batches(mols200, confs_of, args.max_atoms * (world if strong else 1))
+        per_batch, tot_ms, G_local, E_sum, N_sum, gl = [], 0.0, 0, 0, 0, 0.0
+        run = None
+        for bidx, bm in enumerate(batches):
+            if not strong and bidx % world != rank:
+                continue
+            b = driver.pack_batch(bm, confs_of)
+            if strong:
+                b, _, _ = shard_of(b, rank, world)
+            del run
+            el, run, gfrac, gather = timed_run(model, dev, b, cfg, W, K, args.schedule, skip, save_traj, args.seed + bidx,
+                                               rank, use_dist and strong)
+            run.check_nan()
+            ms = el / K * 1e3
+            tot_ms += ms
+            G_local += b["num_graphs"]
+            E_b = int(run.ws.num_edges.item())
+            E_sum, N_sum, gl = E_sum + E_b, N_sum + run.topo.N, gl + gfrac
+            per_batch.append({"molecules": len(bm), "conformers": int(b["num_graphs"]), "atoms": run.topo.N,
+                              "edges": E_b, "ms_per_step": ms})
+        # whole job = every rank works through its batches one after the other: time = max over ranks of its sum
+        tt = torch.tensor([tot_ms], dtype=torch.float64, device=dev)
+        gt = torch.tensor([G_local], dtype=torch.int64, device=dev)
+        if use_dist:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            if not strong:
+                dist.all_reduce(gt)
+        ms_per_step = float(tt.item())          # ms for ONE step of EVERY batch of the slowest rank
+        G_total = sum(confs_of(m["num_refs"]) for m in mols200) if strong else int(gt.item())
+        value = G_total / (ms_per_step * JOB_STEPS / 1e3)
+        global_frac = gl / max(len(per_batch), 1)
+        wl = ("configs[2]: 200 Drugs-shaped synthetic molecules x 2*U{50..500} conformers = %d conformers, %d packed "
+              "batches of <= %d atoms%s (this rank: %d batches, %d atoms, %d edges), %d warm-up + %d timed steps per batch, "
+              "%s schedule, global branch active on %.0f%% of timed steps; ms_per_step = one step of every batch"
+              % (sum(confs_of(m["num_refs"]) for m in mols200), len(batches), args.max_atoms * (world if strong else 1),
+                 " cut into per-rank graph ranges" if strong else "", len(per_batch), N_sum, E_sum, W, K, args.schedule,
+                 100 * global_frac))
+        mols, copies = 200, None
     else:
-        G_total = G
-    run.check_nan()
-    ms_per_step = el / K * 1e3
-    value = G_total / (ms_per_step * JOB_STEPS / 1e3)
+        copies = args.copies if kind != "large" else 1
+        mols = args.mols if kind != "large" else args.mols * args.copies
+        if args.scaling == "strong":
+            gb = build_batch(kind, mols, copies, args.seed)            # ONE global batch, cut by graph ranges
+            b, (g0_, g1_), _ = shard_of(gb, rank, world)
+            if b is None:
+                raise SystemExit("strong scaling: rank %d got no graphs (%d graphs over %d ranks)" % (rank, gb["num_graphs"], world))
+        else:
+            b = build_batch(kind, mols, copies, args.seed + 1000 * rank)   # weak scaling: same shape per rank
+        el, run, global_frac, gather = timed_run(model, dev, b, cfg, W, K, args.schedule, skip, save_traj, args.seed,
+                                                 rank, use_dist)
+        G = b["num_graphs"]
+        if use_dist:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+            gt = torch.tensor([G], dtype=torch.int64, device=dev)
+            dist.all_reduce(gt)
+            G_total = int(gt.item())
+        else:
+            G_total = G
+        run.check_nan()
+        ms_per_step = el / K * 1e3
+        value = G_total / (ms_per_step * JOB_STEPS / 1e3)
+        if gather is not None:
+            parts, any_nan = gather.result()
+            assert len(parts) == world and parts[rank].shape[0] == run.topo.N and not any_nan
+            assert torch.equal(parts[rank], run.pos), "all-gathered shard differs from the local positions"
+        wl = ("%s-shaped synthetic molecules: %d molecules x %d conformers %s (this rank: %d atoms, %d edges, %d local "
+              "edges), %s schedule, global branch active on %.0f%% of timed steps, %d-step job"
+              % (kind, mols, copies, "in ONE global batch cut into per-rank graph ranges" if args.scaling == "strong"
+                 else "per GPU", run.topo.N, int(run.ws.num_edges.item()), run.topo.L, args.schedule, 100 * global_frac,
+                 JOB_STEPS))
 
     # ---- dominant kernel (fused CFConv) timed with events on the launch stream, workspace as the run left it
     ws, topo, pk = run.ws, run.topo, run.pk
     stream = _lib.stream_ptr()
     E = int(ws.num_edges.item())
     roof = None
-    if E > 0:
+    if E > 0 and rank == 0:
         reps, evs = 5, []
         for _ in range(reps):
             for k in range(cfg.num_convs):
@@ -219,16 +347,19 @@ def main():
         # HBM bytes per launch come from a separate rocprofv3 --pmc pass (tools/pmc_traffic.sh); the committed
         # figure applies to the workload it was taken on (same edge count within 1%), otherwise null
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "r01_%s_pmc_traffic.json" % args.precision)
-        if os.path.exists(tf):
-            tj = json.load(open(tf))
-            if abs(tj.get("workload_edges", 0) - E) <= 0.01 * E:
-                traffic = tj["kernels"]["k_cfconv_fused"]["hbm_bytes_per_launch"]
+        for rnd in ("r02", "r01"):
+            tf = os.path.join(ROOT, "profiles", "%s_%s_pmc_traffic.json" % (rnd, args.precision))
+            if os.path.exists(tf):
+                tj = json.load(open(tf))
+                if abs(tj.get("workload_edges", 0) - E) <= 0.01 * E:
+                    traffic = tj["kernels"]["k_cfconv_fused"]["hbm_bytes_per_launch"]
+                break
         roof = {"kernel": "k_cfconv_fused", "bound": "mfma", "achieved": ach, "peak": pk_, "unit": "TFLOP/s",
                 "frac": ach / pk_, "traffic": traffic, "avg_launch_ms": avg_ms, "edges_per_launch": E,
                 "mfma_issued_tflops": ach * MFMA_PASSES[args.precision],
-                "note": "achieved = algorithmic FLOPs (E x 90,112) / launch time; bf16x3 issues 3 bf16 MFMA "
-                        "FLOPs per algorithmic FLOP (hi.hi + lo.hi + hi.lo), fp32 accumulate"}
+                "note": "achieved = algorithmic FLOPs (E x 90,112: the reference evaluates the filter network on every "
+                        "directed edge) / launch time; bf16x3 issues 3 bf16 MFMA FLOPs per algorithmic FLOP (hi.hi + "
+                        "lo.hi + hi.lo), fp32 accumulate"}
 
     # ---- stand-alone CFConv aggregate (PyG propagate x_j * W, schnet.py:156-162) on the same graph: the HBM-bound
     # "scatter" kernel BASELINE.json's north_star prices against the HBM roofline (unfused form: W[E,F] streamed)
@@ -267,43 +398,56 @@ def main():
             torch.cuda.synchronize()
             ops[name] = e0.elapsed_time(e1) / reps
         P, Tp, Wp = ctypes.byref(pk.struct), ctypes.byref(topo.struct), ctypes.byref(ws.struct)
-        et, lt = (topo.max_edges + 31) // 32, (topo.L + 31) // 32
+        et, lt = (topo.max_edges + _lib.TILE - 1) // _lib.TILE, (topo.L + _lib.TILE - 1) // _lib.TILE
         timeit("graph_build", lambda: lib.agdiff_graph_build(Tp, Wp, run.pos_p, ctypes.c_float(cfg.cutoff), stream))
+        timeit("edge_scales", lambda: lib.agdiff_edge_scales(P, Tp, Wp, stream))
         timeit("edge_encoder", lambda: lib.agdiff_edge_encoder(P, _lib.ptr(ws.num_canon), et, _lib.ptr(ws.c_len), _lib.ptr(ws.c_type), _lib.ptr(ws.e_attr), _lib.ptr(ws.l_attr_rows), _lib.ptr(ws.e_loc), _lib.ptr(ws.c_pos), _lib.ptr(ws.c_mir), stream))
         timeit("node_stage_x%d" % (cfg.num_convs + 1), lambda: [lib.agdiff_schnet_node_stage(P, Tp, Wp, k, stream) for k in range(cfg.num_convs + 1)])
         timeit("cfconv_fused_x%d" % cfg.num_convs, lambda: [lib.agdiff_cfconv_fused(P, Tp, Wp, k, stream) for k in range(cfg.num_convs)])
         timeit("head_global", lambda: lib.agdiff_pair_head(ctypes.byref(pk.struct.head_global), _lib.ptr(ws.num_canon), et, _lib.ptr(ws.c_src), _lib.ptr(ws.c_dst), _lib.ptr(ws.h), _lib.ptr(ws.e_attr), None, _lib.ptr(ws.c_pos), _lib.ptr(ws.c_mir), _lib.ptr(ws.e_inv_global), stream))
         timeit("local_branch", lambda: lib.agdiff_score_forward(P, Tp, Wp, run.pos_p, 0, stream))
         timeit("score_forward_global", lambda: lib.agdiff_score_forward(P, Tp, Wp, run.pos_p, 1, stream))
-        ops.update(N=topo.N, E=E, L=topo.L, G=G, ms_per_step=ms_per_step)
+        ops.update(N=topo.N, E=E, L=topo.L, G=int(b["num_graphs"]), ms_per_step=ms_per_step)
         with open(args.breakdown, "w") as f:
             json.dump(ops, f, indent=1)
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(kind, args.schedule, args.seed)
+    # ---- the reference's own schedule on the same batch, with and without simplification (vii) (skipping
+    # the global branch on steps whose result the sampler discards changes the work per step, not the outputs)
+    extra = None
+    if rank == 0 and world == 1 and not args.no_extra and not d200 and args.schedule == "saturated" and kind != "alanine":
+        del run
+        m2, cfg2 = make_model("default")
+        Ke, We = min(K, 200), min(W, 10)
+        extra = {"note": "same batch and checkpoint, reference schedule (beta_end 2e-3: sigma < 0.5 on 2012 of 5000 "
+                         "steps), %d timed steps spread evenly over the schedule; the synthetic model has no restoring "
+                         "force, so at high sigma the molecules spread out and the radius graph thins" % Ke}
+        for name, sk in (("default_schedule_skip_discarded_global", True), ("default_schedule_no_skip", False)):
+            el2, run2, gf2, _ = timed_run(m2, dev, b, cfg2, We, Ke, "default", sk, save_traj, args.seed, rank, False)
+            run2.check_nan()
+            ms2 = el2 / Ke * 1e3
+            extra[name] = {"value": b["num_graphs"] / (ms2 * JOB_STEPS / 1e3), "unit": "conformers/s",
+                           "ms_per_step": ms2, "steps": Ke, "global_branch_share_of_steps": gf2}
+            del run2
+        if cpu is not None:
+            extra["x_vs_cpu_whole_host"] = value / cpu["value"]
+            extra["x_vs_cpu_single_process"] = value / cpu["single_process"]["value"]
 
-    if gather is not None:
-        parts, any_nan = gather.result()
-        assert len(parts) == world and parts[rank].shape[0] == at.shape[0] and not any_nan
-        assert torch.equal(parts[rank], run.pos), "all-gathered shard differs from the local positions"
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:
         out = {
             "metric": "conformers/sec (whole node), GEOM-Drugs 5000-step sampling",
             "value": value, "unit": "conformers/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None,      # the reference publishes no number for this metric
             "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "%s-shaped synthetic molecules: %d molecules x %d conformers per GPU "
-                                   "(%d atoms, %d edges, %d local edges per GPU), %s schedule, "
-                                   "global branch active on %.0f%% of timed steps, %d-step job"
-                                   % (kind, mols, copies, topo.N, E, topo.L, args.schedule, 100 * global_frac, JOB_STEPS),
-                       "conformers_total": G_total, "parallelism": "dp%d" % world,
-                       "all_gather_per_step": use_dist, "trajectory_saved": not args.no_traj,
-                       "skip_discarded_global": not args.no_skip},
-            "roofline": roof, "roofline_cfconv_aggregate": agg_roof, "cpu_baseline": cpu,
+            "config": {"workload": wl, "conformers_total": G_total, "parallelism": "dp%d" % world,
+                       "all_gather_per_step": bool(use_dist), "trajectory_saved": save_traj,
+                       "skip_discarded_global": skip},
+            "roofline": roof, "roofline_cfconv_aggregate": agg_roof, "cpu_baseline": cpu, "extra": extra,
         }
+        if per_batch is not None:
+            out["config"]["batches"] = per_batch
         sys.stdout.flush()
         ctypes.CDLL(None).fflush(None)         # RCCL writes its banner through C stdio (block-buffered on a pipe):
         print(json.dumps(out), flush=True)     # push it out first, so that the JSON is the last line of stdout
