@@ -23,6 +23,12 @@
 namespace {
 
 #define AG_PAIR_WAVES 8
+// timing experiments (separate builds): -DPAIR_ABL=<bits>   1 no mirror MFMAs, 2 no x[dst] gathers, 4 no direct sums
+// measured at the bench workload: full 0.578 ms, 1: 0.543, 2: 0.556, 3: 0.530, 7: 0.445 (profiles/r02_pairs_prototype.txt)
+#ifndef PAIR_ABL
+#define PAIR_ABL 0
+#endif
+#define AG_PABL(bit) ((PAIR_ABL) & (bit))
 
 // ---------------------------------------------------------------------------------------------------------------
 // Both convs in ONE launch.  Per tile the lighter conv2 (64 filter channels) runs first and conv1 (128) second, each as
@@ -124,7 +130,7 @@ __global__ void __launch_bounds__(64 * AG_PAIR_WAVES, 2) k_cfconv_pairs_fused(Pa
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           xg[r] = xb[xoff[r]];
-          xdg[r] = xb[xdoff[r]];
+          xdg[r] = AG_PABL(2) ? xg[r] : xb[xdoff[r]];
         }
       };
       fetch_x(8);
@@ -251,12 +257,14 @@ __global__ void __launch_bounds__(64 * AG_PAIR_WAVES, 2) k_cfconv_pairs_fused(Pa
                 p0[j] = fmaf(t[r], w0[r], p0[j]);
                 p1[j] = fmaf(t[r], w1m[r], p1[j]);
               }
+              if (!AG_PABL(1)) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const float u = zb[r] * (sr[r] * xdp[r]);
-                acc[OT0 + nt - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(selA[r], u, acc[OT0 + nt - 1], 0, 0, 0);
+                for (int r = 0; r < 4; ++r) {
+                  const float u = zb[r] * (sr[r] * xdp[r]);
+                  acc[OT0 + nt - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(selA[r], u, acc[OT0 + nt - 1], 0, 0, 0);
+                }
               }
-              if (j == 3) {
+              if (j == 3 && !AG_PABL(4)) {
                 const float r0 = ag_quarter_reduce_scatter4(p0[0], p0[1], p0[2], p0[3]);
                 const float r1 = ag_quarter_reduce_scatter4(p1[0], p1[1], p1[2], p1[3]);
                 dp0[16 * (OT0 + 4 * g4 + q) + col] = r0;

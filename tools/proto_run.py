@@ -165,7 +165,24 @@ torch.cuda.synchronize()
 d = float((agg2.view(S, 192) - agg_seg.view(S, 192)).abs().max() / agg_seg.abs().max())
 print("old code on the new order: direct sums vs new kernel %.2e (chunk tiles %d)" % (d, ct2))
 
+# the product kernel on its own order, cut to the same number of rows (fixed launch costs vs per-tile costs)
+topo3, ws3 = _lib.Topo(), _lib.Workspace()
+ctypes.memmove(ctypes.byref(topo3), ctypes.byref(topo.struct), ctypes.sizeof(topo3))
+ctypes.memmove(ctypes.byref(ws3), ctypes.byref(ws.struct), ctypes.sizeof(ws3))
+topo3.max_edges = R
+esc3 = torch.zeros(2 * _lib.DEFINES["AGDIFF_MAX_CONVS"] * R, dtype=torch.float32, device=dev)
+for c in (0, 1):
+    esc3[(2 * K + c) * R:(2 * K + c + 1) * R] = ws.e_scale[(2 * K + c) * epad:(2 * K + c) * epad + R]
+first3 = torch.zeros_like(first2)
+setattr(ws3, "num_edges", _lib.ptr(nR)); setattr(ws3, "e_scale", _lib.ptr(esc3)); setattr(ws3, "agg_first", _lib.ptr(first3))
+
+
+def old_cut():
+    assert lib.agdiff_cfconv_fused(P, ctypes.byref(topo3), ctypes.byref(ws3), K, st) == 0
+
+
 for rep in range(3):
+    print("product kernel on its own order, first %d rows only: %.4f ms" % (R, timeit(old_cut, args.reps)))
     print("product kernel code on the pair order (direct sums only): %.4f ms" % timeit(old_on_new, args.reps))
     to = timeit(old, args.reps)
     tf = timeit(newf, args.reps)
