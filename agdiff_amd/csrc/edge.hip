@@ -377,6 +377,18 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, AG_CONV_WAVES / 4) k_cfcon
         for (int r = 0; r < 4; ++r) xg[r] = xb[xoff[r]];
       };
       fetch_x(0);          // requested here, before the first layer: lands while its MFMAs run
+      // the wave's next tile: edge attributes (HBM) + per-edge scalars.  Loads return in issue order (vmcnt), so every
+      // x gather issued after this request waits for it too.  Issuing it later (inside the channel-tile loop, at tile 3 /
+      // 6 / 9) was measured: 0.64 / 0.49 / 0.49 ms per launch against 0.476 here.
+      auto prefetch_next = [&]() {
+        int64_t nxt = tile + 1;
+        if (tt + 1 >= a.chunk_tiles) nxt = (chunk + cstride) * a.chunk_tiles;
+        if (nxt * AG_TW < E && nxt < a.max_chunks * a.chunk_tiles) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) ag_load_attr(ea[t], a.e_attr, nxt, t, lane);
+          prefetch_meta(nxt, lane);
+        }
+      };
       AgIn<MODE> hidb[6];
       {
         // First filter layer of both convs (128 -> 192), all 48 weight blocks from LDS (block (t, ot) at
@@ -423,15 +435,7 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, AG_CONV_WAVES / 4) k_cfcon
           }
           hp0 = h0; hp1 = h1;
         }
-        {
-          int64_t nxt = tile + 1;
-          if (tt + 1 >= a.chunk_tiles) nxt = (chunk + cstride) * a.chunk_tiles;
-          if (nxt * AG_TW < E && nxt < a.max_chunks * a.chunk_tiles) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) ag_load_attr(ea[t], a.e_attr, nxt, t, lane);
-            prefetch_meta(nxt, lane);
-          }
-        }
+        prefetch_next();
       }
       AG_STAMP(c1); st[1] += c1 - c0; c0 = c1;       // layer 1 + softplus + split (one pipeline)
       // Row masks of the first two targets of the tile, built once per tile: almost every 16-edge tile holds

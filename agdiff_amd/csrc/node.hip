@@ -186,6 +186,211 @@ __global__ void __launch_bounds__(LDSW ? 1024 : 256, LDSW ? 1 : 2) k_schnet_node
   }
 }
 
+// ------------------------------------------------------------------------------ SchNet node stage, small batches
+// The same stage for batches with so few node tiles that one wave per tile leaves most of the chip idle and every wave
+// spends its time waiting for its own 188 weight blocks from L2 (376 KiB per tile, ~25 us per launch at 270 tiles):
+// here a WORKGROUP of four waves owns one 16-node tile, wave w computes a quarter of every layer's output tiles
+// (so it streams 50 blocks instead of 188, through one register ring that runs ahead across the layer boundaries), and
+// the waves hand the activations to each other through LDS in MFMA operand form between the layers.
+//   step list of wave w (s = ring position; FINISH part 38 steps, PREP part 12):
+//   [0,8) lin2 conv1: out tiles 2w,2w+1 | [8,12) lin2 conv2 | [12,28) lin: out tiles 2w,2w+1 | [28,32) gate1: out tile w
+//   [32,36) scale fc.0 (all waves alike) | [36,38) scale fc.2: out tiles 2w,2w+1 | [38,50) next lin1: out tiles 3w..3w+2
+template <int MODE>
+__device__ __forceinline__ void ag_xch_put(lds_u32x4* x, int kt, const AgIn<MODE>& v, int lane) {
+  if constexpr (MODE == AG_F32) {
+    x[(kt * 2) * 64 + lane] = __builtin_bit_cast(u32x4, v.v[0]);
+    x[(kt * 2 + 1) * 64 + lane] = __builtin_bit_cast(u32x4, v.v[1]);
+  } else {
+    x[(kt * 2) * 64 + lane] = __builtin_bit_cast(u32x4, v.hi);
+    x[(kt * 2 + 1) * 64 + lane] = __builtin_bit_cast(u32x4, v.lo);
+  }
+}
+template <int MODE>
+__device__ __forceinline__ void ag_xch_get(const lds_u32x4* x, int kt, AgIn<MODE>& v, int lane) {
+  if constexpr (MODE == AG_F32) {
+    v.v[0] = __builtin_bit_cast(f32x4, x[(kt * 2) * 64 + lane]);
+    v.v[1] = __builtin_bit_cast(f32x4, x[(kt * 2 + 1) * 64 + lane]);
+  } else {
+    v.hi = __builtin_bit_cast(bf16x8, x[(kt * 2) * 64 + lane]);
+    v.lo = __builtin_bit_cast(bf16x8, x[(kt * 2 + 1) * 64 + lane]);
+  }
+}
+
+template <int MODE, bool FINISH, bool PREP>
+__global__ void __launch_bounds__(256, 2) k_schnet_node_stage_split(NodeStageArgs a) {
+  __shared__ u32x4 ag_split_xch[20 * 128];         // 20 k-tiles of 2 KiB: U 0..7 | X 8..11 | gated X 12..15 | H 16..19
+  __shared__ float ag_split_red[4][16];
+  lds_u32x4* xch = (lds_u32x4*)ag_split_xch;
+  const int lane = ag_lane(), q = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(ag_wave_in_wg());
+  const int64_t tile = blockIdx.x;
+  const int64_t node = tile * AG_TW + (lane & 15);
+  const bool valid = node < a.n;
+  const int64_t nd = valid ? node : 0;
+  constexpr int NF = FINISH ? 38 : 0, NS = NF + (PREP ? 12 : 0);
+  constexpr int PF = 12, R = PF + 1;      // 12 blocks (24 KiB) in flight per wave: the stage is a chain of L2 round trips
+
+  auto block_of = [&](int s) -> const float* {
+    if (FINISH && s < 8) return a.prev.lin2a_pk + (size_t)((s >> 1) * 8 + 2 * w + (s & 1)) * 512;
+    if (FINISH && s < 12) return a.prev.lin2b_pk + (size_t)(((s - 8) >> 1) * 8 + 2 * w + (s & 1)) * 512;
+    if (FINISH && s < 28) return a.prev.lin_pk + (size_t)((2 * w + ((s - 12) >> 3)) * 8 + ((s - 12) & 7)) * 512;
+    if (FINISH && s < 32) return a.prev.gate1_pk + (size_t)(w * 4 + (s - 28)) * 512;
+    if (FINISH && s < 36) return a.prev.scale1_pk + (size_t)(s - 32) * 512;
+    if (FINISH && s < 38) return a.prev.scale2_pk + (size_t)(2 * w + (s - 36)) * 512;
+    return a.next.lin1_pk + (size_t)((3 * w + ((s - NF) >> 2)) * 4 + ((s - NF) & 3)) * 512;
+  };
+  u32x4 ring[R][2];
+  auto request = [&](int s) {
+    const u32x4* p = reinterpret_cast<const u32x4*>(block_of(s)) + lane;
+    ring[s % R][0] = p[0];
+    ring[s % R][1] = p[64];
+  };
+#pragma unroll
+  for (int s = 0; s < (PF < NS ? PF : NS); ++s) request(s);
+
+  f32x4 u4[4], xc2[2], g1[1], s1[2], s2[2], hv2[2], xo3[3];
+  AgIn<MODE> gk[6], ub[8], xb[4], sb[1], hb[4];
+  if (FINISH) {
+    // aggregates of the tile's nodes (every wave needs the whole 192-wide row): agg[node] + the partial sums its later
+    // chunks kept in agg_first, added in chunk order (as k_schnet_node_stage)
+    const int lo = a.in_ptr[nd], hi = a.in_ptr[nd + 1];
+    const int chunk_e = a.chunk_edges;
+    const bool has = hi > lo;
+    const int c_lo = lo / chunk_e, c_hi = has ? (hi - 1) / chunk_e : c_lo;
+    const float* ar = a.agg + (size_t)nd * 192;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      f32x4 v0 = has ? ag_ld4(ar + 32 * k + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 v1 = has ? ag_ld4(ar + 32 * k + 16 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int c = c_lo + 1; c <= c_hi; ++c) {
+        const float* fr = a.agg_first + (size_t)c * 192;
+        v0 += ag_ld4(fr + 32 * k + 4 * q);
+        v1 += ag_ld4(fr + 32 * k + 16 + 4 * q);
+      }
+      ag_cvt(v0, v1, gk[k]);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      u4[j] = ag_ld4(a.prev.lin2_b + 16 * (2 * w + j) + 4 * q);
+      u4[2 + j] = ag_ld4(a.prev.lin2_b + 128 + 16 * (2 * w + j) + 4 * q);
+      xc2[j] = ag_ld4(a.prev.lin_b + 16 * (2 * w + j) + 4 * q);
+      s2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    g1[0] = ag_ld4(a.prev.gate1_b + 16 * w + 4 * q);
+    s1[0] = s1[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) hv2[j] = ag_ld4(a.h + (size_t)nd * 128 + 16 * (2 * w + j) + 4 * q);   // used at the end
+  } else {
+    // stage 0: h = embedding[z]; wave w writes its two tiles of the row, every wave keeps the whole row as operands
+    f32x4 hrow[8];
+    ag_load_row<8, 0>(hrow, a.emb + (size_t)a.atom_type[nd] * 128, q);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      // tiles 2w, 2w+1 of the row (runtime w: select with a short chain)
+      f32x4 t = hrow[j];
+#pragma unroll
+      for (int ww = 1; ww < 4; ++ww) t = (w == ww) ? hrow[2 * ww + j] : t;
+      if (valid) ag_st4(a.h + (size_t)node * 128 + 16 * (2 * w + j) + 4 * q, t);
+    }
+    ag_cvt_tiles<MODE, 4, 0>(hrow, hb);
+  }
+  if (PREP) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) xo3[j] = ag_ld4(a.next.lin1_b + 16 * (3 * w + j) + 4 * q);
+  }
+
+  // one ring position: request the block PF steps ahead, then use this step's block (every loop below is short and
+  // fully unrolled, so ring / operand / accumulator indices are compile-time constants)
+#define AG_SPLIT_STEP(s, acc, x)                        \
+  do {                                                  \
+    if ((s) + PF < NS) request((s) + PF);               \
+    ag_block_mma<MODE, false>(acc, x, ring[(s) % R]);   \
+    __builtin_amdgcn_sched_barrier(0);                  \
+  } while (0)
+  if constexpr (FINISH) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) AG_SPLIT_STEP(i, u4[i & 1], gk[i >> 1]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) AG_SPLIT_STEP(8 + i, u4[2 + (i & 1)], gk[4 + (i >> 1)]);
+    {
+      const float beta = a.prev.act_beta;
+      AG_FOR_TILE(u4, 4, ag_ssp(beta, v));
+      AgIn<MODE> k0, k1;
+      ag_cvt(u4[0], u4[1], k0);
+      ag_cvt(u4[2], u4[3], k1);
+      ag_xch_put<MODE>(xch, w, k0, lane);
+      ag_xch_put<MODE>(xch, 4 + w, k1, lane);
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < 8; ++t) ag_xch_get<MODE>(xch, t, ub[t], lane);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) AG_SPLIT_STEP(12 + i, xc2[i >> 3], ub[i & 7]);
+    {
+      AgIn<MODE> k0;
+      ag_cvt(xc2[0], xc2[1], k0);
+      ag_xch_put<MODE>(xch, 8 + w, k0, lane);
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < 4; ++t) ag_xch_get<MODE>(xch, 8 + t, xb[t], lane);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) AG_SPLIT_STEP(28 + i, g1[0], xb[i]);
+    {
+      AG_FOR_TILE(g1, 1, ag_relu(v));
+      const f32x4 gw = ag_ld4(a.prev.gate2_w + 16 * w + 4 * q);
+      float part = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part = fmaf(gw[r], g1[0][r], part);
+      part = ag_quarter_sum(part);
+      if (q == 0) ag_split_red[w][lane & 15] = part;
+      __syncthreads();
+      const int c = lane & 15;
+      const float tot = ((ag_split_red[0][c] + ag_split_red[1][c]) + ag_split_red[2][c]) + ag_split_red[3][c];
+      const float gate = ag_sigmoid(tot + a.prev.gate2_b);
+      AG_FOR_TILE(xc2, 2, v * gate);
+      AgIn<MODE> k0;
+      ag_cvt(xc2[0], xc2[1], k0);
+      ag_xch_put<MODE>(xch, 12 + w, k0, lane);
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < 4; ++t) ag_xch_get<MODE>(xch, 12 + t, xb[t], lane);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) AG_SPLIT_STEP(32 + i, s1[0], xb[i]);
+    AG_FOR_TILE(s1, 1, ag_relu(v));
+    ag_cvt(s1[0], s1[1], sb[0]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) AG_SPLIT_STEP(36 + i, s2[i], sb[0]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hv2[j][r] = hv2[j][r] + xc2[j][r] * ag_sigmoid(s2[j][r]);
+      if (valid) ag_st4(a.h + (size_t)node * 128 + 16 * (2 * w + j) + 4 * q, hv2[j]);
+    }
+    if constexpr (PREP) {
+      AgIn<MODE> k0;
+      ag_cvt(hv2[0], hv2[1], k0);
+      ag_xch_put<MODE>(xch, 16 + w, k0, lane);
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < 4; ++t) ag_xch_get<MODE>(xch, 16 + t, hb[t], lane);
+    }
+  }
+  if constexpr (PREP) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) AG_SPLIT_STEP(NF + i, xo3[i >> 2], hb[i & 3]);
+  }
+#undef AG_SPLIT_STEP
+  if (PREP) {
+    AG_FOR_TILE(xo3, 3, ag_lrelu(v));
+    if (valid) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) ag_st4(a.xs + (size_t)node * 192 + 16 * (3 * w + j) + 4 * q, xo3[j]);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------ GIN layer
 struct GinArgs {
   agdiff_gin_params_t gp;
@@ -548,6 +753,12 @@ static int64_t ag_node_ldsw_min_tiles() {
   const char* e = getenv("AGDIFF_NODE_LDSW_MIN_TILES");
   return e ? atoll(e) : 1536;
 }
+// Up to this many node tiles the stage runs with four waves per tile (k_schnet_node_stage_split); AGDIFF_NODE_SPLIT_MAX_TILES
+// overrides (tests run every variant on the same batch; 0 switches the split variant off).
+static int64_t ag_node_split_max_tiles() {
+  const char* e = getenv("AGDIFF_NODE_SPLIT_MAX_TILES");
+  return e ? atoll(e) : 320;      // measured (1 molecule x 25 / 100 / 200 conformers): 70 vs 130, 118 vs 138, 186 vs 150 us per 7 stages
+}
 static int ag_node_waves_per_wg(int64_t tiles) {
   if (tiles < ag_node_ldsw_min_tiles()) return 4;
   int64_t w = (tiles + 255) / 256;
@@ -574,6 +785,21 @@ extern "C" int agdiff_schnet_node_stage(const agdiff_params_t* p, const agdiff_t
   a.n = topo->num_nodes;
   a.chunk_edges = AG_TW * agdiff_conv_chunk_tiles(topo->max_edges);
   const int64_t tiles = (a.n + AG_TW - 1) / AG_TW;
+  hipStream_t st = (hipStream_t)stream;
+  if (tiles <= ag_node_split_max_tiles()) {       // small batch: four waves per tile (k_schnet_node_stage_split)
+    const dim3 grid((unsigned)tiles), block(256);
+#define AG_LAUNCH_SPLIT(M)                                                                  \
+    do {                                                                                    \
+      if (a.finish && a.prep) k_schnet_node_stage_split<M, true, true><<<grid, block, 0, st>>>(a);        \
+      else if (a.finish) k_schnet_node_stage_split<M, true, false><<<grid, block, 0, st>>>(a);            \
+      else k_schnet_node_stage_split<M, false, true><<<grid, block, 0, st>>>(a);                          \
+    } while (0)
+    if (p->precision == AG_BF3) AG_LAUNCH_SPLIT(AG_BF3);
+    else AG_LAUNCH_SPLIT(AG_F32);
+#undef AG_LAUNCH_SPLIT
+    AG_CHECK_LAUNCH();
+    return AGDIFF_OK;
+  }
   const int waves = ag_node_waves_per_wg(tiles);
   const bool ldsw = tiles >= ag_node_ldsw_min_tiles();
   const size_t smem = ldsw ? (size_t)AG_NODE_LDS_BLOCKS * 2048 : 0;
@@ -582,7 +808,6 @@ extern "C" int agdiff_schnet_node_stage(const agdiff_params_t* p, const agdiff_t
                         k_schnet_node_stage<AG_F32, true>))
     return AGDIFF_ERR_LAUNCH;
   const dim3 grid((unsigned)((tiles + waves - 1) / waves)), block(64 * waves);
-  hipStream_t st = (hipStream_t)stream;
   if (p->precision == AG_BF3) {
     if (ldsw) k_schnet_node_stage<AG_BF3, true><<<grid, block, smem, st>>>(a);
     else k_schnet_node_stage<AG_BF3, false><<<grid, block, 0, st>>>(a);

@@ -258,26 +258,32 @@ def test_extend_order_true_matches_reference_golden(precision):
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
-def test_node_kernels_lds_shared_variant(precision, monkeypatch):
-    """The SchNet node stage and the GIN layer have two weight-delivery variants (per-wave streaming for small
-    batches, workgroup-shared LDS copies for large ones, csrc/node.hip) with the same MFMA order: fp32 mode is
-    bitwise equal, the split-bf16 mode differs only by FMA contraction around the hi/lo split (two template
-    instantiations), and both must match the reference fixture."""
+def test_node_kernel_variants(precision, monkeypatch):
+    """The SchNet node stage has three weight-delivery variants (csrc/node.hip): four waves per tile with LDS hand-offs
+    for small batches, one wave per tile streaming from L2, and workgroup-shared LDS copies for large batches (the
+    GIN layer has the last two).  Streaming and LDS-shared run the same MFMA order: bitwise equal in fp32 mode (the
+    split-bf16 mode differs only by FMA contraction around the hi/lo split of two template instantiations); the
+    four-wave variant sums the gate's dot product in another order.  All must match the reference fixture."""
     case = "g3_forward_drugs_capped"
     g = load_golden(case)
     m, _ = _gpu_model(FORWARD_CASES[case](), precision=precision)
     a = (t(g["atom_type"]).cuda(), t(g["pos"]).cuda(), t(g["bond_index"]).cuda(), t(g["bond_type"]).cuda(),
          t(g["batch"]).cuda(), None)
-    base = m(*a, return_edges=True, extend_order=False)
+    split = m(*a, return_edges=True, extend_order=False)                 # default for a batch this small
+    monkeypatch.setenv("AGDIFF_NODE_SPLIT_MAX_TILES", "0")
+    stream = m(*a, return_edges=True, extend_order=False)
     monkeypatch.setenv("AGDIFF_NODE_LDSW_MIN_TILES", "1")
     shared = m(*a, return_edges=True, extend_order=False)
     monkeypatch.delenv("AGDIFF_NODE_LDSW_MIN_TILES")
+    monkeypatch.delenv("AGDIFF_NODE_SPLIT_MAX_TILES")
     if precision == "f32":
-        assert torch.equal(base[0], shared[0]) and torch.equal(base[1], shared[1])
-    assert rel_err(shared[0].cpu().numpy(), base[0].cpu().numpy()) < 1e-5
-    assert rel_err(shared[1].cpu().numpy(), base[1].cpu().numpy()) < 1e-5
-    check_close("node_kernels_lds_shared_variant shared[0]", shared[0].cpu().numpy(), g["edge_inv_global"], precision)
-    check_close("node_kernels_lds_shared_variant shared[1]", shared[1].cpu().numpy(), g["edge_inv_local"], precision)
+        assert torch.equal(stream[0], shared[0]) and torch.equal(stream[1], shared[1])
+    assert torch.equal(stream[1], split[1])                               # the local branch does not use the node stage
+    assert not torch.equal(stream[0], split[0]) or precision == "f32"
+    for name, v in (("split", split), ("stream", stream), ("shared", shared)):
+        assert rel_err(v[0].cpu().numpy(), stream[0].cpu().numpy()) < (2e-6 if precision == "f32" else 1e-5), name
+        check_close("node_kernel_variants %s inv_g" % name, v[0], g["edge_inv_global"], precision)
+        check_close("node_kernel_variants %s inv_l" % name, v[1], g["edge_inv_local"], precision)
 
 
 def test_nan_raises_floating_point_error():
