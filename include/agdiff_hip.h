@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 16
+#define AGDIFF_ABI_VERSION 17
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -32,6 +32,7 @@ extern "C" {
 #define AGDIFF_RADIUS_CAP 33       /* max_num_neighbors + 1 (torch_cluster.radius_graph, common.py:217) */
 #define AGDIFF_TILE 16             /* edges / nodes per MFMA tile */
 #define AGDIFF_MAX_CHUNK_TILES 8   /* most tiles one wave walks per chunk in the fused CFConv kernel (128 edges) */
+#define AGDIFF_RMSD_MAX_ATOMS 256  /* most (heavy) atoms per conformer in agdiff_rmsd_matrix */
 
 enum agdiff_status {
   AGDIFF_OK = 0,
@@ -308,6 +309,25 @@ int agdiff_diffusion_loss(const agdiff_params_t* p, const agdiff_topo_t* topo, c
 /* One denoising step = agdiff_score_forward + agdiff_langevin_update (dualenc.py:478-545). */
 int agdiff_langevin_step(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
                          const agdiff_step_args_t* a, void* stream);
+
+/* ---- evaluation (the step after the path) ------------------------------------------------------
+ * get_rmsd_confusion_matrix (utils/evaluation/covmat.py:16-35): out[j][i] = GetBestRMS(gen_i, ref_j) over the atoms
+ * listed in `atom_idx` (the reference removes hydrogens first, utils/chem.py:133-137) = the smallest, over the atom
+ * mappings `perms`, of the RMSD after the optimal proper rotation + translation (rdkit rdMolAlign.GetBestRMS: every
+ * substructure match of the molecule onto itself is aligned with AlignMol, no reflection, uniform weights).
+ *   pos_ref [R][n][3], pos_gen [G][n][3]   conformers of ONE molecule with n atoms
+ *   atom_idx [m]                            atoms that take part (m <= AGDIFF_RMSD_MAX_ATOMS), e.g. the heavy atoms
+ *   perms [P][m] or null                    mapping p pairs generated atom atom_idx[k] with reference atom
+ *                                           atom_idx[perms[p][k]]; null = the identity only (no symmetry: an upper bound
+ *                                           of GetBestRMS)
+ *   scratch [(R + G) * (3 m + 1)] floats    centred coordinates of the selected atoms (written by the call)
+ *   out [R][G] */
+int agdiff_rmsd_matrix(const float* pos_ref, const float* pos_gen, const int32_t* atom_idx, const int32_t* perms,
+                       int32_t R, int32_t G, int32_t n, int32_t m, int32_t P, float* scratch, float* out, void* stream);
+
+/* Row and column minima of a confusion matrix [R][G] (covmat.py:135-136: rmsd_ref_min = min over generated,
+ * rmsd_gen_min = min over references): row_min [R], col_min [G]. */
+int agdiff_matrix_minima(const float* mat, int32_t R, int32_t G, float* row_min, float* col_min, void* stream);
 
 #ifdef __cplusplus
 }

@@ -327,16 +327,91 @@ def g_extend_order_forward():
     save("g12_extend_order_forward", **rec)
 
 
+def g_covmat():
+    """§8f-4: the COV / MAT reductions and the filtering of CovMatEvaluator.__call__ (utils/evaluation/covmat.py:
+    104-165) on injected RMSD confusion matrices.  rdkit (GetBestRMS) is third party and absent: the matrices are
+    inputs here, and only what the reference's own Python does with them is recorded."""
+    for name in ("rdkit", "rdkit.Chem", "rdkit.Chem.rdForceFieldHelpers"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["rdkit"].Chem = sys.modules["rdkit.Chem"]
+    sys.modules["rdkit.Chem.rdForceFieldHelpers"].MMFFOptimizeMolecule = lambda m: None
+    ed = types.ModuleType("easydict")
+
+    class EasyDict(dict):
+        def __init__(self, d=None):
+            super().__init__(d or {})
+            self.__dict__ = self
+    ed.EasyDict = EasyDict
+    sys.modules.setdefault("easydict", ed)
+    chem.get_best_rmsd = lambda a, b: 0.0
+    chem.set_rdmol_positions = lambda m, p: m
+    from agdiff.utils.evaluation import covmat as ref_covmat
+
+    class Mol:
+        def __init__(self, n):
+            self.n = n
+
+        def GetNumAtoms(self):
+            return self.n
+    rng = np.random.default_rng(13)
+    mats, datas, recs = [], [], {}
+    spec = [(9, 5, 10, "CCO"), (12, 7, 14, "c1ccccc1"), (6, 4, 9, "CC.O"), (8, 6, 11, "CCN"), (7, 3, 6, "C#N")]
+    for i, (n, R, G, smi) in enumerate(spec):
+        d = {"smiles": smi, "rdmol": Mol(n), "pos_ref": torch.randn(R * n, 3), "pos_gen": torch.randn(G * n, 3)}
+        if i == 4:
+            del d["pos_gen"]                       # skipped: nothing generated
+        datas.append(d)
+        recs["n%d" % i], recs["R%d" % i], recs["G%d" % i] = n, R, G
+        recs["disconnected%d" % i] = int("." in smi)
+        recs["has_gen%d" % i] = int(i != 4)
+    # molecule 3 has G = 11 < ratio * R = 12 -> filtered; molecule 2 is disconnected -> filtered
+    kept = [0, 1]
+    for i in kept:
+        R, G = spec[i][1], 2 * spec[i][1]
+        m = np.abs(rng.normal(0.8, 0.5, size=(R, G)))
+        mats.append(m)
+        recs["confusion%d" % i] = m
+    it = iter(mats)
+    ref_covmat.get_rmsd_confusion_matrix = lambda data, useFF=False: next(it)
+    ev = ref_covmat.CovMatEvaluator(num_workers=1, print_fn=lambda s: None)
+    ev.pool.close(); ev.pool.join()
+
+    class Serial:
+        def imap(self, f, xs):
+            return map(lambda x: ref_covmat.get_rmsd_confusion_matrix(x), xs)
+
+        def close(self):
+            pass
+
+        def join(self):
+            pass
+    ev.pool = Serial()
+    res = ev(datas)
+    recs.update(thresholds=res.thresholds, CoverageR=res.CoverageR, MatchingR=res.MatchingR, CoverageP=res.CoverageP,
+                MatchingP=res.MatchingP, kept=np.array(kept))
+    lines = []
+    df = ref_covmat.print_covmat_results(res, print_fn=lines.append)
+    recs["df_values"] = df.values
+    recs["df_columns"] = np.array(list(df.columns))
+    recs["print_lines"] = np.array(lines)
+    # evaluate_conf (covmat.py:38-41) on the first matrix
+    it = iter([mats[0]])
+    ref_covmat.get_rmsd_confusion_matrix = lambda data, useFF=False: next(it)
+    cov, mat = ref_covmat.evaluate_conf(datas[0], threshold=0.5)
+    recs["evaluate_conf"] = np.array([cov, mat])
+    save("g13_covmat", **recs)
+
+
 def g_losses():
     g_loss("g10_loss_qm9", qm9_model_config(), "qm9", 31, 3, 2, 1.6)
     g_loss("g10_loss_drugs", drugs_model_config(), "drugs", 32, 2, 2, 2.5)
 
 
 if __name__ == "__main__":
-    if sys.argv[1:] and all(a in ("gaussian", "alanine", "loss", "variants", "extend") for a in sys.argv[1:]):   # add without touching the others
+    if sys.argv[1:] and all(a in ("gaussian", "alanine", "loss", "variants", "extend", "covmat") for a in sys.argv[1:]):   # add without touching the others
         for a in sys.argv[1:]:
             {"gaussian": g_gaussian, "alanine": g_alanine, "loss": g_losses, "variants": g_forward_variants,
-             "extend": g_extend_order_forward}[a]()
+             "extend": g_extend_order_forward, "covmat": g_covmat}[a]()
         sys.exit(0)
     g_schedule_and_keys()
     # G2+G3 uncapped QM9-shaped batch with per-stage outputs (small: 3 molecules x 1 copy)
@@ -360,3 +435,4 @@ if __name__ == "__main__":
     g_losses()
     g_forward_variants()
     g_extend_order_forward()
+    g_covmat()
