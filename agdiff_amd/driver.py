@@ -56,18 +56,26 @@ def load_testset(path):
 
 
 def plan_batches(mols, confs_of, max_atoms):
-    """Greedy packing in input order: a batch closes when adding the next molecule's copies would exceed
-    `max_atoms` (a molecule larger than that gets a batch of its own)."""
-    batches, cur, atoms = [], [], 0
-    for m in mols:
-        need = int(m["atom_type"].shape[0]) * confs_of(m["num_refs"])
-        if cur and atoms + need > max_atoms:
-            batches.append(cur)
-            cur, atoms = [], 0
-        cur.append(m)
-        atoms += need
-    if cur:
-        batches.append(cur)
+    """First-fit decreasing: molecules sorted by their atom count x conformers (largest first), each put into the first
+    batch it still fits into (a molecule larger than `max_atoms` gets a batch of its own).  Packing in input order
+    leaves many half-empty batches when a few molecules have hundreds of conformers (GEOM test molecules carry 50-500
+    references, utils/datasets.py:720-721), and a half-empty batch costs nearly a full one per denoising step.
+    Results are keyed by molecule index, so the order inside the batches does not matter; every batch keeps its
+    molecules in ascending index order."""
+    need = [int(m["atom_type"].shape[0]) * confs_of(m["num_refs"]) for m in mols]
+    order = sorted(range(len(mols)), key=lambda k: (-need[k], k))
+    bins, room = [], []
+    for k in order:
+        for b in range(len(bins)):
+            if need[k] <= room[b]:
+                bins[b].append(k)
+                room[b] -= need[k]
+                break
+        else:
+            bins.append([k])
+            room.append(max_atoms - need[k])
+    batches = [[mols[k] for k in sorted(b)] for b in bins]
+    batches.sort(key=lambda bm: bm[0].get("index", 0) if isinstance(bm[0], dict) else 0)
     return batches
 
 
@@ -191,10 +199,10 @@ def _done_indices(out_dir):
 
 
 def _batch_path(out_dir, bmols):
-    """Output file of one batch, named by what it holds (first / last molecule index of the batch), never by a
+    """Output file of one batch, named by what it holds (smallest / largest molecule index of the batch), never by a
     batch counter: a --resume run plans its batches over the molecules still missing, and a counter restarting at 0
     would overwrite files of the earlier run that hold other, finished molecules."""
-    base = os.path.join(out_dir, "samples_%05d_%05d" % (bmols[0]["index"], bmols[-1]["index"]))
+    base = os.path.join(out_dir, "samples_%05d_%05d" % (min(m["index"] for m in bmols), max(m["index"] for m in bmols)))
     path, k = base + ".npz", 0
     while os.path.exists(path):
         k += 1

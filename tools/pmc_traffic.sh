@@ -5,13 +5,13 @@ out=${1:-gpurun_out/pmc_traffic}
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-traj > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmctr/$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-traj --no-extra > /dev/null 2>&1
 done
 python3 - <<PY
 import csv, glob, collections
 res = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob("$GRAFT_REPO_ROOT/$out/%s/*/*counter_collection.csv" % c)[0]
+    f = glob.glob("/tmp/pmctr/%s/*/*counter_collection.csv" % c)[0]
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == c:
