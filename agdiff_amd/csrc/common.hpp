@@ -260,7 +260,7 @@ __device__ __forceinline__ void ag_dense_lds(const AgIn<MODE> (&x)[NX], f32x4 (&
 // ahead.  Halves the L2 traffic of a layer that does not fit in LDS next to the others.
 template <int MODE, bool FLIP, bool KOUTER, int KT, int OT, int X0, int O0, int PF, int NX, int NO>
 __device__ __forceinline__ void ag_dense_split(const AgIn<MODE> (&x)[NX], f32x4 (&o)[NO], const lds_u32x4* w0,
-                                               const void* wpk, int lane) {
+                                               const void* wpk, int lane, int lds_lane) {
   static_assert(X0 + KT <= NX && O0 + OT <= NO, "tile range");
   constexpr int S = OT * KT;
   constexpr int R = PF + 1;
@@ -273,7 +273,7 @@ __device__ __forceinline__ void ag_dense_split(const AgIn<MODE> (&x)[NX], f32x4 
     const int t = KOUTER ? s / OT : s % KT, ot = KOUTER ? s % OT : s / KT;
     if (s + PF < S) w1[(s + PF) % R] = wl[((s + PF) * 2) * 64];
     u32x4 w[2];
-    w[0] = w0[s * 64 + lane];
+    w[0] = w0[s * 64 + lds_lane];
     w[1] = w1[s % R];
     ag_block_mma<MODE, FLIP>(o[O0 + ot], x[X0 + t], w);
     __builtin_amdgcn_sched_barrier(0);

@@ -8,6 +8,15 @@
 
 namespace {
 
+// A per-lane LDS base pointer the compiler must keep in a register: ds_read takes a 16-bit immediate offset, so a weight
+// block more than 64 KiB above the wave's only address register costs one v_add_u32 per read (64 per tile in the fused
+// CFConv's second layer alone).  One opaque base per 64-KiB window of resident weights removes them.
+__device__ __forceinline__ const lds_u32x4* ag_lds_base(const lds_u32x4* p, int lane) {
+  const lds_u32x4* b = p + lane;
+  asm volatile("" : "+v"(b));
+  return b;
+}
+
 // ------------------------------------------------------------------------------ edge encoder
 struct EncArgs {
   const float* fe_w;
@@ -113,15 +122,15 @@ __global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_edge_encoder(EncAr
     }
     ag_cvt_tiles<MODE, 4, 0>(y, x);
     ag_init_vec<8>(y, a.t1 + (size_t)ty * 128, q);
-    ag_dense_lds<MODE, false, false, 4, 8, 0, 0>(x, y, lw1, lane);
+    ag_dense_lds<MODE, false, false, 4, 8, 0, 0>(x, y, ag_lds_base(lw1, lane), 0);
     AG_FOR_TILE(y, 8, ag_gelu(v));
     ag_cvt_tiles<MODE, 4, 0>(y, x);
     ag_init_vec<8>(y, a.t3 + (size_t)ty * 128, q);
-    ag_dense_lds<MODE, false, false, 4, 8, 0, 0>(x, y, lw23, lane);
+    ag_dense_lds<MODE, false, false, 4, 8, 0, 0>(x, y, ag_lds_base(lw23, lane), 0);
     AG_FOR_TILE(y, 8, ag_gelu(v));
     ag_cvt_tiles<MODE, 4, 0>(y, x);
     ag_init_vec<8>(y, a.b4, q);
-    ag_dense_split<MODE, false, false, 4, 8, 0, 0, 6>(x, y, lw4, a.w4_pk, lane);
+    ag_dense_split<MODE, false, false, 4, 8, 0, 0, 6>(x, y, ag_lds_base(lw4, lane), a.w4_pk, lane, 0);
     ag_emit_edge_attr<MODE>(y, ag_edge_out(a.pos_index, a.mir_index, e, valid), a.out_frag, a.out_rows, a.row_index,
                             a.pos_index != nullptr, tile, lane);
   }
@@ -221,7 +230,8 @@ struct ConvArgs {
   int64_t max_chunks;
   int32_t chunk_tiles;   // tiles per chunk (agdiff_conv_chunk_tiles)
   int32_t ablate;        // timing experiments only (AGDIFF_ABLATE env): bit0 skip layer 1, bit1 skip ssp,
-                         // bit2 skip layer 2, bit3 skip x gather, bit4 skip reduction
+                         // bit2 skip layer 2, bit3 skip x gather, bit4 skip reduction, bit6 skip the next tile's e_attr
+                         // loads, bit7 skip the first layer's LDS weight reads
 };
 
 #ifdef AG_CONV_STAMPS
@@ -352,7 +362,7 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, AG_CONV_WAVES / 4) k_cfcon
       f32x4 sr;                          // scale of the conv being processed, per edge slot
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        xoff[r] = (uint32_t)__shfl(my_src, 4 * q + r) * 192u + (uint32_t)col;
+        xoff[r] = ((uint32_t)__shfl(my_src, 4 * q + r) * 192u + (uint32_t)col) * 4u;     // byte offset into xs
         sr[r] = __shfl(s1, 4 * q + r);
       }
       // list boundaries of the targets present in this tile, one per lane (in_ptr[t0 + lane]); the
@@ -372,9 +382,11 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, AG_CONV_WAVES / 4) k_cfcon
       f32x4 xg;
       auto fetch_x = [&](int nt) {
         if (AG_ABL(8)) return;
-        const float* xb = a.xs + 16 * nt;
+        // base (SGPR pair) + 32-bit byte offset (VGPR) + immediate 64 nt: one instruction per gathered value, no address
+        // arithmetic in the channel-tile loop
+        const char* xb = reinterpret_cast<const char*>(a.xs);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) xg[r] = xb[xoff[r]];
+        for (int r = 0; r < 4; ++r) xg[r] = *reinterpret_cast<const float*>(xb + (size_t)xoff[r] + 64 * nt);
       };
       fetch_x(0);          // requested here, before the first layer: lands while its MFMAs run
       // the wave's next tile: edge attributes (HBM) + per-edge scalars.  Loads return in issue order (vmcnt), so every
@@ -384,8 +396,10 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, AG_CONV_WAVES / 4) k_cfcon
         int64_t nxt = tile + 1;
         if (tt + 1 >= a.chunk_tiles) nxt = (chunk + cstride) * a.chunk_tiles;
         if (nxt * AG_TW < E && nxt < a.max_chunks * a.chunk_tiles) {
+          if (!(AG_ABL(64))) {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) ag_load_attr(ea[t], a.e_attr, nxt, t, lane);
+            for (int t = 0; t < 4; ++t) ag_load_attr(ea[t], a.e_attr, nxt, t, lane);
+          }
           prefetch_meta(nxt, lane);
         }
       };
@@ -395,16 +409,25 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, AG_CONV_WAVES / 4) k_cfcon
         // t * 12 + ot), two output tiles (= one k-tile of the second layer) at a time, so that the softplus
         // and the operand split of one pair can issue between the MFMAs of the next.
         // weight blocks are read from LDS one step (two blocks) ahead of the MFMAs that use them
-        u32x4 wq[2][2][2];
+#ifndef AG_L1_LDS_AHEAD
+#define AG_L1_LDS_AHEAD 1       // steps (of two blocks) the LDS weight reads run ahead of their MFMAs
+#endif
+        constexpr int WA = AG_L1_LDS_AHEAD, WR = WA + 1;
+        u32x4 wq[WR][2][2];
+        const lds_u32x4* w1_lo = ag_lds_base(w1, lane);
+        const lds_u32x4* w1_hi = ag_lds_base(w1 + 32 * 128, lane);
         auto fetch_w = [&](u32x4 (&dst)[2][2], int step) {     // step = m * 4 + t
           const int m = step >> 2, t = step & 3;
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
-            dst[b][0] = w1[((t * AG_CONV_NCH + 2 * m + b) * 2) * 64 + lane];
-            dst[b][1] = w1[((t * AG_CONV_NCH + 2 * m + b) * 2 + 1) * 64 + lane];
+            const int bi = t * AG_CONV_NCH + 2 * m + b;        // blocks 0..31 from the first 64-KiB window, 32..47 from the second
+            const lds_u32x4* wb = (bi < 32) ? w1_lo + bi * 128 : w1_hi + (bi - 32) * 128;
+            dst[b][0] = wb[0];
+            dst[b][1] = wb[64];
           }
         };
-        fetch_w(wq[0], 0);
+#pragma unroll
+        for (int s0 = 0; s0 < WA; ++s0) fetch_w(wq[s0 % WR], s0);
         // Software pipeline, fenced per step: the six MFMAs of pair m's step t run beside a quarter of pair
         // m-1's softplus + operand split (two of its eight values per lane).
         f32x4 hp0 = {0.f, 0.f, 0.f, 0.f}, hp1 = {0.f, 0.f, 0.f, 0.f};
@@ -419,10 +442,10 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, AG_CONV_WAVES / 4) k_cfcon
           for (int t = 0; t < 4; ++t) {
             const int step = m * 4 + t;
             if (m < AG_CONV_NCH / 2) {
-              if (step + 1 < 4 * (AG_CONV_NCH / 2)) fetch_w(wq[(step + 1) & 1], step + 1);
+              if (step + WA < 4 * (AG_CONV_NCH / 2) && !(AG_ABL(128))) fetch_w(wq[(step + WA) % WR], step + WA);
               if (!(AG_ABL(1))) {
-                ag_block_mma<MODE, false>(h0, ea[t], wq[step & 1][0]);
-                ag_block_mma<MODE, false>(h1, ea[t], wq[step & 1][1]);
+                ag_block_mma<MODE, false>(h0, ea[t], wq[step % WR][0]);
+                ag_block_mma<MODE, false>(h1, ea[t], wq[step % WR][1]);
               }
             }
             if (m > 0) {
@@ -496,12 +519,13 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, AG_CONV_WAVES / 4) k_cfcon
       };
       AG_STAMP(c1); st[2] += c1 - c0; c0 = c1;       // bounds, masks
       // second-layer MFMAs of channel tile nt (flipped: rows = edges, lanes = channels), raw accumulators
+      const lds_u32x4* w2a_l = ag_lds_base(w2a, lane);
       auto dense2 = [&](int nt) -> f32x4 {
         f32x4 z[1] = {{0.f, 0.f, 0.f, 0.f}};
         if (nt == 7) fetch_g(0);
         if (!(AG_ABL(4))) {
           if (nt < 8) {
-            ag_dense_lds<MODE, true, false, 4, 1, 0, 0>(hidb, z, w2a + (nt * 4) * 128, lane);
+            ag_dense_lds<MODE, true, false, 4, 1, 0, 0>(hidb, z, w2a_l + (nt * 4) * 128, 0);
           } else {
             ag_block_mma<MODE, true>(z[0], hidb[4], g[0]);
             ag_block_mma<MODE, true>(z[0], hidb[5], g[1]);
@@ -667,11 +691,14 @@ __global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_pair_head(HeadArgs
         }
       };
       load_slice(sl[0], 0);
+      const lds_u32x4* lw1_lo = ag_lds_base(lw1, lane);
+      const lds_u32x4* lw1_hi = ag_lds_base(lw1 + 32 * 128, lane);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         if (k + 1 < 8) load_slice(sl[(k + 1) & 1], k + 1);
-        if (k & 1) ag_dense_lds<MODE, false, true, 1, 8, 1, 0>(sl, y1, lw1 + (k * 8) * 128, lane);
-        else ag_dense_lds<MODE, false, true, 1, 8, 0, 0>(sl, y1, lw1 + (k * 8) * 128, lane);
+        const lds_u32x4* wk = (k < 4) ? lw1_lo + (k * 8) * 128 : lw1_hi + ((k - 4) * 8) * 128;
+        if (k & 1) ag_dense_lds<MODE, false, true, 1, 8, 1, 0>(sl, y1, wk, 0);
+        else ag_dense_lds<MODE, false, true, 1, 8, 0, 0>(sl, y1, wk, 0);
       }
     }
     AG_FOR_TILE(y1, 8, ag_relu(v));
@@ -680,7 +707,7 @@ __global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_pair_head(HeadArgs
     {
       AgIn<MODE> y1b[4];
       ag_cvt_tiles<MODE, 4, 0>(y1, y1b);
-      ag_dense_lds<MODE, false, false, 4, 4, 0, 0>(y1b, y2, lw2, lane);
+      ag_dense_lds<MODE, false, false, 4, 4, 0, 0>(y1b, y2, ag_lds_base(lw2, lane), 0);
     }
     AG_FOR_TILE(y2, 4, ag_relu(v));
     const float o = ag_dot_vec<4>(y2, a.hp.w3, q) + a.hp.b3;
