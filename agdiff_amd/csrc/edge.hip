@@ -295,6 +295,8 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, AG_CONV_WAVES / 4) k_cfcon
   // edge attributes of the wave's NEXT tile are requested as soon as the current tile's first layer has consumed
   // its own (they land during the rest of the tile)
   AgIn<MODE> ea[4];
+  // first-layer bias of the next pair of output tiles (see the first-layer loop)
+  f32x4 nb0 = ag_ld4(a.cp.filt_b1 + 4 * (lane0 >> 4)), nb1 = ag_ld4(a.cp.filt_b1 + 16 + 4 * (lane0 >> 4));
   // ... and so are its per-edge scalars (source, the two conv scales) and its first / last target
   int pf_src = 0, pf_t0 = 0, pf_t1 = 0;
   float pf_s1 = 0.0f, pf_s2 = 0.0f;
@@ -379,16 +381,24 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, AG_CONV_WAVES / 4) k_cfcon
       // second filter layer per 16-channel tile, flipped (rows = edges, lanes = channels), then message and
       // destination-segmented reduction of that channel tile.  The x[src] rows of the next channel tile are
       // fetched before the current tile's reduction.
-      f32x4 xg;
+      // x[src] rows (and the second-layer bias) of channel tile nt are requested AG_X_AHEAD channel tiles before their
+      // use through a small register ring: one channel tile (12 MFMAs) does not cover an L2 round trip under load
+#ifndef AG_X_AHEAD
+#define AG_X_AHEAD 2
+#endif
+      constexpr int XA = AG_X_AHEAD, XR = XA + 1;
+      f32x4 xring[XR];
+      float bring[XR];
       auto fetch_x = [&](int nt) {
         if (AG_ABL(8)) return;
-        // base (SGPR pair) + 32-bit byte offset (VGPR) + immediate 64 nt: one instruction per gathered value, no address
-        // arithmetic in the channel-tile loop
+        // base (SGPR pair) + 32-bit byte offset (VGPR) + immediate 64 nt: one instruction per gathered value
         const char* xb = reinterpret_cast<const char*>(a.xs);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) xg[r] = *reinterpret_cast<const float*>(xb + (size_t)xoff[r] + 64 * nt);
+        for (int r = 0; r < 4; ++r) xring[nt % XR][r] = *reinterpret_cast<const float*>(xb + (size_t)xoff[r] + 64 * nt);
+        bring[nt % XR] = a.cp.filt_b2[16 * nt + col];
       };
-      fetch_x(0);          // requested here, before the first layer: lands while its MFMAs run
+#pragma unroll
+      for (int nt = 0; nt < XA; ++nt) fetch_x(nt);      // requested here, before the first layer: land while its MFMAs run
       // the wave's next tile: edge attributes (HBM) + per-edge scalars.  Loads return in issue order (vmcnt), so every
       // x gather issued after this request waits for it too.  Issuing it later (inside the channel-tile loop, at tile 3 /
       // 6 / 9) was measured: 0.64 / 0.49 / 0.49 ms per launch against 0.476 here.
@@ -435,8 +445,14 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, AG_CONV_WAVES / 4) k_cfcon
         for (int m = 0; m <= AG_CONV_NCH / 2; ++m) {
           f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = {0.f, 0.f, 0.f, 0.f};
           if (m < AG_CONV_NCH / 2) {
-            h0 = ag_ld4(a.cp.filt_b1 + 32 * m + 4 * q);
-            h1 = ag_ld4(a.cp.filt_b1 + 32 * m + 16 + 4 * q);
+            // The accumulators start from the bias, which the first MFMA of the pair needs at once: it is requested a
+            // whole pair ahead (nb0 / nb1; the last pair requests pair 0's for the wave's next tile).  Loaded where it is
+            // used, every pair began with an exposed L2 round trip -- six per tile.
+            h0 = nb0;
+            h1 = nb1;
+            const int mn = (m + 1) % (AG_CONV_NCH / 2);
+            nb0 = ag_ld4(a.cp.filt_b1 + 32 * mn + 4 * q);
+            nb1 = ag_ld4(a.cp.filt_b1 + 32 * mn + 16 + 4 * q);
           }
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
@@ -520,12 +536,31 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, AG_CONV_WAVES / 4) k_cfcon
       AG_STAMP(c1); st[2] += c1 - c0; c0 = c1;       // bounds, masks
       // second-layer MFMAs of channel tile nt (flipped: rows = edges, lanes = channels), raw accumulators
       const lds_u32x4* w2a_l = ag_lds_base(w2a, lane);
+      // conv1's 32 second-layer blocks are read from LDS AG_L2_LDS_AHEAD blocks ahead of their MFMAs through a small
+      // register ring (left to the compiler, every block's two reads were issued and waited for on the spot: 32
+      // exposed LDS round trips per tile)
+#ifndef AG_L2_LDS_AHEAD
+#define AG_L2_LDS_AHEAD 1
+#endif
+      constexpr int LA = AG_L2_LDS_AHEAD, LR = LA + 1;
+      u32x4 w2q[LR][2];
+      auto fetch_w2 = [&](int b) {             // b = nt * 4 + k
+        w2q[b % LR][0] = w2a_l[(b * 2) * 64];
+        w2q[b % LR][1] = w2a_l[(b * 2 + 1) * 64];
+      };
+#pragma unroll
+      for (int b = 0; b < LA; ++b) fetch_w2(b);
       auto dense2 = [&](int nt) -> f32x4 {
         f32x4 z[1] = {{0.f, 0.f, 0.f, 0.f}};
         if (nt == 7) fetch_g(0);
         if (!(AG_ABL(4))) {
           if (nt < 8) {
-            ag_dense_lds<MODE, true, false, 4, 1, 0, 0>(hidb, z, w2a_l + (nt * 4) * 128, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int b = nt * 4 + k;
+              if (b + LA < 32) fetch_w2(b + LA);
+              ag_block_mma<MODE, true>(z[0], hidb[k], w2q[b % LR]);
+            }
           } else {
             ag_block_mma<MODE, true>(z[0], hidb[4], g[0]);
             ag_block_mma<MODE, true>(z[0], hidb[5], g[1]);
@@ -542,9 +577,9 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, AG_CONV_WAVES / 4) k_cfcon
 #pragma unroll
           for (int r = 0; r < 4; ++r) sr[r] = __shfl(s2, 4 * q + r);
         }
-        bb = a.cp.filt_b2[16 * nt + col];
-        m = with_scale ? sr * xg : xg;
-        if (nt + 1 < AG_CONV_NCH) fetch_x(nt + 1);
+        bb = bring[nt % XR];
+        m = with_scale ? sr * xring[nt % XR] : xring[nt % XR];
+        if (nt + XA < AG_CONV_NCH) fetch_x(nt + XA);
       };
       // software pipeline, fenced per channel tile: the MFMAs of tile nt beside message + reduction of tile nt-1.
       // TWO = the tile holds two targets; with one, the second masked sum, its quarter sums and the store are
