@@ -76,6 +76,7 @@ __global__ void __launch_bounds__(64 * AG_PAIR_WAVES, 2) k_cfconv_pairs_fused(Pa
   if (it_begin >= it_end) return;
 
   AgIn<MODE> ea[4];
+  f32x4 nb0 = ag_ld4(a.cp.filt_b1 + 128 + 4 * (lane0 >> 4)), nb1 = ag_ld4(a.cp.filt_b1 + 128 + 16 + 4 * (lane0 >> 4));
   int pf_src = 0, pf_dst = 0, pf_slot = -1, pf_t0 = 0, pf_t1 = 0;
   float pf_s1 = 0.0f, pf_s2 = 0.0f;
   auto prefetch = [&](int64_t tl, int ln) {
@@ -134,6 +135,12 @@ __global__ void __launch_bounds__(64 * AG_PAIR_WAVES, 2) k_cfconv_pairs_fused(Pa
         }
       };
       fetch_x(8);
+      const lds_u32x4* w1_lo = w1 + lane;
+      asm volatile("" : "+v"(w1_lo));
+      const lds_u32x4* w1_hi = w1 + 32 * 128 + lane;
+      asm volatile("" : "+v"(w1_hi));
+      const lds_u32x4* w2a_l = w2a + lane;
+      asm volatile("" : "+v"(w2a_l));
       f32x4 m0 = {0.f, 0.f, 0.f, 0.f}, m1 = {0.f, 0.f, 0.f, 0.f};
       bool masks_ready = false;
 
@@ -153,8 +160,10 @@ __global__ void __launch_bounds__(64 * AG_PAIR_WAVES, 2) k_cfconv_pairs_fused(Pa
             const int m = step >> 2, t = step & 3;
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-              dst[b][0] = w1[((t * 12 + OT0 + 2 * m + b) * 2) * 64 + lane];
-              dst[b][1] = w1[((t * 12 + OT0 + 2 * m + b) * 2 + 1) * 64 + lane];
+              const int bi = t * 12 + OT0 + 2 * m + b;
+              const lds_u32x4* wb = (bi < 32) ? w1_lo + bi * 128 : w1_hi + (bi - 32) * 128;
+              dst[b][0] = wb[0];
+              dst[b][1] = wb[64];
             }
           };
           fetch_w(wq[0], 0);
@@ -163,8 +172,15 @@ __global__ void __launch_bounds__(64 * AG_PAIR_WAVES, 2) k_cfconv_pairs_fused(Pa
           for (int m = 0; m <= NM; ++m) {
             f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = {0.f, 0.f, 0.f, 0.f};
             if (m < NM) {
-              h0 = ag_ld4(a.cp.filt_b1 + 16 * OT0 + 32 * m + 4 * q);
-              h1 = ag_ld4(a.cp.filt_b1 + 16 * OT0 + 32 * m + 16 + 4 * q);
+              // bias requested a pair ahead (nb0 / nb1 persist across phases and tiles; order of pairs per tile:
+              // conv2's two, then conv1's four, then the next tile's first)
+              h0 = nb0;
+              h1 = nb1;
+              const int gm = (CONV == 2 ? m : 2 + m) + 1;              // global pair counter of the next pair (0..5)
+              const int nm = gm % 6;                                    // 0,1: conv2 pairs (tiles 8..11); 2..5: conv1 pairs
+              const int off = (nm < 2) ? 128 + 32 * nm : 32 * (nm - 2);
+              nb0 = ag_ld4(a.cp.filt_b1 + off + 4 * q);
+              nb1 = ag_ld4(a.cp.filt_b1 + off + 16 + 4 * q);
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -216,7 +232,7 @@ __global__ void __launch_bounds__(64 * AG_PAIR_WAVES, 2) k_cfconv_pairs_fused(Pa
         auto dense2 = [&](int nt) -> f32x4 {
           f32x4 z[1] = {{0.f, 0.f, 0.f, 0.f}};
           if constexpr (CONV == 1) {
-            ag_dense_lds<MODE, true, false, 4, 1, 0, 0>(hidb, z, w2a + (nt * 4) * 128, lane);
+            ag_dense_lds<MODE, true, false, 4, 1, 0, 0>(hidb, z, w2a_l + (nt * 4) * 128, 0);
           } else {
             ag_block_mma<MODE, true>(z[0], hidb[0], g[0]);
             ag_block_mma<MODE, true>(z[0], hidb[1], g[1]);
