@@ -21,4 +21,4 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kstats_refresh -- p
 cp /tmp/kstats_refresh/*/*kernel_stats.csv $out/${R}_bf16x3_bench_kernel_stats.csv
 cd $GRAFT_REPO_ROOT && bash tools/pmc_traffic.sh > $out/${R}_pmc_traffic.txt 2>&1
 bash tools/pmc_sq.sh > $out/${R}_bf16x3_pmc_sq.txt 2>&1
-tail -30 $out/${R}_pmc_traffic.txt $out/${R}_bf16x3_pmc_sq.txt
+tail -n 12 $out/${R}_pmc_traffic.txt; tail -n 30 $out/${R}_bf16x3_pmc_sq.txt
