@@ -301,7 +301,9 @@ class DualEncoderEpsNetwork(nn.Module):
 
     def _forward_given_graph(self, lib, atom_type, pos, batch, edge_index, edge_type, edge_length, return_edges):
         """forward(..., edge_index, edge_type, edge_length) (dualenc.py:165 skips the graph construction): the
-        caller's edges, in the caller's order.  The host sorts them by destination once and uploads them."""
+        caller's edges, in the caller's order.  The host sorts them by destination once and uploads them -- one
+        device-to-host copy and a numpy sort per call (a host synchronisation): this variant is for callers that hold
+        an edge list already, not for inner loops; the sampler never takes it."""
         import numpy as np
         dev = self._device()
         ei = edge_index.detach().cpu().numpy().astype(np.int64).reshape(2, -1)
