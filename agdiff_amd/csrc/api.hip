@@ -71,17 +71,28 @@ ForkJoin& fork_join_for_current_device() {
 int local_branch(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, int flags,
                  bool rows_from_global, hipEvent_t rows_ready, void* stream) {
   const int64_t ltiles = (topo->num_local + AG_TW - 1) / AG_TW;
+  const int64_t ctiles = (topo->num_local_canon + AG_TW - 1) / AG_TW;
+  // caller-supplied lengths (forward(edge_length=...)) need not be symmetric: then every local edge is evaluated
+  const bool canon = !(flags & AGDIFF_FWD_GRAPH_GIVEN) && topo->num_local_canon > 0;
   if (!(flags & AGDIFF_FWD_GRAPH_GIVEN)) AG_TRY(agdiff_local_lengths(topo, ws, pos, stream));
   if (rows_from_global) {
     if (hipStreamWaitEvent((hipStream_t)stream, rows_ready, 0) != hipSuccess) return AGDIFF_ERR_LAUNCH;
   } else if (topo->num_local > 0) {
-    AG_TRY(agdiff_edge_encoder(p, ws->num_local, ltiles, ws->l_len, topo->loc_type, nullptr, ws->l_attr_rows, nullptr,
-                               nullptr, nullptr, stream));
+    if (canon)        // one evaluation per mirror pair of local edges, written to both rows
+      AG_TRY(agdiff_edge_encoder(p, ws->num_local_canon, ctiles, ws->lc_len, topo->lc_type, nullptr, ws->l_attr_rows, nullptr,
+                                 topo->lc_pos, topo->lc_mir, stream));
+    else
+      AG_TRY(agdiff_edge_encoder(p, ws->num_local, ltiles, ws->l_len, topo->loc_type, nullptr, ws->l_attr_rows, nullptr,
+                                 nullptr, nullptr, stream));
   }
   AG_TRY(agdiff_gin_encoder(p, topo, ws, stream));
   if (topo->num_local > 0) {
-    AG_TRY(agdiff_pair_head(&p->head_local, ws->num_local, ltiles, topo->loc_src, topo->loc_dst, ws->hl, nullptr,
-                            ws->l_attr_rows, nullptr, nullptr, ws->l_inv, stream));
+    if (canon)
+      AG_TRY(agdiff_pair_head(&p->head_local, ws->num_local_canon, ctiles, topo->lc_src, topo->lc_dst, ws->hl, nullptr,
+                              ws->l_attr_rows, topo->lc_pos, topo->lc_mir, ws->l_inv, stream));
+    else
+      AG_TRY(agdiff_pair_head(&p->head_local, ws->num_local, ltiles, topo->loc_src, topo->loc_dst, ws->hl, nullptr,
+                              ws->l_attr_rows, nullptr, nullptr, ws->l_inv, stream));
   }
   return AGDIFF_OK;
 }

@@ -721,7 +721,7 @@ __global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_pair_head(HeadArgs
         } else if (a.attr_frag) {
           ag_load_attr(dst, a.attr_frag, tile, k - 4, lane);
         } else {
-          const float* ar = a.attr_rows + (size_t)(valid ? e : 0) * 128 + 32 * (k - 4) + 4 * q;
+          const float* ar = a.attr_rows + (size_t)(valid ? pe : 0) * 128 + 32 * (k - 4) + 4 * q;
           ag_cvt(ag_ld4(ar), ag_ld4(ar + 16), dst);
         }
       };
@@ -906,7 +906,7 @@ extern "C" int agdiff_pair_head(const agdiff_head_params_t* hp, const int32_t* n
                                 const float* attr_rows, const int32_t* pos_index, const int32_t* mir_index, float* out,
                                 void* stream) {
   if (!hp || !n_edges_dev || !src || !dst || !node_h || (!attr_frag == !attr_rows) || !out || max_tiles < 0 ||
-      (!pos_index != !mir_index) || (pos_index && !attr_frag))
+      (!pos_index != !mir_index))
     return AGDIFF_ERR_ARG;
   if (max_tiles == 0) return AGDIFF_OK;
   HeadArgs a;

@@ -294,12 +294,18 @@ __global__ void __launch_bounds__(1024) k_scan_graphs(const int32_t* __restrict_
   }
 }
 
+// one evaluation per canonical local edge (|p_i - p_j| is the same number for j -> i and i -> j: the differences only
+// change sign before they are squared)
 __global__ void k_local_lengths(const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
-                                const float* __restrict__ pos, float* __restrict__ len, int L) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= L) return;
-  int s = src[e], d = dst[e];
-  len[e] = ag_sqrt_rn(dist2_nofma(pos[3 * s], pos[3 * s + 1], pos[3 * s + 2], pos[3 * d], pos[3 * d + 1], pos[3 * d + 2]));
+                                const int32_t* __restrict__ cpos, const int32_t* __restrict__ cmir,
+                                const float* __restrict__ pos, float* __restrict__ len, float* __restrict__ clen, int Lc) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Lc) return;
+  int s = src[c], d = dst[c];
+  const float v = ag_sqrt_rn(dist2_nofma(pos[3 * s], pos[3 * s + 1], pos[3 * s + 2], pos[3 * d], pos[3 * d + 1], pos[3 * d + 2]));
+  clen[c] = v;
+  len[cpos[c]] = v;
+  if (cmir[c] >= 0) len[cmir[c]] = v;
 }
 
 }  // namespace
@@ -364,10 +370,12 @@ extern "C" int agdiff_graph_build(const agdiff_topo_t* topo, const agdiff_ws_t* 
 }
 
 extern "C" int agdiff_local_lengths(const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, void* stream) {
-  if (!topo || !ws || !pos || !ws->l_len) return AGDIFF_ERR_ARG;
+  if (!topo || !ws || !pos || !ws->l_len || !ws->lc_len) return AGDIFF_ERR_ARG;
   if (topo->num_local == 0) return AGDIFF_OK;
-  const int L = (int)topo->num_local;
-  k_local_lengths<<<(L + 255) / 256, 256, 0, (hipStream_t)stream>>>(topo->loc_src, topo->loc_dst, pos, ws->l_len, L);
+  if (!topo->lc_src || !topo->lc_dst || !topo->lc_pos || !topo->lc_mir || topo->num_local_canon <= 0) return AGDIFF_ERR_ARG;
+  const int Lc = (int)topo->num_local_canon;
+  k_local_lengths<<<(Lc + 255) / 256, 256, 0, (hipStream_t)stream>>>(topo->lc_src, topo->lc_dst, topo->lc_pos, topo->lc_mir,
+                                                                     pos, ws->l_len, ws->lc_len, Lc);
   AG_CHECK_LAUNCH();
   return AGDIFF_OK;
 }

@@ -75,6 +75,15 @@ class BatchTopology:
         in_order = np.argsort(dst, kind="stable")               # grouped by dst, src ascending
         in_ptr = np.concatenate([[0], np.cumsum(np.bincount(dst, minlength=N))])
         locdeg = np.diff(in_ptr)
+        # canonical local edges (agdiff_topo_t.lc_*): one of j -> i / i -> j when both exist with the same type
+        # (uniq is sorted, so the mirror of an edge is found by binary search on its swapped key)
+        mkey = dst * N + src
+        mpos = np.searchsorted(uniq, mkey)
+        mpos_c = np.minimum(mpos, max(L - 1, 0))
+        has_m = (mpos < L) & (uniq[mpos_c] == mkey) & (typ[mpos_c] == typ) if L else np.zeros(0, dtype=bool)
+        canon = ~has_m | (src < dst)
+        lc_pos = np.nonzero(canon)[0]
+        lc_mir = np.where(has_m[lc_pos], mpos_c[lc_pos], -1)
 
         n_of_node = counts[ba]
         cap = np.minimum(n_of_node - 1, np.minimum(_lib.RADIUS_CAP, n_of_node - 1) + locdeg)
@@ -94,6 +103,9 @@ class BatchTopology:
         self.atom_type = i32(at)
         self.loc_src, self.loc_dst, self.loc_type = i32(src), i32(dst), i32(typ)
         self.loc_out_ptr, self.loc_in_ptr, self.loc_in_eid = i32(out_ptr), i32(in_ptr), i32(in_order)
+        self.Lc = int(lc_pos.shape[0])
+        self.lc_src, self.lc_dst, self.lc_type = i32(src[lc_pos]), i32(dst[lc_pos]), i32(typ[lc_pos])
+        self.lc_pos, self.lc_mir = i32(lc_pos), i32(lc_mir)
         # int64 copies of the local edges for the API results (forward() returns int64 indices)
         self.loc_index64 = torch.from_numpy(np.stack([src, dst])).to(device)
         self.loc_type64 = torch.from_numpy(typ).to(device)
@@ -103,7 +115,9 @@ class BatchTopology:
         t = _lib.Topo()
         t.num_nodes, t.num_graphs, t.num_local = N, G, L
         t.max_edges, t.max_atoms_per_graph, t.max_in_degree = self.max_edges, self.max_atoms, self.max_in_degree
-        for f in ("graph_ptr", "atom_type", "loc_src", "loc_dst", "loc_type", "loc_out_ptr", "loc_in_ptr", "loc_in_eid"):
+        t.num_local_canon = self.Lc
+        for f in ("graph_ptr", "atom_type", "loc_src", "loc_dst", "loc_type", "loc_out_ptr", "loc_in_ptr", "loc_in_eid",
+                  "lc_src", "lc_dst", "lc_type", "lc_pos", "lc_mir"):
             setattr(t, f, _lib.ptr(getattr(self, f)))
         self.struct = t
 
@@ -141,6 +155,8 @@ class Workspace:
         self.e_inv_global = f32(etiles * TW)
         self.e_scale = f32(2 * _lib.DEFINES["AGDIFF_MAX_CONVS"] * etiles * TW)
         self.l_len, self.l_inv = f32(ltiles * TW), f32(ltiles * TW)
+        self.lc_len = f32(ltiles * TW)
+        self.num_local_canon = torch.tensor([topo.Lc], dtype=torch.int32, device=dev)
         self.l_attr_rows = f32(ltiles * TW * 128)
         self.h, self.xs, self.agg = f32(N * 128), f32(N * 192), f32(N * 192)
         self.agg_first = f32(chunks * 192)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 17
+#define AGDIFF_ABI_VERSION 18
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -149,6 +149,15 @@ typedef struct agdiff_topo {
   const int32_t* loc_out_ptr;/* [N+1]: local edges with src == i are [loc_out_ptr[i], loc_out_ptr[i+1]) */
   const int32_t* loc_in_ptr; /* [N+1] */
   const int32_t* loc_in_eid; /* [L]: local edge ids grouped by dst (src ascending) */
+  /* canonical local edges: the local edges j -> i and i -> j carry the same type and length, hence the same edge_attr and
+   * the same local-head output (h_i * h_j is symmetric); one of the two (src < dst) is canonical, as is every local edge
+   * without such a mirror.  Static like the local list itself. */
+  int64_t num_local_canon;   /* Lc */
+  const int32_t* lc_src;     /* [Lc] */
+  const int32_t* lc_dst;     /* [Lc] */
+  const int32_t* lc_type;    /* [Lc] */
+  const int32_t* lc_pos;     /* [Lc]: the canonical edge's own id in the local list */
+  const int32_t* lc_mir;     /* [Lc]: its mirror's id there, or -1 */
 } agdiff_topo_t;
 
 /* ---- workspace (device buffers the host allocates once per batch) ------------------------- */
@@ -183,9 +192,11 @@ typedef struct agdiff_ws {
   float*   e_scale;          /* [2*num_convs][ceil(max_edges/16)*16]: lw(d)*C(d) of conv1 / conv2 of every block (schnet.py:138-149) */
   /* local edges (reference order) */
   float*   l_len;            /* [L] */
+  float*   lc_len;           /* [Lc] lengths of the canonical local edges (same values as l_len[lc_pos]) */
+  int32_t* num_local_canon;  /* [1]  Lc as a device scalar (written once by the host) */
   float*   l_attr_rows;      /* [L][128] fp32 row-major edge_attr of the local edges (GIN message gather, local head);
                                 written by the global encoder pass through e_loc when that pass runs, else by a
-                                pass over the local list */
+                                pass over the canonical local list (each result to the edge's and its mirror's row) */
   float*   l_inv;            /* [L] grad_local_dist_mlp output */
   /* nodes */
   float*   h;                /* [N][128] SchNet node state */
@@ -230,7 +241,8 @@ int agdiff_struct_sizes(int64_t* out /* [host] */);
  * edge types and lengths from `pos`. */
 int agdiff_graph_build(const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, float cutoff, void* stream);
 
-/* get_distance on the static local edges (geometry.py:5-6 applied to edge_index[:, local_edge_mask]). */
+/* get_distance on the static local edges (geometry.py:5-6 applied to edge_index[:, local_edge_mask]): one evaluation per
+ * canonical local edge, written to l_len of the edge and of its mirror and to lc_len. */
 int agdiff_local_lengths(const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, void* stream);
 
 /* DistanceWeightingNetwork x cutoff envelope of all 2*num_convs CFConvs (encoder/schnet.py:83-100, 138-149):
@@ -262,7 +274,8 @@ int agdiff_cfconv_fused(const agdiff_params_t* p, const agdiff_topo_t* topo, con
  * 226-239) over n edges given by (src, dst); edge_attr either as operand-form tiles (attr_frag) or as fp32
  * rows [n][128] (attr_rows) -- exactly one of the two.  pos_index / mir_index (both or neither, with attr_frag):
  * the n edges are a canonical list; edge e reads its attrs at position pos_index[e] and writes its result to
- * out[pos_index[e]] and, when >= 0, out[mir_index[e]] (h_i * h_j is symmetric, so the mirror's value is the same). */
+ * out[pos_index[e]] and, when >= 0, out[mir_index[e]] (h_i * h_j is symmetric, so the mirror's value is the same).
+ * With attr_rows and pos_index the edge's attributes are row pos_index[e] (the local head over the canonical local list). */
 int agdiff_pair_head(const agdiff_head_params_t* hp, const int32_t* n_edges_dev, int64_t max_tiles,
                      const int32_t* src, const int32_t* dst, const float* node_h, const float* attr_frag,
                      const float* attr_rows, const int32_t* pos_index, const int32_t* mir_index, float* out,

@@ -175,3 +175,34 @@ def test_topology_extend_order_and_errors():
                       np.array([0, 1, 0, 1]), device="cpu")
     with pytest.raises(ValueError):
         BatchTopology(np.ones(4, dtype=np.int64), np.array([[0], [3]]), np.array([1]), np.array([0, 0, 1, 1]), device="cpu")
+
+
+def test_canonical_local_edge_list():
+    """agdiff_topo_t.lc_*: every local edge is canonical or the mirror of exactly one canonical edge; a mirror has the
+    swapped end points and the same type; an edge whose reverse is missing or carries another type stays canonical."""
+    b = synth.make_packed_batch("drugs", 3, 2, seed=12)
+    bi, bt = b["bond_index"].copy(), b["bond_type"].copy()
+    # make the list asymmetric in two places: drop one direction of an edge, change the type of another's reverse
+    drop = 5
+    r0, c0 = bi[0][drop], bi[1][drop]
+    keep = np.ones(bt.shape[0], dtype=bool)
+    keep[drop] = False
+    other = np.nonzero((bi[0] == bi[1][40]) & (bi[1] == bi[0][40]))[0][0]
+    bt[other] = 7 if bt[other] != 7 else 8
+    topo = BatchTopology(b["atom_type"], bi[:, keep], bt[keep], b["batch"], device="cpu")
+    src, dst, typ = topo.loc_src.numpy(), topo.loc_dst.numpy(), topo.loc_type.numpy()
+    cp, cm = topo.lc_pos.numpy(), topo.lc_mir.numpy()
+    assert topo.Lc == cp.shape[0] and np.array_equal(topo.lc_src.numpy(), src[cp]) and np.array_equal(topo.lc_type.numpy(), typ[cp])
+    has = cm >= 0
+    assert np.array_equal(src[cm[has]], dst[cp[has]]) and np.array_equal(dst[cm[has]], src[cp[has]])
+    assert np.array_equal(typ[cm[has]], typ[cp[has]]) and np.all(src[cp[has]] < dst[cp[has]])
+    cover = np.zeros(topo.L, dtype=np.int64)
+    np.add.at(cover, cp, 1)
+    np.add.at(cover, cm[has], 1)
+    assert np.all(cover == 1)
+    key = {(int(a), int(c)): int(t_) for a, c, t_ in zip(src, dst, typ)}
+    unpaired = cp[~has]
+    assert len(unpaired) >= 3                       # the dropped edge's reverse and both directions of the retyped pair
+    for e in unpaired:
+        assert key.get((int(dst[e]), int(src[e])), -1) != int(typ[e])
+    assert (int(c0), int(r0)) in {(int(src[e]), int(dst[e])) for e in unpaired}
