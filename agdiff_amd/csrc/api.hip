@@ -78,14 +78,14 @@ int local_branch(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdi
   if (rows_from_global) {
     if (hipStreamWaitEvent((hipStream_t)stream, rows_ready, 0) != hipSuccess) return AGDIFF_ERR_LAUNCH;
   } else if (topo->num_local > 0) {
-    if (canon)        // one evaluation per mirror pair of local edges, written to both rows
+    if (canon)        // one evaluation and one row per mirror pair of local edges
       AG_TRY(agdiff_edge_encoder(p, ws->num_local_canon, ctiles, ws->lc_len, topo->lc_type, nullptr, ws->l_attr_rows, nullptr,
-                                 topo->lc_pos, topo->lc_mir, stream));
+                                 nullptr, nullptr, stream));
     else
       AG_TRY(agdiff_edge_encoder(p, ws->num_local, ltiles, ws->l_len, topo->loc_type, nullptr, ws->l_attr_rows, nullptr,
                                  nullptr, nullptr, stream));
   }
-  AG_TRY(agdiff_gin_encoder(p, topo, ws, stream));
+  AG_TRY(agdiff_gin_encoder(p, topo, ws, canon ? 1 : 0, stream));
   if (topo->num_local > 0) {
     if (canon)
       AG_TRY(agdiff_pair_head(&p->head_local, ws->num_local_canon, ctiles, topo->lc_src, topo->lc_dst, ws->hl, nullptr,

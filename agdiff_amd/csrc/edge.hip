@@ -55,9 +55,10 @@ __device__ __forceinline__ void ag_emit_edge_attr(const f32x4 (&y)[8], const AgE
       const int64_t row = row_index ? (int64_t)row_index[o.p] : o.p;
       if (row >= 0) ag_store_row<8, 0>(y, out_rows + (size_t)row * 128, q);
     }
-    if (o.pm >= 0) {
+    if (o.pm >= 0) {       // (through row_index a mirror pair may share one row: written once)
       const int64_t row = row_index ? (int64_t)row_index[o.pm] : o.pm;
-      if (row >= 0) ag_store_row<8, 0>(y, out_rows + (size_t)row * 128, q);
+      const int64_t rowp = (row_index && o.p >= 0) ? (int64_t)row_index[o.p] : -1;
+      if (row >= 0 && row != rowp) ag_store_row<8, 0>(y, out_rows + (size_t)row * 128, q);
     }
   }
   if (out_frag) {
@@ -721,7 +722,7 @@ __global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_pair_head(HeadArgs
         } else if (a.attr_frag) {
           ag_load_attr(dst, a.attr_frag, tile, k - 4, lane);
         } else {
-          const float* ar = a.attr_rows + (size_t)(valid ? pe : 0) * 128 + 32 * (k - 4) + 4 * q;
+          const float* ar = a.attr_rows + (size_t)(valid ? e : 0) * 128 + 32 * (k - 4) + 4 * q;
           ag_cvt(ag_ld4(ar), ag_ld4(ar + 16), dst);
         }
       };

@@ -15,6 +15,7 @@ struct GraphArgs {
   const int32_t* loc_in_eid;
   const int32_t* loc_src;
   const int32_t* loc_type;
+  const int32_t* loc_row;
   const float* pos;
   float r2;
   int32_t words;  // ceil(max_atoms_per_graph / 32)
@@ -221,7 +222,7 @@ __global__ void __launch_bounds__(256) k_graph(GraphArgs a) {
           ty = a.loc_type[eid];
         }
         const float len = ag_sqrt_rn(dist2_nofma(xi, yi, zi, spos[3 * jj], spos[3 * jj + 1], spos[3 * jj + 2]));
-        a.e_loc[p] = eid;
+        a.e_loc[p] = eid >= 0 ? a.loc_row[eid] : -1;
         a.e_src[p] = g0 + j;
         a.e_dst[p] = g0 + i;
         a.e_type[p] = ty;
@@ -312,7 +313,8 @@ __global__ void k_local_lengths(const int32_t* __restrict__ src, const int32_t* 
 
 extern "C" int agdiff_graph_build(const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, float cutoff,
                                   void* stream) {
-  if (!topo || !ws || !pos || topo->num_graphs <= 0 || topo->num_nodes <= 0) return AGDIFF_ERR_ARG;
+  if (!topo || !ws || !pos || topo->num_graphs <= 0 || topo->num_nodes <= 0 || (topo->num_local > 0 && !topo->loc_row))
+    return AGDIFF_ERR_ARG;
   if (!ws->graph_edge_cnt || !ws->graph_edge_ptr || !ws->in_ptr || !ws->out_ptr || !ws->e_src || !ws->e_dst ||
       !ws->e_type || !ws->e_len || !ws->ref2dst || !ws->e_loc || !ws->num_edges || !ws->num_canon ||
       !ws->graph_canon_cnt || !ws->graph_canon_ptr || !ws->c_len || !ws->c_type || !ws->c_src || !ws->c_dst ||
@@ -328,6 +330,7 @@ extern "C" int agdiff_graph_build(const agdiff_topo_t* topo, const agdiff_ws_t* 
   a.loc_in_eid = topo->loc_in_eid;
   a.loc_src = topo->loc_src;
   a.loc_type = topo->loc_type;
+  a.loc_row = topo->loc_row;
   a.pos = pos;
   a.r2 = cutoff * cutoff;
   a.graph_edge_cnt = ws->graph_edge_cnt;

@@ -397,9 +397,9 @@ struct GinArgs {
   const float* emb;            // non-null on layer 0: input = node_emb[z]
   const int32_t* atom_type;
   const int32_t* loc_in_ptr;
-  const int32_t* loc_in_eid;
-  const int32_t* loc_src;
-  const float* l_attr_rows;    // [L][128] fp32 local edge attrs, row-major
+  const int32_t* in_src;       // [L] by in-slot: source node
+  const int32_t* in_row;       // [L] by in-slot: row of l_attr_rows
+  const float* l_attr_rows;    // fp32 local edge attrs, row-major
   const float* h_in;
   float* h_out;
   int64_t n;
@@ -437,16 +437,22 @@ __global__ void __launch_bounds__(LDSW ? 1024 : 256, LDSW ? 1 : 2) k_gin_layer(G
     int maxdeg = hi - lo;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, o));
+    // the next message's indices are requested before this one's rows, so a message costs one memory round trip
+    int src_n = lo < hi ? a.in_src[lo] : 0, row_n = lo < hi ? a.in_row[lo] : 0;
     for (int k = 0; k < maxdeg; ++k) {
       const bool on = lo + k < hi;
-      const int eid = on ? a.loc_in_eid[lo + k] : 0;
-      const int src = on ? a.loc_src[eid] : 0;
+      const int src = src_n, row = row_n;
+      {
+        const bool on_n = lo + k + 1 < hi;
+        src_n = on_n ? a.in_src[lo + k + 1] : 0;
+        row_n = on_n ? a.in_row[lo + k + 1] : 0;
+      }
       const float* hsrc = a.emb ? a.emb + (size_t)a.atom_type[src] * 128 : a.h_in + (size_t)src * 128;
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         const int f = 16 * t + 4 * q;
         const f32x4 hvv = ag_ld4(hsrc + f);
-        const f32x4 ev = ag_ld4(a.l_attr_rows + (size_t)eid * 128 + f);
+        const f32x4 ev = ag_ld4(a.l_attr_rows + (size_t)row * 128 + f);
 #pragma unroll
         for (int r = 0; r < 4; ++r) m[t][r] += on ? ag_relu(hvv[r] + ev[r]) : 0.0f;
       }
@@ -819,8 +825,11 @@ extern "C" int agdiff_schnet_node_stage(const agdiff_params_t* p, const agdiff_t
   return AGDIFF_OK;
 }
 
-extern "C" int agdiff_gin_encoder(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, void* stream) {
-  if (!p || !topo || !ws || p->num_convs_local <= 0 || p->num_convs_local > AGDIFF_MAX_CONVS_LOCAL) return AGDIFF_ERR_ARG;
+extern "C" int agdiff_gin_encoder(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
+                                  int32_t rows_per_canonical_edge, void* stream) {
+  if (!p || !topo || !ws || p->num_convs_local <= 0 || p->num_convs_local > AGDIFF_MAX_CONVS_LOCAL ||
+      (topo->num_local > 0 && (!topo->loc_in_src || !topo->loc_in_row)))
+    return AGDIFF_ERR_ARG;
   if (topo->num_nodes <= 0) return AGDIFF_OK;
   const int64_t tiles = (topo->num_nodes + AG_TW - 1) / AG_TW;
   const int waves = ag_node_waves_per_wg(tiles);
@@ -840,8 +849,8 @@ extern "C" int agdiff_gin_encoder(const agdiff_params_t* p, const agdiff_topo_t*
     a.emb = (k == 0) ? p->gin_emb : nullptr;
     a.atom_type = topo->atom_type;
     a.loc_in_ptr = topo->loc_in_ptr;
-    a.loc_in_eid = topo->loc_in_eid;
-    a.loc_src = topo->loc_src;
+    a.in_src = topo->loc_in_src;
+    a.in_row = rows_per_canonical_edge ? topo->loc_in_row : topo->loc_in_eid;
     a.l_attr_rows = ws->l_attr_rows;
     a.h_in = in;
     a.h_out = bufs[cur];

@@ -84,6 +84,10 @@ class BatchTopology:
         canon = ~has_m | (src < dst)
         lc_pos = np.nonzero(canon)[0]
         lc_mir = np.where(has_m[lc_pos], mpos_c[lc_pos], -1)
+        loc_row = np.full(L, -1, dtype=np.int64)          # canonical index (row of l_attr_rows) of every local edge
+        loc_row[lc_pos] = np.arange(lc_pos.shape[0])
+        loc_row[lc_mir[lc_mir >= 0]] = np.nonzero(lc_mir >= 0)[0]
+        assert L == 0 or loc_row.min() >= 0
 
         n_of_node = counts[ba]
         cap = np.minimum(n_of_node - 1, np.minimum(_lib.RADIUS_CAP, n_of_node - 1) + locdeg)
@@ -105,7 +109,8 @@ class BatchTopology:
         self.loc_out_ptr, self.loc_in_ptr, self.loc_in_eid = i32(out_ptr), i32(in_ptr), i32(in_order)
         self.Lc = int(lc_pos.shape[0])
         self.lc_src, self.lc_dst, self.lc_type = i32(src[lc_pos]), i32(dst[lc_pos]), i32(typ[lc_pos])
-        self.lc_pos, self.lc_mir = i32(lc_pos), i32(lc_mir)
+        self.lc_pos, self.lc_mir, self.loc_row = i32(lc_pos), i32(lc_mir), i32(loc_row)
+        self.loc_in_src, self.loc_in_row = i32(src[in_order]), i32(loc_row[in_order])
         # int64 copies of the local edges for the API results (forward() returns int64 indices)
         self.loc_index64 = torch.from_numpy(np.stack([src, dst])).to(device)
         self.loc_type64 = torch.from_numpy(typ).to(device)
@@ -117,7 +122,8 @@ class BatchTopology:
         t.max_edges, t.max_atoms_per_graph, t.max_in_degree = self.max_edges, self.max_atoms, self.max_in_degree
         t.num_local_canon = self.Lc
         for f in ("graph_ptr", "atom_type", "loc_src", "loc_dst", "loc_type", "loc_out_ptr", "loc_in_ptr", "loc_in_eid",
-                  "lc_src", "lc_dst", "lc_type", "lc_pos", "lc_mir"):
+                  "lc_src", "lc_dst", "lc_type", "lc_pos", "lc_mir", "loc_row", "loc_in_src",
+                  "loc_in_row"):
             setattr(t, f, _lib.ptr(getattr(self, f)))
         self.struct = t
 

@@ -407,11 +407,15 @@ def main():
         timeit("head_global", lambda: lib.agdiff_pair_head(ctypes.byref(pk.struct.head_global), _lib.ptr(ws.num_canon), et, _lib.ptr(ws.c_src), _lib.ptr(ws.c_dst), _lib.ptr(ws.h), _lib.ptr(ws.e_attr), None, _lib.ptr(ws.c_pos), _lib.ptr(ws.c_mir), _lib.ptr(ws.e_inv_global), stream))
         ct = (topo.Lc + _lib.TILE - 1) // _lib.TILE
         timeit("local_lengths", lambda: lib.agdiff_local_lengths(Tp, Wp, run.pos_p, stream))
-        timeit("local_encoder", lambda: lib.agdiff_edge_encoder(P, _lib.ptr(ws.num_local_canon), ct, _lib.ptr(ws.lc_len), _lib.ptr(topo.lc_type), None, _lib.ptr(ws.l_attr_rows), None, _lib.ptr(topo.lc_pos), _lib.ptr(topo.lc_mir), stream))
-        timeit("gin_encoder_x%d" % cfg.num_convs_local, lambda: lib.agdiff_gin_encoder(P, Tp, Wp, stream))
+        timeit("local_encoder", lambda: lib.agdiff_edge_encoder(P, _lib.ptr(ws.num_local_canon), ct, _lib.ptr(ws.lc_len), _lib.ptr(topo.lc_type), None, _lib.ptr(ws.l_attr_rows), None, None, None, stream))
+        timeit("gin_encoder_x%d" % cfg.num_convs_local, lambda: lib.agdiff_gin_encoder(P, Tp, Wp, 1, stream))
         timeit("local_head", lambda: lib.agdiff_pair_head(ctypes.byref(pk.struct.head_local), _lib.ptr(ws.num_local_canon), ct, _lib.ptr(topo.lc_src), _lib.ptr(topo.lc_dst), _lib.ptr(ws.hl), None, _lib.ptr(ws.l_attr_rows), _lib.ptr(topo.lc_pos), _lib.ptr(topo.lc_mir), _lib.ptr(ws.l_inv), stream))
         timeit("local_branch", lambda: lib.agdiff_score_forward(P, Tp, Wp, run.pos_p, 0, stream))
         timeit("score_forward_global", lambda: lib.agdiff_score_forward(P, Tp, Wp, run.pos_p, 1, stream))
+        # the same launches on all-zero operands (same instruction stream: nothing in the kernel branches on values);
+        # a large drop means the launch time is set by the clock the chip holds under load, not by cycle counts
+        ws.e_attr.zero_(); ws.xs.zero_()
+        timeit("cfconv_fused_x%d_zero_operands" % cfg.num_convs, lambda: [lib.agdiff_cfconv_fused(P, Tp, Wp, k, stream) for k in range(cfg.num_convs)], reps=20)
         ops.update(N=topo.N, E=E, L=topo.L, G=int(b["num_graphs"]), ms_per_step=ms_per_step)
         with open(args.breakdown, "w") as f:
             json.dump(ops, f, indent=1)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 18
+#define AGDIFF_ABI_VERSION 19
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -158,6 +158,9 @@ typedef struct agdiff_topo {
   const int32_t* lc_type;    /* [Lc] */
   const int32_t* lc_pos;     /* [Lc]: the canonical edge's own id in the local list */
   const int32_t* lc_mir;     /* [Lc]: its mirror's id there, or -1 */
+  const int32_t* loc_row;    /* [L]: canonical index (row of l_attr_rows) of every local edge */
+  const int32_t* loc_in_src; /* [L]: loc_src[loc_in_eid[s]] (the GIN gather reads its indices by in-slot, one level deep) */
+  const int32_t* loc_in_row; /* [L]: loc_row[loc_in_eid[s]] */
 } agdiff_topo_t;
 
 /* ---- workspace (device buffers the host allocates once per batch) ------------------------- */
@@ -174,7 +177,8 @@ typedef struct agdiff_ws {
   int32_t* e_type;           /* [max_edges] */
   float*   e_len;            /* [max_edges] */
   int32_t* ref2dst;          /* [max_edges]: reference position q -> destination-sorted id */
-  int32_t* e_loc;            /* [max_edges]: id of the edge in the local (type > 0) list, -1 for radius-only edges */
+  int32_t* e_loc;            /* [max_edges]: row of l_attr_rows (= canonical index, topo->loc_row) of the edge's local (type > 0)
+                                list entry, -1 for radius-only edges */
   /* canonical edges: j -> i and i -> j with equal type have the same length and type, hence bit-identical
    * edge_attr and pair-head output (dualenc.py:189-211); one of the two (src < dst) is canonical, as is every edge
    * without such a mirror.  Destination-sorted like the full list; the encoder and the global head walk this list. */
@@ -194,9 +198,11 @@ typedef struct agdiff_ws {
   float*   l_len;            /* [L] */
   float*   lc_len;           /* [Lc] lengths of the canonical local edges (same values as l_len[lc_pos]) */
   int32_t* num_local_canon;  /* [1]  Lc as a device scalar (written once by the host) */
-  float*   l_attr_rows;      /* [L][128] fp32 row-major edge_attr of the local edges (GIN message gather, local head);
-                                written by the global encoder pass through e_loc when that pass runs, else by a
-                                pass over the canonical local list (each result to the edge's and its mirror's row) */
+  float*   l_attr_rows;      /* fp32 row-major edge_attr rows [128] of the local edges (GIN message gather, local head): ONE row
+                                per canonical local edge (row c for lc_*[c]; a mirror pair shares it: the GIN layers are
+                                bound by reading these rows), written by the global encoder pass through e_loc when that
+                                pass runs, else by a pass over the canonical local list.  With a caller-supplied graph
+                                (AGDIFF_FWD_GRAPH_GIVEN: lengths need not be symmetric) one row per local edge [L]. */
   float*   l_inv;            /* [L] grad_local_dist_mlp output */
   /* nodes */
   float*   h;                /* [N][128] SchNet node state */
@@ -275,14 +281,18 @@ int agdiff_cfconv_fused(const agdiff_params_t* p, const agdiff_topo_t* topo, con
  * rows [n][128] (attr_rows) -- exactly one of the two.  pos_index / mir_index (both or neither, with attr_frag):
  * the n edges are a canonical list; edge e reads its attrs at position pos_index[e] and writes its result to
  * out[pos_index[e]] and, when >= 0, out[mir_index[e]] (h_i * h_j is symmetric, so the mirror's value is the same).
- * With attr_rows and pos_index the edge's attributes are row pos_index[e] (the local head over the canonical local list). */
+ * With attr_rows the edge's attributes are row e of attr_rows, whatever pos_index is (the local head over the canonical
+ * local list: row c, results to out[lc_pos[c]] and out[lc_mir[c]]). */
 int agdiff_pair_head(const agdiff_head_params_t* hp, const int32_t* n_edges_dev, int64_t max_tiles,
                      const int32_t* src, const int32_t* dst, const float* node_h, const float* attr_frag,
                      const float* attr_rows, const int32_t* pos_index, const int32_t* mir_index, float* out,
                      void* stream);
 
-/* GINEncoder.forward (encoder/gin.py:112-148) on the static local edges; result in ws->hl. */
-int agdiff_gin_encoder(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, void* stream);
+/* GINEncoder.forward (encoder/gin.py:112-148) on the static local edges; result in ws->hl.
+ * rows_per_canonical_edge != 0: ws->l_attr_rows holds one row per canonical local edge (local edge e reads row
+ * topo->loc_row[e]); 0: one row per local edge. */
+int agdiff_gin_encoder(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
+                       int32_t rows_per_canonical_edge, void* stream);
 
 /* PyG MessagePassing.propagate(aggr='add') with message x_j * W (encoder/schnet.py:156,161-162) as a
  * stand-alone op on a destination-sorted CSR: out[i][:] = sum_{e in [in_ptr[i], in_ptr[i+1])} x[src[e]][:] * W[e][:].

@@ -200,6 +200,8 @@ def test_canonical_local_edge_list():
     np.add.at(cover, cp, 1)
     np.add.at(cover, cm[has], 1)
     assert np.all(cover == 1)
+    row = topo.loc_row.numpy()                      # the l_attr_rows row of every local edge: its canonical index
+    assert np.array_equal(row[cp], np.arange(topo.Lc)) and np.array_equal(row[cm[has]], np.nonzero(has)[0])
     key = {(int(a), int(c)): int(t_) for a, c, t_ in zip(src, dst, typ)}
     unpaired = cp[~has]
     assert len(unpaired) >= 3                       # the dropped edge's reverse and both directions of the retyped pair
