@@ -19,6 +19,6 @@ python bench.py --force-dist --scaling strong --steps 300 --no-cpu-baseline --no
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kstats_refresh -- python3 $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extra > $out/kstats_bench.json 2>/dev/null
 cp /tmp/kstats_refresh/*/*kernel_stats.csv $out/${R}_bf16x3_bench_kernel_stats.csv
-cd $GRAFT_REPO_ROOT && bash tools/pmc_traffic.sh > $out/${R}_pmc_traffic.txt 2>&1
+cd $GRAFT_REPO_ROOT && bash tools/pmc_traffic.sh > $out/${R}_bf16x3_pmc_traffic.txt 2>&1
 bash tools/pmc_sq.sh > $out/${R}_bf16x3_pmc_sq.txt 2>&1
-tail -n 12 $out/${R}_pmc_traffic.txt; tail -n 30 $out/${R}_bf16x3_pmc_sq.txt
+tail -n 12 $out/${R}_bf16x3_pmc_traffic.txt; tail -n 30 $out/${R}_bf16x3_pmc_sq.txt
