@@ -1,0 +1,292 @@
+// CFConv with the filter network evaluated ONCE per atom pair, for molecules whose pair set is (nearly) complete
+// (second design).
+//
+// encoder/schnet.py:136-162: W_e = nn(edge_attr_e) * (lw(d_e) * C(d_e)); agg[dst] += x[src] * W_e.  The directed edges
+// j -> i and i -> j of a pair carry the same length and type, hence bit-identical edge_attr and filter.  A 16-row tile is
+// the 4 x 4 block of pairs (T_a, S_b), a, b = 0..3, of four TARGET atoms and four SOURCE atoms of one molecule, row
+// r = 4 a + b.  In the flipped second-layer layout (rows = pairs, lanes = channels) quarter q of the wave holds the four
+// rows of target T_q, so
+//   * the direct message  agg[T_a] += W x[S_b] s(S_b -> T_a)  is a sum over the four values a lane holds: no lane traffic,
+//     accumulated in registers over the tiles of a group (same four targets, up to four source blocks), and
+//   * the mirror message  agg[S_b] += W x[T_a] s(T_a -> S_b)  is a sum over the four quarters: one reduce-scatter
+//     (three lane-swap instructions) leaves the sum for S_j in quarter j, accumulated in registers per source block
+//     (four blocks = one 16-source sweep) and written once per sweep part.
+// A pair that is no edge in one direction (asymmetric 32-neighbour cap) or in both has scale 0 there.  Tiles with the
+// same atoms as targets and sources (the diagonal 4-blocks) carry both directions as separate rows and no mirror part.
+// No atomics: every output row has one writer; the node side adds an atom's few partial rows in a fixed order.
+// STATUS: experiment (tools/proto_run4.py builds the tile tables on the host and compares with k_cfconv_fused).
+#include "common.hpp"
+#include <type_traits>
+
+namespace {
+
+#define AG_P4_WAVES 8
+#ifndef P4_ABL
+#define P4_ABL 0      // timing experiments: 1 no reduce-scatter, no selectors; 2 no selectors; 3 no mirror part at all
+#endif
+
+struct Pairs4Args {
+  agdiff_conv_params_t cp;
+  const int32_t* pt_atoms;     // [tiles][8]: T0..T3, S0..S3 (atom ids; -1: none)
+  const int32_t* pt_info;      // [tiles][4]: k (source block of the sweep, 0..3) | last-of-group << 2 | flush-mirror << 3,
+                               //             direct row group, mirror row set, unused
+  const float* sd1;            // [rows] conv1 scale of S_b -> T_a (0: no such edge)
+  const float* sm1;            // [rows] conv1 scale of T_a -> S_b
+  const float* sd2;            // [rows] conv2 ...
+  const float* sm2;
+  const float* e_attr;         // operand-form tiles in row order
+  const float* xs;             // [N][192]
+  float* dbuf;                 // [groups][4][192] direct sums of the group's targets over its source blocks
+  float* mbuf;                 // [sets][16][192]  mirror sums of the sweep part's 16 sources
+  const int32_t* wave_tile_ptr;  // [waves + 1]
+  int32_t num_waves;
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(64 * AG_P4_WAVES, 2) k_cfconv_pairs4(Pairs4Args a) {
+  extern __shared__ u32x4 ag_p4_smem[];
+  lds_u32x4* w1 = (lds_u32x4*)ag_p4_smem;    // fused first layer, blocks [t][12]
+  lds_u32x4* w2a = w1 + 48 * 128;            // conv1 second layer pk [8][4]
+  {
+    const u32x4* g1 = reinterpret_cast<const u32x4*>(a.cp.filt_w1_pk);
+    const u32x4* ga = reinterpret_cast<const u32x4*>(a.cp.filt_w2a_pk);
+    for (int i = threadIdx.x; i < 48 * 128; i += blockDim.x) w1[i] = g1[i];
+    for (int i = threadIdx.x; i < 32 * 128; i += blockDim.x) w2a[i] = ga[i];
+  }
+  __syncthreads();
+  const int lane0 = ag_lane();
+  const int wave = threadIdx.x >> 6;
+  const int wg = (gridDim.x % 8 == 0) ? (int)((blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8) : (int)blockIdx.x;
+  const int w = wg * AG_P4_WAVES + wave;
+  if (w >= a.num_waves) return;
+  const int t_begin = a.wave_tile_ptr[w], t_end = a.wave_tile_ptr[w + 1];
+  if (t_begin >= t_end) return;
+
+  AgIn<MODE> ea[4];
+  f32x4 nb0 = ag_ld4(a.cp.filt_b1 + 128 + 4 * (lane0 >> 4)), nb1 = ag_ld4(a.cp.filt_b1 + 128 + 16 + 4 * (lane0 >> 4));
+  int pf_atom = 0, pf_info = 0, pf_drow = 0, pf_mrow = 0;
+  float pf_sd1 = 0.0f, pf_sm1 = 0.0f, pf_sd2 = 0.0f, pf_sm2 = 0.0f;
+  auto prefetch = [&](int64_t tl, int ln) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) ag_load_attr(ea[t], a.e_attr, tl, t, ln);
+    const int64_t e = tl * AG_TW + (ln & 15);
+    pf_sd1 = a.sd1[e];
+    pf_sm1 = a.sm1[e];
+    pf_sd2 = a.sd2[e];
+    pf_sm2 = a.sm2[e];
+    const int at = a.pt_atoms[tl * 8 + (ln & 7)];
+    pf_atom = at < 0 ? 0 : at;
+    pf_info = a.pt_info[tl * 4];
+    pf_drow = a.pt_info[tl * 4 + 1];
+    pf_mrow = a.pt_info[tl * 4 + 2];
+  };
+  prefetch(t_begin, lane0);
+
+  float dacc[12];            // direct sums: target T_q, channel 16 c + col
+  float macc[4][12];         // mirror sums: source q of source block s, channel 16 c + col
+#pragma unroll
+  for (int c = 0; c < 12; ++c) {
+    dacc[c] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) macc[s][c] = 0.0f;
+  }
+
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int q = lane >> 4, col = lane & 15;
+    const int my_atom = pf_atom;
+    const float s1d = pf_sd1, s1m = pf_sm1, s2d = pf_sd2, s2m = pf_sm2;
+    const int info = __builtin_amdgcn_readfirstlane(pf_info);
+    const int drow = __builtin_amdgcn_readfirstlane(pf_drow);
+    const int mrow = __builtin_amdgcn_readfirstlane(pf_mrow);
+    const int ksrc = info & 3;
+    float sel[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) sel[s] = (ksrc == s) ? 1.0f : 0.0f;
+    uint32_t xoffS[4], xoffT;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) xoffS[b] = (uint32_t)__shfl(my_atom, 4 + b) * 192u + (uint32_t)col;
+    xoffT = (uint32_t)__shfl(my_atom, q) * 192u + (uint32_t)col;
+    f32x4 xg;
+    float xt;
+    auto fetch_x = [&](int c) {          // c = channel tile in the 192-wide rows
+      const float* xb = a.xs + 16 * c;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xg[r] = xb[xoffS[r]];
+      xt = xb[xoffT];
+    };
+    fetch_x(8);
+    const lds_u32x4* w1_lo = w1 + lane;
+    asm volatile("" : "+v"(w1_lo));
+    const lds_u32x4* w1_hi = w1 + 32 * 128 + lane;
+    asm volatile("" : "+v"(w1_hi));
+    const lds_u32x4* w2a_l = w2a + lane;
+    asm volatile("" : "+v"(w2a_l));
+
+    // one conv: CONV 2 first (channel tiles 8..11, hidden k-tiles from first-layer tiles 8..11), then CONV 1
+    auto phase = [&](auto CONVT, bool prefetch_next) {
+      constexpr int CONV = decltype(CONVT)::value;
+      constexpr int NCH = CONV == 1 ? 8 : 4;
+      constexpr int NM = NCH / 2;
+      constexpr int OT0 = CONV == 1 ? 0 : 8;
+      f32x4 sd, sm;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sd[r] = __shfl(CONV == 1 ? s1d : s2d, 4 * q + r);
+        sm[r] = __shfl(CONV == 1 ? s1m : s2m, 4 * q + r);
+      }
+      AgIn<MODE> hidb[NM];
+      {
+        u32x4 wq[2][2][2];
+        auto fetch_w = [&](u32x4 (&dst)[2][2], int step) {
+          const int m = step >> 2, t = step & 3;
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int bi = t * 12 + OT0 + 2 * m + b;
+            const lds_u32x4* wb = (bi < 32) ? w1_lo + bi * 128 : w1_hi + (bi - 32) * 128;
+            dst[b][0] = wb[0];
+            dst[b][1] = wb[64];
+          }
+        };
+        fetch_w(wq[0], 0);
+        f32x4 hp0 = {0.f, 0.f, 0.f, 0.f}, hp1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m <= NM; ++m) {
+          f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = {0.f, 0.f, 0.f, 0.f};
+          if (m < NM) {
+            // bias requested a pair ahead (order of pairs per tile: conv2's two, conv1's four, the next tile's first)
+            h0 = nb0;
+            h1 = nb1;
+            const int gm = (CONV == 2 ? m : 2 + m) + 1;
+            const int nm = gm % 6;
+            const int off = (nm < 2) ? 128 + 32 * nm : 32 * (nm - 2);
+            nb0 = ag_ld4(a.cp.filt_b1 + off + 4 * q);
+            nb1 = ag_ld4(a.cp.filt_b1 + off + 16 + 4 * q);
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int step = m * 4 + t;
+            if (m < NM) {
+              if (step + 1 < 4 * NM) fetch_w(wq[(step + 1) & 1], step + 1);
+              ag_block_mma<MODE, false>(h0, ea[t], wq[step & 1][0]);
+              ag_block_mma<MODE, false>(h1, ea[t], wq[step & 1][1]);
+            }
+            if (m > 0) {
+              float v0 = (t < 2) ? hp0[2 * t] : hp1[2 * t - 4], v1 = (t < 2) ? hp0[2 * t + 1] : hp1[2 * t - 3];
+              v0 = ag_ssp_base2(v0);
+              v1 = ag_ssp_base2(v1);
+              asm volatile("" : "+v"(v0), "+v"(v1));
+              ag_cvt_pair(hidb[m - 1], 2 * t, v0, v1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          hp0 = h0; hp1 = h1;
+        }
+      }
+      if (prefetch_next && tile + 1 < t_end) prefetch(tile + 1, lane);
+      // conv2's second layer streams from L2 one channel tile ahead (pk [4][2])
+      const u32x4* gl = reinterpret_cast<const u32x4*>(a.cp.filt_w2b_pk) + lane;
+      u32x4 g[2][2];
+      auto fetch_g = [&](int pair) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          g[b][0] = gl[((2 * pair + b) * 2) * 64];
+          g[b][1] = gl[((2 * pair + b) * 2 + 1) * 64];
+        }
+      };
+      if constexpr (CONV == 2) fetch_g(0);
+      auto dense2 = [&](int nt) -> f32x4 {
+        f32x4 z[1] = {{0.f, 0.f, 0.f, 0.f}};
+        if constexpr (CONV == 1) {
+          ag_dense_lds<MODE, true, false, 4, 1, 0, 0>(hidb, z, w2a_l + (nt * 4) * 128, 0);
+        } else {
+          ag_block_mma<MODE, true>(z[0], hidb[0], g[0]);
+          ag_block_mma<MODE, true>(z[0], hidb[1], g[1]);
+          if (nt + 1 < NCH) fetch_g(nt + 1);
+        }
+        return z[0];
+      };
+      constexpr int NEXT_FIRST = CONV == 2 ? 0 : -1;     // after conv2 comes conv1's channel tile 0
+      f32x4 zp = {0.f, 0.f, 0.f, 0.f}, xp = {0.f, 0.f, 0.f, 0.f};
+      float bp = 0.0f, xtp = 0.0f;
+#pragma unroll
+      for (int nt = 0; nt <= NCH; ++nt) {
+        f32x4 z = {0.f, 0.f, 0.f, 0.f}, xc = {0.f, 0.f, 0.f, 0.f};
+        float bb = 0.0f, xtc = 0.0f;
+        if (nt < NCH) {
+          z = dense2(nt);
+          bb = a.cp.filt_b2[16 * (OT0 + nt) + col];
+          xc = xg;
+          xtc = xt;
+          if (nt + 1 < NCH) fetch_x(OT0 + nt + 1);
+          else if (NEXT_FIRST >= 0) fetch_x(NEXT_FIRST);
+        }
+        if (nt > 0) {
+          const int c = OT0 + nt - 1;
+          f32x4 zb, u;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            zb[r] = zp[r] + bp;
+            dacc[c] = fmaf(zb[r], xp[r] * sd[r], dacc[c]);
+            u[r] = zb[r] * (sm[r] * xtp);
+          }
+#if P4_ABL == 1
+          macc[0][c] += u[0] + u[1] + u[2] + u[3];
+#elif P4_ABL == 2
+          const float rs = ag_quarter_reduce_scatter4(u[0], u[1], u[2], u[3]);
+          macc[0][c] += rs;
+#elif P4_ABL == 3
+#else
+          const float rs = ag_quarter_reduce_scatter4(u[0], u[1], u[2], u[3]);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) macc[s][c] = fmaf(sel[s], rs, macc[s][c]);
+#endif
+        }
+        zp = z; xp = xc; bp = bb; xtp = xtc;
+      }
+    };
+    phase(std::integral_constant<int, 2>{}, false);
+    phase(std::integral_constant<int, 1>{}, true);
+
+    if (info & 4) {            // last tile of its group: the four targets' direct sums over the group's source blocks
+      float* dp = a.dbuf + ((size_t)drow * 4 + q) * 192 + col;
+#pragma unroll
+      for (int c = 0; c < 12; ++c) {
+        dp[16 * c] = dacc[c];
+        dacc[c] = 0.0f;
+      }
+    }
+    if (info & 8) {            // end of a sweep part: mirror sums of its 16 sources
+      float* mp = a.mbuf + ((size_t)mrow * 16 + q) * 192 + col;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int c = 0; c < 12; ++c) {
+          mp[(size_t)(4 * s) * 192 + 16 * c] = macc[s][c];
+          macc[s][c] = 0.0f;
+        }
+    }
+  }
+}
+
+}  // namespace
+
+// Experimental entry point (not part of the public header): block k over 4 x 4 pair tiles (tools/proto_pairs4.py).
+extern "C" int agdiff_proto_cfconv_pairs4(const agdiff_params_t* p, int32_t k, const int32_t* pt_atoms, const int32_t* pt_info,
+                                          const float* sd1, const float* sm1, const float* sd2, const float* sm2,
+                                          const float* e_attr, const float* xs, float* dbuf, float* mbuf,
+                                          const int32_t* wave_tile_ptr, int32_t num_waves, void* stream) {
+  if (!p || k < 0 || k >= p->num_convs || num_waves <= 0) return AGDIFF_ERR_ARG;
+  Pairs4Args a{p->conv[k], pt_atoms, pt_info, sd1, sm1, sd2, sm2, e_attr, xs, dbuf, mbuf, wave_tile_ptr, num_waves};
+  const int wgs = (num_waves + AG_P4_WAVES - 1) / AG_P4_WAVES;
+  const size_t smem = (size_t)80 * 2048;
+  static std::atomic<uint64_t> attr_done{0};
+  if (!ag_allow_big_lds(attr_done, smem, k_cfconv_pairs4<AG_BF3>, k_cfconv_pairs4<AG_F32>)) return AGDIFF_ERR_LAUNCH;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)wgs), block(64 * AG_P4_WAVES);
+  if (p->precision == AG_BF3) k_cfconv_pairs4<AG_BF3><<<grid, block, smem, st>>>(a);
+  else k_cfconv_pairs4<AG_F32><<<grid, block, smem, st>>>(a);
+  AG_CHECK_LAUNCH();
+  return AGDIFF_OK;
+}

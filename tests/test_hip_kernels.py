@@ -207,3 +207,22 @@ def test_mirror_sharing_cfconv_prototype_matches_product_kernel(precision):
     ref = _device_agg(lib, topo, ws)
     # same arithmetic per edge in both kernels; only the order of the fp32 additions differs
     check_close("pairs prototype agg", got.float(), ref.float(), "f32")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,mols,copies", [("drugs", 4, 3), ("qm9", 6, 4)])
+def test_pair_tile_cfconv_prototype_matches_product_kernel(workload, mols, copies):
+    """csrc/pairs4.hip (experiment, DESIGN.md §8.2, second design: 4 x 4 pair tiles, direct sums inside a lane, mirror
+    sums by one reduce-scatter over the quarters): direct + mirror partial rows add up to agg[node] of
+    agdiff_cfconv_fused for every molecule of the batch.  The harness (tools/proto_run4.py) builds the tables."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "proto_run4.py"), "--workload", workload, "--mols", str(mols),
+                          "--copies", str(copies), "--max-atoms", "512", "--reps", "2"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["E_dense"] == rec["E"] and rec["pair_tiles"] > 0
+    assert rec["rel_err"] < 1e-5, rec
