@@ -276,6 +276,12 @@ def test_node_kernel_variants(precision, monkeypatch):
     shared = m(*a, return_edges=True, extend_order=False)
     monkeypatch.delenv("AGDIFF_NODE_LDSW_MIN_TILES")
     monkeypatch.delenv("AGDIFF_NODE_SPLIT_MAX_TILES")
+    # the local edges' attribute rows: from the local branch's own encoder pass (batches this small) or written by the
+    # global encoder pass through e_loc (large batches) -- the same encoder on the same lengths
+    monkeypatch.setenv("AGDIFF_SHARE_ROWS_MIN_NODES", "0")
+    rows_shared = m(*a, return_edges=True, extend_order=False)
+    monkeypatch.delenv("AGDIFF_SHARE_ROWS_MIN_NODES")
+    assert torch.equal(rows_shared[0], split[0]) and torch.equal(rows_shared[1], split[1])
     if precision == "f32":
         assert torch.equal(stream[0], shared[0]) and torch.equal(stream[1], shared[1])
     assert torch.equal(stream[1], split[1])                               # the local branch does not use the node stage
