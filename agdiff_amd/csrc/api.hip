@@ -103,7 +103,7 @@ int global_front(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdi
   const int64_t etiles = (topo->max_edges + AG_TW - 1) / AG_TW;
   if (!(flags & AGDIFF_FWD_GRAPH_GIVEN))     // cutoff 0 admits no radius edge: the bond graph alone (extend_radius=False)
     AG_TRY(agdiff_graph_build(topo, ws, pos, (flags & AGDIFF_FWD_NO_RADIUS) ? 0.0f : p->cutoff, stream));
-  AG_TRY(agdiff_edge_scales(p, topo, ws, stream));
+  AG_TRY(agdiff_edge_scales(p, topo, ws, (flags & AGDIFF_FWD_GRAPH_GIVEN) ? 0 : 1, stream));
   if (flags & AGDIFF_FWD_GRAPH_GIVEN) {       // caller's edge list: no canonical list, one encoder evaluation per edge
     AG_TRY(agdiff_edge_encoder(p, ws->num_edges, etiles, ws->e_len, ws->e_type, ws->e_attr, nullptr, nullptr, nullptr,
                                nullptr, stream));

@@ -199,6 +199,8 @@ struct ScaleArgs {
   const float* dw[2 * AGDIFF_MAX_CONVS];
   const int32_t* n_dev;
   const float* e_len;
+  const int32_t* pos_index;    // optional (with mir_index): entry e is the canonical edge of positions pos_index[e] and,
+  const int32_t* mir_index;    // when >= 0, mir_index[e] (a mirror pair has one length, hence one scale)
   float* out;
   int64_t epad;
   int32_t n;
@@ -207,12 +209,20 @@ struct ScaleArgs {
 };
 
 // lw(d) * C(d) for the 2*num_convs CFConvs (schnet.py:138-149), once per step instead of once per
-// block launch: one thread per (edge, conv), blockIdx.y = conv.
+// block launch: one thread per (edge or mirror pair, conv), blockIdx.y = conv.
 __global__ void __launch_bounds__(256) k_edge_scales(ScaleArgs a) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= *a.n_dev) return;
   const int c = blockIdx.y;
-  a.out[(size_t)c * a.epad + e] = cf_edge_scale(a.dw[c], a.e_len[e], a.cutoff, a.smooth);
+  const float s = cf_edge_scale(a.dw[c], a.e_len[e], a.cutoff, a.smooth);
+  float* out = a.out + (size_t)c * a.epad;
+  if (a.pos_index) {
+    out[a.pos_index[e]] = s;
+    const int m = a.mir_index[e];
+    if (m >= 0) out[m] = s;
+  } else {
+    out[e] = s;
+  }
 }
 
 // ------------------------------------------------------------------------------ fused CFConv
@@ -832,17 +842,21 @@ extern "C" int agdiff_edge_encoder(const agdiff_params_t* p, const int32_t* n_ed
   return AGDIFF_OK;
 }
 
-extern "C" int agdiff_edge_scales(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, void* stream) {
+extern "C" int agdiff_edge_scales(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
+                                  int32_t per_canonical_edge, void* stream) {
   if (!p || !topo || !ws || !ws->e_scale || !ws->e_len || !ws->num_edges || p->num_convs > AGDIFF_MAX_CONVS)
     return AGDIFF_ERR_ARG;
+  if (per_canonical_edge && (!ws->num_canon || !ws->c_len || !ws->c_pos || !ws->c_mir)) return AGDIFF_ERR_ARG;
   if (topo->max_edges == 0) return AGDIFF_OK;
   ScaleArgs a;
   for (int k = 0; k < p->num_convs; ++k) {
     a.dw[2 * k] = p->conv[k].dist_w;
     a.dw[2 * k + 1] = p->conv[k].dist_w + 97;
   }
-  a.n_dev = ws->num_edges;
-  a.e_len = ws->e_len;
+  a.n_dev = per_canonical_edge ? ws->num_canon : ws->num_edges;
+  a.e_len = per_canonical_edge ? ws->c_len : ws->e_len;
+  a.pos_index = per_canonical_edge ? ws->c_pos : nullptr;
+  a.mir_index = per_canonical_edge ? ws->c_mir : nullptr;
   a.out = ws->e_scale;
   a.epad = ((topo->max_edges + AG_TW - 1) / AG_TW) * AG_TW;
   a.n = 2 * p->num_convs;

@@ -400,7 +400,7 @@ def main():
         P, Tp, Wp = ctypes.byref(pk.struct), ctypes.byref(topo.struct), ctypes.byref(ws.struct)
         et, lt = (topo.max_edges + _lib.TILE - 1) // _lib.TILE, (topo.L + _lib.TILE - 1) // _lib.TILE
         timeit("graph_build", lambda: lib.agdiff_graph_build(Tp, Wp, run.pos_p, ctypes.c_float(cfg.cutoff), stream))
-        timeit("edge_scales", lambda: lib.agdiff_edge_scales(P, Tp, Wp, stream))
+        timeit("edge_scales", lambda: lib.agdiff_edge_scales(P, Tp, Wp, 1, stream))
         timeit("edge_encoder", lambda: lib.agdiff_edge_encoder(P, _lib.ptr(ws.num_canon), et, _lib.ptr(ws.c_len), _lib.ptr(ws.c_type), _lib.ptr(ws.e_attr), _lib.ptr(ws.l_attr_rows), _lib.ptr(ws.e_loc), _lib.ptr(ws.c_pos), _lib.ptr(ws.c_mir), stream))
         timeit("node_stage_x%d" % (cfg.num_convs + 1), lambda: [lib.agdiff_schnet_node_stage(P, Tp, Wp, k, stream) for k in range(cfg.num_convs + 1)])
         timeit("cfconv_fused_x%d" % cfg.num_convs, lambda: [lib.agdiff_cfconv_fused(P, Tp, Wp, k, stream) for k in range(cfg.num_convs)])

@@ -252,8 +252,10 @@ int agdiff_graph_build(const agdiff_topo_t* topo, const agdiff_ws_t* ws, const f
 int agdiff_local_lengths(const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, void* stream);
 
 /* DistanceWeightingNetwork x cutoff envelope of all 2*num_convs CFConvs (encoder/schnet.py:83-100, 138-149):
- * ws->e_scale from ws->e_len. */
-int agdiff_edge_scales(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, void* stream);
+ * ws->e_scale from ws->e_len; per_canonical_edge != 0: from ws->c_len, one evaluation per canonical edge written to its
+ * position and its mirror's (equal lengths: the same value bit for bit). */
+int agdiff_edge_scales(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
+                       int32_t per_canonical_edge, void* stream);
 
 /* get_edge_encoder(cfg)(edge_length, edge_type) (encoder/edge.py:106-116): MLPEdgeEncoder.forward
  * (edge.py:84-103) when p->edge_encoder == 0, GaussianSmearingEdgeEncoder.forward (edge.py:34-42) when 1.

@@ -43,7 +43,7 @@ def _setup(case, precision):
     P, Tp, Wp = ctypes.byref(pk.struct), ctypes.byref(topo.struct), ctypes.byref(ws.struct)
     etiles = (topo.max_edges + _lib.TILE - 1) // _lib.TILE
     assert lib.agdiff_graph_build(Tp, Wp, _lib.ptr(pos), ctypes.c_float(cfg.cutoff), st) == 0
-    assert lib.agdiff_edge_scales(P, Tp, Wp, st) == 0
+    assert lib.agdiff_edge_scales(P, Tp, Wp, 1, st) == 0
     assert lib.agdiff_edge_encoder(P, _lib.ptr(ws.num_canon), etiles, _lib.ptr(ws.c_len), _lib.ptr(ws.c_type),
                                    _lib.ptr(ws.e_attr), None, None, _lib.ptr(ws.c_pos), _lib.ptr(ws.c_mir), st) == 0
     torch.cuda.synchronize()
