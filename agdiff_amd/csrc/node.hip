@@ -405,10 +405,56 @@ struct GinArgs {
   int64_t n;
 };
 
-// GINEConv + BN + relu + residual (gin.py:57-63, 131-138): m_i = sum relu(h_j + e_ji);
-// u = MLP(m_i + (1+eps) h_i); u = BN(u) (folded); relu except last layer; h = u + h.
+// GINEConv message sum (gin.py:57-63): m_i = sum_{e: dst = i} relu(h_src(e) + edge_attr_e) + (1 + eps) h_i, written to
+// the layer's OUTPUT buffer (k_gin_layer replaces it by the layer's result).  Its own launch because it is bound by
+// memory latency: inside the MLP kernel (16-node tiles, ~110 VGPRs, one 12..16-wave workgroup per CU next to 128 KiB of
+// weights) a wave had no load in flight 80 % of the time and the gather was 55 of the layer's 74 us.  Here a half-wave
+// owns a node, the lanes lie along the 512-byte rows (16 B each), four messages are in flight per node, and 8 waves fit
+// a SIMD.  Messages are added in list order (sources ascending), as before.
+__global__ void __launch_bounds__(256) k_gin_gather(GinArgs a) {
+  const int lane = ag_lane(), half = lane >> 5, j = lane & 31;
+  const int64_t node = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 2 + half;
+  const bool valid = node < a.n;
+  const int nd = valid ? (int)node : 0;
+  const int lo = a.loc_in_ptr[nd], hi = valid ? a.loc_in_ptr[nd + 1] : lo;
+  const int deg2 = max(__builtin_amdgcn_readlane(hi - lo, 0), __builtin_amdgcn_readlane(hi - lo, 32));
+  const float* hbase = a.emb ? a.emb : a.h_in;
+  const f32x4 hself = ag_ld4((a.emb ? a.emb + (size_t)a.atom_type[nd] * 128 : a.h_in + (size_t)nd * 128) + 4 * j);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 4;           // messages in flight per node (8: slower, the extra slots of short lists cost more than they hide)
+  for (int base = 0; base < deg2; base += 32) {
+    // lane j of a half holds the indices of its node's message base + j (-1: past the list)
+    const int slot = lo + base + j;
+    const bool have = slot < hi;
+    int my_src = have ? a.in_src[slot] : -1;
+    const int my_row = have ? a.in_row[slot] : 0;
+    if (a.emb && have) my_src = a.atom_type[my_src];        // layer 0: the source's row of the embedding table
+    const int cnt = min(32, deg2 - base);
+    for (int k = 0; k < cnt; k += U) {
+      f32x4 hv[U], ev[U];
+      bool on[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int s = __shfl(my_src, 32 * half + ((k + u) & 31)), r = __shfl(my_row, 32 * half + ((k + u) & 31));
+        on[u] = s >= 0;
+        hv[u] = ag_ld4(hbase + (size_t)(on[u] ? s : 0) * 128 + 4 * j);
+        ev[u] = ag_ld4(a.l_attr_rows + (size_t)r * 128 + 4 * j);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += on[u] ? ag_relu(hv[u][r] + ev[u][r]) : 0.0f;
+      }
+    }
+  }
+  acc = acc + a.gp.one_plus_eps * hself;
+  if (valid) *reinterpret_cast<f32x4*>(a.h_out + (size_t)node * 128 + 4 * j) = acc;
+}
+
+// GINEConv MLP + BN + relu + residual (gin.py:57-63, 131-138) on the message sums k_gin_gather left in h_out:
+// u = MLP(m_i); u = BN(u) (folded); relu except last layer; h = u + h.
 // Like the SchNet node stage, a workgroup of W one-tile waves shares the layer's two weight matrices (64 blocks,
-// 128 KiB) through LDS; the copy is issued first and lands while the waves gather their messages.
+// 128 KiB) through LDS.
 template <int MODE, bool LDSW>
 __global__ void __launch_bounds__(LDSW ? 1024 : 256, LDSW ? 1 : 2) k_gin_layer(GinArgs a) {
   extern __shared__ u32x4 ag_gin_smem[];
@@ -433,34 +479,8 @@ __global__ void __launch_bounds__(LDSW ? 1024 : 256, LDSW ? 1 : 2) k_gin_layer(G
   for (int t = 0; t < 8; ++t) m[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 hself[8];
   if (active) {
-    const int lo = a.loc_in_ptr[nd], hi = valid ? a.loc_in_ptr[nd + 1] : lo;
-    int maxdeg = hi - lo;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, o));
-    // the next message's indices are requested before this one's rows, so a message costs one memory round trip
-    int src_n = lo < hi ? a.in_src[lo] : 0, row_n = lo < hi ? a.in_row[lo] : 0;
-    for (int k = 0; k < maxdeg; ++k) {
-      const bool on = lo + k < hi;
-      const int src = src_n, row = row_n;
-      {
-        const bool on_n = lo + k + 1 < hi;
-        src_n = on_n ? a.in_src[lo + k + 1] : 0;
-        row_n = on_n ? a.in_row[lo + k + 1] : 0;
-      }
-      const float* hsrc = a.emb ? a.emb + (size_t)a.atom_type[src] * 128 : a.h_in + (size_t)src * 128;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const int f = 16 * t + 4 * q;
-        const f32x4 hvv = ag_ld4(hsrc + f);
-        const f32x4 ev = ag_ld4(a.l_attr_rows + (size_t)row * 128 + f);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) m[t][r] += on ? ag_relu(hvv[r] + ev[r]) : 0.0f;
-      }
-    }
+    ag_load_row<8, 0>(m, a.h_out + (size_t)nd * 128, q);
     ag_load_row<8, 0>(hself, hin_self, q);
-    const float ope = a.gp.one_plus_eps;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) m[t] = m[t] + ope * hself[t];
   }
   if constexpr (LDSW) __syncthreads();
   if (!active) return;
@@ -856,6 +876,8 @@ extern "C" int agdiff_gin_encoder(const agdiff_params_t* p, const agdiff_topo_t*
     a.h_out = bufs[cur];
     a.n = topo->num_nodes;
     hipStream_t st = (hipStream_t)stream;
+    k_gin_gather<<<dim3((unsigned)((topo->num_nodes + 7) / 8)), dim3(256), 0, st>>>(a);
+    AG_CHECK_LAUNCH();
     if (p->precision == AG_BF3) {
       if (ldsw) k_gin_layer<AG_BF3, true><<<grid, block, smem, st>>>(a);
       else k_gin_layer<AG_BF3, false><<<grid, block, 0, st>>>(a);
