@@ -14,7 +14,7 @@ import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("/tmp/pmcsq/set*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        for k in ("k_cfconv_fused", "k_edge_encoder", "k_pair_head", "k_gin_layer", "k_schnet_node_stage"):
+        for k in ("k_cfconv_fused", "k_edge_encoder", "k_pair_head", "k_gin_layer", "k_gin_gather", "k_schnet_node_stage"):
             if k in r["Kernel_Name"]:
                 agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in agg.items():

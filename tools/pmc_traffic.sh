@@ -15,7 +15,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == c:
-            for k in ("k_cfconv_fused", "k_edge_encoder", "k_pair_head", "k_gin_layer", "k_schnet_node_stage"):
+            for k in ("k_cfconv_fused", "k_edge_encoder", "k_pair_head", "k_gin_layer", "k_gin_gather", "k_schnet_node_stage"):
                 if k in r["Kernel_Name"]:
                     agg[k].append(float(r["Counter_Value"]))
     res[c] = {k: sum(v) / len(v) for k, v in agg.items()}
