@@ -64,8 +64,9 @@ extern __shared__ uint32_t ag_graph_smem[];
 // -- and the position of an edge inside the target's list is the population count of the kept mask below its
 // lane, so all per-edge stores are contiguous.  The in-adjacency masks stay in LDS (row i, bit j <=> edge j -> i);
 // out-degrees and the (src, dst)-order permutation ref2dst come from their columns.
+#define AG_GRAPH_THREADS 1024     // launch bound; the launcher picks 512 or 1024 threads per molecule
 template <bool FILL>
-__global__ void __launch_bounds__(256) k_graph(GraphArgs a) {
+__global__ void __launch_bounds__(AG_GRAPH_THREADS) k_graph(GraphArgs a) {
   const int g = blockIdx.x;
   const int g0 = a.graph_ptr[g];
   const int n = a.graph_ptr[g + 1] - g0;
@@ -154,7 +155,7 @@ __global__ void __launch_bounds__(256) k_graph(GraphArgs a) {
   __syncthreads();
 
   if (!FILL) {
-    __shared__ int wsum[2][4];
+    __shared__ int wsum[2][AG_GRAPH_THREADS / 64];
     if (lane == 0) { wsum[0][wave] = wave_total; wsum[1][wave] = wave_ctotal; }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -356,7 +357,10 @@ extern "C" int agdiff_graph_build(const agdiff_topo_t* topo, const agdiff_ws_t* 
   if (max_atoms <= 0 || max_atoms > AGDIFF_MAX_ATOMS_PER_GRAPH) return AGDIFF_ERR_LIMIT;
   a.words = 2 * ((max_atoms + 63) / 64);
   const int nmax = a.words * 32;
-  const int bd = 256;
+  // threads per molecule: a wave walks its targets one after the other (per target a chain of ballots and dependent
+  // look-ups), so more waves per molecule shorten the launch until the workgroups no longer fit the chip at once
+  // (1 x 100 conformers: 61 / 45 / 37 us with 256 / 512 / 1024 threads; 1024 molecules: 133 / 119 / 123)
+  const int bd = topo->num_graphs >= 512 ? 512 : 1024;
   const size_t smem = (size_t)(3 * nmax + 3 * nmax + 2 * nmax * a.words) * 4;
   if (smem > 48 * 1024) {
     static std::atomic<uint64_t> attr_done{0};

@@ -541,11 +541,11 @@ __device__ __forceinline__ void clip3(float& x, float& y, float& z, float limit)
 // (geometry.py:9-17), clip_norm, the Langevin move (dualenc.py:526-538), NaN flag, center_pos,
 // clamp, trajectory copy (dualenc.py:539-545).  P = a.parts lanes share one atom's edge lists (strided) and
 // combine their partial forces with xor-shuffles (P is a power of two <= 16, so the lanes of an atom sit in one wave).
-__global__ void __launch_bounds__(256) k_langevin_update(UpdateArgs a) {
+__global__ void __launch_bounds__(1024) k_langevin_update(UpdateArgs a) {
   const int g = blockIdx.x;
   const int g0 = a.graph_ptr[g], n = a.graph_ptr[g + 1] - g0;
-  __shared__ float red[3][4];
-  __shared__ int nanw[4];
+  __shared__ float red[3][16];
+  __shared__ int nanw[16];
   float sx = 0.f, sy = 0.f, sz = 0.f;
   int bad = 0;
   const int P = a.parts, part = threadIdx.x & (P - 1);
@@ -915,11 +915,15 @@ extern "C" int agdiff_langevin_update(const agdiff_topo_t* topo, const agdiff_ws
   a.e_len = ws->e_len;
   a.e_inv = ws->e_inv_global;
   a.nan_flag = ws->nan_flag;
-  // lanes per atom: as many as a 256-thread workgroup offers for the largest molecule of the batch, at most 16
-  int parts = 16;
-  while (parts > 1 && (int64_t)parts * topo->max_atoms_per_graph > 256) parts >>= 1;
+  // lanes per atom: 16 when a workgroup of up to 1024 threads offers that many for the largest molecule of the batch (the
+  // edge loops are chains of dependent loads: 16 lanes per atom instead of 4 for 46-atom molecules took the launch from
+  // 80 to 4x us), else as many as 1024 threads offer
+  const int bd_max = topo->num_graphs >= 512 ? 512 : 1024;      // many molecules: keep more workgroups resident
+  int bd = 256, parts = 16;
+  while (bd < bd_max && (int64_t)parts * topo->max_atoms_per_graph > bd) bd <<= 1;
+  while (parts > 1 && (int64_t)parts * topo->max_atoms_per_graph > bd) parts >>= 1;
   a.parts = parts;
-  k_langevin_update<<<dim3((unsigned)topo->num_graphs), dim3(256), 0, (hipStream_t)stream>>>(a);
+  k_langevin_update<<<dim3((unsigned)topo->num_graphs), dim3(bd), 0, (hipStream_t)stream>>>(a);
   AG_CHECK_LAUNCH();
   return AGDIFF_OK;
 }
