@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""Kernel timeline of ONE denoising step from a rocprofv3 --kernel-trace run of bench.py (start, duration, stream, kernel),
+plus the main stream's busy time and the gaps between its launches.
+   cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -- python3 $REPO/bench.py --steps 30 --warmup 5 \
+        --no-cpu-baseline --no-extra --no-traj;  python3 tools/step_timeline.py /tmp/kt"""
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
 rows = list(csv.DictReader(open(f)))
