@@ -704,7 +704,10 @@ __global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_pair_head(HeadArgs
   const int lane0 = ag_lane();
   const int E = *a.n_dev;
   const int64_t stride = (int64_t)gridDim.x * AG_PERSIST_WAVES;
-  for (int64_t tile = (int64_t)blockIdx.x * AG_PERSIST_WAVES + (threadIdx.x >> 6); tile < a.max_tiles; tile += stride) {
+  // (workgroups are dealt round-robin to the 8 XCDs: a contiguous tile range per XCD and round keeps a molecule's h rows,
+  // which all of its edges gather, in ONE L2)
+  const int64_t wg = (gridDim.x % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x;
+  for (int64_t tile = wg * AG_PERSIST_WAVES + (threadIdx.x >> 6); tile < a.max_tiles; tile += stride) {
     if (tile * AG_TW >= E) break;
     int lane = lane0;
     asm volatile("" : "+v"(lane));

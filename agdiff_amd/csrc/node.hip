@@ -413,7 +413,11 @@ struct GinArgs {
 // a SIMD.  Messages are added in list order (sources ascending), as before.
 __global__ void __launch_bounds__(256) k_gin_gather(GinArgs a) {
   const int lane = ag_lane(), half = lane >> 5, j = lane & 31;
-  const int64_t node = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 2 + half;
+  // Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8): give each XCD a contiguous range of nodes, so that a
+  // molecule's rows -- every attribute row is read by both of its end points, every h row by all neighbours -- are fetched
+  // into ONE L2
+  const int64_t wg = (gridDim.x % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x;
+  const int64_t node = (wg * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 2 + half;
   const bool valid = node < a.n;
   const int nd = valid ? (int)node : 0;
   const int lo = a.loc_in_ptr[nd], hi = valid ? a.loc_in_ptr[nd + 1] : lo;
@@ -876,7 +880,7 @@ extern "C" int agdiff_gin_encoder(const agdiff_params_t* p, const agdiff_topo_t*
     a.h_out = bufs[cur];
     a.n = topo->num_nodes;
     hipStream_t st = (hipStream_t)stream;
-    k_gin_gather<<<dim3((unsigned)((topo->num_nodes + 7) / 8)), dim3(256), 0, st>>>(a);
+    k_gin_gather<<<dim3((unsigned)((((topo->num_nodes + 7) / 8) + 7) / 8 * 8)), dim3(256), 0, st>>>(a);   // grid: multiple of 8 (XCD ranges)
     AG_CHECK_LAUNCH();
     if (p->precision == AG_BF3) {
       if (ldsw) k_gin_layer<AG_BF3, true><<<grid, block, smem, st>>>(a);
