@@ -68,8 +68,12 @@ ForkJoin& fork_join_for_current_device() {
 // `rows_from_global`: the global branch's encoder pass writes ws->l_attr_rows itself (the local edges are a subset of
 // the edge set it walks and dualenc.py:214-216 evaluates the SAME encoder on them), so the pass over the local list is
 // skipped and everything after it waits for `rows_ready`.
+// `split` (split CFConv): the encoder pass over the canonical local list also writes the operand-form attributes of the
+// local edges by in-slot (ws->l_attr_frag) and is followed by their CFConv scales (ws->l_scale); `split_ready` is recorded
+// once both are enqueued (agdiff_cfconv_local on the other stream waits for it).
 int local_branch(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, int flags,
-                 bool rows_from_global, hipEvent_t rows_ready, void* stream) {
+                 bool rows_from_global, hipEvent_t rows_ready, void* stream, bool split = false,
+                 hipEvent_t split_ready = nullptr) {
   const int64_t ltiles = (topo->num_local + AG_TW - 1) / AG_TW;
   const int64_t ctiles = (topo->num_local_canon + AG_TW - 1) / AG_TW;
   // caller-supplied lengths (forward(edge_length=...)) need not be symmetric: then every local edge is evaluated
@@ -78,13 +82,22 @@ int local_branch(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdi
   if (rows_from_global) {
     if (hipStreamWaitEvent((hipStream_t)stream, rows_ready, 0) != hipSuccess) return AGDIFF_ERR_LAUNCH;
   } else if (topo->num_local > 0) {
-    if (canon)        // one evaluation and one row per mirror pair of local edges
+    if (canon && split) {
+      if (agdiff_local_poly_enabled(p, topo, ws))     // the local CFConv takes its filters from polynomials: rows only
+        AG_TRY(agdiff_edge_encoder(p, ws->num_local_canon, ctiles, ws->lc_len, topo->lc_type, nullptr, ws->l_attr_rows, nullptr,
+                                   nullptr, nullptr, stream));
+      else                  // ... and the operand-form copy at the in-slots of the edge and of its mirror
+        AG_TRY(agdiff_edge_encoder(p, ws->num_local_canon, ctiles, ws->lc_len, topo->lc_type, ws->l_attr_frag, ws->l_attr_rows,
+                                   topo->loc_in_row, topo->lc_inpos, topo->lc_inmir, stream));
+      AG_TRY(agdiff_edge_scales_split(p, topo, ws, 1, stream));
+    } else if (canon)        // one evaluation and one row per mirror pair of local edges
       AG_TRY(agdiff_edge_encoder(p, ws->num_local_canon, ctiles, ws->lc_len, topo->lc_type, nullptr, ws->l_attr_rows, nullptr,
                                  nullptr, nullptr, stream));
     else
       AG_TRY(agdiff_edge_encoder(p, ws->num_local, ltiles, ws->l_len, topo->loc_type, nullptr, ws->l_attr_rows, nullptr,
                                  nullptr, nullptr, stream));
   }
+  if (split && split_ready && hipEventRecord(split_ready, (hipStream_t)stream) != hipSuccess) return AGDIFF_ERR_LAUNCH;
   AG_TRY(agdiff_gin_encoder(p, topo, ws, canon ? 1 : 0, stream));
   if (topo->num_local > 0) {
     if (canon)
@@ -133,6 +146,43 @@ int global_back(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdif
   }
   return AGDIFF_OK;
 }
+
+// Split CFConv (p->poly_kt > 0, graph built here): radius edges take their filters from d-polynomials, local edges go
+// through the filter MLPs on the static local list (include/agdiff_hip.h).
+// front: radius graph -> radius-edge scales (-> the encoder over all canonical edges when the full head will need edge_attr)
+int global_front_split(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, int flags,
+                       void* stream) {
+  const int64_t etiles = (topo->max_edges + AG_TW - 1) / AG_TW;
+  AG_TRY(agdiff_graph_build(topo, ws, pos, (flags & AGDIFF_FWD_NO_RADIUS) ? 0.0f : p->cutoff, stream));
+  AG_TRY(agdiff_edge_scales_split(p, topo, ws, 0, stream));
+  if (!(flags & AGDIFF_FWD_SAMPLER))
+    AG_TRY(agdiff_edge_encoder(p, ws->num_canon, etiles, ws->c_len, ws->c_type, ws->e_attr, nullptr, nullptr, ws->c_pos,
+                               ws->c_mir, stream));
+  return AGDIFF_OK;
+}
+// back: SchNet with split CFConvs -> global head.  `local_ready`: ws->l_attr_frag / ws->l_scale are complete (recorded on
+// the local branch's stream), or null when the local branch ran on this stream.
+int global_back_split(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int flags,
+                      hipEvent_t local_ready, void* stream) {
+  const int64_t etiles = (topo->max_edges + AG_TW - 1) / AG_TW;
+  AG_TRY(agdiff_schnet_node_stage_split(p, topo, ws, 0, 1, stream));
+  for (int k = 0; k < p->num_convs; ++k) {
+    AG_TRY(agdiff_cfconv_radius(p, topo, ws, k, stream));
+    if (k == 0 && local_ready && hipStreamWaitEvent((hipStream_t)stream, local_ready, 0) != hipSuccess) return AGDIFF_ERR_LAUNCH;
+    AG_TRY(agdiff_cfconv_local(p, topo, ws, k, stream));
+    AG_TRY(agdiff_schnet_node_stage_split(p, topo, ws, k + 1, 1, stream));
+  }
+  if (flags & AGDIFF_FWD_SAMPLER) {
+    // only the radius edges' outputs are used (dualenc.py:516-518): the head's edge_attr half from the d-polynomial, over
+    // the canonical list (a mirror pair of radius edges has one length and h_i * h_j is symmetric)
+    AG_TRY(agdiff_pair_head_poly(p, ws->num_canon, etiles, ws->c_src, ws->c_dst, ws->c_len, ws->h, ws->c_pos, ws->c_mir,
+                                 ws->e_inv_global, stream));
+  } else {
+    AG_TRY(agdiff_pair_head(&p->head_global, ws->num_canon, etiles, ws->c_src, ws->c_dst, ws->h, ws->e_attr, nullptr,
+                            ws->c_pos, ws->c_mir, ws->e_inv_global, stream));
+  }
+  return AGDIFF_OK;
+}
 }  // namespace
 
 extern "C" int agdiff_score_forward(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
@@ -150,6 +200,22 @@ extern "C" int agdiff_score_forward(const agdiff_params_t* p, const agdiff_topo_
   static const bool serial = getenv("AGDIFF_SERIAL_BRANCHES") != nullptr;
   ForkJoin& fj = fork_join_for_current_device();
   hipStream_t main = (hipStream_t)stream;
+  const bool split = p->poly_kt > 0 && !(flags & AGDIFF_FWD_GRAPH_GIVEN) && ws->rad_ptr != nullptr;
+  if (split) {
+    if (serial || !fj.ok) {
+      AG_TRY(global_front_split(p, topo, ws, pos, flags, stream));
+      AG_TRY(local_branch(p, topo, ws, pos, flags, false, nullptr, stream, true, nullptr));
+      return global_back_split(p, topo, ws, flags, nullptr, stream);
+    }
+    if (hipEventRecord(fj.fork, main) != hipSuccess || hipStreamWaitEvent(fj.side, fj.fork, 0) != hipSuccess)
+      return AGDIFF_ERR_LAUNCH;
+    AG_TRY(local_branch(p, topo, ws, pos, flags, false, nullptr, (void*)fj.side, true, fj.rows));
+    AG_TRY(global_front_split(p, topo, ws, pos, flags, stream));
+    if (hipEventRecord(fj.join, fj.side) != hipSuccess) return AGDIFF_ERR_LAUNCH;
+    AG_TRY(global_back_split(p, topo, ws, flags, topo->num_local > 0 ? fj.rows : nullptr, stream));
+    if (hipStreamWaitEvent(main, fj.join, 0) != hipSuccess) return AGDIFF_ERR_LAUNCH;
+    return AGDIFF_OK;
+  }
   if (serial || !fj.ok) {
     AG_TRY(global_front(p, topo, ws, pos, flags, share_rows, stream));
     if (share_rows && fj.ok && hipEventRecord(fj.rows, main) != hipSuccess) return AGDIFF_ERR_LAUNCH;
@@ -170,6 +236,6 @@ extern "C" int agdiff_score_forward(const agdiff_params_t* p, const agdiff_topo_
 extern "C" int agdiff_langevin_step(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
                                     const agdiff_step_args_t* a, void* stream) {
   if (!a) return AGDIFF_ERR_ARG;
-  AG_TRY(agdiff_score_forward(p, topo, ws, a->pos_in, a->use_global ? AGDIFF_FWD_GLOBAL : 0, stream));
+  AG_TRY(agdiff_score_forward(p, topo, ws, a->pos_in, (a->use_global ? AGDIFF_FWD_GLOBAL : 0) | AGDIFF_FWD_SAMPLER, stream));
   return agdiff_langevin_update(topo, ws, a, stream);
 }

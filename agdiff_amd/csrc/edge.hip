@@ -767,6 +767,410 @@ __global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_pair_head(HeadArgs
   }
 }
 
+// ------------------------------------------------------------------------------ radius-edge polynomials
+// Operand elements of the lane's edge for the NKT k-tiles of a d-polynomial (include/agdiff_hip.h: agdiff_params_t.poly_kt;
+// host mirror: agdiff_amd/packing.py poly_features): element j of quarter q in k-tile t is
+//   phi[8 (4 t + q) + j](x) = T_{8 (4 t + q)}(x) T_j(x),   x = 2 d / cutoff - 1 in [-1, 1].
+// T_0..T_8 by the three-term recurrence, T_16 .. T_56 from the product rule 2 T_a T_b = T_{a+b} + T_{|a-b|}: ~25 VALU
+// instructions + the operand split per k-tile, instead of a 128-wide MLP chain per edge.
+// `gmask` (1 or 0) multiplies every element: edges outside the group being evaluated contribute nothing.
+template <int MODE, int NKT>
+__device__ __forceinline__ void ag_poly_features(float d, float two_over_rc, int q, AgIn<MODE> (&o)[NKT], float gmask = 1.0f) {
+  static_assert(NKT >= 1 && NKT <= AGDIFF_POLY_MAX_KT, "poly_kt");
+  const float x = fminf(fmaxf(fmaf(d, two_over_rc, -1.0f), -1.0f), 1.0f);
+  const float x2 = x + x;
+  float T[9];
+  T[0] = 1.0f;
+  T[1] = x;
+#pragma unroll
+  for (int n = 2; n <= 8; ++n) T[n] = fmaf(x2, T[n - 1], -T[n - 2]);
+  const float t8 = T[8], t8x2 = t8 + t8;
+  const float g2 = fmaf(t8x2, t8, -1.0f);          // T16
+  const float g3 = fmaf(g2 + g2, t8, -t8);         // T24
+  float G[NKT];
+  G[0] = gmask * ((q == 0) ? 1.0f : (q == 1) ? t8 : (q == 2) ? g2 : g3);
+  if constexpr (NKT == 2) {
+    const float g4 = fmaf(g2 + g2, g2, -1.0f);     // T32
+    const float g5 = fmaf(g4 + g4, t8, -g3);       // T40
+    const float g6 = fmaf(g3 + g3, g3, -1.0f);     // T48
+    const float g7 = fmaf(g6 + g6, t8, -g5);       // T56
+    G[1] = gmask * ((q == 0) ? g4 : (q == 1) ? g5 : (q == 2) ? g6 : g7);
+  }
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) ag_cvt_pair(o[t], j, G[t] * T[j], G[t] * T[j + 1]);
+  }
+}
+
+// ------------------------------------------------------------------------------ CFConv over the radius edges
+struct RadConvArgs {
+  const float* poly_pk;  // pk [12][NKT]: filter polynomials of conv1 (channel tiles 0..7) and conv2 (8..11), bias included
+  const int32_t* n_dev;  // R
+  const int32_t* in_ptr; // rad_ptr [N+1]
+  const int32_t* e_src;
+  const int32_t* e_dst;
+  const float* e_len;
+  const float* scale1;   // [R] lw(d)*C(d) of conv1 of this block
+  const float* scale2;
+  const float* xs;       // [N][192]
+  float* agg;            // [N][192]
+  float* agg_first;      // [chunks][192]
+  int64_t max_chunks;
+  int32_t chunk_tiles;
+  float two_over_rc;
+  // TYPED (local edges): poly_pk holds num_slots coefficient sets, edge e uses set type_slot[e_type[e]]
+  const int32_t* e_type;
+  const int32_t* type_slot;
+  int32_t num_slots;
+};
+
+// encoder/schnet.py:136-162 for conv1 and conv2 of one InteractionBlock over the RADIUS edges only:
+//   W_e = nn(MLPEdgeEncoder(d_e, 0)) = P(d_e)  (a polynomial, see above);  agg[dst] += x[src] * W_e * (lw(d_e) C(d_e)).
+// Same tile walk, message and destination-segmented reduction as k_cfconv_fused (chunks of consecutive 16-edge tiles per
+// wave, running sums in registers, agg_first for lists that span chunks: no atomics, fixed order), but the filter is
+// NKT x 12 x 3 MFMAs per tile instead of 264 and needs no edge_attr stream: what is left is the x[src] gathers and the
+// reduction, so the kernel runs 16 waves per CU next to 24 NKT KiB of coefficients in LDS.
+// TYPED: the same over the LOCAL list, whose edges carry a type each (bond / 2-hop / 3-hop): a tile's edges are grouped
+// by type on the fly (wave-uniform loop over the types present, typically three) and every group adds its masked
+// features times its own coefficient set (all sets resident in LDS) to the tile's filter values before the reduction.
+// Lengths beyond the cutoff are clamped into the fitted range: their CFConv scale is exactly 0 (schnet.py:140-146).
+template <int MODE, int NKT, int WAVES, bool TYPED>
+__global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_radius(RadConvArgs a) {
+  extern __shared__ u32x4 ag_rad_smem[];
+  lds_u32x4* wl = (lds_u32x4*)ag_rad_smem;
+  {
+    const u32x4* g = reinterpret_cast<const u32x4*>(a.poly_pk);
+    const int nset = TYPED ? a.num_slots : 1;
+    for (int i = threadIdx.x; i < nset * AG_CONV_NCH * NKT * 128; i += blockDim.x) wl[i] = g[i];
+  }
+  __syncthreads();
+  const int lane0 = ag_lane();
+  const int wave = threadIdx.x >> 6;
+  const int E = *a.n_dev;
+  const int64_t cstride = (int64_t)gridDim.x * WAVES;
+  const int wg = (gridDim.x % 8 == 0) ? (int)((blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8) : (int)blockIdx.x;
+
+  int pf_src = 0, pf_t0 = 0, pf_t1 = 0, pf_slot = -1;
+  float pf_s1 = 0.0f, pf_s2 = 0.0f, pf_d = 0.0f;
+  auto prefetch_meta = [&](int64_t tl, int ln) {
+    const int64_t tb = tl * AG_TW, e = tb + (ln & 15);
+    const bool valid = e < E;
+    if constexpr (TYPED) pf_slot = valid ? a.type_slot[a.e_type[e]] : -1;
+    pf_src = valid ? a.e_src[e] : 0;
+    pf_s1 = valid ? a.scale1[e] : 0.0f;
+    pf_s2 = valid ? a.scale2[e] : 0.0f;
+    pf_d = valid ? a.e_len[e] : 0.0f;
+    const int64_t last = (tb + AG_TW - 1 < E) ? tb + AG_TW - 1 : (int64_t)E - 1;
+    pf_t0 = a.e_dst[tb];
+    pf_t1 = a.e_dst[last];
+  };
+  {
+    const int64_t first = ((int64_t)wg * WAVES + wave) * a.chunk_tiles;
+    if (first * AG_TW < E) prefetch_meta(first, lane0);
+  }
+  for (int64_t chunk = (int64_t)wg * WAVES + wave; chunk < a.max_chunks; chunk += cstride) {
+    const int64_t e_begin = chunk * (AG_TW * a.chunk_tiles);
+    if (e_begin >= E) break;
+    int run_t = -1;
+    float carry[AG_CONV_NCH / 4];      // as k_cfconv_fused: entry g of lane (col, q) = channel 16 (4 g + q) + col
+#pragma unroll
+    for (int i = 0; i < AG_CONV_NCH / 4; ++i) carry[i] = 0.0f;
+    auto dest = [&](int t) -> float* {
+      const int lo = a.in_ptr[t];
+      return (lo >= e_begin) ? (a.agg + (size_t)t * 192) : (a.agg_first + (size_t)chunk * 192);
+    };
+    for (int tt = 0; tt < a.chunk_tiles; ++tt) {
+      const int64_t tile = chunk * a.chunk_tiles + tt;
+      const int64_t tbase = tile * AG_TW;
+      if (tbase >= E) break;
+      int lane = lane0;
+      asm volatile("" : "+v"(lane));
+      const int q = lane >> 4, col = lane & 15;
+      const int my_src = pf_src;
+      const float s1 = pf_s1, s2 = pf_s2, d = pf_d;
+      const int t0 = __builtin_amdgcn_readfirstlane(pf_t0);
+      const int t1 = __builtin_amdgcn_readfirstlane(pf_t1);
+      if (run_t >= 0 && run_t != t0) {   // previous tile ended exactly on a list boundary
+        float* dp = dest(run_t);
+#pragma unroll
+        for (int i = 0; i < AG_CONV_NCH / 4; ++i) {
+          dp[16 * (4 * i + q) + col] = carry[i];
+          carry[i] = 0.0f;
+        }
+        run_t = -1;
+      }
+      uint32_t xoff[4];
+      f32x4 sr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        xoff[r] = ((uint32_t)__shfl(my_src, 4 * q + r) * 192u + (uint32_t)col) * 4u;
+        sr[r] = __shfl(s1, 4 * q + r);
+      }
+      const int ntg = t1 - t0 + 1;
+      const int ipl = a.in_ptr[t0 + (lane <= ntg ? lane : ntg)];
+      auto bound = [&](int i) -> int {
+        return (i < 64) ? __builtin_amdgcn_readlane(ipl, i) : __builtin_amdgcn_readfirstlane(a.in_ptr[t0 + i]);
+      };
+      auto dest_lo = [&](int t, int lo) -> float* {
+        return (lo >= e_begin) ? (a.agg + (size_t)t * 192) : (a.agg_first + (size_t)chunk * 192);
+      };
+      constexpr int XA = 2, XR = XA + 1;         // x[src] values requested XA channel tiles ahead
+      f32x4 xring[XR];
+      auto fetch_x = [&](int nt) {
+        const char* xb = reinterpret_cast<const char*>(a.xs);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xring[nt % XR][r] = *reinterpret_cast<const float*>(xb + (size_t)xoff[r] + 64 * nt);
+      };
+#pragma unroll
+      for (int nt = 0; nt < XA; ++nt) fetch_x(nt);
+      AgIn<MODE> ph[NKT];
+      [[maybe_unused]] f32x4 zall[TYPED ? AG_CONV_NCH : 1];
+      if constexpr (!TYPED) {
+        ag_poly_features<MODE, NKT>(d, a.two_over_rc, q, ph);
+      } else {
+        const int my_slot = pf_slot;
+#pragma unroll
+        for (int nt = 0; nt < AG_CONV_NCH; ++nt) zall[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const lds_u32x4* wl_t = ag_lds_base(wl, lane);
+        uint64_t todo = __ballot(my_slot >= 0) & 0xFFFFull;      // one lane per edge column (the quarters hold copies)
+        while (todo) {
+          const int g = __builtin_amdgcn_readlane(my_slot, (int)__builtin_ctzll(todo));
+          const bool in = my_slot == g;
+          todo &= ~__ballot(in);
+          ag_poly_features<MODE, NKT>(d, a.two_over_rc, q, ph, in ? 1.0f : 0.0f);
+          const lds_u32x4* wg_ = wl_t + (size_t)g * (AG_CONV_NCH * NKT * 128);
+#pragma unroll
+          for (int nt = 0; nt < AG_CONV_NCH; ++nt) {
+#pragma unroll
+            for (int t = 0; t < NKT; ++t) {
+              u32x4 w[2];
+              w[0] = wg_[((nt * NKT + t) * 2) * 64];
+              w[1] = wg_[((nt * NKT + t) * 2 + 1) * 64];
+              ag_block_mma<MODE, true>(zall[nt], ph[t], w);
+            }
+          }
+        }
+      }
+      {   // the wave's next tile: per-edge scalars and end targets
+        int64_t nxt = tile + 1;
+        if (tt + 1 >= a.chunk_tiles) nxt = (chunk + cstride) * a.chunk_tiles;
+        if (nxt * AG_TW < E && nxt < a.max_chunks * a.chunk_tiles) prefetch_meta(nxt, lane);
+      }
+      f32x4 m0, m1;
+      {
+        const int b0 = bound(0), b1 = bound(1), b2 = bound(ntg >= 2 ? 2 : 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int er = (int)tbase + 4 * q + r;
+          m0[r] = (er >= b0 && er < b1) ? 1.0f : 0.0f;
+          m1[r] = (ntg >= 2 && er >= b1 && er < b2) ? 1.0f : 0.0f;
+        }
+      }
+      float* const dp0 = dest_lo(t0, bound(0));
+      const bool fast = ntg <= 2;
+      const bool two = ntg == 2;
+      auto reduce_general = [&](f32x4 z, int nt, float& cr) {
+        const bool mine = q == (nt & 3);
+        float newcarry = 0.0f;
+        for (int i = 0; i < ntg; ++i) {
+          const int lo = bound(i), hi = bound(i + 1);
+          float p = 0.0f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int er = (int)tbase + 4 * q + r;
+            p += ((er >= lo) && (er < hi)) ? z[r] : 0.0f;
+          }
+          p = ag_quarter_sum(p);
+          if (i == 0) p = cr + p;
+          if (i < ntg - 1) {
+            float* dp = dest_lo(t0 + i, lo);
+            if (mine) dp[16 * nt + col] = p;
+          } else {
+            newcarry = p;
+          }
+        }
+        cr = mine ? newcarry : cr;
+      };
+      // coefficient blocks (pk [12][NKT]: block nt * NKT + t) from LDS, one channel tile ahead
+      const lds_u32x4* wl_l = ag_lds_base(wl, lane);
+      u32x4 wq[2][NKT][2];
+      auto fetch_w = [&](int nt) {
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) {
+          wq[nt & 1][t][0] = wl_l[((nt * NKT + t) * 2) * 64];
+          wq[nt & 1][t][1] = wl_l[((nt * NKT + t) * 2 + 1) * 64];
+        }
+      };
+      if constexpr (!TYPED) fetch_w(0);
+      auto filter = [&](int nt) -> f32x4 {      // flipped: rows = edges, lanes = channels
+        if constexpr (TYPED) return zall[nt];
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        if (nt + 1 < AG_CONV_NCH) fetch_w(nt + 1);
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) ag_block_mma<MODE, true>(z, ph[t], wq[nt & 1][t]);
+        return z;
+      };
+      auto factors = [&](int nt, f32x4& m, bool with_scale) {
+        if (nt == 8) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sr[r] = __shfl(s2, 4 * q + r);
+        }
+        m = with_scale ? sr * xring[nt % XR] : xring[nt % XR];
+        if (nt + XA < AG_CONV_NCH) fetch_x(nt + XA);
+      };
+      auto run_fast = [&](auto TWO) {
+        constexpr bool kTwo = decltype(TWO)::value;
+        f32x4 zp = {0.f, 0.f, 0.f, 0.f}, mp = {0.f, 0.f, 0.f, 0.f};
+        float p0[4], p1[4] = {0.f, 0.f, 0.f, 0.f};
+        f32x4 w0 = m0 * sr, w1 = m1 * sr;          // conv1's scale folded into the row masks
+#pragma unroll
+        for (int nt = 0; nt <= AG_CONV_NCH; ++nt) {
+          f32x4 z = {0.f, 0.f, 0.f, 0.f}, m = {0.f, 0.f, 0.f, 0.f};
+          if (nt < AG_CONV_NCH) {
+            z = filter(nt);
+            factors(nt, m, false);
+          }
+          if (nt == 9) { w0 = m0 * sr; w1 = m1 * sr; }   // tile 8 (reduced in this step) starts conv2: sr is its scale now
+          if (nt > 0) {
+            const int j = (nt - 1) & 3, g4 = (nt - 1) >> 2;
+            f32x4 t;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r] = zp[r] * mp[r];
+            p0[j] = t[0] * w0[0];
+#pragma unroll
+            for (int r = 1; r < 4; ++r) p0[j] = fmaf(t[r], w0[r], p0[j]);
+            if constexpr (kTwo) {
+              p1[j] = t[0] * w1[0];
+#pragma unroll
+              for (int r = 1; r < 4; ++r) p1[j] = fmaf(t[r], w1[r], p1[j]);
+            }
+            if (j == 3) {      // quarter q ends up with the sums of channel tile 4 g4 + q
+              const float r0 = carry[g4] + ag_quarter_reduce_scatter4(p0[0], p0[1], p0[2], p0[3]);
+              if constexpr (kTwo) {
+                dp0[16 * (4 * g4 + q) + col] = r0;
+                carry[g4] = ag_quarter_reduce_scatter4(p1[0], p1[1], p1[2], p1[3]);
+              } else {
+                carry[g4] = r0;
+              }
+            }
+          }
+          zp = z; mp = m;
+        }
+      };
+      if (fast) {
+        if (two) run_fast(std::true_type{});
+        else run_fast(std::false_type{});
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < AG_CONV_NCH; ++nt) {
+          f32x4 z = filter(nt), m;
+          factors(nt, m, true);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) z[r] = z[r] * m[r];
+          reduce_general(z, nt, carry[nt >> 2]);
+        }
+      }
+      run_t = t1;
+    }
+    if (run_t >= 0) {
+      float* dp = dest(run_t);
+#pragma unroll
+      for (int i = 0; i < AG_CONV_NCH / 4; ++i) dp[16 * (4 * i + (lane0 >> 4)) + (lane0 & 15)] = carry[i];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ pair head, edge_attr half by polynomial
+struct HeadPolyArgs {
+  agdiff_head_params_t hp;
+  const int32_t* n_dev;
+  const int32_t* src;
+  const int32_t* dst;
+  const float* len;
+  const float* node_h;
+  const int32_t* pos_index;   // optional (with mir_index): results go to out[pos_index[e]] and, when >= 0, out[mir_index[e]]
+  const int32_t* mir_index;
+  float* out;
+  int64_t max_tiles;
+  float two_over_rc;
+};
+
+// k_pair_head for edges whose edge_attr is MLPEdgeEncoder(d, type 0): the edge_attr half of the first layer,
+// layers.0.weight[:, 128:] @ edge_attr, is the polynomial hp.attr_poly_pk of d (NKT k-tiles instead of four, and no
+// edge_attr to read).  Entries of another type get a finite but meaningless result: the denoising loop multiplies them
+// by 1 - local_edge_mask = 0 (dualenc.py:516-518) and the update kernel never reads them.
+template <int MODE, int NKT>
+__global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_pair_head_poly(HeadPolyArgs a) {
+  extern __shared__ u32x4 ag_headp_smem[];
+  lds_u32x4* lw1 = (lds_u32x4*)ag_headp_smem;     // k-tiles 0..3 of pkk [8][8] (h_src * h_dst half) = 32 blocks
+  lds_u32x4* lwp = lw1 + 32 * 128;                // pkk [NKT][8]
+  lds_u32x4* lw2 = lwp + 8 * NKT * 128;           // pk  [4][4] = 16 blocks
+  {
+    const u32x4* g1 = reinterpret_cast<const u32x4*>(a.hp.w1_pk);
+    const u32x4* gp = reinterpret_cast<const u32x4*>(a.hp.attr_poly_pk);
+    const u32x4* g2 = reinterpret_cast<const u32x4*>(a.hp.w2_pk);
+    for (int i = threadIdx.x; i < 32 * 128; i += blockDim.x) lw1[i] = g1[i];
+    for (int i = threadIdx.x; i < 8 * NKT * 128; i += blockDim.x) lwp[i] = gp[i];
+    for (int i = threadIdx.x; i < 16 * 128; i += blockDim.x) lw2[i] = g2[i];
+  }
+  __syncthreads();
+  const int lane0 = ag_lane();
+  const int E = *a.n_dev;
+  const int64_t stride = (int64_t)gridDim.x * AG_PERSIST_WAVES;
+  const int64_t wg = (gridDim.x % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x;
+  for (int64_t tile = wg * AG_PERSIST_WAVES + (threadIdx.x >> 6); tile < a.max_tiles; tile += stride) {
+    if (tile * AG_TW >= E) break;
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int q = lane >> 4;
+    const int64_t e = tile * AG_TW + (lane & 15);
+    const bool valid = e < E;
+    const int s = valid ? a.src[e] : 0, t = valid ? a.dst[e] : 0;
+    const float d = valid ? a.len[e] : 0.0f;
+    const int64_t pe = a.pos_index ? (valid ? (int64_t)a.pos_index[e] : 0) : e;
+    const int64_t pm = (a.pos_index && valid) ? (int64_t)a.mir_index[e] : -1;
+
+    f32x4 y1[8];
+    ag_init_vec<8>(y1, a.hp.b1, q);
+    {
+      const float* hs = a.node_h + (size_t)s * 128;
+      const float* ht = a.node_h + (size_t)t * 128;
+      AgIn<MODE> sl[2];
+      auto load_slice = [&](AgIn<MODE>& dst, int k) {
+        const f32x4 p0 = ag_ld4(hs + 32 * k + 4 * q) * ag_ld4(ht + 32 * k + 4 * q);
+        const f32x4 p1 = ag_ld4(hs + 32 * k + 16 + 4 * q) * ag_ld4(ht + 32 * k + 16 + 4 * q);
+        ag_cvt(p0, p1, dst);
+      };
+      load_slice(sl[0], 0);
+      const lds_u32x4* lw1_l = ag_lds_base(lw1, lane);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (k + 1 < 4) load_slice(sl[(k + 1) & 1], k + 1);
+        if (k & 1) ag_dense_lds<MODE, false, true, 1, 8, 1, 0>(sl, y1, lw1_l + (k * 8) * 128, 0);
+        else ag_dense_lds<MODE, false, true, 1, 8, 0, 0>(sl, y1, lw1_l + (k * 8) * 128, 0);
+      }
+      AgIn<MODE> ph[NKT];
+      ag_poly_features<MODE, NKT>(d, a.two_over_rc, q, ph);
+      ag_dense_lds<MODE, false, true, NKT, 8, 0, 0>(ph, y1, ag_lds_base(lwp, lane), 0);
+    }
+    AG_FOR_TILE(y1, 8, ag_relu(v));
+    f32x4 y2[4];
+    ag_init_vec<4>(y2, a.hp.b2, q);
+    {
+      AgIn<MODE> y1b[4];
+      ag_cvt_tiles<MODE, 4, 0>(y1, y1b);
+      ag_dense_lds<MODE, false, false, 4, 4, 0, 0>(y1b, y2, ag_lds_base(lw2, lane), 0);
+    }
+    AG_FOR_TILE(y2, 4, ag_relu(v));
+    const float o = ag_dot_vec<4>(y2, a.hp.w3, q) + a.hp.b3;
+    if (valid && q == 0) {
+      a.out[pe] = o;
+      if (pm >= 0) a.out[pm] = o;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------ stand-alone aggregate
 // out[i][:] = sum_{e in in-list of i} x[src[e]][:] * W[e][:]   (PyG propagate, schnet.py:156,161-162).
 // One wave per target node: F/4 lanes cover one edge row with 16-byte loads, so a wave streams
@@ -845,53 +1249,80 @@ extern "C" int agdiff_edge_encoder(const agdiff_params_t* p, const int32_t* n_ed
   return AGDIFF_OK;
 }
 
-extern "C" int agdiff_edge_scales(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
-                                  int32_t per_canonical_edge, void* stream) {
-  if (!p || !topo || !ws || !ws->e_scale || !ws->e_len || !ws->num_edges || p->num_convs > AGDIFF_MAX_CONVS)
-    return AGDIFF_ERR_ARG;
-  if (per_canonical_edge && (!ws->num_canon || !ws->c_len || !ws->c_pos || !ws->c_mir)) return AGDIFF_ERR_ARG;
-  if (topo->max_edges == 0) return AGDIFF_OK;
+namespace {
+int launch_edge_scales(const agdiff_params_t* p, const int32_t* n_dev, int64_t max_n, const float* e_len,
+                       const int32_t* pos_index, const int32_t* mir_index, float* out, int64_t epad, void* stream) {
+  if (max_n == 0) return AGDIFF_OK;
   ScaleArgs a;
   for (int k = 0; k < p->num_convs; ++k) {
     a.dw[2 * k] = p->conv[k].dist_w;
     a.dw[2 * k + 1] = p->conv[k].dist_w + 97;
   }
-  a.n_dev = per_canonical_edge ? ws->num_canon : ws->num_edges;
-  a.e_len = per_canonical_edge ? ws->c_len : ws->e_len;
-  a.pos_index = per_canonical_edge ? ws->c_pos : nullptr;
-  a.mir_index = per_canonical_edge ? ws->c_mir : nullptr;
-  a.out = ws->e_scale;
-  a.epad = ((topo->max_edges + AG_TW - 1) / AG_TW) * AG_TW;
+  a.n_dev = n_dev;
+  a.e_len = e_len;
+  a.pos_index = pos_index;
+  a.mir_index = mir_index;
+  a.out = out;
+  a.epad = epad;
   a.n = 2 * p->num_convs;
   a.cutoff = p->cutoff;
   a.smooth = p->smooth;
-  k_edge_scales<<<dim3((unsigned)((topo->max_edges + 255) / 256), (unsigned)a.n), dim3(256), 0, (hipStream_t)stream>>>(a);
+  k_edge_scales<<<dim3((unsigned)((max_n + 255) / 256), (unsigned)a.n), dim3(256), 0, (hipStream_t)stream>>>(a);
   AG_CHECK_LAUNCH();
   return AGDIFF_OK;
 }
+}  // namespace
 
-extern "C" int agdiff_cfconv_fused(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k,
-                                   void* stream) {
-  if (!p || !topo || !ws || k < 0 || k >= p->num_convs) return AGDIFF_ERR_ARG;
-  const int64_t max_tiles = (topo->max_edges + AG_TW - 1) / AG_TW;
-  const int chunk_tiles = agdiff_conv_chunk_tiles(topo->max_edges);
+extern "C" int agdiff_edge_scales(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
+                                  int32_t per_canonical_edge, void* stream) {
+  if (!p || !topo || !ws || !ws->e_scale || !ws->e_len || !ws->num_edges || p->num_convs > AGDIFF_MAX_CONVS)
+    return AGDIFF_ERR_ARG;
+  if (per_canonical_edge && (!ws->num_canon || !ws->c_len || !ws->c_pos || !ws->c_mir)) return AGDIFF_ERR_ARG;
+  const int64_t epad = ((topo->max_edges + AG_TW - 1) / AG_TW) * AG_TW;
+  return launch_edge_scales(p, per_canonical_edge ? ws->num_canon : ws->num_edges, topo->max_edges,
+                            per_canonical_edge ? ws->c_len : ws->e_len, per_canonical_edge ? ws->c_pos : nullptr,
+                            per_canonical_edge ? ws->c_mir : nullptr, ws->e_scale, epad, stream);
+}
+
+extern "C" int agdiff_edge_scales_split(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
+                                        int32_t which, void* stream) {
+  if (!p || !topo || !ws || p->num_convs > AGDIFF_MAX_CONVS) return AGDIFF_ERR_ARG;
+  if (which == 0) {        // radius list
+    if (!ws->r_scale || !ws->rad_len || !ws->num_rad) return AGDIFF_ERR_ARG;
+    const int64_t R = topo->max_edges - topo->num_local;
+    return launch_edge_scales(p, ws->num_rad, R, ws->rad_len, nullptr, nullptr, ws->r_scale, ((R + AG_TW - 1) / AG_TW) * AG_TW,
+                              stream);
+  }
+  // local list by in-slot: one evaluation per canonical local edge (a mirror pair has one length)
+  if (!ws->l_scale || !ws->lc_len || !ws->num_local_canon || !topo->lc_inpos || !topo->lc_inmir) return AGDIFF_ERR_ARG;
+  return launch_edge_scales(p, ws->num_local_canon, topo->num_local_canon, ws->lc_len, topo->lc_inpos, topo->lc_inmir,
+                            ws->l_scale, ((topo->num_local + AG_TW - 1) / AG_TW) * AG_TW, stream);
+}
+
+namespace {
+// k_cfconv_fused over a destination-sorted edge list of `max_e` slots (live count *n_dev)
+int launch_cfconv_fused(const agdiff_params_t* p, int32_t k, int64_t max_e, const int32_t* n_dev, const int32_t* in_ptr,
+                        const int32_t* e_src, const int32_t* e_dst, const float* scales, const float* e_attr, const float* xs,
+                        float* agg, float* agg_first, void* stream) {
+  const int64_t max_tiles = (max_e + AG_TW - 1) / AG_TW;
+  const int chunk_tiles = agdiff_conv_chunk_tiles(max_e);
   const int64_t max_chunks = (max_tiles + chunk_tiles - 1) / chunk_tiles;
   if (max_chunks == 0) return AGDIFF_OK;
   ConvArgs a;
   a.cp = p->conv[k];
-  a.n_dev = ws->num_edges;
-  a.in_ptr = ws->in_ptr;
-  a.e_src = ws->e_src;
-  a.e_dst = ws->e_dst;
+  a.n_dev = n_dev;
+  a.in_ptr = in_ptr;
+  a.e_src = e_src;
+  a.e_dst = e_dst;
   {
     const size_t epad = (size_t)max_tiles * AG_TW;
-    a.scale1 = ws->e_scale + (size_t)(2 * k) * epad;
-    a.scale2 = ws->e_scale + (size_t)(2 * k + 1) * epad;
+    a.scale1 = scales + (size_t)(2 * k) * epad;
+    a.scale2 = scales + (size_t)(2 * k + 1) * epad;
   }
-  a.e_attr = ws->e_attr;
-  a.xs = ws->xs;
-  a.agg = ws->agg;
-  a.agg_first = ws->agg_first;
+  a.e_attr = e_attr;
+  a.xs = xs;
+  a.agg = agg;
+  a.agg_first = agg_first;
   a.max_chunks = max_chunks;
   a.chunk_tiles = chunk_tiles;
   a.ablate = 0;
@@ -915,6 +1346,162 @@ extern "C" int agdiff_cfconv_fused(const agdiff_params_t* p, const agdiff_topo_t
     k_cfconv_fused<AG_BF3><<<dim3((unsigned)wgs), dim3(64 * AG_CONV_WAVES), smem, (hipStream_t)stream>>>(a);
   else
     k_cfconv_fused<AG_F32><<<dim3((unsigned)wgs), dim3(64 * AG_CONV_WAVES), smem, (hipStream_t)stream>>>(a);
+  AG_CHECK_LAUNCH();
+  return AGDIFF_OK;
+}
+
+#ifndef AG_RAD_WAVES
+#define AG_RAD_WAVES 16
+#endif
+template <int MODE, int NKT>
+int launch_cfconv_radius_t(const RadConvArgs& a, int64_t wgs, void* stream) {
+  const size_t smem = (size_t)AG_CONV_NCH * NKT * 2048;
+  k_cfconv_radius<MODE, NKT, AG_RAD_WAVES, false><<<dim3((unsigned)wgs), dim3(64 * AG_RAD_WAVES), smem, (hipStream_t)stream>>>(a);
+  AG_CHECK_LAUNCH();
+  return AGDIFF_OK;
+}
+#ifndef AG_LOCP_WAVES
+#define AG_LOCP_WAVES 16
+#endif
+template <int MODE>
+int launch_cfconv_local_poly_t(const RadConvArgs& a, int64_t wgs, void* stream) {
+  const size_t smem = (size_t)a.num_slots * AG_CONV_NCH * 2048;
+  static std::atomic<uint64_t> attr_done{0};
+  if (!ag_allow_big_lds(attr_done, (size_t)AGDIFF_POLY_MAX_SLOTS * AG_CONV_NCH * 2048, k_cfconv_radius<MODE, 1, AG_LOCP_WAVES, true>))
+    return AGDIFF_ERR_LAUNCH;
+  k_cfconv_radius<MODE, 1, AG_LOCP_WAVES, true><<<dim3((unsigned)wgs), dim3(64 * AG_LOCP_WAVES), smem, (hipStream_t)stream>>>(a);
+  AG_CHECK_LAUNCH();
+  return AGDIFF_OK;
+}
+}  // namespace
+
+extern "C" int agdiff_cfconv_fused(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k,
+                                   void* stream) {
+  if (!p || !topo || !ws || k < 0 || k >= p->num_convs) return AGDIFF_ERR_ARG;
+  return launch_cfconv_fused(p, k, topo->max_edges, ws->num_edges, ws->in_ptr, ws->e_src, ws->e_dst, ws->e_scale, ws->e_attr,
+                             ws->xs, ws->agg, ws->agg_first, stream);
+}
+
+// Local edges by per-type filter polynomials?  (all of: slots built by the host, one k-tile, the per-slot inputs present)
+extern "C" int agdiff_local_poly_enabled(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws) {
+  static const bool off = getenv("AGDIFF_LOCAL_POLY_OFF") != nullptr;      // A/B runs
+  return !off && p && topo && ws && p->poly_kt == 1 && p->poly_num_slots > 0 && p->poly_num_slots <= AGDIFF_POLY_MAX_SLOTS &&
+         p->poly_type_slot && topo->loc_in_type && ws->l_len_in;
+}
+
+extern "C" int agdiff_cfconv_local(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k,
+                                   void* stream) {
+  if (!p || !topo || !ws || k < 0 || k >= p->num_convs) return AGDIFF_ERR_ARG;
+  if (topo->num_local == 0) return AGDIFF_OK;
+  if (!topo->loc_in_ptr || !topo->loc_in_src || !topo->loc_in_dst || !ws->l_scale || !ws->l_attr_frag || !ws->agg_loc ||
+      !ws->agg_first_loc || !ws->num_local)
+    return AGDIFF_ERR_ARG;
+  if (agdiff_local_poly_enabled(p, topo, ws)) {
+    // every local type of this batch has a filter polynomial: the radius kernel's typed variant on the local list
+    const int64_t max_tiles = (topo->num_local + AG_TW - 1) / AG_TW;
+    const int chunk_tiles = agdiff_conv_chunk_tiles(topo->num_local);
+    const int64_t max_chunks = (max_tiles + chunk_tiles - 1) / chunk_tiles;
+    RadConvArgs a;
+    a.poly_pk = p->conv[k].filt_poly_typed_pk;
+    a.n_dev = ws->num_local;
+    a.in_ptr = topo->loc_in_ptr;
+    a.e_src = topo->loc_in_src;
+    a.e_dst = topo->loc_in_dst;
+    a.e_len = ws->l_len_in;
+    const size_t epad = (size_t)max_tiles * AG_TW;
+    a.scale1 = ws->l_scale + (size_t)(2 * k) * epad;
+    a.scale2 = ws->l_scale + (size_t)(2 * k + 1) * epad;
+    a.xs = ws->xs;
+    a.agg = ws->agg_loc;
+    a.agg_first = ws->agg_first_loc;
+    a.max_chunks = max_chunks;
+    a.chunk_tiles = chunk_tiles;
+    a.two_over_rc = 2.0f / p->cutoff;
+    a.e_type = topo->loc_in_type;
+    a.type_slot = p->poly_type_slot;
+    a.num_slots = p->poly_num_slots;
+    int64_t wgs = (max_chunks + AG_LOCP_WAVES - 1) / AG_LOCP_WAVES;
+    if (wgs > 256) wgs = 256;
+    return p->precision == AG_BF3 ? launch_cfconv_local_poly_t<AG_BF3>(a, wgs, stream)
+                                  : launch_cfconv_local_poly_t<AG_F32>(a, wgs, stream);
+  }
+  return launch_cfconv_fused(p, k, topo->num_local, ws->num_local, topo->loc_in_ptr, topo->loc_in_src, topo->loc_in_dst,
+                             ws->l_scale, ws->l_attr_frag, ws->xs, ws->agg_loc, ws->agg_first_loc, stream);
+}
+
+extern "C" int agdiff_cfconv_radius(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k,
+                                    void* stream) {
+  if (!p || !topo || !ws || k < 0 || k >= p->num_convs) return AGDIFF_ERR_ARG;
+  if (p->poly_kt < 1 || p->poly_kt > AGDIFF_POLY_MAX_KT || !p->conv[k].filt_poly_pk) return AGDIFF_ERR_ARG;
+  if (!ws->num_rad || !ws->rad_ptr || !ws->rad_src || !ws->rad_dst || !ws->rad_len || !ws->r_scale) return AGDIFF_ERR_ARG;
+  const int64_t R = topo->max_edges - topo->num_local;
+  const int64_t max_tiles = (R + AG_TW - 1) / AG_TW;
+  const int chunk_tiles = agdiff_conv_chunk_tiles(R);
+  const int64_t max_chunks = (max_tiles + chunk_tiles - 1) / chunk_tiles;
+  if (max_chunks == 0) return AGDIFF_OK;
+  RadConvArgs a;
+  a.poly_pk = p->conv[k].filt_poly_pk;
+  a.n_dev = ws->num_rad;
+  a.in_ptr = ws->rad_ptr;
+  a.e_src = ws->rad_src;
+  a.e_dst = ws->rad_dst;
+  a.e_len = ws->rad_len;
+  {
+    const size_t epad = (size_t)max_tiles * AG_TW;
+    a.scale1 = ws->r_scale + (size_t)(2 * k) * epad;
+    a.scale2 = ws->r_scale + (size_t)(2 * k + 1) * epad;
+  }
+  a.xs = ws->xs;
+  a.agg = ws->agg;
+  a.agg_first = ws->agg_first;
+  a.max_chunks = max_chunks;
+  a.chunk_tiles = chunk_tiles;
+  a.two_over_rc = 2.0f / p->cutoff;
+  a.e_type = nullptr;
+  a.type_slot = nullptr;
+  a.num_slots = 0;
+  int64_t wgs = (max_chunks + AG_RAD_WAVES - 1) / AG_RAD_WAVES;
+  if (wgs > 256) wgs = 256;
+  if (p->precision == AG_BF3)
+    return p->poly_kt == 1 ? launch_cfconv_radius_t<AG_BF3, 1>(a, wgs, stream) : launch_cfconv_radius_t<AG_BF3, 2>(a, wgs, stream);
+  return p->poly_kt == 1 ? launch_cfconv_radius_t<AG_F32, 1>(a, wgs, stream) : launch_cfconv_radius_t<AG_F32, 2>(a, wgs, stream);
+}
+
+extern "C" int agdiff_pair_head_poly(const agdiff_params_t* p, const int32_t* n_edges_dev, int64_t max_tiles,
+                                     const int32_t* src, const int32_t* dst, const float* len, const float* node_h,
+                                     const int32_t* pos_index, const int32_t* mir_index, float* out, void* stream) {
+  if (!p || !n_edges_dev || !src || !dst || !len || !node_h || !out || max_tiles < 0 || (!pos_index != !mir_index))
+    return AGDIFF_ERR_ARG;
+  if (p->poly_kt < 1 || p->poly_kt > AGDIFF_POLY_MAX_KT || !p->head_global.attr_poly_pk) return AGDIFF_ERR_ARG;
+  if (max_tiles == 0) return AGDIFF_OK;
+  HeadPolyArgs a;
+  a.hp = p->head_global;
+  a.n_dev = n_edges_dev;
+  a.src = src;
+  a.dst = dst;
+  a.len = len;
+  a.node_h = node_h;
+  a.pos_index = pos_index;
+  a.mir_index = mir_index;
+  a.out = out;
+  a.max_tiles = max_tiles;
+  a.two_over_rc = 2.0f / p->cutoff;
+  int64_t wgs = (max_tiles + AG_PERSIST_WAVES - 1) / AG_PERSIST_WAVES;
+  if (wgs > 256) wgs = 256;
+  const size_t smem = (size_t)(48 + 8 * p->poly_kt) * 2048;
+  static std::atomic<uint64_t> attr_done{0};
+  if (!ag_allow_big_lds(attr_done, (size_t)(48 + 8 * AGDIFF_POLY_MAX_KT) * 2048, k_pair_head_poly<AG_BF3, 1>,
+                        k_pair_head_poly<AG_BF3, 2>, k_pair_head_poly<AG_F32, 1>, k_pair_head_poly<AG_F32, 2>))
+    return AGDIFF_ERR_LAUNCH;
+  const dim3 grid((unsigned)wgs), block(64 * AG_PERSIST_WAVES);
+  hipStream_t st = (hipStream_t)stream;
+  if (p->precision == AG_BF3) {
+    if (p->poly_kt == 1) k_pair_head_poly<AG_BF3, 1><<<grid, block, smem, st>>>(a);
+    else k_pair_head_poly<AG_BF3, 2><<<grid, block, smem, st>>>(a);
+  } else {
+    if (p->poly_kt == 1) k_pair_head_poly<AG_F32, 1><<<grid, block, smem, st>>>(a);
+    else k_pair_head_poly<AG_F32, 2><<<grid, block, smem, st>>>(a);
+  }
   AG_CHECK_LAUNCH();
   return AGDIFF_OK;
 }

@@ -39,6 +39,12 @@ struct GraphArgs {
   int32_t* c_dst;
   int32_t* c_pos;
   int32_t* c_mir;
+  // radius edges (type 0) as a destination-sorted list of their own (optional: rad_ptr may be null)
+  int32_t* num_rad;
+  int32_t* rad_ptr;
+  int32_t* rad_src;
+  int32_t* rad_dst;
+  float* rad_len;
   int32_t num_graphs;
 };
 
@@ -195,10 +201,16 @@ __global__ void __launch_bounds__(AG_GRAPH_THREADS) k_graph(GraphArgs a) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     a.in_ptr[g0 + i] = base + (i ? sin[i - 1] : 0);
     a.out_ptr[g0 + i] = base + (i ? sout[i - 1] : 0);
+    // every edge of target i is either local (static list) or radius-only: the radius list's offsets are the difference
+    if (a.rad_ptr) a.rad_ptr[g0 + i] = base + (i ? sin[i - 1] : 0) - a.loc_in_ptr[g0 + i];
   }
   if (g == a.num_graphs - 1 && threadIdx.x == 0) {
     a.in_ptr[g0 + n] = base + (n ? sin[n - 1] : 0);
     a.out_ptr[g0 + n] = base + (n ? sout[n - 1] : 0);
+    if (a.rad_ptr) {
+      a.rad_ptr[g0 + n] = base + (n ? sin[n - 1] : 0) - a.loc_in_ptr[g0 + n];
+      *a.num_rad = a.rad_ptr[g0 + n];
+    }
   }
   // pass 2: emit the lists, one wave per target, contiguous stores
   for (int i = wave; i < n; i += nwaves) {
@@ -206,11 +218,13 @@ __global__ void __launch_bounds__(AG_GRAPH_THREADS) k_graph(GraphArgs a) {
     int p0 = base + (i ? sin[i - 1] : 0);
     int cp0 = a.graph_canon_ptr[g] + (i ? scan_c[i - 1] : 0);
     int lk = a.loc_in_ptr[g0 + i];
+    int rp0 = p0 - lk;
     for (int c = 0; 64 * c < n; ++c) {
       const int j = 64 * c + lane;
       const int jj = (j < n) ? j : 0;
       const uint64_t emask = (uint64_t)inbits[i * words + 2 * c] | ((uint64_t)inbits[i * words + 2 * c + 1] << 32);
       const uint64_t lmask = (uint64_t)locbits[i * words + 2 * c] | ((uint64_t)locbits[i * words + 2 * c + 1] << 32);
+      const uint64_t rmask = emask & ~lmask;
       const bool e = (emask >> lane) & 1ull;
       const bool mir = e && has_mirror(i, j);
       const bool canon = e && (j < i || !mir);
@@ -228,6 +242,12 @@ __global__ void __launch_bounds__(AG_GRAPH_THREADS) k_graph(GraphArgs a) {
         a.e_dst[p] = g0 + i;
         a.e_type[p] = ty;
         a.e_len[p] = len;
+        if (a.rad_ptr && eid < 0) {
+          const int rp = rp0 + __popcll(rmask & lt);
+          a.rad_src[rp] = g0 + j;
+          a.rad_dst[rp] = g0 + i;
+          a.rad_len[rp] = len;
+        }
         if (canon) {
           const int cp = cp0 + __popcll(cmask & lt);
           a.c_len[cp] = len;
@@ -241,6 +261,7 @@ __global__ void __launch_bounds__(AG_GRAPH_THREADS) k_graph(GraphArgs a) {
       p0 += __popcll(emask);
       cp0 += __popcll(cmask);
       lk += __popcll(lmask);
+      rp0 += __popcll(rmask);
     }
   }
   // pass 3: ref2dst, one thread per source walking its column (targets ascending = the (src, dst) order)
@@ -300,7 +321,9 @@ __global__ void __launch_bounds__(1024) k_scan_graphs(const int32_t* __restrict_
 // change sign before they are squared)
 __global__ void k_local_lengths(const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
                                 const int32_t* __restrict__ cpos, const int32_t* __restrict__ cmir,
-                                const float* __restrict__ pos, float* __restrict__ len, float* __restrict__ clen, int Lc) {
+                                const float* __restrict__ pos, float* __restrict__ len, float* __restrict__ clen, int Lc,
+                                const int32_t* __restrict__ inpos, const int32_t* __restrict__ inmir,
+                                float* __restrict__ len_in) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= Lc) return;
   int s = src[c], d = dst[c];
@@ -308,6 +331,10 @@ __global__ void k_local_lengths(const int32_t* __restrict__ src, const int32_t* 
   clen[c] = v;
   len[cpos[c]] = v;
   if (cmir[c] >= 0) len[cmir[c]] = v;
+  if (len_in) {          // the same by in-slot (the local list as a destination-sorted list of its own)
+    len_in[inpos[c]] = v;
+    if (inmir[c] >= 0) len_in[inmir[c]] = v;
+  }
 }
 
 }  // namespace
@@ -352,6 +379,12 @@ extern "C" int agdiff_graph_build(const agdiff_topo_t* topo, const agdiff_ws_t* 
   a.c_dst = ws->c_dst;
   a.c_pos = ws->c_pos;
   a.c_mir = ws->c_mir;
+  const bool rad = ws->num_rad && ws->rad_ptr && ws->rad_src && ws->rad_dst && ws->rad_len;
+  a.num_rad = ws->num_rad;
+  a.rad_ptr = rad ? ws->rad_ptr : nullptr;
+  a.rad_src = ws->rad_src;
+  a.rad_dst = ws->rad_dst;
+  a.rad_len = ws->rad_len;
   a.num_graphs = (int32_t)topo->num_graphs;
   const int max_atoms = (int)topo->max_atoms_per_graph;
   if (max_atoms <= 0 || max_atoms > AGDIFF_MAX_ATOMS_PER_GRAPH) return AGDIFF_ERR_LIMIT;
@@ -381,8 +414,10 @@ extern "C" int agdiff_local_lengths(const agdiff_topo_t* topo, const agdiff_ws_t
   if (topo->num_local == 0) return AGDIFF_OK;
   if (!topo->lc_src || !topo->lc_dst || !topo->lc_pos || !topo->lc_mir || topo->num_local_canon <= 0) return AGDIFF_ERR_ARG;
   const int Lc = (int)topo->num_local_canon;
+  const bool by_slot = ws->l_len_in && topo->lc_inpos && topo->lc_inmir;
   k_local_lengths<<<(Lc + 255) / 256, 256, 0, (hipStream_t)stream>>>(topo->lc_src, topo->lc_dst, topo->lc_pos, topo->lc_mir,
-                                                                     pos, ws->l_len, ws->lc_len, Lc);
+                                                                     pos, ws->l_len, ws->lc_len, Lc, topo->lc_inpos,
+                                                                     topo->lc_inmir, by_slot ? ws->l_len_in : nullptr);
   AG_CHECK_LAUNCH();
   return AGDIFF_OK;
 }

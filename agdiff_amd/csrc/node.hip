@@ -21,7 +21,42 @@ struct NodeStageArgs {
   int32_t finish;
   int32_t prep;
   int32_t chunk_edges;         // AG_TW * agdiff_conv_chunk_tiles(max_edges)
+  // second CFConv pass of the block (split CFConv: agg = radius edges, agg2 = local edges), or in_ptr2 == null
+  const int32_t* in_ptr2;
+  const float* agg2;
+  const float* agg_first2;
+  int32_t chunk_edges2;
 };
+
+// The aggregate of one node from one CFConv pass (edge.hip): agg[node] holds the part of the node's edge list that lies
+// in the chunk where the list starts, every later chunk its part in agg_first[chunk]; they are added in chunk order.
+struct AggSrc {
+  const float* row;
+  const float* first;
+  int c_lo, c_hi;
+  bool has;
+};
+__device__ __forceinline__ AggSrc ag_agg_src(const int32_t* in_ptr, const float* agg, const float* agg_first, int chunk_e,
+                                             int64_t nd) {
+  const int lo = in_ptr[nd], hi = in_ptr[nd + 1];
+  AggSrc r;
+  r.has = hi > lo;
+  r.c_lo = lo / chunk_e;
+  r.c_hi = r.has ? (hi - 1) / chunk_e : r.c_lo;
+  r.row = agg + (size_t)nd * 192;
+  r.first = agg_first;
+  return r;
+}
+// features 32 k + 4 q .. +3 (v0) and 32 k + 16 + 4 q .. +3 (v1) of the aggregate
+__device__ __forceinline__ void ag_agg_slice(const AggSrc& r, int k, int q, f32x4& v0, f32x4& v1) {
+  v0 = r.has ? ag_ld4(r.row + 32 * k + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+  v1 = r.has ? ag_ld4(r.row + 32 * k + 16 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int c = r.c_lo + 1; c <= r.c_hi; ++c) {
+    const float* fr = r.first + (size_t)c * 192;
+    v0 += ag_ld4(fr + 32 * k + 4 * q);
+    v1 += ag_ld4(fr + 32 * k + 16 + 4 * q);
+  }
+}
 
 // Stage k of SchNetEncoder.forward (schnet.py:268-282):
 //   finish: p1 = BN(lin2_1(agg1)), p2 = BN(lin2_2(agg2))         (schnet.py:157-158, BN folded)
@@ -82,23 +117,20 @@ __global__ void __launch_bounds__(LDSW ? 1024 : 256, LDSW ? 1 : 2) k_schnet_node
     if (active) {
       f32x4 u[16];
       {
-        // aggregates: agg[node] (+ the partial its last chunk kept separately, edge.hip k_cfconv_fused)
-        const int lo = a.in_ptr[nd], hi = a.in_ptr[nd + 1];
-        // A list that spans chunks c_lo..c_hi: chunk c_lo wrote its part to agg[node], every later chunk to
-        // agg_first[c]; they are added in chunk order.
-        const int chunk_e = a.chunk_edges;
-        const bool has = hi > lo;
-        const int c_lo = lo / chunk_e, c_hi = has ? (hi - 1) / chunk_e : c_lo;
-        const float* ar = a.agg + (size_t)nd * 192;
+        // aggregates of the node: one CFConv pass, or the sum of the radius and the local pass (split CFConv)
+        const AggSrc src1 = ag_agg_src(a.in_ptr, a.agg, a.agg_first, a.chunk_edges, nd);
+        const bool two = a.in_ptr2 != nullptr;
+        const AggSrc src2 = two ? ag_agg_src(a.in_ptr2, a.agg2, a.agg_first2, a.chunk_edges2, nd) : src1;
         ag_init_vec<16>(u, a.prev.lin2_b, q);
         AgIn<MODE> g[2];
         auto load_slice = [&](AgIn<MODE>& dst, int k) {
-          f32x4 v0 = has ? ag_ld4(ar + 32 * k + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
-          f32x4 v1 = has ? ag_ld4(ar + 32 * k + 16 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
-          for (int c = c_lo + 1; c <= c_hi; ++c) {
-            const float* fr = a.agg_first + (size_t)c * 192;
-            v0 += ag_ld4(fr + 32 * k + 4 * q);
-            v1 += ag_ld4(fr + 32 * k + 16 + 4 * q);
+          f32x4 v0, v1;
+          ag_agg_slice(src1, k, q, v0, v1);
+          if (two) {
+            f32x4 w0, w1;
+            ag_agg_slice(src2, k, q, w0, w1);
+            v0 += w0;
+            v1 += w1;
           }
           ag_cvt(v0, v1, dst);
         };
@@ -251,21 +283,19 @@ __global__ void __launch_bounds__(256, 2) k_schnet_node_stage_split(NodeStageArg
   f32x4 u4[4], xc2[2], g1[1], s1[2], s2[2], hv2[2], xo3[3];
   AgIn<MODE> gk[6], ub[8], xb[4], sb[1], hb[4];
   if (FINISH) {
-    // aggregates of the tile's nodes (every wave needs the whole 192-wide row): agg[node] + the partial sums its later
-    // chunks kept in agg_first, added in chunk order (as k_schnet_node_stage)
-    const int lo = a.in_ptr[nd], hi = a.in_ptr[nd + 1];
-    const int chunk_e = a.chunk_edges;
-    const bool has = hi > lo;
-    const int c_lo = lo / chunk_e, c_hi = has ? (hi - 1) / chunk_e : c_lo;
-    const float* ar = a.agg + (size_t)nd * 192;
+    // aggregates of the tile's nodes (every wave needs the whole 192-wide row), as k_schnet_node_stage
+    const AggSrc src1 = ag_agg_src(a.in_ptr, a.agg, a.agg_first, a.chunk_edges, nd);
+    const bool two = a.in_ptr2 != nullptr;
+    const AggSrc src2 = two ? ag_agg_src(a.in_ptr2, a.agg2, a.agg_first2, a.chunk_edges2, nd) : src1;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-      f32x4 v0 = has ? ag_ld4(ar + 32 * k + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
-      f32x4 v1 = has ? ag_ld4(ar + 32 * k + 16 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int c = c_lo + 1; c <= c_hi; ++c) {
-        const float* fr = a.agg_first + (size_t)c * 192;
-        v0 += ag_ld4(fr + 32 * k + 4 * q);
-        v1 += ag_ld4(fr + 32 * k + 16 + 4 * q);
+      f32x4 v0, v1;
+      ag_agg_slice(src1, k, q, v0, v1);
+      if (two) {
+        f32x4 w0, w1;
+        ag_agg_slice(src2, k, q, w0, w1);
+        v0 += w0;
+        v1 += w1;
       }
       ag_cvt(v0, v1, gk[k]);
     }
@@ -798,7 +828,13 @@ static int ag_node_waves_per_wg(int64_t tiles) {
 
 extern "C" int agdiff_schnet_node_stage(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
                                         int32_t k, void* stream) {
+  return agdiff_schnet_node_stage_split(p, topo, ws, k, 0, stream);
+}
+
+extern "C" int agdiff_schnet_node_stage_split(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
+                                              int32_t k, int32_t split, void* stream) {
   if (!p || !topo || !ws || k < 0 || k > p->num_convs || p->num_convs > AGDIFF_MAX_CONVS) return AGDIFF_ERR_ARG;
+  if (split && (!ws->rad_ptr || !ws->agg_loc || !ws->agg_first_loc || !topo->loc_in_ptr)) return AGDIFF_ERR_ARG;
   if (topo->num_nodes <= 0) return AGDIFF_OK;
   NodeStageArgs a;
   a.finish = k > 0;
@@ -814,6 +850,20 @@ extern "C" int agdiff_schnet_node_stage(const agdiff_params_t* p, const agdiff_t
   a.xs = ws->xs;
   a.n = topo->num_nodes;
   a.chunk_edges = AG_TW * agdiff_conv_chunk_tiles(topo->max_edges);
+  a.in_ptr2 = nullptr;
+  a.agg2 = nullptr;
+  a.agg_first2 = nullptr;
+  a.chunk_edges2 = 1;
+  if (split) {         // block k-1 ran as agdiff_cfconv_radius (ws->agg) + agdiff_cfconv_local (ws->agg_loc)
+    a.in_ptr = ws->rad_ptr;
+    a.chunk_edges = AG_TW * agdiff_conv_chunk_tiles(topo->max_edges - topo->num_local);
+    if (topo->num_local > 0) {
+      a.in_ptr2 = topo->loc_in_ptr;
+      a.agg2 = ws->agg_loc;
+      a.agg_first2 = ws->agg_first_loc;
+      a.chunk_edges2 = AG_TW * agdiff_conv_chunk_tiles(topo->num_local);
+    }
+  }
   const int64_t tiles = (a.n + AG_TW - 1) / AG_TW;
   hipStream_t st = (hipStream_t)stream;
   if (tiles <= ag_node_split_max_tiles()) {       // small batch: four waves per tile (k_schnet_node_stage_split)

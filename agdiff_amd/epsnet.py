@@ -211,6 +211,9 @@ class DualEncoderEpsNetwork(nn.Module):
         # arithmetic of the HIP kernels: "f32" = exact fp32 MFMA; "bf16x3" = split-bf16 MFMA (hi+lo operands,
         # three passes, fp32 accumulation, ~2^-16 relative per product).  Both meet the 1e-4 parity bar.
         self.precision = getattr(config, "precision", None) or os.environ.get("AGDIFF_PRECISION", "bf16x3")
+        # "auto": radius edges take their CFConv filters / head inputs from d-polynomials when packing.py accepts the
+        # fit for these weights (<= 1e-6 of the networks they replace), "off": every edge through the MLPs
+        self.radius_poly = getattr(config, "radius_poly", None) or os.environ.get("AGDIFF_RADIUS_POLY", "auto")
         self._packed = None
         self._packed_key = None
         self._batch_cache = None
@@ -228,14 +231,14 @@ class DualEncoderEpsNetwork(nn.Module):
         return _lib.load()
 
     def _weights_key(self):
-        return (str(self._device()), self.precision) + tuple(int(p._version) for p in self.state_dict(keep_vars=True).values())
+        return (str(self._device()), self.precision, self.radius_poly) + tuple(int(p._version) for p in self.state_dict(keep_vars=True).values())
 
     def packed(self):
         """Packed device weights, rebuilt when any parameter / buffer changed (load_state_dict, .to)."""
         key = self._weights_key()
         if self._packed is None or self._packed_key != key:
             sd = {k: v for k, v in self.state_dict().items()}
-            self._packed = PackedParams(sd, self.config, self._device(), self.precision)
+            self._packed = PackedParams(sd, self.config, self._device(), self.precision, self.radius_poly)
             self._packed_key = key
         return self._packed
 
@@ -260,6 +263,8 @@ class DualEncoderEpsNetwork(nn.Module):
         topo = BatchTopology(atom_type, bond_index, bond_type, batch, num_graphs=num_graphs,
                              extend_order=extend_order, order=self.config.edge_order, device=self._device())
         ws = Workspace(topo)
+        if self._packed is not None and topo.L:
+            self._packed.ensure_local_types(topo.local_types)     # filter polynomials for this batch's local edge types
         self._batch_cache = (key, topo, ws)
         return topo, ws
 
@@ -463,6 +468,7 @@ class LangevinRun:
             self.pk = model._renorm_embedding(atom_type)
             self.topo, self.ws = model._batch(atom_type, bond_index, bond_type, batch, num_graphs, extend_order)
             self.radius_flags = model._fwd_flags(self.topo, extend_radius, with_global=False)
+            self._sampler_flag = _lib.DEFINES["AGDIFF_FWD_SAMPLER"]    # only radius edges' global scores are used (dualenc.py:516-518)
             T = model.num_timesteps
             self.steps = list(step_indices) if step_indices is not None else list(reversed(range(T - n_steps, T)))
             self.pos = (pos_init.detach().to(dev, torch.float32) * self.sigmas[-1].to(dev)).contiguous()
@@ -525,7 +531,7 @@ class LangevinRun:
                 self.global_steps += run_global
                 _lib.check(lib.agdiff_score_forward(ctypes.byref(pk.struct), ctypes.byref(topo.struct),
                                                     ctypes.byref(ws.struct), self.pos_p,
-                                                    run_global | self.radius_flags, stream),
+                                                    run_global | self.radius_flags | self._sampler_flag, stream),
                            "agdiff_score_forward")
                 _lib.check(lib.agdiff_langevin_update(ctypes.byref(topo.struct), ctypes.byref(ws.struct),
                                                       ctypes.byref(a), stream), "agdiff_langevin_update")

@@ -96,6 +96,146 @@ def fold_bn(W, b, sd, p, eps=1e-5):
     return W * s[:, None], (b - _np(sd, p + ".running_mean")) * s + _np(sd, p + ".bias")
 
 
+# ---------------------------------------------------------------------------------- radius-edge polynomials
+# A radius edge (type 0, d < cutoff by construction: common.py:217) has NO input but its length: edge_attr = MLPEdgeEncoder(d,
+# type 0) (edge.py:84-103), the CFConv filter nn(edge_attr) (schnet.py:169-179) and the edge_attr half of the global head's
+# first layer (common.py:106-109) are therefore functions of ONE scalar on [0, cutoff] -- compositions of Linear, GELU
+# and softplus, i.e. analytic -- and a Chebyshev expansion converges geometrically.  They are fitted here in float64
+# (interpolation at Chebyshev nodes) and ACCEPTED ONLY IF they reproduce the networks on a dense grid to `POLY_TOL` of the
+# largest value; otherwise the kernels evaluate the MLPs for every edge as before (poly_kt = 0).
+POLY_TOL = 1e-6
+POLY_MAX_KT = 2
+
+
+def poly_feature_order(kt):
+    """Natural column n of a packed K = 32 kt matrix -> index f of the product-basis function phi_f it multiplies
+    (include/agdiff_hip.h, agdiff_params_t.poly_kt): operand element j of lane quarter q in k-tile t sits at natural
+    column 32 t + 16 (j >> 2) + 4 q + (j & 3) (pack_blocks / csrc/common.hpp) and holds phi[8 (4 t + q) + j]."""
+    order = np.empty(32 * kt, dtype=np.int64)
+    for t in range(kt):
+        for q in range(4):
+            for j in range(8):
+                order[32 * t + 16 * (j >> 2) + 4 * q + (j & 3)] = 8 * (4 * t + q) + j
+    return order
+
+
+def poly_basis_matrix(K):
+    """M[n, f]: coefficient of T_n in phi_f = T_{8 g} T_j (f = 8 g + j): T_a T_b = (T_{a+b} + T_{|a-b|}) / 2."""
+    M = np.zeros((K, K))
+    for f in range(K):
+        g, j = divmod(f, 8)
+        a = 8 * g
+        if a == 0 or j == 0:
+            M[a + j, f] = 1.0
+        else:
+            M[a + j, f] += 0.5
+            M[a - j, f] += 0.5
+    return M
+
+
+def poly_features(x, K):
+    """phi_f(x), f < K, evaluated the way the kernels do (csrc/edge.hip: ag_poly_features): float64 here."""
+    x = np.asarray(x, dtype=np.float64)
+    T = [np.ones_like(x), x]
+    for n in range(2, 9):
+        T.append(2 * x * T[-1] - T[-2])
+    T8 = T[8]
+    G = [np.ones_like(x), T8]
+    G.append(2 * T8 * T8 - 1)                 # T16
+    G.append(2 * G[2] * T8 - T8)              # T24
+    G.append(2 * G[2] * G[2] - 1)             # T32
+    G.append(2 * G[4] * T8 - G[3])            # T40
+    G.append(2 * G[3] * G[3] - 1)             # T48
+    G.append(2 * G[6] * T8 - G[5])            # T56
+    return np.stack([G[f // 8] * T[f % 8] for f in range(K)], axis=-1)
+
+
+def fit_poly(fn, cutoff, K):
+    """Coefficients C[out, K] (product basis) of the degree-(K-1) interpolant of fn: d[M] -> [M, out] at the K Chebyshev
+    nodes of [0, cutoff], and its largest error on a dense grid relative to the largest |fn|."""
+    k = np.arange(K)
+    xn = np.cos(np.pi * (k + 0.5) / K)
+    fv = fn((xn + 1.0) * (cutoff / 2.0))                                   # [K, out]
+    b = np.polynomial.chebyshev.chebfit(xn, fv, K - 1)                      # [K, out] Chebyshev coefficients
+    c = np.linalg.solve(poly_basis_matrix(K), b)                            # product-basis coefficients
+    dg = np.linspace(0.0, cutoff, 4097)
+    ref = fn(dg)
+    err = np.abs(poly_features(2.0 * dg / cutoff - 1.0, K) @ c - ref).max() / max(np.abs(ref).max(), 1e-300)
+    return c.T, float(err)
+
+
+def _edge_attr_fn(sd, e, typ):
+    """d[M] (float64 numpy) -> edge_attr [M, 128] of edges of type `typ`, MLPEdgeEncoder.forward (edge.py:84-103) in
+    float64; the trailing attention factor is a softmax over a size-1 axis, i.e. 1."""
+    import torch
+    import torch.nn.functional as F
+    g = lambda k: sd[e + k].detach().cpu().double()
+    few, feb = g(".feature_expansion.weight"), g(".feature_expansion.bias")
+    W0, b0, W2, b2 = g(".edge_feature_mlp.0.weight"), g(".edge_feature_mlp.0.bias"), g(".edge_feature_mlp.2.weight"), g(".edge_feature_mlp.2.bias")
+    C0, c0, C2, c2 = g(".combination_mlp.0.weight"), g(".combination_mlp.0.bias"), g(".combination_mlp.2.weight"), g(".combination_mlp.2.bias")
+    emb = g(".bond_emb.weight")[int(typ)]
+
+    def fn(d):
+        d = torch.from_numpy(np.ascontiguousarray(d, dtype=np.float64)).view(-1, 1)
+        x = F.gelu(F.linear(d, few, feb))
+        b = emb.expand(d.shape[0], -1)
+        h = F.linear(F.gelu(F.linear(torch.cat([x, b], 1), W0, b0)), W2, b2)
+        return F.linear(F.gelu(F.linear(torch.cat([h, b], 1), C0, c0)), C2, c2)
+    return fn
+
+
+def _poly_targets(sd, cfg, typ, with_head):
+    """name -> function d[M] -> [M, out] (float64 numpy) of everything the kernels replace by a polynomial for edges of
+    type `typ`: the two CFConv filters of every block (schnet.py:169-179) and, for radius edges, the edge_attr half of the
+    global head's first layer (common.py:106-109)."""
+    import torch
+    import torch.nn.functional as F
+    attr = _edge_attr_fn(sd, "edge_encoder_global", typ)
+    g = lambda k: sd[k].detach().cpu().double()
+    LN2 = float(np.log(2.0))
+    fns = {}
+    for k in range(cfg.num_convs):
+        def filt(d, k=k):
+            a = attr(d)
+            outs = []
+            for conv in ("conv1", "conv2"):
+                p = "encoder_global.interactions.%d.%s" % (k, conv)
+                u = F.linear(a, g(p + ".nn.0.weight"), g(p + ".nn.0.bias"))
+                s = F.softplus(g(p + ".nn.1.beta") * u) - LN2                          # schnet.py:71-80
+                outs.append(F.linear(s, g(p + ".nn.2.weight"), g(p + ".nn.2.bias")))
+            return torch.cat(outs, 1).numpy()
+        fns["conv%d.filt_poly_pk" % k] = filt
+    if with_head:
+        Wb = g("grad_global_dist_mlp.layers.0.weight")[:, H:]
+        fns["head_global.attr_poly_pk"] = lambda d: F.linear(attr(d), Wb).numpy()
+    return fns
+
+
+def fit_type(sd, cfg, typ, kt, with_head):
+    """({name: coefficient matrix in natural packed column order}, worst relative error) for edges of type `typ`."""
+    order = poly_feature_order(kt)
+    mats, worst = {}, 0.0
+    for name, fn in _poly_targets(sd, cfg, typ, with_head).items():
+        c, err = fit_poly(fn, float(cfg.cutoff), 32 * kt)
+        mats[name] = c[:, order]
+        worst = max(worst, err)
+    return mats, worst
+
+
+def radius_polynomials(sd, cfg, tol=POLY_TOL, max_kt=POLY_MAX_KT):
+    """(poly_kt, {name: coefficient matrix}, errors) or (0, {}, errors) when no degree up to 32 max_kt - 1 meets `tol`
+    (or the edge encoder is not the MLP one)."""
+    if cfg.edge_encoder != "mlp":
+        return 0, {}, {}
+    errors = {}
+    for kt in range(1, max_kt + 1):
+        mats, worst = fit_type(sd, cfg, 0, kt, True)
+        errors[kt] = worst
+        if worst <= tol:
+            return kt, mats, errors
+    return 0, {}, errors
+
+
 PRECISIONS = {"f32": 0, "bf16x3": 1}
 EDGE_ENCODERS = {"mlp": 0, "gaussian": 1}       # agdiff_params_t.edge_encoder
 
@@ -103,9 +243,18 @@ EDGE_ENCODERS = {"mlp": 0, "gaussian": 1}       # agdiff_params_t.edge_encoder
 class PackedParams:
     """Owns the device copies of all packed weights and the agdiff_params_t that points at them."""
 
-    def __init__(self, sd, cfg, device, precision="f32"):
+    def __init__(self, sd, cfg, device, precision="f32", radius_poly="auto"):
+        """radius_poly: "auto" -- radius edges take their filters from d-polynomials when the fit is accepted
+        (radius_polynomials above); "off" -- every edge goes through the encoder + filter MLPs."""
         import torch
         self.device = device
+        if radius_poly not in ("auto", "off"):
+            raise ValueError("radius_poly must be 'auto' or 'off'")
+        self.poly_kt, self._poly, self.poly_errors = (0, {}, {}) if radius_poly == "off" else radius_polynomials(sd, cfg)
+        # local edge types with filter polynomials (ensure_local_types): type -> slot, grown as batches bring new types
+        self._sd, self._cfg, self._mode = sd, cfg, PRECISIONS.get(precision, 0)
+        self.local_slots, self._typed_mats, self._typed_ok = {}, {}, self.poly_kt == 1
+        self.typed_flat = self.slot_table = None
         if precision not in PRECISIONS:
             raise ValueError("precision must be one of %s" % (list(PRECISIONS),))
         self.precision = precision
@@ -225,6 +374,10 @@ class PackedParams:
             arrays[n + "w3"] = _np(sd, p + ".layers.2.weight")[0]
             scalars[n + "b3"] = float(_np(sd, p + ".layers.2.bias")[0])
 
+        # ---------------- radius-edge polynomials (include/agdiff_hip.h: agdiff_params_t.poly_kt)
+        for name, c in self._poly.items():
+            arrays[name] = pack_blocks(c, kouter=name.startswith("head_"))
+
         # one flat device buffer, every section 256-byte aligned
         offs, total = {}, 0
         for k, v in arrays.items():
@@ -258,7 +411,7 @@ class PackedParams:
             for f, _ in _lib.ConvParams._fields_:
                 if (n + f) in offs:
                     setattr(cp, f, P(n + f))
-                else:
+                elif f not in ("filt_poly_pk", "filt_poly_typed_pk"):          # (null when the polynomials are off)
                     setattr(cp, f, scalars[n + f])
         for k in range(cfg.num_convs_local):
             gp, n = prm.gin[k], "gin%d." % k
@@ -270,6 +423,8 @@ class PackedParams:
             hp, n = getattr(prm, name), name + "."
             for f in ("w1_pk", "b1", "w2_pk", "b2", "w3"):
                 setattr(hp, f, P(n + f))
+            if (n + "attr_poly_pk") in offs:
+                hp.attr_poly_pk = P(n + "attr_poly_pk")
             hp.b3 = scalars[n + "b3"]
             hp.act = 0
             hp.precision = mode
@@ -278,7 +433,47 @@ class PackedParams:
         prm.cutoff = float(cfg.cutoff)
         prm.smooth = 1 if cfg.smooth_conv else 0
         prm.precision = mode
+        prm.poly_kt = self.poly_kt
+        prm.poly_num_slots = 0
         self.struct = prm
+
+    def ensure_local_types(self, types):
+        """Give every local edge type of a batch (BatchTopology.local_types) a filter-polynomial slot, so that
+        agdiff_cfconv_local needs no edge_attr either (include/agdiff_hip.h: poly_num_slots).  A type whose fit misses
+        POLY_TOL, or more than AGDIFF_POLY_MAX_SLOTS types in all, turns the slots off for good: the local edges then go
+        through the filter MLPs (the radius edges keep their polynomials)."""
+        import torch
+        if not self._typed_ok:
+            return False
+        new = [int(t) for t in types if int(t) not in self.local_slots]
+        if not new:
+            return True
+        prm = self.struct
+        max_slots = _lib.DEFINES["AGDIFF_POLY_MAX_SLOTS"]
+        for t in new:
+            mats, err = fit_type(self._sd, self._cfg, t, 1, False)
+            self.poly_errors["type%d" % t] = err
+            if err > POLY_TOL or len(self.local_slots) >= max_slots:
+                self._typed_ok = False
+                prm.poly_num_slots = 0
+                return False
+            self.local_slots[t] = len(self.local_slots)
+            self._typed_mats[t] = mats
+        by_slot = sorted(self.local_slots, key=self.local_slots.get)
+        nc = self._cfg.num_convs
+        per_conv = [np.concatenate([pack_blocks(self._typed_mats[t]["conv%d.filt_poly_pk" % k], mode=self._mode) for t in by_slot])
+                    for k in range(nc)]
+        self.typed_flat = torch.from_numpy(np.concatenate(per_conv)).to(self.device)     # (the old buffer may still be in
+        table = np.full(100, -1, dtype=np.int32)                                         #  use by enqueued launches: torch's
+        for t, sl in self.local_slots.items():                                           #  allocator keeps it alive in stream order)
+            table[t] = sl
+        self.slot_table = torch.from_numpy(table).to(self.device)
+        stride = per_conv[0].size
+        for k in range(nc):
+            prm.conv[k].filt_poly_typed_pk = ctypes.c_void_p(self.typed_flat.data_ptr() + 4 * stride * k)
+        prm.poly_type_slot = ctypes.c_void_p(self.slot_table.data_ptr())
+        prm.poly_num_slots = len(by_slot)
+        return True
 
     def view(self, name):
         o = self.offsets[name]

@@ -111,6 +111,14 @@ class BatchTopology:
         self.lc_src, self.lc_dst, self.lc_type = i32(src[lc_pos]), i32(dst[lc_pos]), i32(typ[lc_pos])
         self.lc_pos, self.lc_mir, self.loc_row = i32(lc_pos), i32(lc_mir), i32(loc_row)
         self.loc_in_src, self.loc_in_row = i32(src[in_order]), i32(loc_row[in_order])
+        # the local list as a destination-sorted edge list of its own (split CFConv: agdiff_ws_t.l_attr_frag / l_scale)
+        inslot = np.empty(L, dtype=np.int64)
+        inslot[in_order] = np.arange(L)
+        self.loc_in_dst = i32(dst[in_order])
+        self.loc_in_type = i32(typ[in_order])
+        self.local_types = np.unique(typ)                 # PackedParams.ensure_local_types (per-type filter polynomials)
+        self.lc_inpos = i32(inslot[lc_pos])
+        self.lc_inmir = i32(np.where(lc_mir >= 0, inslot[np.maximum(lc_mir, 0)], -1))
         # int64 copies of the local edges for the API results (forward() returns int64 indices)
         self.loc_index64 = torch.from_numpy(np.stack([src, dst])).to(device)
         self.loc_type64 = torch.from_numpy(typ).to(device)
@@ -123,7 +131,7 @@ class BatchTopology:
         t.num_local_canon = self.Lc
         for f in ("graph_ptr", "atom_type", "loc_src", "loc_dst", "loc_type", "loc_out_ptr", "loc_in_ptr", "loc_in_eid",
                   "lc_src", "lc_dst", "lc_type", "lc_pos", "lc_mir", "loc_row", "loc_in_src",
-                  "loc_in_row"):
+                  "loc_in_row", "loc_in_dst", "lc_inpos", "lc_inmir", "loc_in_type"):
             setattr(t, f, _lib.ptr(getattr(self, f)))
         self.struct = t
 
@@ -165,10 +173,26 @@ class Workspace:
         self.num_local_canon = torch.tensor([topo.Lc], dtype=torch.int32, device=dev)
         self.l_attr_rows = f32(ltiles * TW * 128)
         self.h, self.xs, self.agg = f32(N * 128), f32(N * 192), f32(N * 192)
-        self.agg_first = f32(chunks * 192)
+        # (the split CFConv's radius pass cuts its own, shorter list into chunks of its own length: size for both)
+        rtiles_ = (max(E - L, 0) + TW - 1) // TW
+        rchunk = _lib.load().agdiff_conv_chunk_tiles(max(E - L, 0))
+        self.agg_first = f32(max(chunks, (rtiles_ + rchunk - 1) // rchunk) * 192)
         self.hl, self.hl2 = f32(N * 128), f32(N * 128)
         self.nan_flag = i32(1 + G)
         self.scratch = f32(N * 3)
+        # split CFConv (radius edges by polynomial filters + local edges through the filter MLPs)
+        R = max(E - L, 0)
+        rtiles = (R + TW - 1) // TW
+        lchunk = _lib.load().agdiff_conv_chunk_tiles(L)
+        self.num_rad = i32(1)
+        self.rad_ptr = i32(N + 1)
+        self.rad_src, self.rad_dst, self.rad_len = i32(rtiles * TW), i32(rtiles * TW), f32(rtiles * TW)
+        self.r_scale = f32(2 * _lib.DEFINES["AGDIFF_MAX_CONVS"] * rtiles * TW)
+        self.l_scale = f32(2 * _lib.DEFINES["AGDIFF_MAX_CONVS"] * ltiles * TW)
+        self.l_attr_frag = f32(ltiles * TW * 128)
+        self.l_len_in = f32(ltiles * TW)
+        self.agg_loc = f32(N * 192)
+        self.agg_first_loc = f32((ltiles + lchunk - 1) // lchunk * 192)
         w = _lib.Workspace()
         for f, _ in _lib.Workspace._fields_:
             setattr(w, f, _lib.ptr(getattr(self, f)))

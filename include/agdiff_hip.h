@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 19
+#define AGDIFF_ABI_VERSION 20
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -33,6 +33,8 @@ extern "C" {
 #define AGDIFF_TILE 16             /* edges / nodes per MFMA tile */
 #define AGDIFF_MAX_CHUNK_TILES 8   /* most tiles one wave walks per chunk in the fused CFConv kernel (128 edges) */
 #define AGDIFF_RMSD_MAX_ATOMS 256  /* most (heavy) atoms per conformer in agdiff_rmsd_matrix */
+#define AGDIFF_POLY_MAX_KT 2       /* most 32-term k-tiles of the radius-edge filter polynomial (degree 63) */
+#define AGDIFF_POLY_MAX_SLOTS 6    /* most local edge types with filter polynomials (6 x 24 KiB of coefficients in LDS) */
 
 enum agdiff_status {
   AGDIFF_OK = 0,
@@ -74,6 +76,12 @@ typedef struct agdiff_conv_params {
   const float* gate2_w;      /* [64]  attention.2 */
   const float* scale1_pk;    /* pk [1][4]: scaling fc.0 (128->8, rows 8..15 zero) */
   const float* scale2_pk;    /* pk [8][1]: scaling fc.2 (8->128, cols 8..31 zero) */
+  const float* filt_poly_pk; /* pk [12][poly_kt] or null: the whole filter network of a RADIUS edge (type 0, d < cutoff) as a
+                                polynomial in d -- see agdiff_params_t.poly_kt.  Rows 0..127 conv1, 128..191 conv2; nn.2.bias
+                                is the constant term */
+  const float* filt_poly_typed_pk; /* [poly_num_slots] x pk [12][poly_kt] or null: the same for the LOCAL edge types that have
+                                a slot (agdiff_params_t.poly_type_slot), d in [0, cutoff] (beyond it the CFConv's cutoff factor
+                                C(d) is exactly 0, schnet.py:140-146) */
   float gate2_b;
   float act_beta;            /* InteractionBlock.act.beta */
 } agdiff_conv_params_t;
@@ -93,6 +101,8 @@ typedef struct agdiff_head_params {
   const float* w2_pk;        /* pk [4][4] layers.1 (128->64) */
   const float* b2;           /* [64] */
   const float* w3;           /* [64]  layers.2 */
+  const float* attr_poly_pk; /* pkk [poly_kt][8] or null: layers.0.weight[:, 128:] @ edge_attr(d, type 0) as a polynomial in d
+                                (agdiff_params_t.poly_kt) */
   float b3;
   int32_t act;               /* 0 relu (configs: mlp_act relu) */
   int32_t precision;         /* as agdiff_params_t.precision */
@@ -116,6 +126,7 @@ typedef struct agdiff_params {
   const float* ge_emb;       /* [100][64] bond_emb.weight */
   const float* schnet_emb;   /* [100][128] encoder_global.embedding (max_norm renorm applied to used rows) */
   const float* gin_emb;      /* [100][128] encoder_local.node_emb */
+  const int32_t* poly_type_slot; /* [100] or null: slot of an edge type in filt_poly_typed_pk, -1 = none */
   agdiff_conv_params_t conv[AGDIFF_MAX_CONVS];
   agdiff_gin_params_t gin[AGDIFF_MAX_CONVS_LOCAL];
   agdiff_head_params_t head_global;
@@ -128,7 +139,19 @@ typedef struct agdiff_params {
                                 both the kernels and the layout of every packed matrix and of e_attr / l_attr */
   int32_t edge_encoder;      /* config.edge_encoder: 0 'mlp' (edge.py:45-103), 1 'gaussian' (edge.py:17-42) */
   float ge_coeff;            /* -0.5 / (offset[1] - offset[0])^2 (schnet.py:22) */
-  int32_t pad0;
+  int32_t poly_num_slots;    /* 0, or 1..AGDIFF_POLY_MAX_SLOTS: local edge types whose CFConv filters are d-polynomials too
+                                (every type the host has met in a batch so far; only with poly_kt == 1, so that all slots fit
+                                in LDS); 0 sends the local edges through the filter MLPs */
+  int32_t pad1;
+  int32_t poly_kt;           /* 0: off.  1..AGDIFF_POLY_MAX_KT: radius edges (type 0: no bond embedding; d < cutoff by
+                                construction) take their CFConv filters and the edge_attr half of the global head's first layer
+                                from polynomials in d instead of the encoder + filter MLPs: both are smooth functions of the ONE
+                                scalar d (edge.py:84-103 -> schnet.py:169-179), fitted by the host in float64 at Chebyshev nodes
+                                and accepted only when they reproduce the networks to <= 1e-6 of the largest value on a dense
+                                grid (agdiff_amd/packing.py).  K = 32 poly_kt terms in the product basis
+                                  phi[8 g + j](x) = T_{8 g}(x) T_j(x),  x = 2 d / cutoff - 1,  g < 4 poly_kt,  j < 8
+                                (T_n = Chebyshev polynomials; spans all polynomials of degree < K); operand element j of lane
+                                quarter q in k-tile t is phi[8 (4 t + q) + j], and the packed blocks are ordered to match. */
 } agdiff_params_t;
 
 /* ---- static topology of one packed batch (host builds it once per batch) ---------------------
@@ -161,6 +184,10 @@ typedef struct agdiff_topo {
   const int32_t* loc_row;    /* [L]: canonical index (row of l_attr_rows) of every local edge */
   const int32_t* loc_in_src; /* [L]: loc_src[loc_in_eid[s]] (the GIN gather reads its indices by in-slot, one level deep) */
   const int32_t* loc_in_row; /* [L]: loc_row[loc_in_eid[s]] */
+  const int32_t* loc_in_dst; /* [L]: loc_dst[loc_in_eid[s]] (the local list as a destination-sorted edge list of its own) */
+  const int32_t* lc_inpos;   /* [Lc]: in-slot s of the canonical edge (loc_in_eid[s] == lc_pos[c]) */
+  const int32_t* lc_inmir;   /* [Lc]: in-slot of its mirror, or -1 */
+  const int32_t* loc_in_type;/* [L]: loc_type[loc_in_eid[s]] */
 } agdiff_topo_t;
 
 /* ---- workspace (device buffers the host allocates once per batch) ------------------------- */
@@ -208,12 +235,27 @@ typedef struct agdiff_ws {
   float*   h;                /* [N][128] SchNet node state */
   float*   xs;               /* [N][192] lin1/BN/LeakyReLU outputs feeding conv1 (0..127) and conv2 (128..191) */
   float*   agg;              /* [N][192] CFConv aggregates */
-  float*   agg_first;        /* [ceil(tiles / agdiff_conv_chunk_tiles(max_edges))][192]: partial sum of the target whose list was
+  float*   agg_first;        /* [chunks][192], chunks = the larger of ceil(ceil(n/16) / agdiff_conv_chunk_tiles(n)) for n = max_edges
+                                and n = max_edges - num_local (the split CFConv's radius pass): partial sum of the target whose list was
                                 already open when the chunk started; the node stage adds them in chunk order */
   float*   hl;               /* [N][128] GIN node state (ping) */
   float*   hl2;              /* [N][128] (pong) */
   int32_t* nan_flag;         /* [1 + G]: [0] set to 1 when any position becomes NaN, [1 + g] when one of graph g does
                                 (sticky: the host clears them when a sampling job starts) */
+  /* split CFConv (agdiff_params_t.poly_kt > 0): the radius edges (type 0) of the dynamic graph as a destination-sorted
+   * list of their own (written by agdiff_graph_build next to the full list), and the static local list's per-step data
+   * by in-slot (topo->loc_in_*) */
+  int32_t* num_rad;          /* [1]  R = E - L (device scalar) */
+  int32_t* rad_ptr;          /* [N+1]: radius edges of target i are [rad_ptr[i], rad_ptr[i+1]) = in_ptr - loc_in_ptr */
+  int32_t* rad_src;          /* [max_edges - L] */
+  int32_t* rad_dst;          /* [max_edges - L] */
+  float*   rad_len;          /* [max_edges - L] */
+  float*   r_scale;          /* [2*num_convs][ceil((max_edges - L)/16)*16]: lw(d)*C(d) by radius-list position */
+  float*   l_scale;          /* [2*num_convs][ceil(L/16)*16]: the same by local in-slot */
+  float*   l_attr_frag;      /* [ceil(L/16)] tiles x 2048 floats: edge_attr of the local edges in operand form, by in-slot */
+  float*   l_len_in;         /* [L] lengths of the local edges by in-slot (written by agdiff_local_lengths next to l_len) */
+  float*   agg_loc;          /* [N][192] CFConv aggregates over the local edges */
+  float*   agg_first_loc;    /* [ceil(ceil(L/16) / agdiff_conv_chunk_tiles(L))][192] */
 } agdiff_ws_t;
 
 typedef struct agdiff_step_args {
@@ -273,10 +315,37 @@ int agdiff_edge_encoder(const agdiff_params_t* p, const int32_t* n_edges_dev, in
  * k >= 1 finishes InteractionBlock k-1 (lin2/BN, act, lin, gate, AdaptiveScaling, residual);
  * k < num_convs also applies block k's conv{1,2}.lin1/BN/LeakyReLU into ws->xs. */
 int agdiff_schnet_node_stage(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k, void* stream);
+/* The same with split != 0: block k-1's aggregates are ws->agg (radius edges, lists ws->rad_ptr) + ws->agg_loc (local
+ * edges, lists topo->loc_in_ptr) -- agdiff_cfconv_radius / agdiff_cfconv_local below. */
+int agdiff_schnet_node_stage_split(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k,
+                                   int32_t split, void* stream);
 
 /* CFConv filter generation + message + aggr='add' for both convs of block k
  * (encoder/schnet.py:138-162; PyG MessagePassing.propagate): ws->agg / ws->agg_first. */
 int agdiff_cfconv_fused(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k, void* stream);
+
+/* Split CFConv (agdiff_params_t.poly_kt > 0): block k's two convs as the sum of
+ *   agdiff_cfconv_radius  over the radius edges (ws->rad_*, ws->r_scale; filters from the d-polynomials
+ *                         p->conv[k].filt_poly_pk) -> ws->agg / ws->agg_first, and
+ *   agdiff_cfconv_local   over the static local list by in-slot (topo->loc_in_*, ws->l_scale; filters from the per-type
+ *                         d-polynomials p->conv[k].filt_poly_typed_pk at ws->l_len_in when every local type has a slot,
+ *                         else the filter MLPs on ws->l_attr_frag as in agdiff_cfconv_fused) -> ws->agg_loc / ws->agg_first_loc;
+ * agdiff_schnet_node_stage adds the two.  agdiff_edge_scales_split fills ws->r_scale (which == 0) or ws->l_scale
+ * (which == 1). */
+int agdiff_cfconv_radius(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k, void* stream);
+int agdiff_cfconv_local(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k, void* stream);
+/* 1 when agdiff_cfconv_local takes the local edges' filters from per-type d-polynomials (p->poly_num_slots > 0, poly_kt == 1,
+ * topo->loc_in_type, ws->l_len_in), 0 when it evaluates the filter MLPs on ws->l_attr_frag. */
+int agdiff_local_poly_enabled(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws);
+int agdiff_edge_scales_split(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t which,
+                             void* stream);
+
+/* agdiff_pair_head with p->head_global for edges whose edge_attr is MLPEdgeEncoder(len, type 0): the edge_attr half of the
+ * first layer comes from the d-polynomial head_global.attr_poly_pk (needs p->poly_kt > 0).  pos_index / mir_index as in
+ * agdiff_pair_head (both or neither). */
+int agdiff_pair_head_poly(const agdiff_params_t* p, const int32_t* n_edges_dev, int64_t max_tiles,
+                          const int32_t* src, const int32_t* dst, const float* len, const float* node_h,
+                          const int32_t* pos_index, const int32_t* mir_index, float* out, void* stream);
 
 /* assemble_atom_pair_feature + grad_*_dist_mlp (models/common.py:106-109, 86-103; dualenc.py:203-211,
  * 226-239) over n edges given by (src, dst); edge_attr either as operand-form tiles (attr_frag) or as fp32
@@ -312,6 +381,11 @@ int agdiff_cfconv_aggregate(const float* x, const float* W, const int32_t* in_pt
 #define AGDIFF_FWD_GLOBAL 1
 #define AGDIFF_FWD_NO_RADIUS 2
 #define AGDIFF_FWD_GRAPH_GIVEN 4
+/*   AGDIFF_FWD_SAMPLER      the caller is the denoising loop: of the global head's outputs only those of radius edges are
+ *                           used (edge_inv_global * (1 - local_edge_mask), dualenc.py:516-518), so with
+ *                           poly_kt > 0 neither the edge encoder nor the head runs on anything but d-polynomials and the
+ *                           local list; ws->e_inv_global is then only valid at radius edges */
+#define AGDIFF_FWD_SAMPLER 8
 int agdiff_score_forward(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
                          const float* pos, int32_t flags, void* stream);
 

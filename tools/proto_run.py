@@ -4,6 +4,7 @@ device graph of the bench batch, runs the new kernels next to agdiff_cfconv_fuse
 aggregates and times both.   python tools/proto_run.py [--workload drugs|qm9] [--mols 8] [--copies 128] [--max-tiles 8]"""
 import argparse, ctypes, json, os, sys, time
 import numpy as np
+os.environ["AGDIFF_RADIUS_POLY"] = "off"    # this experiment compares against the one-list product kernel (agdiff_cfconv_fused)
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -5,6 +5,7 @@ next to agdiff_cfconv_fused on the same inputs, compares the aggregates and time
    python tools/proto_run4.py [--workload drugs|qm9] [--mols 8] [--copies 128] [--max-atoms 56]"""
 import argparse, ctypes, json, os, sys, time
 import numpy as np
+os.environ["AGDIFF_RADIUS_POLY"] = "off"    # this experiment compares against the one-list product kernel (agdiff_cfconv_fused)
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
