@@ -1294,9 +1294,9 @@ extern "C" int agdiff_edge_scales_split(const agdiff_params_t* p, const agdiff_t
                               stream);
   }
   // local list by in-slot: one evaluation per canonical local edge (a mirror pair has one length)
-  if (!ws->l_scale || !ws->lc_len || !ws->num_local_canon || !topo->lc_inpos || !topo->lc_inmir) return AGDIFF_ERR_ARG;
-  return launch_edge_scales(p, ws->num_local_canon, topo->num_local_canon, ws->lc_len, topo->lc_inpos, topo->lc_inmir,
-                            ws->l_scale, ((topo->num_local + AG_TW - 1) / AG_TW) * AG_TW, stream);
+  if (!ws->l_scale || !ws->lc_len || !ws->num_local_canon || !topo->lc_ppos || !topo->lc_pmir) return AGDIFF_ERR_ARG;
+  return launch_edge_scales(p, ws->num_local_canon, topo->num_local_canon, ws->lc_len, topo->lc_ppos, topo->lc_pmir,
+                            ws->l_scale, ((topo->num_local_padded + AG_TW - 1) / AG_TW) * AG_TW, stream);
 }
 
 namespace {
@@ -1386,28 +1386,28 @@ extern "C" int agdiff_cfconv_fused(const agdiff_params_t* p, const agdiff_topo_t
 extern "C" int agdiff_local_poly_enabled(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws) {
   static const bool off = getenv("AGDIFF_LOCAL_POLY_OFF") != nullptr;      // A/B runs
   return !off && p && topo && ws && p->poly_kt == 1 && p->poly_num_slots > 0 && p->poly_num_slots <= AGDIFF_POLY_MAX_SLOTS &&
-         p->poly_type_slot && topo->loc_in_type && ws->l_len_in;
+         p->poly_type_slot && topo->lp_type && ws->l_len_p;
 }
 
 extern "C" int agdiff_cfconv_local(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k,
                                    void* stream) {
   if (!p || !topo || !ws || k < 0 || k >= p->num_convs) return AGDIFF_ERR_ARG;
   if (topo->num_local == 0) return AGDIFF_OK;
-  if (!topo->loc_in_ptr || !topo->loc_in_src || !topo->loc_in_dst || !ws->l_scale || !ws->l_attr_frag || !ws->agg_loc ||
-      !ws->agg_first_loc || !ws->num_local)
+  if (!topo->lp_ptr || !topo->lp_src || !topo->lp_dst || !ws->l_scale || !ws->l_attr_frag || !ws->agg_loc ||
+      !ws->agg_first_loc || !ws->num_local_padded)
     return AGDIFF_ERR_ARG;
   if (agdiff_local_poly_enabled(p, topo, ws)) {
     // every local type of this batch has a filter polynomial: the radius kernel's typed variant on the local list
-    const int64_t max_tiles = (topo->num_local + AG_TW - 1) / AG_TW;
-    const int chunk_tiles = agdiff_conv_chunk_tiles(topo->num_local);
+    const int64_t max_tiles = (topo->num_local_padded + AG_TW - 1) / AG_TW;
+    const int chunk_tiles = agdiff_conv_chunk_tiles(topo->num_local_padded);
     const int64_t max_chunks = (max_tiles + chunk_tiles - 1) / chunk_tiles;
     RadConvArgs a;
     a.poly_pk = p->conv[k].filt_poly_typed_pk;
-    a.n_dev = ws->num_local;
-    a.in_ptr = topo->loc_in_ptr;
-    a.e_src = topo->loc_in_src;
-    a.e_dst = topo->loc_in_dst;
-    a.e_len = ws->l_len_in;
+    a.n_dev = ws->num_local_padded;
+    a.in_ptr = topo->lp_ptr;
+    a.e_src = topo->lp_src;
+    a.e_dst = topo->lp_dst;
+    a.e_len = ws->l_len_p;
     const size_t epad = (size_t)max_tiles * AG_TW;
     a.scale1 = ws->l_scale + (size_t)(2 * k) * epad;
     a.scale2 = ws->l_scale + (size_t)(2 * k + 1) * epad;
@@ -1417,7 +1417,7 @@ extern "C" int agdiff_cfconv_local(const agdiff_params_t* p, const agdiff_topo_t
     a.max_chunks = max_chunks;
     a.chunk_tiles = chunk_tiles;
     a.two_over_rc = 2.0f / p->cutoff;
-    a.e_type = topo->loc_in_type;
+    a.e_type = topo->lp_type;
     a.type_slot = p->poly_type_slot;
     a.num_slots = p->poly_num_slots;
     int64_t wgs = (max_chunks + AG_LOCP_WAVES - 1) / AG_LOCP_WAVES;
@@ -1425,7 +1425,7 @@ extern "C" int agdiff_cfconv_local(const agdiff_params_t* p, const agdiff_topo_t
     return p->precision == AG_BF3 ? launch_cfconv_local_poly_t<AG_BF3>(a, wgs, stream)
                                   : launch_cfconv_local_poly_t<AG_F32>(a, wgs, stream);
   }
-  return launch_cfconv_fused(p, k, topo->num_local, ws->num_local, topo->loc_in_ptr, topo->loc_in_src, topo->loc_in_dst,
+  return launch_cfconv_fused(p, k, topo->num_local_padded, ws->num_local_padded, topo->lp_ptr, topo->lp_src, topo->lp_dst,
                              ws->l_scale, ws->l_attr_frag, ws->xs, ws->agg_loc, ws->agg_first_loc, stream);
 }
 

@@ -331,7 +331,7 @@ __global__ void k_local_lengths(const int32_t* __restrict__ src, const int32_t* 
   clen[c] = v;
   len[cpos[c]] = v;
   if (cmir[c] >= 0) len[cmir[c]] = v;
-  if (len_in) {          // the same by in-slot (the local list as a destination-sorted list of its own)
+  if (len_in) {          // the same by padded-list position (agdiff_topo_t.lp_*)
     len_in[inpos[c]] = v;
     if (inmir[c] >= 0) len_in[inmir[c]] = v;
   }
@@ -414,10 +414,10 @@ extern "C" int agdiff_local_lengths(const agdiff_topo_t* topo, const agdiff_ws_t
   if (topo->num_local == 0) return AGDIFF_OK;
   if (!topo->lc_src || !topo->lc_dst || !topo->lc_pos || !topo->lc_mir || topo->num_local_canon <= 0) return AGDIFF_ERR_ARG;
   const int Lc = (int)topo->num_local_canon;
-  const bool by_slot = ws->l_len_in && topo->lc_inpos && topo->lc_inmir;
+  const bool by_slot = ws->l_len_p && topo->lc_ppos && topo->lc_pmir;
   k_local_lengths<<<(Lc + 255) / 256, 256, 0, (hipStream_t)stream>>>(topo->lc_src, topo->lc_dst, topo->lc_pos, topo->lc_mir,
-                                                                     pos, ws->l_len, ws->lc_len, Lc, topo->lc_inpos,
-                                                                     topo->lc_inmir, by_slot ? ws->l_len_in : nullptr);
+                                                                     pos, ws->l_len, ws->lc_len, Lc, topo->lc_ppos,
+                                                                     topo->lc_pmir, by_slot ? ws->l_len_p : nullptr);
   AG_CHECK_LAUNCH();
   return AGDIFF_OK;
 }

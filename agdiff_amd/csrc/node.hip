@@ -834,7 +834,7 @@ extern "C" int agdiff_schnet_node_stage(const agdiff_params_t* p, const agdiff_t
 extern "C" int agdiff_schnet_node_stage_split(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
                                               int32_t k, int32_t split, void* stream) {
   if (!p || !topo || !ws || k < 0 || k > p->num_convs || p->num_convs > AGDIFF_MAX_CONVS) return AGDIFF_ERR_ARG;
-  if (split && (!ws->rad_ptr || !ws->agg_loc || !ws->agg_first_loc || !topo->loc_in_ptr)) return AGDIFF_ERR_ARG;
+  if (split && (!ws->rad_ptr || !ws->agg_loc || !ws->agg_first_loc || !topo->lp_ptr)) return AGDIFF_ERR_ARG;
   if (topo->num_nodes <= 0) return AGDIFF_OK;
   NodeStageArgs a;
   a.finish = k > 0;
@@ -858,10 +858,10 @@ extern "C" int agdiff_schnet_node_stage_split(const agdiff_params_t* p, const ag
     a.in_ptr = ws->rad_ptr;
     a.chunk_edges = AG_TW * agdiff_conv_chunk_tiles(topo->max_edges - topo->num_local);
     if (topo->num_local > 0) {
-      a.in_ptr2 = topo->loc_in_ptr;
+      a.in_ptr2 = topo->lp_ptr;
       a.agg2 = ws->agg_loc;
       a.agg_first2 = ws->agg_first_loc;
-      a.chunk_edges2 = AG_TW * agdiff_conv_chunk_tiles(topo->num_local);
+      a.chunk_edges2 = AG_TW * agdiff_conv_chunk_tiles(topo->num_local_padded);
     }
   }
   const int64_t tiles = (a.n + AG_TW - 1) / AG_TW;

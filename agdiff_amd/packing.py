@@ -211,8 +211,33 @@ def _poly_targets(sd, cfg, typ, with_head):
     return fns
 
 
-def fit_type(sd, cfg, typ, kt, with_head):
-    """({name: coefficient matrix in natural packed column order}, worst relative error) for edges of type `typ`."""
+_FIT_CACHE = {}      # (weights digest, cutoff, type, kt, with_head) -> fit_type result; a few MB at most
+
+
+def _poly_weights_digest(sd, cfg):
+    """Digest of every tensor the fitted functions depend on (edge encoder, filter networks, the head's first layer)."""
+    import hashlib
+    h = hashlib.sha1()
+    for k in sorted(sd):
+        if k.startswith("edge_encoder_global.") or ".nn." in k and k.startswith("encoder_global.") or \
+                k == "grad_global_dist_mlp.layers.0.weight":
+            h.update(k.encode())
+            h.update(np.ascontiguousarray(sd[k].detach().cpu().numpy()).tobytes())
+    return h.hexdigest()
+
+
+def fit_type(sd, cfg, typ, kt, with_head, digest=None):
+    """({name: coefficient matrix in natural packed column order}, worst relative error) for edges of type `typ`.
+    Results are cached per process by the digest of the weights they depend on."""
+    key = (digest or _poly_weights_digest(sd, cfg), float(cfg.cutoff), int(cfg.num_convs), int(typ), int(kt), bool(with_head))
+    if key not in _FIT_CACHE:
+        if len(_FIT_CACHE) > 256:
+            _FIT_CACHE.clear()
+        _FIT_CACHE[key] = _fit_type(sd, cfg, typ, kt, with_head)
+    return _FIT_CACHE[key]
+
+
+def _fit_type(sd, cfg, typ, kt, with_head):
     order = poly_feature_order(kt)
     mats, worst = {}, 0.0
     for name, fn in _poly_targets(sd, cfg, typ, with_head).items():
@@ -222,14 +247,15 @@ def fit_type(sd, cfg, typ, kt, with_head):
     return mats, worst
 
 
-def radius_polynomials(sd, cfg, tol=POLY_TOL, max_kt=POLY_MAX_KT):
+def radius_polynomials(sd, cfg, tol=POLY_TOL, max_kt=POLY_MAX_KT, min_kt=1):
     """(poly_kt, {name: coefficient matrix}, errors) or (0, {}, errors) when no degree up to 32 max_kt - 1 meets `tol`
-    (or the edge encoder is not the MLP one)."""
+    (or the edge encoder is not the MLP one).  min_kt > 1 skips the shorter expansions (tests of the two-k-tile kernels)."""
     if cfg.edge_encoder != "mlp":
         return 0, {}, {}
     errors = {}
-    for kt in range(1, max_kt + 1):
-        mats, worst = fit_type(sd, cfg, 0, kt, True)
+    digest = _poly_weights_digest(sd, cfg)
+    for kt in range(min_kt, max_kt + 1):
+        mats, worst = fit_type(sd, cfg, 0, kt, True, digest)
         errors[kt] = worst
         if worst <= tol:
             return kt, mats, errors
@@ -245,15 +271,19 @@ class PackedParams:
 
     def __init__(self, sd, cfg, device, precision="f32", radius_poly="auto"):
         """radius_poly: "auto" -- radius edges take their filters from d-polynomials when the fit is accepted
-        (radius_polynomials above); "off" -- every edge goes through the encoder + filter MLPs."""
+        (radius_polynomials above), and so do the local edges, per type (ensure_local_types); "off" -- every edge goes
+        through the encoder + filter MLPs; "radius" -- polynomials for the radius edges only; "kt2" -- as "auto" but
+        starting at 64 terms (the variants exist for tests and A/B runs)."""
         import torch
         self.device = device
-        if radius_poly not in ("auto", "off"):
-            raise ValueError("radius_poly must be 'auto' or 'off'")
-        self.poly_kt, self._poly, self.poly_errors = (0, {}, {}) if radius_poly == "off" else radius_polynomials(sd, cfg)
+        if radius_poly not in ("auto", "off", "radius", "kt2"):
+            raise ValueError("radius_poly must be one of 'auto', 'off', 'radius', 'kt2'")
+        self.poly_kt, self._poly, self.poly_errors = (0, {}, {}) if radius_poly == "off" else \
+            radius_polynomials(sd, cfg, min_kt=2 if radius_poly == "kt2" else 1)
         # local edge types with filter polynomials (ensure_local_types): type -> slot, grown as batches bring new types
         self._sd, self._cfg, self._mode = sd, cfg, PRECISIONS.get(precision, 0)
-        self.local_slots, self._typed_mats, self._typed_ok = {}, {}, self.poly_kt == 1
+        self.local_slots, self._typed_mats = {}, {}
+        self._typed_ok = self.poly_kt == 1 and radius_poly != "radius"
         self.typed_flat = self.slot_table = None
         if precision not in PRECISIONS:
             raise ValueError("precision must be one of %s" % (list(PRECISIONS),))

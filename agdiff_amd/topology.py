@@ -111,14 +111,28 @@ class BatchTopology:
         self.lc_src, self.lc_dst, self.lc_type = i32(src[lc_pos]), i32(dst[lc_pos]), i32(typ[lc_pos])
         self.lc_pos, self.lc_mir, self.loc_row = i32(lc_pos), i32(lc_mir), i32(loc_row)
         self.loc_in_src, self.loc_in_row = i32(src[in_order]), i32(loc_row[in_order])
-        # the local list as a destination-sorted edge list of its own (split CFConv: agdiff_ws_t.l_attr_frag / l_scale)
-        inslot = np.empty(L, dtype=np.int64)
-        inslot[in_order] = np.arange(L)
-        self.loc_in_dst = i32(dst[in_order])
-        self.loc_in_type = i32(typ[in_order])
+        # the local list as a destination-sorted edge list of its own for the split CFConv, every target's list padded to
+        # a multiple of 8 entries (agdiff_topo_t.lp_*: a 16-edge tile then holds at most two targets)
+        pdeg = (locdeg + 7) // 8 * 8
+        lp_ptr = np.concatenate([[0], np.cumsum(pdeg)])
+        Lp = int(lp_ptr[-1])
+        tgt = np.repeat(np.arange(N), pdeg)                               # target of every padded entry
+        k_in = np.arange(Lp) - lp_ptr[tgt]                                # its index inside the target's list
+        real = k_in < locdeg[tgt]
+        slot = np.minimum(in_ptr[tgt] + k_in, max(L - 1, 0))              # in-slot of a real entry
+        first = in_order[np.minimum(in_ptr[tgt], max(L - 1, 0))] if L else np.zeros(Lp, dtype=np.int64)
+        eid = np.where(real, in_order[slot], first) if L else np.zeros(0, dtype=np.int64)
+        ppos = np.empty(L, dtype=np.int64)                                 # local edge id -> padded position
+        ppos[eid[real]] = np.nonzero(real)[0]
+        self.Lp = Lp
+        self.lp_ptr = i32(lp_ptr)
+        self.lp_src = i32(np.where(real, src[eid], tgt) if L else tgt)
+        self.lp_dst = i32(tgt)
+        self.lp_type = i32(typ[eid] if L else np.zeros(Lp))
+        self.lp_row = i32(np.where(real, loc_row[eid], -1) if L else np.zeros(Lp))
+        self.lc_ppos = i32(ppos[lc_pos])
+        self.lc_pmir = i32(np.where(lc_mir >= 0, ppos[np.maximum(lc_mir, 0)], -1))
         self.local_types = np.unique(typ)                 # PackedParams.ensure_local_types (per-type filter polynomials)
-        self.lc_inpos = i32(inslot[lc_pos])
-        self.lc_inmir = i32(np.where(lc_mir >= 0, inslot[np.maximum(lc_mir, 0)], -1))
         # int64 copies of the local edges for the API results (forward() returns int64 indices)
         self.loc_index64 = torch.from_numpy(np.stack([src, dst])).to(device)
         self.loc_type64 = torch.from_numpy(typ).to(device)
@@ -129,9 +143,10 @@ class BatchTopology:
         t.num_nodes, t.num_graphs, t.num_local = N, G, L
         t.max_edges, t.max_atoms_per_graph, t.max_in_degree = self.max_edges, self.max_atoms, self.max_in_degree
         t.num_local_canon = self.Lc
+        t.num_local_padded = self.Lp
         for f in ("graph_ptr", "atom_type", "loc_src", "loc_dst", "loc_type", "loc_out_ptr", "loc_in_ptr", "loc_in_eid",
                   "lc_src", "lc_dst", "lc_type", "lc_pos", "lc_mir", "loc_row", "loc_in_src",
-                  "loc_in_row", "loc_in_dst", "lc_inpos", "lc_inmir", "loc_in_type"):
+                  "loc_in_row", "lp_ptr", "lp_src", "lp_dst", "lp_type", "lp_row", "lc_ppos", "lc_pmir"):
             setattr(t, f, _lib.ptr(getattr(self, f)))
         self.struct = t
 
@@ -183,16 +198,19 @@ class Workspace:
         # split CFConv (radius edges by polynomial filters + local edges through the filter MLPs)
         R = max(E - L, 0)
         rtiles = (R + TW - 1) // TW
-        lchunk = _lib.load().agdiff_conv_chunk_tiles(L)
+        Lp = topo.Lp
+        ptiles = (Lp + TW - 1) // TW
+        lchunk = _lib.load().agdiff_conv_chunk_tiles(Lp)
         self.num_rad = i32(1)
         self.rad_ptr = i32(N + 1)
         self.rad_src, self.rad_dst, self.rad_len = i32(rtiles * TW), i32(rtiles * TW), f32(rtiles * TW)
         self.r_scale = f32(2 * _lib.DEFINES["AGDIFF_MAX_CONVS"] * rtiles * TW)
-        self.l_scale = f32(2 * _lib.DEFINES["AGDIFF_MAX_CONVS"] * ltiles * TW)
-        self.l_attr_frag = f32(ltiles * TW * 128)
-        self.l_len_in = f32(ltiles * TW)
+        self.num_local_padded = torch.tensor([Lp], dtype=torch.int32, device=dev)
+        self.l_scale = f32(2 * _lib.DEFINES["AGDIFF_MAX_CONVS"] * ptiles * TW)
+        self.l_attr_frag = f32(ptiles * TW * 128)
+        self.l_len_p = f32(ptiles * TW)
         self.agg_loc = f32(N * 192)
-        self.agg_first_loc = f32((ltiles + lchunk - 1) // lchunk * 192)
+        self.agg_first_loc = f32((ptiles + lchunk - 1) // lchunk * 192)
         w = _lib.Workspace()
         for f, _ in _lib.Workspace._fields_:
             setattr(w, f, _lib.ptr(getattr(self, f)))

@@ -190,6 +190,8 @@ def main():
     ap.add_argument("--breakdown", default=None, help="write per-op timings (ms) to this JSON file")
     ap.add_argument("--seed", type=int, default=2021)
     ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"])
+    ap.add_argument("--radius-poly", default="auto", choices=["auto", "radius", "kt2", "off"],
+                    help="filter polynomials (agdiff_amd/packing.py): off = every edge through the encoder + filter MLPs")
     ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL all-gather path even with one rank")
     ap.add_argument("--job-steps", type=int, default=JOB_STEPS, help="denoising steps of one sampling job (5000; the "
                     "alanine dipeptide example runs 100)")
@@ -235,6 +237,7 @@ def main():
         cfg = make_cfg(kind, schedule)
         m = get_model(cfg)
         m.precision = args.precision
+        m.radius_poly = args.radius_poly
         m.load_state_dict(synth.synth_state_dict(m.state_dict()))
         return m.to(dev).eval(), cfg
     model, cfg = make_model(args.schedule)
@@ -326,40 +329,75 @@ def main():
                  else "per GPU", run.topo.N, int(run.ws.num_edges.item()), run.topo.L, args.schedule, 100 * global_frac,
                  JOB_STEPS))
 
-    # ---- dominant kernel (fused CFConv) timed with events on the launch stream, workspace as the run left it
+    # ---- dominant operation (the two CFConvs of one InteractionBlock) timed with events on the launch stream, workspace as
+    # the run left it.  With the filter polynomials on (pk.poly_kt > 0) it is two launches -- k_cfconv_radius over the
+    # radius list and its typed variant (or k_cfconv_fused) over the padded local list --, otherwise one k_cfconv_fused.
     ws, topo, pk = run.ws, run.topo, run.pk
     stream = _lib.stream_ptr()
     E = int(ws.num_edges.item())
+    poly_info = {"mode": args.radius_poly, "poly_kt": pk.poly_kt, "local_type_slots": int(pk.struct.poly_num_slots),
+                 "fit_errors_vs_float64_networks": {str(k): v for k, v in pk.poly_errors.items()}}
     roof = None
     if E > 0 and rank == 0:
-        reps, evs = 5, []
+        P_, T_, W_ = ctypes.byref(pk.struct), ctypes.byref(topo.struct), ctypes.byref(ws.struct)
+        split = pk.poly_kt > 0
+        if split:
+            calls = [("radius", lambda k: lib.agdiff_cfconv_radius(P_, T_, W_, k, stream)),
+                     ("local", lambda k: lib.agdiff_cfconv_local(P_, T_, W_, k, stream))]
+        else:
+            calls = [("all", lambda k: lib.agdiff_cfconv_fused(P_, T_, W_, k, stream))]
+        reps, evs = 5, {n: [] for n, _ in calls}
         for _ in range(reps):
             for k in range(cfg.num_convs):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                lib.agdiff_cfconv_fused(ctypes.byref(pk.struct), ctypes.byref(topo.struct), ctypes.byref(ws.struct), k, stream)
-                e1.record()
-                evs.append((e0, e1))
+                for n, fn in calls:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    fn(k)
+                    e1.record()
+                    evs[n].append((e0, e1))
         torch.cuda.synchronize()
-        avg_ms = sum(a.elapsed_time(bb) for a, bb in evs) / len(evs)
+        part_ms = {n: sum(a.elapsed_time(bb) for a, bb in v) / len(v) for n, v in evs.items()}
+        avg_ms = sum(part_ms.values())
         ach = E * FLOP_PER_EDGE_CFCONV / (avg_ms * 1e-3) / 1e12
         pk_ = PEAK[args.precision]
         # HBM bytes per launch come from a separate rocprofv3 --pmc pass (tools/pmc_traffic.sh); the committed
         # figure applies to the workload it was taken on (same edge count within 1%), otherwise null
         traffic = None
-        for rnd in ("r02", "r01"):
+        names = ["k_cfconv_radius", "k_cfconv_local"] if split else ["k_cfconv_fused"]
+        for rnd in ("r02b", "r02", "r01"):
             tf = os.path.join(ROOT, "profiles", "%s_%s_pmc_traffic.json" % (rnd, args.precision))
             if os.path.exists(tf):
                 tj = json.load(open(tf))
-                if abs(tj.get("workload_edges", 0) - E) <= 0.01 * E:
-                    traffic = tj["kernels"]["k_cfconv_fused"]["hbm_bytes_per_launch"]
-                break
-        roof = {"kernel": "k_cfconv_fused", "bound": "mfma", "achieved": ach, "peak": pk_, "unit": "TFLOP/s",
+                if abs(tj.get("workload_edges", 0) - E) <= 0.01 * E and all(n in tj["kernels"] for n in names):
+                    traffic = sum(tj["kernels"][n]["hbm_bytes_per_launch"] for n in names)
+                    break
+        R = int(ws.num_rad.item()) if split else 0
+        if split:
+            local_poly = bool(lib.agdiff_local_poly_enabled(P_, T_, W_))
+            kernel = ("k_cfconv_radius<NKT=%d> (radius list, %d edges) + %s (padded local list, %d edges + %d pad entries)"
+                      % (pk.poly_kt, R, "k_cfconv_radius<typed>" if local_poly else "k_cfconv_fused", topo.L, topo.Lp - topo.L))
+            note = ("one InteractionBlock's two CFConvs = two launches (radius list + local list), avg_launch_ms is their sum; "
+                    "achieved prices the REFERENCE's arithmetic -- E x 90,112 FLOP: it evaluates the 128->192->192 filter "
+                    "network on every directed edge -- over that time.  The kernels themselves issue far fewer MFMA FLOPs: "
+                    "the filter of an edge is a 32-term polynomial in its length (fitted to the networks in float64 at load "
+                    "time, accepted at <= 1e-6; DESIGN.md), E x 192 x 32 x 2 x %d FLOP per launch pair; what bounds them is "
+                    "the x[src] row gathers (768 B per edge through L1/L2) and the segmented reduction, not MFMA or HBM"
+                    % MFMA_PASSES[args.precision])
+            issued = E * 192 * 32 * pk.poly_kt * 2 * MFMA_PASSES[args.precision] / (avg_ms * 1e-3) / 1e12
+        else:
+            kernel = "k_cfconv_fused"
+            note = ("achieved = algorithmic FLOPs (E x 90,112: the reference evaluates the filter network on every "
+                    "directed edge) / launch time; bf16x3 issues 3 bf16 MFMA FLOPs per algorithmic FLOP (hi.hi + "
+                    "lo.hi + hi.lo), fp32 accumulate")
+            issued = ach * MFMA_PASSES[args.precision]
+        roof = {"kernel": kernel, "bound": "mfma", "achieved": ach, "peak": pk_, "unit": "TFLOP/s",
                 "frac": ach / pk_, "traffic": traffic, "avg_launch_ms": avg_ms, "edges_per_launch": E,
-                "mfma_issued_tflops": ach * MFMA_PASSES[args.precision],
-                "note": "achieved = algorithmic FLOPs (E x 90,112: the reference evaluates the filter network on every "
-                        "directed edge) / launch time; bf16x3 issues 3 bf16 MFMA FLOPs per algorithmic FLOP (hi.hi + "
-                        "lo.hi + hi.lo), fp32 accumulate"}
+                "launch_ms_by_kernel": part_ms, "mfma_issued_tflops": issued, "note": note}
+        if split:
+            # the same operation against the HBM roofline: what one launch pair has to move at least
+            nbytes = E * 16 + topo.N * 192 * 4 * 3          # per edge src + length + 2 scales; xs read once, two aggregates written
+            roof["hbm_view"] = {"algorithmic_bytes": nbytes, "achieved_GBps": nbytes / (avg_ms * 1e-3) / 1e9, "peak_GBps": 8000.0,
+                                "frac": nbytes / (avg_ms * 1e-3) / 1e9 / 8000.0}
 
     # ---- stand-alone CFConv aggregate (PyG propagate x_j * W, schnet.py:156-162) on the same graph: the HBM-bound
     # "scatter" kernel BASELINE.json's north_star prices against the HBM roofline (unfused form: W[E,F] streamed)
@@ -412,6 +450,16 @@ def main():
         timeit("local_head", lambda: lib.agdiff_pair_head(ctypes.byref(pk.struct.head_local), _lib.ptr(ws.num_local_canon), ct, _lib.ptr(topo.lc_src), _lib.ptr(topo.lc_dst), _lib.ptr(ws.hl), None, _lib.ptr(ws.l_attr_rows), _lib.ptr(topo.lc_pos), _lib.ptr(topo.lc_mir), _lib.ptr(ws.l_inv), stream))
         timeit("local_branch", lambda: lib.agdiff_score_forward(P, Tp, Wp, run.pos_p, 0, stream))
         timeit("score_forward_global", lambda: lib.agdiff_score_forward(P, Tp, Wp, run.pos_p, 1, stream))
+        if pk.poly_kt > 0:       # the split path the sampler runs (the entries above time the one-list kernels on the same graph)
+            nc = cfg.num_convs
+            timeit("split_scales_radius", lambda: lib.agdiff_edge_scales_split(P, Tp, Wp, 0, stream))
+            timeit("split_scales_local", lambda: lib.agdiff_edge_scales_split(P, Tp, Wp, 1, stream))
+            timeit("split_cfconv_radius_x%d" % nc, lambda: [lib.agdiff_cfconv_radius(P, Tp, Wp, k, stream) for k in range(nc)])
+            timeit("split_cfconv_local_x%d" % nc, lambda: [lib.agdiff_cfconv_local(P, Tp, Wp, k, stream) for k in range(nc)])
+            timeit("split_node_stage_x%d" % (nc + 1), lambda: [lib.agdiff_schnet_node_stage_split(P, Tp, Wp, k, 1, stream) for k in range(nc + 1)])
+            timeit("split_head_poly", lambda: lib.agdiff_pair_head_poly(P, _lib.ptr(ws.num_canon), et, _lib.ptr(ws.c_src), _lib.ptr(ws.c_dst), _lib.ptr(ws.c_len), _lib.ptr(ws.h), _lib.ptr(ws.c_pos), _lib.ptr(ws.c_mir), _lib.ptr(ws.e_inv_global), stream))
+            timeit("score_forward_global_sampler", lambda: lib.agdiff_score_forward(P, Tp, Wp, run.pos_p, 1 | 8, stream))
+            ops.update(R=int(ws.num_rad.item()), Lp=topo.Lp, poly_kt=pk.poly_kt, local_poly_slots=int(pk.struct.poly_num_slots))
         # the same launches on all-zero operands (same instruction stream: nothing in the kernel branches on values);
         # a large drop means the launch time is set by the clock the chip holds under load, not by cycle counts
         ws.e_attr.zero_(); ws.xs.zero_()
@@ -452,7 +500,7 @@ def main():
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": wl, "conformers_total": G_total, "parallelism": "dp%d" % world,
                        "all_gather_per_step": bool(use_dist), "trajectory_saved": save_traj,
-                       "skip_discarded_global": skip},
+                       "skip_discarded_global": skip, "filter_polynomials": poly_info},
             "roofline": roof, "roofline_cfconv_aggregate": agg_roof, "cpu_baseline": cpu, "extra": extra,
         }
         if per_batch is not None:

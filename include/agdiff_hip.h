@@ -184,10 +184,18 @@ typedef struct agdiff_topo {
   const int32_t* loc_row;    /* [L]: canonical index (row of l_attr_rows) of every local edge */
   const int32_t* loc_in_src; /* [L]: loc_src[loc_in_eid[s]] (the GIN gather reads its indices by in-slot, one level deep) */
   const int32_t* loc_in_row; /* [L]: loc_row[loc_in_eid[s]] */
-  const int32_t* loc_in_dst; /* [L]: loc_dst[loc_in_eid[s]] (the local list as a destination-sorted edge list of its own) */
-  const int32_t* lc_inpos;   /* [Lc]: in-slot s of the canonical edge (loc_in_eid[s] == lc_pos[c]) */
-  const int32_t* lc_inmir;   /* [Lc]: in-slot of its mirror, or -1 */
-  const int32_t* loc_in_type;/* [L]: loc_type[loc_in_eid[s]] */
+  /* the local list as a destination-sorted edge list of its own for the split CFConv, every target's list PADDED to a
+   * multiple of 8 entries: a 16-edge tile then holds at most two targets (local in-degrees are ~8: unpadded, most tiles
+   * would hold three or more and take the kernels' general reduction).  Pad entries: src = dst = the target, type of the
+   * list's first edge, and nothing ever writes their CFConv scale (zero-initialised): they contribute exactly 0. */
+  int64_t num_local_padded;  /* Lp */
+  const int32_t* lp_ptr;     /* [N+1]: padded list of target i = [lp_ptr[i], lp_ptr[i+1]) */
+  const int32_t* lp_src;     /* [Lp] */
+  const int32_t* lp_dst;     /* [Lp] */
+  const int32_t* lp_type;    /* [Lp] */
+  const int32_t* lp_row;     /* [Lp]: canonical index (row of l_attr_rows) of the entry's edge, -1 for pad entries */
+  const int32_t* lc_ppos;    /* [Lc]: padded-list position of the canonical edge */
+  const int32_t* lc_pmir;    /* [Lc]: ... of its mirror, or -1 */
 } agdiff_topo_t;
 
 /* ---- workspace (device buffers the host allocates once per batch) ------------------------- */
@@ -251,11 +259,13 @@ typedef struct agdiff_ws {
   int32_t* rad_dst;          /* [max_edges - L] */
   float*   rad_len;          /* [max_edges - L] */
   float*   r_scale;          /* [2*num_convs][ceil((max_edges - L)/16)*16]: lw(d)*C(d) by radius-list position */
-  float*   l_scale;          /* [2*num_convs][ceil(L/16)*16]: the same by local in-slot */
-  float*   l_attr_frag;      /* [ceil(L/16)] tiles x 2048 floats: edge_attr of the local edges in operand form, by in-slot */
-  float*   l_len_in;         /* [L] lengths of the local edges by in-slot (written by agdiff_local_lengths next to l_len) */
+  int32_t* num_local_padded; /* [1]  Lp as a device scalar (written once by the host) */
+  float*   l_scale;          /* [2*num_convs][ceil(Lp/16)*16]: the same by padded-list position (pad entries stay 0) */
+  float*   l_attr_frag;      /* [ceil(Lp/16)] tiles x 2048 floats: edge_attr of the local edges in operand form, by padded-list
+                                position (only written / read when the local edges go through the filter MLPs) */
+  float*   l_len_p;          /* [Lp] lengths of the local edges by padded-list position (agdiff_local_lengths; pads stay 0) */
   float*   agg_loc;          /* [N][192] CFConv aggregates over the local edges */
-  float*   agg_first_loc;    /* [ceil(ceil(L/16) / agdiff_conv_chunk_tiles(L))][192] */
+  float*   agg_first_loc;    /* [ceil(ceil(Lp/16) / agdiff_conv_chunk_tiles(Lp))][192] */
 } agdiff_ws_t;
 
 typedef struct agdiff_step_args {
@@ -316,7 +326,7 @@ int agdiff_edge_encoder(const agdiff_params_t* p, const int32_t* n_edges_dev, in
  * k < num_convs also applies block k's conv{1,2}.lin1/BN/LeakyReLU into ws->xs. */
 int agdiff_schnet_node_stage(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k, void* stream);
 /* The same with split != 0: block k-1's aggregates are ws->agg (radius edges, lists ws->rad_ptr) + ws->agg_loc (local
- * edges, lists topo->loc_in_ptr) -- agdiff_cfconv_radius / agdiff_cfconv_local below. */
+ * edges, lists topo->lp_ptr) -- agdiff_cfconv_radius / agdiff_cfconv_local below. */
 int agdiff_schnet_node_stage_split(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k,
                                    int32_t split, void* stream);
 
@@ -327,15 +337,15 @@ int agdiff_cfconv_fused(const agdiff_params_t* p, const agdiff_topo_t* topo, con
 /* Split CFConv (agdiff_params_t.poly_kt > 0): block k's two convs as the sum of
  *   agdiff_cfconv_radius  over the radius edges (ws->rad_*, ws->r_scale; filters from the d-polynomials
  *                         p->conv[k].filt_poly_pk) -> ws->agg / ws->agg_first, and
- *   agdiff_cfconv_local   over the static local list by in-slot (topo->loc_in_*, ws->l_scale; filters from the per-type
- *                         d-polynomials p->conv[k].filt_poly_typed_pk at ws->l_len_in when every local type has a slot,
+ *   agdiff_cfconv_local   over the static, padded local list (topo->lp_*, ws->l_scale; filters from the per-type
+ *                         d-polynomials p->conv[k].filt_poly_typed_pk at ws->l_len_p when every local type has a slot,
  *                         else the filter MLPs on ws->l_attr_frag as in agdiff_cfconv_fused) -> ws->agg_loc / ws->agg_first_loc;
  * agdiff_schnet_node_stage adds the two.  agdiff_edge_scales_split fills ws->r_scale (which == 0) or ws->l_scale
  * (which == 1). */
 int agdiff_cfconv_radius(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k, void* stream);
 int agdiff_cfconv_local(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k, void* stream);
 /* 1 when agdiff_cfconv_local takes the local edges' filters from per-type d-polynomials (p->poly_num_slots > 0, poly_kt == 1,
- * topo->loc_in_type, ws->l_len_in), 0 when it evaluates the filter MLPs on ws->l_attr_frag. */
+ * topo->lp_type, ws->l_len_p), 0 when it evaluates the filter MLPs on ws->l_attr_frag. */
 int agdiff_local_poly_enabled(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws);
 int agdiff_edge_scales_split(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t which,
                              void* stream);

@@ -1,0 +1,179 @@
+"""GPU (MI355X): the filter-polynomial kernels (split CFConv: csrc/edge.hip k_cfconv_radius, its typed variant for the
+local list, k_pair_head_poly) and every fallback around them, against the reference fixtures and against the one-list
+kernels that evaluate the filter MLPs for every edge.  `radius_poly` (agdiff_amd/packing.py PackedParams):
+  auto    radius edges and every local edge type from d-polynomials (the default the other test files run)
+  radius  polynomials for the radius edges only, local edges through the filter MLPs on the padded local list
+  kt2     64-term expansions (two k-tiles; local edges through the MLPs)
+  off     one list, every edge through the encoder + filter MLPs (rounds 1-2a product path)"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import FORWARD_CASES, check_close, load_golden, sampler_case_cfg, sampler_case_kwargs, t
+
+pytestmark = pytest.mark.gpu
+MODES = ["auto", "radius", "kt2", "off"]
+
+
+def _model(cfg, mode, head_scale=1e-3, precision="bf16x3"):
+    from agdiff_amd import get_model
+    from oracle import agdiff_oracle as O
+    sd = O.synth_state_dict_for(cfg, head_scale=head_scale)
+    m = get_model(cfg)
+    m.precision, m.radius_poly = precision, mode
+    m.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+    return m.to("cuda:0").eval()
+
+
+def _one_pass(ptr, agg, first, chunk_edges, N):
+    """agg[node] plus the partial sums the node's later chunks kept in `first` (csrc/node.hip ag_agg_slice)."""
+    ip = ptr.cpu().numpy().astype(np.int64)
+    a = agg.view(-1, 192).cpu().double().numpy().copy()
+    f = first.view(-1, 192).cpu().double().numpy()
+    for i in range(N):
+        lo, hi = ip[i], ip[i + 1]
+        if hi <= lo:
+            a[i] = 0.0
+            continue
+        for c in range(lo // chunk_edges + 1, (hi - 1) // chunk_edges + 1):
+            a[i] += f[c]
+    return a
+
+
+def _aggregates(ws, topo, lib, split=False):
+    from agdiff_amd import _lib
+    ct = lambda n: _lib.TILE * lib.agdiff_conv_chunk_tiles(ctypes.c_int64(n))
+    if not split:
+        return _one_pass(ws.in_ptr, ws.agg, ws.agg_first, ct(topo.max_edges), topo.N)
+    return (_one_pass(ws.rad_ptr, ws.agg, ws.agg_first, ct(topo.max_edges - topo.L), topo.N) +
+            _one_pass(topo.lp_ptr, ws.agg_loc, ws.agg_first_loc, ct(topo.Lp), topo.N))
+
+
+def _expect(pk, mode):
+    assert pk.poly_kt == {"auto": 1, "radius": 1, "kt2": 2, "off": 0}[mode]
+    want_slots = mode == "auto"
+    assert (pk.struct.poly_num_slots > 0) == want_slots, (mode, pk.struct.poly_num_slots, pk.poly_errors)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("case", ["g3_forward_qm9_small", "g3_forward_drugs_capped"])
+def test_forward_every_filter_mode(case, mode, precision):
+    g = load_golden(case)
+    m = _model(FORWARD_CASES[case](), mode, precision=precision)
+    out = m(t(g["atom_type"]).cuda(), t(g["pos"]).cuda(), t(g["bond_index"]).cuda(), t(g["bond_type"]).cuda(),
+            t(g["batch"]).cuda(), None, return_edges=True, extend_order=False)
+    _expect(m.packed(), mode)
+    ws = m._batch_cache[2]
+    assert np.array_equal(out[2].cpu().numpy(), g["edge_index"]) and np.array_equal(out[3].cpu().numpy(), g["edge_type"])
+    if "schnet_out" in g:
+        check_close("poly[%s] schnet_out[%s]" % (mode, case), ws.h.view(-1, 128).cpu().numpy(), g["schnet_out"], precision)
+    check_close("poly[%s] inv_g[%s]" % (mode, case), out[0].cpu().numpy(), g["edge_inv_global"], precision)
+    check_close("poly[%s] inv_l[%s]" % (mode, case), out[1].cpu().numpy(), g["edge_inv_local"], precision)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("case", ["g5_sampler_lowT_global", "g5_sampler_mixed_cliplocal"])
+def test_sampler_every_filter_mode(case, mode, precision):
+    """The denoising loop (polynomial global head on the radius edges in every mode but `off`)."""
+    g = load_golden(case)
+    m = _model(sampler_case_cfg(g, case), mode, head_scale=float(g["head_scale"]), precision=precision)
+    pos, traj = m.langevin_dynamics_sample_diffusion(
+        t(g["atom_type"]).cuda(), t(g["pos_init"]).cuda(), t(g["bond_index"]).cuda(), t(g["bond_type"]).cuda(),
+        t(g["batch"]).cuda(), int(g["num_graphs"]), extend_order=False, n_steps=int(g["n_steps"]),
+        noise=t(g["noise"]).cuda(), **sampler_case_kwargs(g))
+    _expect(m.packed(), mode)
+    check_close("poly[%s] traj[%s]" % (mode, case), torch.stack(traj).numpy(), g["traj"], precision)
+    check_close("poly[%s] pos[%s]" % (mode, case), pos.cpu().numpy(), g["pos_final"], precision)
+
+
+@pytest.mark.parametrize("kind,mols,copies", [("drugs", 5, 4), ("qm9", 7, 5)])
+def test_split_cfconv_equals_one_list_kernel(kind, mols, copies):
+    """Kernel level, through the C ABI: on the same graph, node inputs and block, the radius pass + the local pass
+    (polynomial filters) add up to what agdiff_cfconv_fused (filter MLPs on every edge) aggregates; the radius list is
+    the type-0 subsequence of the full list; padded local entries contribute exactly nothing."""
+    from agdiff_amd import _lib, drugs_model_config, qm9_model_config, synth
+    lib = _lib.load()
+    cfg = (qm9_model_config if kind == "qm9" else drugs_model_config)(num_diffusion_timesteps=50, beta_end=2e-5)
+    for precision in ("f32", "bf16x3"):
+        m = _model(cfg, "auto", precision=precision)
+        b = synth.make_packed_batch(kind, mols, copies, seed=17)
+        at, bi, bt, ba = [t(b[k]).cuda() for k in ("atom_type", "bond_index", "bond_type", "batch")]
+        pos = (torch.randn(at.shape[0], 3, generator=torch.Generator().manual_seed(2)) * 2.0).cuda()
+        m(at, pos, bi, bt, ba, None, return_edges=True, extend_order=False)     # full forward: e_attr, scales of every list
+        topo, ws, pk = m._batch_cache[1], m._batch_cache[2], m.packed()
+        assert pk.struct.poly_num_slots > 0 and lib.agdiff_local_poly_enabled(
+            ctypes.byref(pk.struct), ctypes.byref(topo.struct), ctypes.byref(ws.struct)) == 1
+        P, T, W, st = ctypes.byref(pk.struct), ctypes.byref(topo.struct), ctypes.byref(ws.struct), _lib.stream_ptr()
+        E, R = int(ws.num_edges.item()), int(ws.num_rad.item())
+        ety = ws.e_type[:E].cpu().numpy()
+        assert R == int((ety == 0).sum()) and R + topo.L == E
+        for name, full, rad in (("src", ws.e_src, ws.rad_src), ("dst", ws.e_dst, ws.rad_dst), ("len", ws.e_len, ws.rad_len)):
+            assert np.array_equal(full[:E].cpu().numpy()[ety == 0], rad[:R].cpu().numpy()), name
+        rp = ws.rad_ptr.cpu().numpy()
+        assert rp[-1] == R and np.array_equal(np.diff(rp), np.bincount(ws.rad_dst[:R].cpu().numpy(), minlength=topo.N))
+        assert lib.agdiff_edge_scales(P, T, W, 1, st) == 0
+        # ws.xs holds lin1 outputs of the last block after the forward: any block's filters may be applied to them
+        for k in (0, cfg.num_convs - 1):
+            assert lib.agdiff_cfconv_fused(P, T, W, k, st) == 0
+            torch.cuda.synchronize()
+            ref = _aggregates(ws, topo, lib)
+            ws.agg.zero_(); ws.agg_first.zero_()
+            assert lib.agdiff_cfconv_radius(P, T, W, k, st) == 0 and lib.agdiff_cfconv_local(P, T, W, k, st) == 0
+            torch.cuda.synchronize()
+            got = _aggregates(ws, topo, lib, split=True)
+            check_close("split_cfconv[%s] block %d" % (kind, k), got, ref, precision)
+
+
+def test_rejected_fit_falls_back_to_the_mlps():
+    """A first layer too sharp for 64 terms at 1e-6: the polynomials are refused at load time and every edge goes through
+    the encoder + filter MLPs; results still match the oracle."""
+    from agdiff_amd import get_model, qm9_model_config, synth
+    from oracle import agdiff_oracle as O
+    cfg = qm9_model_config(num_diffusion_timesteps=30, beta_end=2e-5)
+    sd = O.synth_state_dict_for(cfg)
+    for k in ("edge_encoder_global.feature_expansion.weight", "model_global.0.feature_expansion.weight"):
+        sd[k] = sd[k] * 40.0
+    m = get_model(cfg)
+    m.load_state_dict({k: v.clone() for k, v in sd.items()})
+    m = m.to("cuda:0").eval()
+    b = synth.make_packed_batch("qm9", 2, 2, seed=3)
+    at, bi, bt, ba = [t(b[k]) for k in ("atom_type", "bond_index", "bond_type", "batch")]
+    g = torch.Generator().manual_seed(5)
+    pos_init, noise = torch.randn(at.shape[0], 3, generator=g), torch.randn(4, at.shape[0], 3, generator=g)
+    kw = dict(extend_order=False, n_steps=4, w_global=1.0, global_start_sigma=0.5, clip=1000.0)
+    ref, _ = O.langevin_dynamics_sample_diffusion(sd, cfg, at, pos_init, bi, bt, ba, b["num_graphs"], noise=noise, **kw)
+    got, _ = m.langevin_dynamics_sample_diffusion(at.cuda(), pos_init.cuda(), bi.cuda(), bt.cuda(), ba.cuda(),
+                                                  b["num_graphs"], noise=noise.cuda(), **kw)
+    pk = m.packed()
+    assert pk.poly_kt == 0 and pk.struct.poly_num_slots == 0 and min(pk.poly_errors.values()) > 1e-6, pk.poly_errors
+    check_close("rejected_fit sampler", got.cpu().numpy(), ref.numpy(), "bf16x3")
+
+
+def test_more_local_types_than_slots_uses_the_mlps_for_local_edges():
+    """Seven distinct bond types in one batch (AGDIFF_POLY_MAX_SLOTS = 6): the local list goes through the filter MLPs,
+    the radius edges keep their polynomials; against the oracle."""
+    from agdiff_amd import get_model, qm9_model_config
+    from oracle import agdiff_oracle as O
+    cfg = qm9_model_config(num_diffusion_timesteps=30, beta_end=2e-5)
+    sd = O.synth_state_dict_for(cfg)
+    m = get_model(cfg)
+    m.load_state_dict({k: v.clone() for k, v in sd.items()})
+    m = m.to("cuda:0").eval()
+    n = 9                                                   # a chain with a different bond type on every link
+    src = np.arange(n - 1); dst = src + 1
+    bi = torch.from_numpy(np.concatenate([np.stack([src, dst]), np.stack([dst, src])], axis=1)).long()
+    bt = torch.from_numpy(np.concatenate([np.arange(1, n), np.arange(1, n)])).long()        # types 1..8
+    at = torch.full((n,), 6, dtype=torch.long); ba = torch.zeros(n, dtype=torch.long)
+    g = torch.Generator().manual_seed(9)
+    pos_init, noise = torch.randn(n, 3, generator=g), torch.randn(3, n, 3, generator=g)
+    kw = dict(extend_order=False, n_steps=3, w_global=1.0, global_start_sigma=0.5, clip=1000.0)
+    ref, _ = O.langevin_dynamics_sample_diffusion(sd, cfg, at, pos_init, bi, bt, ba, 1, noise=noise, **kw)
+    got, _ = m.langevin_dynamics_sample_diffusion(at.cuda(), pos_init.cuda(), bi.cuda(), bt.cuda(), ba.cuda(), 1,
+                                                  noise=noise.cuda(), **kw)
+    pk = m.packed()
+    assert pk.poly_kt == 1 and pk.struct.poly_num_slots == 0
+    check_close("too_many_local_types sampler", got.cpu().numpy(), ref.numpy(), "bf16x3")

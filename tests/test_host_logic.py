@@ -208,3 +208,93 @@ def test_canonical_local_edge_list():
     for e in unpaired:
         assert key.get((int(dst[e]), int(src[e])), -1) != int(typ[e])
     assert (int(c0), int(r0)) in {(int(src[e]), int(dst[e])) for e in unpaired}
+
+
+# ---------------------------------------------------------------------------------- filter polynomials (host side)
+def test_poly_basis_and_feature_order():
+    from agdiff_amd import packing
+    x = np.linspace(-1, 1, 513)
+    for K in (32, 64):
+        ph = packing.poly_features(x, K)
+        Tn = np.polynomial.chebyshev.chebvander(x, K - 1)
+        assert np.abs(ph - Tn @ packing.poly_basis_matrix(K)).max() < 1e-12          # phi = T_{8g} T_j, product rule
+        assert np.linalg.cond(packing.poly_basis_matrix(K)) < 20
+        order = packing.poly_feature_order(K // 32)
+        assert sorted(order.tolist()) == list(range(K))
+    o = packing.poly_feature_order(1)      # element j of quarter q sits at natural column 16 (j >> 2) + 4 q + (j & 3)
+    assert o[0] == 0 and o[3] == 3 and o[4] == 8 and o[16] == 4 and o[31] == 31
+
+
+@pytest.mark.parametrize("which", ["synth", "default_init"])
+def test_filter_polynomials_reproduce_the_networks(which):
+    """The accepted fits against the ORACLE's encoder + filter network evaluated in float64 at lengths that are not fit
+    nodes, for a radius type and the local types of the synthetic molecules."""
+    import torch
+    from agdiff_amd import drugs_model_config, get_model, packing
+    from oracle import agdiff_oracle as O
+    cfg = drugs_model_config()
+    if which == "synth":
+        sd = O.synth_state_dict_for(cfg)
+    else:
+        torch.manual_seed(1)
+        sd = get_model(cfg).state_dict()
+    kt, mats, errs = packing.radius_polynomials(sd, cfg)
+    assert kt == 1 and errs[1] < 1e-8
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    d = torch.rand(257, 1, dtype=torch.float64, generator=torch.Generator().manual_seed(0)) * cfg.cutoff
+    inv = np.argsort(packing.poly_feature_order(1))        # phi index -> natural packed column
+    ph = packing.poly_features(2.0 * d[:, 0].numpy() / cfg.cutoff - 1.0, 32)
+    for typ in (0, 1, 12, 24):
+        m, err = packing.fit_type(sd, cfg, typ, 1, typ == 0)
+        assert err < 1e-6
+        a = O.mlp_edge_encoder(sd64, "edge_encoder_global", d, torch.full((257,), typ, dtype=torch.long))
+        for k in (0, cfg.num_convs - 1):
+            ws = []
+            for conv in ("conv1", "conv2"):
+                p = "encoder_global.interactions.%d.%s" % (k, conv)
+                ws.append(O._lin(sd64, p + ".nn.2", O._ssp(sd64[p + ".nn.1.beta"], O._lin(sd64, p + ".nn.0", a))))
+            ref = torch.cat(ws, 1).numpy()
+            got = ph @ m["conv%d.filt_poly_pk" % k][:, inv].T
+            assert np.abs(got - ref).max() < 2e-6 * np.abs(ref).max()
+        if typ == 0:
+            ref = (a @ sd64["grad_global_dist_mlp.layers.0.weight"][:, 128:].T).numpy()
+            assert np.abs(ph @ m["head_global.attr_poly_pk"][:, inv].T - ref).max() < 2e-6 * np.abs(ref).max()
+
+
+def test_sharp_networks_need_more_terms_or_are_refused():
+    from agdiff_amd import packing, qm9_model_config
+    from oracle import agdiff_oracle as O
+    cfg = qm9_model_config()
+    sd = O.synth_state_dict_for(cfg)
+    base = sd["edge_encoder_global.feature_expansion.weight"].clone()
+    seen = set()
+    for scale in (1.0, 12.0, 40.0):
+        sd["edge_encoder_global.feature_expansion.weight"] = base * scale
+        kt, mats, errs = packing.radius_polynomials(sd, cfg)
+        assert (kt == 0) == (min(errs.values()) > packing.POLY_TOL)
+        assert kt == 0 or errs[kt] <= packing.POLY_TOL
+        seen.add(kt)
+    assert 1 in seen and 0 in seen          # smooth weights: 32 terms; a 40x sharper first layer: refused
+
+
+def test_padded_local_list():
+    """agdiff_topo_t.lp_*: every target's local list padded to a multiple of 8, real entries first and in in-slot order."""
+    from agdiff_amd import synth
+    from agdiff_amd.topology import BatchTopology
+    b = synth.make_packed_batch("drugs", 3, 2, seed=5)
+    tp = BatchTopology(b["atom_type"], b["bond_index"], b["bond_type"], b["batch"], device="cpu")
+    lp = tp.lp_ptr.numpy(); src, dst, row = tp.lp_src.numpy(), tp.lp_dst.numpy(), tp.lp_row.numpy()
+    ip, isrc, irow = tp.loc_in_ptr.numpy(), tp.loc_in_src.numpy(), tp.loc_in_row.numpy()
+    assert lp[-1] == tp.Lp and tp.struct.num_local_padded == tp.Lp
+    for i in range(tp.N):
+        dg = ip[i + 1] - ip[i]
+        assert (lp[i + 1] - lp[i]) % 8 == 0 and 0 <= lp[i + 1] - lp[i] - dg < 8
+        assert np.array_equal(src[lp[i]:lp[i] + dg], isrc[ip[i]:ip[i + 1]]) and np.all(dst[lp[i]:lp[i + 1]] == i)
+        assert np.array_equal(row[lp[i]:lp[i] + dg], irow[ip[i]:ip[i + 1]]) and np.all(row[lp[i] + dg:lp[i + 1]] == -1)
+        assert np.all(src[lp[i] + dg:lp[i + 1]] == i)
+    pp, pm = tp.lc_ppos.numpy(), tp.lc_pmir.numpy()
+    assert np.array_equal(src[pp], tp.lc_src.numpy()) and np.array_equal(dst[pp], tp.lc_dst.numpy())
+    mk = pm >= 0
+    assert np.array_equal(src[pm[mk]], tp.lc_dst.numpy()[mk]) and np.array_equal(dst[pm[mk]], tp.lc_src.numpy()[mk])
+    cover = np.zeros(tp.Lp, bool); cover[pp] = True; cover[pm[mk]] = True
+    assert np.array_equal(cover, row >= 0)
