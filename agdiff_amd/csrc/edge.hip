@@ -851,19 +851,17 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_radius(RadConv
   const int64_t cstride = (int64_t)gridDim.x * WAVES;
   const int wg = (gridDim.x % 8 == 0) ? (int)((blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8) : (int)blockIdx.x;
 
-  int pf_src = 0, pf_t0 = 0, pf_t1 = 0, pf_slot = -1;
+  int pf_src = 0, pf_dst = -1, pf_slot = -1;
   float pf_s1 = 0.0f, pf_s2 = 0.0f, pf_d = 0.0f;
   auto prefetch_meta = [&](int64_t tl, int ln) {
     const int64_t tb = tl * AG_TW, e = tb + (ln & 15);
     const bool valid = e < E;
     if constexpr (TYPED) pf_slot = valid ? a.type_slot[a.e_type[e]] : -1;
     pf_src = valid ? a.e_src[e] : 0;
+    pf_dst = valid ? a.e_dst[e] : -1;
     pf_s1 = valid ? a.scale1[e] : 0.0f;
     pf_s2 = valid ? a.scale2[e] : 0.0f;
     pf_d = valid ? a.e_len[e] : 0.0f;
-    const int64_t last = (tb + AG_TW - 1 < E) ? tb + AG_TW - 1 : (int64_t)E - 1;
-    pf_t0 = a.e_dst[tb];
-    pf_t1 = a.e_dst[last];
   };
   {
     const int64_t first = ((int64_t)wg * WAVES + wave) * a.chunk_tiles;
@@ -887,10 +885,11 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_radius(RadConv
       int lane = lane0;
       asm volatile("" : "+v"(lane));
       const int q = lane >> 4, col = lane & 15;
-      const int my_src = pf_src;
+      const int my_src = pf_src, my_dst = pf_dst;
       const float s1 = pf_s1, s2 = pf_s2, d = pf_d;
-      const int t0 = __builtin_amdgcn_readfirstlane(pf_t0);
-      const int t1 = __builtin_amdgcn_readfirstlane(pf_t1);
+      // first and last target of the tile: the targets of its first and last live row (lane = row for lanes 0..15)
+      const int t0 = __builtin_amdgcn_readfirstlane(my_dst);
+      const int t1 = __builtin_amdgcn_readlane(my_dst, (int)((tbase + AG_TW <= E) ? AG_TW - 1 : E - 1 - tbase));
       if (run_t >= 0 && run_t != t0) {   // previous tile ended exactly on a list boundary
         float* dp = dest(run_t);
 #pragma unroll
@@ -970,25 +969,30 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_radius(RadConv
       float* const dp0 = dest_lo(t0, bound(0));
       const bool fast = ntg <= 2;
       const bool two = ntg == 2;
-      auto reduce_general = [&](f32x4 z, int nt, float& cr) {
+      // General reduction (three or more targets between the tile's first and last row): one masked sum per target
+      // PRESENT in the tile, found from the rows' own targets -- a radius list may be empty for many consecutive atoms
+      // (molecules spread out at high sigma), so walking the index range t0..t1 would not do.  Replicated over the
+      // quarters; quarter nt & 3 keeps / stores it (the fast path's distribution).
+      auto reduce_general = [&](f32x4 z, int nt, float& cr, const int (&rd)[4]) {
         const bool mine = q == (nt & 3);
         float newcarry = 0.0f;
-        for (int i = 0; i < ntg; ++i) {
-          const int lo = bound(i), hi = bound(i + 1);
+        int cur = t0;
+        bool first = true;
+        while (true) {
           float p = 0.0f;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int er = (int)tbase + 4 * q + r;
-            p += ((er >= lo) && (er < hi)) ? z[r] : 0.0f;
-          }
+          for (int r = 0; r < 4; ++r) p += (rd[r] == cur) ? z[r] : 0.0f;
           p = ag_quarter_sum(p);
-          if (i == 0) p = cr + p;
-          if (i < ntg - 1) {
-            float* dp = dest_lo(t0 + i, lo);
-            if (mine) dp[16 * nt + col] = p;
-          } else {
+          if (first) p = cr + p;
+          const uint64_t later = __ballot(my_dst > cur) & 0xFFFFull;      // rows of later targets (invalid rows hold -1)
+          if (later == 0) {
             newcarry = p;
+            break;
           }
+          float* dp = first ? dp0 : (a.agg + (size_t)cur * 192);          // a list that starts inside this tile starts in this chunk
+          if (mine) dp[16 * nt + col] = p;
+          cur = __builtin_amdgcn_readlane(my_dst, (int)__builtin_ctzll(later));
+          first = false;
         }
         cr = mine ? newcarry : cr;
       };
@@ -1062,13 +1066,16 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_radius(RadConv
         if (two) run_fast(std::true_type{});
         else run_fast(std::false_type{});
       } else {
+        int rd[4];                 // targets of the lane's four rows
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rd[r] = __shfl(my_dst, 4 * q + r);
 #pragma unroll
         for (int nt = 0; nt < AG_CONV_NCH; ++nt) {
           f32x4 z = filter(nt), m;
           factors(nt, m, true);
 #pragma unroll
           for (int r = 0; r < 4; ++r) z[r] = z[r] * m[r];
-          reduce_general(z, nt, carry[nt >> 2]);
+          reduce_general(z, nt, carry[nt >> 2], rd);
         }
       }
       run_t = t1;

@@ -125,7 +125,9 @@ def test_split_cfconv_equals_one_list_kernel(kind, mols, copies):
             assert lib.agdiff_cfconv_radius(P, T, W, k, st) == 0 and lib.agdiff_cfconv_local(P, T, W, k, st) == 0
             torch.cuda.synchronize()
             got = _aggregates(ws, topo, lib, split=True)
-            check_close("split_cfconv[%s] block %d" % (kind, k), got, ref, precision)
+            # (both sides carry their own split-bf16 rounding -- polynomial vs MLP chain --, each ~1.5e-5 from the exact
+            # value: the gate is for a difference of two such figures)
+            check_close("split_cfconv[%s] block %d" % (kind, k), got, ref, precision, scale=3.0 if precision == "bf16x3" else 1.0)
 
 
 def test_rejected_fit_falls_back_to_the_mlps():
