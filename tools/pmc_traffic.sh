@@ -15,11 +15,21 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == c:
-            for k in ("k_cfconv_fused", "k_edge_encoder", "k_pair_head", "k_gin_layer", "k_gin_gather", "k_schnet_node_stage"):
-                if k in r["Kernel_Name"]:
+            kn = r["Kernel_Name"]
+            # the split CFConv's two instantiations of one template: <.., false> = radius list, <.., true> = typed local list
+            if "k_cfconv_radius" in kn:
+                agg["k_cfconv_local" if "true>" in kn else "k_cfconv_radius"].append(float(r["Counter_Value"]))
+                continue
+            for k in ("k_cfconv_fused", "k_edge_encoder", "k_pair_head_poly", "k_pair_head", "k_gin_layer", "k_gin_gather", "k_schnet_node_stage", "k_graph"):
+                if k in kn:
                     agg[k].append(float(r["Counter_Value"]))
+                    break
     res[c] = {k: sum(v) / len(v) for k, v in agg.items()}
+import json
+rec = {"kernels": {}}
 for k in res["FETCH_SIZE"]:
     fk, wk = res["FETCH_SIZE"][k], res["WRITE_SIZE"].get(k, 0)
     print("%-22s FETCH_SIZE %10.0f KiB (x2 = %8.1f MB)  WRITE_SIZE %10.0f KiB (%7.1f MB)" % (k, fk, 2 * fk * 1024 / 1e6, wk, wk * 1024 / 1e6))
+    rec["kernels"][k] = {"fetch_size_kib": fk, "write_size_kib": wk, "hbm_bytes_per_launch": 2 * fk * 1024 + wk * 1024}
+json.dump(rec, open("$GRAFT_REPO_ROOT/$out/traffic.json", "w"), indent=1)
 PY
