@@ -215,6 +215,24 @@ __device__ __forceinline__ void ag_block_mma(f32x4& o, const AgIn<MODE>& x, cons
   }
 }
 
+// The same product one MFMA at a time (part p of AgParts<MODE>::n), for callers that interleave the parts of several
+// independent accumulators: back-to-back MFMAs on ONE accumulator wait for each other's result.
+template <int MODE> struct AgParts { static constexpr int n = (MODE == AG_F32) ? 8 : 3; };
+template <int MODE, bool FLIP>
+__device__ __forceinline__ void ag_block_mma_part(f32x4& o, const AgIn<MODE>& x, const u32x4 (&w)[2], int part) {
+  if constexpr (MODE == AG_F32) {
+    const int u = part >> 2, r = part & 3;
+    const f32x4 wf = __builtin_bit_cast(f32x4, w[u]);
+    o = FLIP ? __builtin_amdgcn_mfma_f32_16x16x4f32(x.v[u][r], wf[r], o, 0, 0, 0)
+             : __builtin_amdgcn_mfma_f32_16x16x4f32(wf[r], x.v[u][r], o, 0, 0, 0);
+  } else {
+    const bf16x8 wv = __builtin_bit_cast(bf16x8, w[part == 2 ? 1 : 0]);
+    const bf16x8 xv = (part == 1) ? x.lo : x.hi;
+    o = FLIP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(xv, wv, o, 0, 0, 0)
+             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, xv, o, 0, 0, 0);
+  }
+}
+
 // Weight blocks are consumed in storage order: output-tile-outer ("pk": [OT][KT]) or k-tile-outer
 // ("pkk": [KT][OT]).  Global source: loads run PF blocks ahead of their MFMAs, with
 // __builtin_amdgcn_sched_barrier(0) between blocks so that hipcc cannot hoist every load of a layer to its

@@ -850,8 +850,16 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_radius(RadConv
   const int E = *a.n_dev;
   const int64_t cstride = (int64_t)gridDim.x * WAVES;
   const int wg = (gridDim.x % 8 == 0) ? (int)((blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8) : (int)blockIdx.x;
+#ifndef AG_RAD_ABL
+#define AG_RAD_ABL 0        // timing experiments only (wrong results): 1 no x gathers, 2 no filter MFMAs, 4 no reduction arithmetic
+#endif
 
-  int pf_src = 0, pf_dst = -1, pf_slot = -1;
+  // A tile is short here (a few hundred instructions), so every memory round trip that starts inside it is exposed.
+  // Everything a tile needs from memory is therefore requested during the PREVIOUS tile of the wave: its per-edge
+  // scalars (source, target, length, the two scales, type slot) and the target of the row before it, and -- once the
+  // sources have arrived -- the x[src] values of its first channel-tile group.  Nothing in a tile depends on in_ptr:
+  // list boundaries come from the rows' own targets.
+  int pf_src = 0, pf_dst = -1, pf_slot = -1, pf_prev = -1;
   float pf_s1 = 0.0f, pf_s2 = 0.0f, pf_d = 0.0f;
   auto prefetch_meta = [&](int64_t tl, int ln) {
     const int64_t tb = tl * AG_TW, e = tb + (ln & 15);
@@ -862,223 +870,257 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_radius(RadConv
     pf_s1 = valid ? a.scale1[e] : 0.0f;
     pf_s2 = valid ? a.scale2[e] : 0.0f;
     pf_d = valid ? a.e_len[e] : 0.0f;
+    pf_prev = (tb > 0) ? a.e_dst[tb - 1] : -1;
+  };
+  // x[src] values of a group of four channel tiles (16 per lane), two groups in flight
+  f32x4 xg[2][4];
+  uint32_t xoff[4];
+  auto set_xoff = [&](int src, int ln) {      // byte offsets of the lane's four rows (row 4 q + r lives in lane 4 q + r)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xoff[r] = ((uint32_t)__shfl(src, 4 * (ln >> 4) + r) * 192u + (uint32_t)(ln & 15)) * 4u;
+  };
+  auto fetch_xg = [&](auto BUF, int g4) {
+    constexpr int kb = decltype(BUF)::value;
+    const char* xb = reinterpret_cast<const char*>(a.xs);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (AG_RAD_ABL & 1) xg[kb][j][r] = __uint_as_float(xoff[r] + j);
+        else xg[kb][j][r] = *reinterpret_cast<const float*>(xb + (size_t)xoff[r] + 64 * (4 * g4 + j));
+      }
+    }
   };
   {
     const int64_t first = ((int64_t)wg * WAVES + wave) * a.chunk_tiles;
-    if (first * AG_TW < E) prefetch_meta(first, lane0);
+    if (first * AG_TW < E) {
+      prefetch_meta(first, lane0);
+      set_xoff(pf_src, lane0);
+      fetch_xg(std::integral_constant<int, 0>{}, 0);
+    }
   }
+  int parity = 0;           // which of the two x buffers holds the current tile's first group
   for (int64_t chunk = (int64_t)wg * WAVES + wave; chunk < a.max_chunks; chunk += cstride) {
     const int64_t e_begin = chunk * (AG_TW * a.chunk_tiles);
     if (e_begin >= E) break;
     int run_t = -1;
+    int carried = -1;       // the target whose list was already open when the chunk started: its sum goes to agg_first[chunk]
     float carry[AG_CONV_NCH / 4];      // as k_cfconv_fused: entry g of lane (col, q) = channel 16 (4 g + q) + col
 #pragma unroll
     for (int i = 0; i < AG_CONV_NCH / 4; ++i) carry[i] = 0.0f;
     auto dest = [&](int t) -> float* {
-      const int lo = a.in_ptr[t];
-      return (lo >= e_begin) ? (a.agg + (size_t)t * 192) : (a.agg_first + (size_t)chunk * 192);
+      return (t == carried) ? (a.agg_first + (size_t)chunk * 192) : (a.agg + (size_t)t * 192);
     };
     for (int tt = 0; tt < a.chunk_tiles; ++tt) {
       const int64_t tile = chunk * a.chunk_tiles + tt;
       const int64_t tbase = tile * AG_TW;
       if (tbase >= E) break;
-      int lane = lane0;
-      asm volatile("" : "+v"(lane));
-      const int q = lane >> 4, col = lane & 15;
-      const int my_src = pf_src, my_dst = pf_dst;
-      const float s1 = pf_s1, s2 = pf_s2, d = pf_d;
-      // first and last target of the tile: the targets of its first and last live row (lane = row for lanes 0..15)
-      const int t0 = __builtin_amdgcn_readfirstlane(my_dst);
-      const int t1 = __builtin_amdgcn_readlane(my_dst, (int)((tbase + AG_TW <= E) ? AG_TW - 1 : E - 1 - tbase));
-      if (run_t >= 0 && run_t != t0) {   // previous tile ended exactly on a list boundary
-        float* dp = dest(run_t);
+      auto tile_body = [&](auto PAR) {
+        constexpr int kPar = decltype(PAR)::value;
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int q = lane >> 4, col = lane & 15;
+        const int my_dst = pf_dst;
+        const float s1 = pf_s1, s2 = pf_s2, d = pf_d;
+        [[maybe_unused]] const int my_slot = pf_slot;
+        // first and last target of the tile: the targets of its first and last live row (lane = row for lanes 0..15)
+        const int t0 = __builtin_amdgcn_readfirstlane(my_dst);
+        const int t1 = __builtin_amdgcn_readlane(my_dst, (int)((tbase + AG_TW <= E) ? AG_TW - 1 : E - 1 - tbase));
+        if (tt == 0) carried = (__builtin_amdgcn_readfirstlane(pf_prev) == t0) ? t0 : -1;
+        if (run_t >= 0 && run_t != t0) {   // previous tile ended exactly on a list boundary
+          float* dp = dest(run_t);
 #pragma unroll
-        for (int i = 0; i < AG_CONV_NCH / 4; ++i) {
-          dp[16 * (4 * i + q) + col] = carry[i];
-          carry[i] = 0.0f;
-        }
-        run_t = -1;
-      }
-      uint32_t xoff[4];
-      f32x4 sr;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        xoff[r] = ((uint32_t)__shfl(my_src, 4 * q + r) * 192u + (uint32_t)col) * 4u;
-        sr[r] = __shfl(s1, 4 * q + r);
-      }
-      const int ntg = t1 - t0 + 1;
-      const int ipl = a.in_ptr[t0 + (lane <= ntg ? lane : ntg)];
-      auto bound = [&](int i) -> int {
-        return (i < 64) ? __builtin_amdgcn_readlane(ipl, i) : __builtin_amdgcn_readfirstlane(a.in_ptr[t0 + i]);
-      };
-      auto dest_lo = [&](int t, int lo) -> float* {
-        return (lo >= e_begin) ? (a.agg + (size_t)t * 192) : (a.agg_first + (size_t)chunk * 192);
-      };
-      constexpr int XA = 2, XR = XA + 1;         // x[src] values requested XA channel tiles ahead
-      f32x4 xring[XR];
-      auto fetch_x = [&](int nt) {
-        const char* xb = reinterpret_cast<const char*>(a.xs);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xring[nt % XR][r] = *reinterpret_cast<const float*>(xb + (size_t)xoff[r] + 64 * nt);
-      };
-#pragma unroll
-      for (int nt = 0; nt < XA; ++nt) fetch_x(nt);
-      AgIn<MODE> ph[NKT];
-      [[maybe_unused]] f32x4 zall[TYPED ? AG_CONV_NCH : 1];
-      if constexpr (!TYPED) {
-        ag_poly_features<MODE, NKT>(d, a.two_over_rc, q, ph);
-      } else {
-        const int my_slot = pf_slot;
-#pragma unroll
-        for (int nt = 0; nt < AG_CONV_NCH; ++nt) zall[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const lds_u32x4* wl_t = ag_lds_base(wl, lane);
-        uint64_t todo = __ballot(my_slot >= 0) & 0xFFFFull;      // one lane per edge column (the quarters hold copies)
-        while (todo) {
-          const int g = __builtin_amdgcn_readlane(my_slot, (int)__builtin_ctzll(todo));
-          const bool in = my_slot == g;
-          todo &= ~__ballot(in);
-          ag_poly_features<MODE, NKT>(d, a.two_over_rc, q, ph, in ? 1.0f : 0.0f);
-          const lds_u32x4* wg_ = wl_t + (size_t)g * (AG_CONV_NCH * NKT * 128);
-#pragma unroll
-          for (int nt = 0; nt < AG_CONV_NCH; ++nt) {
-#pragma unroll
-            for (int t = 0; t < NKT; ++t) {
-              u32x4 w[2];
-              w[0] = wg_[((nt * NKT + t) * 2) * 64];
-              w[1] = wg_[((nt * NKT + t) * 2 + 1) * 64];
-              ag_block_mma<MODE, true>(zall[nt], ph[t], w);
-            }
+          for (int i = 0; i < AG_CONV_NCH / 4; ++i) {
+            dp[16 * (4 * i + q) + col] = carry[i];
+            carry[i] = 0.0f;
           }
+          run_t = -1;
         }
-      }
-      {   // the wave's next tile: per-edge scalars and end targets
-        int64_t nxt = tile + 1;
-        if (tt + 1 >= a.chunk_tiles) nxt = (chunk + cstride) * a.chunk_tiles;
-        if (nxt * AG_TW < E && nxt < a.max_chunks * a.chunk_tiles) prefetch_meta(nxt, lane);
-      }
-      f32x4 m0, m1;
-      {
-        const int b0 = bound(0), b1 = bound(1), b2 = bound(ntg >= 2 ? 2 : 1);
+        f32x4 sr;                          // scale of the conv being processed, per edge row
+        int rd[4];                         // targets of the lane's four rows
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int er = (int)tbase + 4 * q + r;
-          m0[r] = (er >= b0 && er < b1) ? 1.0f : 0.0f;
-          m1[r] = (ntg >= 2 && er >= b1 && er < b2) ? 1.0f : 0.0f;
+          sr[r] = __shfl(s1, 4 * q + r);
+          rd[r] = __shfl(my_dst, 4 * q + r);
         }
-      }
-      float* const dp0 = dest_lo(t0, bound(0));
-      const bool fast = ntg <= 2;
-      const bool two = ntg == 2;
-      // General reduction (three or more targets between the tile's first and last row): one masked sum per target
-      // PRESENT in the tile, found from the rows' own targets -- a radius list may be empty for many consecutive atoms
-      // (molecules spread out at high sigma), so walking the index range t0..t1 would not do.  Replicated over the
-      // quarters; quarter nt & 3 keeps / stores it (the fast path's distribution).
-      auto reduce_general = [&](f32x4 z, int nt, float& cr, const int (&rd)[4]) {
-        const bool mine = q == (nt & 3);
-        float newcarry = 0.0f;
-        int cur = t0;
-        bool first = true;
-        while (true) {
-          float p = 0.0f;
+        // one or two targets in the tile (every live row belongs to the first or to the last one): fast reduction
+        const bool fast = __ballot(my_dst >= 0 && my_dst != t0 && my_dst != t1) == 0;
+        const bool two = t1 != t0;
+        f32x4 m0, m1;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) p += (rd[r] == cur) ? z[r] : 0.0f;
-          p = ag_quarter_sum(p);
-          if (first) p = cr + p;
-          const uint64_t later = __ballot(my_dst > cur) & 0xFFFFull;      // rows of later targets (invalid rows hold -1)
-          if (later == 0) {
-            newcarry = p;
-            break;
+        for (int r = 0; r < 4; ++r) {
+          m0[r] = (rd[r] == t0) ? 1.0f : 0.0f;
+          m1[r] = (two && rd[r] == t1) ? 1.0f : 0.0f;
+        }
+        float* const dp0 = dest(t0);
+
+        AgIn<MODE> ph[NKT];
+        [[maybe_unused]] f32x4 zall[TYPED ? AG_CONV_NCH : 1];
+        const lds_u32x4* wl_l = ag_lds_base(wl, lane);
+        // four channel tiles' coefficient blocks (pk [12][NKT]: block nt * NKT + t of set `base`) times the features:
+        // four independent accumulator chains with their MFMA passes interleaved
+        auto mma_group = [&](const lds_u32x4* base, int g4, f32x4 (&zg)[4]) {
+          u32x4 w[4][NKT][2];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int t = 0; t < NKT; ++t) {
+              w[j][t][0] = base[(((4 * g4 + j) * NKT + t) * 2) * 64];
+              w[j][t][1] = base[(((4 * g4 + j) * NKT + t) * 2 + 1) * 64];
+            }
           }
-          float* dp = first ? dp0 : (a.agg + (size_t)cur * 192);          // a list that starts inside this tile starts in this chunk
-          if (mine) dp[16 * nt + col] = p;
-          cur = __builtin_amdgcn_readlane(my_dst, (int)__builtin_ctzll(later));
-          first = false;
-        }
-        cr = mine ? newcarry : cr;
-      };
-      // coefficient blocks (pk [12][NKT]: block nt * NKT + t) from LDS, one channel tile ahead
-      const lds_u32x4* wl_l = ag_lds_base(wl, lane);
-      u32x4 wq[2][NKT][2];
-      auto fetch_w = [&](int nt) {
+          if (AG_RAD_ABL & 2) {
 #pragma unroll
-        for (int t = 0; t < NKT; ++t) {
-          wq[nt & 1][t][0] = wl_l[((nt * NKT + t) * 2) * 64];
-          wq[nt & 1][t][1] = wl_l[((nt * NKT + t) * 2 + 1) * 64];
-        }
-      };
-      if constexpr (!TYPED) fetch_w(0);
-      auto filter = [&](int nt) -> f32x4 {      // flipped: rows = edges, lanes = channels
-        if constexpr (TYPED) return zall[nt];
-        f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        if (nt + 1 < AG_CONV_NCH) fetch_w(nt + 1);
-#pragma unroll
-        for (int t = 0; t < NKT; ++t) ag_block_mma<MODE, true>(z, ph[t], wq[nt & 1][t]);
-        return z;
-      };
-      auto factors = [&](int nt, f32x4& m, bool with_scale) {
-        if (nt == 8) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) sr[r] = __shfl(s2, 4 * q + r);
-        }
-        m = with_scale ? sr * xring[nt % XR] : xring[nt % XR];
-        if (nt + XA < AG_CONV_NCH) fetch_x(nt + XA);
-      };
-      auto run_fast = [&](auto TWO) {
-        constexpr bool kTwo = decltype(TWO)::value;
-        f32x4 zp = {0.f, 0.f, 0.f, 0.f}, mp = {0.f, 0.f, 0.f, 0.f};
-        float p0[4], p1[4] = {0.f, 0.f, 0.f, 0.f};
-        f32x4 w0 = m0 * sr, w1 = m1 * sr;          // conv1's scale folded into the row masks
-#pragma unroll
-        for (int nt = 0; nt <= AG_CONV_NCH; ++nt) {
-          f32x4 z = {0.f, 0.f, 0.f, 0.f}, m = {0.f, 0.f, 0.f, 0.f};
-          if (nt < AG_CONV_NCH) {
-            z = filter(nt);
-            factors(nt, m, false);
+            for (int j = 0; j < 4; ++j) zg[j] += __builtin_bit_cast(f32x4, w[j][0][0]);
+            return;
           }
-          if (nt == 9) { w0 = m0 * sr; w1 = m1 * sr; }   // tile 8 (reduced in this step) starts conv2: sr is its scale now
-          if (nt > 0) {
-            const int j = (nt - 1) & 3, g4 = (nt - 1) >> 2;
-            f32x4 t;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) t[r] = zp[r] * mp[r];
-            p0[j] = t[0] * w0[0];
+          for (int t = 0; t < NKT; ++t) {
 #pragma unroll
-            for (int r = 1; r < 4; ++r) p0[j] = fmaf(t[r], w0[r], p0[j]);
-            if constexpr (kTwo) {
+            for (int part = 0; part < AgParts<MODE>::n; ++part) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) ag_block_mma_part<MODE, true>(zg[j], ph[t], w[j][t], part);
+            }
+          }
+        };
+        if constexpr (!TYPED) {
+          ag_poly_features<MODE, NKT>(d, a.two_over_rc, q, ph);
+        } else {
+#pragma unroll
+          for (int nt = 0; nt < AG_CONV_NCH; ++nt) zall[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          uint64_t todo = __ballot(my_slot >= 0) & 0xFFFFull;      // one lane per edge column (the quarters hold copies)
+          while (todo) {
+            const int g = __builtin_amdgcn_readlane(my_slot, (int)__builtin_ctzll(todo));
+            const bool in = my_slot == g;
+            todo &= ~__ballot(in);
+            ag_poly_features<MODE, NKT>(d, a.two_over_rc, q, ph, in ? 1.0f : 0.0f);
+            const lds_u32x4* wg_ = wl_l + (size_t)g * (AG_CONV_NCH * NKT * 128);
+#pragma unroll
+            for (int g4 = 0; g4 < AG_CONV_NCH / 4; ++g4) {
+              f32x4 (&zg)[4] = *reinterpret_cast<f32x4 (*)[4]>(&zall[4 * g4]);
+              mma_group(wg_, g4, zg);
+            }
+          }
+        }
+        // the wave's next tile: per-edge scalars now, its first x group below
+        int64_t nxt = tile + 1;
+        if (tt + 1 >= a.chunk_tiles) nxt = (chunk + cstride) * a.chunk_tiles;
+        const bool has_next = nxt * AG_TW < E && nxt < a.max_chunks * a.chunk_tiles;
+        if (has_next) prefetch_meta(nxt, lane);
+
+        // General reduction (a third target somewhere in the tile): one masked sum per target PRESENT in the tile, found
+        // from the rows' own targets -- a radius list may be empty for many consecutive atoms (molecules spread out at high
+        // sigma).  Replicated over the quarters; quarter nt & 3 keeps / stores it (the fast path's distribution).
+        auto reduce_general = [&](f32x4 z, int nt, float& cr) {
+          const bool mine = q == (nt & 3);
+          float newcarry = 0.0f;
+          int cur = t0;
+          bool first = true;
+          while (true) {
+            float p = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p += (rd[r] == cur) ? z[r] : 0.0f;
+            p = ag_quarter_sum(p);
+            if (first) p = cr + p;
+            const uint64_t later = __ballot(my_dst > cur) & 0xFFFFull;      // rows of later targets (invalid rows hold -1)
+            if (later == 0) {
+              newcarry = p;
+              break;
+            }
+            float* dp = first ? dp0 : (a.agg + (size_t)cur * 192);          // a list that starts inside this tile starts in this chunk
+            if (mine) dp[16 * nt + col] = p;
+            cur = __builtin_amdgcn_readlane(my_dst, (int)__builtin_ctzll(later));
+            first = false;
+          }
+          cr = mine ? newcarry : cr;
+        };
+        auto filter_group = [&](int g4, f32x4 (&zg)[4]) {      // flipped: rows = edges, lanes = channels
+          if constexpr (TYPED) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) zg[j] = zall[4 * g4 + j];
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) zg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mma_group(wl_l, g4, zg);
+          }
+        };
+        // The 12 channel tiles go in three groups of four (groups 0, 1 are conv1, group 2 is conv2).  Group g4's x values
+        // sit in buffer (kPar + g4) & 1; the next group's gathers and MFMAs are issued before this group's reduction, and
+        // before the LAST reduction the next tile's first group is requested.
+        f32x4 zc[4];
+        filter_group(0, zc);
+        auto reduce_group = [&](auto G4) {
+          constexpr int g4 = decltype(G4)::value;
+          constexpr int kb = (kPar + g4) & 1;
+          if (fast) {
+            // masked sums as FMAs (the conv's scale folded into the row masks), then ONE reduce-scatter over the quarters
+            // for the four channel tiles: quarter q ends up with channel tile 4 g4 + q.  (Packed fp32 for these sums and
+            // skipping the second target's where the tile has one target were measured: +5 % per launch, not kept.)
+            const f32x4 w0 = m0 * sr, w1 = m1 * sr;
+            float p0[4], p1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              f32x4 t;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) t[r] = zc[j][r] * xg[kb][j][r];
+              if (AG_RAD_ABL & 4) {
+                p0[j] = t[0] + t[1];
+                p1[j] = t[2] + t[3];
+                continue;
+              }
+              p0[j] = t[0] * w0[0];
               p1[j] = t[0] * w1[0];
 #pragma unroll
-              for (int r = 1; r < 4; ++r) p1[j] = fmaf(t[r], w1[r], p1[j]);
-            }
-            if (j == 3) {      // quarter q ends up with the sums of channel tile 4 g4 + q
-              const float r0 = carry[g4] + ag_quarter_reduce_scatter4(p0[0], p0[1], p0[2], p0[3]);
-              if constexpr (kTwo) {
-                dp0[16 * (4 * g4 + q) + col] = r0;
-                carry[g4] = ag_quarter_reduce_scatter4(p1[0], p1[1], p1[2], p1[3]);
-              } else {
-                carry[g4] = r0;
+              for (int r = 1; r < 4; ++r) {
+                p0[j] = fmaf(t[r], w0[r], p0[j]);
+                p1[j] = fmaf(t[r], w1[r], p1[j]);
               }
             }
+            const float r0 = carry[g4] + ag_quarter_reduce_scatter4(p0[0], p0[1], p0[2], p0[3]);
+            if (two) {       // the first target's list ends in this tile; the second one's sum stays open
+              dp0[16 * (4 * g4 + q) + col] = r0;
+              carry[g4] = ag_quarter_reduce_scatter4(p1[0], p1[1], p1[2], p1[3]);
+            } else {
+              carry[g4] = r0;
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              f32x4 z;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) z[r] = zc[j][r] * xg[kb][j][r] * sr[r];
+              reduce_general(z, 4 * g4 + j, carry[g4]);
+            }
           }
-          zp = z; mp = m;
+        };
+        {
+          f32x4 zn[4];
+          fetch_xg(std::integral_constant<int, (kPar + 1) & 1>{}, 1);
+          filter_group(1, zn);
+          reduce_group(std::integral_constant<int, 0>{});
+#pragma unroll
+          for (int j = 0; j < 4; ++j) zc[j] = zn[j];
         }
+        {
+          f32x4 zn[4];
+          fetch_xg(std::integral_constant<int, (kPar + 2) & 1>{}, 2);
+          filter_group(2, zn);
+          reduce_group(std::integral_constant<int, 1>{});
+#pragma unroll
+          for (int j = 0; j < 4; ++j) zc[j] = zn[j];
+        }
+        if (has_next) {                     // (all of this tile's gathers are out: xoff is free)
+          set_xoff(pf_src, lane);
+          fetch_xg(std::integral_constant<int, (kPar + 3) & 1>{}, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sr[r] = __shfl(s2, 4 * q + r);      // channel tiles 8..11 are conv2: its per-edge scale
+        reduce_group(std::integral_constant<int, 2>{});
+        run_t = t1;
       };
-      if (fast) {
-        if (two) run_fast(std::true_type{});
-        else run_fast(std::false_type{});
-      } else {
-        int rd[4];                 // targets of the lane's four rows
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rd[r] = __shfl(my_dst, 4 * q + r);
-#pragma unroll
-        for (int nt = 0; nt < AG_CONV_NCH; ++nt) {
-          f32x4 z = filter(nt), m;
-          factors(nt, m, true);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) z[r] = z[r] * m[r];
-          reduce_general(z, nt, carry[nt >> 2], rd);
-        }
-      }
-      run_t = t1;
+      if (parity) tile_body(std::integral_constant<int, 1>{});
+      else tile_body(std::integral_constant<int, 0>{});
+      parity ^= 1;
     }
     if (run_t >= 0) {
       float* dp = dest(run_t);
@@ -1358,7 +1400,7 @@ int launch_cfconv_fused(const agdiff_params_t* p, int32_t k, int64_t max_e, cons
 }
 
 #ifndef AG_RAD_WAVES
-#define AG_RAD_WAVES 16
+#define AG_RAD_WAVES 12     // ~160 VGPRs (two x groups in flight across tiles): three waves per SIMD
 #endif
 template <int MODE, int NKT>
 int launch_cfconv_radius_t(const RadConvArgs& a, int64_t wgs, void* stream) {
@@ -1368,7 +1410,7 @@ int launch_cfconv_radius_t(const RadConvArgs& a, int64_t wgs, void* stream) {
   return AGDIFF_OK;
 }
 #ifndef AG_LOCP_WAVES
-#define AG_LOCP_WAVES 16
+#define AG_LOCP_WAVES 12     // the typed variant needs ~160 VGPRs: at 16 waves (128) it spilled 18 of them (A/B: 0.092 -> 0.079 ms)
 #endif
 template <int MODE>
 int launch_cfconv_local_poly_t(const RadConvArgs& a, int64_t wgs, void* stream) {

@@ -19,9 +19,12 @@ for _ in range(reps):
                               "--no-cpu-baseline", "--no-traj", "--no-extra"] + extra, env=env, capture_output=True, text=True)
         try:
             d = json.loads(out.stdout.strip().splitlines()[-1])
-            res[lib].append((d["roofline"]["avg_launch_ms"], d["ms_per_step"]))
+            by = d["roofline"].get("launch_ms_by_kernel", {})
+            res[lib].append((d["roofline"]["avg_launch_ms"], d["ms_per_step"], by))
         except Exception:
             print(lib, "FAILED", out.stderr[-600:])
 for lib, v in res.items():
     if v:
-        print("%-40s conv_ms %s   step_ms %s" % (os.path.basename(lib), " ".join("%.4f" % a for a, _ in v), " ".join("%.3f" % b for _, b in v)))
+        print("%-40s conv_ms %s   step_ms %s   %s" % (os.path.basename(lib), " ".join("%.4f" % a for a, _, _ in v),
+                                                        " ".join("%.3f" % b for _, b, _ in v),
+                                                        " ".join("%s %s" % (k, "/".join("%.4f" % x[2][k] for x in v)) for k in v[0][2])))
