@@ -333,6 +333,34 @@ __device__ __forceinline__ void ag_load_attr(AgIn<AG_BF3>& x, const float* frag,
   x.hi = __builtin_bit_cast(bf16x8, p[ag_attr_unit(tile, t, 0, lane)]);
   x.lo = __builtin_bit_cast(bf16x8, p[ag_attr_unit(tile, t, 1, lane)]);
 }
+// global -> LDS copy of n 16-byte units by the whole workgroup (weights that stay resident for a launch or a phase).
+// The loads of U units per thread are issued back to back and stored afterwards: the plain loop `dst[i] = src[i]`
+// compiles to load, s_waitcnt vmcnt(0), ds_write per iteration -- one exposed L2 round trip per 16 bytes and thread,
+// 10..13 in a row for a 160-KiB fill (found in the ISA of every kernel that stages weights; the node stage and the GIN
+// layer do it three times / once per 16-node tile).
+template <int U = 8, typename F>
+__device__ __forceinline__ void ag_copy_lds_map(lds_u32x4* dst, const u32x4* __restrict__ src, int n, F src_index) {
+  const int stride = (int)blockDim.x;
+  for (int base = (int)threadIdx.x; base < n; base += U * stride) {
+    u32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int i = base + u * stride;
+      i = i < n ? i : n - 1;                   // (clamped: every load is issued, stores are conditional)
+      v[u] = src[src_index(i)];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * stride;
+      if (i < n) dst[i] = v[u];
+    }
+  }
+}
+template <int U = 8>
+__device__ __forceinline__ void ag_copy_lds(lds_u32x4* dst, const u32x4* __restrict__ src, int n) {
+  ag_copy_lds_map<U>(dst, src, n, [](int i) { return i; });
+}
+
 // Kernels that declare more than 64 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize, and HIP keeps
 // function attributes PER DEVICE: `done` has one bit per device id, so a process that drives several GPUs sets the
 // attribute on each of them (setting it twice from two threads is harmless, hence no lock).

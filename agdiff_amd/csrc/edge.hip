@@ -95,9 +95,9 @@ __global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_edge_encoder(EncAr
     const u32x4* g1 = reinterpret_cast<const u32x4*>(a.w1_pk);
     const u32x4* g2 = reinterpret_cast<const u32x4*>(a.w23_pk);
     const u32x4* g4 = reinterpret_cast<const u32x4*>(a.w4_pk);
-    for (int i = threadIdx.x; i < 32 * 128; i += blockDim.x) lw1[i] = g1[i];
-    for (int i = threadIdx.x; i < 32 * 128; i += blockDim.x) lw23[i] = g2[i];
-    for (int i = threadIdx.x; i < 32 * 64; i += blockDim.x) lw4[i] = g4[(i >> 6) * 128 + (i & 63)];
+    ag_copy_lds(lw1, g1, 32 * 128);
+    ag_copy_lds(lw23, g2, 32 * 128);
+    ag_copy_lds_map(lw4, g4, 32 * 64, [](int i) { return (i >> 6) * 128 + (i & 63); });
   }
   __syncthreads();
   const int lane0 = ag_lane();
@@ -290,8 +290,8 @@ __global__ void __launch_bounds__(64 * AG_CONV_WAVES, AG_CONV_WAVES / 4) k_cfcon
   {
     const u32x4* g1 = reinterpret_cast<const u32x4*>(a.cp.filt_w1_pk);
     const u32x4* ga = reinterpret_cast<const u32x4*>(a.cp.filt_w2a_pk);
-    for (int i = threadIdx.x; i < 48 * 128; i += blockDim.x) w1[i] = g1[i];
-    for (int i = threadIdx.x; i < 32 * 128; i += blockDim.x) w2a[i] = ga[i];
+    ag_copy_lds(w1, g1, 48 * 128);
+    ag_copy_lds(w2a, ga, 32 * 128);
   }
   __syncthreads();
   const int lane0 = ag_lane();
@@ -697,8 +697,8 @@ __global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_pair_head(HeadArgs
   {
     const u32x4* g1 = reinterpret_cast<const u32x4*>(a.hp.w1_pk);
     const u32x4* g2 = reinterpret_cast<const u32x4*>(a.hp.w2_pk);
-    for (int i = threadIdx.x; i < 64 * 128; i += blockDim.x) lw1[i] = g1[i];
-    for (int i = threadIdx.x; i < 16 * 128; i += blockDim.x) lw2[i] = g2[i];
+    ag_copy_lds(lw1, g1, 64 * 128);
+    ag_copy_lds(lw2, g2, 16 * 128);
   }
   __syncthreads();
   const int lane0 = ag_lane();
@@ -842,7 +842,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_radius(RadConv
   {
     const u32x4* g = reinterpret_cast<const u32x4*>(a.poly_pk);
     const int nset = TYPED ? a.num_slots : 1;
-    for (int i = threadIdx.x; i < nset * AG_CONV_NCH * NKT * 128; i += blockDim.x) wl[i] = g[i];
+    ag_copy_lds(wl, g, nset * AG_CONV_NCH * NKT * 128);
   }
   __syncthreads();
   const int lane0 = ag_lane();
@@ -1159,9 +1159,9 @@ __global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_pair_head_poly(Hea
     const u32x4* g1 = reinterpret_cast<const u32x4*>(a.hp.w1_pk);
     const u32x4* gp = reinterpret_cast<const u32x4*>(a.hp.attr_poly_pk);
     const u32x4* g2 = reinterpret_cast<const u32x4*>(a.hp.w2_pk);
-    for (int i = threadIdx.x; i < 32 * 128; i += blockDim.x) lw1[i] = g1[i];
-    for (int i = threadIdx.x; i < 8 * NKT * 128; i += blockDim.x) lwp[i] = gp[i];
-    for (int i = threadIdx.x; i < 16 * 128; i += blockDim.x) lw2[i] = g2[i];
+    ag_copy_lds(lw1, g1, 32 * 128);
+    ag_copy_lds(lwp, gp, 8 * NKT * 128);
+    ag_copy_lds(lw2, g2, 16 * 128);
   }
   __syncthreads();
   const int lane0 = ag_lane();

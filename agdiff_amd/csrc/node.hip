@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(LDSW ? 1024 : 256, LDSW ? 1 : 2) k_schnet_node
   auto stage_in = [&](int dst_block, const float* src, int nblocks) {
     if constexpr (LDSW) {
       const u32x4* g = reinterpret_cast<const u32x4*>(src);
-      for (int i = threadIdx.x; i < nblocks * 128; i += blockDim.x) L[dst_block * 128 + i] = g[i];
+      ag_copy_lds<4>(L + dst_block * 128, g, nblocks * 128);     // (4 deep: tile state is live across the later phases)
     }
   };
   auto sync = [&]() {
@@ -497,8 +497,8 @@ __global__ void __launch_bounds__(LDSW ? 1024 : 256, LDSW ? 1 : 2) k_gin_layer(G
   if constexpr (LDSW) {
     const u32x4* g1 = reinterpret_cast<const u32x4*>(a.gp.w1_pk);
     const u32x4* g2 = reinterpret_cast<const u32x4*>(a.gp.w2_pk);
-    for (int i = threadIdx.x; i < 32 * 128; i += blockDim.x) L[i] = g1[i];
-    for (int i = threadIdx.x; i < 32 * 128; i += blockDim.x) L[32 * 128 + i] = g2[i];
+    ag_copy_lds(L, g1, 32 * 128);
+    ag_copy_lds(L + 32 * 128, g2, 32 * 128);
   }
   const int lane = ag_lane(), q = lane >> 4;
   const int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
