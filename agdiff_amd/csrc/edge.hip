@@ -807,7 +807,6 @@ __device__ __forceinline__ void ag_poly_features(float d, float two_over_rc, int
 struct RadConvArgs {
   const float* poly_pk;  // pk [12][NKT]: filter polynomials of conv1 (channel tiles 0..7) and conv2 (8..11), bias included
   const int32_t* n_dev;  // R
-  const int32_t* in_ptr; // rad_ptr [N+1]
   const int32_t* e_src;
   const int32_t* e_dst;
   const float* e_len;
@@ -830,7 +829,8 @@ struct RadConvArgs {
 // Same tile walk, message and destination-segmented reduction as k_cfconv_fused (chunks of consecutive 16-edge tiles per
 // wave, running sums in registers, agg_first for lists that span chunks: no atomics, fixed order), but the filter is
 // NKT x 12 x 3 MFMAs per tile instead of 264 and needs no edge_attr stream: what is left is the x[src] gathers and the
-// reduction, so the kernel runs 16 waves per CU next to 24 NKT KiB of coefficients in LDS.
+// reduction, so the kernel runs 12 waves per CU (~160 VGPRs) next to 24 NKT KiB of coefficients in LDS.  The lists'
+// offsets (rad_ptr / lp_ptr) are only needed by the node stage: here every boundary comes from the rows' own targets.
 // TYPED: the same over the LOCAL list, whose edges carry a type each (bond / 2-hop / 3-hop): a tile's edges are grouped
 // by type on the fly (wave-uniform loop over the types present, typically three) and every group adds its masked
 // features times its own coefficient set (all sets resident in LDS) to the tile's filter values before the reduction.
@@ -1453,7 +1453,6 @@ extern "C" int agdiff_cfconv_local(const agdiff_params_t* p, const agdiff_topo_t
     RadConvArgs a;
     a.poly_pk = p->conv[k].filt_poly_typed_pk;
     a.n_dev = ws->num_local_padded;
-    a.in_ptr = topo->lp_ptr;
     a.e_src = topo->lp_src;
     a.e_dst = topo->lp_dst;
     a.e_len = ws->l_len_p;
@@ -1491,7 +1490,6 @@ extern "C" int agdiff_cfconv_radius(const agdiff_params_t* p, const agdiff_topo_
   RadConvArgs a;
   a.poly_pk = p->conv[k].filt_poly_pk;
   a.n_dev = ws->num_rad;
-  a.in_ptr = ws->rad_ptr;
   a.e_src = ws->rad_src;
   a.e_dst = ws->rad_dst;
   a.e_len = ws->rad_len;
