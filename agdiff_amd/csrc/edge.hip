@@ -944,8 +944,13 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_radius(RadConv
           rd[r] = __shfl(my_dst, 4 * q + r);
         }
         // one or two targets in the tile (every live row belongs to the first or to the last one): fast reduction
-        const bool fast = __ballot(my_dst >= 0 && my_dst != t0 && my_dst != t1) == 0;
+        const uint64_t others = __ballot(my_dst >= 0 && my_dst != t0 && my_dst != t1) & 0xFFFFull;
         const bool two = t1 != t0;
+        // a third target between the first and the last one (its whole list lies inside the tile): still a fast reduction
+        // when every other row belongs to it -- QM9-shaped molecules (radius in-degree ~14) have such a tile every few tiles
+        const int tm = others ? __builtin_amdgcn_readlane(my_dst, (int)__builtin_ctzll(others)) : -1;
+        const bool three = others != 0 && (__ballot(my_dst >= 0 && my_dst != t0 && my_dst != t1 && my_dst != tm) & 0xFFFFull) == 0;
+        const bool fast = others == 0 || three;
         f32x4 m0, m1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1077,11 +1082,21 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_radius(RadConv
               }
             }
             const float r0 = carry[g4] + ag_quarter_reduce_scatter4(p0[0], p0[1], p0[2], p0[3]);
-            if (two) {       // the first target's list ends in this tile; the second one's sum stays open
+            if (two) {       // the first target's list ends in this tile; the last one's sum stays open
               dp0[16 * (4 * g4 + q) + col] = r0;
               carry[g4] = ag_quarter_reduce_scatter4(p1[0], p1[1], p1[2], p1[3]);
             } else {
               carry[g4] = r0;
+            }
+            if (three) {     // the middle target's list starts and ends here: its sums go straight to its row of agg
+              float pm[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                pm[j] = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pm[j] = fmaf(zc[j][r] * xg[kb][j][r], (rd[r] == tm) ? sr[r] : 0.0f, pm[j]);
+              }
+              a.agg[(size_t)tm * 192 + 16 * (4 * g4 + q) + col] = ag_quarter_reduce_scatter4(pm[0], pm[1], pm[2], pm[3]);
             }
           } else {
 #pragma unroll

@@ -823,6 +823,8 @@ static int64_t ag_node_split_max_tiles() {
 }
 static int ag_node_waves_per_wg(int64_t tiles) {
   if (tiles < ag_node_ldsw_min_tiles()) return 4;
+  static const int forced = getenv("AGDIFF_NODE_WAVES") ? atoi(getenv("AGDIFF_NODE_WAVES")) : 0;      // experiments
+  if (forced >= 4 && forced <= 16) return forced;
   int64_t w = (tiles + 255) / 256;
   if (w > 16) w = 16;
   return (int)w;
