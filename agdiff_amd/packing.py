@@ -8,6 +8,10 @@ Output-preserving transformations applied here (each checked against the oracle 
     (== 1.0) is dropped (edge.py:84-103);
   * conv1/conv2 first filter layers and lin1 layers are fused along the output dimension.
 All folding is done in float64 and rounded once to float32.
+
+Since round 2b also the *filter polynomials* (DESIGN.md §4a): MLPEdgeEncoder followed by a CFConv's filter network is a
+function of the edge length alone for a given edge type, fitted here in float64 at Chebyshev nodes and handed to the
+kernels only when it reproduces the networks to POLY_TOL (otherwise those edges keep the MLP kernels).
 """
 import ctypes
 
@@ -195,14 +199,17 @@ def _poly_targets(sd, cfg, typ, with_head):
     LN2 = float(np.log(2.0))
     fns = {}
     for k in range(cfg.num_convs):
-        def filt(d, k=k):
+        convs = []          # (nn.0 weight, bias, beta, nn.2 weight, bias) of conv1 / conv2, copied to the host once
+        for conv in ("conv1", "conv2"):
+            p = "encoder_global.interactions.%d.%s" % (k, conv)
+            convs.append((g(p + ".nn.0.weight"), g(p + ".nn.0.bias"), g(p + ".nn.1.beta"), g(p + ".nn.2.weight"), g(p + ".nn.2.bias")))
+
+        def filt(d, convs=convs):
             a = attr(d)
             outs = []
-            for conv in ("conv1", "conv2"):
-                p = "encoder_global.interactions.%d.%s" % (k, conv)
-                u = F.linear(a, g(p + ".nn.0.weight"), g(p + ".nn.0.bias"))
-                s = F.softplus(g(p + ".nn.1.beta") * u) - LN2                          # schnet.py:71-80
-                outs.append(F.linear(s, g(p + ".nn.2.weight"), g(p + ".nn.2.bias")))
+            for W0, b0, beta, W2, b2 in convs:
+                s = F.softplus(beta * F.linear(a, W0, b0)) - LN2                           # schnet.py:71-80
+                outs.append(F.linear(s, W2, b2))
             return torch.cat(outs, 1).numpy()
         fns["conv%d.filt_poly_pk" % k] = filt
     if with_head:
