@@ -1351,6 +1351,12 @@ extern "C" int agdiff_edge_scales(const agdiff_params_t* p, const agdiff_topo_t*
 extern "C" int agdiff_edge_scales_split(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
                                         int32_t which, void* stream) {
   if (!p || !topo || !ws || p->num_convs > AGDIFF_MAX_CONVS) return AGDIFF_ERR_ARG;
+  if (which == 2) {        // radius list, one evaluation per canonical (radius-only) entry written to both directions
+    if (!ws->r_scale || !ws->c_len || !ws->num_canon || !ws->c_rpos || !ws->c_rmir) return AGDIFF_ERR_ARG;
+    const int64_t R = topo->max_edges - topo->num_local;
+    return launch_edge_scales(p, ws->num_canon, R, ws->c_len, ws->c_rpos, ws->c_rmir, ws->r_scale,
+                              ((R + AG_TW - 1) / AG_TW) * AG_TW, stream);
+  }
   if (which == 0) {        // radius list
     if (!ws->r_scale || !ws->rad_len || !ws->num_rad) return AGDIFF_ERR_ARG;
     const int64_t R = topo->max_edges - topo->num_local;

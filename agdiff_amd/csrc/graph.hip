@@ -45,6 +45,11 @@ struct GraphArgs {
   int32_t* rad_src;
   int32_t* rad_dst;
   float* rad_len;
+  // canon_radius_only != 0: the canonical list holds radius edges only (the denoising loop: nothing but the global head
+  // and the radius scales walks it then), and c_rpos / c_rmir give the entry's and its mirror's position in the radius list
+  int32_t canon_radius_only;
+  int32_t* c_rpos;
+  int32_t* c_rmir;
   int32_t num_graphs;
 };
 
@@ -152,7 +157,13 @@ __global__ void __launch_bounds__(AG_GRAPH_THREADS) k_graph(GraphArgs a) {
     for (int c = 0; 64 * c < n; ++c) {
       const int j = 64 * c + lane;
       const bool e = j < n && bit(inbits, i, j);
-      const bool canon = e && (j < i || !has_mirror(i, j));
+      bool canon;
+      if (a.canon_radius_only) {       // radius edges: a mirror is the radius edge the other way round (same length)
+        const bool rad = e && !bit(locbits, i, j);
+        canon = rad && (j < i || !(bit(inbits, j, i) && !bit(locbits, j, i)));
+      } else {
+        canon = e && (j < i || !has_mirror(i, j));
+      }
       cdeg += __popcll(__ballot(canon));
     }
     if (lane == 0) scan_c[i] = cdeg;
@@ -226,8 +237,15 @@ __global__ void __launch_bounds__(AG_GRAPH_THREADS) k_graph(GraphArgs a) {
       const uint64_t lmask = (uint64_t)locbits[i * words + 2 * c] | ((uint64_t)locbits[i * words + 2 * c + 1] << 32);
       const uint64_t rmask = emask & ~lmask;
       const bool e = (emask >> lane) & 1ull;
-      const bool mir = e && has_mirror(i, j);
-      const bool canon = e && (j < i || !mir);
+      bool mir, canon;
+      if (a.canon_radius_only) {
+        const bool rad = (rmask >> lane) & 1ull;
+        mir = rad && bit(inbits, j, i) && !bit(locbits, j, i);
+        canon = rad && (j < i || !mir);
+      } else {
+        mir = e && has_mirror(i, j);
+        canon = e && (j < i || !mir);
+      }
       const uint64_t cmask = __ballot(canon);
       if (e) {
         const int p = p0 + __popcll(emask & lt);
@@ -256,6 +274,18 @@ __global__ void __launch_bounds__(AG_GRAPH_THREADS) k_graph(GraphArgs a) {
           a.c_dst[cp] = g0 + i;
           a.c_pos[cp] = p;
           a.c_mir[cp] = mir ? base + (j ? sin[j - 1] : 0) + rank_below(inbits, j, i) : -1;
+          if (a.canon_radius_only && a.c_rpos) {     // positions in the radius list (row j's radius bits below column i)
+            a.c_rpos[cp] = rp0 + __popcll(rmask & lt);
+            int rm = -1;
+            if (mir) {
+              const uint32_t* rj = inbits + j * words;
+              const uint32_t* lj = locbits + j * words;
+              int k = __popc(rj[i >> 5] & ~lj[i >> 5] & ((1u << (i & 31)) - 1u));
+              for (int w = 0; w < (i >> 5); ++w) k += __popc(rj[w] & ~lj[w]);
+              rm = base + (j ? sin[j - 1] : 0) - a.loc_in_ptr[g0 + j] + k;
+            }
+            a.c_rmir[cp] = rm;
+          }
         }
       }
       p0 += __popcll(emask);
@@ -341,6 +371,11 @@ __global__ void k_local_lengths(const int32_t* __restrict__ src, const int32_t* 
 
 extern "C" int agdiff_graph_build(const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, float cutoff,
                                   void* stream) {
+  return agdiff_graph_build_ex(topo, ws, pos, cutoff, 0, stream);
+}
+
+extern "C" int agdiff_graph_build_ex(const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, float cutoff,
+                                     int32_t canon_radius_only, void* stream) {
   if (!topo || !ws || !pos || topo->num_graphs <= 0 || topo->num_nodes <= 0 || (topo->num_local > 0 && !topo->loc_row))
     return AGDIFF_ERR_ARG;
   if (!ws->graph_edge_cnt || !ws->graph_edge_ptr || !ws->in_ptr || !ws->out_ptr || !ws->e_src || !ws->e_dst ||
@@ -385,6 +420,10 @@ extern "C" int agdiff_graph_build(const agdiff_topo_t* topo, const agdiff_ws_t* 
   a.rad_src = ws->rad_src;
   a.rad_dst = ws->rad_dst;
   a.rad_len = ws->rad_len;
+  if (canon_radius_only && (!rad || !ws->c_rpos || !ws->c_rmir)) return AGDIFF_ERR_ARG;
+  a.canon_radius_only = canon_radius_only ? 1 : 0;
+  a.c_rpos = ws->c_rpos;
+  a.c_rmir = ws->c_rmir;
   a.num_graphs = (int32_t)topo->num_graphs;
   const int max_atoms = (int)topo->max_atoms_per_graph;
   if (max_atoms <= 0 || max_atoms > AGDIFF_MAX_ATOMS_PER_GRAPH) return AGDIFF_ERR_LIMIT;
