@@ -168,12 +168,18 @@ int global_front_split(const agdiff_params_t* p, const agdiff_topo_t* topo, cons
 int global_back_split(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int flags,
                       hipEvent_t local_ready, void* stream) {
   const int64_t etiles = (topo->max_edges + AG_TW - 1) / AG_TW;
-  AG_TRY(agdiff_schnet_node_stage_split(p, topo, ws, 0, 1, stream));
+  // stage 0 (embeddings + block 0's lin1) is the same on every step of a run: written to ws->h0 / ws->xs0 once, block 0
+  // reads it from there
+  const bool cache = ws->h0 && ws->xs0;
+  if (!(cache && (flags & AGDIFF_FWD_STAGE0_CACHED))) AG_TRY(agdiff_schnet_node_stage_split(p, topo, ws, 0, 1 | 4, stream));
+  agdiff_ws_t ws0 = *ws;
+  if (cache) ws0.xs = ws->xs0;
   for (int k = 0; k < p->num_convs; ++k) {
-    AG_TRY(agdiff_cfconv_radius(p, topo, ws, k, stream));
+    const agdiff_ws_t* wk = (k == 0) ? &ws0 : ws;
+    AG_TRY(agdiff_cfconv_radius(p, topo, wk, k, stream));
     if (k == 0 && local_ready && hipStreamWaitEvent((hipStream_t)stream, local_ready, 0) != hipSuccess) return AGDIFF_ERR_LAUNCH;
-    AG_TRY(agdiff_cfconv_local(p, topo, ws, k, stream));
-    AG_TRY(agdiff_schnet_node_stage_split(p, topo, ws, k + 1, 1, stream));
+    AG_TRY(agdiff_cfconv_local(p, topo, wk, k, stream));
+    AG_TRY(agdiff_schnet_node_stage_split(p, topo, ws, k + 1, 1 | (k == 0 ? 2 : 0), stream));
   }
   if (flags & AGDIFF_FWD_SAMPLER) {
     // only the radius edges' outputs are used (dualenc.py:516-518): the head's edge_attr half from the d-polynomial, over

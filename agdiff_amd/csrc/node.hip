@@ -16,6 +16,7 @@ struct NodeStageArgs {
   const float* agg;
   const float* agg_first;
   float* h;
+  const float* h_in;           // the block's input h for the residual (= h, or the cached stage-0 output for block 0)
   float* xs;
   int64_t n;
   int32_t finish;
@@ -198,7 +199,7 @@ __global__ void __launch_bounds__(LDSW ? 1024 : 256, LDSW ? 1 : 2) k_schnet_node
         ag_cvt_tiles<MODE, 1, 0>(s1, sb);
         AG_NODE_DENSE(false, 1, 8, 0, 0, sb, s2, a.prev.scale2_pk, 4);
       }
-      ag_load_row<8, 0>(hv, a.h + (size_t)nd * 128, q);
+      ag_load_row<8, 0>(hv, a.h_in + (size_t)nd * 128, q);
 #pragma unroll
       for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -311,7 +312,7 @@ __global__ void __launch_bounds__(256, 2) k_schnet_node_stage_split(NodeStageArg
     g1[0] = ag_ld4(a.prev.gate1_b + 16 * w + 4 * q);
     s1[0] = s1[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 2; ++j) hv2[j] = ag_ld4(a.h + (size_t)nd * 128 + 16 * (2 * w + j) + 4 * q);   // used at the end
+    for (int j = 0; j < 2; ++j) hv2[j] = ag_ld4(a.h_in + (size_t)nd * 128 + 16 * (2 * w + j) + 4 * q);   // used at the end
   } else {
     // stage 0: h = embedding[z]; wave w writes its two tiles of the row, every wave keeps the whole row as operands
     f32x4 hrow[8];
@@ -838,7 +839,7 @@ extern "C" int agdiff_schnet_node_stage(const agdiff_params_t* p, const agdiff_t
 extern "C" int agdiff_schnet_node_stage_split(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
                                               int32_t k, int32_t split, void* stream) {
   if (!p || !topo || !ws || k < 0 || k > p->num_convs || p->num_convs > AGDIFF_MAX_CONVS) return AGDIFF_ERR_ARG;
-  if (split && (!ws->rad_ptr || !ws->agg_loc || !ws->agg_first_loc || !topo->lp_ptr)) return AGDIFF_ERR_ARG;
+  if ((split & 1) && (!ws->rad_ptr || !ws->agg_loc || !ws->agg_first_loc || !topo->lp_ptr)) return AGDIFF_ERR_ARG;
   if (topo->num_nodes <= 0) return AGDIFF_OK;
   NodeStageArgs a;
   a.finish = k > 0;
@@ -851,6 +852,7 @@ extern "C" int agdiff_schnet_node_stage_split(const agdiff_params_t* p, const ag
   a.agg = ws->agg;
   a.agg_first = ws->agg_first;
   a.h = ws->h;
+  a.h_in = ws->h;
   a.xs = ws->xs;
   a.n = topo->num_nodes;
   a.chunk_edges = AG_TW * agdiff_conv_chunk_tiles(topo->max_edges);
@@ -858,7 +860,14 @@ extern "C" int agdiff_schnet_node_stage_split(const agdiff_params_t* p, const ag
   a.agg2 = nullptr;
   a.agg_first2 = nullptr;
   a.chunk_edges2 = 1;
-  if (split) {         // block k-1 ran as agdiff_cfconv_radius (ws->agg) + agdiff_cfconv_local (ws->agg_loc)
+  // Stage 0 (embedding + block 0's lin1) does not depend on the positions: split bit 2 makes stage 0 write its outputs to
+  // the cache ws->h0 / ws->xs0 instead of ws->h / ws->xs, bit 1 makes stage 1 take block 0's input h from that cache.
+  if ((split & 4) && k == 0 && ws->h0 && ws->xs0) {
+    a.h = ws->h0;
+    a.xs = ws->xs0;
+  }
+  if ((split & 2) && k == 1 && ws->h0) a.h_in = ws->h0;
+  if (split & 1) {     // block k-1 ran as agdiff_cfconv_radius (ws->agg) + agdiff_cfconv_local (ws->agg_loc)
     a.in_ptr = ws->rad_ptr;
     a.chunk_edges = AG_TW * agdiff_conv_chunk_tiles(topo->max_edges - topo->num_local);
     if (topo->num_local > 0) {

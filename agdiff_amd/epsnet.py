@@ -469,6 +469,7 @@ class LangevinRun:
             self.topo, self.ws = model._batch(atom_type, bond_index, bond_type, batch, num_graphs, extend_order)
             self.radius_flags = model._fwd_flags(self.topo, extend_radius, with_global=False)
             self._sampler_flag = _lib.DEFINES["AGDIFF_FWD_SAMPLER"]    # only radius edges' global scores are used (dualenc.py:516-518)
+            self._stage0_done = False
             T = model.num_timesteps
             self.steps = list(step_indices) if step_indices is not None else list(reversed(range(T - n_steps, T)))
             self.pos = (pos_init.detach().to(dev, torch.float32) * self.sigmas[-1].to(dev)).contiguous()
@@ -529,10 +530,14 @@ class LangevinRun:
                 a.use_global = 1 if use_global else 0
                 run_global = 1 if (use_global or not self.skip_discarded) else 0
                 self.global_steps += run_global
+                # node stage 0 of the SchNet encoder does not depend on the positions: from the second global step of
+                # the run on its cached outputs are used (ws.h0 / ws.xs0)
+                cached = _lib.DEFINES["AGDIFF_FWD_STAGE0_CACHED"] if (run_global and self._stage0_done) else 0
                 _lib.check(lib.agdiff_score_forward(ctypes.byref(pk.struct), ctypes.byref(topo.struct),
                                                     ctypes.byref(ws.struct), self.pos_p,
-                                                    run_global | self.radius_flags | self._sampler_flag, stream),
+                                                    run_global | self.radius_flags | self._sampler_flag | cached, stream),
                            "agdiff_score_forward")
+                self._stage0_done = self._stage0_done or bool(run_global)
                 _lib.check(lib.agdiff_langevin_update(ctypes.byref(topo.struct), ctypes.byref(ws.struct),
                                                       ctypes.byref(a), stream), "agdiff_langevin_update")
                 self.k += 1

@@ -210,6 +210,7 @@ class Workspace:
         self.l_scale = f32(2 * _lib.DEFINES["AGDIFF_MAX_CONVS"] * ptiles * TW)
         self.l_attr_frag = f32(ptiles * TW * 128)
         self.l_len_p = f32(ptiles * TW)
+        self.h0, self.xs0 = f32(N * 128), f32(N * 192)
         self.agg_loc = f32(N * 192)
         self.agg_first_loc = f32((ptiles + lchunk - 1) // lchunk * 192)
         w = _lib.Workspace()

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 21
+#define AGDIFF_ABI_VERSION 22
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -266,6 +266,8 @@ typedef struct agdiff_ws {
   float*   l_attr_frag;      /* [ceil(Lp/16)] tiles x 2048 floats: edge_attr of the local edges in operand form, by padded-list
                                 position (only written / read when the local edges go through the filter MLPs) */
   float*   l_len_p;          /* [Lp] lengths of the local edges by padded-list position (agdiff_local_lengths; pads stay 0) */
+  float*   h0;               /* [N][128] cache of node stage 0's h (the atom embeddings: they do not depend on the positions) */
+  float*   xs0;              /* [N][192] ... and of its xs (block 0's lin1 / BN / LeakyReLU outputs) */
   float*   agg_loc;          /* [N][192] CFConv aggregates over the local edges */
   float*   agg_first_loc;    /* [ceil(ceil(Lp/16) / agdiff_conv_chunk_tiles(Lp))][192] */
 } agdiff_ws_t;
@@ -333,8 +335,9 @@ int agdiff_edge_encoder(const agdiff_params_t* p, const int32_t* n_edges_dev, in
  * k >= 1 finishes InteractionBlock k-1 (lin2/BN, act, lin, gate, AdaptiveScaling, residual);
  * k < num_convs also applies block k's conv{1,2}.lin1/BN/LeakyReLU into ws->xs. */
 int agdiff_schnet_node_stage(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k, void* stream);
-/* The same with split != 0: block k-1's aggregates are ws->agg (radius edges, lists ws->rad_ptr) + ws->agg_loc (local
- * edges, lists topo->lp_ptr) -- agdiff_cfconv_radius / agdiff_cfconv_local below. */
+/* The same with split bit 0 set: block k-1's aggregates are ws->agg (radius edges, lists ws->rad_ptr) + ws->agg_loc (local
+ * edges, lists topo->lp_ptr) -- agdiff_cfconv_radius / agdiff_cfconv_local below.  Bit 2 (k == 0): write the stage's h / xs
+ * to the cache ws->h0 / ws->xs0; bit 1 (k == 1): block 0's input h is ws->h0. */
 int agdiff_schnet_node_stage_split(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k,
                                    int32_t split, void* stream);
 
@@ -405,6 +408,10 @@ int agdiff_cfconv_aggregate(const float* x, const float* W, const int32_t* in_pt
  *                           poly_kt > 0 neither the edge encoder nor the head runs on anything but d-polynomials and the
  *                           local list; ws->e_inv_global is then only valid at radius edges */
 #define AGDIFF_FWD_SAMPLER 8
+/*   AGDIFF_FWD_STAGE0_CACHED ws->h0 / ws->xs0 already hold node stage 0's outputs for this topology and these weights (an
+ *                           earlier call with AGDIFF_FWD_GLOBAL on the same workspace wrote them): stage 0 -- embedding
+ *                           look-up and block 0's lin1, which do not depend on `pos` -- is not launched again */
+#define AGDIFF_FWD_STAGE0_CACHED 16
 int agdiff_score_forward(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
                          const float* pos, int32_t flags, void* stream);
 
