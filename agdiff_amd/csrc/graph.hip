@@ -50,6 +50,11 @@ struct GraphArgs {
   int32_t canon_radius_only;
   int32_t* c_rpos;
   int32_t* c_rmir;
+  // hand-over from the count pass to the fill pass (optional): the in-adjacency masks and the two degree arrays of every
+  // molecule, so that the fill pass does not repeat the distance tests and the mirror look-ups
+  uint32_t* g_inbits;    // [N][words]
+  int32_t* g_deg;        // [N] in-degrees
+  int32_t* g_cdeg;       // [N] canonical in-degrees
   int32_t num_graphs;
 };
 
@@ -123,8 +128,17 @@ __global__ void __launch_bounds__(AG_GRAPH_THREADS) k_graph(GraphArgs a) {
   }
   __syncthreads();
 
+  int wave_total = 0, wave_ctotal = 0;
+  if (FILL && a.g_inbits) {
+    // the count pass of this build left the masks and degrees in global memory
+    for (int k = threadIdx.x; k < n * words; k += blockDim.x) inbits[k] = a.g_inbits[(size_t)g0 * words + k];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      sin[i] = a.g_deg[g0 + i];
+      scan_c[i] = a.g_cdeg[g0 + i];
+    }
+    __syncthreads();
+  } else {
   // pass 1: kept masks and in-degrees
-  int wave_total = 0;
   for (int i = wave; i < n; i += nwaves) {
     const float xi = spos[3 * i], yi = spos[3 * i + 1], zi = spos[3 * i + 2];
     int cnt_r = 0, deg = 0;
@@ -151,7 +165,6 @@ __global__ void __launch_bounds__(AG_GRAPH_THREADS) k_graph(GraphArgs a) {
   __syncthreads();
 
   // canonical in-degrees (needs every row of inbits: after the barrier)
-  int wave_ctotal = 0;
   for (int i = wave; i < n; i += nwaves) {
     int cdeg = 0;
     for (int c = 0; 64 * c < n; ++c) {
@@ -170,6 +183,14 @@ __global__ void __launch_bounds__(AG_GRAPH_THREADS) k_graph(GraphArgs a) {
     wave_ctotal += cdeg;
   }
   __syncthreads();
+  if (!FILL && a.g_inbits) {        // hand the masks and degrees over to the fill pass
+    for (int k = threadIdx.x; k < n * words; k += blockDim.x) a.g_inbits[(size_t)g0 * words + k] = inbits[k];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      a.g_deg[g0 + i] = sin[i];
+      a.g_cdeg[g0 + i] = scan_c[i];
+    }
+  }
+  }
 
   if (!FILL) {
     __shared__ int wsum[2][AG_GRAPH_THREADS / 64];
@@ -424,6 +445,10 @@ extern "C" int agdiff_graph_build_ex(const agdiff_topo_t* topo, const agdiff_ws_
   a.canon_radius_only = canon_radius_only ? 1 : 0;
   a.c_rpos = ws->c_rpos;
   a.c_rmir = ws->c_rmir;
+  const bool handover = ws->g_inbits && ws->g_deg && ws->g_cdeg;
+  a.g_inbits = handover ? reinterpret_cast<uint32_t*>(ws->g_inbits) : nullptr;
+  a.g_deg = ws->g_deg;
+  a.g_cdeg = ws->g_cdeg;
   a.num_graphs = (int32_t)topo->num_graphs;
   const int max_atoms = (int)topo->max_atoms_per_graph;
   if (max_atoms <= 0 || max_atoms > AGDIFF_MAX_ATOMS_PER_GRAPH) return AGDIFF_ERR_LIMIT;

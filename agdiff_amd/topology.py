@@ -211,6 +211,8 @@ class Workspace:
         self.l_attr_frag = f32(ptiles * TW * 128)
         self.l_len_p = f32(ptiles * TW)
         self.h0, self.xs0 = f32(N * 128), f32(N * 192)
+        self.g_inbits = i32(N * 2 * ((topo.max_atoms + 63) // 64))
+        self.g_deg, self.g_cdeg = i32(N), i32(N)
         self.agg_loc = f32(N * 192)
         self.agg_first_loc = f32((ptiles + lchunk - 1) // lchunk * 192)
         w = _lib.Workspace()

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 22
+#define AGDIFF_ABI_VERSION 23
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -266,6 +266,10 @@ typedef struct agdiff_ws {
   float*   l_attr_frag;      /* [ceil(Lp/16)] tiles x 2048 floats: edge_attr of the local edges in operand form, by padded-list
                                 position (only written / read when the local edges go through the filter MLPs) */
   float*   l_len_p;          /* [Lp] lengths of the local edges by padded-list position (agdiff_local_lengths; pads stay 0) */
+  int32_t* g_inbits;         /* [N][2 * ceil(max_atoms_per_graph / 64)] hand-over from the graph build's count pass to its fill
+                                pass: row i = in-adjacency bit mask of atom i inside its molecule (optional, with g_deg / g_cdeg) */
+  int32_t* g_deg;            /* [N] in-degrees */
+  int32_t* g_cdeg;           /* [N] canonical in-degrees */
   float*   h0;               /* [N][128] cache of node stage 0's h (the atom embeddings: they do not depend on the positions) */
   float*   xs0;              /* [N][192] ... and of its xs (block 0's lin1 / BN / LeakyReLU outputs) */
   float*   agg_loc;          /* [N][192] CFConv aggregates over the local edges */
