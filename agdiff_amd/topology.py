@@ -112,8 +112,8 @@ class BatchTopology:
         self.lc_pos, self.lc_mir, self.loc_row = i32(lc_pos), i32(lc_mir), i32(loc_row)
         self.loc_in_src, self.loc_in_row = i32(src[in_order]), i32(loc_row[in_order])
         # the local list as a destination-sorted edge list of its own for the split CFConv, every target's list padded to
-        # a multiple of 8 entries (agdiff_topo_t.lp_*: a 16-edge tile then holds at most two targets)
-        pdeg = (locdeg + 7) // 8 * 8
+        # at least 8 entries (agdiff_topo_t.lp_*: a 16-edge tile then holds at most three targets, the middle one whole)
+        pdeg = np.where(locdeg > 0, np.maximum(locdeg, 8), 0)
         lp_ptr = np.concatenate([[0], np.cumsum(pdeg)])
         Lp = int(lp_ptr[-1])
         tgt = np.repeat(np.arange(N), pdeg)                               # target of every padded entry

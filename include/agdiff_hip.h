@@ -184,10 +184,11 @@ typedef struct agdiff_topo {
   const int32_t* loc_row;    /* [L]: canonical index (row of l_attr_rows) of every local edge */
   const int32_t* loc_in_src; /* [L]: loc_src[loc_in_eid[s]] (the GIN gather reads its indices by in-slot, one level deep) */
   const int32_t* loc_in_row; /* [L]: loc_row[loc_in_eid[s]] */
-  /* the local list as a destination-sorted edge list of its own for the split CFConv, every target's list PADDED to a
-   * multiple of 8 entries: a 16-edge tile then holds at most two targets (local in-degrees are ~8: unpadded, most tiles
-   * would hold three or more and take the kernels' general reduction).  Pad entries: src = dst = the target, type of the
-   * list's first edge, and nothing ever writes their CFConv scale (zero-initialised): they contribute exactly 0. */
+  /* the local list as a destination-sorted edge list of its own for the split CFConv, every non-empty target's list PADDED to
+   * at least 8 entries: a 16-edge tile then holds at most three targets with the middle one's list whole, which the
+   * kernels' fast reduction covers (local in-degrees are ~8: unpadded, many tiles would hold four or more and take the
+   * general reduction).  Pad entries: src = dst = the target, type of the list's first edge, and nothing ever writes their
+   * CFConv scale (zero-initialised): they contribute exactly 0. */
   int64_t num_local_padded;  /* Lp */
   const int32_t* lp_ptr;     /* [N+1]: padded list of target i = [lp_ptr[i], lp_ptr[i+1]) */
   const int32_t* lp_src;     /* [Lp] */
