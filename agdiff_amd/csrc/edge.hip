@@ -994,11 +994,24 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_radius(RadConv
 #pragma unroll
           for (int nt = 0; nt < AG_CONV_NCH; ++nt) zall[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
           uint64_t todo = __ballot(my_slot >= 0) & 0xFFFFull;      // one lane per edge column (the quarters hold copies)
+          // the features are evaluated (and split) once; a group's operand is a copy with the other rows zeroed
+          AgIn<MODE> phall[NKT];
+          ag_poly_features<MODE, NKT>(d, a.two_over_rc, q, phall);
           while (todo) {
             const int g = __builtin_amdgcn_readlane(my_slot, (int)__builtin_ctzll(todo));
             const bool in = my_slot == g;
             todo &= ~__ballot(in);
-            ag_poly_features<MODE, NKT>(d, a.two_over_rc, q, ph, in ? 1.0f : 0.0f);
+#pragma unroll
+            for (int t = 0; t < NKT; ++t) {
+              const u32x4 zero = {0u, 0u, 0u, 0u};
+              if constexpr (MODE == AG_F32) {
+                ph[t].v[0] = in ? phall[t].v[0] : f32x4{0.f, 0.f, 0.f, 0.f};
+                ph[t].v[1] = in ? phall[t].v[1] : f32x4{0.f, 0.f, 0.f, 0.f};
+              } else {
+                ph[t].hi = __builtin_bit_cast(bf16x8, in ? __builtin_bit_cast(u32x4, phall[t].hi) : zero);
+                ph[t].lo = __builtin_bit_cast(bf16x8, in ? __builtin_bit_cast(u32x4, phall[t].lo) : zero);
+              }
+            }
             const lds_u32x4* wg_ = wl_l + (size_t)g * (AG_CONV_NCH * NKT * 128);
 #pragma unroll
             for (int g4 = 0; g4 < AG_CONV_NCH / 4; ++g4) {
