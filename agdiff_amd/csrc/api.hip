@@ -84,15 +84,13 @@ int local_branch(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdi
   } else if (topo->num_local > 0) {
     if (canon && split) {
       if (agdiff_local_poly_enabled(p, topo, ws))     // the local CFConv takes its filters from polynomials: rows only
-        AG_TRY(agdiff_edge_encoder(p, ws->num_local_canon, ctiles, ws->lc_len, topo->lc_type, nullptr, ws->l_attr_rows, nullptr,
-                                   nullptr, nullptr, stream));
+        AG_TRY(agdiff_local_edge_rows(p, topo, ws, stream));
       else                  // ... and the operand-form copy at the padded-list positions of the edge and of its mirror
         AG_TRY(agdiff_edge_encoder(p, ws->num_local_canon, ctiles, ws->lc_len, topo->lc_type, ws->l_attr_frag, ws->l_attr_rows,
                                    topo->lp_row, topo->lc_ppos, topo->lc_pmir, stream));
       AG_TRY(agdiff_edge_scales_split(p, topo, ws, 1, stream));
-    } else if (canon)        // one evaluation and one row per mirror pair of local edges
-      AG_TRY(agdiff_edge_encoder(p, ws->num_local_canon, ctiles, ws->lc_len, topo->lc_type, nullptr, ws->l_attr_rows, nullptr,
-                                 nullptr, nullptr, stream));
+    } else if (canon)        // one evaluation and one row per mirror pair of local edges (polynomials where they apply)
+      AG_TRY(agdiff_local_edge_rows(p, topo, ws, stream));
     else
       AG_TRY(agdiff_edge_encoder(p, ws->num_local, ltiles, ws->l_len, topo->loc_type, nullptr, ws->l_attr_rows, nullptr,
                                  nullptr, nullptr, stream));

@@ -36,6 +36,7 @@ struct EncArgs {
   const int32_t* pos_index;   // optional (with mir_index): edge e's results go to positions pos_index[e] and, if
   const int32_t* mir_index;   // >= 0, mir_index[e] of out_frag / row_index instead of position e
   int64_t max_tiles;
+  const int32_t* tile_flags;  // optional: [0] = number of tiles to do (0: the launch returns at once), [1 + tile] != 0: do it
 };
 
 // Where one edge's results go (shared by the encoder kernels).
@@ -91,6 +92,7 @@ __global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_edge_encoder(EncAr
   lds_u32x4* lw1 = (lds_u32x4*)ag_enc_smem;
   lds_u32x4* lw23 = lw1 + 32 * 128;
   lds_u32x4* lw4 = lw23 + 32 * 128;           // 32 blocks x 64 (unit 0 only)
+  if (a.tile_flags && a.tile_flags[0] == 0) return;      // nothing flagged this step (uniform: before the fill)
   {
     const u32x4* g1 = reinterpret_cast<const u32x4*>(a.w1_pk);
     const u32x4* g2 = reinterpret_cast<const u32x4*>(a.w23_pk);
@@ -105,6 +107,7 @@ __global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_edge_encoder(EncAr
   const int64_t stride = (int64_t)gridDim.x * AG_PERSIST_WAVES;
   for (int64_t tile = (int64_t)blockIdx.x * AG_PERSIST_WAVES + (threadIdx.x >> 6); tile < a.max_tiles; tile += stride) {
     if (tile * AG_TW >= E) break;
+    if (a.tile_flags && a.tile_flags[1 + tile] == 0) continue;
     int lane = lane0;
     asm volatile("" : "+v"(lane));      // keep lane-derived addresses out of the loop-invariant set
     const int q = lane >> 4;
@@ -1158,6 +1161,93 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_radius(RadConv
   }
 }
 
+// ------------------------------------------------------------------------------ local edge_attr rows by polynomial
+struct AttrPolyArgs {
+  const float* poly_pk;       // [num_slots] x pk [8][1]
+  const int32_t* type_slot;
+  const int32_t* n_dev;
+  const float* e_len;
+  const int32_t* e_type;
+  float* out_rows;            // [n][128]
+  int32_t* flags;             // [1 + tiles]
+  int64_t max_tiles;
+  int32_t num_slots;
+  float cutoff;
+  float two_over_rc;
+};
+
+// edge_attr rows (fp32, natural feature order) of the canonical local edges from the per-type polynomials: a tile whose
+// 16 lengths all lie in [0, cutoff] and whose types all have a slot is evaluated here (features once, one masked MFMA
+// round per type present); any other tile is flagged for the encoder MLP (agdiff_local_edge_rows).
+#define AG_ATTRP_WAVES 8
+template <int MODE>
+__global__ void __launch_bounds__(64 * AG_ATTRP_WAVES, 2) k_edge_attr_poly(AttrPolyArgs a) {
+  extern __shared__ u32x4 ag_attrp_smem[];
+  lds_u32x4* wl = (lds_u32x4*)ag_attrp_smem;
+  __shared__ int wg_flagged;
+  if (threadIdx.x == 0) wg_flagged = 0;
+  ag_copy_lds(wl, reinterpret_cast<const u32x4*>(a.poly_pk), a.num_slots * 8 * 128);
+  __syncthreads();
+  const int lane0 = ag_lane();
+  const int E = *a.n_dev;
+  const int64_t stride = (int64_t)gridDim.x * AG_ATTRP_WAVES;
+  int my_flagged = 0;
+  for (int64_t tile = (int64_t)blockIdx.x * AG_ATTRP_WAVES + (threadIdx.x >> 6); tile < a.max_tiles; tile += stride) {
+    if (tile * AG_TW >= E) break;
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int q = lane >> 4;
+    const int64_t e = tile * AG_TW + (lane & 15);
+    const bool valid = e < E;
+    const float d = valid ? a.e_len[e] : 0.0f;
+    const int slot = valid ? a.type_slot[a.e_type[e]] : -1;
+    const bool hard = valid && (!(d >= 0.0f && d <= a.cutoff) || slot < 0);      // (also catches NaN lengths)
+    if (__ballot(hard)) {
+      if (lane == 0) a.flags[1 + tile] = 1;
+      ++my_flagged;
+      continue;
+    }
+    if (lane == 0) a.flags[1 + tile] = 0;
+    AgIn<MODE> phall[1], ph[1];
+    ag_poly_features<MODE, 1>(d, a.two_over_rc, q, phall);
+    f32x4 y[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) y[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const lds_u32x4* wl_l = ag_lds_base(wl, lane);
+    uint64_t todo = __ballot(slot >= 0) & 0xFFFFull;
+    while (todo) {
+      const int g = __builtin_amdgcn_readlane(slot, (int)__builtin_ctzll(todo));
+      const bool in = slot == g;
+      todo &= ~__ballot(in);
+      const u32x4 zero = {0u, 0u, 0u, 0u};
+      if constexpr (MODE == AG_F32) {
+        ph[0].v[0] = in ? phall[0].v[0] : f32x4{0.f, 0.f, 0.f, 0.f};
+        ph[0].v[1] = in ? phall[0].v[1] : f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+        ph[0].hi = __builtin_bit_cast(bf16x8, in ? __builtin_bit_cast(u32x4, phall[0].hi) : zero);
+        ph[0].lo = __builtin_bit_cast(bf16x8, in ? __builtin_bit_cast(u32x4, phall[0].lo) : zero);
+      }
+      const lds_u32x4* wg_ = wl_l + (size_t)g * (8 * 128);
+      u32x4 w[8][2];
+#pragma unroll
+      for (int ot = 0; ot < 8; ++ot) {
+        w[ot][0] = wg_[(ot * 2) * 64];
+        w[ot][1] = wg_[(ot * 2 + 1) * 64];
+      }
+#pragma unroll
+      for (int part = 0; part < AgParts<MODE>::n; ++part) {
+#pragma unroll
+        for (int ot = 0; ot < 8; ++ot) ag_block_mma_part<MODE, false>(y[ot], ph[0], w[ot], part);
+      }
+    }
+    if (valid) ag_store_row<8, 0>(y, a.out_rows + (size_t)e * 128, q);
+  }
+  // flagged tiles of the launch: one atomic per workgroup (a count of integers: the order does not matter)
+  if (lane0 == 0 && my_flagged) atomicAdd(&wg_flagged, my_flagged);
+  __syncthreads();
+  if (threadIdx.x == 0 && wg_flagged) atomicAdd(&a.flags[0], wg_flagged);
+}
+
 // ------------------------------------------------------------------------------ pair head, edge_attr half by polynomial
 struct HeadPolyArgs {
   agdiff_head_params_t hp;
@@ -1291,6 +1381,9 @@ extern "C" int agdiff_debug_conv_stamps(unsigned long long* out, int reset) {
 }
 #endif
 
+// (set by agdiff_local_edge_rows around its call of agdiff_edge_encoder: the launch then only does the flagged tiles)
+static thread_local const int32_t* g_enc_tile_flags = nullptr;
+
 extern "C" int agdiff_edge_encoder(const agdiff_params_t* p, const int32_t* n_edges_dev, int64_t max_tiles,
                                    const float* e_len, const int32_t* e_type, float* attr_frag, float* attr_rows,
                                    const int32_t* row_index, const int32_t* pos_index, const int32_t* mir_index,
@@ -1312,7 +1405,8 @@ extern "C" int agdiff_edge_encoder(const agdiff_params_t* p, const int32_t* n_ed
   }
   if (p->edge_encoder != 0) return AGDIFF_ERR_ARG;
   EncArgs a{p->ee_fe_w, p->ee_fe_b, p->ee_t1, p->ee_w1_pk, p->ee_t3, p->ee_w23_pk, p->ee_w4_pk, p->ee_b4,
-            n_edges_dev, e_len, e_type, attr_frag, attr_rows, row_index, pos_index, mir_index, max_tiles};
+            n_edges_dev, e_len, e_type, attr_frag, attr_rows, row_index, pos_index, mir_index, max_tiles, g_enc_tile_flags};
+  g_enc_tile_flags = nullptr;
   int64_t wgs = (max_tiles + AG_PERSIST_WAVES - 1) / AG_PERSIST_WAVES;
   if (wgs > 256) wgs = 256;
   const size_t smem = (size_t)80 * 2048;     // w1 (32 blocks) + w23 (32) + unit 0 of w4's 32 blocks
@@ -1585,6 +1679,48 @@ extern "C" int agdiff_pair_head_poly(const agdiff_params_t* p, const int32_t* n_
   }
   AG_CHECK_LAUNCH();
   return AGDIFF_OK;
+}
+
+extern "C" int agdiff_local_edge_rows(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, void* stream) {
+  if (!p || !topo || !ws) return AGDIFF_ERR_ARG;
+  if (topo->num_local == 0) return AGDIFF_OK;
+  if (!ws->l_attr_rows || !ws->lc_len || !ws->num_local_canon || !topo->lc_type || topo->num_local_canon <= 0) return AGDIFF_ERR_ARG;
+  const int64_t ctiles = (topo->num_local_canon + AG_TW - 1) / AG_TW;
+  static const bool off = getenv("AGDIFF_ATTR_POLY_OFF") != nullptr;      // A/B runs
+  const bool poly = !off && p->edge_encoder == 0 && p->poly_kt == 1 && p->poly_num_slots > 0 &&
+                    p->poly_num_slots <= AGDIFF_POLY_MAX_SLOTS && p->attr_poly_typed_pk && p->poly_type_slot && ws->enc_flags;
+  if (!poly)
+    return agdiff_edge_encoder(p, ws->num_local_canon, ctiles, ws->lc_len, topo->lc_type, nullptr, ws->l_attr_rows, nullptr,
+                               nullptr, nullptr, stream);
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(ws->enc_flags, 0, sizeof(int32_t), st) != hipSuccess) return AGDIFF_ERR_LAUNCH;
+  AttrPolyArgs a;
+  a.poly_pk = p->attr_poly_typed_pk;
+  a.type_slot = p->poly_type_slot;
+  a.n_dev = ws->num_local_canon;
+  a.e_len = ws->lc_len;
+  a.e_type = topo->lc_type;
+  a.out_rows = ws->l_attr_rows;
+  a.flags = ws->enc_flags;
+  a.max_tiles = ctiles;
+  a.num_slots = p->poly_num_slots;
+  a.cutoff = p->cutoff;
+  a.two_over_rc = 2.0f / p->cutoff;
+  int64_t wgs = (ctiles + AG_ATTRP_WAVES - 1) / AG_ATTRP_WAVES;
+  if (wgs > 512) wgs = 512;
+  const size_t smem = (size_t)p->poly_num_slots * 8 * 2048;
+  static std::atomic<uint64_t> attr_done{0};
+  if (!ag_allow_big_lds(attr_done, (size_t)AGDIFF_POLY_MAX_SLOTS * 8 * 2048, k_edge_attr_poly<AG_BF3>, k_edge_attr_poly<AG_F32>))
+    return AGDIFF_ERR_LAUNCH;
+  if (p->precision == AG_BF3)
+    k_edge_attr_poly<AG_BF3><<<dim3((unsigned)wgs), dim3(64 * AG_ATTRP_WAVES), smem, st>>>(a);
+  else
+    k_edge_attr_poly<AG_F32><<<dim3((unsigned)wgs), dim3(64 * AG_ATTRP_WAVES), smem, st>>>(a);
+  AG_CHECK_LAUNCH();
+  // the flagged tiles (if any) through the MLP: the launch returns before staging its weights when the count is 0
+  g_enc_tile_flags = ws->enc_flags;
+  return agdiff_edge_encoder(p, ws->num_local_canon, ctiles, ws->lc_len, topo->lc_type, nullptr, ws->l_attr_rows, nullptr,
+                             nullptr, nullptr, stream);
 }
 
 extern "C" int agdiff_pair_head(const agdiff_head_params_t* hp, const int32_t* n_edges_dev, int64_t max_tiles,

@@ -215,6 +215,8 @@ def _poly_targets(sd, cfg, typ, with_head):
     if with_head:
         Wb = g("grad_global_dist_mlp.layers.0.weight")[:, H:]
         fns["head_global.attr_poly_pk"] = lambda d: F.linear(attr(d), Wb).numpy()
+    else:               # local types: edge_attr itself (the GIN layers and the local head read it, agdiff_local_edge_rows)
+        fns["edge_attr_poly_pk"] = lambda d: attr(d).numpy()
     return fns
 
 
@@ -500,6 +502,9 @@ class PackedParams:
         nc = self._cfg.num_convs
         per_conv = [np.concatenate([pack_blocks(self._typed_mats[t]["conv%d.filt_poly_pk" % k], mode=self._mode) for t in by_slot])
                     for k in range(nc)]
+        attr_sets = np.concatenate([pack_blocks(self._typed_mats[t]["edge_attr_poly_pk"], mode=self._mode) for t in by_slot])
+        self.typed_attr_flat = torch.from_numpy(attr_sets).to(self.device)
+        prm.attr_poly_typed_pk = ctypes.c_void_p(self.typed_attr_flat.data_ptr())
         self.typed_flat = torch.from_numpy(np.concatenate(per_conv)).to(self.device)     # (the old buffer may still be in
         table = np.full(100, -1, dtype=np.int32)                                         #  use by enqueued launches: torch's
         for t, sl in self.local_slots.items():                                           #  allocator keeps it alive in stream order)

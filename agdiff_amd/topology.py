@@ -211,6 +211,7 @@ class Workspace:
         self.l_attr_frag = f32(ptiles * TW * 128)
         self.l_len_p = f32(ptiles * TW)
         self.h0, self.xs0 = f32(N * 128), f32(N * 192)
+        self.enc_flags = i32(1 + (topo.Lc + TW - 1) // TW)
         self.g_inbits = i32(N * 2 * ((topo.max_atoms + 63) // 64))
         self.g_deg, self.g_cdeg = i32(N), i32(N)
         self.agg_loc = f32(N * 192)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 23
+#define AGDIFF_ABI_VERSION 24
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -127,6 +127,8 @@ typedef struct agdiff_params {
   const float* schnet_emb;   /* [100][128] encoder_global.embedding (max_norm renorm applied to used rows) */
   const float* gin_emb;      /* [100][128] encoder_local.node_emb */
   const int32_t* poly_type_slot; /* [100] or null: slot of an edge type in filt_poly_typed_pk, -1 = none */
+  const float* attr_poly_typed_pk; /* [poly_num_slots] x pk [8][1] or null: edge_attr itself (128 features) of a local edge of a
+                                slotted type as a polynomial in d on [0, cutoff] (agdiff_local_edge_rows) */
   agdiff_conv_params_t conv[AGDIFF_MAX_CONVS];
   agdiff_gin_params_t gin[AGDIFF_MAX_CONVS_LOCAL];
   agdiff_head_params_t head_global;
@@ -271,6 +273,8 @@ typedef struct agdiff_ws {
                                 pass: row i = in-adjacency bit mask of atom i inside its molecule (optional, with g_deg / g_cdeg) */
   int32_t* g_deg;            /* [N] in-degrees */
   int32_t* g_cdeg;           /* [N] canonical in-degrees */
+  int32_t* enc_flags;        /* [1 + ceil(Lc/16)]: agdiff_local_edge_rows: [0] = tiles of the canonical local list that hold an edge
+                                longer than the cutoff this step (they go through the encoder MLP), [1 + tile] = 1 for those */
   float*   h0;               /* [N][128] cache of node stage 0's h (the atom embeddings: they do not depend on the positions) */
   float*   xs0;              /* [N][192] ... and of its xs (block 0's lin1 / BN / LeakyReLU outputs) */
   float*   agg_loc;          /* [N][192] CFConv aggregates over the local edges */
@@ -335,6 +339,13 @@ int agdiff_edge_scales(const agdiff_params_t* p, const agdiff_topo_t* topo, cons
 int agdiff_edge_encoder(const agdiff_params_t* p, const int32_t* n_edges_dev, int64_t max_tiles,
                         const float* e_len, const int32_t* e_type, float* attr_frag, float* attr_rows,
                         const int32_t* row_index, const int32_t* pos_index, const int32_t* mir_index, void* stream);
+
+/* edge_attr rows of the canonical local edges (ws->l_attr_rows, one row per canonical edge: what the GIN layers and the
+ * local head read; dualenc.py:214-216): with per-type polynomials available (p->attr_poly_typed_pk, p->poly_num_slots > 0)
+ * every 16-edge tile whose lengths all lie inside [0, cutoff] takes its rows from them; a tile with a longer edge (bonded
+ * atoms far apart at high sigma) is flagged and goes through agdiff_edge_encoder's MLP.  Without polynomials: the MLP for
+ * all of them.  Needs ws->lc_len (agdiff_local_lengths). */
+int agdiff_local_edge_rows(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, void* stream);
 
 /* Node-side stage k of SchNetEncoder.forward (encoder/schnet.py:268-282): k == 0 embeds atoms;
  * k >= 1 finishes InteractionBlock k-1 (lin2/BN, act, lin, gate, AdaptiveScaling, residual);

@@ -212,3 +212,45 @@ def test_radius_only_canonical_list_of_the_sampler(kind, mols, copies):
     assert np.all(cs[mk] < cd[mk])                                        # the canonical one of a pair is src < dst
     cover = np.bincount(np.concatenate([crp, crm[mk]]), minlength=R)
     assert R == int((ety == 0).sum()) and np.all(cover == 1)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_local_edge_rows_polynomial_and_flagged_tiles(precision):
+    """agdiff_local_edge_rows against agdiff_edge_encoder (the MLP) on the same canonical local list, through the C ABI:
+    compact molecules (every length inside the cutoff: all tiles by polynomial, none flagged), stretched ones (bonded atoms
+    far apart, as at high sigma: those tiles are flagged and go through the MLP), and a mix."""
+    from agdiff_amd import _lib, drugs_model_config, synth
+    lib = _lib.load()
+    cfg = drugs_model_config(num_diffusion_timesteps=20, beta_end=2e-5)
+    m = _model(cfg, "auto", precision=precision)
+    b = synth.make_packed_batch("drugs", 5, 3, seed=31)
+    at, bi, bt, ba = [t(b[k]).cuda() for k in ("atom_type", "bond_index", "bond_type", "batch")]
+    gen = torch.Generator().manual_seed(8)
+    base = torch.randn(at.shape[0], 3, generator=gen)
+    G = b["num_graphs"]
+    stretch = torch.ones(G)
+    stretch[G // 2:] = 9.0                       # the second half of the molecules blown up: lengths far beyond 10 A
+    for name, pos in (("compact", base * 1.5), ("stretched", base * 12.0), ("mixed", base * 1.5 * stretch[t(b["batch"])].unsqueeze(1))):
+        m(at, pos.cuda(), bi, bt, ba, None, extend_order=False)
+        topo, ws, pk = m._batch_cache[1], m._batch_cache[2], m.packed()
+        assert pk.struct.poly_num_slots > 0
+        P, T, W, st = ctypes.byref(pk.struct), ctypes.byref(topo.struct), ctypes.byref(ws.struct), _lib.stream_ptr()
+        ct = (topo.Lc + _lib.TILE - 1) // _lib.TILE
+        assert lib.agdiff_edge_encoder(P, _lib.ptr(ws.num_local_canon), ct, _lib.ptr(ws.lc_len), _lib.ptr(topo.lc_type), None,
+                                       _lib.ptr(ws.l_attr_rows), None, None, None, st) == 0
+        torch.cuda.synchronize()
+        ref = ws.l_attr_rows.view(-1, 128)[:topo.Lc].clone()
+        ws.l_attr_rows.zero_()
+        assert lib.agdiff_local_edge_rows(P, T, W, st) == 0
+        torch.cuda.synchronize()
+        got = ws.l_attr_rows.view(-1, 128)[:topo.Lc]
+        flags = ws.enc_flags.cpu().numpy()
+        lens = ws.lc_len[:topo.Lc].cpu().numpy()
+        want = np.array([np.any(lens[16 * k:16 * k + 16] > cfg.cutoff) for k in range(ct)])
+        assert np.array_equal(flags[1:1 + ct] != 0, want) and flags[0] == want.sum(), name
+        assert {"compact": want.sum() == 0, "stretched": want.sum() > ct // 2, "mixed": 0 < want.sum() < ct}[name]
+        check_close("local_edge_rows[%s]" % name, got.cpu().numpy(), ref.cpu().numpy(), precision,
+                    scale=3.0 if precision == "bf16x3" else 1.0)       # (two split-bf16 evaluations against each other)
+        # flagged tiles are the MLP's own output, bit for bit
+        rows = np.repeat(want, 16)[:topo.Lc]
+        assert torch.equal(got[torch.from_numpy(rows)], ref[torch.from_numpy(rows)])
