@@ -181,11 +181,14 @@ __global__ void __launch_bounds__(256) k_edge_gaussian(GaussArgs a) {
 // DistanceWeightingNetwork (schnet.py:83-100) times the cutoff envelope (schnet.py:140-146).
 // cos via v_cos_f32 on the half angle (0.5 (cos x + 1) = cos^2(x/2), argument <= 1/4 revolution inside the
 // cutoff), sigmoid / gaussian via v_exp_f32: absolute error ~1e-6 on a factor in [0, 1].
-__device__ __forceinline__ float cf_edge_scale(const float* __restrict__ dw, float d, float cutoff, int smooth) {
-  float acc = dw[96];
-#pragma unroll 8
-  for (int k = 0; k < 32; ++k) acc = fmaf(dw[64 + k], ag_relu(fmaf(dw[k], d, dw[32 + k])), acc);
-  const float lw = ag_sigmoid(acc);
+__device__ __forceinline__ float cf_edge_scale(const float* __restrict__ seg, float d, float cutoff, int smooth) {
+  // DistanceWeightingNetwork before its sigmoid is piecewise linear in d (agdiff_conv_params_t.dist_seg): binary search for
+  // the segment among the 32 sorted kinks (padded with +inf), then one FMA -- instead of 32 hidden units per edge and conv
+  int s = 0;
+#pragma unroll
+  for (int step = 16; step >= 1; step >>= 1) s += (seg[s + step - 1] <= d) ? step : 0;
+  s += (s == 31 && seg[31] <= d) ? 1 : 0;
+  const float lw = ag_sigmoid(fmaf(seg[32 + s], d, seg[65 + s]));
   float C;
   if (smooth) {
     const float c = __builtin_amdgcn_cosf(d * (0.25f / cutoff));     // cos(pi d / (2 rc)), input in revolutions
@@ -1426,8 +1429,8 @@ int launch_edge_scales(const agdiff_params_t* p, const int32_t* n_dev, int64_t m
   if (max_n == 0) return AGDIFF_OK;
   ScaleArgs a;
   for (int k = 0; k < p->num_convs; ++k) {
-    a.dw[2 * k] = p->conv[k].dist_w;
-    a.dw[2 * k + 1] = p->conv[k].dist_w + 97;
+    a.dw[2 * k] = p->conv[k].dist_seg;
+    a.dw[2 * k + 1] = p->conv[k].dist_seg + 100;
   }
   a.n_dev = n_dev;
   a.e_len = e_len;

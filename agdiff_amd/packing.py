@@ -271,6 +271,38 @@ def radius_polynomials(sd, cfg, tol=POLY_TOL, max_kt=POLY_MAX_KT, min_kt=1):
     return 0, {}, errors
 
 
+def dist_segments(w1, b1, w2, b2):
+    """DistanceWeightingNetwork before its sigmoid, layer2(relu(layer1(d))) (schnet.py:83-100), as a piecewise linear
+    function of d (agdiff_conv_params_t.dist_seg): kinks bp[32] ascending (+inf padded), alpha[33], beta[33], 2 unused.
+    Segment s = number of kinks <= d; its line is the sum over the hidden units active there, in float64."""
+    w1, b1, w2 = (np.asarray(x, dtype=np.float64) for x in (w1, b1, w2))
+    H_ = w1.shape[0]
+    assert H_ == 32
+    nz = w1 != 0
+    t = np.sort(-b1[nz] / w1[nz])
+    bp = np.full(32, np.inf)
+    bp[:t.size] = t
+    alpha, beta = np.zeros(33), np.zeros(33)
+    for s_ in range(33):
+        if s_ > t.size:                      # (segments beyond the last kink repeat the last one: never selected)
+            alpha[s_], beta[s_] = alpha[t.size], beta[t.size]
+            continue
+        lo = t[s_ - 1] if s_ > 0 else None
+        hi = t[s_] if s_ < t.size else None
+        if lo is None and hi is None:
+            x = 0.0
+        elif lo is None:
+            x = hi - 1.0
+        elif hi is None:
+            x = lo + 1.0
+        else:
+            x = 0.5 * (lo + hi)
+        act = (w1 * x + b1) > 0              # (on an empty segment lo == hi any choice gives the same value at its one point)
+        alpha[s_] = float((w2 * w1)[act].sum())
+        beta[s_] = float((w2 * b1)[act].sum()) + float(b2)
+    return np.concatenate([bp, alpha, beta, np.zeros(2)])
+
+
 PRECISIONS = {"f32": 0, "bf16x3": 1}
 EDGE_ENCODERS = {"mlp": 0, "gaussian": 1}       # agdiff_params_t.edge_encoder
 
@@ -365,12 +397,11 @@ class PackedParams:
             arrays[n + "filt_w2b_pk"] = pack_blocks(LN2 * f64(c2_ + ".nn.2.weight"))
             arrays[n + "filt_b2"] = np.concatenate([f64(c1 + ".nn.2.bias") - LN2 * f64(c1 + ".nn.2.weight").sum(1),
                                                     f64(c2_ + ".nn.2.bias") - LN2 * f64(c2_ + ".nn.2.weight").sum(1)])
-            dws = []
-            for c in (c1, c2_):
-                d = c + ".distance_weighting"
-                dws.append(np.concatenate([_np(sd, d + ".layer1.weight")[:, 0], _np(sd, d + ".layer1.bias"),
-                                           _np(sd, d + ".layer2.weight")[0], _np(sd, d + ".layer2.bias")]))
-            arrays[n + "dist_w"] = np.concatenate(dws)
+            arrays[n + "dist_seg"] = np.concatenate([dist_segments(_np(sd, c + ".distance_weighting.layer1.weight")[:, 0],
+                                                                   _np(sd, c + ".distance_weighting.layer1.bias"),
+                                                                   _np(sd, c + ".distance_weighting.layer2.weight")[0],
+                                                                   float(_np(sd, c + ".distance_weighting.layer2.bias")[0]))
+                                                     for c in (c1, c2_)])
             W1a, b1a = fold_bn(_np(sd, c1 + ".lin1.weight"), _np(sd, c1 + ".lin1.bias"), sd, c1 + ".norm1")
             W1b, b1b = fold_bn(_np(sd, c2_ + ".lin1.weight"), _np(sd, c2_ + ".lin1.bias"), sd, c2_ + ".norm1")
             arrays[n + "lin1_pk"] = pack_blocks(np.concatenate([W1a, W1b], 0))

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 24
+#define AGDIFF_ABI_VERSION 25
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -62,7 +62,11 @@ typedef struct agdiff_conv_params {
   const float* filt_w2a_pk;  /* pk [8][4]: ln2 * conv1.nn.2.weight */
   const float* filt_w2b_pk;  /* pk [4][2]: ln2 * conv2.nn.2.weight */
   const float* filt_b2;      /* [192] nn.2.bias - ln2 * rowsum(nn.2.weight) */
-  const float* dist_w;       /* [2][97]: DistanceWeightingNetwork (schnet.py:83-100): w1[32] b1[32] w2[32] b2 */
+  const float* dist_seg;     /* [2][100]: DistanceWeightingNetwork (schnet.py:83-100) of conv1 / conv2 by segments: the network's
+                                pre-sigmoid value layer2(relu(layer1(d))) is piecewise linear in d with at most 32 kinks
+                                (d = -b1_k / w1_k); bp[32] = the kinks in ascending order (padded with +inf), then
+                                alpha[33], beta[33] with value = alpha[s] d + beta[s] on segment s = #{kinks <= d}, summed
+                                over the active hidden units in float64 by the host; [98..99] unused */
   /* node side of the block (schnet.py:153-158, 201-216, 219-234) */
   const float* lin1_pk;      /* pk [12][4]: BN-folded conv1.lin1 (rows 0..127) and conv2.lin1 (128..191) */
   const float* lin1_b;       /* [192] */

@@ -287,7 +287,8 @@ def test_node_kernel_variants(precision, monkeypatch):
     assert torch.equal(stream[1], split[1])                               # the local branch does not use the node stage
     assert not torch.equal(stream[0], split[0]) or precision == "f32"
     for name, v in (("split", split), ("stream", stream), ("shared", shared)):
-        assert rel_err(v[0].cpu().numpy(), stream[0].cpu().numpy()) < (2e-6 if precision == "f32" else 1e-5), name
+        # (two split-bf16 evaluations against each other: each ~1.5e-5 from the exact value)
+        assert rel_err(v[0].cpu().numpy(), stream[0].cpu().numpy()) < (2e-6 if precision == "f32" else 2e-5), name
         check_close("node_kernel_variants %s inv_g" % name, v[0], g["edge_inv_global"], precision)
         check_close("node_kernel_variants %s inv_l" % name, v[1], g["edge_inv_local"], precision)
 
