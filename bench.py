@@ -452,6 +452,7 @@ def main():
         timeit("score_forward_global", lambda: lib.agdiff_score_forward(P, Tp, Wp, run.pos_p, 1, stream))
         if pk.poly_kt > 0:       # the split path the sampler runs (the entries above time the one-list kernels on the same graph)
             nc = cfg.num_convs
+            timeit("local_edge_rows", lambda: lib.agdiff_local_edge_rows(P, Tp, Wp, stream))
             timeit("split_scales_radius", lambda: lib.agdiff_edge_scales_split(P, Tp, Wp, 0, stream))
             timeit("split_scales_local", lambda: lib.agdiff_edge_scales_split(P, Tp, Wp, 1, stream))
             timeit("split_cfconv_radius_x%d" % nc, lambda: [lib.agdiff_cfconv_radius(P, Tp, Wp, k, stream) for k in range(nc)])

@@ -18,7 +18,7 @@ for f in glob.glob("/tmp/pmcsq/set*/*/*counter_collection.csv"):
         if "k_cfconv_radius" in kn:
             agg["k_cfconv_local (typed)" if "true>" in kn else "k_cfconv_radius"][r["Counter_Name"]].append(float(r["Counter_Value"]))
             continue
-        for k in ("k_cfconv_fused", "k_edge_encoder", "k_pair_head_poly", "k_pair_head", "k_gin_layer", "k_gin_gather", "k_schnet_node_stage"):
+        for k in ("k_cfconv_fused", "k_edge_attr_poly", "k_edge_encoder", "k_pair_head_poly", "k_pair_head", "k_gin_layer", "k_gin_gather", "k_schnet_node_stage"):
             if k in kn:
                 agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 break

@@ -20,7 +20,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if "k_cfconv_radius" in kn:
                 agg["k_cfconv_local" if "true>" in kn else "k_cfconv_radius"].append(float(r["Counter_Value"]))
                 continue
-            for k in ("k_cfconv_fused", "k_edge_encoder", "k_pair_head_poly", "k_pair_head", "k_gin_layer", "k_gin_gather", "k_schnet_node_stage", "k_graph"):
+            for k in ("k_cfconv_fused", "k_edge_attr_poly", "k_edge_encoder", "k_pair_head_poly", "k_pair_head", "k_gin_layer", "k_gin_gather", "k_schnet_node_stage", "k_graph"):
                 if k in kn:
                     agg[k].append(float(r["Counter_Value"]))
                     break

@@ -56,6 +56,7 @@ def main():
     timeit("local_encoder_frag_rows", lambda: lib.agdiff_edge_encoder(
         P, _lib.ptr(ws.num_local_canon), ct, _lib.ptr(ws.lc_len), _lib.ptr(topo.lc_type), _lib.ptr(ws.l_attr_frag),
         _lib.ptr(ws.l_attr_rows), _lib.ptr(topo.lp_row), _lib.ptr(topo.lc_ppos), _lib.ptr(topo.lc_pmir), st))
+    timeit("local_edge_rows", lambda: lib.agdiff_local_edge_rows(P, Tp, Wp, st))
     timeit("cfconv_radius_x%d" % nc, lambda: [lib.agdiff_cfconv_radius(P, Tp, Wp, k, st) for k in range(nc)])
     timeit("cfconv_local_x%d" % nc, lambda: [lib.agdiff_cfconv_local(P, Tp, Wp, k, st) for k in range(nc)])
     timeit("node_stage_split_x%d" % (nc + 1), lambda: [lib.agdiff_schnet_node_stage_split(P, Tp, Wp, k, 1, st) for k in range(nc + 1)])
