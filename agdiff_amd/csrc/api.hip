@@ -151,11 +151,11 @@ int global_back(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdif
 int global_front_split(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, int flags,
                        void* stream) {
   const int64_t etiles = (topo->max_edges + AG_TW - 1) / AG_TW;
-  // inside the denoising loop nothing but the radius scales and the polynomial head walks the canonical list: radius
-  // edges only then (one scale evaluation / head evaluation per mirror pair of radius edges)
-  const bool ronly = (flags & AGDIFF_FWD_SAMPLER) && ws->c_rpos && ws->c_rmir;
+  // inside the denoising loop nothing but the polynomial head walks the canonical list: radius edges only then (one head
+  // evaluation per mirror pair of radius edges)
+  const bool ronly = (flags & AGDIFF_FWD_SAMPLER) != 0;
   AG_TRY(agdiff_graph_build_ex(topo, ws, pos, (flags & AGDIFF_FWD_NO_RADIUS) ? 0.0f : p->cutoff, ronly ? 1 : 0, stream));
-  AG_TRY(agdiff_edge_scales_split(p, topo, ws, ronly ? 2 : 0, stream));
+  AG_TRY(agdiff_edge_scales_split(p, topo, ws, 0, stream));
   if (!(flags & AGDIFF_FWD_SAMPLER))
     AG_TRY(agdiff_edge_encoder(p, ws->num_canon, etiles, ws->c_len, ws->c_type, ws->e_attr, nullptr, nullptr, ws->c_pos,
                                ws->c_mir, stream));

@@ -181,14 +181,19 @@ __global__ void __launch_bounds__(256) k_edge_gaussian(GaussArgs a) {
 // DistanceWeightingNetwork (schnet.py:83-100) times the cutoff envelope (schnet.py:140-146).
 // cos via v_cos_f32 on the half angle (0.5 (cos x + 1) = cos^2(x/2), argument <= 1/4 revolution inside the
 // cutoff), sigmoid / gaussian via v_exp_f32: absolute error ~1e-6 on a factor in [0, 1].
-__device__ __forceinline__ float cf_edge_scale(const float* __restrict__ seg, float d, float cutoff, int smooth) {
-  // DistanceWeightingNetwork before its sigmoid is piecewise linear in d (agdiff_conv_params_t.dist_seg): binary search for
-  // the segment among the 32 sorted kinks (padded with +inf), then one FMA -- instead of 32 hidden units per edge and conv
+// DistanceWeightingNetwork before its sigmoid is piecewise linear in d (agdiff_conv_params_t.dist_seg): binary search for
+// the segment among the 32 sorted kinks (padded with +inf), then one FMA -- instead of 32 hidden units per edge and conv.
+// SEG: a pointer to global memory or to LDS.
+template <typename SEG>
+__device__ __forceinline__ float cf_dist_weight(SEG seg, float d) {
   int s = 0;
 #pragma unroll
   for (int step = 16; step >= 1; step >>= 1) s += (seg[s + step - 1] <= d) ? step : 0;
   s += (s == 31 && seg[31] <= d) ? 1 : 0;
-  const float lw = ag_sigmoid(fmaf(seg[32 + s], d, seg[65 + s]));
+  return ag_sigmoid(fmaf(seg[32 + s], d, seg[65 + s]));
+}
+// the cutoff envelope C(d) (schnet.py:140-146), the same for every CFConv
+__device__ __forceinline__ float cf_envelope(float d, float cutoff, int smooth) {
   float C;
   if (smooth) {
     const float c = __builtin_amdgcn_cosf(d * (0.25f / cutoff));     // cos(pi d / (2 rc)), input in revolutions
@@ -197,8 +202,7 @@ __device__ __forceinline__ float cf_edge_scale(const float* __restrict__ seg, fl
     const float t = d - cutoff;
     C = ag_exp2(-(t * t) / (2.0f * cutoff * cutoff) * 1.44269504088896340736f);
   }
-  C = (d <= cutoff && d >= 0.0f) ? C : 0.0f;
-  return lw * C;
+  return (d <= cutoff && d >= 0.0f) ? C : 0.0f;
 }
 
 struct ScaleArgs {
@@ -214,20 +218,26 @@ struct ScaleArgs {
   int32_t smooth;
 };
 
-// lw(d) * C(d) for the 2*num_convs CFConvs (schnet.py:138-149), once per step instead of once per
-// block launch: one thread per (edge or mirror pair, conv), blockIdx.y = conv.
+// lw(d) * C(d) for the 2*num_convs CFConvs (schnet.py:138-149), once per step instead of once per block launch: one
+// thread per edge (or mirror pair) evaluates ALL the convs -- the length (and the pair's two positions) are read once, the
+// envelope is evaluated once, and in per-edge mode every conv's store is coalesced across the workgroup (one thread
+// per (edge, conv) with scattered per-pair stores was bound by exactly those stores).  The segment tables of all convs
+// (n x 100 floats) sit in LDS.
 __global__ void __launch_bounds__(256) k_edge_scales(ScaleArgs a) {
+  __shared__ float seg[2 * AGDIFF_MAX_CONVS * 100];
+  for (int i = threadIdx.x; i < a.n * 100; i += blockDim.x) seg[i] = a.dw[i / 100][i % 100];
+  __syncthreads();
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= *a.n_dev) return;
-  const int c = blockIdx.y;
-  const float s = cf_edge_scale(a.dw[c], a.e_len[e], a.cutoff, a.smooth);
-  float* out = a.out + (size_t)c * a.epad;
-  if (a.pos_index) {
-    out[a.pos_index[e]] = s;
-    const int m = a.mir_index[e];
-    if (m >= 0) out[m] = s;
-  } else {
-    out[e] = s;
+  const float d = a.e_len[e];
+  const float C = cf_envelope(d, a.cutoff, a.smooth);
+  const int64_t p0 = a.pos_index ? (int64_t)a.pos_index[e] : e;
+  const int64_t p1 = a.pos_index ? (int64_t)a.mir_index[e] : -1;
+  for (int c = 0; c < a.n; ++c) {
+    const float s = cf_dist_weight(seg + c * 100, d) * C;
+    float* out = a.out + (size_t)c * a.epad;
+    out[p0] = s;
+    if (p1 >= 0) out[p1] = s;
   }
 }
 
@@ -1441,7 +1451,7 @@ int launch_edge_scales(const agdiff_params_t* p, const int32_t* n_dev, int64_t m
   a.n = 2 * p->num_convs;
   a.cutoff = p->cutoff;
   a.smooth = p->smooth;
-  k_edge_scales<<<dim3((unsigned)((max_n + 255) / 256), (unsigned)a.n), dim3(256), 0, (hipStream_t)stream>>>(a);
+  k_edge_scales<<<dim3((unsigned)((max_n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(a);
   AG_CHECK_LAUNCH();
   return AGDIFF_OK;
 }
@@ -1461,12 +1471,6 @@ extern "C" int agdiff_edge_scales(const agdiff_params_t* p, const agdiff_topo_t*
 extern "C" int agdiff_edge_scales_split(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
                                         int32_t which, void* stream) {
   if (!p || !topo || !ws || p->num_convs > AGDIFF_MAX_CONVS) return AGDIFF_ERR_ARG;
-  if (which == 2) {        // radius list, one evaluation per canonical (radius-only) entry written to both directions
-    if (!ws->r_scale || !ws->c_len || !ws->num_canon || !ws->c_rpos || !ws->c_rmir) return AGDIFF_ERR_ARG;
-    const int64_t R = topo->max_edges - topo->num_local;
-    return launch_edge_scales(p, ws->num_canon, R, ws->c_len, ws->c_rpos, ws->c_rmir, ws->r_scale,
-                              ((R + AG_TW - 1) / AG_TW) * AG_TW, stream);
-  }
   if (which == 0) {        // radius list
     if (!ws->r_scale || !ws->rad_len || !ws->num_rad) return AGDIFF_ERR_ARG;
     const int64_t R = topo->max_edges - topo->num_local;

@@ -46,10 +46,8 @@ struct GraphArgs {
   int32_t* rad_dst;
   float* rad_len;
   // canon_radius_only != 0: the canonical list holds radius edges only (the denoising loop: nothing but the global head
-  // and the radius scales walks it then), and c_rpos / c_rmir give the entry's and its mirror's position in the radius list
+  // walks it then)
   int32_t canon_radius_only;
-  int32_t* c_rpos;
-  int32_t* c_rmir;
   // hand-over from the count pass to the fill pass (optional): the in-adjacency masks and the two degree arrays of every
   // molecule, so that the fill pass does not repeat the distance tests and the mirror look-ups
   uint32_t* g_inbits;    // [N][words]
@@ -295,18 +293,6 @@ __global__ void __launch_bounds__(AG_GRAPH_THREADS) k_graph(GraphArgs a) {
           a.c_dst[cp] = g0 + i;
           a.c_pos[cp] = p;
           a.c_mir[cp] = mir ? base + (j ? sin[j - 1] : 0) + rank_below(inbits, j, i) : -1;
-          if (a.canon_radius_only && a.c_rpos) {     // positions in the radius list (row j's radius bits below column i)
-            a.c_rpos[cp] = rp0 + __popcll(rmask & lt);
-            int rm = -1;
-            if (mir) {
-              const uint32_t* rj = inbits + j * words;
-              const uint32_t* lj = locbits + j * words;
-              int k = __popc(rj[i >> 5] & ~lj[i >> 5] & ((1u << (i & 31)) - 1u));
-              for (int w = 0; w < (i >> 5); ++w) k += __popc(rj[w] & ~lj[w]);
-              rm = base + (j ? sin[j - 1] : 0) - a.loc_in_ptr[g0 + j] + k;
-            }
-            a.c_rmir[cp] = rm;
-          }
         }
       }
       p0 += __popcll(emask);
@@ -441,10 +427,8 @@ extern "C" int agdiff_graph_build_ex(const agdiff_topo_t* topo, const agdiff_ws_
   a.rad_src = ws->rad_src;
   a.rad_dst = ws->rad_dst;
   a.rad_len = ws->rad_len;
-  if (canon_radius_only && (!rad || !ws->c_rpos || !ws->c_rmir)) return AGDIFF_ERR_ARG;
+  if (canon_radius_only && !rad) return AGDIFF_ERR_ARG;
   a.canon_radius_only = canon_radius_only ? 1 : 0;
-  a.c_rpos = ws->c_rpos;
-  a.c_rmir = ws->c_rmir;
   const bool handover = ws->g_inbits && ws->g_deg && ws->g_cdeg;
   a.g_inbits = handover ? reinterpret_cast<uint32_t*>(ws->g_inbits) : nullptr;
   a.g_deg = ws->g_deg;

@@ -205,7 +205,6 @@ class Workspace:
         self.rad_ptr = i32(N + 1)
         self.rad_src, self.rad_dst, self.rad_len = i32(rtiles * TW), i32(rtiles * TW), f32(rtiles * TW)
         self.r_scale = f32(2 * _lib.DEFINES["AGDIFF_MAX_CONVS"] * rtiles * TW)
-        self.c_rpos, self.c_rmir = i32(etiles * TW), i32(etiles * TW)
         self.num_local_padded = torch.tensor([Lp], dtype=torch.int32, device=dev)
         self.l_scale = f32(2 * _lib.DEFINES["AGDIFF_MAX_CONVS"] * ptiles * TW)
         self.l_attr_frag = f32(ptiles * TW * 128)

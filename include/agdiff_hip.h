@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 25
+#define AGDIFF_ABI_VERSION 26
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -266,8 +266,6 @@ typedef struct agdiff_ws {
   int32_t* rad_dst;          /* [max_edges - L] */
   float*   rad_len;          /* [max_edges - L] */
   float*   r_scale;          /* [2*num_convs][ceil((max_edges - L)/16)*16]: lw(d)*C(d) by radius-list position */
-  int32_t* c_rpos;           /* [max_edges]: radius-list position of a canonical entry (agdiff_graph_build_ex, radius-only mode) */
-  int32_t* c_rmir;           /* [max_edges]: ... of its mirror, or -1 */
   int32_t* num_local_padded; /* [1]  Lp as a device scalar (written once by the host) */
   float*   l_scale;          /* [2*num_convs][ceil(Lp/16)*16]: the same by padded-list position (pad entries stay 0) */
   float*   l_attr_frag;      /* [ceil(Lp/16)] tiles x 2048 floats: edge_attr of the local edges in operand form, by padded-list
@@ -316,9 +314,8 @@ int agdiff_struct_sizes(int64_t* out /* [host] */);
  * edge types and lengths from `pos`. */
 int agdiff_graph_build(const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, float cutoff, void* stream);
 /* The same with canon_radius_only != 0: the canonical list (ws->c_*, num_canon) holds RADIUS edges only -- one of j -> i /
- * i -> j when both are radius edges -- and ws->c_rpos / c_rmir give the entry's and its mirror's position in the radius
- * list (ws->rad_*).  What the denoising loop asks for (AGDIFF_FWD_SAMPLER with poly_kt > 0): there only the global head
- * and the radius scales walk the canonical list, and only radius edges' results are used. */
+ * i -> j when both are radius edges.  What the denoising loop asks for (AGDIFF_FWD_SAMPLER with poly_kt > 0): there only
+ * the global head walks the canonical list, and only radius edges' results are used. */
 int agdiff_graph_build_ex(const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, float cutoff,
                           int32_t canon_radius_only, void* stream);
 
@@ -379,8 +376,7 @@ int agdiff_cfconv_local(const agdiff_params_t* p, const agdiff_topo_t* topo, con
  * topo->lp_type, ws->l_len_p), 0 when it evaluates the filter MLPs on ws->l_attr_frag. */
 int agdiff_local_poly_enabled(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws);
 int agdiff_edge_scales_split(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t which,
-                             void* stream);     /* which == 2: ws->r_scale through the radius-only canonical list
-                                                   (one evaluation per mirror pair; needs agdiff_graph_build_ex(.., 1, ..)) */
+                             void* stream);
 
 /* agdiff_pair_head with p->head_global for edges whose edge_attr is MLPEdgeEncoder(len, type 0): the edge_attr half of the
  * first layer comes from the d-polynomial head_global.attr_poly_pk (needs p->poly_kt > 0).  pos_index / mir_index as in
