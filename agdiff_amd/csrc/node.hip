@@ -595,20 +595,64 @@ __global__ void __launch_bounds__(1024) k_langevin_update(UpdateArgs a) {
     const float px = a.s.pos_in[3 * i], py = a.s.pos_in[3 * i + 1], pz = a.s.pos_in[3 * i + 2];
     float lx = 0.f, ly = 0.f, lz = 0.f;
     if (on) {
-      for (int e = a.loc_out_ptr[i] + part; e < a.loc_out_ptr[i + 1]; e += P) {   // row == i: + dd_dr * score
-        const int j = a.loc_dst[e];
-        const float w = (1.0f / a.l_len[e]), sc = a.l_inv[e];
-        lx += (w * (px - a.s.pos_in[3 * j])) * sc;
-        ly += (w * (py - a.s.pos_in[3 * j + 1])) * sc;
-        lz += (w * (pz - a.s.pos_in[3 * j + 2])) * sc;
+      // (as the global loops below: four edges at a time, the loads of each dependency level issued together)
+      constexpr int UL = 4;
+      const int lo1 = a.loc_out_ptr[i + 1];
+      for (int e0 = a.loc_out_ptr[i] + part; e0 < lo1; e0 += UL * P) {            // row == i: + dd_dr * score
+        int j[UL];
+        float ln[UL], sc[UL];
+        bool ok[UL];
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+          ok[u] = e0 + u * P < lo1;
+          const int e = ok[u] ? e0 + u * P : 0;
+          j[u] = ok[u] ? a.loc_dst[e] : i;
+          ln[u] = ok[u] ? a.l_len[e] : 1.0f;
+          sc[u] = ok[u] ? a.l_inv[e] : 0.0f;
+        }
+        float qx[UL], qy[UL], qz[UL];
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+          qx[u] = a.s.pos_in[3 * j[u]]; qy[u] = a.s.pos_in[3 * j[u] + 1]; qz[u] = a.s.pos_in[3 * j[u] + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+          if (!ok[u]) continue;
+          const float w = 1.0f / ln[u];
+          lx += (w * (px - qx[u])) * sc[u];
+          ly += (w * (py - qy[u])) * sc[u];
+          lz += (w * (pz - qz[u])) * sc[u];
+        }
       }
-      for (int k = a.loc_in_ptr[i] + part; k < a.loc_in_ptr[i + 1]; k += P) {     // col == i: - dd_dr * score
-        const int e = a.loc_in_eid[k];
-        const int j = a.loc_src[e];
-        const float w = (1.0f / a.l_len[e]), sc = a.l_inv[e];
-        lx -= (w * (a.s.pos_in[3 * j] - px)) * sc;
-        ly -= (w * (a.s.pos_in[3 * j + 1] - py)) * sc;
-        lz -= (w * (a.s.pos_in[3 * j + 2] - pz)) * sc;
+      const int li1 = a.loc_in_ptr[i + 1];
+      for (int k0 = a.loc_in_ptr[i] + part; k0 < li1; k0 += UL * P) {              // col == i: - dd_dr * score
+        int e[UL], j[UL];
+        float ln[UL], sc[UL];
+        bool ok[UL];
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+          ok[u] = k0 + u * P < li1;
+          e[u] = ok[u] ? a.loc_in_eid[k0 + u * P] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+          j[u] = ok[u] ? a.loc_src[e[u]] : i;
+          ln[u] = ok[u] ? a.l_len[e[u]] : 1.0f;
+          sc[u] = ok[u] ? a.l_inv[e[u]] : 0.0f;
+        }
+        float qx[UL], qy[UL], qz[UL];
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+          qx[u] = a.s.pos_in[3 * j[u]]; qy[u] = a.s.pos_in[3 * j[u] + 1]; qz[u] = a.s.pos_in[3 * j[u] + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+          if (!ok[u]) continue;
+          const float w = 1.0f / ln[u];
+          lx -= (w * (qx[u] - px)) * sc[u];
+          ly -= (w * (qy[u] - py)) * sc[u];
+          lz -= (w * (qz[u] - pz)) * sc[u];
+        }
       }
     }
     for (int o = P >> 1; o > 0; o >>= 1) { lx += __shfl_xor(lx, o); ly += __shfl_xor(ly, o); lz += __shfl_xor(lz, o); }
