@@ -264,6 +264,7 @@ __device__ __forceinline__ void ag_dense(const AgIn<MODE> (&x)[NX], f32x4 (&o)[N
 template <int MODE, bool FLIP, bool KOUTER, int KT, int OT, int X0, int O0, int NX, int NO>
 __device__ __forceinline__ void ag_dense_lds(const AgIn<MODE> (&x)[NX], f32x4 (&o)[NO], const lds_u32x4* wl, int lane) {
   static_assert(X0 + KT <= NX && O0 + OT <= NO, "tile range");
+#ifdef AG_DENSE_LDS_PLAIN
 #pragma unroll
   for (int s = 0; s < OT * KT; ++s) {
     const int t = KOUTER ? s / OT : s % KT, ot = KOUTER ? s % OT : s / KT;
@@ -272,6 +273,31 @@ __device__ __forceinline__ void ag_dense_lds(const AgIn<MODE> (&x)[NX], f32x4 (&
     w[1] = wl[(s * 2 + 1) * 64 + lane];
     ag_block_mma<MODE, FLIP>(o[O0 + ot], x[X0 + t], w);
   }
+#else
+  // Output tiles in groups of G: the G blocks of a k-tile are read together and their MFMA passes interleaved over the G
+  // accumulators (back-to-back MFMAs on one accumulator, each behind its own LDS read, made these layers a chain of
+  // exposed latencies).  Per accumulator the order of the additions is unchanged (k-tile outer, pass inner).
+  constexpr int G = (OT % 4 == 0) ? 4 : (OT % 2 == 0) ? 2 : 1;
+#pragma unroll
+  for (int og = 0; og < OT / G; ++og) {
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      u32x4 w[G][2];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int ot = og * G + g;
+        const int s = KOUTER ? t * OT + ot : ot * KT + t;
+        w[g][0] = wl[(s * 2) * 64 + lane];
+        w[g][1] = wl[(s * 2 + 1) * 64 + lane];
+      }
+#pragma unroll
+      for (int part = 0; part < AgParts<MODE>::n; ++part) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) ag_block_mma_part<MODE, FLIP>(o[O0 + og * G + g], x[X0 + t], w[g], part);
+      }
+    }
+  }
+#endif
 }
 // Mixed source: unit 0 of every block (hi halves in AG_BF3, first k-half in AG_F32) from an LDS array that holds
 // only those units (64 u32x4 per block), unit 1 streamed from the full packed matrix in global memory PF blocks
