@@ -298,3 +298,37 @@ def test_padded_local_list():
     assert np.array_equal(src[pm[mk]], tp.lc_dst.numpy()[mk]) and np.array_equal(dst[pm[mk]], tp.lc_src.numpy()[mk])
     cover = np.zeros(tp.Lp, bool); cover[pp] = True; cover[pm[mk]] = True
     assert np.array_equal(cover, row >= 0)
+
+
+def test_distance_weighting_segments():
+    """packing.dist_segments (agdiff_conv_params_t.dist_seg): the piecewise-linear form of DistanceWeightingNetwork before its
+    sigmoid equals layer2(relu(layer1(d))) (schnet.py:83-100) at random lengths and at the kinks themselves, also with
+    dead hidden units (w1 = 0) and against the oracle's cfconv weights."""
+    from agdiff_amd.packing import dist_segments
+    rng = np.random.default_rng(0)
+    for trial in range(6):
+        w1, b1, w2 = rng.uniform(-1, 1, 32), rng.uniform(-1, 1, 32), rng.uniform(-1, 1, 32)
+        b2 = float(rng.uniform(-1, 1))
+        if trial == 3:
+            w1[:5] = 0.0
+        if trial == 4:
+            w1[:] = np.abs(w1); b1[:] = np.abs(b1)          # no kink inside d >= 0
+        seg = dist_segments(w1, b1, w2, b2)
+        bp, al, be = seg[:32], seg[32:65], seg[65:98]
+        assert np.all(np.diff(bp[np.isfinite(bp)]) >= 0)
+        d = np.concatenate([rng.uniform(0, 12, 2000), bp[np.isfinite(bp)], [0.0]])
+        s = (bp[None, :] <= d[:, None]).sum(1)               # the kernel's binary search computes this count
+        got = al[s] * d + be[s]
+        ref = (w2[None, :] * np.maximum(w1[None, :] * d[:, None] + b1[None, :], 0)).sum(1) + b2
+        assert np.abs(got - ref).max() < 1e-12
+    cfg = drugs_model_config()
+    sd = O.synth_state_dict_for(cfg)
+    p = "encoder_global.interactions.2.conv2.distance_weighting"
+    seg = dist_segments(sd[p + ".layer1.weight"][:, 0].numpy(), sd[p + ".layer1.bias"].numpy(), sd[p + ".layer2.weight"][0].numpy(),
+                        float(sd[p + ".layer2.bias"][0]))
+    d = torch.linspace(0, 11, 501, dtype=torch.float64)
+    ref = torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(d.view(-1, 1), sd[p + ".layer1.weight"].double(),
+                                                                             sd[p + ".layer1.bias"].double())),
+                                     sd[p + ".layer2.weight"].double(), sd[p + ".layer2.bias"].double())[:, 0].numpy()
+    s = (seg[None, :32] <= d.numpy()[:, None]).sum(1)
+    assert np.abs(seg[32:65][s] * d.numpy() + seg[65:98][s] - ref).max() < 1e-12
