@@ -148,6 +148,15 @@ int global_back(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdif
 // Split CFConv (p->poly_kt > 0, graph built here): radius edges take their filters from d-polynomials, local edges go
 // through the filter MLPs on the static local list (include/agdiff_hip.h).
 // front: radius graph -> radius-edge scales (-> the encoder over all canonical edges when the full head will need edge_attr)
+// Small batches are bound by launch and fill latencies, not by arithmetic: below this many atoms the two CFConv passes of a
+// block run as ONE launch over the full edge list (agdiff_cfconv_merged: every tile then pays for the type groups, but a
+// launch, a coefficient fill and a tail are saved per block).  AGDIFF_MERGED_MAX_NODES overrides (0 = never).
+bool use_merged(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int flags) {
+  const char* env = getenv("AGDIFF_MERGED_MAX_NODES");         // (read per call: tests switch it)
+  const int64_t max_nodes = env ? atoll(env) : 12288;     // 1 molecule x 25 / 100 / 200 / 400 conformers: -17 / -8 / -3 / +4 %
+  return (flags & AGDIFF_FWD_SAMPLER) && topo->num_nodes < max_nodes && topo->num_local > 0 && agdiff_cfconv_merged_ok(p, topo, ws);
+}
+
 int global_front_split(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, int flags,
                        void* stream) {
   const int64_t etiles = (topo->max_edges + AG_TW - 1) / AG_TW;
@@ -155,7 +164,10 @@ int global_front_split(const agdiff_params_t* p, const agdiff_topo_t* topo, cons
   // evaluation per mirror pair of radius edges)
   const bool ronly = (flags & AGDIFF_FWD_SAMPLER) != 0;
   AG_TRY(agdiff_graph_build_ex(topo, ws, pos, (flags & AGDIFF_FWD_NO_RADIUS) ? 0.0f : p->cutoff, ronly ? 1 : 0, stream));
-  AG_TRY(agdiff_edge_scales_split(p, topo, ws, 0, stream));
+  if (use_merged(p, topo, ws, flags))
+    AG_TRY(agdiff_edge_scales(p, topo, ws, 0, stream));        // one list: scales by position in the full edge list
+  else
+    AG_TRY(agdiff_edge_scales_split(p, topo, ws, 0, stream));
   if (!(flags & AGDIFF_FWD_SAMPLER))
     AG_TRY(agdiff_edge_encoder(p, ws->num_canon, etiles, ws->c_len, ws->c_type, ws->e_attr, nullptr, nullptr, ws->c_pos,
                                ws->c_mir, stream));
@@ -169,15 +181,21 @@ int global_back_split(const agdiff_params_t* p, const agdiff_topo_t* topo, const
   // stage 0 (embeddings + block 0's lin1) is the same on every step of a run: written to ws->h0 / ws->xs0 once, block 0
   // reads it from there
   const bool cache = ws->h0 && ws->xs0;
-  if (!(cache && (flags & AGDIFF_FWD_STAGE0_CACHED))) AG_TRY(agdiff_schnet_node_stage_split(p, topo, ws, 0, 1 | 4, stream));
+  const bool merged = use_merged(p, topo, ws, flags);
+  const int sp = merged ? 0 : 1;             // node stage: one aggregate (merged pass) or radius + local
+  if (!(cache && (flags & AGDIFF_FWD_STAGE0_CACHED))) AG_TRY(agdiff_schnet_node_stage_split(p, topo, ws, 0, sp | 4, stream));
   agdiff_ws_t ws0 = *ws;
   if (cache) ws0.xs = ws->xs0;
   for (int k = 0; k < p->num_convs; ++k) {
     const agdiff_ws_t* wk = (k == 0) ? &ws0 : ws;
-    AG_TRY(agdiff_cfconv_radius(p, topo, wk, k, stream));
-    if (k == 0 && local_ready && hipStreamWaitEvent((hipStream_t)stream, local_ready, 0) != hipSuccess) return AGDIFF_ERR_LAUNCH;
-    AG_TRY(agdiff_cfconv_local(p, topo, wk, k, stream));
-    AG_TRY(agdiff_schnet_node_stage_split(p, topo, ws, k + 1, 1 | (k == 0 ? 2 : 0), stream));
+    if (merged) {
+      AG_TRY(agdiff_cfconv_merged(p, topo, wk, k, stream));
+    } else {
+      AG_TRY(agdiff_cfconv_radius(p, topo, wk, k, stream));
+      if (k == 0 && local_ready && hipStreamWaitEvent((hipStream_t)stream, local_ready, 0) != hipSuccess) return AGDIFF_ERR_LAUNCH;
+      AG_TRY(agdiff_cfconv_local(p, topo, wk, k, stream));
+    }
+    AG_TRY(agdiff_schnet_node_stage_split(p, topo, ws, k + 1, sp | (k == 0 ? 2 : 0), stream));
   }
   if (flags & AGDIFF_FWD_SAMPLER) {
     // only the radius edges' outputs are used (dualenc.py:516-518): the head's edge_attr half from the d-polynomial, over

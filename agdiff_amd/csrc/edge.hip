@@ -1612,6 +1612,42 @@ extern "C" int agdiff_cfconv_local(const agdiff_params_t* p, const agdiff_topo_t
                              ws->l_scale, ws->l_attr_frag, ws->xs, ws->agg_loc, ws->agg_first_loc, stream);
 }
 
+extern "C" int agdiff_cfconv_merged_ok(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws) {
+  return agdiff_local_poly_enabled(p, topo, ws) && p->poly_num_slots + 1 <= AGDIFF_POLY_MAX_SLOTS && ws->e_scale && ws->e_type;
+}
+
+extern "C" int agdiff_cfconv_merged(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k,
+                                    void* stream) {
+  if (!p || !topo || !ws || k < 0 || k >= p->num_convs) return AGDIFF_ERR_ARG;
+  if (!agdiff_cfconv_merged_ok(p, topo, ws) || !p->conv[k].filt_poly_typed_pk) return AGDIFF_ERR_ARG;
+  const int64_t max_tiles = (topo->max_edges + AG_TW - 1) / AG_TW;
+  const int chunk_tiles = agdiff_conv_chunk_tiles(topo->max_edges);
+  const int64_t max_chunks = (max_tiles + chunk_tiles - 1) / chunk_tiles;
+  if (max_chunks == 0) return AGDIFF_OK;
+  RadConvArgs a;
+  a.poly_pk = p->conv[k].filt_poly_typed_pk;
+  a.n_dev = ws->num_edges;
+  a.e_src = ws->e_src;
+  a.e_dst = ws->e_dst;
+  a.e_len = ws->e_len;
+  const size_t epad = (size_t)max_tiles * AG_TW;
+  a.scale1 = ws->e_scale + (size_t)(2 * k) * epad;
+  a.scale2 = ws->e_scale + (size_t)(2 * k + 1) * epad;
+  a.xs = ws->xs;
+  a.agg = ws->agg;
+  a.agg_first = ws->agg_first;
+  a.max_chunks = max_chunks;
+  a.chunk_tiles = chunk_tiles;
+  a.two_over_rc = 2.0f / p->cutoff;
+  a.e_type = ws->e_type;
+  a.type_slot = p->poly_type_slot;
+  a.num_slots = p->poly_num_slots + 1;          // the radius edges' set is the last one (poly_type_slot[0])
+  int64_t wgs = (max_chunks + AG_LOCP_WAVES - 1) / AG_LOCP_WAVES;
+  if (wgs > 256) wgs = 256;
+  return p->precision == AG_BF3 ? launch_cfconv_local_poly_t<AG_BF3>(a, wgs, stream)
+                                : launch_cfconv_local_poly_t<AG_F32>(a, wgs, stream);
+}
+
 extern "C" int agdiff_cfconv_radius(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k,
                                     void* stream) {
   if (!p || !topo || !ws || k < 0 || k >= p->num_convs) return AGDIFF_ERR_ARG;

@@ -531,7 +531,10 @@ class PackedParams:
             self._typed_mats[t] = mats
         by_slot = sorted(self.local_slots, key=self.local_slots.get)
         nc = self._cfg.num_convs
-        per_conv = [np.concatenate([pack_blocks(self._typed_mats[t]["conv%d.filt_poly_pk" % k], mode=self._mode) for t in by_slot])
+        # per conv: the local types' sets by slot, then the radius edges' set once more as slot S (type 0): the one-list
+        # variant of the pass for small batches (agdiff_cfconv_merged) takes every edge's filter from this buffer
+        per_conv = [np.concatenate([pack_blocks(self._typed_mats[t]["conv%d.filt_poly_pk" % k], mode=self._mode) for t in by_slot] +
+                                   [pack_blocks(self._poly["conv%d.filt_poly_pk" % k], mode=self._mode)])
                     for k in range(nc)]
         attr_sets = np.concatenate([pack_blocks(self._typed_mats[t]["edge_attr_poly_pk"], mode=self._mode) for t in by_slot])
         self.typed_attr_flat = torch.from_numpy(attr_sets).to(self.device)
@@ -540,6 +543,7 @@ class PackedParams:
         table = np.full(100, -1, dtype=np.int32)                                         #  use by enqueued launches: torch's
         for t, sl in self.local_slots.items():                                           #  allocator keeps it alive in stream order)
             table[t] = sl
+        table[0] = len(by_slot)                                                          # type 0 = radius edges: the extra set
         self.slot_table = torch.from_numpy(table).to(self.device)
         stride = per_conv[0].size
         for k in range(nc):

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 26
+#define AGDIFF_ABI_VERSION 27
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -83,9 +83,10 @@ typedef struct agdiff_conv_params {
   const float* filt_poly_pk; /* pk [12][poly_kt] or null: the whole filter network of a RADIUS edge (type 0, d < cutoff) as a
                                 polynomial in d -- see agdiff_params_t.poly_kt.  Rows 0..127 conv1, 128..191 conv2; nn.2.bias
                                 is the constant term */
-  const float* filt_poly_typed_pk; /* [poly_num_slots] x pk [12][poly_kt] or null: the same for the LOCAL edge types that have
+  const float* filt_poly_typed_pk; /* [poly_num_slots + 1] x pk [12][poly_kt] or null: the same for the LOCAL edge types that have
                                 a slot (agdiff_params_t.poly_type_slot), d in [0, cutoff] (beyond it the CFConv's cutoff factor
-                                C(d) is exactly 0, schnet.py:140-146) */
+                                C(d) is exactly 0, schnet.py:140-146); set poly_num_slots repeats the radius edges' filt_poly_pk
+                                (poly_type_slot[0] = poly_num_slots) for agdiff_cfconv_merged */
   float gate2_b;
   float act_beta;            /* InteractionBlock.act.beta */
 } agdiff_conv_params_t;
@@ -372,6 +373,12 @@ int agdiff_cfconv_fused(const agdiff_params_t* p, const agdiff_topo_t* topo, con
  * (which == 1). */
 int agdiff_cfconv_radius(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k, void* stream);
 int agdiff_cfconv_local(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k, void* stream);
+/* Small batches: both CFConvs of block k in ONE launch over the full destination-sorted edge list (ws->in_ptr, e_src, e_dst,
+ * e_type, e_len, e_scale -> ws->agg / agg_first, as agdiff_cfconv_fused), every edge's filter from the polynomial set of its
+ * type (radius edges included as one more slot).  Needs agdiff_local_poly_enabled() and poly_num_slots + 1 <=
+ * AGDIFF_POLY_MAX_SLOTS; agdiff_cfconv_merged_ok says whether that holds. */
+int agdiff_cfconv_merged(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k, void* stream);
+int agdiff_cfconv_merged_ok(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws);
 /* 1 when agdiff_cfconv_local takes the local edges' filters from per-type d-polynomials (p->poly_num_slots > 0, poly_kt == 1,
  * topo->lp_type, ws->l_len_p), 0 when it evaluates the filter MLPs on ws->l_attr_frag. */
 int agdiff_local_poly_enabled(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws);

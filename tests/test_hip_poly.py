@@ -75,10 +75,15 @@ def test_forward_every_filter_mode(case, mode, precision):
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
-@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("mode", MODES + ["auto-two-lists"])
 @pytest.mark.parametrize("case", ["g5_sampler_lowT_global", "g5_sampler_mixed_cliplocal"])
-def test_sampler_every_filter_mode(case, mode, precision):
-    """The denoising loop (polynomial global head on the radius edges in every mode but `off`)."""
+def test_sampler_every_filter_mode(case, mode, precision, monkeypatch):
+    """The denoising loop (polynomial global head on the radius edges in every mode but `off`).  Batches this small run
+    both CFConv passes of a block as ONE launch over the full edge list in mode `auto` (agdiff_cfconv_merged);
+    `auto-two-lists` forces the radius-list + local-list launches that large batches take."""
+    if mode == "auto-two-lists":
+        monkeypatch.setenv("AGDIFF_MERGED_MAX_NODES", "0")
+        mode = "auto"
     g = load_golden(case)
     m = _model(sampler_case_cfg(g, case), mode, head_scale=float(g["head_scale"]), precision=precision)
     pos, traj = m.langevin_dynamics_sample_diffusion(
@@ -128,6 +133,13 @@ def test_split_cfconv_equals_one_list_kernel(kind, mols, copies):
             # (both sides carry their own split-bf16 rounding -- polynomial vs MLP chain --, each ~1.5e-5 from the exact
             # value: the gate is for a difference of two such figures)
             check_close("split_cfconv[%s] block %d" % (kind, k), got, ref, precision, scale=3.0 if precision == "bf16x3" else 1.0)
+            # the one-launch variant for small batches: every edge of the full list by the polynomial of its type
+            assert lib.agdiff_cfconv_merged_ok(P, T, W) == 1
+            ws.agg.zero_(); ws.agg_first.zero_()
+            assert lib.agdiff_cfconv_merged(P, T, W, k, st) == 0
+            torch.cuda.synchronize()
+            check_close("merged_cfconv[%s] block %d" % (kind, k), _aggregates(ws, topo, lib), ref, precision,
+                        scale=3.0 if precision == "bf16x3" else 1.0)
 
 
 def test_rejected_fit_falls_back_to_the_mlps():
