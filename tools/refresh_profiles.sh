@@ -15,6 +15,7 @@ python bench.py --workload qm9 --mols 40 --copies 64 --steps 1000 --no-cpu-basel
 python bench.py --workload large --mols 2 --copies 128 --steps 300 --no-cpu-baseline --no-extra 2>/dev/null | tail -1 > $out/${R}_bench_large.json
 python bench.py --workload alanine --mols 1 --copies 250 --schedule default --job-steps 100 --steps 100 --warmup 0 --no-cpu-baseline 2>/dev/null | tail -1 > $out/${R}_bench_alanine.json
 python bench.py --mols 1 --copies 100 --steps 2000 --no-cpu-baseline --no-extra 2>/dev/null | tail -1 > $out/${R}_bench_small_batch.json
+python bench.py --mols 1 --copies 25 --steps 2000 --no-cpu-baseline --no-extra 2>/dev/null | tail -1 > $out/${R}_bench_small_batch_25.json
 python bench.py --force-dist --steps 300 --no-cpu-baseline --no-extra 2>/dev/null | tail -1 > $out/${R}_force_dist.json
 python bench.py --force-dist --scaling strong --steps 300 --no-cpu-baseline --no-extra 2>/dev/null | tail -1 > $out/${R}_force_dist_strong.json
 cd /tmp && export TMPDIR=/tmp
