@@ -1762,8 +1762,10 @@ extern "C" int agdiff_local_edge_rows(const agdiff_params_t* p, const agdiff_top
   AG_CHECK_LAUNCH();
   // the flagged tiles (if any) through the MLP: the launch returns before staging its weights when the count is 0
   g_enc_tile_flags = ws->enc_flags;
-  return agdiff_edge_encoder(p, ws->num_local_canon, ctiles, ws->lc_len, topo->lc_type, nullptr, ws->l_attr_rows, nullptr,
-                             nullptr, nullptr, stream);
+  const int rc = agdiff_edge_encoder(p, ws->num_local_canon, ctiles, ws->lc_len, topo->lc_type, nullptr, ws->l_attr_rows,
+                                     nullptr, nullptr, nullptr, stream);
+  g_enc_tile_flags = nullptr;        // (also when the call returned before it consumed the pointer)
+  return rc;
 }
 
 extern "C" int agdiff_pair_head(const agdiff_head_params_t* hp, const int32_t* n_edges_dev, int64_t max_tiles,
