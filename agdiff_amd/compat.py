@@ -15,24 +15,44 @@ import types
 
 from .config import Config
 
+# Exact (module, name) pairs a reference checkpoint pickles (scripts/train.py:219-231: a state_dict, two optimizer and two
+# scheduler state_dicts, an int and a float, the EasyDict config).  Nothing is admitted by module prefix: a pickle may name
+# ANY attribute reachable from an admitted module ("torch.serialization" -> os), so every global is listed by hand.
+_SAFE_GLOBALS = {
+    ("collections", "OrderedDict"), ("collections", "defaultdict"),
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
+    ("torch._utils", "_rebuild_parameter_with_state"),
+    ("torch", "Size"), ("torch", "device"), ("torch", "Tensor"), ("torch.nn.parameter", "Parameter"),
+    ("numpy", "ndarray"), ("numpy", "dtype"),
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"),
+    ("numpy._core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "scalar"),
+    ("_codecs", "encode"),
+}
 _SAFE_BUILTINS = {"dict", "list", "tuple", "set", "frozenset", "int", "float", "complex", "bool", "str", "bytes",
-                  "bytearray", "slice", "range", "object", "getattr"}
-_SAFE_PREFIXES = ("torch.", "collections.", "numpy.")
-_SAFE_MODULES = {"torch", "collections", "numpy", "copyreg", "_codecs"}
+                  "bytearray", "slice", "range"}
+_TORCH_STORAGES = {"DoubleStorage", "FloatStorage", "HalfStorage", "BFloat16Storage", "LongStorage", "IntStorage",
+                   "ShortStorage", "CharStorage", "ByteStorage", "BoolStorage", "UntypedStorage"}
 
 
 class _Unpickler(pickle.Unpickler):
-    """Allow-list unpickler: torch tensor rebuild helpers, numpy scalars / arrays, std containers, and
-    easydict.EasyDict -> agdiff_amd.Config.  Anything else is refused (pass trust=True to load_checkpoint for a
+    """Allow-list unpickler: torch tensor rebuild helpers, torch storages / dtypes, numpy scalars / arrays, std
+    containers, and easydict.EasyDict -> agdiff_amd.Config, each by its exact (module, name).  Anything else -- dotted
+    names, getattr, other attributes of the admitted modules -- is refused (pass trust=True to load_checkpoint for a
     file you trust that pickles other classes)."""
 
     def find_class(self, module, name):
         if (module, name) in (("easydict", "EasyDict"), ("agdiff_amd.config", "Config")):
             return Config
-        if module == "builtins":
-            if name in _SAFE_BUILTINS:
-                return super().find_class(module, name)
-        elif module in _SAFE_MODULES or module.startswith(_SAFE_PREFIXES):
+        ok = False
+        if "." not in name:
+            if module == "builtins":
+                ok = name in _SAFE_BUILTINS
+            elif (module, name) in _SAFE_GLOBALS:
+                ok = True
+            elif module == "torch":
+                import torch
+                ok = name in _TORCH_STORAGES or isinstance(getattr(torch, name, None), torch.dtype)
+        if ok:
             return super().find_class(module, name)
         raise pickle.UnpicklingError("checkpoint pickles %s.%s, which agdiff_amd.compat.load_checkpoint does not admit; "
                                      "pass trust=True if the file comes from a source you trust" % (module, name))

@@ -123,7 +123,9 @@ def sample_batch_sharded(model, packed, device, sampler_kwargs, save_traj=False,
     denoising step (StepAllGather), and the last gather is the job's result on every rank.  Molecules in which a NaN
     appeared (on any rank) are re-sampled, sharded again, with clip_local=20 (test.py:143-181).
     `pos_init` [N,3] / `noise` [steps,N,3] for the WHOLE batch replace the first attempt's draws (tests).
-    Returns (pos [N,3] cpu, traj or None, ok [num molecules]) like driver.sample_batch, identical on all ranks."""
+    Returns (pos [N,3] cpu, traj or None, ok [num molecules]) like driver.sample_batch; pos and ok are identical on all
+    ranks, the trajectories [steps, N, 3] are gathered to rank 0 only (None elsewhere).  A rank that raises while the
+    others sample keeps issuing its collectives, then every rank raises."""
     from .driver import subset_batch
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)
@@ -133,39 +135,54 @@ def sample_batch_sharded(model, packed, device, sampler_kwargs, save_traj=False,
     traj_out = None
     ok = np.zeros(n_mol, dtype=bool)
     todo, clip_local = list(range(n_mol)), None
-    n_steps = int(sampler_kwargs.get("n_steps", 5000))
+    # collectives per attempt = steps LangevinRun will take (epsnet.py: len(step_indices) if given, else n_steps): a rank
+    # without graphs must issue exactly as many gathers as the ranks that sample
+    si = sampler_kwargs.get("step_indices")
+    n_steps = len(si) if si is not None else int(sampler_kwargs.get("n_steps", 5000))
     for attempt in range(max_retry):
         sub = packed if len(todo) == n_mol else subset_batch(packed, todo)
         mine, (g0, g1), (lo, hi) = shard_of(sub, rank, world)
         first = attempt == 0
         gather = StepAllGather(hi - lo, device, group)
-        if mine is None:                      # more ranks than graphs: take part in the collectives only
-            empty, zero = torch.zeros(0, 3, device=device), torch.zeros(1, dtype=torch.int32, device=device)
-            for k in range(n_steps):
-                gather(k, k, empty, zero)
-            bad_local, traj = np.zeros(0, dtype=bool), None
-        else:
-            p0 = pos_init[lo:hi].to(device) if (first and pos_init is not None) else torch.randn(hi - lo, 3).to(device)
-            run = model.begin_sampling(T(mine["atom_type"]), p0, T(mine["bond_index"]), T(mine["bond_type"]),
-                                       T(mine["batch"]), mine["num_graphs"], False, clip_local=clip_local,
-                                       save_traj=save_traj, raise_on_nan=False,
-                                       noise=(noise[:, lo:hi] if (first and noise is not None) else None),
-                                       **sampler_kwargs)
-            run.on_step = lambda k, i, pos: gather(k, i, pos, run.ws.nan_flag)
-            run.advance(run.remaining())
-            _, traj = run.finish()
-            bad_local = run.nan_graphs().numpy()
+        empty, zero = torch.zeros(0, 3, device=device), torch.zeros(1, dtype=torch.int32, device=device)
+        err, traj, bad_local = None, None, np.zeros(0, dtype=bool)
+        if mine is not None:
+            try:
+                p0 = pos_init[lo:hi].to(device) if (first and pos_init is not None) else torch.randn(hi - lo, 3).to(device)
+                run = model.begin_sampling(T(mine["atom_type"]), p0, T(mine["bond_index"]), T(mine["bond_type"]),
+                                           T(mine["batch"]), mine["num_graphs"], False, clip_local=clip_local,
+                                           save_traj=save_traj, raise_on_nan=False,
+                                           noise=(noise[:, lo:hi] if (first and noise is not None) else None),
+                                           **sampler_kwargs)
+                run.on_step = lambda k, i, pos: gather(k, i, pos, run.ws.nan_flag)
+                run.advance(run.remaining())
+                _, traj = run.finish()
+                bad_local = run.nan_graphs().numpy()
+            except Exception as e:            # (AgdiffLimitError, out of memory, ...): the other ranks are inside the
+                err = e                       # per-step collectives -- keep this rank's count whole, fail together below
+        # a rank without graphs (more ranks than graphs) or one that failed takes part in the collectives only
+        filler = empty if (mine is None or err is None) else torch.zeros(hi - lo, 3, device=device)
+        for k in range(gather.calls, n_steps):
+            gather(k, k, filler if mine is not None else empty, zero)
+        errs = [None] * world
+        dist.all_gather_object(errs, None if err is None else "%s: %s" % (type(err).__name__, err), group=group)
+        if any(e is not None for e in errs):
+            if err is not None:
+                raise err
+            raise RuntimeError("sample_batch_sharded: rank(s) %s failed: %s"
+                               % ([r for r, e in enumerate(errs) if e is not None], [e for e in errs if e is not None]))
         parts, _ = gather.result()
         pos = torch.cat([p.cpu() for p in parts], dim=0)            # rank order == graph order
         bad_all = [None] * world
         dist.all_gather_object(bad_all, bad_local.tolist(), group=group)
         bad_graph = np.array([b for part in bad_all for b in part], dtype=bool)
-        if save_traj:
-            trajs = [None] * world
-            dist.all_gather_object(trajs, None if traj is None else torch.stack(traj).numpy(), group=group)
-            traj = torch.from_numpy(np.concatenate([x for x in trajs if x is not None], axis=1))
-            if traj_out is None:
-                traj_out = torch.full((traj.shape[0], N, 3), float("nan"))
+        if save_traj:                          # [steps, N_r, 3] per rank: to rank 0 only (it writes them)
+            trajs = [None] * world if rank == 0 else None
+            dist.gather_object(None if traj is None else torch.stack(traj).numpy(), trajs, dst=0, group=group)
+            if rank == 0:
+                traj = torch.from_numpy(np.concatenate([x for x in trajs if x is not None], axis=1))
+                if traj_out is None:
+                    traj_out = torch.full((traj.shape[0], N, 3), float("nan"))
         failed, g_off = [], 0
         for slot, (off_s, n, g) in zip(todo, sub["spans"]):
             off, _, _ = spans[slot]
@@ -174,7 +191,7 @@ def sample_batch_sharded(model, packed, device, sampler_kwargs, save_traj=False,
             else:
                 ok[slot] = True
                 pos_out[off:off + n * g] = pos[off_s:off_s + n * g]
-                if save_traj:
+                if save_traj and rank == 0:
                     traj_out[:, off:off + n * g] = traj[:, off_s:off_s + n * g]
             g_off += g
         todo = failed

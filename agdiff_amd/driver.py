@@ -211,8 +211,11 @@ def _batch_path(out_dir, bmols):
 
 
 def _save_npz_atomic(path, arrays):
-    tmp = path[:-4] + ".tmp.npz"
-    np.savez_compressed(tmp, **arrays)
+    # the temporary's name must not match the `samples_[0-9]*.npz` globs of _done_indices / merge_outputs: a run killed
+    # mid-write leaves it behind, and np.load of a truncated archive would end the next --resume
+    tmp = os.path.join(os.path.dirname(path), "." + os.path.basename(path) + ".tmp")
+    with open(tmp, "wb") as f:
+        np.savez_compressed(f, **arrays)
     os.replace(tmp, path)
 
 

@@ -6,9 +6,10 @@ import argparse, ctypes, json, os, sys, time
 import numpy as np
 os.environ["AGDIFF_RADIUS_POLY"] = "off"    # this experiment compares against the one-list product kernel (agdiff_cfconv_fused)
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, HERE)
 from proto_pairs import build_pair_sweeps, wave_partition   # noqa: E402
 
 ap = argparse.ArgumentParser()
@@ -22,6 +23,7 @@ args = ap.parse_args()
 
 from agdiff_amd import _lib, drugs_model_config, get_model, qm9_model_config, synth   # noqa: E402
 lib = _lib.load()
+proto = ctypes.CDLL(os.path.join(HERE, "libagdiff_proto.so"))       # make -C experiments/mirror_pairs
 dev = torch.device("cuda", 0)
 cfg = (qm9_model_config if args.workload == "qm9" else drugs_model_config)(beta_end=2e-5)
 model = get_model(cfg)
@@ -81,7 +83,7 @@ agg_seg = torch.zeros(S * 192, dtype=torch.float32, device=dev)
 mir_rows = torch.zeros(I * 16 * 192, dtype=torch.float32, device=dev)
 
 
-fnf = lib.agdiff_proto_cfconv_pairs_fused
+fnf = proto.agdiff_proto_cfconv_pairs_fused
 fnf.restype = ctypes.c_int
 fnf.argtypes = [ctypes.c_void_p, ctypes.c_int32] + [ctypes.c_void_p] * 14 + [ctypes.c_int32, ctypes.c_void_p]
 

@@ -7,9 +7,10 @@ import argparse, ctypes, json, os, sys, time
 import numpy as np
 os.environ["AGDIFF_RADIUS_POLY"] = "off"    # this experiment compares against the one-list product kernel (agdiff_cfconv_fused)
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, HERE)
 from proto_pairs4 import build_pair_tiles, pair_rows   # noqa: E402
 
 ap = argparse.ArgumentParser()
@@ -23,6 +24,7 @@ args = ap.parse_args()
 
 from agdiff_amd import _lib, drugs_model_config, get_model, qm9_model_config, synth   # noqa: E402
 lib = _lib.load()
+proto = ctypes.CDLL(os.path.join(HERE, "libagdiff_proto.so"))       # make -C experiments/mirror_pairs
 dev = torch.device("cuda", 0)
 cfg = (qm9_model_config if args.workload == "qm9" else drugs_model_config)(beta_end=2e-5)
 model = get_model(cfg)
@@ -134,7 +136,7 @@ pt_atoms, pt_info = i32(tabs["pt_atoms"].reshape(-1)), i32(tabs["pt_info"].resha
 wave_ptr = i32(tabs["wave_tile_ptr"])
 dbuf = torch.zeros(tabs["n_groups"] * 4 * 192, dtype=torch.float32, device=dev)
 mbuf = torch.zeros(tabs["n_sets"] * 16 * 192, dtype=torch.float32, device=dev)
-fn = lib.agdiff_proto_cfconv_pairs4
+fn = proto.agdiff_proto_cfconv_pairs4
 fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int32] + [ctypes.c_void_p] * 11 + [ctypes.c_int32, ctypes.c_void_p]
 

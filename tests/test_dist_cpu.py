@@ -113,7 +113,10 @@ def _shard_worker(rank, world, port, out):
         keep = torch.ones(N, dtype=torch.bool)
         keep[off:off + n * gg] = False
         good = bool(ok.all()) and torch.equal(pos[keep], ref[keep]) and bool(torch.isfinite(pos).all())
-        good = good and traj.shape == (3, N, 3) and torch.equal(traj[-1][keep], ref[keep])
+        if rank == 0:                       # the trajectories go to rank 0 only (it writes them)
+            good = good and traj.shape == (3, N, 3) and torch.equal(traj[-1][keep], ref[keep])
+        else:
+            good = good and traj is None
         # first attempt: this rank's share of the 15 graphs; second: its share of molecule 3's three conformers
         good = good and len(model.calls) == 2 and model.calls[0][1] is None and model.calls[1][1] == 20
         out[rank] = (int(good), model.calls[0][0], model.calls[1][0])
@@ -128,3 +131,45 @@ def test_sharded_sampling_matches_unsharded_world2_gloo():
     mp.spawn(_shard_worker, args=(2, port, out), nprocs=2, join=True)
     assert out[0][0] == 1 and out[1][0] == 1
     assert out[0][1] + out[1][1] == 15 and out[0][2] + out[1][2] == 3      # graphs of both attempts, split over the ranks
+
+
+def _shard_fault_worker(rank, world, port, out):
+    """(a) more ranks than graphs + step_indices shorter than n_steps: the idle rank issues len(step_indices)
+    collectives, not n_steps; (b) a rank that raises inside begin_sampling must not leave the other in all_gather."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_driver_cpu import _FakeSampler, _mols
+    from agdiff_amd import driver
+    from agdiff_amd.dist import sample_batch_sharded
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=60))
+    try:
+        one = driver.pack_batch(_mols(1), driver.num_confs("1"))          # ONE graph over two ranks: rank 1 idles
+        model = _FakeSampler()
+        run0 = model.begin_sampling
+        model.begin_sampling = lambda *a, step_indices=None, **k: run0(*a, **dict(k, n_steps=len(step_indices)))
+        pos, _, ok = sample_batch_sharded(model, one, "cpu", dict(n_steps=5000, step_indices=[9, 5, 1]), log=lambda s: None)
+        a_ok = bool(ok.all()) and bool(torch.isfinite(pos).all())
+        packed = driver.pack_batch(_mols(4), driver.num_confs("2"))
+        bad = _FakeSampler()
+        if rank == 1:
+            def boom(*a, **k):
+                raise MemoryError("rank 1 ran out of memory")
+            bad.begin_sampling = boom
+        msg = ""
+        try:
+            sample_batch_sharded(bad, packed, "cpu", dict(n_steps=3), log=lambda s: None)
+        except Exception as e:
+            msg = "%s: %s" % (type(e).__name__, e)
+        out[rank] = (int(a_ok), msg)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_sampling_idle_rank_and_failing_rank_world2_gloo():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_shard_fault_worker, args=(2, port, out), nprocs=2, join=True)
+    assert out[0][0] == 1 and out[1][0] == 1
+    assert out[1][1].startswith("MemoryError") and "rank(s) [1] failed" in out[0][1] and "MemoryError" in out[0][1]

@@ -217,6 +217,26 @@ def test_reference_checkpoint_with_easydict_config(tmp_path):
     with pytest.raises(pickle.UnpicklingError):
         compat.load_checkpoint(bad)
     assert compat.load_checkpoint(bad, trust=True)["x"].name == "a"
+    # ... and nothing by module PREFIX: a global reached through an admitted module (torch.serialization imports os),
+    # a dotted name, builtins.getattr and a real optimizer's numpy-scalar state are each decided by exact (module, name)
+    import io
+    for mod, name in (("torch.serialization", "os.getcwd"), ("torch.serialization", "os"), ("torch", "serialization.os.getcwd"),
+                      ("builtins", "getattr"), ("builtins", "eval"), ("numpy", "load"), ("collections", "abc"),
+                      ("torch.hub", "load"), ("torch", "load")):
+        with pytest.raises(pickle.UnpicklingError):
+            compat._Unpickler(io.BytesIO(b"")).find_class(mod, name)
+    payload = (b"\x80\x04" + b"\x8c\x13torch.serialization" + b"\x8c\x09os.getcwd" + b"\x93" + b")R.")   # STACK_GLOBAL; call
+    with pytest.raises(pickle.UnpicklingError):
+        compat._Unpickler(io.BytesIO(payload)).load()
+    for mod, name in (("torch._utils", "_rebuild_tensor_v2"), ("collections", "OrderedDict"), ("torch", "FloatStorage"),
+                      ("torch", "float32"), ("torch", "Size"), ("numpy", "dtype")):
+        assert compat._Unpickler(io.BytesIO(b"")).find_class(mod, name) is not None
+    full = str(tmp_path / "full.pt")          # what scripts/train.py:219-231 really saves: live optimizer / scheduler state
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    sch = torch.optim.lr_scheduler.ReduceLROnPlateau(opt)
+    torch.save({"config": Config(model=cfg), "model": m.state_dict(), "optimizer_global": opt.state_dict(),
+                "scheduler_global": sch.state_dict(), "iteration": 3, "avg_val_loss": float(np.float32(0.25))}, full)
+    assert compat.load_checkpoint(full)["scheduler_global"]["patience"] == 10
 
 
 def test_compat_install_aliases_the_reference_import_path():

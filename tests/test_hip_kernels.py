@@ -150,79 +150,3 @@ def test_node_stage_block0_vs_reference_modules(case, precision):
                 g["scaled_b0"], precision, scale=4.0)      # difference of two O(1) fp32 numbers, |result| ~ 0.3
     xs1 = _xs_ref(sd, "encoder_global.interactions.1", torch.from_numpy(h1_ref))
     check_close("node_stage1 xs[%s]" % case, ws.xs.view(-1, 192), xs1.float(), precision)
-
-
-@pytest.mark.parametrize("precision", PRECISIONS)
-def test_mirror_sharing_cfconv_prototype_matches_product_kernel(precision):
-    """csrc/pairs.hip (experiment, DESIGN.md §8.2: filter evaluated once per mirror pair, mirror sums accumulated in
-    registers through a 0/1 selection MFMA): its aggregates equal the product kernel's on the capped Drugs-shaped
-    fixture -- the direct sums and the per-slot mirror sums add up to agg[node] of agdiff_cfconv_fused."""
-    import os
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
-    from proto_pairs import build_pair_sweeps, wave_partition
-    from agdiff_amd import _lib
-    g, cfg, sd, m, lib, topo, ws, (P, Tp, Wp, st) = _setup("g3_forward_drugs_capped", precision)
-    dev = "cuda:0"
-    C = int(ws.num_canon.item())
-    r = build_pair_sweeps(ws.c_src[:C].cpu().numpy(), ws.c_dst[:C].cpu().numpy(), ws.c_mir[:C].cpu().numpy(),
-                          topo.graph_ptr.cpu().numpy(), max_tiles=3)
-    R, S, I = r["rows"], len(r["seg_dst"]), len(r["item_tiles"])
-    assert (r["p_slot"] >= 0).any() and (r["p_slot"][r["p_can"] >= 0] < 0).any()      # mirrored and unpaired rows
-    i32 = lambda x: torch.from_numpy(np.ascontiguousarray(x).astype(np.int32)).to(dev)
-    p_src, p_dst, p_slot, p_seg = i32(r["p_src"]), i32(r["p_dst"]), i32(r["p_slot"]), i32(r["p_seg"])
-    seg_ptr, item_row0, item_tiles = i32(r["seg_ptr"]), i32(r["item_row0"]), i32(r["item_tiles"])
-    num_waves = 24
-    wave_ptr = i32(wave_partition(r["item_tiles"], num_waves))
-    p_can = torch.from_numpy(r["p_can"]).to(dev)
-    valid = p_can >= 0
-    row_of_can = torch.empty(C, dtype=torch.int32, device=dev)
-    row_of_can[p_can[valid]] = torch.nonzero(valid).flatten().to(torch.int32)
-    e_attr2 = torch.zeros((R // 16) * 2048, dtype=torch.float32, device=dev)
-    nomir = torch.full((C,), -1, dtype=torch.int32, device=dev)
-    etiles = (topo.max_edges + 15) // 16
-    assert lib.agdiff_edge_encoder(P, _lib.ptr(ws.num_canon), etiles, _lib.ptr(ws.c_len), _lib.ptr(ws.c_type),
-                                   _lib.ptr(e_attr2), None, None, _lib.ptr(row_of_can), _lib.ptr(nomir), st) == 0
-    epad, c_pos, scales = etiles * 16, ws.c_pos[:C].long(), []
-    for c in (0, 1):
-        srow = torch.zeros(R, dtype=torch.float32, device=dev)
-        srow[valid] = ws.e_scale[c * epad:(c + 1) * epad][c_pos[p_can[valid]]]
-        scales.append(srow)
-    assert lib.agdiff_schnet_node_stage(P, Tp, Wp, 0, st) == 0
-    assert lib.agdiff_cfconv_fused(P, Tp, Wp, 0, st) == 0
-    fnf = lib.agdiff_proto_cfconv_pairs_fused
-    fnf.restype = ctypes.c_int
-    fnf.argtypes = [ctypes.c_void_p, ctypes.c_int32] + [ctypes.c_void_p] * 14 + [ctypes.c_int32, ctypes.c_void_p]
-    agg_seg = torch.zeros(S * 192, dtype=torch.float32, device=dev)
-    mir_rows = torch.zeros(I * 16 * 192, dtype=torch.float32, device=dev)
-    assert fnf(P, 0, _lib.ptr(p_src), _lib.ptr(p_dst), _lib.ptr(p_slot), _lib.ptr(p_seg), _lib.ptr(seg_ptr),
-               _lib.ptr(scales[0]), _lib.ptr(scales[1]), _lib.ptr(e_attr2), _lib.ptr(ws.xs), _lib.ptr(agg_seg),
-               _lib.ptr(mir_rows), _lib.ptr(item_row0), _lib.ptr(item_tiles), _lib.ptr(wave_ptr), num_waves, st) == 0
-    torch.cuda.synchronize()
-    got = torch.zeros(topo.N, 192, device=dev, dtype=torch.float64)
-    got.index_add_(0, torch.from_numpy(r["seg_dst"]).to(dev), agg_seg.view(S, 192).double())
-    slots_atom = (torch.from_numpy(r["item_j0"]).to(dev)[:, None] + torch.arange(16, device=dev)[None, :]).reshape(-1)
-    ok = slots_atom < topo.N
-    got.index_add_(0, slots_atom[ok], mir_rows.view(I * 16, 192)[ok].double())
-    ref = _device_agg(lib, topo, ws)
-    # same arithmetic per edge in both kernels; only the order of the fp32 additions differs
-    check_close("pairs prototype agg", got.float(), ref.float(), "f32")
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("workload,mols,copies", [("drugs", 4, 3), ("qm9", 6, 4)])
-def test_pair_tile_cfconv_prototype_matches_product_kernel(workload, mols, copies):
-    """csrc/pairs4.hip (experiment, DESIGN.md §8.2, second design: 4 x 4 pair tiles, direct sums inside a lane, mirror
-    sums by one reduce-scatter over the quarters): direct + mirror partial rows add up to agg[node] of
-    agdiff_cfconv_fused for every molecule of the batch.  The harness (tools/proto_run4.py) builds the tables."""
-    import json
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "proto_run4.py"), "--workload", workload, "--mols", str(mols),
-                          "--copies", str(copies), "--max-atoms", "512", "--reps", "2"], capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    rec = json.loads(out.stdout.strip().splitlines()[-1])
-    assert rec["E_dense"] == rec["E"] and rec["pair_tiles"] > 0
-    assert rec["rel_err"] < 1e-5, rec
