@@ -1,18 +1,15 @@
 // Whole-path entry points: ABI self-description, the score network (dualenc.py:142-251) and one
 // denoising step (dualenc.py:478-545), composed from the per-op launchers.
 #include "common.hpp"
-#include <cstdlib>
 #include <mutex>
+#include <vector>
 
 extern "C" int agdiff_abi_version(void) { return AGDIFF_ABI_VERSION; }
 
 // Tiles per chunk of the fused CFConv: every one of the 2,048 resident waves (256 CUs x 8) should walk at least
 // 16 chunks, so that the uneven last round of the grid-stride loop stays a small tail (measured at 100 k tiles:
 // 8-tile chunks = 6.1 chunks per wave cost 4 % over 2-tile chunks); at most AGDIFF_MAX_CHUNK_TILES.
-// AGDIFF_CHUNK_TILES overrides (experiments).
 extern "C" int agdiff_conv_chunk_tiles(int64_t max_edges) {
-  static const int forced = getenv("AGDIFF_CHUNK_TILES") ? atoi(getenv("AGDIFF_CHUNK_TILES")) : 0;
-  if (forced >= 1 && forced <= AGDIFF_MAX_CHUNK_TILES) return forced;
   const int64_t tiles = (max_edges + AG_TW - 1) / AG_TW;
   int c = 1;
   while (c < AGDIFF_MAX_CHUNK_TILES && tiles / (2 * c) >= 16 * 2048) c *= 2;
@@ -28,6 +25,64 @@ extern "C" int agdiff_struct_sizes(int64_t* out) {
   out[4] = sizeof(agdiff_topo_t);
   out[5] = sizeof(agdiff_ws_t);
   out[6] = sizeof(agdiff_step_args_t);
+  return AGDIFF_OK;
+}
+
+// ---- in-step timing of the CFConv launches (bench.py's roofline object): when switched on, agdiff_score_forward brackets
+// every CFConv launch of the global branch (agdiff_cfconv_node [+ agdiff_cfconv_local], or agdiff_cfconv_fused) with a pair
+// of HIP events on the stream it launches them on; agdiff_profile_cfconv_read synchronises them and returns the sum.
+namespace {
+struct CfconvProfile {
+  std::mutex mu;
+  bool on = false;
+  std::vector<hipEvent_t> pool;      // pairs: [2 i] before, [2 i + 1] after
+  size_t used = 0;
+};
+CfconvProfile g_prof;
+struct ProfScope {                   // records the pair around one block's CFConv launches when profiling is on
+  hipStream_t st;
+  hipEvent_t after = nullptr;
+  explicit ProfScope(void* stream) : st((hipStream_t)stream) {
+    std::lock_guard<std::mutex> lock(g_prof.mu);
+    if (!g_prof.on) return;
+    if (g_prof.used + 2 > g_prof.pool.size()) {
+      hipEvent_t a = nullptr, b = nullptr;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+      g_prof.pool.push_back(a);
+      g_prof.pool.push_back(b);
+    }
+    if (hipEventRecord(g_prof.pool[g_prof.used], st) != hipSuccess) return;
+    after = g_prof.pool[g_prof.used + 1];
+    g_prof.used += 2;
+  }
+  ~ProfScope() {
+    if (after) (void)hipEventRecord(after, st);
+  }
+};
+}  // namespace
+
+extern "C" int agdiff_profile_cfconv(int32_t enable) {
+  std::lock_guard<std::mutex> lock(g_prof.mu);
+  g_prof.on = enable != 0;
+  if (enable) g_prof.used = 0;
+  return AGDIFF_OK;
+}
+
+extern "C" int agdiff_profile_cfconv_read(double* total_ms, int64_t* launches) {
+  if (!total_ms || !launches) return AGDIFF_ERR_ARG;
+  std::lock_guard<std::mutex> lock(g_prof.mu);
+  double sum = 0.0;
+  int64_t n = 0;
+  for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+    float ms = 0.0f;
+    if (hipEventSynchronize(g_prof.pool[i + 1]) != hipSuccess) return AGDIFF_ERR_LAUNCH;
+    if (hipEventElapsedTime(&ms, g_prof.pool[i], g_prof.pool[i + 1]) != hipSuccess) return AGDIFF_ERR_LAUNCH;
+    sum += ms;
+    ++n;
+  }
+  g_prof.used = 0;
+  *total_ms = sum;
+  *launches = n;
   return AGDIFF_OK;
 }
 
@@ -68,9 +123,10 @@ ForkJoin& fork_join_for_current_device() {
 // `rows_from_global`: the global branch's encoder pass writes ws->l_attr_rows itself (the local edges are a subset of
 // the edge set it walks and dualenc.py:214-216 evaluates the SAME encoder on them), so the pass over the local list is
 // skipped and everything after it waits for `rows_ready`.
-// `split` (split CFConv): the encoder pass over the canonical local list also writes the operand-form attributes of the
-// local edges by in-slot (ws->l_attr_frag) and is followed by their CFConv scales (ws->l_scale); `split_ready` is recorded
-// once both are enqueued (agdiff_cfconv_local on the other stream waits for it).
+// `split` (CFConv by filter polynomials): the local edges' CFConv inputs are prepared here too -- their scales by pair-tile row
+// (ws->lt_scale) when agdiff_cfconv_node takes their filters from polynomials, else their operand-form attributes and
+// scales by padded-list position (ws->l_attr_frag, ws->l_scale) for agdiff_cfconv_local; `split_ready` is recorded once
+// they are enqueued (the CFConv launches on the other stream wait for it).
 int local_branch(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, int flags,
                  bool rows_from_global, hipEvent_t rows_ready, void* stream, bool split = false,
                  hipEvent_t split_ready = nullptr) {
@@ -83,12 +139,14 @@ int local_branch(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdi
     if (hipStreamWaitEvent((hipStream_t)stream, rows_ready, 0) != hipSuccess) return AGDIFF_ERR_LAUNCH;
   } else if (topo->num_local > 0) {
     if (canon && split) {
-      if (agdiff_local_poly_enabled(p, topo, ws))     // the local CFConv takes its filters from polynomials: rows only
+      if (agdiff_local_poly_enabled(p, topo, ws)) {   // the local CFConv takes its filters from polynomials: rows only
+        AG_TRY(agdiff_edge_scales_split(p, topo, ws, 2, stream));
         AG_TRY(agdiff_local_edge_rows(p, topo, ws, stream));
-      else                  // ... and the operand-form copy at the padded-list positions of the edge and of its mirror
+      } else {              // ... and the operand-form copy at the padded-list positions of the edge and of its mirror
         AG_TRY(agdiff_edge_encoder(p, ws->num_local_canon, ctiles, ws->lc_len, topo->lc_type, ws->l_attr_frag, ws->l_attr_rows,
                                    topo->lp_row, topo->lc_ppos, topo->lc_pmir, stream));
-      AG_TRY(agdiff_edge_scales_split(p, topo, ws, 1, stream));
+        AG_TRY(agdiff_edge_scales_split(p, topo, ws, 1, stream));
+      }
     } else if (canon)        // one evaluation and one row per mirror pair of local edges (polynomials where they apply)
       AG_TRY(agdiff_local_edge_rows(p, topo, ws, stream));
     else
@@ -133,7 +191,10 @@ int global_back(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdif
   const int64_t etiles = (topo->max_edges + AG_TW - 1) / AG_TW;
   for (int k = 0; k <= p->num_convs; ++k) {
     AG_TRY(agdiff_schnet_node_stage(p, topo, ws, k, stream));
-    if (k < p->num_convs) AG_TRY(agdiff_cfconv_fused(p, topo, ws, k, stream));
+    if (k < p->num_convs) {
+      ProfScope prof(stream);
+      AG_TRY(agdiff_cfconv_fused(p, topo, ws, k, stream));
+    }
   }
   if (flags & AGDIFF_FWD_GRAPH_GIVEN) {
     AG_TRY(agdiff_pair_head(&p->head_global, ws->num_edges, etiles, ws->e_src, ws->e_dst, ws->h, ws->e_attr, nullptr,
@@ -145,18 +206,8 @@ int global_back(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdif
   return AGDIFF_OK;
 }
 
-// Split CFConv (p->poly_kt > 0, graph built here): radius edges take their filters from d-polynomials, local edges go
-// through the filter MLPs on the static local list (include/agdiff_hip.h).
-// front: radius graph -> radius-edge scales (-> the encoder over all canonical edges when the full head will need edge_attr)
-// Small batches are bound by launch and fill latencies, not by arithmetic: below this many atoms the two CFConv passes of a
-// block run as ONE launch over the full edge list (agdiff_cfconv_merged: every tile then pays for the type groups, but a
-// launch, a coefficient fill and a tail are saved per block).  AGDIFF_MERGED_MAX_NODES overrides (0 = never).
-bool use_merged(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int flags) {
-  const char* env = getenv("AGDIFF_MERGED_MAX_NODES");         // (read per call: tests switch it)
-  const int64_t max_nodes = env ? atoll(env) : 12288;     // 1 molecule x 25 / 100 / 200 / 400 conformers: -17 / -8 / -3 / +4 %
-  return (flags & AGDIFF_FWD_SAMPLER) && topo->num_nodes < max_nodes && topo->num_local > 0 && agdiff_cfconv_merged_ok(p, topo, ws);
-}
-
+// CFConv by filter polynomials (p->poly_kt > 0, graph built here): one agdiff_cfconv_node launch per block (include/agdiff_hip.h).
+// front: radius graph -> radius-row scales (-> the encoder over all canonical edges when the full head will need edge_attr)
 int global_front_split(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, int flags,
                        void* stream) {
   const int64_t etiles = (topo->max_edges + AG_TW - 1) / AG_TW;
@@ -164,42 +215,41 @@ int global_front_split(const agdiff_params_t* p, const agdiff_topo_t* topo, cons
   // evaluation per mirror pair of radius edges)
   const bool ronly = (flags & AGDIFF_FWD_SAMPLER) != 0;
   AG_TRY(agdiff_graph_build_ex(topo, ws, pos, (flags & AGDIFF_FWD_NO_RADIUS) ? 0.0f : p->cutoff, ronly ? 1 : 0, stream));
-  if (use_merged(p, topo, ws, flags))
-    AG_TRY(agdiff_edge_scales(p, topo, ws, 0, stream));        // one list: scales by position in the full edge list
-  else
-    AG_TRY(agdiff_edge_scales_split(p, topo, ws, 0, stream));
+  AG_TRY(agdiff_edge_scales_split(p, topo, ws, 0, stream));
   if (!(flags & AGDIFF_FWD_SAMPLER))
     AG_TRY(agdiff_edge_encoder(p, ws->num_canon, etiles, ws->c_len, ws->c_type, ws->e_attr, nullptr, nullptr, ws->c_pos,
                                ws->c_mir, stream));
   return AGDIFF_OK;
 }
-// back: SchNet with split CFConvs -> global head.  `local_ready`: ws->l_attr_frag / ws->l_scale are complete (recorded on
-// the local branch's stream), or null when the local branch ran on this stream.
+// back: SchNet with polynomial CFConvs -> global head.  `local_ready`: the local edges' CFConv inputs (ws->lt_len / lt_scale,
+// or ws->l_attr_frag / l_scale) are complete (recorded on the local branch's stream), or null when the local branch ran on
+// this stream.
 int global_back_split(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int flags,
                       hipEvent_t local_ready, void* stream) {
   const int64_t etiles = (topo->max_edges + AG_TW - 1) / AG_TW;
   // stage 0 (embeddings + block 0's lin1) is the same on every step of a run: written to ws->h0 / ws->xs0 once, block 0
   // reads it from there
   const bool cache = ws->h0 && ws->xs0;
-  const bool merged = use_merged(p, topo, ws, flags);
-  const int sp = merged ? 0 : 1;             // node stage: one aggregate (merged pass) or radius + local
+  // local edges: inside agdiff_cfconv_node (per-type polynomials), or agdiff_cfconv_local's second aggregate (filter MLPs)
+  const bool local_mlp = topo->num_local > 0 && !agdiff_local_poly_enabled(p, topo, ws);
+  const int sp = 1 | (local_mlp ? 8 : 0);
   if (!(cache && (flags & AGDIFF_FWD_STAGE0_CACHED))) AG_TRY(agdiff_schnet_node_stage_split(p, topo, ws, 0, sp | 4, stream));
   agdiff_ws_t ws0 = *ws;
   if (cache) ws0.xs = ws->xs0;
   for (int k = 0; k < p->num_convs; ++k) {
     const agdiff_ws_t* wk = (k == 0) ? &ws0 : ws;
-    if (merged) {
-      AG_TRY(agdiff_cfconv_merged(p, topo, wk, k, stream));
-    } else {
-      AG_TRY(agdiff_cfconv_radius(p, topo, wk, k, stream));
-      if (k == 0 && local_ready && hipStreamWaitEvent((hipStream_t)stream, local_ready, 0) != hipSuccess) return AGDIFF_ERR_LAUNCH;
-      AG_TRY(agdiff_cfconv_local(p, topo, wk, k, stream));
+    if (k == 0 && local_ready && hipStreamWaitEvent((hipStream_t)stream, local_ready, 0) != hipSuccess) return AGDIFF_ERR_LAUNCH;
+    {
+      ProfScope prof(stream);
+      AG_TRY(agdiff_cfconv_node(p, topo, wk, k, stream));
+      if (local_mlp) AG_TRY(agdiff_cfconv_local(p, topo, wk, k, stream));
     }
     AG_TRY(agdiff_schnet_node_stage_split(p, topo, ws, k + 1, sp | (k == 0 ? 2 : 0), stream));
   }
   if (flags & AGDIFF_FWD_SAMPLER) {
     // only the radius edges' outputs are used (dualenc.py:516-518): the head's edge_attr half from the d-polynomial, over
     // the canonical list (a mirror pair of radius edges has one length and h_i * h_j is symmetric)
+    ag_log_variant(ws, AGDIFF_VAR_HEAD_POLY);
     AG_TRY(agdiff_pair_head_poly(p, ws->num_canon, etiles, ws->c_src, ws->c_dst, ws->c_len, ws->h, ws->c_pos, ws->c_mir,
                                  ws->e_inv_global, stream));
   } else {
@@ -218,14 +268,14 @@ extern "C" int agdiff_score_forward(const agdiff_params_t* p, const agdiff_topo_
   // ... for batches above ~8 k atoms.  Below, the local branch runs its own encoder pass over the canonical local list:
   // it then does not wait for the global encoder and overlaps the graph build and the encoder instead of the first
   // CFConv launches, whose persistent workgroups it would delay (1 molecule x 25 / 100 / 400 conformers:
-  // 0.415 / 0.645 / 1.82 ms per step against 0.441 / 0.668 / 1.79).  AGDIFF_SHARE_ROWS_MIN_NODES overrides (tests).
-  const char* share_env = getenv("AGDIFF_SHARE_ROWS_MIN_NODES");
-  const int64_t share_min = share_env ? atoll(share_env) : 8192;
+  // 0.415 / 0.645 / 1.82 ms per step against 0.441 / 0.668 / 1.79): agdiff_params_t.tune_share_rows_min_nodes.
+  const int64_t share_min = ag_tune(p->tune_share_rows_min_nodes, 8192);
   const bool share_rows = !(flags & AGDIFF_FWD_GRAPH_GIVEN) && topo->num_local > 0 && ws->e_loc && topo->num_nodes >= share_min;
-  static const bool serial = getenv("AGDIFF_SERIAL_BRANCHES") != nullptr;
+  const bool serial = p->tune_serial_branches != 0;
   ForkJoin& fj = fork_join_for_current_device();
   hipStream_t main = (hipStream_t)stream;
-  const bool split = p->poly_kt > 0 && !(flags & AGDIFF_FWD_GRAPH_GIVEN) && ws->rad_ptr != nullptr;
+  const bool split = p->poly_kt > 0 && !(flags & AGDIFF_FWD_GRAPH_GIVEN) && ws->rad_cnt != nullptr;
+  if (!(serial || !fj.ok)) ag_log_variant(ws, AGDIFF_VAR_SIDE_STREAM);
   if (split) {
     if (serial || !fj.ok) {
       AG_TRY(global_front_split(p, topo, ws, pos, flags, stream));
@@ -241,6 +291,7 @@ extern "C" int agdiff_score_forward(const agdiff_params_t* p, const agdiff_topo_
     if (hipStreamWaitEvent(main, fj.join, 0) != hipSuccess) return AGDIFF_ERR_LAUNCH;
     return AGDIFF_OK;
   }
+  if (share_rows) ag_log_variant(ws, AGDIFF_VAR_SHARE_ROWS);
   if (serial || !fj.ok) {
     AG_TRY(global_front(p, topo, ws, pos, flags, share_rows, stream));
     if (share_rows && fj.ok && hipEventRecord(fj.rows, main) != hipSuccess) return AGDIFF_ERR_LAUNCH;

@@ -175,11 +175,26 @@ __device__ __forceinline__ void ag_cvt_pair(AgIn<AG_F32>& o, int j, float v0, fl
   o.v[j >> 2][(j & 3) + 1] = v1;
 }
 __device__ __forceinline__ void ag_cvt_pair(AgIn<AG_BF3>& o, int j, float v0, float v1) {
+#ifdef AG_CVT_PAIR_SCALAR
   const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
   o.hi[j] = h0;
   o.hi[j + 1] = h1;
   o.lo[j] = (__bf16)(v0 - (float)h0);
   o.lo[j + 1] = (__bf16)(v1 - (float)h1);
+#else
+  // one v_cvt_pk_bf16_f32 per pair for hi and one for lo; the rounded values come back as floats by a shift / a mask of the
+  // packed word (six instructions per pair: element-wise conversion compiled to eight)
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  const bf16x2 hp = __builtin_convertvector(f32x2{v0, v1}, bf16x2);
+  const uint32_t hw = __builtin_bit_cast(uint32_t, hp);
+  const float h0 = __uint_as_float(hw << 16), h1 = __uint_as_float(hw & 0xFFFF0000u);
+  const bf16x2 lp = __builtin_convertvector(f32x2{v0 - h0, v1 - h1}, bf16x2);
+  o.hi[j] = hp[0];
+  o.hi[j + 1] = hp[1];
+  o.lo[j] = lp[0];
+  o.lo[j + 1] = lp[1];
+#endif
 }
 // NK k-tiles from accumulator tiles A0, A0+1, ...
 template <int MODE, int NK, int A0, int NA, int NO>
@@ -230,6 +245,22 @@ __device__ __forceinline__ void ag_block_mma_part(f32x4& o, const AgIn<MODE>& x,
     const bf16x8 xv = (part == 1) ? x.lo : x.hi;
     o = FLIP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(xv, wv, o, 0, 0, 0)
              : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, xv, o, 0, 0, 0);
+  }
+}
+
+// The first part of a product that starts from zero: the accumulator input is the literal 0 (an inline constant of the
+// MFMA), not a register the compiler has to clear first.
+template <int MODE, bool FLIP>
+__device__ __forceinline__ f32x4 ag_block_mma_first(const AgIn<MODE>& x, const u32x4 (&w)[2]) {
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (MODE == AG_F32) {
+    const f32x4 wf = __builtin_bit_cast(f32x4, w[0]);
+    return FLIP ? __builtin_amdgcn_mfma_f32_16x16x4f32(x.v[0][0], wf[0], zero, 0, 0, 0)
+                : __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0], x.v[0][0], zero, 0, 0, 0);
+  } else {
+    const bf16x8 wv = __builtin_bit_cast(bf16x8, w[0]);
+    return FLIP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(x.hi, wv, zero, 0, 0, 0)
+                : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, x.hi, zero, 0, 0, 0);
   }
 }
 
@@ -359,6 +390,42 @@ __device__ __forceinline__ void ag_load_attr(AgIn<AG_BF3>& x, const float* frag,
   x.hi = __builtin_bit_cast(bf16x8, p[ag_attr_unit(tile, t, 0, lane)]);
   x.lo = __builtin_bit_cast(bf16x8, p[ag_attr_unit(tile, t, 1, lane)]);
 }
+// ---------------------------------------------------------------------------------- filter polynomials
+// Operand elements of the lane's edge for the NKT k-tiles of a d-polynomial (include/agdiff_hip.h: agdiff_params_t.poly_kt;
+// host mirror: agdiff_amd/packing.py poly_features): element j of quarter q in k-tile t is
+//   phi[8 (4 t + q) + j](x) = T_{8 (4 t + q)}(x) T_j(x),   x = 2 d / cutoff - 1 in [-1, 1].
+// T_0..T_8 by the three-term recurrence, T_16 .. T_56 from the product rule 2 T_a T_b = T_{a+b} + T_{|a-b|}: ~25 VALU
+// instructions + the operand split per k-tile, instead of a 128-wide MLP chain per edge.
+// `gmask` (1 or 0) multiplies every element: edges outside the group being evaluated contribute nothing.
+template <int MODE, int NKT>
+__device__ __forceinline__ void ag_poly_features(float d, float two_over_rc, int q, AgIn<MODE> (&o)[NKT], float gmask = 1.0f) {
+  static_assert(NKT >= 1 && NKT <= AGDIFF_POLY_MAX_KT, "poly_kt");
+  const float x = fminf(fmaxf(fmaf(d, two_over_rc, -1.0f), -1.0f), 1.0f);
+  const float x2 = x + x;
+  float T[9];
+  T[0] = 1.0f;
+  T[1] = x;
+#pragma unroll
+  for (int n = 2; n <= 8; ++n) T[n] = fmaf(x2, T[n - 1], -T[n - 2]);
+  const float t8 = T[8], t8x2 = t8 + t8;
+  const float g2 = fmaf(t8x2, t8, -1.0f);          // T16
+  const float g3 = fmaf(g2 + g2, t8, -t8);         // T24
+  float G[NKT];
+  G[0] = gmask * ((q == 0) ? 1.0f : (q == 1) ? t8 : (q == 2) ? g2 : g3);
+  if constexpr (NKT == 2) {
+    const float g4 = fmaf(g2 + g2, g2, -1.0f);     // T32
+    const float g5 = fmaf(g4 + g4, t8, -g3);       // T40
+    const float g6 = fmaf(g3 + g3, g3, -1.0f);     // T48
+    const float g7 = fmaf(g6 + g6, t8, -g5);       // T56
+    G[1] = gmask * ((q == 0) ? g4 : (q == 1) ? g5 : (q == 2) ? g6 : g7);
+  }
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) ag_cvt_pair(o[t], j, G[t] * T[j], G[t] * T[j + 1]);
+  }
+}
+
 // global -> LDS copy of n 16-byte units by the whole workgroup (weights that stay resident for a launch or a phase).
 // The loads of U units per thread are issued back to back and stored afterwards: the plain loop `dst[i] = src[i]`
 // compiles to load, s_waitcnt vmcnt(0), ds_write per iteration -- one exposed L2 round trip per 16 bytes and thread,
@@ -401,6 +468,12 @@ static inline bool ag_allow_big_lds(std::atomic<uint64_t>& done, size_t smem, K.
   if (ok) done.fetch_or(bit, std::memory_order_release);
   return ok;
 }
+// Host side: the variant a launcher chose, for agdiff_ws_t.variant_log (a host word the tests read), and a tuning field of
+// agdiff_params_t with its library default (0 = default).
+static inline void ag_log_variant(const agdiff_ws_t* ws, int64_t bits) {
+  if (ws && ws->variant_log) *ws->variant_log |= bits;
+}
+static inline int64_t ag_tune(int64_t v, int64_t dflt) { return v != 0 ? v : dflt; }
 // Host-side launch check
 #define AG_CHECK_LAUNCH()                                         \
   do {                                                            \

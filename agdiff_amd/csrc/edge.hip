@@ -783,395 +783,37 @@ __global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_pair_head(HeadArgs
   }
 }
 
-// ------------------------------------------------------------------------------ radius-edge polynomials
-// Operand elements of the lane's edge for the NKT k-tiles of a d-polynomial (include/agdiff_hip.h: agdiff_params_t.poly_kt;
-// host mirror: agdiff_amd/packing.py poly_features): element j of quarter q in k-tile t is
-//   phi[8 (4 t + q) + j](x) = T_{8 (4 t + q)}(x) T_j(x),   x = 2 d / cutoff - 1 in [-1, 1].
-// T_0..T_8 by the three-term recurrence, T_16 .. T_56 from the product rule 2 T_a T_b = T_{a+b} + T_{|a-b|}: ~25 VALU
-// instructions + the operand split per k-tile, instead of a 128-wide MLP chain per edge.
-// `gmask` (1 or 0) multiplies every element: edges outside the group being evaluated contribute nothing.
-template <int MODE, int NKT>
-__device__ __forceinline__ void ag_poly_features(float d, float two_over_rc, int q, AgIn<MODE> (&o)[NKT], float gmask = 1.0f) {
-  static_assert(NKT >= 1 && NKT <= AGDIFF_POLY_MAX_KT, "poly_kt");
-  const float x = fminf(fmaxf(fmaf(d, two_over_rc, -1.0f), -1.0f), 1.0f);
-  const float x2 = x + x;
-  float T[9];
-  T[0] = 1.0f;
-  T[1] = x;
-#pragma unroll
-  for (int n = 2; n <= 8; ++n) T[n] = fmaf(x2, T[n - 1], -T[n - 2]);
-  const float t8 = T[8], t8x2 = t8 + t8;
-  const float g2 = fmaf(t8x2, t8, -1.0f);          // T16
-  const float g3 = fmaf(g2 + g2, t8, -t8);         // T24
-  float G[NKT];
-  G[0] = gmask * ((q == 0) ? 1.0f : (q == 1) ? t8 : (q == 2) ? g2 : g3);
-  if constexpr (NKT == 2) {
-    const float g4 = fmaf(g2 + g2, g2, -1.0f);     // T32
-    const float g5 = fmaf(g4 + g4, t8, -g3);       // T40
-    const float g6 = fmaf(g3 + g3, g3, -1.0f);     // T48
-    const float g7 = fmaf(g6 + g6, t8, -g5);       // T56
-    G[1] = gmask * ((q == 0) ? g4 : (q == 1) ? g5 : (q == 2) ? g6 : g7);
-  }
-#pragma unroll
-  for (int t = 0; t < NKT; ++t) {
-#pragma unroll
-    for (int j = 0; j < 8; j += 2) ag_cvt_pair(o[t], j, G[t] * T[j], G[t] * T[j + 1]);
-  }
-}
-
-// ------------------------------------------------------------------------------ CFConv over the radius edges
-struct RadConvArgs {
-  const float* poly_pk;  // pk [12][NKT]: filter polynomials of conv1 (channel tiles 0..7) and conv2 (8..11), bias included
-  const int32_t* n_dev;  // R
-  const int32_t* e_src;
-  const int32_t* e_dst;
-  const float* e_len;
-  const float* scale1;   // [R] lw(d)*C(d) of conv1 of this block
-  const float* scale2;
-  const float* xs;       // [N][192]
-  float* agg;            // [N][192]
-  float* agg_first;      // [chunks][192]
-  int64_t max_chunks;
-  int32_t chunk_tiles;
-  float two_over_rc;
-  // TYPED (local edges): poly_pk holds num_slots coefficient sets, edge e uses set type_slot[e_type[e]]
-  const int32_t* e_type;
-  const int32_t* type_slot;
-  int32_t num_slots;
+// lw(d) * C(d) of the 2*num_convs CFConvs for the radius rows (ws->rad_*: AGDIFF_RAD_STRIDE rows per target), and the pad
+// rows that complete a target's last 16-row tile: src = the target itself, length 0, every scale 0.
+struct RadScaleArgs {
+  const float* dw[2 * AGDIFF_MAX_CONVS];
+  const int32_t* rad_cnt;
+  int32_t* rad_src;
+  float* rad_len;
+  float* out;
+  int64_t rpad;      // N * AGDIFF_RAD_STRIDE
+  int32_t n;
+  float cutoff;
+  int32_t smooth;
 };
-
-// encoder/schnet.py:136-162 for conv1 and conv2 of one InteractionBlock over the RADIUS edges only:
-//   W_e = nn(MLPEdgeEncoder(d_e, 0)) = P(d_e)  (a polynomial, see above);  agg[dst] += x[src] * W_e * (lw(d_e) C(d_e)).
-// Same tile walk, message and destination-segmented reduction as k_cfconv_fused (chunks of consecutive 16-edge tiles per
-// wave, running sums in registers, agg_first for lists that span chunks: no atomics, fixed order), but the filter is
-// NKT x 12 x 3 MFMAs per tile instead of 264 and needs no edge_attr stream: what is left is the x[src] gathers and the
-// reduction, so the kernel runs 12 waves per CU (~160 VGPRs) next to 24 NKT KiB of coefficients in LDS.  The lists'
-// offsets (rad_ptr / lp_ptr) are only needed by the node stage: here every boundary comes from the rows' own targets.
-// TYPED: the same over the LOCAL list, whose edges carry a type each (bond / 2-hop / 3-hop): a tile's edges are grouped
-// by type on the fly (wave-uniform loop over the types present, typically three) and every group adds its masked
-// features times its own coefficient set (all sets resident in LDS) to the tile's filter values before the reduction.
-// Lengths beyond the cutoff are clamped into the fitted range: their CFConv scale is exactly 0 (schnet.py:140-146).
-template <int MODE, int NKT, int WAVES, bool TYPED>
-__global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_radius(RadConvArgs a) {
-  extern __shared__ u32x4 ag_rad_smem[];
-  lds_u32x4* wl = (lds_u32x4*)ag_rad_smem;
-  {
-    const u32x4* g = reinterpret_cast<const u32x4*>(a.poly_pk);
-    const int nset = TYPED ? a.num_slots : 1;
-    ag_copy_lds(wl, g, nset * AG_CONV_NCH * NKT * 128);
-  }
+__global__ void __launch_bounds__(256) k_rad_scales(RadScaleArgs a) {
+  __shared__ float seg[2 * AGDIFF_MAX_CONVS * 100];
+  for (int i = threadIdx.x; i < a.n * 100; i += blockDim.x) seg[i] = a.dw[i / 100][i % 100];
   __syncthreads();
-  const int lane0 = ag_lane();
-  const int wave = threadIdx.x >> 6;
-  const int E = *a.n_dev;
-  const int64_t cstride = (int64_t)gridDim.x * WAVES;
-  const int wg = (gridDim.x % 8 == 0) ? (int)((blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8) : (int)blockIdx.x;
-#ifndef AG_RAD_ABL
-#define AG_RAD_ABL 0        // timing experiments only (wrong results): 1 no x gathers, 2 no filter MFMAs, 4 no reduction arithmetic
-#endif
-
-  // A tile is short here (a few hundred instructions), so every memory round trip that starts inside it is exposed.
-  // Everything a tile needs from memory is therefore requested during the PREVIOUS tile of the wave: its per-edge
-  // scalars (source, target, length, the two scales, type slot) and the target of the row before it, and -- once the
-  // sources have arrived -- the x[src] values of its first channel-tile group.  Nothing in a tile depends on in_ptr:
-  // list boundaries come from the rows' own targets.
-  int pf_src = 0, pf_dst = -1, pf_slot = -1, pf_prev = -1;
-  float pf_s1 = 0.0f, pf_s2 = 0.0f, pf_d = 0.0f;
-  auto prefetch_meta = [&](int64_t tl, int ln) {
-    const int64_t tb = tl * AG_TW, e = tb + (ln & 15);
-    const bool valid = e < E;
-    if constexpr (TYPED) pf_slot = valid ? a.type_slot[a.e_type[e]] : -1;
-    pf_src = valid ? a.e_src[e] : 0;
-    pf_dst = valid ? a.e_dst[e] : -1;
-    pf_s1 = valid ? a.scale1[e] : 0.0f;
-    pf_s2 = valid ? a.scale2[e] : 0.0f;
-    pf_d = valid ? a.e_len[e] : 0.0f;
-    pf_prev = (tb > 0) ? a.e_dst[tb - 1] : -1;
-  };
-  // x[src] values of a group of four channel tiles (16 per lane), two groups in flight
-  f32x4 xg[2][4];
-  uint32_t xoff[4];
-  auto set_xoff = [&](int src, int ln) {      // byte offsets of the lane's four rows (row 4 q + r lives in lane 4 q + r)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) xoff[r] = ((uint32_t)__shfl(src, 4 * (ln >> 4) + r) * 192u + (uint32_t)(ln & 15)) * 4u;
-  };
-  auto fetch_xg = [&](auto BUF, int g4) {
-    constexpr int kb = decltype(BUF)::value;
-    const char* xb = reinterpret_cast<const char*>(a.xs);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (AG_RAD_ABL & 1) xg[kb][j][r] = __uint_as_float(xoff[r] + j);
-        else xg[kb][j][r] = *reinterpret_cast<const float*>(xb + (size_t)xoff[r] + 64 * (4 * g4 + j));
-      }
-    }
-  };
-  {
-    const int64_t first = ((int64_t)wg * WAVES + wave) * a.chunk_tiles;
-    if (first * AG_TW < E) {
-      prefetch_meta(first, lane0);
-      set_xoff(pf_src, lane0);
-      fetch_xg(std::integral_constant<int, 0>{}, 0);
-    }
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= a.rpad) return;
+  const int i = (int)(row / AGDIFF_RAD_STRIDE), k = (int)(row - (int64_t)i * AGDIFF_RAD_STRIDE);
+  const int cnt = a.rad_cnt[i];
+  if (k >= ((cnt + AG_TW - 1) / AG_TW) * AG_TW) return;
+  if (k >= cnt) {
+    a.rad_src[row] = i;
+    a.rad_len[row] = 0.0f;
+    for (int c = 0; c < a.n; ++c) a.out[(size_t)c * a.rpad + row] = 0.0f;
+    return;
   }
-  int parity = 0;           // which of the two x buffers holds the current tile's first group
-  for (int64_t chunk = (int64_t)wg * WAVES + wave; chunk < a.max_chunks; chunk += cstride) {
-    const int64_t e_begin = chunk * (AG_TW * a.chunk_tiles);
-    if (e_begin >= E) break;
-    int run_t = -1;
-    int carried = -1;       // the target whose list was already open when the chunk started: its sum goes to agg_first[chunk]
-    float carry[AG_CONV_NCH / 4];      // as k_cfconv_fused: entry g of lane (col, q) = channel 16 (4 g + q) + col
-#pragma unroll
-    for (int i = 0; i < AG_CONV_NCH / 4; ++i) carry[i] = 0.0f;
-    auto dest = [&](int t) -> float* {
-      return (t == carried) ? (a.agg_first + (size_t)chunk * 192) : (a.agg + (size_t)t * 192);
-    };
-    for (int tt = 0; tt < a.chunk_tiles; ++tt) {
-      const int64_t tile = chunk * a.chunk_tiles + tt;
-      const int64_t tbase = tile * AG_TW;
-      if (tbase >= E) break;
-      auto tile_body = [&](auto PAR) {
-        constexpr int kPar = decltype(PAR)::value;
-        int lane = lane0;
-        asm volatile("" : "+v"(lane));
-        const int q = lane >> 4, col = lane & 15;
-        const int my_dst = pf_dst;
-        const float s1 = pf_s1, s2 = pf_s2, d = pf_d;
-        [[maybe_unused]] const int my_slot = pf_slot;
-        // first and last target of the tile: the targets of its first and last live row (lane = row for lanes 0..15)
-        const int t0 = __builtin_amdgcn_readfirstlane(my_dst);
-        const int t1 = __builtin_amdgcn_readlane(my_dst, (int)((tbase + AG_TW <= E) ? AG_TW - 1 : E - 1 - tbase));
-        if (tt == 0) carried = (__builtin_amdgcn_readfirstlane(pf_prev) == t0) ? t0 : -1;
-        if (run_t >= 0 && run_t != t0) {   // previous tile ended exactly on a list boundary
-          float* dp = dest(run_t);
-#pragma unroll
-          for (int i = 0; i < AG_CONV_NCH / 4; ++i) {
-            dp[16 * (4 * i + q) + col] = carry[i];
-            carry[i] = 0.0f;
-          }
-          run_t = -1;
-        }
-        f32x4 sr;                          // scale of the conv being processed, per edge row
-        int rd[4];                         // targets of the lane's four rows
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          sr[r] = __shfl(s1, 4 * q + r);
-          rd[r] = __shfl(my_dst, 4 * q + r);
-        }
-        // one or two targets in the tile (every live row belongs to the first or to the last one): fast reduction
-        const uint64_t others = __ballot(my_dst >= 0 && my_dst != t0 && my_dst != t1) & 0xFFFFull;
-        const bool two = t1 != t0;
-        // a third target between the first and the last one (its whole list lies inside the tile): still a fast reduction
-        // when every other row belongs to it -- QM9-shaped molecules (radius in-degree ~14) have such a tile every few tiles
-        const int tm = others ? __builtin_amdgcn_readlane(my_dst, (int)__builtin_ctzll(others)) : -1;
-        const bool three = others != 0 && (__ballot(my_dst >= 0 && my_dst != t0 && my_dst != t1 && my_dst != tm) & 0xFFFFull) == 0;
-        const bool fast = others == 0 || three;
-        f32x4 m0, m1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          m0[r] = (rd[r] == t0) ? 1.0f : 0.0f;
-          m1[r] = (two && rd[r] == t1) ? 1.0f : 0.0f;
-        }
-        float* const dp0 = dest(t0);
-
-        AgIn<MODE> ph[NKT];
-        [[maybe_unused]] f32x4 zall[TYPED ? AG_CONV_NCH : 1];
-        const lds_u32x4* wl_l = ag_lds_base(wl, lane);
-        // four channel tiles' coefficient blocks (pk [12][NKT]: block nt * NKT + t of set `base`) times the features:
-        // four independent accumulator chains with their MFMA passes interleaved
-        auto mma_group = [&](const lds_u32x4* base, int g4, f32x4 (&zg)[4]) {
-          u32x4 w[4][NKT][2];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int t = 0; t < NKT; ++t) {
-              w[j][t][0] = base[(((4 * g4 + j) * NKT + t) * 2) * 64];
-              w[j][t][1] = base[(((4 * g4 + j) * NKT + t) * 2 + 1) * 64];
-            }
-          }
-          if (AG_RAD_ABL & 2) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) zg[j] += __builtin_bit_cast(f32x4, w[j][0][0]);
-            return;
-          }
-#pragma unroll
-          for (int t = 0; t < NKT; ++t) {
-#pragma unroll
-            for (int part = 0; part < AgParts<MODE>::n; ++part) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) ag_block_mma_part<MODE, true>(zg[j], ph[t], w[j][t], part);
-            }
-          }
-        };
-        if constexpr (!TYPED) {
-          ag_poly_features<MODE, NKT>(d, a.two_over_rc, q, ph);
-        } else {
-#pragma unroll
-          for (int nt = 0; nt < AG_CONV_NCH; ++nt) zall[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-          uint64_t todo = __ballot(my_slot >= 0) & 0xFFFFull;      // one lane per edge column (the quarters hold copies)
-          // the features are evaluated (and split) once; a group's operand is a copy with the other rows zeroed
-          AgIn<MODE> phall[NKT];
-          ag_poly_features<MODE, NKT>(d, a.two_over_rc, q, phall);
-          while (todo) {
-            const int g = __builtin_amdgcn_readlane(my_slot, (int)__builtin_ctzll(todo));
-            const bool in = my_slot == g;
-            todo &= ~__ballot(in);
-#pragma unroll
-            for (int t = 0; t < NKT; ++t) {
-              const u32x4 zero = {0u, 0u, 0u, 0u};
-              if constexpr (MODE == AG_F32) {
-                ph[t].v[0] = in ? phall[t].v[0] : f32x4{0.f, 0.f, 0.f, 0.f};
-                ph[t].v[1] = in ? phall[t].v[1] : f32x4{0.f, 0.f, 0.f, 0.f};
-              } else {
-                ph[t].hi = __builtin_bit_cast(bf16x8, in ? __builtin_bit_cast(u32x4, phall[t].hi) : zero);
-                ph[t].lo = __builtin_bit_cast(bf16x8, in ? __builtin_bit_cast(u32x4, phall[t].lo) : zero);
-              }
-            }
-            const lds_u32x4* wg_ = wl_l + (size_t)g * (AG_CONV_NCH * NKT * 128);
-#pragma unroll
-            for (int g4 = 0; g4 < AG_CONV_NCH / 4; ++g4) {
-              f32x4 (&zg)[4] = *reinterpret_cast<f32x4 (*)[4]>(&zall[4 * g4]);
-              mma_group(wg_, g4, zg);
-            }
-          }
-        }
-        // the wave's next tile: per-edge scalars now, its first x group below
-        int64_t nxt = tile + 1;
-        if (tt + 1 >= a.chunk_tiles) nxt = (chunk + cstride) * a.chunk_tiles;
-        const bool has_next = nxt * AG_TW < E && nxt < a.max_chunks * a.chunk_tiles;
-        if (has_next) prefetch_meta(nxt, lane);
-
-        // General reduction (a third target somewhere in the tile): one masked sum per target PRESENT in the tile, found
-        // from the rows' own targets -- a radius list may be empty for many consecutive atoms (molecules spread out at high
-        // sigma).  Replicated over the quarters; quarter nt & 3 keeps / stores it (the fast path's distribution).
-        auto reduce_general = [&](f32x4 z, int nt, float& cr) {
-          const bool mine = q == (nt & 3);
-          float newcarry = 0.0f;
-          int cur = t0;
-          bool first = true;
-          while (true) {
-            float p = 0.0f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) p += (rd[r] == cur) ? z[r] : 0.0f;
-            p = ag_quarter_sum(p);
-            if (first) p = cr + p;
-            const uint64_t later = __ballot(my_dst > cur) & 0xFFFFull;      // rows of later targets (invalid rows hold -1)
-            if (later == 0) {
-              newcarry = p;
-              break;
-            }
-            float* dp = first ? dp0 : (a.agg + (size_t)cur * 192);          // a list that starts inside this tile starts in this chunk
-            if (mine) dp[16 * nt + col] = p;
-            cur = __builtin_amdgcn_readlane(my_dst, (int)__builtin_ctzll(later));
-            first = false;
-          }
-          cr = mine ? newcarry : cr;
-        };
-        auto filter_group = [&](int g4, f32x4 (&zg)[4]) {      // flipped: rows = edges, lanes = channels
-          if constexpr (TYPED) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) zg[j] = zall[4 * g4 + j];
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) zg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            mma_group(wl_l, g4, zg);
-          }
-        };
-        // The 12 channel tiles go in three groups of four (groups 0, 1 are conv1, group 2 is conv2).  Group g4's x values
-        // sit in buffer (kPar + g4) & 1; the next group's gathers and MFMAs are issued before this group's reduction, and
-        // before the LAST reduction the next tile's first group is requested.
-        f32x4 zc[4];
-        filter_group(0, zc);
-        auto reduce_group = [&](auto G4) {
-          constexpr int g4 = decltype(G4)::value;
-          constexpr int kb = (kPar + g4) & 1;
-          if (fast) {
-            // masked sums as FMAs (the conv's scale folded into the row masks), then ONE reduce-scatter over the quarters
-            // for the four channel tiles: quarter q ends up with channel tile 4 g4 + q.  (Packed fp32 for these sums and
-            // skipping the second target's where the tile has one target were measured: +5 % per launch, not kept.)
-            const f32x4 w0 = m0 * sr, w1 = m1 * sr;
-            float p0[4], p1[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              f32x4 t;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) t[r] = zc[j][r] * xg[kb][j][r];
-              if (AG_RAD_ABL & 4) {
-                p0[j] = t[0] + t[1];
-                p1[j] = t[2] + t[3];
-                continue;
-              }
-              p0[j] = t[0] * w0[0];
-              p1[j] = t[0] * w1[0];
-#pragma unroll
-              for (int r = 1; r < 4; ++r) {
-                p0[j] = fmaf(t[r], w0[r], p0[j]);
-                p1[j] = fmaf(t[r], w1[r], p1[j]);
-              }
-            }
-            const float r0 = carry[g4] + ag_quarter_reduce_scatter4(p0[0], p0[1], p0[2], p0[3]);
-            if (two) {       // the first target's list ends in this tile; the last one's sum stays open
-              dp0[16 * (4 * g4 + q) + col] = r0;
-              carry[g4] = ag_quarter_reduce_scatter4(p1[0], p1[1], p1[2], p1[3]);
-            } else {
-              carry[g4] = r0;
-            }
-            if (three) {     // the middle target's list starts and ends here: its sums go straight to its row of agg
-              float pm[4];
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                pm[j] = 0.0f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pm[j] = fmaf(zc[j][r] * xg[kb][j][r], (rd[r] == tm) ? sr[r] : 0.0f, pm[j]);
-              }
-              a.agg[(size_t)tm * 192 + 16 * (4 * g4 + q) + col] = ag_quarter_reduce_scatter4(pm[0], pm[1], pm[2], pm[3]);
-            }
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              f32x4 z;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) z[r] = zc[j][r] * xg[kb][j][r] * sr[r];
-              reduce_general(z, 4 * g4 + j, carry[g4]);
-            }
-          }
-        };
-        {
-          f32x4 zn[4];
-          fetch_xg(std::integral_constant<int, (kPar + 1) & 1>{}, 1);
-          filter_group(1, zn);
-          reduce_group(std::integral_constant<int, 0>{});
-#pragma unroll
-          for (int j = 0; j < 4; ++j) zc[j] = zn[j];
-        }
-        {
-          f32x4 zn[4];
-          fetch_xg(std::integral_constant<int, (kPar + 2) & 1>{}, 2);
-          filter_group(2, zn);
-          reduce_group(std::integral_constant<int, 1>{});
-#pragma unroll
-          for (int j = 0; j < 4; ++j) zc[j] = zn[j];
-        }
-        if (has_next) {                     // (all of this tile's gathers are out: xoff is free)
-          set_xoff(pf_src, lane);
-          fetch_xg(std::integral_constant<int, (kPar + 3) & 1>{}, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sr[r] = __shfl(s2, 4 * q + r);      // channel tiles 8..11 are conv2: its per-edge scale
-        reduce_group(std::integral_constant<int, 2>{});
-        run_t = t1;
-      };
-      if (parity) tile_body(std::integral_constant<int, 1>{});
-      else tile_body(std::integral_constant<int, 0>{});
-      parity ^= 1;
-    }
-    if (run_t >= 0) {
-      float* dp = dest(run_t);
-#pragma unroll
-      for (int i = 0; i < AG_CONV_NCH / 4; ++i) dp[16 * (4 * i + (lane0 >> 4)) + (lane0 & 15)] = carry[i];
-    }
-  }
+  const float d = a.rad_len[row];
+  const float C = cf_envelope(d, a.cutoff, a.smooth);
+  for (int c = 0; c < a.n; ++c) a.out[(size_t)c * a.rpad + row] = cf_dist_weight(seg + c * 100, d) * C;
 }
 
 // ------------------------------------------------------------------------------ local edge_attr rows by polynomial
@@ -1193,6 +835,7 @@ struct AttrPolyArgs {
 // 16 lengths all lie in [0, cutoff] and whose types all have a slot is evaluated here (features once, one masked MFMA
 // round per type present); any other tile is flagged for the encoder MLP (agdiff_local_edge_rows).
 #define AG_ATTRP_WAVES 8
+#define AG_ATTRP_MAX_SLOTS 9         // 9 x 16 KiB of coefficients in LDS
 template <int MODE>
 __global__ void __launch_bounds__(64 * AG_ATTRP_WAVES, 2) k_edge_attr_poly(AttrPolyArgs a) {
   extern __shared__ u32x4 ag_attrp_smem[];
@@ -1471,16 +1114,37 @@ extern "C" int agdiff_edge_scales(const agdiff_params_t* p, const agdiff_topo_t*
 extern "C" int agdiff_edge_scales_split(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
                                         int32_t which, void* stream) {
   if (!p || !topo || !ws || p->num_convs > AGDIFF_MAX_CONVS) return AGDIFF_ERR_ARG;
-  if (which == 0) {        // radius list
-    if (!ws->r_scale || !ws->rad_len || !ws->num_rad) return AGDIFF_ERR_ARG;
-    const int64_t R = topo->max_edges - topo->num_local;
-    return launch_edge_scales(p, ws->num_rad, R, ws->rad_len, nullptr, nullptr, ws->r_scale, ((R + AG_TW - 1) / AG_TW) * AG_TW,
-                              stream);
+  if (which == 0) {        // radius rows by target (+ the pad rows of every target's last tile)
+    if (!ws->r_scale || !ws->rad_len || !ws->rad_src || !ws->rad_cnt) return AGDIFF_ERR_ARG;
+    if (topo->num_nodes <= 0) return AGDIFF_OK;
+    RadScaleArgs a;
+    for (int k = 0; k < p->num_convs; ++k) {
+      a.dw[2 * k] = p->conv[k].dist_seg;
+      a.dw[2 * k + 1] = p->conv[k].dist_seg + 100;
+    }
+    a.rad_cnt = ws->rad_cnt;
+    a.rad_src = ws->rad_src;
+    a.rad_len = ws->rad_len;
+    a.out = ws->r_scale;
+    a.rpad = topo->num_nodes * (int64_t)AGDIFF_RAD_STRIDE;
+    a.n = 2 * p->num_convs;
+    a.cutoff = p->cutoff;
+    a.smooth = p->smooth;
+    k_rad_scales<<<dim3((unsigned)((a.rpad + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(a);
+    AG_CHECK_LAUNCH();
+    return AGDIFF_OK;
   }
-  // local list by in-slot: one evaluation per canonical local edge (a mirror pair has one length)
-  if (!ws->l_scale || !ws->lc_len || !ws->num_local_canon || !topo->lc_ppos || !topo->lc_pmir) return AGDIFF_ERR_ARG;
-  return launch_edge_scales(p, ws->num_local_canon, topo->num_local_canon, ws->lc_len, topo->lc_ppos, topo->lc_pmir,
-                            ws->l_scale, ((topo->num_local_padded + AG_TW - 1) / AG_TW) * AG_TW, stream);
+  // local edges: one evaluation per canonical local edge (a mirror pair has one length), written to both of its positions
+  if (!ws->lc_len || !ws->num_local_canon) return AGDIFF_ERR_ARG;
+  if (which == 1) {        // ... in the padded local list (agdiff_cfconv_local)
+    if (!ws->l_scale || !topo->lc_ppos || !topo->lc_pmir) return AGDIFF_ERR_ARG;
+    return launch_edge_scales(p, ws->num_local_canon, topo->num_local_canon, ws->lc_len, topo->lc_ppos, topo->lc_pmir,
+                              ws->l_scale, ((topo->num_local_padded + AG_TW - 1) / AG_TW) * AG_TW, stream);
+  }
+  // ... in the pair tiles (agdiff_cfconv_node)
+  if (!ws->lt_scale || !topo->lc_tpos || !topo->lc_tmir) return AGDIFF_ERR_ARG;
+  return launch_edge_scales(p, ws->num_local_canon, topo->num_local_canon, ws->lc_len, topo->lc_tpos, topo->lc_tmir,
+                            ws->lt_scale, topo->num_local_tiles * AG_TW, stream);
 }
 
 namespace {
@@ -1534,45 +1198,24 @@ int launch_cfconv_fused(const agdiff_params_t* p, int32_t k, int64_t max_e, cons
   return AGDIFF_OK;
 }
 
-#ifndef AG_RAD_WAVES
-#define AG_RAD_WAVES 12     // ~160 VGPRs (two x groups in flight across tiles): three waves per SIMD
-#endif
-template <int MODE, int NKT>
-int launch_cfconv_radius_t(const RadConvArgs& a, int64_t wgs, void* stream) {
-  const size_t smem = (size_t)AG_CONV_NCH * NKT * 2048;
-  k_cfconv_radius<MODE, NKT, AG_RAD_WAVES, false><<<dim3((unsigned)wgs), dim3(64 * AG_RAD_WAVES), smem, (hipStream_t)stream>>>(a);
-  AG_CHECK_LAUNCH();
-  return AGDIFF_OK;
-}
-#ifndef AG_LOCP_WAVES
-#define AG_LOCP_WAVES 12     // the typed variant needs ~160 VGPRs: at 16 waves (128) it spilled 18 of them (A/B: 0.092 -> 0.079 ms)
-#endif
-template <int MODE>
-int launch_cfconv_local_poly_t(const RadConvArgs& a, int64_t wgs, void* stream) {
-  const size_t smem = (size_t)a.num_slots * AG_CONV_NCH * 2048;
-  static std::atomic<uint64_t> attr_done{0};
-  if (!ag_allow_big_lds(attr_done, (size_t)AGDIFF_POLY_MAX_SLOTS * AG_CONV_NCH * 2048, k_cfconv_radius<MODE, 1, AG_LOCP_WAVES, true>))
-    return AGDIFF_ERR_LAUNCH;
-  k_cfconv_radius<MODE, 1, AG_LOCP_WAVES, true><<<dim3((unsigned)wgs), dim3(64 * AG_LOCP_WAVES), smem, (hipStream_t)stream>>>(a);
-  AG_CHECK_LAUNCH();
-  return AGDIFF_OK;
-}
 }  // namespace
 
 extern "C" int agdiff_cfconv_fused(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k,
                                    void* stream) {
   if (!p || !topo || !ws || k < 0 || k >= p->num_convs) return AGDIFF_ERR_ARG;
+  ag_log_variant(ws, AGDIFF_VAR_CFCONV_FUSED);
   return launch_cfconv_fused(p, k, topo->max_edges, ws->num_edges, ws->in_ptr, ws->e_src, ws->e_dst, ws->e_scale, ws->e_attr,
                              ws->xs, ws->agg, ws->agg_first, stream);
 }
 
-// Local edges by per-type filter polynomials?  (all of: slots built by the host, one k-tile, the per-slot inputs present)
+// Local edges by per-type filter polynomials?  (all of: slots built by the host, the pair-tile inputs present)
 extern "C" int agdiff_local_poly_enabled(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws) {
-  static const bool off = getenv("AGDIFF_LOCAL_POLY_OFF") != nullptr;      // A/B runs
-  return !off && p && topo && ws && p->poly_kt == 1 && p->poly_num_slots > 0 && p->poly_num_slots <= AGDIFF_POLY_MAX_SLOTS &&
-         p->poly_type_slot && topo->lp_type && ws->l_len_p;
+  return p && topo && ws && !p->tune_local_poly_off && p->poly_kt >= 1 && p->poly_kt <= AGDIFF_POLY_MAX_KT &&
+         p->poly_num_slots > 0 && p->poly_num_slots <= AGDIFF_POLY_MAX_SLOTS && p->poly_type_slot && topo->lt_ptr &&
+         topo->lt_src && topo->lt_type && ws->lt_len && ws->lt_scale;
 }
 
+// The local edges through the filter MLPs (no per-type polynomials): k_cfconv_fused over the padded local list
 extern "C" int agdiff_cfconv_local(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k,
                                    void* stream) {
   if (!p || !topo || !ws || k < 0 || k >= p->num_convs) return AGDIFF_ERR_ARG;
@@ -1580,109 +1223,9 @@ extern "C" int agdiff_cfconv_local(const agdiff_params_t* p, const agdiff_topo_t
   if (!topo->lp_ptr || !topo->lp_src || !topo->lp_dst || !ws->l_scale || !ws->l_attr_frag || !ws->agg_loc ||
       !ws->agg_first_loc || !ws->num_local_padded)
     return AGDIFF_ERR_ARG;
-  if (agdiff_local_poly_enabled(p, topo, ws)) {
-    // every local type of this batch has a filter polynomial: the radius kernel's typed variant on the local list
-    const int64_t max_tiles = (topo->num_local_padded + AG_TW - 1) / AG_TW;
-    const int chunk_tiles = agdiff_conv_chunk_tiles(topo->num_local_padded);
-    const int64_t max_chunks = (max_tiles + chunk_tiles - 1) / chunk_tiles;
-    RadConvArgs a;
-    a.poly_pk = p->conv[k].filt_poly_typed_pk;
-    a.n_dev = ws->num_local_padded;
-    a.e_src = topo->lp_src;
-    a.e_dst = topo->lp_dst;
-    a.e_len = ws->l_len_p;
-    const size_t epad = (size_t)max_tiles * AG_TW;
-    a.scale1 = ws->l_scale + (size_t)(2 * k) * epad;
-    a.scale2 = ws->l_scale + (size_t)(2 * k + 1) * epad;
-    a.xs = ws->xs;
-    a.agg = ws->agg_loc;
-    a.agg_first = ws->agg_first_loc;
-    a.max_chunks = max_chunks;
-    a.chunk_tiles = chunk_tiles;
-    a.two_over_rc = 2.0f / p->cutoff;
-    a.e_type = topo->lp_type;
-    a.type_slot = p->poly_type_slot;
-    a.num_slots = p->poly_num_slots;
-    int64_t wgs = (max_chunks + AG_LOCP_WAVES - 1) / AG_LOCP_WAVES;
-    if (wgs > 256) wgs = 256;
-    return p->precision == AG_BF3 ? launch_cfconv_local_poly_t<AG_BF3>(a, wgs, stream)
-                                  : launch_cfconv_local_poly_t<AG_F32>(a, wgs, stream);
-  }
+  ag_log_variant(ws, AGDIFF_VAR_CFCONV_LOCAL_MLP);
   return launch_cfconv_fused(p, k, topo->num_local_padded, ws->num_local_padded, topo->lp_ptr, topo->lp_src, topo->lp_dst,
                              ws->l_scale, ws->l_attr_frag, ws->xs, ws->agg_loc, ws->agg_first_loc, stream);
-}
-
-extern "C" int agdiff_cfconv_merged_ok(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws) {
-  return agdiff_local_poly_enabled(p, topo, ws) && p->poly_num_slots + 1 <= AGDIFF_POLY_MAX_SLOTS && ws->e_scale && ws->e_type;
-}
-
-extern "C" int agdiff_cfconv_merged(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k,
-                                    void* stream) {
-  if (!p || !topo || !ws || k < 0 || k >= p->num_convs) return AGDIFF_ERR_ARG;
-  if (!agdiff_cfconv_merged_ok(p, topo, ws) || !p->conv[k].filt_poly_typed_pk) return AGDIFF_ERR_ARG;
-  const int64_t max_tiles = (topo->max_edges + AG_TW - 1) / AG_TW;
-  const int chunk_tiles = agdiff_conv_chunk_tiles(topo->max_edges);
-  const int64_t max_chunks = (max_tiles + chunk_tiles - 1) / chunk_tiles;
-  if (max_chunks == 0) return AGDIFF_OK;
-  RadConvArgs a;
-  a.poly_pk = p->conv[k].filt_poly_typed_pk;
-  a.n_dev = ws->num_edges;
-  a.e_src = ws->e_src;
-  a.e_dst = ws->e_dst;
-  a.e_len = ws->e_len;
-  const size_t epad = (size_t)max_tiles * AG_TW;
-  a.scale1 = ws->e_scale + (size_t)(2 * k) * epad;
-  a.scale2 = ws->e_scale + (size_t)(2 * k + 1) * epad;
-  a.xs = ws->xs;
-  a.agg = ws->agg;
-  a.agg_first = ws->agg_first;
-  a.max_chunks = max_chunks;
-  a.chunk_tiles = chunk_tiles;
-  a.two_over_rc = 2.0f / p->cutoff;
-  a.e_type = ws->e_type;
-  a.type_slot = p->poly_type_slot;
-  a.num_slots = p->poly_num_slots + 1;          // the radius edges' set is the last one (poly_type_slot[0])
-  int64_t wgs = (max_chunks + AG_LOCP_WAVES - 1) / AG_LOCP_WAVES;
-  if (wgs > 256) wgs = 256;
-  return p->precision == AG_BF3 ? launch_cfconv_local_poly_t<AG_BF3>(a, wgs, stream)
-                                : launch_cfconv_local_poly_t<AG_F32>(a, wgs, stream);
-}
-
-extern "C" int agdiff_cfconv_radius(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k,
-                                    void* stream) {
-  if (!p || !topo || !ws || k < 0 || k >= p->num_convs) return AGDIFF_ERR_ARG;
-  if (p->poly_kt < 1 || p->poly_kt > AGDIFF_POLY_MAX_KT || !p->conv[k].filt_poly_pk) return AGDIFF_ERR_ARG;
-  if (!ws->num_rad || !ws->rad_ptr || !ws->rad_src || !ws->rad_dst || !ws->rad_len || !ws->r_scale) return AGDIFF_ERR_ARG;
-  const int64_t R = topo->max_edges - topo->num_local;
-  const int64_t max_tiles = (R + AG_TW - 1) / AG_TW;
-  const int chunk_tiles = agdiff_conv_chunk_tiles(R);
-  const int64_t max_chunks = (max_tiles + chunk_tiles - 1) / chunk_tiles;
-  if (max_chunks == 0) return AGDIFF_OK;
-  RadConvArgs a;
-  a.poly_pk = p->conv[k].filt_poly_pk;
-  a.n_dev = ws->num_rad;
-  a.e_src = ws->rad_src;
-  a.e_dst = ws->rad_dst;
-  a.e_len = ws->rad_len;
-  {
-    const size_t epad = (size_t)max_tiles * AG_TW;
-    a.scale1 = ws->r_scale + (size_t)(2 * k) * epad;
-    a.scale2 = ws->r_scale + (size_t)(2 * k + 1) * epad;
-  }
-  a.xs = ws->xs;
-  a.agg = ws->agg;
-  a.agg_first = ws->agg_first;
-  a.max_chunks = max_chunks;
-  a.chunk_tiles = chunk_tiles;
-  a.two_over_rc = 2.0f / p->cutoff;
-  a.e_type = nullptr;
-  a.type_slot = nullptr;
-  a.num_slots = 0;
-  int64_t wgs = (max_chunks + AG_RAD_WAVES - 1) / AG_RAD_WAVES;
-  if (wgs > 256) wgs = 256;
-  if (p->precision == AG_BF3)
-    return p->poly_kt == 1 ? launch_cfconv_radius_t<AG_BF3, 1>(a, wgs, stream) : launch_cfconv_radius_t<AG_BF3, 2>(a, wgs, stream);
-  return p->poly_kt == 1 ? launch_cfconv_radius_t<AG_F32, 1>(a, wgs, stream) : launch_cfconv_radius_t<AG_F32, 2>(a, wgs, stream);
 }
 
 extern "C" int agdiff_pair_head_poly(const agdiff_params_t* p, const int32_t* n_edges_dev, int64_t max_tiles,
@@ -1729,9 +1272,9 @@ extern "C" int agdiff_local_edge_rows(const agdiff_params_t* p, const agdiff_top
   if (topo->num_local == 0) return AGDIFF_OK;
   if (!ws->l_attr_rows || !ws->lc_len || !ws->num_local_canon || !topo->lc_type || topo->num_local_canon <= 0) return AGDIFF_ERR_ARG;
   const int64_t ctiles = (topo->num_local_canon + AG_TW - 1) / AG_TW;
-  static const bool off = getenv("AGDIFF_ATTR_POLY_OFF") != nullptr;      // A/B runs
-  const bool poly = !off && p->edge_encoder == 0 && p->poly_kt == 1 && p->poly_num_slots > 0 &&
-                    p->poly_num_slots <= AGDIFF_POLY_MAX_SLOTS && p->attr_poly_typed_pk && p->poly_type_slot && ws->enc_flags;
+  // (all slots' 16-KiB sets sit in LDS: up to AG_ATTRP_MAX_SLOTS local edge types, else the encoder MLP for every tile)
+  const bool poly = !p->tune_attr_poly_off && p->edge_encoder == 0 && p->poly_kt == 1 && p->poly_num_slots > 0 &&
+                    p->poly_num_slots <= AG_ATTRP_MAX_SLOTS && p->attr_poly_typed_pk && p->poly_type_slot && ws->enc_flags;
   if (!poly)
     return agdiff_edge_encoder(p, ws->num_local_canon, ctiles, ws->lc_len, topo->lc_type, nullptr, ws->l_attr_rows, nullptr,
                                nullptr, nullptr, stream);
@@ -1753,13 +1296,14 @@ extern "C" int agdiff_local_edge_rows(const agdiff_params_t* p, const agdiff_top
   if (wgs > 512) wgs = 512;
   const size_t smem = (size_t)p->poly_num_slots * 8 * 2048;
   static std::atomic<uint64_t> attr_done{0};
-  if (!ag_allow_big_lds(attr_done, (size_t)AGDIFF_POLY_MAX_SLOTS * 8 * 2048, k_edge_attr_poly<AG_BF3>, k_edge_attr_poly<AG_F32>))
+  if (!ag_allow_big_lds(attr_done, (size_t)AG_ATTRP_MAX_SLOTS * 8 * 2048, k_edge_attr_poly<AG_BF3>, k_edge_attr_poly<AG_F32>))
     return AGDIFF_ERR_LAUNCH;
   if (p->precision == AG_BF3)
     k_edge_attr_poly<AG_BF3><<<dim3((unsigned)wgs), dim3(64 * AG_ATTRP_WAVES), smem, st>>>(a);
   else
     k_edge_attr_poly<AG_F32><<<dim3((unsigned)wgs), dim3(64 * AG_ATTRP_WAVES), smem, st>>>(a);
   AG_CHECK_LAUNCH();
+  ag_log_variant(ws, AGDIFF_VAR_ATTR_POLY);
   // the flagged tiles (if any) through the MLP: the launch returns before staging its weights when the count is 0
   g_enc_tile_flags = ws->enc_flags;
   const int rc = agdiff_edge_encoder(p, ws->num_local_canon, ctiles, ws->lc_len, topo->lc_type, nullptr, ws->l_attr_rows,

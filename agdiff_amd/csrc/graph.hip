@@ -39,11 +39,9 @@ struct GraphArgs {
   int32_t* c_dst;
   int32_t* c_pos;
   int32_t* c_mir;
-  // radius edges (type 0) as a destination-sorted list of their own (optional: rad_ptr may be null)
-  int32_t* num_rad;
-  int32_t* rad_ptr;
+  // radius edges (type 0) by target, AGDIFF_RAD_STRIDE rows per target (optional: rad_cnt may be null)
+  int32_t* rad_cnt;
   int32_t* rad_src;
-  int32_t* rad_dst;
   float* rad_len;
   // canon_radius_only != 0: the canonical list holds radius edges only (the denoising loop: nothing but the global head
   // walks it then)
@@ -231,16 +229,10 @@ __global__ void __launch_bounds__(AG_GRAPH_THREADS) k_graph(GraphArgs a) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     a.in_ptr[g0 + i] = base + (i ? sin[i - 1] : 0);
     a.out_ptr[g0 + i] = base + (i ? sout[i - 1] : 0);
-    // every edge of target i is either local (static list) or radius-only: the radius list's offsets are the difference
-    if (a.rad_ptr) a.rad_ptr[g0 + i] = base + (i ? sin[i - 1] : 0) - a.loc_in_ptr[g0 + i];
   }
   if (g == a.num_graphs - 1 && threadIdx.x == 0) {
     a.in_ptr[g0 + n] = base + (n ? sin[n - 1] : 0);
     a.out_ptr[g0 + n] = base + (n ? sout[n - 1] : 0);
-    if (a.rad_ptr) {
-      a.rad_ptr[g0 + n] = base + (n ? sin[n - 1] : 0) - a.loc_in_ptr[g0 + n];
-      *a.num_rad = a.rad_ptr[g0 + n];
-    }
   }
   // pass 2: emit the lists, one wave per target, contiguous stores
   for (int i = wave; i < n; i += nwaves) {
@@ -248,7 +240,7 @@ __global__ void __launch_bounds__(AG_GRAPH_THREADS) k_graph(GraphArgs a) {
     int p0 = base + (i ? sin[i - 1] : 0);
     int cp0 = a.graph_canon_ptr[g] + (i ? scan_c[i - 1] : 0);
     int lk = a.loc_in_ptr[g0 + i];
-    int rp0 = p0 - lk;
+    int rp0 = (g0 + i) * AGDIFF_RAD_STRIDE;        // the target's own rows of the radius list (at most AGDIFF_RADIUS_CAP used)
     for (int c = 0; 64 * c < n; ++c) {
       const int j = 64 * c + lane;
       const int jj = (j < n) ? j : 0;
@@ -279,10 +271,9 @@ __global__ void __launch_bounds__(AG_GRAPH_THREADS) k_graph(GraphArgs a) {
         a.e_dst[p] = g0 + i;
         a.e_type[p] = ty;
         a.e_len[p] = len;
-        if (a.rad_ptr && eid < 0) {
+        if (a.rad_cnt && eid < 0) {
           const int rp = rp0 + __popcll(rmask & lt);
           a.rad_src[rp] = g0 + j;
-          a.rad_dst[rp] = g0 + i;
           a.rad_len[rp] = len;
         }
         if (canon) {
@@ -300,6 +291,7 @@ __global__ void __launch_bounds__(AG_GRAPH_THREADS) k_graph(GraphArgs a) {
       lk += __popcll(lmask);
       rp0 += __popcll(rmask);
     }
+    if (a.rad_cnt && lane == 0) a.rad_cnt[g0 + i] = rp0 - (g0 + i) * AGDIFF_RAD_STRIDE;
   }
   // pass 3: ref2dst, one thread per source walking its column (targets ascending = the (src, dst) order)
   for (int j = threadIdx.x; j < n; j += blockDim.x) {
@@ -360,7 +352,8 @@ __global__ void k_local_lengths(const int32_t* __restrict__ src, const int32_t* 
                                 const int32_t* __restrict__ cpos, const int32_t* __restrict__ cmir,
                                 const float* __restrict__ pos, float* __restrict__ len, float* __restrict__ clen, int Lc,
                                 const int32_t* __restrict__ inpos, const int32_t* __restrict__ inmir,
-                                float* __restrict__ len_in) {
+                                float* __restrict__ len_in, const int32_t* __restrict__ tpos,
+                                const int32_t* __restrict__ tmir, float* __restrict__ len_t) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= Lc) return;
   int s = src[c], d = dst[c];
@@ -371,6 +364,10 @@ __global__ void k_local_lengths(const int32_t* __restrict__ src, const int32_t* 
   if (len_in) {          // the same by padded-list position (agdiff_topo_t.lp_*)
     len_in[inpos[c]] = v;
     if (inmir[c] >= 0) len_in[inmir[c]] = v;
+  }
+  if (len_t) {           // ... and by pair-tile row (agdiff_topo_t.lt_*)
+    len_t[tpos[c]] = v;
+    if (tmir[c] >= 0) len_t[tmir[c]] = v;
   }
 }
 
@@ -421,11 +418,9 @@ extern "C" int agdiff_graph_build_ex(const agdiff_topo_t* topo, const agdiff_ws_
   a.c_dst = ws->c_dst;
   a.c_pos = ws->c_pos;
   a.c_mir = ws->c_mir;
-  const bool rad = ws->num_rad && ws->rad_ptr && ws->rad_src && ws->rad_dst && ws->rad_len;
-  a.num_rad = ws->num_rad;
-  a.rad_ptr = rad ? ws->rad_ptr : nullptr;
+  const bool rad = ws->rad_cnt && ws->rad_src && ws->rad_len;
+  a.rad_cnt = rad ? ws->rad_cnt : nullptr;
   a.rad_src = ws->rad_src;
-  a.rad_dst = ws->rad_dst;
   a.rad_len = ws->rad_len;
   if (canon_radius_only && !rad) return AGDIFF_ERR_ARG;
   a.canon_radius_only = canon_radius_only ? 1 : 0;
@@ -463,9 +458,11 @@ extern "C" int agdiff_local_lengths(const agdiff_topo_t* topo, const agdiff_ws_t
   if (!topo->lc_src || !topo->lc_dst || !topo->lc_pos || !topo->lc_mir || topo->num_local_canon <= 0) return AGDIFF_ERR_ARG;
   const int Lc = (int)topo->num_local_canon;
   const bool by_slot = ws->l_len_p && topo->lc_ppos && topo->lc_pmir;
+  const bool by_tile = ws->lt_len && topo->lc_tpos && topo->lc_tmir;
   k_local_lengths<<<(Lc + 255) / 256, 256, 0, (hipStream_t)stream>>>(topo->lc_src, topo->lc_dst, topo->lc_pos, topo->lc_mir,
                                                                      pos, ws->l_len, ws->lc_len, Lc, topo->lc_ppos,
-                                                                     topo->lc_pmir, by_slot ? ws->l_len_p : nullptr);
+                                                                     topo->lc_pmir, by_slot ? ws->l_len_p : nullptr,
+                                                                     topo->lc_tpos, topo->lc_tmir, by_tile ? ws->lt_len : nullptr);
   AG_CHECK_LAUNCH();
   return AGDIFF_OK;
 }

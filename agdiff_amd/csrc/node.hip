@@ -39,8 +39,15 @@ struct AggSrc {
 };
 __device__ __forceinline__ AggSrc ag_agg_src(const int32_t* in_ptr, const float* agg, const float* agg_first, int chunk_e,
                                              int64_t nd) {
-  const int lo = in_ptr[nd], hi = in_ptr[nd + 1];
   AggSrc r;
+  if (!in_ptr) {            // agdiff_cfconv_node: one complete row per node, no chunks
+    r.has = true;
+    r.c_lo = r.c_hi = 0;
+    r.row = agg + (size_t)nd * 192;
+    r.first = agg_first;
+    return r;
+  }
+  const int lo = in_ptr[nd], hi = in_ptr[nd + 1];
   r.has = hi > lo;
   r.c_lo = lo / chunk_e;
   r.c_hi = r.has ? (hi - 1) / chunk_e : r.c_lo;
@@ -899,23 +906,14 @@ __global__ void __launch_bounds__(256) k_diffusion_loss(LossArgs a) {
 }  // namespace
 
 // Waves (= 16-node tiles) per workgroup for the LDS-sharing node kernels: about one workgroup per CU.
-// Below AG_NODE_LDSW_MIN_TILES the 4-wave streaming variants are faster (measured crossover between 275 and
-// 2,928 tiles: 24 vs 43 us and 75 vs 56 us per node stage).
-// AGDIFF_NODE_LDSW_MIN_TILES overrides the threshold (tests run both variants on the same small batch).
-static int64_t ag_node_ldsw_min_tiles() {
-  const char* e = getenv("AGDIFF_NODE_LDSW_MIN_TILES");
-  return e ? atoll(e) : 1536;
-}
-// Up to this many node tiles the stage runs with four waves per tile (k_schnet_node_stage_split); AGDIFF_NODE_SPLIT_MAX_TILES
-// overrides (tests run every variant on the same batch; 0 switches the split variant off).
-static int64_t ag_node_split_max_tiles() {
-  const char* e = getenv("AGDIFF_NODE_SPLIT_MAX_TILES");
-  return e ? atoll(e) : 320;      // measured (1 molecule x 25 / 100 / 200 conformers): 70 vs 130, 118 vs 138, 186 vs 150 us per 7 stages
-}
-static int ag_node_waves_per_wg(int64_t tiles) {
-  if (tiles < ag_node_ldsw_min_tiles()) return 4;
-  static const int forced = getenv("AGDIFF_NODE_WAVES") ? atoi(getenv("AGDIFF_NODE_WAVES")) : 0;      // experiments
-  if (forced >= 4 && forced <= 16) return forced;
+// Below agdiff_params_t.tune_node_ldsw_min_tiles the 4-wave streaming variants are faster (measured crossover between 275
+// and 2,928 tiles: 24 vs 43 us and 75 vs 56 us per node stage).
+static int64_t ag_node_ldsw_min_tiles(const agdiff_params_t* p) { return ag_tune(p->tune_node_ldsw_min_tiles, 1536); }
+// Up to this many node tiles the stage runs with four waves per tile (k_schnet_node_stage_split); measured (1 molecule x
+// 25 / 100 / 200 conformers): 70 vs 130, 118 vs 138, 186 vs 150 us per 7 stages
+static int64_t ag_node_split_max_tiles(const agdiff_params_t* p) { return ag_tune(p->tune_node_split_max_tiles, 320); }
+static int ag_node_waves_per_wg(const agdiff_params_t* p, int64_t tiles) {
+  if (tiles < ag_node_ldsw_min_tiles(p)) return 4;
   int64_t w = (tiles + 255) / 256;
   if (w > 16) w = 16;
   return (int)w;
@@ -929,7 +927,7 @@ extern "C" int agdiff_schnet_node_stage(const agdiff_params_t* p, const agdiff_t
 extern "C" int agdiff_schnet_node_stage_split(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
                                               int32_t k, int32_t split, void* stream) {
   if (!p || !topo || !ws || k < 0 || k > p->num_convs || p->num_convs > AGDIFF_MAX_CONVS) return AGDIFF_ERR_ARG;
-  if ((split & 1) && (!ws->rad_ptr || !ws->agg_loc || !ws->agg_first_loc || !topo->lp_ptr)) return AGDIFF_ERR_ARG;
+  if ((split & 8) && (!(split & 1) || !ws->agg_loc || !ws->agg_first_loc || !topo->lp_ptr)) return AGDIFF_ERR_ARG;
   if (topo->num_nodes <= 0) return AGDIFF_OK;
   NodeStageArgs a;
   a.finish = k > 0;
@@ -957,10 +955,9 @@ extern "C" int agdiff_schnet_node_stage_split(const agdiff_params_t* p, const ag
     a.xs = ws->xs0;
   }
   if ((split & 2) && k == 1 && ws->h0) a.h_in = ws->h0;
-  if (split & 1) {     // block k-1 ran as agdiff_cfconv_radius (ws->agg) + agdiff_cfconv_local (ws->agg_loc)
-    a.in_ptr = ws->rad_ptr;
-    a.chunk_edges = AG_TW * agdiff_conv_chunk_tiles(topo->max_edges - topo->num_local);
-    if (topo->num_local > 0) {
+  if (split & 1) {     // block k-1 ran as agdiff_cfconv_node: ws->agg holds one complete row per node ...
+    a.in_ptr = nullptr;
+    if ((split & 8) && topo->num_local > 0) {     // ... plus agdiff_cfconv_local's ws->agg_loc (local edges through the filter MLPs)
       a.in_ptr2 = topo->lp_ptr;
       a.agg2 = ws->agg_loc;
       a.agg_first2 = ws->agg_first_loc;
@@ -969,7 +966,8 @@ extern "C" int agdiff_schnet_node_stage_split(const agdiff_params_t* p, const ag
   }
   const int64_t tiles = (a.n + AG_TW - 1) / AG_TW;
   hipStream_t st = (hipStream_t)stream;
-  if (tiles <= ag_node_split_max_tiles()) {       // small batch: four waves per tile (k_schnet_node_stage_split)
+  if (tiles <= ag_node_split_max_tiles(p)) {       // small batch: four waves per tile (k_schnet_node_stage_split)
+    ag_log_variant(ws, AGDIFF_VAR_NODE_SPLIT4);
     const dim3 grid((unsigned)tiles), block(256);
 #define AG_LAUNCH_SPLIT(M)                                                                  \
     do {                                                                                    \
@@ -983,8 +981,9 @@ extern "C" int agdiff_schnet_node_stage_split(const agdiff_params_t* p, const ag
     AG_CHECK_LAUNCH();
     return AGDIFF_OK;
   }
-  const int waves = ag_node_waves_per_wg(tiles);
-  const bool ldsw = tiles >= ag_node_ldsw_min_tiles();
+  const int waves = ag_node_waves_per_wg(p, tiles);
+  const bool ldsw = tiles >= ag_node_ldsw_min_tiles(p);
+  ag_log_variant(ws, ldsw ? AGDIFF_VAR_NODE_LDSW : AGDIFF_VAR_NODE_STREAM);
   const size_t smem = ldsw ? (size_t)AG_NODE_LDS_BLOCKS * 2048 : 0;
   static std::atomic<uint64_t> attr_done{0};
   if (!ag_allow_big_lds(attr_done, (size_t)AG_NODE_LDS_BLOCKS * 2048, k_schnet_node_stage<AG_BF3, true>,
@@ -1009,8 +1008,9 @@ extern "C" int agdiff_gin_encoder(const agdiff_params_t* p, const agdiff_topo_t*
     return AGDIFF_ERR_ARG;
   if (topo->num_nodes <= 0) return AGDIFF_OK;
   const int64_t tiles = (topo->num_nodes + AG_TW - 1) / AG_TW;
-  const int waves = ag_node_waves_per_wg(tiles);
-  const bool ldsw = tiles >= ag_node_ldsw_min_tiles();
+  const int waves = ag_node_waves_per_wg(p, tiles);
+  const bool ldsw = tiles >= ag_node_ldsw_min_tiles(p);
+  if (ldsw) ag_log_variant(ws, AGDIFF_VAR_GIN_LDSW);
   const size_t smem = ldsw ? (size_t)64 * 2048 : 0;
   static std::atomic<uint64_t> attr_done{0};
   if (!ag_allow_big_lds(attr_done, (size_t)64 * 2048, k_gin_layer<AG_BF3, true>, k_gin_layer<AG_F32, true>))

@@ -214,6 +214,9 @@ class DualEncoderEpsNetwork(nn.Module):
         # "auto": radius edges take their CFConv filters / head inputs from d-polynomials when packing.py accepts the
         # fit for these weights (<= 1e-6 of the networks they replace), "off": every edge through the MLPs
         self.radius_poly = getattr(config, "radius_poly", None) or os.environ.get("AGDIFF_RADIUS_POLY", "auto")
+        # kernel-variant thresholds (PackedParams.set_tuning; include/agdiff_hip.h: agdiff_params_t.tune_*), e.g.
+        # model.tuning["node_ldsw_min_tiles"] = 1 -- tests reach every variant on small fixtures this way
+        self.tuning = {}
         self._packed = None
         self._packed_key = None
         self._batch_cache = None
@@ -240,6 +243,7 @@ class DualEncoderEpsNetwork(nn.Module):
             sd = {k: v for k, v in self.state_dict().items()}
             self._packed = PackedParams(sd, self.config, self._device(), self.precision, self.radius_poly)
             self._packed_key = key
+        self._packed.set_tuning(**{k: self.tuning.get(k, 0) for k in PackedParams.TUNING})
         return self._packed
 
     def _renorm_embedding(self, atom_type):

@@ -324,7 +324,8 @@ class PackedParams:
         # local edge types with filter polynomials (ensure_local_types): type -> slot, grown as batches bring new types
         self._sd, self._cfg, self._mode = sd, cfg, PRECISIONS.get(precision, 0)
         self.local_slots, self._typed_mats = {}, {}
-        self._typed_ok = self.poly_kt == 1 and radius_poly != "radius"
+        self._typed_ok = self.poly_kt >= 1 and radius_poly != "radius"
+        self.poly_refused_type = None
         self.typed_flat = self.slot_table = None
         if precision not in PRECISIONS:
             raise ValueError("precision must be one of %s" % (list(PRECISIONS),))
@@ -509,9 +510,11 @@ class PackedParams:
 
     def ensure_local_types(self, types):
         """Give every local edge type of a batch (BatchTopology.local_types) a filter-polynomial slot, so that
-        agdiff_cfconv_local needs no edge_attr either (include/agdiff_hip.h: poly_num_slots).  A type whose fit misses
-        POLY_TOL, or more than AGDIFF_POLY_MAX_SLOTS types in all, turns the slots off for good: the local edges then go
-        through the filter MLPs (the radius edges keep their polynomials)."""
+        agdiff_cfconv_node needs no edge_attr for the local edges either (include/agdiff_hip.h: poly_num_slots).  Slots are
+        kept in order of first appearance (the first ones that fit stay LDS-resident in the kernel, later ones are read
+        from L2), fitted with the radius edges' number of terms (poly_kt).  A type whose fit misses POLY_TOL, or more than
+        AGDIFF_POLY_MAX_SLOTS types in all, switches the local polynomials off for THIS model (poly_num_slots = 0): the
+        local edges then go through the filter MLPs (agdiff_cfconv_local); the radius edges keep their polynomials."""
         import torch
         if not self._typed_ok:
             return False
@@ -520,30 +523,30 @@ class PackedParams:
             return True
         prm = self.struct
         max_slots = _lib.DEFINES["AGDIFF_POLY_MAX_SLOTS"]
+        kt = self.poly_kt
         for t in new:
-            mats, err = fit_type(self._sd, self._cfg, t, 1, False)
+            mats, err = fit_type(self._sd, self._cfg, t, kt, False)
             self.poly_errors["type%d" % t] = err
             if err > POLY_TOL or len(self.local_slots) >= max_slots:
                 self._typed_ok = False
+                self.poly_refused_type = t
                 prm.poly_num_slots = 0
                 return False
             self.local_slots[t] = len(self.local_slots)
             self._typed_mats[t] = mats
         by_slot = sorted(self.local_slots, key=self.local_slots.get)
         nc = self._cfg.num_convs
-        # per conv: the local types' sets by slot, then the radius edges' set once more as slot S (type 0): the one-list
-        # variant of the pass for small batches (agdiff_cfconv_merged) takes every edge's filter from this buffer
-        per_conv = [np.concatenate([pack_blocks(self._typed_mats[t]["conv%d.filt_poly_pk" % k], mode=self._mode) for t in by_slot] +
-                                   [pack_blocks(self._poly["conv%d.filt_poly_pk" % k], mode=self._mode)])
+        per_conv = [np.concatenate([pack_blocks(self._typed_mats[t]["conv%d.filt_poly_pk" % k], mode=self._mode) for t in by_slot])
                     for k in range(nc)]
-        attr_sets = np.concatenate([pack_blocks(self._typed_mats[t]["edge_attr_poly_pk"], mode=self._mode) for t in by_slot])
-        self.typed_attr_flat = torch.from_numpy(attr_sets).to(self.device)
-        prm.attr_poly_typed_pk = ctypes.c_void_p(self.typed_attr_flat.data_ptr())
+        # edge_attr itself per type (agdiff_local_edge_rows): pk [8][kt] -- the kernel takes one k-tile, so only with kt == 1
+        if kt == 1:
+            attr_sets = np.concatenate([pack_blocks(self._typed_mats[t]["edge_attr_poly_pk"], mode=self._mode) for t in by_slot])
+            self.typed_attr_flat = torch.from_numpy(attr_sets).to(self.device)
+            prm.attr_poly_typed_pk = ctypes.c_void_p(self.typed_attr_flat.data_ptr())
         self.typed_flat = torch.from_numpy(np.concatenate(per_conv)).to(self.device)     # (the old buffer may still be in
         table = np.full(100, -1, dtype=np.int32)                                         #  use by enqueued launches: torch's
         for t, sl in self.local_slots.items():                                           #  allocator keeps it alive in stream order)
             table[t] = sl
-        table[0] = len(by_slot)                                                          # type 0 = radius edges: the extra set
         self.slot_table = torch.from_numpy(table).to(self.device)
         stride = per_conv[0].size
         for k in range(nc):
@@ -551,6 +554,16 @@ class PackedParams:
         prm.poly_type_slot = ctypes.c_void_p(self.slot_table.data_ptr())
         prm.poly_num_slots = len(by_slot)
         return True
+
+    TUNING = ("share_rows_min_nodes", "node_ldsw_min_tiles", "node_split_max_tiles", "serial_branches", "local_poly_off",
+              "attr_poly_off", "poly_lds_sets")
+
+    def set_tuning(self, **kw):
+        """Kernel-variant thresholds (include/agdiff_hip.h: agdiff_params_t.tune_*; 0 = library default)."""
+        for k, v in kw.items():
+            if k not in self.TUNING:
+                raise KeyError("unknown tuning field %r (known: %s)" % (k, ", ".join(self.TUNING)))
+            setattr(self.struct, "tune_" + k, int(v))
 
     def view(self, name):
         o = self.offsets[name]

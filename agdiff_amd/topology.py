@@ -132,6 +132,40 @@ class BatchTopology:
         self.lp_row = i32(np.where(real, loc_row[eid], -1) if L else np.zeros(Lp))
         self.lc_ppos = i32(ppos[lc_pos])
         self.lc_pmir = i32(np.where(lc_mir >= 0, ppos[np.maximum(lc_mir, 0)], -1))
+        # ... and as PAIR TILES for agdiff_cfconv_node (agdiff_topo_t.lt_*): targets two at a time, tile t of pair p holds
+        # in-edges [8 t, 8 t + 8) of target 2 p in rows 0..7 and of target 2 p + 1 in rows 8..15
+        P2 = (N + 1) // 2
+        deg2 = np.zeros(2 * P2, dtype=np.int64)
+        deg2[:N] = locdeg
+        nt_pair = (np.maximum(deg2[0::2], deg2[1::2]) + 7) // 8
+        lt_ptr = np.concatenate([[0], np.cumsum(nt_pair)])
+        T = int(lt_ptr[-1])
+        trow = np.arange(16 * T)
+        tile_of = trow // 16
+        pair_of = np.repeat(np.arange(P2), nt_pair)[tile_of] if T else np.zeros(0, dtype=np.int64)
+        half = (trow % 16) // 8
+        tgt_t = 2 * pair_of + half                                          # (may be N for the odd last pair's second half)
+        k_t = (tile_of - lt_ptr[pair_of]) * 8 + trow % 8                    # index inside the target's in-list
+        tgt_c = np.minimum(tgt_t, N - 1)
+        real_t = (tgt_t < N) & (k_t < locdeg[tgt_c])
+        slot_t = np.minimum(in_ptr[tgt_c] + k_t, max(L - 1, 0))
+        eid_t = in_order[slot_t] if L else np.zeros(16 * T, dtype=np.int64)
+        # pad rows: src = the target itself (a valid row of xs; the odd last pair's missing target: the last node), and the
+        # type of the tile's first real row (the kernel loops over the types present in a tile: pads must not add one)
+        first_real = np.full(max(T, 1), max(16 * T - 1, 0), dtype=np.int64)
+        if T:
+            idx = np.nonzero(real_t)[0]
+            np.minimum.at(first_real, tile_of[idx], idx)                     # smallest real row of every tile
+        pad_type = typ[eid_t[first_real[tile_of]]] if (L and T) else np.zeros(16 * T, dtype=np.int64)
+        tpos = np.empty(L, dtype=np.int64)
+        tpos[eid_t[real_t]] = np.nonzero(real_t)[0]
+        self.T = T
+        self.lt_ptr = i32(lt_ptr)
+        self.lt_src = i32(np.where(real_t, src[eid_t], tgt_c) if L else np.zeros(16 * T))
+        self.lt_type = i32(np.where(real_t, typ[eid_t], pad_type) if L else np.zeros(16 * T))
+        self.lt_real = real_t
+        self.lc_tpos = i32(tpos[lc_pos])
+        self.lc_tmir = i32(np.where(lc_mir >= 0, tpos[np.maximum(lc_mir, 0)], -1))
         self.local_types = np.unique(typ)                 # PackedParams.ensure_local_types (per-type filter polynomials)
         # int64 copies of the local edges for the API results (forward() returns int64 indices)
         self.loc_index64 = torch.from_numpy(np.stack([src, dst])).to(device)
@@ -144,9 +178,11 @@ class BatchTopology:
         t.max_edges, t.max_atoms_per_graph, t.max_in_degree = self.max_edges, self.max_atoms, self.max_in_degree
         t.num_local_canon = self.Lc
         t.num_local_padded = self.Lp
+        t.num_local_tiles = self.T
         for f in ("graph_ptr", "atom_type", "loc_src", "loc_dst", "loc_type", "loc_out_ptr", "loc_in_ptr", "loc_in_eid",
                   "lc_src", "lc_dst", "lc_type", "lc_pos", "lc_mir", "loc_row", "loc_in_src",
-                  "loc_in_row", "lp_ptr", "lp_src", "lp_dst", "lp_type", "lp_row", "lc_ppos", "lc_pmir"):
+                  "loc_in_row", "lp_ptr", "lp_src", "lp_dst", "lp_type", "lp_row", "lc_ppos", "lc_pmir",
+                  "lt_ptr", "lt_src", "lt_type", "lc_tpos", "lc_tmir"):
             setattr(t, f, _lib.ptr(getattr(self, f)))
         self.struct = t
 
@@ -188,23 +224,21 @@ class Workspace:
         self.num_local_canon = torch.tensor([topo.Lc], dtype=torch.int32, device=dev)
         self.l_attr_rows = f32(ltiles * TW * 128)
         self.h, self.xs, self.agg = f32(N * 128), f32(N * 192), f32(N * 192)
-        # (the split CFConv's radius pass cuts its own, shorter list into chunks of its own length: size for both)
-        rtiles_ = (max(E - L, 0) + TW - 1) // TW
-        rchunk = _lib.load().agdiff_conv_chunk_tiles(max(E - L, 0))
-        self.agg_first = f32(max(chunks, (rtiles_ + rchunk - 1) // rchunk) * 192)
+        self.agg_first = f32(chunks * 192)
         self.hl, self.hl2 = f32(N * 128), f32(N * 128)
         self.nan_flag = i32(1 + G)
         self.scratch = f32(N * 3)
-        # split CFConv (radius edges by polynomial filters + local edges through the filter MLPs)
-        R = max(E - L, 0)
-        rtiles = (R + TW - 1) // TW
+        # CFConv by filter polynomials: radius rows by target (agdiff_ws_t.rad_*), local pair tiles (lt_*), padded local list
+        RS = _lib.DEFINES["AGDIFF_RAD_STRIDE"]
         Lp = topo.Lp
         ptiles = (Lp + TW - 1) // TW
         lchunk = _lib.load().agdiff_conv_chunk_tiles(Lp)
-        self.num_rad = i32(1)
-        self.rad_ptr = i32(N + 1)
-        self.rad_src, self.rad_dst, self.rad_len = i32(rtiles * TW), i32(rtiles * TW), f32(rtiles * TW)
-        self.r_scale = f32(2 * _lib.DEFINES["AGDIFF_MAX_CONVS"] * rtiles * TW)
+        self.rad_cnt = i32(N)
+        self.rad_src, self.rad_len = i32(N * RS), f32(N * RS)
+        self.r_scale = f32(2 * _lib.DEFINES["AGDIFF_MAX_CONVS"] * N * RS)
+        self.lt_len = f32(TW * topo.T)
+        self.lt_scale = f32(2 * _lib.DEFINES["AGDIFF_MAX_CONVS"] * TW * topo.T)
+        self.variant_log = torch.zeros(1, dtype=torch.int64)          # host word (include/agdiff_hip.h: AGDIFF_VAR_*)
         self.num_local_padded = torch.tensor([Lp], dtype=torch.int32, device=dev)
         self.l_scale = f32(2 * _lib.DEFINES["AGDIFF_MAX_CONVS"] * ptiles * TW)
         self.l_attr_frag = f32(ptiles * TW * 128)

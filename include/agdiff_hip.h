@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 27
+#define AGDIFF_ABI_VERSION 28
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -34,7 +34,9 @@ extern "C" {
 #define AGDIFF_MAX_CHUNK_TILES 8   /* most tiles one wave walks per chunk in the fused CFConv kernel (128 edges) */
 #define AGDIFF_RMSD_MAX_ATOMS 256  /* most (heavy) atoms per conformer in agdiff_rmsd_matrix */
 #define AGDIFF_POLY_MAX_KT 2       /* most 32-term k-tiles of the radius-edge filter polynomial (degree 63) */
-#define AGDIFF_POLY_MAX_SLOTS 6    /* most local edge types with filter polynomials (6 x 24 KiB of coefficients in LDS) */
+#define AGDIFF_POLY_MAX_SLOTS 16   /* most local edge types with filter polynomials; the first sets that fit stay in LDS next to the
+                                      radius edges' set (5 at poly_kt 1), the others are read from L2 by the tiles that meet them */
+#define AGDIFF_RAD_STRIDE 48       /* rows reserved per target in the radius-edge list (three 16-row tiles >= AGDIFF_RADIUS_CAP) */
 
 enum agdiff_status {
   AGDIFF_OK = 0,
@@ -83,10 +85,9 @@ typedef struct agdiff_conv_params {
   const float* filt_poly_pk; /* pk [12][poly_kt] or null: the whole filter network of a RADIUS edge (type 0, d < cutoff) as a
                                 polynomial in d -- see agdiff_params_t.poly_kt.  Rows 0..127 conv1, 128..191 conv2; nn.2.bias
                                 is the constant term */
-  const float* filt_poly_typed_pk; /* [poly_num_slots + 1] x pk [12][poly_kt] or null: the same for the LOCAL edge types that have
+  const float* filt_poly_typed_pk; /* [poly_num_slots] x pk [12][poly_kt] or null: the same for the LOCAL edge types that have
                                 a slot (agdiff_params_t.poly_type_slot), d in [0, cutoff] (beyond it the CFConv's cutoff factor
-                                C(d) is exactly 0, schnet.py:140-146); set poly_num_slots repeats the radius edges' filt_poly_pk
-                                (poly_type_slot[0] = poly_num_slots) for agdiff_cfconv_merged */
+                                C(d) is exactly 0, schnet.py:140-146) */
   float gate2_b;
   float act_beta;            /* InteractionBlock.act.beta */
 } agdiff_conv_params_t;
@@ -147,8 +148,7 @@ typedef struct agdiff_params {
   int32_t edge_encoder;      /* config.edge_encoder: 0 'mlp' (edge.py:45-103), 1 'gaussian' (edge.py:17-42) */
   float ge_coeff;            /* -0.5 / (offset[1] - offset[0])^2 (schnet.py:22) */
   int32_t poly_num_slots;    /* 0, or 1..AGDIFF_POLY_MAX_SLOTS: local edge types whose CFConv filters are d-polynomials too
-                                (every type the host has met in a batch so far; only with poly_kt == 1, so that all slots fit
-                                in LDS); 0 sends the local edges through the filter MLPs */
+                                (every type the host has met in a batch so far); 0 sends the local edges through the filter MLPs */
   int32_t pad1;
   int32_t poly_kt;           /* 0: off.  1..AGDIFF_POLY_MAX_KT: radius edges (type 0: no bond embedding; d < cutoff by
                                 construction) take their CFConv filters and the edge_attr half of the global head's first layer
@@ -159,7 +159,34 @@ typedef struct agdiff_params {
                                   phi[8 g + j](x) = T_{8 g}(x) T_j(x),  x = 2 d / cutoff - 1,  g < 4 poly_kt,  j < 8
                                 (T_n = Chebyshev polynomials; spans all polynomials of degree < K); operand element j of lane
                                 quarter q in k-tile t is phi[8 (4 t + q) + j], and the packed blocks are ordered to match. */
+  /* Kernel-variant thresholds: batch-size crossovers measured on MI355X.  0 selects the library default in
+   * brackets; tests set them to reach every variant on small fixtures, agdiff_ws_t.variant_log reports what ran. */
+  int64_t tune_share_rows_min_nodes;  /* [8192] batches with at least this many atoms take the local edges' edge_attr rows from
+                                         the global encoder pass (ws->e_loc) instead of a pass over the canonical local list */
+  int64_t tune_node_ldsw_min_tiles;   /* [1536] node stage / GIN layer: from this many 16-node tiles on, workgroups share the
+                                         weights through LDS; below, every wave streams them from L2 */
+  int64_t tune_node_split_max_tiles;  /* [320] node stage: up to this many tiles four waves share one tile (-1: never) */
+  int32_t tune_serial_branches;       /* [0] 1: local and global branch on the caller's stream, no side stream */
+  int32_t tune_local_poly_off;        /* [0] 1: local edges through the filter MLPs even when every type has a polynomial */
+  int32_t tune_attr_poly_off;         /* [0] 1: agdiff_local_edge_rows evaluates the encoder MLP for every tile */
+  int32_t tune_poly_lds_sets;         /* [0 = as many as fit in 160 KiB] agdiff_cfconv_node: at most this many coefficient sets in
+                                         LDS, the radius edges' one included (1: every local type's set is read from L2) */
 } agdiff_params_t;
+
+/* bits of agdiff_ws_t.variant_log: which kernel variants the launchers chose since the host last cleared it */
+#define AGDIFF_VAR_CFCONV_NODE 1        /* agdiff_cfconv_node: radius rows (+ local pair tiles) by filter polynomials */
+#define AGDIFF_VAR_CFCONV_NODE_LOCAL 2  /* ... its local pair tiles ran (every local type has a polynomial) */
+#define AGDIFF_VAR_CFCONV_LOCAL_MLP 4   /* agdiff_cfconv_local: local edges through the filter MLPs */
+#define AGDIFF_VAR_CFCONV_FUSED 8       /* agdiff_cfconv_fused: every edge through the filter MLPs */
+#define AGDIFF_VAR_NODE_LDSW 16         /* node stage with workgroup-shared LDS weights */
+#define AGDIFF_VAR_NODE_STREAM 32       /* node stage, one wave per tile streaming from L2 */
+#define AGDIFF_VAR_NODE_SPLIT4 64       /* node stage, four waves per tile */
+#define AGDIFF_VAR_GIN_LDSW 128         /* GIN layer with workgroup-shared LDS weights */
+#define AGDIFF_VAR_SHARE_ROWS 256       /* local edge_attr rows written by the global encoder pass */
+#define AGDIFF_VAR_ATTR_POLY 512        /* local edge_attr rows from per-type polynomials (agdiff_local_edge_rows) */
+#define AGDIFF_VAR_HEAD_POLY 1024       /* global head with the edge_attr half from the d-polynomial */
+#define AGDIFF_VAR_SIDE_STREAM 2048     /* local branch forked onto the side stream */
+#define AGDIFF_VAR_POLY_L2_SETS 4096    /* agdiff_cfconv_node: some local types' coefficient sets did not fit in LDS (read from L2) */
 
 /* ---- static topology of one packed batch (host builds it once per batch) ---------------------
  * Graphs are contiguous node ranges (PyG Batch, utils/misc.py:88-90).  "Local" edges are the
@@ -204,6 +231,16 @@ typedef struct agdiff_topo {
   const int32_t* lp_row;     /* [Lp]: canonical index (row of l_attr_rows) of the entry's edge, -1 for pad entries */
   const int32_t* lc_ppos;    /* [Lc]: padded-list position of the canonical edge */
   const int32_t* lc_pmir;    /* [Lc]: ... of its mirror, or -1 */
+  /* the local edges once more as PAIR TILES for agdiff_cfconv_node: targets are taken two at a time (2 p, 2 p + 1); tile t of
+   * pair p holds local in-edges [8 t, 8 t + 8) of target 2 p in rows 0..7 and of target 2 p + 1 in rows 8..15 (pad rows:
+   * src = the target itself, the type of a real row, and nothing ever writes their CFConv scale: they contribute exactly 0),
+   * so that the rows of one lane quarter belong to ONE target and the sum over a target's edges needs no masks */
+  int64_t num_local_tiles;   /* T = lt_ptr[ceil(N/2)] */
+  const int32_t* lt_ptr;     /* [ceil(N/2) + 1]: tiles of pair p are [lt_ptr[p], lt_ptr[p+1]) */
+  const int32_t* lt_src;     /* [16 T] */
+  const int32_t* lt_type;    /* [16 T] */
+  const int32_t* lc_tpos;    /* [Lc]: pair-tile row of the canonical edge */
+  const int32_t* lc_tmir;    /* [Lc]: ... of its mirror, or -1 */
 } agdiff_topo_t;
 
 /* ---- workspace (device buffers the host allocates once per batch) ------------------------- */
@@ -251,22 +288,21 @@ typedef struct agdiff_ws {
   float*   h;                /* [N][128] SchNet node state */
   float*   xs;               /* [N][192] lin1/BN/LeakyReLU outputs feeding conv1 (0..127) and conv2 (128..191) */
   float*   agg;              /* [N][192] CFConv aggregates */
-  float*   agg_first;        /* [chunks][192], chunks = the larger of ceil(ceil(n/16) / agdiff_conv_chunk_tiles(n)) for n = max_edges
-                                and n = max_edges - num_local (the split CFConv's radius pass): partial sum of the target whose list was
-                                already open when the chunk started; the node stage adds them in chunk order */
+  float*   agg_first;        /* [chunks][192], chunks = ceil(ceil(max_edges/16) / agdiff_conv_chunk_tiles(max_edges)) (agdiff_cfconv_fused):
+                                partial sum of the target whose list was already open when the chunk started; the node stage
+                                adds them in chunk order */
   float*   hl;               /* [N][128] GIN node state (ping) */
   float*   hl2;              /* [N][128] (pong) */
   int32_t* nan_flag;         /* [1 + G]: [0] set to 1 when any position becomes NaN, [1 + g] when one of graph g does
                                 (sticky: the host clears them when a sampling job starts) */
-  /* split CFConv (agdiff_params_t.poly_kt > 0): the radius edges (type 0) of the dynamic graph as a destination-sorted
-   * list of their own (written by agdiff_graph_build next to the full list), and the static local list's per-step data
-   * by in-slot (topo->loc_in_*) */
-  int32_t* num_rad;          /* [1]  R = E - L (device scalar) */
-  int32_t* rad_ptr;          /* [N+1]: radius edges of target i are [rad_ptr[i], rad_ptr[i+1]) = in_ptr - loc_in_ptr */
-  int32_t* rad_src;          /* [max_edges - L] */
-  int32_t* rad_dst;          /* [max_edges - L] */
-  float*   rad_len;          /* [max_edges - L] */
-  float*   r_scale;          /* [2*num_convs][ceil((max_edges - L)/16)*16]: lw(d)*C(d) by radius-list position */
+  /* CFConv by filter polynomials (agdiff_params_t.poly_kt > 0): the radius edges (type 0) of the dynamic graph by TARGET, in
+   * AGDIFF_RAD_STRIDE rows per target (written by agdiff_graph_build next to the full list; sources ascending).  Rows
+   * [rad_cnt[i], 16 ceil(rad_cnt[i] / 16)) of target i are pad rows (src = i, length 0, scale 0: agdiff_edge_scales_split
+   * writes them), rows beyond are never read: every 16-row tile belongs to ONE target. */
+  int32_t* rad_cnt;          /* [N]  radius edges of target i (<= AGDIFF_RADIUS_CAP) */
+  int32_t* rad_src;          /* [N * AGDIFF_RAD_STRIDE] */
+  float*   rad_len;          /* [N * AGDIFF_RAD_STRIDE] */
+  float*   r_scale;          /* [2*num_convs][N * AGDIFF_RAD_STRIDE]: lw(d)*C(d) by radius-list row */
   int32_t* num_local_padded; /* [1]  Lp as a device scalar (written once by the host) */
   float*   l_scale;          /* [2*num_convs][ceil(Lp/16)*16]: the same by padded-list position (pad entries stay 0) */
   float*   l_attr_frag;      /* [ceil(Lp/16)] tiles x 2048 floats: edge_attr of the local edges in operand form, by padded-list
@@ -280,8 +316,11 @@ typedef struct agdiff_ws {
                                 longer than the cutoff this step (they go through the encoder MLP), [1 + tile] = 1 for those */
   float*   h0;               /* [N][128] cache of node stage 0's h (the atom embeddings: they do not depend on the positions) */
   float*   xs0;              /* [N][192] ... and of its xs (block 0's lin1 / BN / LeakyReLU outputs) */
-  float*   agg_loc;          /* [N][192] CFConv aggregates over the local edges */
+  float*   agg_loc;          /* [N][192] CFConv aggregates over the local edges (agdiff_cfconv_local) */
   float*   agg_first_loc;    /* [ceil(ceil(Lp/16) / agdiff_conv_chunk_tiles(Lp))][192] */
+  float*   lt_len;           /* [16 T] lengths of the local edges by pair-tile row (agdiff_local_lengths; pads stay 0) */
+  float*   lt_scale;         /* [2*num_convs][16 T]: lw(d)*C(d) by pair-tile row (pad rows stay 0) */
+  int64_t* variant_log;      /* [host] one word or null: every launcher ORs the AGDIFF_VAR_* bit of the variant it chose */
 } agdiff_ws_t;
 
 typedef struct agdiff_step_args {
@@ -321,7 +360,8 @@ int agdiff_graph_build_ex(const agdiff_topo_t* topo, const agdiff_ws_t* ws, cons
                           int32_t canon_radius_only, void* stream);
 
 /* get_distance on the static local edges (geometry.py:5-6 applied to edge_index[:, local_edge_mask]): one evaluation per
- * canonical local edge, written to l_len of the edge and of its mirror and to lc_len. */
+ * canonical local edge, written to l_len of the edge and of its mirror, to lc_len and -- where the workspace has them --
+ * to l_len_p (padded-list positions) and lt_len (pair-tile rows). */
 int agdiff_local_lengths(const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, void* stream);
 
 /* DistanceWeightingNetwork x cutoff envelope of all 2*num_convs CFConvs (encoder/schnet.py:83-100, 138-149):
@@ -351,11 +391,12 @@ int agdiff_local_edge_rows(const agdiff_params_t* p, const agdiff_topo_t* topo, 
 
 /* Node-side stage k of SchNetEncoder.forward (encoder/schnet.py:268-282): k == 0 embeds atoms;
  * k >= 1 finishes InteractionBlock k-1 (lin2/BN, act, lin, gate, AdaptiveScaling, residual);
- * k < num_convs also applies block k's conv{1,2}.lin1/BN/LeakyReLU into ws->xs. */
+ * k < num_convs also applies block k's conv{1,2}.lin1/BN/LeakyReLU into ws->xs.  Block k-1's aggregates are ws->agg /
+ * ws->agg_first by chunks of the full edge list (agdiff_cfconv_fused). */
 int agdiff_schnet_node_stage(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k, void* stream);
-/* The same with split bit 0 set: block k-1's aggregates are ws->agg (radius edges, lists ws->rad_ptr) + ws->agg_loc (local
- * edges, lists topo->lp_ptr) -- agdiff_cfconv_radius / agdiff_cfconv_local below.  Bit 2 (k == 0): write the stage's h / xs
- * to the cache ws->h0 / ws->xs0; bit 1 (k == 1): block 0's input h is ws->h0. */
+/* The same with `split` bits: 1: block k-1's aggregates are ws->agg as agdiff_cfconv_node wrote it (one complete row per
+ * node); 8 (with 1): plus ws->agg_loc / ws->agg_first_loc of agdiff_cfconv_local (lists topo->lp_ptr).  4 (k == 0): write
+ * the stage's h / xs to the cache ws->h0 / ws->xs0; 2 (k == 1): block 0's input h is ws->h0. */
 int agdiff_schnet_node_stage_split(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k,
                                    int32_t split, void* stream);
 
@@ -363,24 +404,18 @@ int agdiff_schnet_node_stage_split(const agdiff_params_t* p, const agdiff_topo_t
  * (encoder/schnet.py:138-162; PyG MessagePassing.propagate): ws->agg / ws->agg_first. */
 int agdiff_cfconv_fused(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k, void* stream);
 
-/* Split CFConv (agdiff_params_t.poly_kt > 0): block k's two convs as the sum of
- *   agdiff_cfconv_radius  over the radius edges (ws->rad_*, ws->r_scale; filters from the d-polynomials
- *                         p->conv[k].filt_poly_pk) -> ws->agg / ws->agg_first, and
- *   agdiff_cfconv_local   over the static, padded local list (topo->lp_*, ws->l_scale; filters from the per-type
- *                         d-polynomials p->conv[k].filt_poly_typed_pk at ws->l_len_p when every local type has a slot,
- *                         else the filter MLPs on ws->l_attr_frag as in agdiff_cfconv_fused) -> ws->agg_loc / ws->agg_first_loc;
- * agdiff_schnet_node_stage adds the two.  agdiff_edge_scales_split fills ws->r_scale (which == 0) or ws->l_scale
- * (which == 1). */
-int agdiff_cfconv_radius(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k, void* stream);
+/* The same two CFConvs with the filters from d-polynomials (agdiff_params_t.poly_kt > 0), one launch, one wave per PAIR of
+ * targets: the radius rows of each (ws->rad_*, ws->r_scale; p->conv[k].filt_poly_pk) and -- when agdiff_local_poly_enabled
+ * -- the pair's local tiles (topo->lt_*, ws->lt_len, ws->lt_scale; per-type sets p->conv[k].filt_poly_typed_pk) are
+ * summed in registers and ws->agg[i] is written once, complete, for every node (zeros for a node without edges).  Without
+ * local polynomials the local edges' part comes from agdiff_cfconv_local: the filter MLPs over the padded local list
+ * (topo->lp_*, ws->l_scale, ws->l_attr_frag) -> ws->agg_loc / ws->agg_first_loc, added by the node stage (split bit 8).
+ * agdiff_edge_scales_split fills ws->r_scale and the radius pad rows (which == 0), ws->l_scale (1) or ws->lt_scale (2). */
+int agdiff_cfconv_node(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k, void* stream);
 int agdiff_cfconv_local(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k, void* stream);
-/* Small batches: both CFConvs of block k in ONE launch over the full destination-sorted edge list (ws->in_ptr, e_src, e_dst,
- * e_type, e_len, e_scale -> ws->agg / agg_first, as agdiff_cfconv_fused), every edge's filter from the polynomial set of its
- * type (radius edges included as one more slot).  Needs agdiff_local_poly_enabled() and poly_num_slots + 1 <=
- * AGDIFF_POLY_MAX_SLOTS; agdiff_cfconv_merged_ok says whether that holds. */
-int agdiff_cfconv_merged(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k, void* stream);
-int agdiff_cfconv_merged_ok(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws);
-/* 1 when agdiff_cfconv_local takes the local edges' filters from per-type d-polynomials (p->poly_num_slots > 0, poly_kt == 1,
- * topo->lp_type, ws->l_len_p), 0 when it evaluates the filter MLPs on ws->l_attr_frag. */
+/* 1 when agdiff_cfconv_node takes the local edges' filters from per-type d-polynomials (p->poly_num_slots > 0,
+ * topo->lt_*, ws->lt_len, ws->lt_scale, not switched off by p->tune_local_poly_off), 0 when agdiff_cfconv_local
+ * evaluates the filter MLPs on ws->l_attr_frag. */
 int agdiff_local_poly_enabled(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws);
 int agdiff_edge_scales_split(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t which,
                              void* stream);
@@ -437,6 +472,13 @@ int agdiff_cfconv_aggregate(const float* x, const float* W, const int32_t* in_pt
 #define AGDIFF_FWD_STAGE0_CACHED 16
 int agdiff_score_forward(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
                          const float* pos, int32_t flags, void* stream);
+
+/* In-step timing of the dominant kernel (bench.py's roofline object): between agdiff_profile_cfconv(1) and (0) every CFConv
+ * launch that agdiff_score_forward issues for the global branch (one InteractionBlock's agdiff_cfconv_node [+ agdiff_cfconv_local],
+ * or agdiff_cfconv_fused) is bracketed by a pair of HIP events on the stream it runs on; agdiff_profile_cfconv_read waits for
+ * them, returns their summed elapsed time and the number of bracketed launches, and resets the list.  [host] pointers. */
+int agdiff_profile_cfconv(int32_t enable);
+int agdiff_profile_cfconv_read(double* total_ms, int64_t* launches);
 
 /* eq_transform x2, clip_norm, Langevin update, NaN check, center_pos, clamp
  * (geometry.py:9-17; dualenc.py:506-545, 581-589) from ws->l_inv / ws->e_inv_global. */

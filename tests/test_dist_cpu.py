@@ -173,3 +173,24 @@ def test_sharded_sampling_idle_rank_and_failing_rank_world2_gloo():
     mp.spawn(_shard_fault_worker, args=(2, port, out), nprocs=2, join=True)
     assert out[0][0] == 1 and out[1][0] == 1
     assert out[1][1].startswith("MemoryError") and "rank(s) [1] failed" in out[0][1] and "MemoryError" in out[0][1]
+
+
+def test_bench_launcher_spawns_ranks_and_fails_cleanly():
+    """`python bench.py --gpus N` (no torchrun) starts N fresh rank processes itself -- the parent never
+    initialises a GPU -- relays rank 0's JSON line, and on a node with fewer GPUs than ranks it stops with a device-count
+    message instead of a launcher hint.  The wiring (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*) is exercised over gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--launcher-selftest"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec == {"selftest": True, "rccl_ranks": 3, "sum_of_ranks": 6, "local_rank_env": "0"}
+    if torch.cuda.device_count() < 2:
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                             capture_output=True, text=True, timeout=300, env=env)
+        assert out.returncode == 2 and "GPU(s) visible" in out.stderr and "nothing was measured" in out.stderr
+        assert out.stdout.strip() == ""

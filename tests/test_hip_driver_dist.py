@@ -173,7 +173,7 @@ def test_full_size_properties_other_configs(kind, mols, copies, min_mean_deg):
     batch = b["batch"]
     assert np.array_equal(batch[src], batch[dst])                    # no edge crosses a molecule
     # the denoising loop with filter polynomials keeps only RADIUS edges in the canonical list (agdiff_graph_build_ex)
-    Ec = int(ws.num_rad.item()) if m.packed().poly_kt > 0 else E
+    Ec = int(ws.rad_cnt.sum().item()) if m.packed().poly_kt > 0 else E
     if kind == "qm9":
         assert 2 * C == Ec                                           # uncapped: every edge has its mirror
     else:

@@ -258,29 +258,35 @@ def test_extend_order_true_matches_reference_golden(precision):
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
-def test_node_kernel_variants(precision, monkeypatch):
+def test_node_kernel_variants(precision):
     """The SchNet node stage has three weight-delivery variants (csrc/node.hip): four waves per tile with LDS hand-offs
     for small batches, one wave per tile streaming from L2, and workgroup-shared LDS copies for large batches (the
     GIN layer has the last two).  Streaming and LDS-shared run the same MFMA order: bitwise equal in fp32 mode (the
     split-bf16 mode differs only by FMA contraction around the hi/lo split of two template instantiations); the
-    four-wave variant sums the gate's dot product in another order.  All must match the reference fixture."""
+    four-wave variant sums the gate's dot product in another order.  All must match the reference fixture.  The
+    variants are selected through agdiff_params_t.tune_* (model.tuning) and confirmed by agdiff_ws_t.variant_log."""
+    from agdiff_amd import _lib
+    V = _lib.DEFINES
     case = "g3_forward_drugs_capped"
     g = load_golden(case)
     m, _ = _gpu_model(FORWARD_CASES[case](), precision=precision)
     a = (t(g["atom_type"]).cuda(), t(g["pos"]).cuda(), t(g["bond_index"]).cuda(), t(g["bond_type"]).cuda(),
          t(g["batch"]).cuda(), None)
-    split = m(*a, return_edges=True, extend_order=False)                 # default for a batch this small
-    monkeypatch.setenv("AGDIFF_NODE_SPLIT_MAX_TILES", "0")
-    stream = m(*a, return_edges=True, extend_order=False)
-    monkeypatch.setenv("AGDIFF_NODE_LDSW_MIN_TILES", "1")
-    shared = m(*a, return_edges=True, extend_order=False)
-    monkeypatch.delenv("AGDIFF_NODE_LDSW_MIN_TILES")
-    monkeypatch.delenv("AGDIFF_NODE_SPLIT_MAX_TILES")
+
+    def run(want, **tuning):
+        m.tuning = dict(tuning)
+        out = m(*a, return_edges=True, extend_order=False)
+        var = int(m._batch_cache[2].variant_log.item())
+        for name in ("NODE_SPLIT4", "NODE_STREAM", "NODE_LDSW", "GIN_LDSW", "SHARE_ROWS"):
+            assert bool(var & V["AGDIFF_VAR_" + name]) == (name in want), (name, want, hex(var))
+        return out
+    split = run({"NODE_SPLIT4"})                                         # default for a batch this small
+    stream = run({"NODE_STREAM"}, node_split_max_tiles=-1)
+    shared = run({"NODE_LDSW", "GIN_LDSW"}, node_split_max_tiles=-1, node_ldsw_min_tiles=1)
     # the local edges' attribute rows: from the local branch's own encoder pass (batches this small) or written by the
     # global encoder pass through e_loc (large batches) -- the same encoder on the same lengths
-    monkeypatch.setenv("AGDIFF_SHARE_ROWS_MIN_NODES", "0")
-    rows_shared = m(*a, return_edges=True, extend_order=False)
-    monkeypatch.delenv("AGDIFF_SHARE_ROWS_MIN_NODES")
+    rows_shared = run({"NODE_SPLIT4", "SHARE_ROWS"} if m.packed().poly_kt == 0 else {"NODE_SPLIT4"}, share_rows_min_nodes=1)
+    m.tuning = {}
     assert torch.equal(rows_shared[0], split[0]) and torch.equal(rows_shared[1], split[1])
     if precision == "f32":
         assert torch.equal(stream[0], shared[0]) and torch.equal(stream[1], shared[1])
@@ -332,6 +338,90 @@ def test_oracle_parity_on_seeded_batches_and_wrapper_defaults():
                                                  b["num_graphs"], False, n_steps=5, noise=noise.cuda())
         check_close("oracle_parity_on_seeded_batches_and_wrapper_defaults gpos", gpos.cpu().numpy(), rpos.numpy(), "bf16x3")
         assert len(gtraj) == 5
+
+
+_BENCH_SIZE = {}
+
+
+def _bench_size_oracle():
+    """The oracle on a Drugs-shaped batch large enough for every large-batch kernel variant to be the NATURAL choice
+    (8 molecules x 80 conformers ~ 29 k atoms, ~1 M edges at the 32-neighbour cap: >= 1,536 node tiles, >= 8,192 atoms):
+    one forward(return_edges=True) at the sampler's first positions and two denoising steps with injected noise.  Computed
+    once per session (about a minute of host time), shared by both precisions and both filter modes."""
+    if _BENCH_SIZE:
+        return _BENCH_SIZE
+    import os
+    from agdiff_amd import drugs_model_config, synth
+    from oracle import agdiff_oracle as O
+    cfg = drugs_model_config(num_diffusion_timesteps=40, beta_end=2e-5)          # sigma < 0.5 on every step: global branch on
+    sd = O.synth_state_dict_for(cfg)
+    b = synth.make_packed_batch("drugs", 8, 80, seed=2021)
+    at, bi, bt, ba = [t(b[k]) for k in ("atom_type", "bond_index", "bond_type", "batch")]
+    gen = torch.Generator().manual_seed(11)
+    pos_init = torch.randn(at.shape[0], 3, generator=gen)
+    noise = torch.randn(2, at.shape[0], 3, generator=gen)
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(max(nthr, min(32, os.cpu_count() or 1)))
+    try:
+        with torch.no_grad():
+            sig_T = O.schedule_tensors(cfg)[2][-1]
+            pos0 = pos_init * sig_T
+            fwd = O.forward(sd, cfg, at, pos0, bi, bt, ba, extend_order=False)
+            kw = dict(extend_order=False, n_steps=2, w_global=1.0, global_start_sigma=0.5, clip=1000.0)
+            ref_pos, ref_traj = O.langevin_dynamics_sample_diffusion(sd, cfg, at, pos_init, bi, bt, ba, b["num_graphs"],
+                                                                     noise=noise, **kw)
+    finally:
+        torch.set_num_threads(nthr)
+    _BENCH_SIZE.update(cfg=cfg, sd=sd, b=b, inputs=(at, bi, bt, ba), pos_init=pos_init, pos0=pos0, noise=noise, kw=kw,
+                       fwd=[x.numpy() for x in fwd], ref_pos=ref_pos.numpy(), ref_traj=torch.stack(ref_traj).numpy())
+    return _BENCH_SIZE
+
+
+@pytest.mark.parametrize("mode", ["auto", "off"])
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_oracle_parity_at_natural_thresholds(precision, mode):
+    """the kernels the bench times, against the ORACLE, at a size where they are chosen by the
+    library's own thresholds -- no tuning override, no environment variable -- with agdiff_ws_t.variant_log asserting which
+    variants ran: the per-target polynomial CFConv with its local pair tiles (`auto`) or the one-list MLP CFConv with the
+    local rows shared from the global encoder pass (`off`), the LDS-shared node stage and GIN layer, the side stream.
+    Matches dualenc.py:142-251 (forward) and :478-545 (two denoising steps)."""
+    import os
+    from agdiff_amd import _lib, get_model
+    assert not [k for k in os.environ if k.startswith("AGDIFF_") and k not in ("AGDIFF_PARITY_GATE_SCALE",)], "no AGDIFF_* overrides here"
+    o = _bench_size_oracle()
+    cfg, b = o["cfg"], o["b"]
+    m = get_model(cfg)
+    m.precision, m.radius_poly = precision, mode
+    m.load_state_dict({k: v.clone() for k, v in o["sd"].items()}, strict=True)
+    m = m.to("cuda:0").eval()
+    assert m.tuning == {}
+    at, bi, bt, ba = [x.cuda() for x in o["inputs"]]
+    V = _lib.DEFINES
+    out = m(at, o["pos0"].cuda(), bi, bt, ba, None, return_edges=True, extend_order=False)
+    topo, ws = m._batch_cache[1], m._batch_cache[2]
+    assert topo.N >= 25000 and (topo.N + 15) // 16 >= 1536
+    var = int(ws.variant_log.item())
+    want = {"NODE_LDSW", "GIN_LDSW", "SIDE_STREAM"} | ({"CFCONV_NODE", "CFCONV_NODE_LOCAL", "ATTR_POLY"} if mode == "auto"
+                                                       else {"CFCONV_FUSED", "SHARE_ROWS"})
+    for name in ("CFCONV_NODE", "CFCONV_NODE_LOCAL", "CFCONV_LOCAL_MLP", "CFCONV_FUSED", "NODE_LDSW", "NODE_STREAM", "NODE_SPLIT4",
+                 "GIN_LDSW", "SHARE_ROWS", "ATTR_POLY", "SIDE_STREAM", "POLY_L2_SETS"):
+        assert bool(var & V["AGDIFF_VAR_" + name]) == (name in want), (name, hex(var))
+    inv_g, inv_l, ei, et, el, lm = o["fwd"]
+    assert np.array_equal(out[2].cpu().numpy(), ei) and np.array_equal(out[3].cpu().numpy(), et)     # bit-exact graph
+    assert np.array_equal(out[5].cpu().numpy(), lm)
+    assert np.diff(np.bincount(ei[1], minlength=topo.N)).size and np.bincount(ei[1], minlength=topo.N).mean() > 30      # at the cap
+    tag = "natural[%s]" % mode
+    check_close(tag + " edge_length", out[4], el, precision)
+    # (the normwise figure is a maximum over 1.0 M edges here against a few thousand on the fixtures the gates were set on:
+    # the split-bf16 error's tail reaches 3.2e-5 on the MLP path at this size, still 3x inside north_star's 1e-4)
+    check_close(tag + " inv_g", out[0], inv_g, precision, scale=2.0)
+    check_close(tag + " inv_l", out[1], inv_l, precision, scale=2.0)
+    pos, traj = m.langevin_dynamics_sample_diffusion(at, o["pos_init"].cuda(), bi, bt, ba, b["num_graphs"],
+                                                     noise=o["noise"].cuda(), **o["kw"])
+    var = int(m._batch_cache[2].variant_log.item())
+    assert bool(var & V["AGDIFF_VAR_HEAD_POLY"]) == (mode == "auto") and var & V["AGDIFF_VAR_NODE_LDSW"]
+    check_close(tag + " traj", torch.stack(traj), o["ref_traj"], precision)
+    check_close(tag + " pos", pos, o["ref_pos"], precision)
 
 
 def test_full_size_properties():

@@ -1,10 +1,12 @@
-"""GPU (MI355X): the filter-polynomial kernels (split CFConv: csrc/edge.hip k_cfconv_radius, its typed variant for the
-local list, k_pair_head_poly) and every fallback around them, against the reference fixtures and against the one-list
-kernels that evaluate the filter MLPs for every edge.  `radius_poly` (agdiff_amd/packing.py PackedParams):
+"""GPU (MI355X): the filter-polynomial kernels (csrc/nodeconv.hip k_cfconv_node: one wave per pair of targets, radius rows +
+local pair tiles; k_pair_head_poly; k_edge_attr_poly) and every fallback around them, against the reference fixtures and
+against the one-list kernels that evaluate the filter MLPs for every edge.  `radius_poly` (agdiff_amd/packing.py):
   auto    radius edges and every local edge type from d-polynomials (the default the other test files run)
   radius  polynomials for the radius edges only, local edges through the filter MLPs on the padded local list
-  kt2     64-term expansions (two k-tiles; local edges through the MLPs)
-  off     one list, every edge through the encoder + filter MLPs (rounds 1-2a product path)"""
+  kt2     64-term expansions (two k-tiles) for radius edges and local types alike
+  off     one list, every edge through the encoder + filter MLPs (rounds 1-2a product path)
+plus `auto-l2`: as auto with every local type's coefficient set read from L2 instead of LDS (tune_poly_lds_sets = 1: the
+path types beyond the LDS-resident sets take)."""
 import ctypes
 
 import numpy as np
@@ -42,18 +44,20 @@ def _one_pass(ptr, agg, first, chunk_edges, N):
     return a
 
 
-def _aggregates(ws, topo, lib, split=False):
+def _aggregates(ws, topo, lib):
+    """What the node stage reads after agdiff_cfconv_fused over the full list."""
     from agdiff_amd import _lib
     ct = lambda n: _lib.TILE * lib.agdiff_conv_chunk_tiles(ctypes.c_int64(n))
-    if not split:
-        return _one_pass(ws.in_ptr, ws.agg, ws.agg_first, ct(topo.max_edges), topo.N)
-    return (_one_pass(ws.rad_ptr, ws.agg, ws.agg_first, ct(topo.max_edges - topo.L), topo.N) +
-            _one_pass(topo.lp_ptr, ws.agg_loc, ws.agg_first_loc, ct(topo.Lp), topo.N))
+    return _one_pass(ws.in_ptr, ws.agg, ws.agg_first, ct(topo.max_edges), topo.N)
+
+
+def _variants(ws):
+    return int(ws.variant_log.item())
 
 
 def _expect(pk, mode):
     assert pk.poly_kt == {"auto": 1, "radius": 1, "kt2": 2, "off": 0}[mode]
-    want_slots = mode == "auto"
+    want_slots = mode in ("auto", "kt2")
     assert (pk.struct.poly_num_slots > 0) == want_slots, (mode, pk.struct.poly_num_slots, pk.poly_errors)
 
 
@@ -75,33 +79,43 @@ def test_forward_every_filter_mode(case, mode, precision):
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
-@pytest.mark.parametrize("mode", MODES + ["auto-two-lists"])
+@pytest.mark.parametrize("mode", MODES + ["auto-l2"])
 @pytest.mark.parametrize("case", ["g5_sampler_lowT_global", "g5_sampler_mixed_cliplocal"])
-def test_sampler_every_filter_mode(case, mode, precision, monkeypatch):
-    """The denoising loop (polynomial global head on the radius edges in every mode but `off`).  Batches this small run
-    both CFConv passes of a block as ONE launch over the full edge list in mode `auto` (agdiff_cfconv_merged);
-    `auto-two-lists` forces the radius-list + local-list launches that large batches take."""
-    if mode == "auto-two-lists":
-        monkeypatch.setenv("AGDIFF_MERGED_MAX_NODES", "0")
-        mode = "auto"
+def test_sampler_every_filter_mode(case, mode, precision):
+    """The denoising loop (polynomial global head on the radius edges in every mode but `off`)."""
+    from agdiff_amd import _lib
+    l2 = mode == "auto-l2"
+    mode = "auto" if l2 else mode
     g = load_golden(case)
     m = _model(sampler_case_cfg(g, case), mode, head_scale=float(g["head_scale"]), precision=precision)
+    if l2:
+        m.tuning["poly_lds_sets"] = 1
     pos, traj = m.langevin_dynamics_sample_diffusion(
         t(g["atom_type"]).cuda(), t(g["pos_init"]).cuda(), t(g["bond_index"]).cuda(), t(g["bond_type"]).cuda(),
         t(g["batch"]).cuda(), int(g["num_graphs"]), extend_order=False, n_steps=int(g["n_steps"]),
         noise=t(g["noise"]).cuda(), **sampler_case_kwargs(g))
     _expect(m.packed(), mode)
+    V, var = _lib.DEFINES, _variants(m._batch_cache[2])
+    if "lowT" in case:        # the global branch ran: which CFConv did?
+        assert bool(var & V["AGDIFF_VAR_CFCONV_NODE"]) == (mode != "off") and bool(var & V["AGDIFF_VAR_CFCONV_FUSED"]) == (mode == "off")
+        assert bool(var & V["AGDIFF_VAR_CFCONV_NODE_LOCAL"]) == (mode in ("auto", "kt2"))
+        assert bool(var & V["AGDIFF_VAR_CFCONV_LOCAL_MLP"]) == (mode == "radius")
+        if mode != "kt2":     # (two-k-tile sets are 48 KiB: two typed ones fit next to the radius edges', the rest come from L2)
+            assert bool(var & V["AGDIFF_VAR_POLY_L2_SETS"]) == l2
     check_close("poly[%s] traj[%s]" % (mode, case), torch.stack(traj).numpy(), g["traj"], precision)
     check_close("poly[%s] pos[%s]" % (mode, case), pos.cpu().numpy(), g["pos_final"], precision)
 
 
 @pytest.mark.parametrize("kind,mols,copies", [("drugs", 5, 4), ("qm9", 7, 5)])
-def test_split_cfconv_equals_one_list_kernel(kind, mols, copies):
-    """Kernel level, through the C ABI: on the same graph, node inputs and block, the radius pass + the local pass
-    (polynomial filters) add up to what agdiff_cfconv_fused (filter MLPs on every edge) aggregates; the radius list is
-    the type-0 subsequence of the full list; padded local entries contribute exactly nothing."""
+def test_node_cfconv_equals_one_list_kernel(kind, mols, copies):
+    """Kernel level, through the C ABI: on the same graph, node inputs and block, agdiff_cfconv_node (polynomial filters;
+    radius rows + local pair tiles, one complete row of agg per node) equals what agdiff_cfconv_fused (filter MLPs on
+    every edge of the full list) aggregates; the radius rows of a target are the type-0 subsequence of its list, the pad
+    rows that complete its last tile contribute exactly nothing; and the same with the local edges through the filter MLPs
+    (agdiff_cfconv_local's second aggregate) and with the typed sets read from L2."""
     from agdiff_amd import _lib, drugs_model_config, qm9_model_config, synth
     lib = _lib.load()
+    RS = _lib.DEFINES["AGDIFF_RAD_STRIDE"]
     cfg = (qm9_model_config if kind == "qm9" else drugs_model_config)(num_diffusion_timesteps=50, beta_end=2e-5)
     for precision in ("f32", "bf16x3"):
         m = _model(cfg, "auto", precision=precision)
@@ -113,33 +127,60 @@ def test_split_cfconv_equals_one_list_kernel(kind, mols, copies):
         assert pk.struct.poly_num_slots > 0 and lib.agdiff_local_poly_enabled(
             ctypes.byref(pk.struct), ctypes.byref(topo.struct), ctypes.byref(ws.struct)) == 1
         P, T, W, st = ctypes.byref(pk.struct), ctypes.byref(topo.struct), ctypes.byref(ws.struct), _lib.stream_ptr()
-        E, R = int(ws.num_edges.item()), int(ws.num_rad.item())
-        ety = ws.e_type[:E].cpu().numpy()
-        assert R == int((ety == 0).sum()) and R + topo.L == E
-        for name, full, rad in (("src", ws.e_src, ws.rad_src), ("dst", ws.e_dst, ws.rad_dst), ("len", ws.e_len, ws.rad_len)):
-            assert np.array_equal(full[:E].cpu().numpy()[ety == 0], rad[:R].cpu().numpy()), name
-        rp = ws.rad_ptr.cpu().numpy()
-        assert rp[-1] == R and np.array_equal(np.diff(rp), np.bincount(ws.rad_dst[:R].cpu().numpy(), minlength=topo.N))
+        E, N = int(ws.num_edges.item()), topo.N
+        ety, edst = ws.e_type[:E].cpu().numpy(), ws.e_dst[:E].cpu().numpy()
+        esrc, elen = ws.e_src[:E].cpu().numpy(), ws.e_len[:E].cpu().numpy()
+        cnt = ws.rad_cnt.cpu().numpy()
+        rsrc, rlen = ws.rad_src.view(N, RS).cpu().numpy(), ws.rad_len.view(N, RS).cpu().numpy()
+        rsc = ws.r_scale.view(-1, N, RS)[: 2 * cfg.num_convs].cpu().numpy()
+        assert np.array_equal(cnt, np.bincount(edst[ety == 0], minlength=N)) and cnt.max() <= _lib.RADIUS_CAP
+        ip = ws.in_ptr.cpu().numpy()
+        for i in range(N):
+            sel = slice(ip[i], ip[i + 1])
+            r0 = ety[sel] == 0
+            c, cp = cnt[i], (cnt[i] + 15) // 16 * 16
+            assert np.array_equal(rsrc[i, :c], esrc[sel][r0]) and np.array_equal(rlen[i, :c], elen[sel][r0])
+            assert np.all(rsrc[i, c:cp] == i) and np.all(rlen[i, c:cp] == 0) and np.all(rsc[:, i, c:cp] == 0)
         assert lib.agdiff_edge_scales(P, T, W, 1, st) == 0
+        sc = 3.0 if precision == "bf16x3" else 1.0
         # ws.xs holds lin1 outputs of the last block after the forward: any block's filters may be applied to them
         for k in (0, cfg.num_convs - 1):
             assert lib.agdiff_cfconv_fused(P, T, W, k, st) == 0
             torch.cuda.synchronize()
             ref = _aggregates(ws, topo, lib)
-            ws.agg.zero_(); ws.agg_first.zero_()
-            assert lib.agdiff_cfconv_radius(P, T, W, k, st) == 0 and lib.agdiff_cfconv_local(P, T, W, k, st) == 0
+            ws.agg.fill_(float("nan"))
+            assert lib.agdiff_cfconv_node(P, T, W, k, st) == 0
             torch.cuda.synchronize()
-            got = _aggregates(ws, topo, lib, split=True)
+            got = ws.agg.view(-1, 192).cpu().double().numpy()
             # (both sides carry their own split-bf16 rounding -- polynomial vs MLP chain --, each ~1.5e-5 from the exact
             # value: the gate is for a difference of two such figures)
-            check_close("split_cfconv[%s] block %d" % (kind, k), got, ref, precision, scale=3.0 if precision == "bf16x3" else 1.0)
-            # the one-launch variant for small batches: every edge of the full list by the polynomial of its type
-            assert lib.agdiff_cfconv_merged_ok(P, T, W) == 1
-            ws.agg.zero_(); ws.agg_first.zero_()
-            assert lib.agdiff_cfconv_merged(P, T, W, k, st) == 0
+            check_close("node_cfconv[%s] block %d" % (kind, k), got, ref, precision, scale=sc)
+            again = ws.agg.clone()
+            ws.agg.fill_(float("nan"))
+            assert lib.agdiff_cfconv_node(P, T, W, k, st) == 0
             torch.cuda.synchronize()
-            check_close("merged_cfconv[%s] block %d" % (kind, k), _aggregates(ws, topo, lib), ref, precision,
-                        scale=3.0 if precision == "bf16x3" else 1.0)
+            assert torch.equal(again, ws.agg)                                  # fixed summation order: bitwise reproducible
+            # every local type's set from L2 instead of LDS: the same arithmetic in the same order
+            pk.set_tuning(poly_lds_sets=1)
+            ws.agg.fill_(float("nan"))
+            assert lib.agdiff_cfconv_node(P, T, W, k, st) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(again, ws.agg)
+            pk.set_tuning(poly_lds_sets=0)
+            # local edges through the filter MLPs: agdiff_cfconv_node (radius rows only) + agdiff_cfconv_local
+            pk.set_tuning(local_poly_off=1)
+            ctl = (topo.Lc + 15) // 16
+            assert lib.agdiff_edge_encoder(P, _lib.ptr(ws.num_local_canon), ctl, _lib.ptr(ws.lc_len), _lib.ptr(topo.lc_type),
+                                           _lib.ptr(ws.l_attr_frag), _lib.ptr(ws.l_attr_rows), _lib.ptr(topo.lp_row),
+                                           _lib.ptr(topo.lc_ppos), _lib.ptr(topo.lc_pmir), st) == 0
+            assert lib.agdiff_edge_scales_split(P, T, W, 1, st) == 0
+            ws.agg.fill_(float("nan"))
+            assert lib.agdiff_cfconv_node(P, T, W, k, st) == 0 and lib.agdiff_cfconv_local(P, T, W, k, st) == 0
+            torch.cuda.synchronize()
+            ct = lambda n: _lib.TILE * lib.agdiff_conv_chunk_tiles(ctypes.c_int64(n))
+            got2 = ws.agg.view(-1, 192).cpu().double().numpy() + _one_pass(topo.lp_ptr, ws.agg_loc, ws.agg_first_loc, ct(topo.Lp), N)
+            check_close("node_cfconv+local_mlp[%s] block %d" % (kind, k), got2, ref, precision, scale=sc)
+            pk.set_tuning(local_poly_off=0)
 
 
 def test_rejected_fit_falls_back_to_the_mlps():
@@ -167,30 +208,40 @@ def test_rejected_fit_falls_back_to_the_mlps():
     check_close("rejected_fit sampler", got.cpu().numpy(), ref.numpy(), "bf16x3")
 
 
-def test_more_local_types_than_slots_uses_the_mlps_for_local_edges():
-    """Seven distinct bond types in one batch (AGDIFF_POLY_MAX_SLOTS = 6): the local list goes through the filter MLPs,
-    the radius edges keep their polynomials; against the oracle."""
-    from agdiff_amd import get_model, qm9_model_config
+def _chain_with_bond_types(n_types):
+    n = n_types + 1                                         # a chain with a different bond type on every link
+    src = np.arange(n - 1); dst = src + 1
+    bi = torch.from_numpy(np.concatenate([np.stack([src, dst]), np.stack([dst, src])], axis=1)).long()
+    bt = torch.from_numpy(np.concatenate([np.arange(1, n), np.arange(1, n)])).long()        # types 1..n_types
+    return torch.full((n,), 6, dtype=torch.long), bi, bt, torch.zeros(n, dtype=torch.long)
+
+
+@pytest.mark.parametrize("n_types,slots_kept", [(8, True), (17, False)])
+def test_many_local_edge_types(n_types, slots_kept):
+    """Eight distinct bond types in one batch: more than the five typed coefficient sets that fit in LDS next to the radius
+    edges' one -- the later types' sets are read from L2 by the tiles that meet them; seventeen: more than
+    AGDIFF_POLY_MAX_SLOTS (16) -- the local list goes through the filter MLPs, the radius edges keep their polynomials.
+    Both against the oracle."""
+    from agdiff_amd import _lib, get_model, qm9_model_config
     from oracle import agdiff_oracle as O
     cfg = qm9_model_config(num_diffusion_timesteps=30, beta_end=2e-5)
     sd = O.synth_state_dict_for(cfg)
     m = get_model(cfg)
     m.load_state_dict({k: v.clone() for k, v in sd.items()})
     m = m.to("cuda:0").eval()
-    n = 9                                                   # a chain with a different bond type on every link
-    src = np.arange(n - 1); dst = src + 1
-    bi = torch.from_numpy(np.concatenate([np.stack([src, dst]), np.stack([dst, src])], axis=1)).long()
-    bt = torch.from_numpy(np.concatenate([np.arange(1, n), np.arange(1, n)])).long()        # types 1..8
-    at = torch.full((n,), 6, dtype=torch.long); ba = torch.zeros(n, dtype=torch.long)
+    at, bi, bt, ba = _chain_with_bond_types(n_types)
+    n = at.shape[0]
     g = torch.Generator().manual_seed(9)
     pos_init, noise = torch.randn(n, 3, generator=g), torch.randn(3, n, 3, generator=g)
     kw = dict(extend_order=False, n_steps=3, w_global=1.0, global_start_sigma=0.5, clip=1000.0)
     ref, _ = O.langevin_dynamics_sample_diffusion(sd, cfg, at, pos_init, bi, bt, ba, 1, noise=noise, **kw)
     got, _ = m.langevin_dynamics_sample_diffusion(at.cuda(), pos_init.cuda(), bi.cuda(), bt.cuda(), ba.cuda(), 1,
                                                   noise=noise.cuda(), **kw)
-    pk = m.packed()
-    assert pk.poly_kt == 1 and pk.struct.poly_num_slots == 0
-    check_close("too_many_local_types sampler", got.cpu().numpy(), ref.numpy(), "bf16x3")
+    pk, var, V = m.packed(), _variants(m._batch_cache[2]), _lib.DEFINES
+    assert pk.poly_kt == 1 and pk.struct.poly_num_slots == (n_types if slots_kept else 0)
+    assert bool(var & V["AGDIFF_VAR_POLY_L2_SETS"]) == slots_kept and bool(var & V["AGDIFF_VAR_CFCONV_LOCAL_MLP"]) == (not slots_kept)
+    assert var & V["AGDIFF_VAR_CFCONV_NODE"]
+    check_close("many_local_types[%d] sampler" % n_types, got.cpu().numpy(), ref.numpy(), "bf16x3")
 
 
 @pytest.mark.parametrize("kind,mols,copies", [("drugs", 4, 3), ("qm9", 6, 4)])
@@ -207,7 +258,8 @@ def test_radius_only_canonical_list_of_the_sampler(kind, mols, copies):
     m.langevin_dynamics_sample_diffusion(at, pos_init, bi, bt, ba, b["num_graphs"], extend_order=False, n_steps=2,
                                          w_global=1.0, global_start_sigma=0.5, clip=1000.0)
     ws = m._batch_cache[2]
-    E, R, C = int(ws.num_edges.item()), int(ws.num_rad.item()), int(ws.num_canon.item())
+    E, C = int(ws.num_edges.item()), int(ws.num_canon.item())
+    R = int(ws.rad_cnt.sum().item())
     g = lambda x, n: x[:n].cpu().numpy()
     ety, esrc, edst = g(ws.e_type, E), g(ws.e_src, E), g(ws.e_dst, E)
     cs, cd, cp, cm = [g(x, C) for x in (ws.c_src, ws.c_dst, ws.c_pos, ws.c_mir)]

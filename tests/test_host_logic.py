@@ -300,6 +300,52 @@ def test_padded_local_list():
     assert np.array_equal(cover, row >= 0)
 
 
+@pytest.mark.parametrize("kind,mols,copies,drop_last", [("drugs", 3, 2, False), ("qm9", 3, 1, True)])
+def test_local_pair_tiles(kind, mols, copies, drop_last):
+    """agdiff_topo_t.lt_* (agdiff_cfconv_node): targets two at a time; tile t of pair p holds in-edges [8 t, 8 t + 8) of
+    target 2 p in rows 0..7 and of target 2 p + 1 in rows 8..15; pad rows point at the target itself and carry the type
+    of a real row of their tile; every local edge sits in exactly one row; an odd node count leaves the last pair's
+    second half empty."""
+    from agdiff_amd import synth
+    from agdiff_amd.topology import BatchTopology
+    b = synth.make_packed_batch(kind, mols, copies, seed=5)
+    at, bi, bt, ba = b["atom_type"], b["bond_index"], b["bond_type"], b["batch"]
+    if drop_last or at.shape[0] % 2 == 0:       # make the node count odd: cut the last atom and its bonds
+        n = at.shape[0] - 1
+        keep = (bi[0] < n) & (bi[1] < n)
+        at, bi, bt, ba = at[:n], bi[:, keep], bt[keep], ba[:n]
+    tp = BatchTopology(at, bi, bt, ba, device="cpu")
+    assert tp.N % 2 == 1
+    ltp, src, typ = tp.lt_ptr.numpy(), tp.lt_src.numpy(), tp.lt_type.numpy()
+    ip, isrc, eid, ltyp = tp.loc_in_ptr.numpy(), tp.loc_in_src.numpy(), tp.loc_in_eid.numpy(), tp.loc_type.numpy()
+    P = (tp.N + 1) // 2
+    assert ltp.shape[0] == P + 1 and ltp[-1] == tp.T == tp.struct.num_local_tiles and src.shape[0] == 16 * tp.T
+    real = np.zeros(16 * tp.T, bool)
+    for p_ in range(P):
+        degs = [ip[i + 1] - ip[i] if i < tp.N else 0 for i in (2 * p_, 2 * p_ + 1)]
+        assert ltp[p_ + 1] - ltp[p_] == (max(degs) + 7) // 8
+        for tl in range(ltp[p_], ltp[p_ + 1]):
+            for h, i in enumerate((2 * p_, 2 * p_ + 1)):
+                k0 = 8 * (tl - ltp[p_])
+                rows = np.arange(16 * tl + 8 * h, 16 * tl + 8 * h + 8)
+                nreal = int(np.clip(degs[h] - k0, 0, 8))
+                if nreal:
+                    assert np.array_equal(src[rows[:nreal]], isrc[ip[i] + k0: ip[i] + k0 + nreal])
+                    assert np.array_equal(typ[rows[:nreal]], ltyp[eid[ip[i] + k0: ip[i] + k0 + nreal]])
+                    real[rows[:nreal]] = True
+                assert np.all(src[rows[nreal:]] == min(i, tp.N - 1))
+            tile_rows = np.arange(16 * tl, 16 * tl + 16)
+            assert real[tile_rows].any() and set(typ[tile_rows]) == set(typ[tile_rows][real[tile_rows]])
+    assert real.sum() == tp.L and np.array_equal(real, tp.lt_real)
+    tpos, tmir = tp.lc_tpos.numpy(), tp.lc_tmir.numpy()
+    mk = tmir >= 0
+    cover = np.zeros(16 * tp.T, int)
+    np.add.at(cover, tpos, 1); np.add.at(cover, tmir[mk], 1)
+    assert np.array_equal(cover, real.astype(int))
+    assert np.array_equal(src[tpos], tp.lc_src.numpy()) and np.array_equal(src[tmir[mk]], tp.lc_dst.numpy()[mk])
+    assert np.array_equal(typ[tpos], tp.lc_type.numpy())
+
+
 def test_distance_weighting_segments():
     """packing.dist_segments (agdiff_conv_params_t.dist_seg): the piecewise-linear form of DistanceWeightingNetwork before its
     sigmoid equals layer2(relu(layer1(d))) (schnet.py:83-100) at random lengths and at the kinks themselves, also with

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Build a variant of libagdiff_hip.so for same-box A/B runs:   bash tools/build_variant.sh <name> [extra hipcc flags]
+# -> _ab/lib_<name>.so (objects under _ab/build_<name>/; _ab/ is git-ignored but travels to the GPU box).
+set -e
+root=$(cd "$(dirname "$0")/.." && pwd)
+name=$1; shift
+mkdir -p "$root/_ab/build_$name"
+cd "$root/agdiff_amd/csrc"
+for f in graph edge nodeconv node eval api; do
+  flags=""
+  [ $f = edge ] && flags="-fno-honor-nans"
+  [ $f = nodeconv ] && flags="-fno-honor-nans -fno-slp-vectorize"
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -Wno-unused-function $flags "$@" -c $f.hip -o "$root/_ab/build_$name/$f.o" &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$root"/_ab/build_$name/*.o -o "$root/_ab/lib_$name.so"
+echo "built _ab/lib_$name.so"
