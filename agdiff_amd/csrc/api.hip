@@ -139,10 +139,12 @@ int local_branch(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdi
     if (hipStreamWaitEvent((hipStream_t)stream, rows_ready, 0) != hipSuccess) return AGDIFF_ERR_LAUNCH;
   } else if (topo->num_local > 0) {
     if (canon && split) {
-      if (agdiff_local_poly_enabled(p, topo, ws)) {   // the local CFConv takes its filters from polynomials: rows only
-        AG_TRY(agdiff_edge_scales_split(p, topo, ws, 2, stream));
+      const int lp = agdiff_local_poly_enabled(p, topo, ws);
+      if (lp != 0) AG_TRY(agdiff_edge_scales_split(p, topo, ws, 2, stream));      // scales by pair-tile row (agdiff_cfconv_node)
+      if (lp == 1) {        // the local CFConv takes every filter from polynomials: only the rows are needed
         AG_TRY(agdiff_local_edge_rows(p, topo, ws, stream));
-      } else {              // ... and the operand-form copy at the padded-list positions of the edge and of its mirror
+      } else {              // (some) local edges through the filter MLPs: rows and the operand-form copy at the padded-list
+                            // positions of the edge and of its mirror; in a mixed batch the slotted types' scales stay 0 there
         AG_TRY(agdiff_edge_encoder(p, ws->num_local_canon, ctiles, ws->lc_len, topo->lc_type, ws->l_attr_frag, ws->l_attr_rows,
                                    topo->lp_row, topo->lc_ppos, topo->lc_pmir, stream));
         AG_TRY(agdiff_edge_scales_split(p, topo, ws, 1, stream));
@@ -231,7 +233,7 @@ int global_back_split(const agdiff_params_t* p, const agdiff_topo_t* topo, const
   // reads it from there
   const bool cache = ws->h0 && ws->xs0;
   // local edges: inside agdiff_cfconv_node (per-type polynomials), or agdiff_cfconv_local's second aggregate (filter MLPs)
-  const bool local_mlp = topo->num_local > 0 && !agdiff_local_poly_enabled(p, topo, ws);
+  const bool local_mlp = topo->num_local > 0 && agdiff_local_poly_enabled(p, topo, ws) != 1;    // none or only some by polynomials
   const int sp = 1 | (local_mlp ? 8 : 0);
   if (!(cache && (flags & AGDIFF_FWD_STAGE0_CACHED))) AG_TRY(agdiff_schnet_node_stage_split(p, topo, ws, 0, sp | 4, stream));
   agdiff_ws_t ws0 = *ws;

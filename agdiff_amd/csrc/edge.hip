@@ -211,6 +211,8 @@ struct ScaleArgs {
   const float* e_len;
   const int32_t* pos_index;    // optional (with mir_index): entry e is the canonical edge of positions pos_index[e] and,
   const int32_t* mir_index;    // when >= 0, mir_index[e] (a mirror pair has one length, hence one scale)
+  const int32_t* e_type;       // optional (with type_slot): entries whose type has a polynomial slot get scale 0 -- the MLP
+  const int32_t* type_slot;    // pass of a mixed batch must not count them a second time
   float* out;
   int64_t epad;
   int32_t n;
@@ -230,7 +232,8 @@ __global__ void __launch_bounds__(256) k_edge_scales(ScaleArgs a) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= *a.n_dev) return;
   const float d = a.e_len[e];
-  const float C = cf_envelope(d, a.cutoff, a.smooth);
+  float C = cf_envelope(d, a.cutoff, a.smooth);
+  if (a.e_type && a.type_slot[a.e_type[e]] >= 0) C = 0.0f;
   const int64_t p0 = a.pos_index ? (int64_t)a.pos_index[e] : e;
   const int64_t p1 = a.pos_index ? (int64_t)a.mir_index[e] : -1;
   for (int c = 0; c < a.n; ++c) {
@@ -857,7 +860,10 @@ __global__ void __launch_bounds__(64 * AG_ATTRP_WAVES, 2) k_edge_attr_poly(AttrP
     const bool valid = e < E;
     const float d = valid ? a.e_len[e] : 0.0f;
     const int slot = valid ? a.type_slot[a.e_type[e]] : -1;
-    const bool hard = valid && (!(d >= 0.0f && d <= a.cutoff) || slot < 0);      // (also catches NaN lengths)
+    // (NaN lengths by their bit pattern: this file is built with -fno-honor-nans, under which `!(d >= 0 && d <= rc)` may be
+    // rewritten into comparisons that a NaN passes)
+    const bool is_nan = (__float_as_uint(d) & 0x7FFFFFFFu) > 0x7F800000u;
+    const bool hard = valid && (is_nan || d < 0.0f || d > a.cutoff || slot < 0);
     if (__ballot(hard)) {
       if (lane == 0) a.flags[1 + tile] = 1;
       ++my_flagged;
@@ -1078,9 +1084,12 @@ extern "C" int agdiff_edge_encoder(const agdiff_params_t* p, const int32_t* n_ed
 
 namespace {
 int launch_edge_scales(const agdiff_params_t* p, const int32_t* n_dev, int64_t max_n, const float* e_len,
-                       const int32_t* pos_index, const int32_t* mir_index, float* out, int64_t epad, void* stream) {
+                       const int32_t* pos_index, const int32_t* mir_index, float* out, int64_t epad, void* stream,
+                       const int32_t* zero_slotted_types = nullptr) {
   if (max_n == 0) return AGDIFF_OK;
   ScaleArgs a;
+  a.e_type = zero_slotted_types;
+  a.type_slot = zero_slotted_types ? p->poly_type_slot : nullptr;
   for (int k = 0; k < p->num_convs; ++k) {
     a.dw[2 * k] = p->conv[k].dist_seg;
     a.dw[2 * k + 1] = p->conv[k].dist_seg + 100;
@@ -1139,7 +1148,8 @@ extern "C" int agdiff_edge_scales_split(const agdiff_params_t* p, const agdiff_t
   if (which == 1) {        // ... in the padded local list (agdiff_cfconv_local)
     if (!ws->l_scale || !topo->lc_ppos || !topo->lc_pmir) return AGDIFF_ERR_ARG;
     return launch_edge_scales(p, ws->num_local_canon, topo->num_local_canon, ws->lc_len, topo->lc_ppos, topo->lc_pmir,
-                              ws->l_scale, ((topo->num_local_padded + AG_TW - 1) / AG_TW) * AG_TW, stream);
+                              ws->l_scale, ((topo->num_local_padded + AG_TW - 1) / AG_TW) * AG_TW, stream,
+                              agdiff_local_poly_enabled(p, topo, ws) == 2 ? topo->lc_type : nullptr);
   }
   // ... in the pair tiles (agdiff_cfconv_node)
   if (!ws->lt_scale || !topo->lc_tpos || !topo->lc_tmir) return AGDIFF_ERR_ARG;
@@ -1210,9 +1220,16 @@ extern "C" int agdiff_cfconv_fused(const agdiff_params_t* p, const agdiff_topo_t
 
 // Local edges by per-type filter polynomials?  (all of: slots built by the host, the pair-tile inputs present)
 extern "C" int agdiff_local_poly_enabled(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws) {
-  return p && topo && ws && !p->tune_local_poly_off && p->poly_kt >= 1 && p->poly_kt <= AGDIFF_POLY_MAX_KT &&
-         p->poly_num_slots > 0 && p->poly_num_slots <= AGDIFF_POLY_MAX_SLOTS && p->poly_type_slot && topo->lt_ptr &&
-         topo->lt_src && topo->lt_type && ws->lt_len && ws->lt_scale;
+  const bool on = p && topo && ws && !p->tune_local_poly_off && p->poly_kt >= 1 && p->poly_kt <= AGDIFF_POLY_MAX_KT &&
+                  p->poly_num_slots > 0 && p->poly_num_slots <= AGDIFF_POLY_MAX_SLOTS && p->poly_type_slot && topo->lt_ptr &&
+                  topo->lt_src && topo->lt_type && ws->lt_len && ws->lt_scale;
+  if (!on) return 0;
+  const uint64_t miss0 = (uint64_t)topo->local_type_mask[0] & ~(uint64_t)p->poly_slot_mask[0];
+  const uint64_t miss1 = (uint64_t)topo->local_type_mask[1] & ~(uint64_t)p->poly_slot_mask[1];
+  if (!(miss0 | miss1)) return 1;                          // every local type of the batch has a slot
+  const uint64_t have = ((uint64_t)topo->local_type_mask[0] & (uint64_t)p->poly_slot_mask[0]) |
+                        ((uint64_t)topo->local_type_mask[1] & (uint64_t)p->poly_slot_mask[1]);
+  return have ? 2 : 0;                                     // some do (mixed) / none does
 }
 
 // The local edges through the filter MLPs (no per-type polynomials): k_cfconv_fused over the padded local list

@@ -71,7 +71,10 @@ __device__ unsigned long long ag_node_stamp_acc[8];
 // during the wave's previous tile; x groups are double-buffered inside a tile.
 // Lengths beyond the cutoff are clamped into the fitted range: their CFConv scale is exactly 0 (schnet.py:140-146).
 #ifndef AG_NODE_GRP
-#define AG_NODE_GRP 3                       // channel tiles per x / MFMA group (12 = an even number of groups: the buffer parity is static)
+#define AG_NODE_GRP 3                       // channel tiles per x / MFMA group
+#endif
+#ifndef AG_NODE_XD
+#define AG_NODE_XD 2                        // x groups in flight (ring of buffers; must divide the number of groups: static indices)
 #endif
 #ifndef AG_NODE_ABL
 #define AG_NODE_ABL 0       // timing experiments only (wrong results): 1 no x gathers, 2 no filter MFMAs, 4 no features, 8 no sums
@@ -142,7 +145,8 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
     }
   };
   // x[src] values of a group of AG_NODE_GRP channel tiles, two groups in flight
-  f32x4 xg[2][AG_NODE_GRP];
+  static_assert((AG_CONV_NCH / AG_NODE_GRP) % AG_NODE_XD == 0 && AG_NODE_XD >= 2, "ring of x buffers");
+  f32x4 xg[AG_NODE_XD][AG_NODE_GRP];
   uint32_t xoff[4];
   auto set_xoff = [&]() {
 #pragma unroll
@@ -159,6 +163,10 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
         else xg[kb][j][r] = *reinterpret_cast<const float*>(xb + (size_t)xoff[r] + 64 * (AG_NODE_GRP * g + j));
       }
     }
+  };
+  // the first AG_NODE_XD - 1 x groups of a radius tile (requested before the tile starts)
+  auto fetch_first_groups = [&]() {
+    ag_static_for<0, AG_NODE_XD - 1>([&](auto G) { fetch_xg(G, decltype(G)::value); });
   };
   const lds_u32x4* wl_l = wl + lane;
   // CN channel tiles C0 .. C0 + CN - 1 of one coefficient set (pk [12][NKT]: block nt * NKT + t) times the features:
@@ -254,7 +262,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
       prefetch_meta(rows, loc);
       if (!loc) {                               // (a local tile fetches its own x values and evaluates its own features)
         set_xoff();
-        fetch_xg(std::integral_constant<int, 0>{}, 0);
+        fetch_first_groups();
         next_features();
       }
     }
@@ -300,7 +308,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             if ((AG_NODE_ABL & 8) && r) continue;
-            acc[AG_NODE_GRP * gg + jj] = fmaf(z[jj][r], xg[gg & 1][jj][r], acc[AG_NODE_GRP * gg + jj]);
+            acc[AG_NODE_GRP * gg + jj] = fmaf(z[jj][r], xg[gg % AG_NODE_XD][jj][r], acc[AG_NODE_GRP * gg + jj]);
           }
           // (pins the sum to this step: the optimiser otherwise sinks all 48 FMAs of a tile below its last MFMA -- nothing
           // needs acc before the target is complete -- and the wave then waits for x loads and MFMAs with nothing to do)
@@ -311,7 +319,8 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
       // (fences between the steps: the scheduler otherwise hoists every group's coefficient reads to the top of the tile and
       // spills; inside a step it is free to run the sums beside the MFMAs)
       AG_NSTAMP(t0);
-      fetch_xg(std::integral_constant<int, 1>{}, 1);
+      constexpr int XD = AG_NODE_XD;
+      fetch_xg(std::integral_constant<int, XD - 1>{}, XD - 1);
       mma_g(std::integral_constant<int, 0>{}, z[0]);
       __builtin_amdgcn_sched_barrier(0);
       AG_NSTAMP(t1);
@@ -319,12 +328,14 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
         constexpr int g = decltype(G)::value;
         mma_g(G, z[g & 1]);
         sums(std::integral_constant<int, g - 1>{}, z[(g - 1) & 1]);
-        if constexpr (g + 1 < NG) {
-          fetch_xg(std::integral_constant<int, (g + 1) & 1>{}, g + 1);     // (into the buffer the sums have just freed)
-        } else if (has_next && !nloc) {          // (all of this tile's gathers are out: xoff is free)
-          set_xoff();
-          fetch_xg(std::integral_constant<int, 0>{}, 0);
-          next_features();
+        // the buffer the sums have just freed takes the group XD - 1 steps ahead: of this tile, or -- once all of this tile's
+        // gathers are out and xoff is free -- of the wave's next radius tile (whose features follow the last request)
+        if constexpr (g + XD - 1 < NG) {
+          fetch_xg(std::integral_constant<int, (g - 1) % XD>{}, g + XD - 1);
+        } else if (has_next && !nloc) {
+          if constexpr (g + XD - 1 == NG) set_xoff();
+          fetch_xg(std::integral_constant<int, (g - 1) % XD>{}, g + XD - 1 - NG);
+          if constexpr (g == NG - 1) next_features();
         }
         __builtin_amdgcn_sched_barrier(0);
       });
@@ -416,11 +427,13 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
       }
       if (has_next && !nloc) {
         set_xoff();
-        fetch_xg(std::integral_constant<int, 0>{}, 0);
+        fetch_first_groups();
         next_features();
-      } else {                                  // (definite writes: keep the buffer and the features out of this tile's live registers)
+      } else {                                  // (definite writes: keep the buffers and the features out of this tile's live registers)
 #pragma unroll
-        for (int jj = 0; jj < AG_NODE_GRP; ++jj) xg[0][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < AG_NODE_XD - 1; ++b)
+#pragma unroll
+          for (int jj = 0; jj < AG_NODE_GRP; ++jj) xg[b][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
         const u32x4 zero = {0u, 0u, 0u, 0u};
         u32x4 zz[2] = {zero, zero};
 #pragma unroll
@@ -484,7 +497,7 @@ extern "C" int agdiff_cfconv_node(const agdiff_params_t* p, const agdiff_topo_t*
   if (!ws->rad_cnt || !ws->rad_src || !ws->rad_len || !ws->r_scale || !ws->xs || !ws->agg) return AGDIFF_ERR_ARG;
   if (topo->num_nodes <= 0) return AGDIFF_OK;
   if (topo->num_nodes * (int64_t)AGDIFF_RAD_STRIDE >= (1ll << 31)) return AGDIFF_ERR_LIMIT;
-  const bool local = topo->num_local > 0 && agdiff_local_poly_enabled(p, topo, ws);
+  const bool local = topo->num_local > 0 && agdiff_local_poly_enabled(p, topo, ws) != 0;   // (1 all, 2 the slotted types' edges)
   if (local && !p->conv[k].filt_poly_typed_pk) return AGDIFF_ERR_ARG;
   NodeConvArgs a;
   a.poly_rad = p->conv[k].filt_poly_pk;

@@ -217,6 +217,7 @@ class DualEncoderEpsNetwork(nn.Module):
         # kernel-variant thresholds (PackedParams.set_tuning; include/agdiff_hip.h: agdiff_params_t.tune_*), e.g.
         # model.tuning["node_ldsw_min_tiles"] = 1 -- tests reach every variant on small fixtures this way
         self.tuning = {}
+        self.poly_refuse_types = ()          # (tests: local edge types to treat as if their polynomial fit had been refused)
         self._packed = None
         self._packed_key = None
         self._batch_cache = None
@@ -234,14 +235,15 @@ class DualEncoderEpsNetwork(nn.Module):
         return _lib.load()
 
     def _weights_key(self):
-        return (str(self._device()), self.precision, self.radius_poly) + tuple(int(p._version) for p in self.state_dict(keep_vars=True).values())
+        return (str(self._device()), self.precision, self.radius_poly, tuple(self.poly_refuse_types)) + tuple(int(p._version) for p in self.state_dict(keep_vars=True).values())
 
     def packed(self):
         """Packed device weights, rebuilt when any parameter / buffer changed (load_state_dict, .to)."""
         key = self._weights_key()
         if self._packed is None or self._packed_key != key:
             sd = {k: v for k, v in self.state_dict().items()}
-            self._packed = PackedParams(sd, self.config, self._device(), self.precision, self.radius_poly)
+            self._packed = PackedParams(sd, self.config, self._device(), self.precision, self.radius_poly,
+                                        refuse_types=self.poly_refuse_types)
             self._packed_key = key
         self._packed.set_tuning(**{k: self.tuning.get(k, 0) for k in PackedParams.TUNING})
         return self._packed

@@ -310,7 +310,7 @@ EDGE_ENCODERS = {"mlp": 0, "gaussian": 1}       # agdiff_params_t.edge_encoder
 class PackedParams:
     """Owns the device copies of all packed weights and the agdiff_params_t that points at them."""
 
-    def __init__(self, sd, cfg, device, precision="f32", radius_poly="auto"):
+    def __init__(self, sd, cfg, device, precision="f32", radius_poly="auto", refuse_types=()):
         """radius_poly: "auto" -- radius edges take their filters from d-polynomials when the fit is accepted
         (radius_polynomials above), and so do the local edges, per type (ensure_local_types); "off" -- every edge goes
         through the encoder + filter MLPs; "radius" -- polynomials for the radius edges only; "kt2" -- as "auto" but
@@ -325,7 +325,9 @@ class PackedParams:
         self._sd, self._cfg, self._mode = sd, cfg, PRECISIONS.get(precision, 0)
         self.local_slots, self._typed_mats = {}, {}
         self._typed_ok = self.poly_kt >= 1 and radius_poly != "radius"
-        self.poly_refused_type = None
+        # local edge types without a slot (fit refused / slots full): filter MLPs for them.  `refuse_types` seeds the set
+        # (tests of the mixed path: a type is treated as if its fit had missed POLY_TOL)
+        self.poly_refused_types = set(int(t) for t in refuse_types)
         self.typed_flat = self.slot_table = None
         if precision not in PRECISIONS:
             raise ValueError("precision must be one of %s" % (list(PRECISIONS),))
@@ -512,28 +514,32 @@ class PackedParams:
         """Give every local edge type of a batch (BatchTopology.local_types) a filter-polynomial slot, so that
         agdiff_cfconv_node needs no edge_attr for the local edges either (include/agdiff_hip.h: poly_num_slots).  Slots are
         kept in order of first appearance (the first ones that fit stay LDS-resident in the kernel, later ones are read
-        from L2), fitted with the radius edges' number of terms (poly_kt).  A type whose fit misses POLY_TOL, or more than
-        AGDIFF_POLY_MAX_SLOTS types in all, switches the local polynomials off for THIS model (poly_num_slots = 0): the
-        local edges then go through the filter MLPs (agdiff_cfconv_local); the radius edges keep their polynomials."""
+        from L2), fitted with the radius edges' number of terms (poly_kt).  A type whose fit misses POLY_TOL, or a type beyond
+        AGDIFF_POLY_MAX_SLOTS, gets no slot: ITS edges go through the filter MLPs (agdiff_cfconv_local, in a "mixed" batch
+        next to agdiff_cfconv_node's polynomial tiles for the slotted types); everything else keeps its polynomials.
+        Returns True when every type of `types` has a slot."""
         import torch
         if not self._typed_ok:
             return False
-        new = [int(t) for t in types if int(t) not in self.local_slots]
+        new = [int(t) for t in types if int(t) not in self.local_slots and int(t) not in self.poly_refused_types]
         if not new:
-            return True
+            return not any(int(t) in self.poly_refused_types for t in types)
         prm = self.struct
         max_slots = _lib.DEFINES["AGDIFF_POLY_MAX_SLOTS"]
         kt = self.poly_kt
+        added = False
         for t in new:
             mats, err = fit_type(self._sd, self._cfg, t, kt, False)
             self.poly_errors["type%d" % t] = err
             if err > POLY_TOL or len(self.local_slots) >= max_slots:
-                self._typed_ok = False
-                self.poly_refused_type = t
-                prm.poly_num_slots = 0
-                return False
+                # THIS type keeps the filter MLPs (agdiff_cfconv_local in a mixed batch); the slotted ones keep their polynomials
+                self.poly_refused_types.add(t)
+                continue
             self.local_slots[t] = len(self.local_slots)
             self._typed_mats[t] = mats
+            added = True
+        if not added:
+            return not any(int(t) in self.poly_refused_types for t in types)
         by_slot = sorted(self.local_slots, key=self.local_slots.get)
         nc = self._cfg.num_convs
         per_conv = [np.concatenate([pack_blocks(self._typed_mats[t]["conv%d.filt_poly_pk" % k], mode=self._mode) for t in by_slot])
@@ -553,7 +559,12 @@ class PackedParams:
             prm.conv[k].filt_poly_typed_pk = ctypes.c_void_p(self.typed_flat.data_ptr() + 4 * stride * k)
         prm.poly_type_slot = ctypes.c_void_p(self.slot_table.data_ptr())
         prm.poly_num_slots = len(by_slot)
-        return True
+        sm = [0, 0]
+        for t in self.local_slots:
+            sm[t >> 6] |= 1 << (t & 63)
+        for w in (0, 1):
+            prm.poly_slot_mask[w] = sm[w] - (1 << 64) if sm[w] >= (1 << 63) else sm[w]
+        return not any(int(t) in self.poly_refused_types for t in types)
 
     TUNING = ("share_rows_min_nodes", "node_ldsw_min_tiles", "node_split_max_tiles", "serial_branches", "local_poly_off",
               "attr_poly_off", "poly_lds_sets")

@@ -179,6 +179,11 @@ class BatchTopology:
         t.num_local_canon = self.Lc
         t.num_local_padded = self.Lp
         t.num_local_tiles = self.T
+        tm = [0, 0]
+        for ty in self.local_types:
+            tm[int(ty) >> 6] |= 1 << (int(ty) & 63)
+        for w in (0, 1):
+            t.local_type_mask[w] = tm[w] - (1 << 64) if tm[w] >= (1 << 63) else tm[w]
         for f in ("graph_ptr", "atom_type", "loc_src", "loc_dst", "loc_type", "loc_out_ptr", "loc_in_ptr", "loc_in_eid",
                   "lc_src", "lc_dst", "lc_type", "lc_pos", "lc_mir", "loc_row", "loc_in_src",
                   "loc_in_row", "lp_ptr", "lp_src", "lp_dst", "lp_type", "lp_row", "lc_ppos", "lc_pmir",

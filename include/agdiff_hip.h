@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 28
+#define AGDIFF_ABI_VERSION 29
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -148,7 +148,10 @@ typedef struct agdiff_params {
   int32_t edge_encoder;      /* config.edge_encoder: 0 'mlp' (edge.py:45-103), 1 'gaussian' (edge.py:17-42) */
   float ge_coeff;            /* -0.5 / (offset[1] - offset[0])^2 (schnet.py:22) */
   int32_t poly_num_slots;    /* 0, or 1..AGDIFF_POLY_MAX_SLOTS: local edge types whose CFConv filters are d-polynomials too
-                                (every type the host has met in a batch so far); 0 sends the local edges through the filter MLPs */
+                                (the types the host has met in batches so far and whose fit it accepted); 0 sends the local
+                                edges through the filter MLPs.  A batch that brings a type without a slot (fit refused, or more
+                                than AGDIFF_POLY_MAX_SLOTS types) runs MIXED: the slotted types' edges by polynomials inside
+                                agdiff_cfconv_node, the others through agdiff_cfconv_local (topo->local_type_mask tells) */
   int32_t pad1;
   int32_t poly_kt;           /* 0: off.  1..AGDIFF_POLY_MAX_KT: radius edges (type 0: no bond embedding; d < cutoff by
                                 construction) take their CFConv filters and the edge_attr half of the global head's first layer
@@ -161,6 +164,7 @@ typedef struct agdiff_params {
                                 quarter q in k-tile t is phi[8 (4 t + q) + j], and the packed blocks are ordered to match. */
   /* Kernel-variant thresholds: batch-size crossovers measured on MI355X.  0 selects the library default in
    * brackets; tests set them to reach every variant on small fixtures, agdiff_ws_t.variant_log reports what ran. */
+  int64_t poly_slot_mask[2]; /* bit t of the 128-bit mask: edge type t has a slot in poly_type_slot */
   int64_t tune_share_rows_min_nodes;  /* [8192] batches with at least this many atoms take the local edges' edge_attr rows from
                                          the global encoder pass (ws->e_loc) instead of a pass over the canonical local list */
   int64_t tune_node_ldsw_min_tiles;   /* [1536] node stage / GIN layer: from this many 16-node tiles on, workgroups share the
@@ -235,6 +239,7 @@ typedef struct agdiff_topo {
    * pair p holds local in-edges [8 t, 8 t + 8) of target 2 p in rows 0..7 and of target 2 p + 1 in rows 8..15 (pad rows:
    * src = the target itself, the type of a real row, and nothing ever writes their CFConv scale: they contribute exactly 0),
    * so that the rows of one lane quarter belong to ONE target and the sum over a target's edges needs no masks */
+  int64_t local_type_mask[2];/* bit t of the 128-bit mask: the batch has a local edge of type t */
   int64_t num_local_tiles;   /* T = lt_ptr[ceil(N/2)] */
   const int32_t* lt_ptr;     /* [ceil(N/2) + 1]: tiles of pair p are [lt_ptr[p], lt_ptr[p+1]) */
   const int32_t* lt_src;     /* [16 T] */
@@ -413,9 +418,12 @@ int agdiff_cfconv_fused(const agdiff_params_t* p, const agdiff_topo_t* topo, con
  * agdiff_edge_scales_split fills ws->r_scale and the radius pad rows (which == 0), ws->l_scale (1) or ws->lt_scale (2). */
 int agdiff_cfconv_node(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k, void* stream);
 int agdiff_cfconv_local(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k, void* stream);
-/* 1 when agdiff_cfconv_node takes the local edges' filters from per-type d-polynomials (p->poly_num_slots > 0,
- * topo->lt_*, ws->lt_len, ws->lt_scale, not switched off by p->tune_local_poly_off), 0 when agdiff_cfconv_local
- * evaluates the filter MLPs on ws->l_attr_frag. */
+/* How the local edges' CFConv filters are evaluated for this (model, batch):
+ *   1  all by per-type d-polynomials inside agdiff_cfconv_node (every local type of the batch has a slot; topo->lt_*,
+ *      ws->lt_len, ws->lt_scale present; not switched off by p->tune_local_poly_off);
+ *   2  mixed: the slotted types as in 1, the others by agdiff_cfconv_local (filter MLPs on ws->l_attr_frag, where
+ *      agdiff_edge_scales_split(which = 1) leaves the slotted types' scales at 0);
+ *   0  all by agdiff_cfconv_local. */
 int agdiff_local_poly_enabled(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws);
 int agdiff_edge_scales_split(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t which,
                              void* stream);

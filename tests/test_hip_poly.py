@@ -79,17 +79,19 @@ def test_forward_every_filter_mode(case, mode, precision):
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
-@pytest.mark.parametrize("mode", MODES + ["auto-l2"])
+@pytest.mark.parametrize("mode", MODES + ["auto-l2", "auto-mixed"])
 @pytest.mark.parametrize("case", ["g5_sampler_lowT_global", "g5_sampler_mixed_cliplocal"])
 def test_sampler_every_filter_mode(case, mode, precision):
     """The denoising loop (polynomial global head on the radius edges in every mode but `off`)."""
     from agdiff_amd import _lib
-    l2 = mode == "auto-l2"
-    mode = "auto" if l2 else mode
+    l2, mixed = mode == "auto-l2", mode == "auto-mixed"
+    mode = "auto" if (l2 or mixed) else mode
     g = load_golden(case)
     m = _model(sampler_case_cfg(g, case), mode, head_scale=float(g["head_scale"]), precision=precision)
     if l2:
         m.tuning["poly_lds_sets"] = 1
+    if mixed:      # the 2-hop edges (type 23) as if their fit had been refused: THEY go through the filter MLPs, the other local
+        m.poly_refuse_types = (23,)      # types and the radius edges keep their polynomials (a "mixed" batch)
     pos, traj = m.langevin_dynamics_sample_diffusion(
         t(g["atom_type"]).cuda(), t(g["pos_init"]).cuda(), t(g["bond_index"]).cuda(), t(g["bond_type"]).cuda(),
         t(g["batch"]).cuda(), int(g["num_graphs"]), extend_order=False, n_steps=int(g["n_steps"]),
@@ -99,7 +101,9 @@ def test_sampler_every_filter_mode(case, mode, precision):
     if "lowT" in case:        # the global branch ran: which CFConv did?
         assert bool(var & V["AGDIFF_VAR_CFCONV_NODE"]) == (mode != "off") and bool(var & V["AGDIFF_VAR_CFCONV_FUSED"]) == (mode == "off")
         assert bool(var & V["AGDIFF_VAR_CFCONV_NODE_LOCAL"]) == (mode in ("auto", "kt2"))
-        assert bool(var & V["AGDIFF_VAR_CFCONV_LOCAL_MLP"]) == (mode == "radius")
+        assert bool(var & V["AGDIFF_VAR_CFCONV_LOCAL_MLP"]) == (mode == "radius" or mixed)
+        if mixed:
+            assert 23 in m.packed().poly_refused_types and 23 not in m.packed().local_slots and m.packed().struct.poly_num_slots > 0
         if mode != "kt2":     # (two-k-tile sets are 48 KiB: two typed ones fit next to the radius edges', the rest come from L2)
             assert bool(var & V["AGDIFF_VAR_POLY_L2_SETS"]) == l2
     check_close("poly[%s] traj[%s]" % (mode, case), torch.stack(traj).numpy(), g["traj"], precision)
@@ -183,6 +187,44 @@ def test_node_cfconv_equals_one_list_kernel(kind, mols, copies):
             pk.set_tuning(local_poly_off=0)
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_sharper_first_layer_takes_64_terms_at_bench_scale(precision):
+    """a feature_expansion layer 8 x sharper than the synthetic checkpoint's is not a 32-term polynomial
+    at 1e-6 but a 64-term one: in mode `auto` the radius edges AND every local type run on two-k-tile sets (48 KiB each:
+    two typed sets LDS-resident, the rest from L2), no MLP filter anywhere, on a batch past every small-batch threshold
+    (>= 12,288 atoms); three denoising steps against the oracle."""
+    from agdiff_amd import _lib, drugs_model_config, get_model, synth
+    from oracle import agdiff_oracle as O
+    cfg = drugs_model_config(num_diffusion_timesteps=30, beta_end=2e-5)
+    sd = O.synth_state_dict_for(cfg)
+    for k in ("edge_encoder_global.feature_expansion.weight", "model_global.0.feature_expansion.weight"):
+        sd[k] = sd[k] * 8.0             # (Drugs config: 5 x still passes at 32 terms with 8e-7; 8 x gives 7e-6 / 4e-10)
+    m = get_model(cfg)
+    m.precision = precision
+    m.load_state_dict({k: v.clone() for k, v in sd.items()})
+    m = m.to("cuda:0").eval()
+    b = synth.make_packed_batch("drugs", 6, 56, seed=41)
+    at, bi, bt, ba = [t(b[k]) for k in ("atom_type", "bond_index", "bond_type", "batch")]
+    assert at.shape[0] >= 12288
+    g = torch.Generator().manual_seed(13)
+    pos_init, noise = torch.randn(at.shape[0], 3, generator=g), torch.randn(3, at.shape[0], 3, generator=g)
+    kw = dict(extend_order=False, n_steps=3, w_global=1.0, global_start_sigma=0.5, clip=1000.0)
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(max(nthr, 16))
+    try:
+        ref, _ = O.langevin_dynamics_sample_diffusion(sd, cfg, at, pos_init, bi, bt, ba, b["num_graphs"], noise=noise, **kw)
+    finally:
+        torch.set_num_threads(nthr)
+    got, _ = m.langevin_dynamics_sample_diffusion(at.cuda(), pos_init.cuda(), bi.cuda(), bt.cuda(), ba.cuda(),
+                                                  b["num_graphs"], noise=noise.cuda(), **kw)
+    pk, var, V = m.packed(), _variants(m._batch_cache[2]), _lib.DEFINES
+    assert pk.poly_kt == 2 and pk.poly_errors[1] > 1e-6 >= pk.poly_errors[2], pk.poly_errors
+    assert pk.struct.poly_num_slots == len(m._batch_cache[1].local_types) and not pk.poly_refused_types
+    assert var & V["AGDIFF_VAR_CFCONV_NODE_LOCAL"] and var & V["AGDIFF_VAR_HEAD_POLY"] and var & V["AGDIFF_VAR_POLY_L2_SETS"]
+    assert not var & (V["AGDIFF_VAR_CFCONV_LOCAL_MLP"] | V["AGDIFF_VAR_CFCONV_FUSED"])
+    check_close("sharper_first_layer_kt2 sampler", got.cpu().numpy(), ref.numpy(), precision)
+
+
 def test_rejected_fit_falls_back_to_the_mlps():
     """A first layer too sharp for 64 terms at 1e-6: the polynomials are refused at load time and every edge goes through
     the encoder + filter MLPs; results still match the oracle."""
@@ -219,9 +261,9 @@ def _chain_with_bond_types(n_types):
 @pytest.mark.parametrize("n_types,slots_kept", [(8, True), (17, False)])
 def test_many_local_edge_types(n_types, slots_kept):
     """Eight distinct bond types in one batch: more than the five typed coefficient sets that fit in LDS next to the radius
-    edges' one -- the later types' sets are read from L2 by the tiles that meet them; seventeen: more than
-    AGDIFF_POLY_MAX_SLOTS (16) -- the local list goes through the filter MLPs, the radius edges keep their polynomials.
-    Both against the oracle."""
+    edges' one -- the later types' sets are read from L2 by the tiles that meet them; seventeen: one more than
+    AGDIFF_POLY_MAX_SLOTS -- the seventeenth type's edges go through the filter MLPs (a "mixed" batch), the sixteen
+    slotted types and the radius edges keep their polynomials.  Both against the oracle."""
     from agdiff_amd import _lib, get_model, qm9_model_config
     from oracle import agdiff_oracle as O
     cfg = qm9_model_config(num_diffusion_timesteps=30, beta_end=2e-5)
@@ -238,9 +280,10 @@ def test_many_local_edge_types(n_types, slots_kept):
     got, _ = m.langevin_dynamics_sample_diffusion(at.cuda(), pos_init.cuda(), bi.cuda(), bt.cuda(), ba.cuda(), 1,
                                                   noise=noise.cuda(), **kw)
     pk, var, V = m.packed(), _variants(m._batch_cache[2]), _lib.DEFINES
-    assert pk.poly_kt == 1 and pk.struct.poly_num_slots == (n_types if slots_kept else 0)
-    assert bool(var & V["AGDIFF_VAR_POLY_L2_SETS"]) == slots_kept and bool(var & V["AGDIFF_VAR_CFCONV_LOCAL_MLP"]) == (not slots_kept)
-    assert var & V["AGDIFF_VAR_CFCONV_NODE"]
+    assert pk.poly_kt == 1 and pk.struct.poly_num_slots == min(n_types, V["AGDIFF_POLY_MAX_SLOTS"])
+    assert pk.poly_refused_types == (set() if slots_kept else {17})
+    assert var & V["AGDIFF_VAR_POLY_L2_SETS"] and var & V["AGDIFF_VAR_CFCONV_NODE_LOCAL"]
+    assert bool(var & V["AGDIFF_VAR_CFCONV_LOCAL_MLP"]) == (not slots_kept)      # the seventeenth type alone takes the MLPs
     check_close("many_local_types[%d] sampler" % n_types, got.cpu().numpy(), ref.numpy(), "bf16x3")
 
 
