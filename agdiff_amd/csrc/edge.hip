@@ -36,7 +36,8 @@ struct EncArgs {
   const int32_t* pos_index;   // optional (with mir_index): edge e's results go to positions pos_index[e] and, if
   const int32_t* mir_index;   // >= 0, mir_index[e] of out_frag / row_index instead of position e
   int64_t max_tiles;
-  const int32_t* tile_flags;  // optional: [0] = number of tiles to do (0: the launch returns at once), [1 + tile] != 0: do it
+  const int32_t* tile_flags;  // optional: [0] = number of tiles to do (0: the launch returns at once), [1 + tile] = 16-bit mask of
+                              // the tile's rows to evaluate and store (0: skip the tile)
 };
 
 // Where one edge's results go (shared by the encoder kernels).
@@ -107,12 +108,15 @@ __global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_edge_encoder(EncAr
   const int64_t stride = (int64_t)gridDim.x * AG_PERSIST_WAVES;
   for (int64_t tile = (int64_t)blockIdx.x * AG_PERSIST_WAVES + (threadIdx.x >> 6); tile < a.max_tiles; tile += stride) {
     if (tile * AG_TW >= E) break;
-    if (a.tile_flags && a.tile_flags[1 + tile] == 0) continue;
+    const int row_mask = a.tile_flags ? a.tile_flags[1 + tile] : 0xFFFF;
+    if (row_mask == 0) continue;
     int lane = lane0;
     asm volatile("" : "+v"(lane));      // keep lane-derived addresses out of the loop-invariant set
     const int q = lane >> 4;
     const int64_t e = tile * AG_TW + (lane & 15);
-    const bool valid = e < E;
+    // (flagged mode: only the flagged rows are stored -- what an edge's row holds depends on that edge alone, never on
+    // which other edges share its tile)
+    const bool valid = e < E && ((row_mask >> (lane & 15)) & 1);
     const float d = valid ? a.e_len[e] : 0.0f;
     const int ty = valid ? a.e_type[e] : 0;
 
@@ -864,22 +868,22 @@ __global__ void __launch_bounds__(64 * AG_ATTRP_WAVES, 2) k_edge_attr_poly(AttrP
     // rewritten into comparisons that a NaN passes)
     const bool is_nan = (__float_as_uint(d) & 0x7FFFFFFFu) > 0x7F800000u;
     const bool hard = valid && (is_nan || d < 0.0f || d > a.cutoff || slot < 0);
-    if (__ballot(hard)) {
-      if (lane == 0) a.flags[1 + tile] = 1;
-      ++my_flagged;
-      continue;
-    }
-    if (lane == 0) a.flags[1 + tile] = 0;
+    // rows the polynomials do not cover (longer than the cutoff, a type without a slot) are left to the encoder MLP: the
+    // tile's flag word is the mask of those rows, everything else is stored here -- per edge, whatever its tile-mates are
+    const int hard_rows = (int)(__ballot(hard) & 0xFFFFull);
+    if (lane == 0) a.flags[1 + tile] = hard_rows;
+    if (hard_rows) ++my_flagged;
+    if (hard_rows == (int)(__ballot(valid) & 0xFFFFull)) continue;        // nothing for the polynomials in this tile
     AgIn<MODE> phall[1], ph[1];
     ag_poly_features<MODE, 1>(d, a.two_over_rc, q, phall);
     f32x4 y[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) y[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const lds_u32x4* wl_l = ag_lds_base(wl, lane);
-    uint64_t todo = __ballot(slot >= 0) & 0xFFFFull;
+    uint64_t todo = __ballot(slot >= 0 && !hard) & 0xFFFFull;
     while (todo) {
       const int g = __builtin_amdgcn_readlane(slot, (int)__builtin_ctzll(todo));
-      const bool in = slot == g;
+      const bool in = slot == g && !hard;
       todo &= ~__ballot(in);
       const u32x4 zero = {0u, 0u, 0u, 0u};
       if constexpr (MODE == AG_F32) {
@@ -902,7 +906,7 @@ __global__ void __launch_bounds__(64 * AG_ATTRP_WAVES, 2) k_edge_attr_poly(AttrP
         for (int ot = 0; ot < 8; ++ot) ag_block_mma_part<MODE, false>(y[ot], ph[0], w[ot], part);
       }
     }
-    if (valid) ag_store_row<8, 0>(y, a.out_rows + (size_t)e * 128, q);
+    if (valid && !hard) ag_store_row<8, 0>(y, a.out_rows + (size_t)e * 128, q);
   }
   // flagged tiles of the launch: one atomic per workgroup (a count of integers: the order does not matter)
   if (lane0 == 0 && my_flagged) atomicAdd(&wg_flagged, my_flagged);

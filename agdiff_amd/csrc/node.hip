@@ -592,6 +592,12 @@ __global__ void __launch_bounds__(1024) k_langevin_update(UpdateArgs a) {
   __shared__ int nanw[16];
   float sx = 0.f, sy = 0.f, sz = 0.f;
   int bad = 0;
+  // A graph in which a NaN has appeared is QUARANTINED from then on (sticky flag, cleared by the host when a job starts):
+  // its positions are replaced by a finite placeholder geometry and no longer updated, so that no NaN ever enters another
+  // forward -- graphs are independent by construction, but a 0 x NaN in a masked sum of a kernel whose 16-edge tile spans
+  // two graphs would not be.  The reference stops the whole job at this step (dualenc.py:539-541); here the host raises at
+  // its next poll of nan_flag[0], or re-samples the flagged molecules (agdiff_amd/driver.py).
+  const int was_bad = a.nan_flag[1 + g];
   const int P = a.parts, part = threadIdx.x & (P - 1);
   const int per_pass = blockDim.x / P;
   // pass 1: new (uncentred) positions into scratch, per-thread partial sums for the centroid
@@ -764,6 +770,7 @@ __global__ void __launch_bounds__(1024) k_langevin_update(UpdateArgs a) {
     a.nan_flag[0] = 1;
     a.nan_flag[1 + g] = 1;       // per graph: the driver re-samples only the molecules that diverged (test.py:143-181)
   }
+  const bool frozen = was_bad || anybad;
   for (int li = threadIdx.x; li < n; li += blockDim.x) {
     const int i = g0 + li;
     float x = a.s.scratch[3 * i] - cx, y = a.s.scratch[3 * i + 1] - cy, z = a.s.scratch[3 * i + 2] - cz;
@@ -772,8 +779,14 @@ __global__ void __launch_bounds__(1024) k_langevin_update(UpdateArgs a) {
       y = fminf(fmaxf(y, -a.s.clip_pos), a.s.clip_pos);
       z = fminf(fmaxf(z, -a.s.clip_pos), a.s.clip_pos);
     }
+    float tx = x, ty = y, tz = z;
+    if (frozen) {          // placeholder: a centred straight chain, 1.5 apart (finite, no two atoms at one place)
+      x = ((float)li - 0.5f * (float)(n - 1)) * 1.5f;
+      y = z = 0.0f;
+      tx = ty = tz = __uint_as_float(0x7FC00000u);       // the trajectory shows the graph as lost
+    }
     a.s.pos_out[3 * i] = x; a.s.pos_out[3 * i + 1] = y; a.s.pos_out[3 * i + 2] = z;
-    if (a.s.traj_out) { a.s.traj_out[3 * i] = x; a.s.traj_out[3 * i + 1] = y; a.s.traj_out[3 * i + 2] = z; }
+    if (a.s.traj_out) { a.s.traj_out[3 * i] = tx; a.s.traj_out[3 * i + 1] = ty; a.s.traj_out[3 * i + 2] = tz; }
   }
 }
 

@@ -487,6 +487,7 @@ class LangevinRun:
         self.raise_on_nan = bool(raise_on_nan)
         self.k = 0
         self.ws.nan_flag.zero_()
+        self._quarantine_non_finite_input()
         self.pos_p = _lib.ptr(self.pos)
         a = _lib.StepArgs()
         a.pos_in = self.pos_p
@@ -505,6 +506,22 @@ class LangevinRun:
         step = self.step_lr * (sig / 0.01) ** 2
         self._sched = list(zip(sig.tolist(), step.tolist(), torch.sqrt(step * 2).tolist(),
                                (sig < self.global_start_sigma).tolist()))
+
+    def _quarantine_non_finite_input(self):
+        """Graphs whose INITIAL positions hold a NaN / inf are flagged like graphs that diverge later (k_langevin_update) and
+        get the same finite placeholder geometry, so that no non-finite value ever enters a forward (device ops only: no
+        host synchronisation; the reference would raise at the end of its first step, dualenc.py:539-541)."""
+        topo, G, N = self.topo, self.topo.G, self.topo.N
+        bad_node = ~torch.isfinite(self.pos).all(dim=1)
+        bad_graph = torch.zeros(G, dtype=torch.int32, device=self.pos.device).index_add_(0, topo.batch64, bad_node.to(torch.int32)) > 0
+        self.ws.nan_flag[1:1 + G] |= bad_graph.to(torch.int32)
+        self.ws.nan_flag[0:1] |= bad_graph.any().to(torch.int32).reshape(1)
+        gp = topo.graph_ptr.long()
+        n_of = (gp[1:] - gp[:-1])[topo.batch64].to(torch.float32)
+        li = (torch.arange(N, device=self.pos.device) - gp[:-1][topo.batch64]).to(torch.float32)
+        chain = torch.zeros_like(self.pos)
+        chain[:, 0] = (li - 0.5 * (n_of - 1.0)) * 1.5
+        self.pos.copy_(torch.where(bad_graph[topo.batch64].unsqueeze(1), chain, self.pos))
 
     def remaining(self):
         return len(self.steps) - self.k

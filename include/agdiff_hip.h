@@ -318,7 +318,8 @@ typedef struct agdiff_ws {
   int32_t* g_deg;            /* [N] in-degrees */
   int32_t* g_cdeg;           /* [N] canonical in-degrees */
   int32_t* enc_flags;        /* [1 + ceil(Lc/16)]: agdiff_local_edge_rows: [0] = tiles of the canonical local list that hold an edge
-                                longer than the cutoff this step (they go through the encoder MLP), [1 + tile] = 1 for those */
+                                longer than the cutoff (or of a type without a polynomial) this step, [1 + tile] = the 16-bit mask
+                                of those rows: the encoder MLP evaluates exactly them, the polynomials all the others */
   float*   h0;               /* [N][128] cache of node stage 0's h (the atom embeddings: they do not depend on the positions) */
   float*   xs0;              /* [N][192] ... and of its xs (block 0's lin1 / BN / LeakyReLU outputs) */
   float*   agg_loc;          /* [N][192] CFConv aggregates over the local edges (agdiff_cfconv_local) */

@@ -88,6 +88,62 @@ def test_driver_resamples_only_the_diverging_molecule():
                                              packed["num_graphs"], extend_order=False, n_steps=3)
 
 
+@pytest.mark.parametrize("mode", ["auto", "radius", "off"])
+def test_a_graph_that_goes_nan_mid_run_never_touches_its_neighbours(mode):
+    """with raise_on_nan=False a diverged graph stays in the batch for the rest of the job.  One conformer's noise
+    turns NaN at step 3 of 150: from that update on the graph is quarantined (finite placeholder positions, sticky flag,
+    NaN in its trajectory rows), and every other graph ends bit for bit where a run without the fault puts it -- on the
+    polynomial path (`auto`) and with the local edges through the MLP kernel (`radius`); with every edge through the MLP
+    kernels (`off`: 16-edge tiles there span graph boundaries and sum with 0 / 1 masks, which a NaN would cross) within
+    rounding."""
+    from agdiff_amd import driver, get_model, qm9_model_config
+    from oracle import agdiff_oracle as O
+    cfg = qm9_model_config(num_diffusion_timesteps=150, beta_end=2e-5)
+    sd = O.synth_state_dict_for(cfg)
+    m = get_model(cfg)
+    m.radius_poly = mode
+    m.load_state_dict({k: v.clone() for k, v in sd.items()})
+    m = m.to("cuda:0").eval()
+    packed = driver.pack_batch(_three_molecules(seed=9), driver.num_confs("3"))
+    N, G, n_steps = packed["atom_type"].shape[0], packed["num_graphs"], 150
+    gen = torch.Generator().manual_seed(21)
+    pos_init, noise = torch.randn(N, 3, generator=gen), torch.randn(n_steps, N, 3, generator=gen)
+    a = [t(packed[k]).cuda() for k in ("atom_type", "bond_index", "bond_type", "batch")]
+    kw = dict(extend_order=False, n_steps=n_steps, w_global=1.0, global_start_sigma=0.5, clip=1000.0, raise_on_nan=False)
+
+    def run(nz):
+        r = m.begin_sampling(a[0], pos_init.cuda(), a[1], a[2], a[3], G, noise=nz.cuda(), **kw)
+        r.advance(r.remaining())
+        torch.cuda.synchronize()
+        return r.pos.cpu(), r.traj.cpu(), r.nan_graphs()
+    clean, ctraj, cbad = run(noise)
+    assert not cbad.any() and torch.isfinite(clean).all()
+    ba = t(packed["batch"])
+    victim = 4                                            # a graph in the middle of the batch
+    rows = (ba == victim).nonzero().flatten()
+    bad_noise = noise.clone()
+    bad_noise[3, rows[1], 2] = float("nan")
+    pos, traj, bad = run(bad_noise)
+    assert bad.tolist() == [g == victim for g in range(G)]
+    keep = ba != victim
+    if mode == "off":
+        # the one-list MLP CFConv sums a target's list over 16-edge tiles of the FULL edge list: when the victim's edge count
+        # changes, its neighbours' lists sit at other tile offsets and associate their fp32 sums differently (last-bit noise,
+        # as between any two batch compositions) -- no NaN, nothing beyond rounding
+        assert float((pos[keep] - clean[keep]).abs().max()) < 1e-6 * float(clean.abs().max())
+    else:
+        assert torch.equal(pos[keep], clean[keep]) and torch.equal(traj[:, keep], ctraj[:, keep])
+    assert torch.isfinite(pos).all()                      # the quarantined graph holds its placeholder, not NaN
+    assert torch.equal(traj[:3, ~keep], ctraj[:3, ~keep]) and torch.isnan(traj[3:, ~keep]).all()
+    # a NaN in the INITIAL positions is quarantined before the first forward
+    bad_init = pos_init.clone()
+    bad_init[rows[0], 0] = float("inf")
+    r = m.begin_sampling(a[0], bad_init.cuda(), a[1], a[2], a[3], G, noise=noise.cuda(), **kw)
+    r.advance(r.remaining())
+    assert r.nan_graphs().tolist() == [g == victim for g in range(G)]
+    assert torch.equal(r.pos.cpu()[keep], clean[keep]) or mode == "off"
+
+
 def test_all_gather_path_on_one_gpu_nccl_world1():
     """SURVEY §8e on hardware: process group 'nccl' (= RCCL) with one rank; StepAllGather as the sampler's on_step.
     Every step's gathered shard equals the positions of that step (the snapshot is taken on the compute stream before
