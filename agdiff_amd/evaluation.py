@@ -9,10 +9,10 @@ There is no CPU fallback.
 Data items are plain dicts (the reference uses PyG Data objects with an rdkit molecule):
     pos_ref [R*n, 3] or [R, n, 3], pos_gen [G*n, 3] or [G, n, 3], atom_type [n] (atomic numbers; hydrogens = 1 are
     removed like utils/chem.py:133-137 does with RemoveHs), smiles (optional; "." marks a disconnected molecule),
-    perms [P, m] (optional): the molecule's heavy-atom self-matches, e.g. from rdkit
-    `RemoveHs(mol).GetSubstructMatches(RemoveHs(mol), uniquify=False)`.  With them the matrix is rdkit's GetBestRMS;
-    without (identity only) symmetric molecules get an UPPER BOUND of it -- COV is then a lower bound, MAT an upper
-    bound, and the numbers are indicative only.
+    bond_index [2, e] + bond_type [e] (or edge_index / edge_type; 2-/3-hop entries are ignored): the molecule's bonds, from
+    which the heavy-atom self-matches GetBestRMS minimises over are enumerated here (heavy_atom_automorphisms) -- or
+    perms [P, m]: those matches given directly.  With neither only the identity mapping is tried and symmetric molecules
+    get an UPPER BOUND of GetBestRMS (COV a lower bound, MAT an upper bound).
 Force-field relaxation (use_force_field=True -> rdkit MMFF) is not available.
 """
 import ctypes
@@ -27,6 +27,107 @@ def _as_conformers(pos, n):
     import torch
     t = pos if hasattr(pos, "is_cuda") else torch.as_tensor(np.asarray(pos))
     return t.reshape(-1, n, 3).to(torch.float32)
+
+
+def heavy_atom_automorphisms(atom_type, bond_index, bond_type, max_perms=65536):
+    """The atom mappings rdkit's GetBestRMS minimises over (utils/chem.py:133-137, covmat.py:16-35): every match of the
+    hydrogen-free molecule onto itself, i.e. every automorphism of its heavy-atom graph that keeps atomic numbers and bond
+    types (rdkit: `RemoveHs(mol).GetSubstructMatches(RemoveHs(mol), uniquify=False)`; a molecule used as a query matches
+    atoms by atomic number and bonds by type, aromatic with aromatic).  Returns int32 [P, m] over the heavy atoms in
+    ascending index order (row 0 is the identity): perms[p][k] = image of heavy atom k.
+      atom_type  [n] atomic numbers (hydrogens = 1 are dropped)
+      bond_index [2, e], bond_type [e]  directed or undirected bond list; entries with type >= 22 (the 2-/3-hop edges of
+                 utils/transforms.py:12-71) and bonds to hydrogens are ignored
+    Colour refinement (1-WL over atom type and typed neighbourhoods) partitions the atoms first; a backtracking search then
+    maps atoms class by class, checking every bond to the atoms already placed.  Raises if the group has more than
+    `max_perms` elements (rdkit's own cap, maxMatches, is 1e6)."""
+    at = np.asarray(atom_type).reshape(-1).astype(np.int64)
+    heavy = np.nonzero(at != 1)[0]
+    m = int(heavy.size)
+    if m == 0:
+        raise ValueError("molecule without heavy atoms")
+    new_id = np.full(at.shape[0], -1, dtype=np.int64)
+    new_id[heavy] = np.arange(m)
+    bi = np.asarray(bond_index).reshape(2, -1).astype(np.int64)
+    bt = np.asarray(bond_type).reshape(-1).astype(np.int64)
+    adj = [dict() for _ in range(m)]                 # neighbour -> bond type
+    for (u, v), ty in zip(bi.T, bt):
+        if ty <= 0 or ty >= 22 or u == v:
+            continue
+        a, b = new_id[u], new_id[v]
+        if a < 0 or b < 0:
+            continue
+        adj[a][int(b)] = int(ty)
+        adj[b][int(a)] = int(ty)
+    colour = [int(at[h]) for h in heavy]
+    for _ in range(m):                               # 1-WL refinement to a fixed point
+        sig = [(colour[i], tuple(sorted((colour[j], ty) for j, ty in adj[i].items()))) for i in range(m)]
+        ids = {s_: k for k, s_ in enumerate(sorted(set(sig)))}
+        new = [ids[s_] for s_ in sig]
+        if len(set(new)) == len(set(colour)):
+            colour = new
+            break
+        colour = new
+    # visiting order: breadth first from the rarest colour class, so that every atom after the first of its component has
+    # a placed neighbour to be checked against
+    count = {c: colour.count(c) for c in set(colour)}
+    order, seen = [], [False] * m
+    for start in sorted(range(m), key=lambda i: (count[colour[i]], i)):
+        if seen[start]:
+            continue
+        queue = [start]
+        seen[start] = True
+        while queue:
+            i = queue.pop(0)
+            order.append(i)
+            for j in sorted(adj[i], key=lambda j: (count[colour[j]], j)):
+                if not seen[j]:
+                    seen[j] = True
+                    queue.append(j)
+    placed_nbrs = []                                  # for order[k]: its neighbours among order[:k]
+    pos_in_order = {a: k for k, a in enumerate(order)}
+    for k, i in enumerate(order):
+        placed_nbrs.append([(j, ty) for j, ty in adj[i].items() if pos_in_order[j] < k])
+    by_colour = {}
+    for i in range(m):
+        by_colour.setdefault(colour[i], []).append(i)
+    perms, image, used = [], [-1] * m, [False] * m
+
+    def place(k):
+        if k == m:
+            perms.append(list(image))
+            if len(perms) > max_perms:
+                raise ValueError("more than %d heavy-atom self-matches; pass a larger max_perms" % max_perms)
+            return
+        i = order[k]
+        nb = placed_nbrs[k]
+        if nb:          # candidates: the neighbours of an already placed neighbour's image
+            j0, ty0 = nb[0]
+            cands = [c for c, ty in adj[image[j0]].items() if ty == ty0]
+        else:
+            cands = by_colour[colour[i]]
+        for c in sorted(cands):
+            if used[c] or colour[c] != colour[i] or len(adj[c]) != len(adj[i]):
+                continue
+            if any(adj[c].get(image[j]) != ty for j, ty in nb):
+                continue
+            image[i], used[c] = c, True
+            place(k + 1)
+            image[i], used[c] = -1, False
+
+    import sys
+    lim = sys.getrecursionlimit()
+    if lim < m + 100:
+        sys.setrecursionlimit(m + 100)
+    try:
+        place(0)
+    finally:
+        sys.setrecursionlimit(lim)
+    out = np.asarray(perms, dtype=np.int32).reshape(-1, m)
+    ident = np.nonzero((out == np.arange(m)[None, :]).all(1))[0]
+    if ident.size and ident[0] != 0:                  # identity first
+        out[[0, ident[0]]] = out[[ident[0], 0]]
+    return out
 
 
 def get_rmsd_confusion_matrix(data, useFF=False, device="cuda"):
@@ -44,7 +145,13 @@ def get_rmsd_confusion_matrix(data, useFF=False, device="cuda"):
         raise ValueError("molecule without heavy atoms")
     m = int(heavy.size)
     idx = torch.from_numpy(heavy).to(device)
-    perms = data.get("perms") if isinstance(data, dict) else getattr(data, "perms", None)
+    get = (lambda k: data.get(k)) if isinstance(data, dict) else (lambda k: getattr(data, k, None))
+    perms = get("perms")
+    if perms is None:       # the molecule's own symmetry, as GetBestRMS finds it, when the item carries its bonds
+        b_idx = get("bond_index") if get("bond_index") is not None else get("edge_index")
+        b_typ = get("bond_type") if get("bond_type") is not None else get("edge_type")
+        if b_idx is not None and b_typ is not None:
+            perms = heavy_atom_automorphisms(at, b_idx, b_typ)
     P, pt = 0, None
     if perms is not None:
         pa = np.ascontiguousarray(np.asarray(perms, dtype=np.int32).reshape(-1, m))
@@ -165,7 +272,7 @@ class CovMatEvaluator(object):
 def main(argv=None):
     """python -m agdiff_amd.evaluation --samples samples_all.npz --refs refs.npz
     samples: `pos_gen_<i>` [G, n, 3] (agdiff_amd.driver output); refs: `pos_ref_<i>` [R, n, 3], `atom_type_<i>` [n],
-    optional `smiles_<i>`, `perms_<i>` [P, m].  Prints the COV / MAT table of the reference's eval_covmat.py."""
+    optional `smiles_<i>`, `bond_index_<i>` + `bond_type_<i>` (symmetry-aware RMSD) or `perms_<i>` [P, m].  Prints the COV / MAT table of the reference's eval_covmat.py."""
     import argparse
     ap = argparse.ArgumentParser(description=main.__doc__)
     ap.add_argument("--samples", required=True)
@@ -183,6 +290,9 @@ def main(argv=None):
             d["smiles"] = str(zr["smiles_" + i])
         if "perms_" + i in zr.files:
             d["perms"] = zr["perms_" + i]
+        for k in ("bond_index", "bond_type", "edge_index", "edge_type"):
+            if "%s_%s" % (k, i) in zr.files:
+                d[k] = zr["%s_%s" % (k, i)]
         if "pos_gen_" + i in zs.files:
             d["pos_gen"] = zs["pos_gen_" + i]
         items.append(d)

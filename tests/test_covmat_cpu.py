@@ -87,3 +87,59 @@ def test_oracle_kabsch_known_answers():
     # hydrogens (not in atom_idx) do not count
     moved = x.copy(); moved[0] += 5.0
     assert CO.best_rmsd(moved, x, idx[1:]) < 1e-7
+
+
+def _mol(atoms, bonds):
+    """atoms: atomic numbers; bonds: (i, j, type) undirected -> both directions, as the reference's edge lists."""
+    bi = np.array([[i, j] for i, j, _ in bonds] + [[j, i] for i, j, _ in bonds]).T
+    bt = np.array([t for _, _, t in bonds] * 2)
+    return np.array(atoms), bi, bt
+
+
+def _check_group(perms, atoms, bi, bt):
+    heavy = np.nonzero(atoms != 1)[0]
+    m = heavy.size
+    new_id = -np.ones(atoms.size, int); new_id[heavy] = np.arange(m)
+    A = np.zeros((m, m), int)
+    for (u, v), t in zip(bi.T, bt):
+        if new_id[u] >= 0 and new_id[v] >= 0 and t < 22:
+            A[new_id[u], new_id[v]] = t
+    assert (perms[0] == np.arange(m)).all() and len({tuple(p) for p in perms}) == len(perms)
+    for p in perms:
+        assert sorted(p) == list(range(m)) and (atoms[heavy][p] == atoms[heavy]).all()
+        assert (A[np.ix_(p, p)] == A).all()                       # bonds and bond types preserved
+    S = {tuple(p) for p in perms}
+    for p in perms[:8]:
+        for q in perms[:8]:
+            assert tuple(np.asarray(p)[q]) in S                    # closed under composition
+
+
+def test_heavy_atom_automorphisms_hand_derivable_cases():
+    """the symmetry mappings GetBestRMS enumerates (covmat.py:16-35, chem.py:133-137), on molecules whose
+    heavy-atom symmetry group is known by hand."""
+    from agdiff_amd.evaluation import heavy_atom_automorphisms as auto
+    ring = lambda n, t: [(i, (i + 1) % n, t) for i in range(n)]
+    cases = {
+        "benzene (D6h on the ring: 12)": (_mol([6] * 6 + [1] * 6, ring(6, 12) + [(i, 6 + i, 1) for i in range(6)]), 12),
+        "cyclohexane": (_mol([6] * 6, ring(6, 1)), 12),
+        "toluene (mirror of the ring: 2)": (_mol([6] * 7, ring(6, 12) + [(0, 6, 1)]), 2),
+        "tert-butanol (three methyls: 6)": (_mol([6, 6, 6, 6, 8], [(0, 1, 1), (0, 2, 1), (0, 3, 1), (0, 4, 1)]), 6),
+        "neopentane (S4: 24)": (_mol([6] * 5, [(0, k, 1) for k in range(1, 5)]), 24),
+        "pyridine (2)": (_mol([7] + [6] * 5, ring(6, 12)), 2),
+        "acetic acid, C=O vs C-O (1)": (_mol([6, 6, 8, 8], [(0, 1, 1), (1, 2, 2), (1, 3, 1)]), 1),
+        "acetate-like, two equal C-O (2)": (_mol([6, 6, 8, 8], [(0, 1, 1), (1, 2, 12), (1, 3, 12)]), 2),
+        "biphenyl (2 x 2 x 2 = 8)": (_mol([6] * 12, ring(6, 12) + [(6 + i, 6 + (i + 1) % 6, 12) for i in range(6)] + [(0, 6, 1)]), 8),
+        "naphthalene (4)": (_mol([6] * 10, [(0, 1, 12), (1, 2, 12), (2, 3, 12), (3, 4, 12), (4, 5, 12), (5, 0, 12),
+                                           (4, 6, 12), (6, 7, 12), (7, 8, 12), (8, 9, 12), (9, 5, 12)]), 4),
+        "two fragments: ethane + ethane, no swap of labels across... (2 x 2 x 2 = 8)": (_mol([6] * 4, [(0, 1, 1), (2, 3, 1)]), 8),
+        "CF3 on a ring (2 x 6 = 12)": (_mol([6] * 7 + [9] * 3, ring(6, 12) + [(0, 6, 1), (6, 7, 1), (6, 8, 1), (6, 9, 1)]), 12),
+    }
+    for name, ((atoms, bi, bt), order) in cases.items():
+        perms = auto(atoms, bi, bt)
+        assert perms.shape == (order, int((atoms != 1).sum())), (name, perms.shape)
+        _check_group(perms, atoms, bi, bt)
+    # higher-order edges (types 23 / 24 of AddHigherOrderEdges) are not bonds; the cap raises
+    atoms, bi, bt = _mol([6] * 6, ring(6, 1) + [(0, 2, 23), (0, 3, 24)])
+    assert auto(atoms, bi, bt).shape[0] == 12
+    with pytest.raises(ValueError):
+        auto(*_mol([6] * 9, [(0, k, 1) for k in range(1, 9)]), max_perms=1000)        # 8! = 40320 > 1000
