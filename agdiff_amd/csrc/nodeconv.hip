@@ -31,6 +31,7 @@ struct NodeConvArgs {
   const float* r_scale1;      // lw(d)*C(d) of conv1 / conv2 of this block by radius row
   const float* r_scale2;
   // local pair tiles (agdiff_topo_t.lt_*, agdiff_ws_t.lt_*)
+  const int32_t* pair_tgt;    // [2 P]: the two targets of a pair (second: -1 for none)
   const int32_t* lt_ptr;
   const int32_t* lt_src;
   const int32_t* lt_type;
@@ -55,8 +56,9 @@ __device__ unsigned long long ag_node_stamp_acc[8];
 
 // encoder/schnet.py:136-162 for conv1 and conv2 of one InteractionBlock, filters from d-polynomials:
 //   W_e = nn(MLPEdgeEncoder(d_e, type_e)) = P_type(d_e);   agg[dst] += x[src] * W_e * (lw(d_e) C(d_e)).
-// One wave owns a PAIR of targets (2 p, 2 p + 1) and walks, in this order, the pair's local tiles (rows 0..7 = in-edges
-// of target 2 p, rows 8..15 = of target 2 p + 1; static, topo->lt_*), the radius tiles of 2 p, the radius tiles of 2 p + 1
+// One wave owns a PAIR of targets (topo->pair_tgt: two atoms of one molecule with like local in-lists) and walks, in this
+// order, the pair's local tiles (rows 0..7 = in-edges of its first target, rows 8..15 = of its second; static,
+// topo->lt_*), the radius tiles of the first, the radius tiles of the second
 // (every 16-row tile of the radius list belongs to one target, ws->rad_*).  Per tile: the K = 32 NKT polynomial features
 // of each row, SCALED by the row's lw C (one set per conv: the per-edge scale rides through the MFMAs), times the
 // LDS-resident coefficient blocks (flipped product: rows = edges, lanes = channels), then x[src] gathered per (row,
@@ -98,11 +100,13 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
   const int p_end = (p_begin + per_wg < a.num_pairs) ? p_begin + per_wg : a.num_pairs;
   const bool with_local = a.num_slots > 0;
 
-  struct PairInfo { int nL, nA, nB, lt0; };
+  struct PairInfo { int nL, nA, nB, lt0, tA, tB; };
   auto pair_info = [&](int p) -> PairInfo {
     PairInfo r;
-    const int cA = a.rad_cnt[2 * p];
-    const int cB = (2 * p + 1 < a.n) ? a.rad_cnt[2 * p + 1] : 0;
+    r.tA = a.pair_tgt[2 * p];
+    r.tB = a.pair_tgt[2 * p + 1];
+    const int cA = a.rad_cnt[r.tA];
+    const int cB = (r.tB >= 0) ? a.rad_cnt[r.tB] : 0;
     r.nA = (cA + AG_TW - 1) / AG_TW;
     r.nB = (cB + AG_TW - 1) / AG_TW;
     r.lt0 = with_local ? a.lt_ptr[p] : 0;
@@ -114,7 +118,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
     local = j < pi.nL;
     if (local) return (pi.lt0 + j) * AG_TW;
     j -= pi.nL;
-    return (j < pi.nA) ? (2 * p) * AGDIFF_RAD_STRIDE + j * AG_TW : (2 * p + 1) * AGDIFF_RAD_STRIDE + (j - pi.nA) * AG_TW;
+    return (j < pi.nA) ? pi.tA * AGDIFF_RAD_STRIDE + j * AG_TW : pi.tB * AGDIFF_RAD_STRIDE + (j - pi.nA) * AG_TW;
   };
   // per-row inputs of the wave's NEXT tile: length, the two scales and the type slot of row `col`, the sources of the lane's
   // four rows 4 q .. 4 q + 3
@@ -253,7 +257,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
   bool have_pf = false;
   while (p < p_end) {
     const int pn = p + WAVES;
-    PairInfo pin = {0, 0, 0, 0};
+    PairInfo pin = {0, 0, 0, 0, 0, -1};
     if (pn < p_end) pin = pair_info(pn);
     const int ntiles = pi.nL + pi.nA + pi.nB;
     if (ntiles > 0 && !have_pf) {               // cold start (first pair of the wave, or the pair before had no tile)
@@ -451,7 +455,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
     bool first_done = false;
     for (; j < ntiles; ++j) {
       if (j == pi.nL + pi.nA) {                 // target 2 p is complete: write it, start target 2 p + 1
-        finalize(2 * p, false);
+        finalize(pi.tA, false);
         first_done = true;
 #pragma unroll
         for (int i = 0; i < AG_CONV_NCH; ++i) acc[i] = 0.0f;
@@ -459,11 +463,11 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
       radius_tile(j);
     }
     if (!first_done) {
-      finalize(2 * p, false);
+      finalize(pi.tA, false);
 #pragma unroll
       for (int i = 0; i < AG_CONV_NCH; ++i) acc[i] = 0.0f;
     }
-    if (2 * p + 1 < a.n) finalize(2 * p + 1, true);
+    if (pi.tB >= 0) finalize(pi.tB, true);
     if (ntiles == 0) have_pf = false;
     p = pn;
     pi = pin;
@@ -494,7 +498,9 @@ extern "C" int agdiff_cfconv_node(const agdiff_params_t* p, const agdiff_topo_t*
                                   void* stream) {
   if (!p || !topo || !ws || k < 0 || k >= p->num_convs) return AGDIFF_ERR_ARG;
   if (p->poly_kt < 1 || p->poly_kt > AGDIFF_POLY_MAX_KT || !p->conv[k].filt_poly_pk) return AGDIFF_ERR_ARG;
-  if (!ws->rad_cnt || !ws->rad_src || !ws->rad_len || !ws->r_scale || !ws->xs || !ws->agg) return AGDIFF_ERR_ARG;
+  if (!ws->rad_cnt || !ws->rad_src || !ws->rad_len || !ws->r_scale || !ws->xs || !ws->agg || !topo->pair_tgt ||
+      topo->num_pairs <= 0)
+    return AGDIFF_ERR_ARG;
   if (topo->num_nodes <= 0) return AGDIFF_OK;
   if (topo->num_nodes * (int64_t)AGDIFF_RAD_STRIDE >= (1ll << 31)) return AGDIFF_ERR_LIMIT;
   const bool local = topo->num_local > 0 && agdiff_local_poly_enabled(p, topo, ws) != 0;   // (1 all, 2 the slotted types' edges)
@@ -515,6 +521,7 @@ extern "C" int agdiff_cfconv_node(const agdiff_params_t* p, const agdiff_topo_t*
   const size_t rpad = (size_t)topo->num_nodes * AGDIFF_RAD_STRIDE;
   a.r_scale1 = ws->r_scale + (size_t)(2 * k) * rpad;
   a.r_scale2 = ws->r_scale + (size_t)(2 * k + 1) * rpad;
+  a.pair_tgt = topo->pair_tgt;
   a.lt_ptr = topo->lt_ptr;
   a.lt_src = topo->lt_src;
   a.lt_type = topo->lt_type;
@@ -525,7 +532,7 @@ extern "C" int agdiff_cfconv_node(const agdiff_params_t* p, const agdiff_topo_t*
   a.xs = ws->xs;
   a.agg = ws->agg;
   a.n = (int32_t)topo->num_nodes;
-  a.num_pairs = (int32_t)((topo->num_nodes + 1) / 2);
+  a.num_pairs = (int32_t)topo->num_pairs;
   a.two_over_rc = 2.0f / p->cutoff;
   int64_t wgs = (a.num_pairs + AG_NODECONV_WAVES - 1) / AG_NODECONV_WAVES;
   if (wgs > 256) wgs = 256;

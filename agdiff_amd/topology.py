@@ -132,26 +132,46 @@ class BatchTopology:
         self.lp_row = i32(np.where(real, loc_row[eid], -1) if L else np.zeros(Lp))
         self.lc_ppos = i32(ppos[lc_pos])
         self.lc_pmir = i32(np.where(lc_mir >= 0, ppos[np.maximum(lc_mir, 0)], -1))
-        # ... and as PAIR TILES for agdiff_cfconv_node (agdiff_topo_t.lt_*): targets two at a time, tile t of pair p holds
-        # in-edges [8 t, 8 t + 8) of target 2 p in rows 0..7 and of target 2 p + 1 in rows 8..15
-        P2 = (N + 1) // 2
-        deg2 = np.zeros(2 * P2, dtype=np.int64)
-        deg2[:N] = locdeg
-        nt_pair = (np.maximum(deg2[0::2], deg2[1::2]) + 7) // 8
+        # ... and as PAIR TILES for agdiff_cfconv_node (agdiff_topo_t.pair_tgt, lt_*): one wave owns two targets.  Atoms of a
+        # molecule are paired by (tiles their local in-list needs, set of local edge types, index): a pair's tile count is the
+        # larger of the two and a tile's cost grows with the distinct types in it.
+        deg_tiles = (locdeg + 7) // 8
+        sig_of = {}
+        sig = np.zeros(N, dtype=np.int64)
+        for i in range(N):
+            key = tuple(np.unique(typ[in_order[in_ptr[i]:in_ptr[i + 1]]]).tolist())
+            sig[i] = sig_of.setdefault(key, len(sig_of))
+        order_in_mol = np.lexsort((np.arange(N), sig, deg_tiles, ba))        # by molecule, then the pairing key
+        pair_tgt = []
+        for g in range(G):
+            idx = order_in_mol[gptr[g]:gptr[g + 1]]
+            if idx.size % 2:
+                idx = np.concatenate([idx, [-1]])
+            pair_tgt.append(idx)
+        pair_tgt = np.concatenate(pair_tgt).astype(np.int64) if pair_tgt else np.zeros(0, dtype=np.int64)
+        P2 = pair_tgt.size // 2
+        tA, tB = pair_tgt[0::2], pair_tgt[1::2]
+        degA, degB = locdeg[tA], np.where(tB >= 0, locdeg[np.maximum(tB, 0)], 0)
+        nt_pair = (np.maximum(degA, degB) + 7) // 8
         lt_ptr = np.concatenate([[0], np.cumsum(nt_pair)])
         T = int(lt_ptr[-1])
+        # a target's in-edges in order of (type, source): fewer distinct types per 8-row half
+        in_order_t = in_order.copy()
+        for i in range(N):
+            seg = in_order[in_ptr[i]:in_ptr[i + 1]]
+            in_order_t[in_ptr[i]:in_ptr[i + 1]] = seg[np.lexsort((src[seg], typ[seg]))]
         trow = np.arange(16 * T)
         tile_of = trow // 16
         pair_of = np.repeat(np.arange(P2), nt_pair)[tile_of] if T else np.zeros(0, dtype=np.int64)
         half = (trow % 16) // 8
-        tgt_t = 2 * pair_of + half                                          # (may be N for the odd last pair's second half)
+        tgt_t = np.where(half == 0, tA[pair_of], tB[pair_of]) if T else np.zeros(0, dtype=np.int64)      # (-1: no second target)
         k_t = (tile_of - lt_ptr[pair_of]) * 8 + trow % 8                    # index inside the target's in-list
-        tgt_c = np.minimum(tgt_t, N - 1)
-        real_t = (tgt_t < N) & (k_t < locdeg[tgt_c])
+        tgt_c = np.where(tgt_t >= 0, tgt_t, tA[pair_of]) if T else tgt_t
+        real_t = (tgt_t >= 0) & (k_t < locdeg[tgt_c])
         slot_t = np.minimum(in_ptr[tgt_c] + k_t, max(L - 1, 0))
-        eid_t = in_order[slot_t] if L else np.zeros(16 * T, dtype=np.int64)
-        # pad rows: src = the target itself (a valid row of xs; the odd last pair's missing target: the last node), and the
-        # type of the tile's first real row (the kernel loops over the types present in a tile: pads must not add one)
+        eid_t = in_order_t[slot_t] if L else np.zeros(16 * T, dtype=np.int64)
+        # pad rows: src = the target itself (a valid row of xs; a missing second target: the first), and the type of the
+        # tile's first real row (the kernel loops over the types present in a tile: pads must not add one)
         first_real = np.full(max(T, 1), max(16 * T - 1, 0), dtype=np.int64)
         if T:
             idx = np.nonzero(real_t)[0]
@@ -159,11 +179,13 @@ class BatchTopology:
         pad_type = typ[eid_t[first_real[tile_of]]] if (L and T) else np.zeros(16 * T, dtype=np.int64)
         tpos = np.empty(L, dtype=np.int64)
         tpos[eid_t[real_t]] = np.nonzero(real_t)[0]
-        self.T = T
+        self.T, self.P = T, int(P2)
+        self.pair_tgt = i32(pair_tgt)
         self.lt_ptr = i32(lt_ptr)
         self.lt_src = i32(np.where(real_t, src[eid_t], tgt_c) if L else np.zeros(16 * T))
         self.lt_type = i32(np.where(real_t, typ[eid_t], pad_type) if L else np.zeros(16 * T))
         self.lt_real = real_t
+        self.lt_eid = np.where(real_t, eid_t, -1)
         self.lc_tpos = i32(tpos[lc_pos])
         self.lc_tmir = i32(np.where(lc_mir >= 0, tpos[np.maximum(lc_mir, 0)], -1))
         self.local_types = np.unique(typ)                 # PackedParams.ensure_local_types (per-type filter polynomials)
@@ -179,6 +201,7 @@ class BatchTopology:
         t.num_local_canon = self.Lc
         t.num_local_padded = self.Lp
         t.num_local_tiles = self.T
+        t.num_pairs = self.P
         tm = [0, 0]
         for ty in self.local_types:
             tm[int(ty) >> 6] |= 1 << (int(ty) & 63)
@@ -187,7 +210,7 @@ class BatchTopology:
         for f in ("graph_ptr", "atom_type", "loc_src", "loc_dst", "loc_type", "loc_out_ptr", "loc_in_ptr", "loc_in_eid",
                   "lc_src", "lc_dst", "lc_type", "lc_pos", "lc_mir", "loc_row", "loc_in_src",
                   "loc_in_row", "lp_ptr", "lp_src", "lp_dst", "lp_type", "lp_row", "lc_ppos", "lc_pmir",
-                  "lt_ptr", "lt_src", "lt_type", "lc_tpos", "lc_tmir"):
+                  "pair_tgt", "lt_ptr", "lt_src", "lt_type", "lc_tpos", "lc_tmir"):
             setattr(t, f, _lib.ptr(getattr(self, f)))
         self.struct = t
 

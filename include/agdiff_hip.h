@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 29
+#define AGDIFF_ABI_VERSION 30
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -235,13 +235,18 @@ typedef struct agdiff_topo {
   const int32_t* lp_row;     /* [Lp]: canonical index (row of l_attr_rows) of the entry's edge, -1 for pad entries */
   const int32_t* lc_ppos;    /* [Lc]: padded-list position of the canonical edge */
   const int32_t* lc_pmir;    /* [Lc]: ... of its mirror, or -1 */
-  /* the local edges once more as PAIR TILES for agdiff_cfconv_node: targets are taken two at a time (2 p, 2 p + 1); tile t of
-   * pair p holds local in-edges [8 t, 8 t + 8) of target 2 p in rows 0..7 and of target 2 p + 1 in rows 8..15 (pad rows:
-   * src = the target itself, the type of a real row, and nothing ever writes their CFConv scale: they contribute exactly 0),
-   * so that the rows of one lane quarter belong to ONE target and the sum over a target's edges needs no masks */
+  /* PAIRS of targets for agdiff_cfconv_node: one wave owns the two targets pair_tgt[2 p], pair_tgt[2 p + 1] (the second is -1
+   * for the odd atom of a molecule).  The host pairs atoms of ONE molecule with like numbers of local in-edges (both <= 8,
+   * both 9..16, ...) and like sets of local edge types.  The local edges once more as pair tiles: tile t of pair p holds
+   * local in-edges [8 t, 8 t + 8) of its first target in rows 0..7 and of its second in rows 8..15, a target's in-edges
+   * taken in order of (type, source) -- pad rows: src = the target itself, the type of a real row of the tile, and nothing
+   * ever writes their CFConv scale: they contribute exactly 0 --, so that the rows of one lane quarter belong to ONE target
+   * and the sum over a target's edges needs no masks, and a tile holds few distinct types */
+  int64_t num_pairs;         /* P */
+  const int32_t* pair_tgt;   /* [2 P] */
   int64_t local_type_mask[2];/* bit t of the 128-bit mask: the batch has a local edge of type t */
-  int64_t num_local_tiles;   /* T = lt_ptr[ceil(N/2)] */
-  const int32_t* lt_ptr;     /* [ceil(N/2) + 1]: tiles of pair p are [lt_ptr[p], lt_ptr[p+1]) */
+  int64_t num_local_tiles;   /* T = lt_ptr[P] */
+  const int32_t* lt_ptr;     /* [P + 1]: tiles of pair p are [lt_ptr[p], lt_ptr[p+1]) */
   const int32_t* lt_src;     /* [16 T] */
   const int32_t* lt_type;    /* [16 T] */
   const int32_t* lc_tpos;    /* [Lc]: pair-tile row of the canonical edge */

@@ -300,42 +300,53 @@ def test_padded_local_list():
     assert np.array_equal(cover, row >= 0)
 
 
-@pytest.mark.parametrize("kind,mols,copies,drop_last", [("drugs", 3, 2, False), ("qm9", 3, 1, True)])
-def test_local_pair_tiles(kind, mols, copies, drop_last):
-    """agdiff_topo_t.lt_* (agdiff_cfconv_node): targets two at a time; tile t of pair p holds in-edges [8 t, 8 t + 8) of
-    target 2 p in rows 0..7 and of target 2 p + 1 in rows 8..15; pad rows point at the target itself and carry the type
-    of a real row of their tile; every local edge sits in exactly one row; an odd node count leaves the last pair's
-    second half empty."""
+@pytest.mark.parametrize("kind,mols,copies", [("drugs", 3, 2), ("qm9", 5, 1)])
+def test_local_pair_tiles(kind, mols, copies):
+    """agdiff_topo_t.pair_tgt / lt_* (agdiff_cfconv_node): every atom sits in exactly one pair, both atoms of a pair belong to
+    one molecule (the odd atom of a molecule pairs with -1), pairs are formed between atoms whose local in-lists need the
+    same number of tiles wherever possible; tile t of pair p holds in-edges [8 t, 8 t + 8) -- in (type, source) order -- of
+    its first target in rows 0..7 and of its second in rows 8..15; pad rows point at the target itself and carry the type
+    of a real row of their tile; every local edge sits in exactly one row."""
     from agdiff_amd import synth
     from agdiff_amd.topology import BatchTopology
     b = synth.make_packed_batch(kind, mols, copies, seed=5)
-    at, bi, bt, ba = b["atom_type"], b["bond_index"], b["bond_type"], b["batch"]
-    if drop_last or at.shape[0] % 2 == 0:       # make the node count odd: cut the last atom and its bonds
-        n = at.shape[0] - 1
-        keep = (bi[0] < n) & (bi[1] < n)
-        at, bi, bt, ba = at[:n], bi[:, keep], bt[keep], ba[:n]
-    tp = BatchTopology(at, bi, bt, ba, device="cpu")
-    assert tp.N % 2 == 1
-    ltp, src, typ = tp.lt_ptr.numpy(), tp.lt_src.numpy(), tp.lt_type.numpy()
-    ip, isrc, eid, ltyp = tp.loc_in_ptr.numpy(), tp.loc_in_src.numpy(), tp.loc_in_eid.numpy(), tp.loc_type.numpy()
-    P = (tp.N + 1) // 2
-    assert ltp.shape[0] == P + 1 and ltp[-1] == tp.T == tp.struct.num_local_tiles and src.shape[0] == 16 * tp.T
+    tp = BatchTopology(b["atom_type"], b["bond_index"], b["bond_type"], b["batch"], device="cpu")
+    pt, ltp, src, typ = tp.pair_tgt.numpy(), tp.lt_ptr.numpy(), tp.lt_src.numpy(), tp.lt_type.numpy()
+    ip, eid = tp.loc_in_ptr.numpy(), tp.loc_in_eid.numpy()
+    lsrc, ltyp, ba = tp.loc_src.numpy(), tp.loc_type.numpy(), b["batch"]
+    P = tp.P
+    assert pt.shape[0] == 2 * P == tp.struct.num_pairs * 2 and ltp.shape[0] == P + 1 and ltp[-1] == tp.T == tp.struct.num_local_tiles
+    assert sorted(pt[pt >= 0].tolist()) == list(range(tp.N)) and np.all(pt[0::2] >= 0)
+    sizes = np.bincount(ba)
+    assert int((pt < 0).sum()) == int((sizes % 2).sum())              # one unpaired atom per odd molecule
+    deg = np.diff(ip)
     real = np.zeros(16 * tp.T, bool)
+    mixed_pairs = {}
     for p_ in range(P):
-        degs = [ip[i + 1] - ip[i] if i < tp.N else 0 for i in (2 * p_, 2 * p_ + 1)]
+        tA, tB = int(pt[2 * p_]), int(pt[2 * p_ + 1])
+        if tB >= 0:
+            assert ba[tA] == ba[tB]
+            if (deg[tA] + 7) // 8 != (deg[tB] + 7) // 8:
+                mixed_pairs[ba[tA]] = mixed_pairs.get(ba[tA], 0) + 1
+        degs = [deg[tA], deg[tB] if tB >= 0 else 0]
         assert ltp[p_ + 1] - ltp[p_] == (max(degs) + 7) // 8
-        for tl in range(ltp[p_], ltp[p_ + 1]):
-            for h, i in enumerate((2 * p_, 2 * p_ + 1)):
-                k0 = 8 * (tl - ltp[p_])
+        for h, tgt in enumerate((tA, tB)):
+            want = eid[ip[tgt]:ip[tgt + 1]] if tgt >= 0 else np.zeros(0, int)
+            want = want[np.lexsort((lsrc[want], ltyp[want]))]          # (type, source) order
+            got_rows = []
+            for tl in range(ltp[p_], ltp[p_ + 1]):
                 rows = np.arange(16 * tl + 8 * h, 16 * tl + 8 * h + 8)
+                k0 = 8 * (tl - ltp[p_])
                 nreal = int(np.clip(degs[h] - k0, 0, 8))
-                if nreal:
-                    assert np.array_equal(src[rows[:nreal]], isrc[ip[i] + k0: ip[i] + k0 + nreal])
-                    assert np.array_equal(typ[rows[:nreal]], ltyp[eid[ip[i] + k0: ip[i] + k0 + nreal]])
-                    real[rows[:nreal]] = True
-                assert np.all(src[rows[nreal:]] == min(i, tp.N - 1))
+                got_rows += rows[:nreal].tolist()
+                assert np.all(src[rows[nreal:]] == (tgt if tgt >= 0 else tA))
+            assert np.array_equal(src[got_rows], lsrc[want]) and np.array_equal(typ[got_rows], ltyp[want])
+            assert np.array_equal(tp.lt_eid[got_rows], want)
+            real[got_rows] = True
+        for tl in range(ltp[p_], ltp[p_ + 1]):
             tile_rows = np.arange(16 * tl, 16 * tl + 16)
             assert real[tile_rows].any() and set(typ[tile_rows]) == set(typ[tile_rows][real[tile_rows]])
+    assert all(v <= 2 for v in mixed_pairs.values())                   # at most a boundary pair or two per molecule
     assert real.sum() == tp.L and np.array_equal(real, tp.lt_real)
     tpos, tmir = tp.lc_tpos.numpy(), tp.lc_tmir.numpy()
     mk = tmir >= 0
