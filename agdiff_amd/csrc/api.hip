@@ -216,8 +216,8 @@ int global_front_split(const agdiff_params_t* p, const agdiff_topo_t* topo, cons
   // inside the denoising loop nothing but the polynomial head walks the canonical list: radius edges only then (one head
   // evaluation per mirror pair of radius edges)
   const bool ronly = (flags & AGDIFF_FWD_SAMPLER) != 0;
-  AG_TRY(agdiff_graph_build_ex(topo, ws, pos, (flags & AGDIFF_FWD_NO_RADIUS) ? 0.0f : p->cutoff, ronly ? 1 : 0, stream));
-  AG_TRY(agdiff_edge_scales_split(p, topo, ws, 0, stream));
+  // (the radius rows' scales and pad rows come out of the graph build's fill pass)
+  AG_TRY(agdiff_graph_build_scaled(p, topo, ws, pos, (flags & AGDIFF_FWD_NO_RADIUS) ? 0.0f : p->cutoff, ronly ? 1 : 0, stream));
   if (!(flags & AGDIFF_FWD_SAMPLER))
     AG_TRY(agdiff_edge_encoder(p, ws->num_canon, etiles, ws->c_len, ws->c_type, ws->e_attr, nullptr, nullptr, ws->c_pos,
                                ws->c_mir, stream));

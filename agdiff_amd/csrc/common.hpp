@@ -390,6 +390,33 @@ __device__ __forceinline__ void ag_load_attr(AgIn<AG_BF3>& x, const float* frag,
   x.hi = __builtin_bit_cast(bf16x8, p[ag_attr_unit(tile, t, 0, lane)]);
   x.lo = __builtin_bit_cast(bf16x8, p[ag_attr_unit(tile, t, 1, lane)]);
 }
+// DistanceWeightingNetwork (schnet.py:83-100) times the cutoff envelope (schnet.py:140-146).
+// cos via v_cos_f32 on the half angle (0.5 (cos x + 1) = cos^2(x/2), argument <= 1/4 revolution inside the
+// cutoff), sigmoid / gaussian via v_exp_f32: absolute error ~1e-6 on a factor in [0, 1].
+// DistanceWeightingNetwork before its sigmoid is piecewise linear in d (agdiff_conv_params_t.dist_seg): binary search for
+// the segment among the 32 sorted kinks (padded with +inf), then one FMA -- instead of 32 hidden units per edge and conv.
+// SEG: a pointer to global memory or to LDS.
+template <typename SEG>
+__device__ __forceinline__ float cf_dist_weight(SEG seg, float d) {
+  int s = 0;
+#pragma unroll
+  for (int step = 16; step >= 1; step >>= 1) s += (seg[s + step - 1] <= d) ? step : 0;
+  s += (s == 31 && seg[31] <= d) ? 1 : 0;
+  return ag_sigmoid(fmaf(seg[32 + s], d, seg[65 + s]));
+}
+// the cutoff envelope C(d) (schnet.py:140-146), the same for every CFConv
+__device__ __forceinline__ float cf_envelope(float d, float cutoff, int smooth) {
+  float C;
+  if (smooth) {
+    const float c = __builtin_amdgcn_cosf(d * (0.25f / cutoff));     // cos(pi d / (2 rc)), input in revolutions
+    C = c * c;
+  } else {
+    const float t = d - cutoff;
+    C = ag_exp2(-(t * t) / (2.0f * cutoff * cutoff) * 1.44269504088896340736f);
+  }
+  return (d <= cutoff && d >= 0.0f) ? C : 0.0f;
+}
+
 // ---------------------------------------------------------------------------------- filter polynomials
 // Operand elements of the lane's edge for the NKT k-tiles of a d-polynomial (include/agdiff_hip.h: agdiff_params_t.poly_kt;
 // host mirror: agdiff_amd/packing.py poly_features): element j of quarter q in k-tile t is

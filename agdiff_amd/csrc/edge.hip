@@ -182,33 +182,6 @@ __global__ void __launch_bounds__(256) k_edge_gaussian(GaussArgs a) {
 }
 
 // ------------------------------------------------------------------------------ per-edge conv scales
-// DistanceWeightingNetwork (schnet.py:83-100) times the cutoff envelope (schnet.py:140-146).
-// cos via v_cos_f32 on the half angle (0.5 (cos x + 1) = cos^2(x/2), argument <= 1/4 revolution inside the
-// cutoff), sigmoid / gaussian via v_exp_f32: absolute error ~1e-6 on a factor in [0, 1].
-// DistanceWeightingNetwork before its sigmoid is piecewise linear in d (agdiff_conv_params_t.dist_seg): binary search for
-// the segment among the 32 sorted kinks (padded with +inf), then one FMA -- instead of 32 hidden units per edge and conv.
-// SEG: a pointer to global memory or to LDS.
-template <typename SEG>
-__device__ __forceinline__ float cf_dist_weight(SEG seg, float d) {
-  int s = 0;
-#pragma unroll
-  for (int step = 16; step >= 1; step >>= 1) s += (seg[s + step - 1] <= d) ? step : 0;
-  s += (s == 31 && seg[31] <= d) ? 1 : 0;
-  return ag_sigmoid(fmaf(seg[32 + s], d, seg[65 + s]));
-}
-// the cutoff envelope C(d) (schnet.py:140-146), the same for every CFConv
-__device__ __forceinline__ float cf_envelope(float d, float cutoff, int smooth) {
-  float C;
-  if (smooth) {
-    const float c = __builtin_amdgcn_cosf(d * (0.25f / cutoff));     // cos(pi d / (2 rc)), input in revolutions
-    C = c * c;
-  } else {
-    const float t = d - cutoff;
-    C = ag_exp2(-(t * t) / (2.0f * cutoff * cutoff) * 1.44269504088896340736f);
-  }
-  return (d <= cutoff && d >= 0.0f) ? C : 0.0f;
-}
-
 struct ScaleArgs {
   const float* dw[2 * AGDIFF_MAX_CONVS];
   const int32_t* n_dev;
@@ -824,6 +797,10 @@ __global__ void __launch_bounds__(256) k_rad_scales(RadScaleArgs a) {
 }
 
 // ------------------------------------------------------------------------------ local edge_attr rows by polynomial
+__global__ void k_zero_word(int32_t* p) {
+  if (threadIdx.x == 0) *p = 0;
+}
+
 struct AttrPolyArgs {
   const float* poly_pk;       // [num_slots] x pk [8][1]
   const int32_t* type_slot;
@@ -1300,7 +1277,8 @@ extern "C" int agdiff_local_edge_rows(const agdiff_params_t* p, const agdiff_top
     return agdiff_edge_encoder(p, ws->num_local_canon, ctiles, ws->lc_len, topo->lc_type, nullptr, ws->l_attr_rows, nullptr,
                                nullptr, nullptr, stream);
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(ws->enc_flags, 0, sizeof(int32_t), st) != hipSuccess) return AGDIFF_ERR_LAUNCH;
+  k_zero_word<<<1, 64, 0, st>>>(ws->enc_flags);       // (hipMemsetAsync of these four bytes ran a 17-us fill kernel)
+  AG_CHECK_LAUNCH();
   AttrPolyArgs a;
   a.poly_pk = p->attr_poly_typed_pk;
   a.type_slot = p->poly_type_slot;

@@ -52,6 +52,15 @@ struct GraphArgs {
   int32_t* g_deg;        // [N] in-degrees
   int32_t* g_cdeg;       // [N] canonical in-degrees
   int32_t num_graphs;
+  // optional (r_scale != null): lw(d) * C(d) of the 2 * num_convs CFConvs for the radius rows, and the pad rows that complete
+  // every target's last 16-row tile, straight from the fill pass (what agdiff_edge_scales_split(which = 0) does as a launch
+  // of its own: 36 us alone, 70 us beside the local branch's kernels)
+  const float* dw[2 * AGDIFF_MAX_CONVS];
+  float* r_scale;
+  int64_t rpad;
+  int32_t n_scales;
+  float cutoff;
+  int32_t smooth;
 };
 
 // Edge lengths must come out bit-identical wherever they are computed (the per-step graph build and the local-edge
@@ -113,6 +122,9 @@ __global__ void __launch_bounds__(AG_GRAPH_THREADS) k_graph(GraphArgs a) {
     return !li || local_type(i, j) == local_type(j, i);
   };
 
+  __shared__ float sseg[FILL ? 2 * AGDIFF_MAX_CONVS * 100 : 1];         // the CFConvs' distance-weighting segment tables
+  if (FILL && a.r_scale)
+    for (int i = threadIdx.x; i < a.n_scales * 100; i += blockDim.x) sseg[i] = a.dw[i / 100][i % 100];
   for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) spos[i] = a.pos[3 * (size_t)g0 + i];
   // static local in-adjacency of the molecule: the thread that owns target i sets its row
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -275,6 +287,10 @@ __global__ void __launch_bounds__(AG_GRAPH_THREADS) k_graph(GraphArgs a) {
           const int rp = rp0 + __popcll(rmask & lt);
           a.rad_src[rp] = g0 + j;
           a.rad_len[rp] = len;
+          if (a.r_scale) {
+            const float C = cf_envelope(len, a.cutoff, a.smooth);
+            for (int c = 0; c < a.n_scales; ++c) a.r_scale[(size_t)c * a.rpad + rp] = cf_dist_weight(sseg + c * 100, len) * C;
+          }
         }
         if (canon) {
           const int cp = cp0 + __popcll(cmask & lt);
@@ -291,7 +307,16 @@ __global__ void __launch_bounds__(AG_GRAPH_THREADS) k_graph(GraphArgs a) {
       lk += __popcll(lmask);
       rp0 += __popcll(rmask);
     }
-    if (a.rad_cnt && lane == 0) a.rad_cnt[g0 + i] = rp0 - (g0 + i) * AGDIFF_RAD_STRIDE;
+    if (a.rad_cnt) {
+      const int cnt = rp0 - (g0 + i) * AGDIFF_RAD_STRIDE;
+      if (lane == 0) a.rad_cnt[g0 + i] = cnt;
+      if (a.r_scale && lane < ((cnt + AG_TW - 1) / AG_TW) * AG_TW - cnt) {     // pad rows: src = the target itself, length 0, scale 0
+        const int rp = rp0 + lane;
+        a.rad_src[rp] = g0 + i;
+        a.rad_len[rp] = 0.0f;
+        for (int c = 0; c < a.n_scales; ++c) a.r_scale[(size_t)c * a.rpad + rp] = 0.0f;
+      }
+    }
   }
   // pass 3: ref2dst, one thread per source walking its column (targets ascending = the (src, dst) order)
   for (int j = threadIdx.x; j < n; j += blockDim.x) {
@@ -378,8 +403,25 @@ extern "C" int agdiff_graph_build(const agdiff_topo_t* topo, const agdiff_ws_t* 
   return agdiff_graph_build_ex(topo, ws, pos, cutoff, 0, stream);
 }
 
+namespace {
+int graph_build_impl(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, float cutoff,
+                     int32_t canon_radius_only, void* stream);
+}
+
 extern "C" int agdiff_graph_build_ex(const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, float cutoff,
                                      int32_t canon_radius_only, void* stream) {
+  return graph_build_impl(nullptr, topo, ws, pos, cutoff, canon_radius_only, stream);
+}
+
+extern "C" int agdiff_graph_build_scaled(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
+                                         const float* pos, float cutoff, int32_t canon_radius_only, void* stream) {
+  if (!p || !ws || !ws->r_scale || !ws->rad_cnt || p->num_convs > AGDIFF_MAX_CONVS) return AGDIFF_ERR_ARG;
+  return graph_build_impl(p, topo, ws, pos, cutoff, canon_radius_only, stream);
+}
+
+namespace {
+int graph_build_impl(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, float cutoff,
+                     int32_t canon_radius_only, void* stream) {
   if (!topo || !ws || !pos || topo->num_graphs <= 0 || topo->num_nodes <= 0 || (topo->num_local > 0 && !topo->loc_row))
     return AGDIFF_ERR_ARG;
   if (!ws->graph_edge_cnt || !ws->graph_edge_ptr || !ws->in_ptr || !ws->out_ptr || !ws->e_src || !ws->e_dst ||
@@ -429,6 +471,22 @@ extern "C" int agdiff_graph_build_ex(const agdiff_topo_t* topo, const agdiff_ws_
   a.g_deg = ws->g_deg;
   a.g_cdeg = ws->g_cdeg;
   a.num_graphs = (int32_t)topo->num_graphs;
+  a.r_scale = nullptr;
+  a.rpad = 0;
+  a.n_scales = 0;
+  a.cutoff = cutoff;
+  a.smooth = 0;
+  if (p) {                 // the radius rows' CFConv scales from the fill pass (agdiff_graph_build_scaled)
+    for (int k = 0; k < p->num_convs; ++k) {
+      a.dw[2 * k] = p->conv[k].dist_seg;
+      a.dw[2 * k + 1] = p->conv[k].dist_seg + 100;
+    }
+    a.r_scale = ws->r_scale;
+    a.rpad = topo->num_nodes * (int64_t)AGDIFF_RAD_STRIDE;
+    a.n_scales = 2 * p->num_convs;
+    a.cutoff = p->cutoff;       // (the envelope's cutoff is the model's, also when the graph is built without radius edges)
+    a.smooth = p->smooth;
+  }
   const int max_atoms = (int)topo->max_atoms_per_graph;
   if (max_atoms <= 0 || max_atoms > AGDIFF_MAX_ATOMS_PER_GRAPH) return AGDIFF_ERR_LIMIT;
   a.words = 2 * ((max_atoms + 63) / 64);
@@ -451,6 +509,7 @@ extern "C" int agdiff_graph_build_ex(const agdiff_topo_t* topo, const agdiff_ws_
   AG_CHECK_LAUNCH();
   return AGDIFF_OK;
 }
+}  // namespace
 
 extern "C" int agdiff_local_lengths(const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, void* stream) {
   if (!topo || !ws || !pos || !ws->l_len || !ws->lc_len) return AGDIFF_ERR_ARG;

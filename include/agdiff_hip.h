@@ -370,6 +370,12 @@ int agdiff_graph_build(const agdiff_topo_t* topo, const agdiff_ws_t* ws, const f
 int agdiff_graph_build_ex(const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, float cutoff,
                           int32_t canon_radius_only, void* stream);
 
+/* The same with the radius rows' CFConv scales (ws->r_scale, all 2 * num_convs of them: DistanceWeightingNetwork x cutoff
+ * envelope, encoder/schnet.py:83-100,138-149) and the pad rows of every target's last tile written by the fill pass itself:
+ * what the denoising loop calls (one launch less per step than agdiff_graph_build_ex + agdiff_edge_scales_split(0)). */
+int agdiff_graph_build_scaled(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos,
+                              float cutoff, int32_t canon_radius_only, void* stream);
+
 /* get_distance on the static local edges (geometry.py:5-6 applied to edge_index[:, local_edge_mask]): one evaluation per
  * canonical local edge, written to l_len of the edge and of its mirror, to lc_len and -- where the workspace has them --
  * to l_len_p (padded-list positions) and lt_len (pair-tile rows). */

@@ -145,6 +145,17 @@ def test_node_cfconv_equals_one_list_kernel(kind, mols, copies):
             c, cp = cnt[i], (cnt[i] + 15) // 16 * 16
             assert np.array_equal(rsrc[i, :c], esrc[sel][r0]) and np.array_equal(rlen[i, :c], elen[sel][r0])
             assert np.all(rsrc[i, c:cp] == i) and np.all(rlen[i, c:cp] == 0) and np.all(rsc[:, i, c:cp] == 0)
+        # the scales the graph build's fill pass wrote are those of the stand-alone launch, bit for bit
+        fused = ws.r_scale.clone()
+        ws.r_scale.fill_(float("nan"))
+        assert lib.agdiff_edge_scales_split(P, T, W, 0, st) == 0
+        torch.cuda.synchronize()
+        used = torch.zeros(N, RS, dtype=torch.bool)
+        for i in range(N):
+            used[i, :(cnt[i] + 15) // 16 * 16] = True
+        used = used.cuda().view(-1)
+        for c in range(2 * cfg.num_convs):
+            assert torch.equal(fused.view(-1, N * RS)[c][used], ws.r_scale.view(-1, N * RS)[c][used]), c
         assert lib.agdiff_edge_scales(P, T, W, 1, st) == 0
         sc = 3.0 if precision == "bf16x3" else 1.0
         # ws.xs holds lin1 outputs of the last block after the forward: any block's filters may be applied to them
