@@ -134,13 +134,15 @@ int local_branch(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdi
   const int64_t ctiles = (topo->num_local_canon + AG_TW - 1) / AG_TW;
   // caller-supplied lengths (forward(edge_length=...)) need not be symmetric: then every local edge is evaluated
   const bool canon = !(flags & AGDIFF_FWD_GRAPH_GIVEN) && topo->num_local_canon > 0;
-  if (!(flags & AGDIFF_FWD_GRAPH_GIVEN)) AG_TRY(agdiff_local_lengths(topo, ws, pos, stream));
+  // (the fused sampler front has written the lengths -- and the pair-tile scales -- already)
+  const bool front_did_local = (flags & AGDIFF_FWD_GRAPH_READY) != 0;
+  if (!(flags & AGDIFF_FWD_GRAPH_GIVEN) && !front_did_local) AG_TRY(agdiff_local_lengths(topo, ws, pos, stream));
   if (rows_from_global) {
     if (hipStreamWaitEvent((hipStream_t)stream, rows_ready, 0) != hipSuccess) return AGDIFF_ERR_LAUNCH;
   } else if (topo->num_local > 0) {
     if (canon && split) {
       const int lp = agdiff_local_poly_enabled(p, topo, ws);
-      if (lp != 0) AG_TRY(agdiff_edge_scales_split(p, topo, ws, 2, stream));      // scales by pair-tile row (agdiff_cfconv_node)
+      if (lp != 0 && !front_did_local) AG_TRY(agdiff_edge_scales_split(p, topo, ws, 2, stream));   // scales by pair-tile row (agdiff_cfconv_node)
       if (lp == 1) {        // the local CFConv takes every filter from polynomials: only the rows are needed
         AG_TRY(agdiff_local_edge_rows(p, topo, ws, stream));
       } else {              // (some) local edges through the filter MLPs: rows and the operand-form copy at the padded-list
@@ -216,6 +218,13 @@ int global_front_split(const agdiff_params_t* p, const agdiff_topo_t* topo, cons
   // inside the denoising loop nothing but the polynomial head walks the canonical list: radius edges only then (one head
   // evaluation per mirror pair of radius edges)
   const bool ronly = (flags & AGDIFF_FWD_SAMPLER) != 0;
+  if ((flags & AGDIFF_FWD_GRAPH_READY) && ronly) {
+    if (!(flags & AGDIFF_FWD_GRAPH_PENDING)) return AGDIFF_OK;          // agdiff_sampler_front has built this step's graph
+    agdiff_step_args_t sa = {};                                          // ... or left its graph phase to this side of the fork
+    sa.pos_in = pos;
+    return agdiff_sampler_front(p, topo, ws, &sa, 2 | ((flags & AGDIFF_FWD_PARITY) ? 16 : 0),
+                                (flags & AGDIFF_FWD_NO_RADIUS) ? 0.0f : p->cutoff, stream);
+  }
   // (the radius rows' scales and pad rows come out of the graph build's fill pass)
   AG_TRY(agdiff_graph_build_scaled(p, topo, ws, pos, (flags & AGDIFF_FWD_NO_RADIUS) ? 0.0f : p->cutoff, ronly ? 1 : 0, stream));
   if (!(flags & AGDIFF_FWD_SAMPLER))
@@ -240,7 +249,10 @@ int global_back_split(const agdiff_params_t* p, const agdiff_topo_t* topo, const
   if (cache) ws0.xs = ws->xs0;
   for (int k = 0; k < p->num_convs; ++k) {
     const agdiff_ws_t* wk = (k == 0) ? &ws0 : ws;
-    if (k == 0 && local_ready && hipStreamWaitEvent((hipStream_t)stream, local_ready, 0) != hipSuccess) return AGDIFF_ERR_LAUNCH;
+    // (the local edges' inputs come from the side stream -- unless the fused front wrote them on this one and no MLP pass needs more)
+    if (k == 0 && local_ready && (local_mlp || !(flags & AGDIFF_FWD_GRAPH_READY)) &&
+        hipStreamWaitEvent((hipStream_t)stream, local_ready, 0) != hipSuccess)
+      return AGDIFF_ERR_LAUNCH;
     {
       ProfScope prof(stream);
       AG_TRY(agdiff_cfconv_node(p, topo, wk, k, stream));
@@ -252,8 +264,11 @@ int global_back_split(const agdiff_params_t* p, const agdiff_topo_t* topo, const
     // only the radius edges' outputs are used (dualenc.py:516-518): the head's edge_attr half from the d-polynomial, over
     // the canonical list (a mirror pair of radius edges has one length and h_i * h_j is symmetric)
     ag_log_variant(ws, AGDIFF_VAR_HEAD_POLY);
-    AG_TRY(agdiff_pair_head_poly(p, ws->num_canon, etiles, ws->c_src, ws->c_dst, ws->c_len, ws->h, ws->c_pos, ws->c_mir,
-                                 ws->e_inv_global, stream));
+    if (flags & AGDIFF_FWD_GRAPH_READY)       // segmented canonical list, results by radius row (ws->inv_r)
+      AG_TRY(agdiff_pair_head_poly_rows(p, topo, ws, (flags & AGDIFF_FWD_PARITY) ? 1 : 0, stream));
+    else
+      AG_TRY(agdiff_pair_head_poly(p, ws->num_canon, etiles, ws->c_src, ws->c_dst, ws->c_len, ws->h, ws->c_pos, ws->c_mir,
+                                   ws->e_inv_global, stream));
   } else {
     AG_TRY(agdiff_pair_head(&p->head_global, ws->num_canon, etiles, ws->c_src, ws->c_dst, ws->h, ws->e_attr, nullptr,
                             ws->c_pos, ws->c_mir, ws->e_inv_global, stream));

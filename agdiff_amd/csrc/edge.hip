@@ -904,6 +904,8 @@ struct HeadPolyArgs {
   float* out;
   int64_t max_tiles;
   float two_over_rc;
+  const int32_t* seg_tile_live;   // optional: the list is cut into 16-aligned segments, one per molecule (agdiff_sampler_front);
+                                  // [max_tiles] live entries (0..16) of every tile; n_dev is unused then
 };
 
 // k_pair_head for edges whose edge_attr is MLPEdgeEncoder(d, type 0): the edge_attr half of the first layer,
@@ -926,16 +928,24 @@ __global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_pair_head_poly(Hea
   }
   __syncthreads();
   const int lane0 = ag_lane();
-  const int E = *a.n_dev;
+  const int E = a.seg_tile_live ? 0 : *a.n_dev;
   const int64_t stride = (int64_t)gridDim.x * AG_PERSIST_WAVES;
   const int64_t wg = (gridDim.x % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x;
   for (int64_t tile = wg * AG_PERSIST_WAVES + (threadIdx.x >> 6); tile < a.max_tiles; tile += stride) {
-    if (tile * AG_TW >= E) break;
+    int64_t live_end;                    // entries of the list at or beyond this index are not live
+    if (a.seg_tile_live) {
+      const int live = a.seg_tile_live[tile];
+      if (live == 0) continue;
+      live_end = tile * AG_TW + live;
+    } else {
+      live_end = E;
+      if (tile * AG_TW >= E) break;
+    }
     int lane = lane0;
     asm volatile("" : "+v"(lane));
     const int q = lane >> 4;
     const int64_t e = tile * AG_TW + (lane & 15);
-    const bool valid = e < E;
+    const bool valid = e < live_end;
     const int s = valid ? a.src[e] : 0, t = valid ? a.dst[e] : 0;
     const float d = valid ? a.len[e] : 0.0f;
     const int64_t pe = a.pos_index ? (valid ? (int64_t)a.pos_index[e] : 0) : e;
@@ -1226,15 +1236,40 @@ extern "C" int agdiff_cfconv_local(const agdiff_params_t* p, const agdiff_topo_t
                              ws->l_scale, ws->l_attr_frag, ws->xs, ws->agg_loc, ws->agg_first_loc, stream);
 }
 
+namespace {
+int launch_pair_head_poly(const agdiff_params_t* p, const int32_t* n_edges_dev, int64_t max_tiles,
+                          const int32_t* src, const int32_t* dst, const float* len, const float* node_h,
+                          const int32_t* pos_index, const int32_t* mir_index, float* out, const int32_t* seg_tile_live,
+                          void* stream);
+}
+
 extern "C" int agdiff_pair_head_poly(const agdiff_params_t* p, const int32_t* n_edges_dev, int64_t max_tiles,
                                      const int32_t* src, const int32_t* dst, const float* len, const float* node_h,
                                      const int32_t* pos_index, const int32_t* mir_index, float* out, void* stream) {
-  if (!p || !n_edges_dev || !src || !dst || !len || !node_h || !out || max_tiles < 0 || (!pos_index != !mir_index))
+  if (!n_edges_dev) return AGDIFF_ERR_ARG;
+  return launch_pair_head_poly(p, n_edges_dev, max_tiles, src, dst, len, node_h, pos_index, mir_index, out, nullptr, stream);
+}
+
+extern "C" int agdiff_pair_head_poly_rows(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
+                                          int32_t parity, void* stream) {
+  if (!p || !topo || !ws || !ws->canon_counter || !ws->inv_r) return AGDIFF_ERR_ARG;
+  const int64_t tiles = (topo->max_edges - topo->num_local + AG_TW - 1) / AG_TW + 1;
+  return launch_pair_head_poly(p, ws->canon_counter + (parity & 1), tiles, ws->c_src, ws->c_dst, ws->c_len, ws->h, ws->c_pos,
+                               ws->c_mir, ws->inv_r, nullptr, stream);
+}
+
+namespace {
+int launch_pair_head_poly(const agdiff_params_t* p, const int32_t* n_edges_dev, int64_t max_tiles,
+                          const int32_t* src, const int32_t* dst, const float* len, const float* node_h,
+                          const int32_t* pos_index, const int32_t* mir_index, float* out, const int32_t* seg_tile_live,
+                          void* stream) {
+  if (!p || !src || !dst || !len || !node_h || !out || max_tiles < 0 || (!pos_index != !mir_index))
     return AGDIFF_ERR_ARG;
   if (p->poly_kt < 1 || p->poly_kt > AGDIFF_POLY_MAX_KT || !p->head_global.attr_poly_pk) return AGDIFF_ERR_ARG;
   if (max_tiles == 0) return AGDIFF_OK;
   HeadPolyArgs a;
   a.hp = p->head_global;
+  a.seg_tile_live = seg_tile_live;
   a.n_dev = n_edges_dev;
   a.src = src;
   a.dst = dst;
@@ -1264,6 +1299,7 @@ extern "C" int agdiff_pair_head_poly(const agdiff_params_t* p, const int32_t* n_
   AG_CHECK_LAUNCH();
   return AGDIFF_OK;
 }
+}  // namespace
 
 extern "C" int agdiff_local_edge_rows(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, void* stream) {
   if (!p || !topo || !ws) return AGDIFF_ERR_ARG;

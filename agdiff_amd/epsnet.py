@@ -535,12 +535,76 @@ class LangevinRun:
             self._nz_base = k
         return self._nz[k - self._nz_base]
 
+    def _fused_front(self):
+        """The polynomial path keeps the serial front of a step in one launch (agdiff_sampler_front: update of step t +
+        radius graph of step t + 1): whenever the radius edges have their polynomials and the graph is built here."""
+        return self.pk.poly_kt > 0 and getattr(self.model, "fused_front", True)
+
+    def _fill_args(self, a, k, dev, N):
+        sig, step_size, noise_scale, use_global = self._sched[k]
+        cur = self._noise_for(k, dev, N)
+        a.noise = _lib.ptr(cur)
+        a.traj_out = ctypes.c_void_p(self.traj[k].data_ptr()) if self.traj is not None else ctypes.c_void_p(0)
+        a.sigma = sig
+        a.step_size = step_size
+        a.noise_scale = noise_scale
+        a.use_global = 1 if use_global else 0
+        return cur, bool(use_global or not self.skip_discarded)
+
+    def _advance_fused(self, end):
+        """Steps k .. end - 1 with ONE launch between a step's global head and the next step's first CFConv: iteration k
+        enqueues [update of step k - 1 | radius graph of step k] (agdiff_sampler_front), then the forward on the graph it
+        left (AGDIFF_FWD_GRAPH_READY); a last update-only launch closes the chunk."""
+        lib, a, pk, topo, ws = self.lib, self.args, self.pk, self.topo, self.ws
+        dev, N = self.pos.device, topo.N
+        stream = _lib.stream_ptr()
+        V = _lib.DEFINES
+        cutoff = ctypes.c_float(0.0 if (self.radius_flags & V["AGDIFF_FWD_NO_RADIUS"]) else float(self.model.config.cutoff))
+        P, T, W = ctypes.byref(pk.struct), ctypes.byref(topo.struct), ctypes.byref(ws.struct)
+        first, keep = self.k, []
+        split_graph = bool(getattr(self.model, "front_split_graph", False))
+        ws.canon_counter.zero_()
+        self._graph_parity = 0
+        while self.k < end:
+            k, i = self.k, self.steps[self.k]
+            run_global = 1 if (self._sched[k][3] or not self.skip_discarded) else 0
+            if run_global:                   # the canonical list's length counter alternates with every graph build
+                self._graph_parity ^= 1
+            par = self._graph_parity
+            pending = bool(run_global) and split_graph
+            # update(k - 1) | radius graph(k) | local edges(k)   (a carries step k - 1 when an update is due; its noise row
+            # stays alive in `keep`).  With `front_split_graph` the graph phase is launched by the forward, after the fork.
+            mode = (1 if k > first else 0) | (2 if (run_global and not pending) else 0) | 4 | (par << 4)
+            _lib.check(lib.agdiff_sampler_front(P, T, W, ctypes.byref(a), mode, cutoff, stream), "agdiff_sampler_front")
+            if k > first and self.on_step is not None:
+                self.on_step(k - 1, self.steps[k - 1], self.pos)
+            self.global_steps += run_global
+            cached = V["AGDIFF_FWD_STAGE0_CACHED"] if (run_global and self._stage0_done) else 0
+            _lib.check(lib.agdiff_score_forward(P, T, W, self.pos_p, run_global | self.radius_flags | self._sampler_flag | cached |
+                                                V["AGDIFF_FWD_GRAPH_READY"] | (V["AGDIFF_FWD_PARITY"] if par else 0) |
+                                                (V["AGDIFF_FWD_GRAPH_PENDING"] if pending else 0), stream), "agdiff_score_forward")
+            self._stage0_done = self._stage0_done or bool(run_global)
+            keep = [self._fill_args(a, k, dev, N)[0]]
+            a.use_global = 1 if self._sched[k][3] else 0
+            self.k += 1
+            if self.raise_on_nan and self.k % self.nan_every == 0 and self.k < end:
+                self.check_nan()
+        if end > first:     # the chunk's last update
+            _lib.check(lib.agdiff_sampler_front(P, T, W, ctypes.byref(a), 1, cutoff, stream), "agdiff_sampler_front")
+            if self.on_step is not None:
+                self.on_step(end - 1, self.steps[end - 1], self.pos)
+            if self.raise_on_nan and (self.k % self.nan_every == 0 or self.k == len(self.steps)):
+                self.check_nan()
+        del keep
+
     def advance(self, m):
         lib, a, pk, topo, ws = self.lib, self.args, self.pk, self.topo, self.ws
         dev, N = self.pos.device, topo.N
         stream = _lib.stream_ptr()
         end = min(self.k + int(m), len(self.steps))
         with torch.no_grad():
+            if self._fused_front():
+                return self._advance_fused(end)
             while self.k < end:
                 k, i = self.k, self.steps[self.k]
                 cur = self._noise_for(k, dev, N)

@@ -188,6 +188,7 @@ class BatchTopology:
         self.lt_eid = np.where(real_t, eid_t, -1)
         self.lc_tpos = i32(tpos[lc_pos])
         self.lc_tmir = i32(np.where(lc_mir >= 0, tpos[np.maximum(lc_mir, 0)], -1))
+        self.lcm_ptr = i32(np.searchsorted(ba[src[lc_pos]], np.arange(G + 1)) if L else np.zeros(G + 1))
         self.local_types = np.unique(typ)                 # PackedParams.ensure_local_types (per-type filter polynomials)
         # int64 copies of the local edges for the API results (forward() returns int64 indices)
         self.loc_index64 = torch.from_numpy(np.stack([src, dst])).to(device)
@@ -210,7 +211,7 @@ class BatchTopology:
         for f in ("graph_ptr", "atom_type", "loc_src", "loc_dst", "loc_type", "loc_out_ptr", "loc_in_ptr", "loc_in_eid",
                   "lc_src", "lc_dst", "lc_type", "lc_pos", "lc_mir", "loc_row", "loc_in_src",
                   "loc_in_row", "lp_ptr", "lp_src", "lp_dst", "lp_type", "lp_row", "lc_ppos", "lc_pmir",
-                  "pair_tgt", "lt_ptr", "lt_src", "lt_type", "lc_tpos", "lc_tmir"):
+                  "pair_tgt", "lt_ptr", "lt_src", "lt_type", "lc_tpos", "lc_tmir", "lcm_ptr"):
             setattr(t, f, _lib.ptr(getattr(self, f)))
         self.struct = t
 
@@ -240,9 +241,10 @@ class Workspace:
         self.e_loc = i32(etiles * TW)
         self.num_canon = i32(1)
         self.graph_canon_cnt, self.graph_canon_ptr = i32(G), i32(G + 1)
-        self.c_len = f32(etiles * TW)
-        self.c_type, self.c_src, self.c_dst = i32(etiles * TW), i32(etiles * TW), i32(etiles * TW)
-        self.c_pos, self.c_mir = i32(etiles * TW), i32(etiles * TW)
+        cn = etiles * TW
+        self.c_len = f32(cn)
+        self.c_type, self.c_src, self.c_dst = i32(cn), i32(cn), i32(cn)
+        self.c_pos, self.c_mir = i32(cn), i32(cn)
         self.e_len = f32(etiles * TW)
         self.e_attr = f32(etiles * TW * 128)
         self.e_inv_global = f32(etiles * TW)
@@ -266,6 +268,8 @@ class Workspace:
         self.r_scale = f32(2 * _lib.DEFINES["AGDIFF_MAX_CONVS"] * N * RS)
         self.lt_len = f32(TW * topo.T)
         self.lt_scale = f32(2 * _lib.DEFINES["AGDIFF_MAX_CONVS"] * TW * topo.T)
+        self.inv_r = f32(N * RS)
+        self.canon_counter = i32(2)
         self.variant_log = torch.zeros(1, dtype=torch.int64)          # host word (include/agdiff_hip.h: AGDIFF_VAR_*)
         self.num_local_padded = torch.tensor([Lp], dtype=torch.int32, device=dev)
         self.l_scale = f32(2 * _lib.DEFINES["AGDIFF_MAX_CONVS"] * ptiles * TW)

@@ -287,6 +287,9 @@ def main():
     ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"])
     ap.add_argument("--radius-poly", default="auto", choices=["auto", "radius", "kt2", "off"],
                     help="filter polynomials (agdiff_amd/packing.py): off = every edge through the encoder + filter MLPs")
+    ap.add_argument("--front", default="fused", choices=["fused", "split", "unfused"],
+                    help="serial front of a step: one launch (update + local edges + radius graph), the same with the graph "
+                         "phase launched after the local branch's fork, or the unfused kernels (A/B runs)")
     ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL all-gather path even with one rank")
     ap.add_argument("--job-steps", type=int, default=JOB_STEPS, help="denoising steps of one sampling job (5000; the "
                     "alanine dipeptide example runs 100)")
@@ -342,6 +345,7 @@ def main():
         m = get_model(cfg)
         m.precision = args.precision
         m.radius_poly = radius_poly or args.radius_poly
+        m.fused_front, m.front_split_graph = args.front != "unfused", args.front == "split"
         m.load_state_dict(synth.synth_state_dict(m.state_dict()))
         return m.to(dev).eval(), cfg
     model, cfg = make_model(args.schedule)

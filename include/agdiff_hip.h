@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 30
+#define AGDIFF_ABI_VERSION 33
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -191,6 +191,7 @@ typedef struct agdiff_params {
 #define AGDIFF_VAR_HEAD_POLY 1024       /* global head with the edge_attr half from the d-polynomial */
 #define AGDIFF_VAR_SIDE_STREAM 2048     /* local branch forked onto the side stream */
 #define AGDIFF_VAR_POLY_L2_SETS 4096    /* agdiff_cfconv_node: some local types' coefficient sets did not fit in LDS (read from L2) */
+#define AGDIFF_VAR_FUSED_FRONT 8192     /* agdiff_sampler_front: update of step t + radius graph of step t + 1 in one launch */
 
 /* ---- static topology of one packed batch (host builds it once per batch) ---------------------
  * Graphs are contiguous node ranges (PyG Batch, utils/misc.py:88-90).  "Local" edges are the
@@ -244,6 +245,8 @@ typedef struct agdiff_topo {
    * and the sum over a target's edges needs no masks, and a tile holds few distinct types */
   int64_t num_pairs;         /* P */
   const int32_t* pair_tgt;   /* [2 P] */
+  const int32_t* lcm_ptr;    /* [G+1]: the canonical local edges lc_*[lcm_ptr[g] .. lcm_ptr[g+1]) belong to molecule g (the list is
+                                sorted by source) */
   int64_t local_type_mask[2];/* bit t of the 128-bit mask: the batch has a local edge of type t */
   int64_t num_local_tiles;   /* T = lt_ptr[P] */
   const int32_t* lt_ptr;     /* [P + 1]: tiles of pair p are [lt_ptr[p], lt_ptr[p+1]) */
@@ -331,6 +334,9 @@ typedef struct agdiff_ws {
   float*   agg_first_loc;    /* [ceil(ceil(Lp/16) / agdiff_conv_chunk_tiles(Lp))][192] */
   float*   lt_len;           /* [16 T] lengths of the local edges by pair-tile row (agdiff_local_lengths; pads stay 0) */
   float*   lt_scale;         /* [2*num_convs][16 T]: lw(d)*C(d) by pair-tile row (pad rows stay 0) */
+  float*   inv_r;            /* [N * AGDIFF_RAD_STRIDE] grad_global_dist_mlp output by radius row (fused sampler front) */
+  int32_t* canon_counter;    /* [2] live length of the fused sampler front's canonical radius list, by step parity: every molecule
+                                claims its range of ws->c_* with one atomic add on [parity] (and molecule 0 zeroes the other) */
   int64_t* variant_log;      /* [host] one word or null: every launcher ORs the AGDIFF_VAR_* bit of the variant it chose */
 } agdiff_ws_t;
 
@@ -490,8 +496,39 @@ int agdiff_cfconv_aggregate(const float* x, const float* W, const int32_t* in_pt
  *                           earlier call with AGDIFF_FWD_GLOBAL on the same workspace wrote them): stage 0 -- embedding
  *                           look-up and block 0's lin1, which do not depend on `pos` -- is not launched again */
 #define AGDIFF_FWD_STAGE0_CACHED 16
+/*   AGDIFF_FWD_GRAPH_READY  (with AGDIFF_FWD_SAMPLER, poly_kt > 0) agdiff_sampler_front has already built this step's radius rows,
+ *                           their scales and its canonical radius list from `pos` (and written the local edges' lengths and
+ *                           pair-tile scales): no graph build here; the global head's outputs go to ws->inv_r (by radius
+ *                           row), where the next agdiff_sampler_front reads them.  AGDIFF_FWD_PARITY: the step's parity bit
+ *                           (which of ws->canon_counter[2] holds the list's length) */
+#define AGDIFF_FWD_GRAPH_READY 32
+#define AGDIFF_FWD_PARITY 64
+/*   AGDIFF_FWD_GRAPH_PENDING (with AGDIFF_FWD_GRAPH_READY) the front has run its update and local phases only (mode 1 | 4): the
+ *                           graph phase (mode 2) is launched here, on `stream`, AFTER the local branch has been forked onto the
+ *                           side stream -- the local branch then runs beside it instead of beside the first CFConv */
+#define AGDIFF_FWD_GRAPH_PENDING 128
 int agdiff_score_forward(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
                          const float* pos, int32_t flags, void* stream);
+
+/* The serial front of a denoising step in ONE launch (csrc/front.hip), one workgroup per molecule:
+ *   mode & 1  the Langevin update of the step described by `s` (eq_transform x 2, clip_norm, move, NaN check, center_pos,
+ *             clamp, trajectory row: geometry.py:9-17, dualenc.py:506-545, 581-589) from ws->l_inv and -- when
+ *             s->use_global -- ws->inv_r over the radius rows the last graph phase wrote;
+ *   mode & 2  then the radius graph of the NEXT forward on the positions just written (s->pos_out; s->pos_in without an
+ *             update): ws->rad_cnt / rad_src / rad_len / r_scale with pad rows, and the canonical radius list ws->c_len /
+ *             c_src / c_dst / c_pos / c_mir (c_pos / c_mir = radius rows) of live length ws->canon_counter[parity], parity =
+ *             (mode >> 4) & 1 alternating from step to step.  `cutoff` = p->cutoff, or 0 for extend_radius = False;
+ *   mode & 4  and, on the same positions, what agdiff_local_lengths and agdiff_edge_scales_split(which = 2) write: the local
+ *             edges' lengths in every layout (ws->l_len, lc_len, l_len_p, lt_len) and their CFConv scales by pair-tile row
+ *             (ws->lt_scale) -- agdiff_score_forward then skips both (AGDIFF_FWD_GRAPH_READY).
+ * The following agdiff_score_forward takes AGDIFF_FWD_SAMPLER | AGDIFF_FWD_GRAPH_READY.  Replaces agdiff_langevin_update +
+ * agdiff_graph_build_scaled inside the denoising loop (models/common.py:208-233 is rebuilt every step). */
+int agdiff_sampler_front(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
+                         const agdiff_step_args_t* s, int32_t mode, float cutoff, void* stream);
+/* The polynomial global head (agdiff_pair_head_poly) over the canonical radius list of agdiff_sampler_front (step parity as
+ * there): results to ws->inv_r at the entry's radius row and its mirror's. */
+int agdiff_pair_head_poly_rows(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t parity,
+                               void* stream);
 
 /* In-step timing of the dominant kernel (bench.py's roofline object): between agdiff_profile_cfconv(1) and (0) every CFConv
  * launch that agdiff_score_forward issues for the global branch (one InteractionBlock's agdiff_cfconv_node [+ agdiff_cfconv_local],

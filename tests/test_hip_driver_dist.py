@@ -217,8 +217,26 @@ def test_full_size_properties_other_configs(kind, mols, copies, min_mean_deg):
     p1, tr1 = m.langevin_dynamics_sample_diffusion(at, pos_init, bi, bt, ba, b["num_graphs"], **kw)
     p2, tr2 = m.langevin_dynamics_sample_diffusion(at, pos_init, bi, bt, ba, b["num_graphs"], **kw)
     assert torch.equal(p1, p2) and torch.equal(torch.stack(tr1), torch.stack(tr2))
-    ws, topo = m._batch_cache[2], m._batch_cache[1]
-    E, C = int(ws.num_edges.item()), int(ws.num_canon.item())
+    wsf, topo = m._batch_cache[2], m._batch_cache[1]
+    # what the fused front (agdiff_sampler_front) left for the last forward: radius rows and the segmented canonical list
+    cnt = wsf.rad_cnt.cpu().numpy()
+    ccnt = wsf.canon_counter.cpu().numpy()           # [parity of the last graph build] = live length, the other 0
+    assert cnt.max() <= 33 and ccnt.min() == 0 < ccnt.max()
+    live = np.arange(int(ccnt.max()))
+    cs, cd, cp, cm = [x.cpu().numpy()[live] for x in (wsf.c_src, wsf.c_dst, wsf.c_pos, wsf.c_mir)]
+    RS = 48
+    assert np.array_equal(cp // RS, cd) and np.all(cp % RS < cnt[cd])                 # an entry's row belongs to its target
+    mk = cm >= 0
+    assert np.array_equal(cm[mk] // RS, cs[mk]) and np.all(cs[mk] < cd[mk])            # its mirror's row to its source
+    rsrc = wsf.rad_src.cpu().numpy()
+    assert np.array_equal(rsrc[cp], cs) and np.array_equal(rsrc[cm[mk]], cd[mk])
+    cover = np.bincount(np.concatenate([cp, cm[mk]]), minlength=topo.N * RS).reshape(topo.N, RS)
+    assert all(np.array_equal(cover[i, :cnt[i]], np.ones(cnt[i], int)) and cover[i, cnt[i]:].sum() == 0 for i in range(0, topo.N, 7))
+    C_front, Ec_front = int(ccnt.max()), int(cnt.sum())
+    # the full destination-sorted list of the same (final) positions, as forward() builds it
+    m(at, p1, bi, bt, ba, None, extend_order=False)
+    ws = m._batch_cache[2]
+    E, C = int(ws.num_edges.item()), C_front
     ip = ws.in_ptr.cpu().numpy()
     indeg = np.diff(ip)
     dst, src = ws.e_dst[:E].cpu().numpy(), ws.e_src[:E].cpu().numpy()
@@ -229,7 +247,7 @@ def test_full_size_properties_other_configs(kind, mols, copies, min_mean_deg):
     batch = b["batch"]
     assert np.array_equal(batch[src], batch[dst])                    # no edge crosses a molecule
     # the denoising loop with filter polynomials keeps only RADIUS edges in the canonical list (agdiff_graph_build_ex)
-    Ec = int(ws.rad_cnt.sum().item()) if m.packed().poly_kt > 0 else E
+    Ec = Ec_front if m.packed().poly_kt > 0 else E
     if kind == "qm9":
         assert 2 * C == Ec                                           # uncapped: every edge has its mirror
     else:

@@ -441,6 +441,7 @@ def test_full_size_properties():
     p1, tr1 = m.langevin_dynamics_sample_diffusion(at, pos_init, bi, bt, ba, b["num_graphs"], **kw)
     p2, tr2 = m.langevin_dynamics_sample_diffusion(at, pos_init, bi, bt, ba, b["num_graphs"], **kw)
     assert torch.equal(p1, p2) and torch.equal(torch.stack(tr1), torch.stack(tr2))
+    m(at, p1, bi, bt, ba, None, extend_order=False)        # (the loop itself keeps no full edge list: forward() builds one)
     ws, topo = m._batch_cache[2], m._batch_cache[1]
     E = int(ws.num_edges.item())
     indeg = np.diff(ws.in_ptr.cpu().numpy())

@@ -306,6 +306,7 @@ def test_radius_only_canonical_list_of_the_sampler(kind, mols, copies):
     from agdiff_amd import drugs_model_config, qm9_model_config, synth
     cfg = (qm9_model_config if kind == "qm9" else drugs_model_config)(num_diffusion_timesteps=20, beta_end=2e-5)
     m = _model(cfg, "auto")
+    m.fused_front = False                # (the unfused loop: agdiff_langevin_update + agdiff_graph_build_scaled per step)
     b = synth.make_packed_batch(kind, mols, copies, seed=23)
     at, bi, bt, ba = [t(b[k]).cuda() for k in ("atom_type", "bond_index", "bond_type", "batch")]
     pos_init = torch.randn(at.shape[0], 3, generator=torch.Generator().manual_seed(6)).cuda()
@@ -372,3 +373,62 @@ def test_local_edge_rows_polynomial_and_flagged_tiles(precision):
         rows = torch.from_numpy(lens > cfg.cutoff)
         assert torch.equal(got[rows], ref[rows])
         assert name == "stretched" or not torch.equal(got[~rows], ref[~rows])
+
+
+@pytest.mark.parametrize("kind,mols,copies", [("drugs", 4, 3), ("qm9", 6, 4)])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_fused_front_equals_the_unfused_loop(kind, mols, copies, precision):
+    """agdiff_sampler_front (update of step t + radius graph of step t + 1 in one launch, scores by radius row) against the
+    unfused loop (agdiff_langevin_update + agdiff_graph_build_scaled, scores by position in the full list): the graph phase
+    alone writes the radius rows, scales and pad rows of agdiff_graph_build_scaled bit for bit and the same canonical
+    entries (molecule by molecule, in the order the workgroups claim their ranges); six denoising steps agree to fp32 rounding (the update sums a node's terms over another
+    lane partition)."""
+    from agdiff_amd import _lib, drugs_model_config, qm9_model_config, synth
+    lib = _lib.load()
+    RS = _lib.DEFINES["AGDIFF_RAD_STRIDE"]
+    cfg = (qm9_model_config if kind == "qm9" else drugs_model_config)(num_diffusion_timesteps=20, beta_end=2e-5)
+    m = _model(cfg, "auto", precision=precision)
+    b = synth.make_packed_batch(kind, mols, copies, seed=29)
+    at, bi, bt, ba = [t(b[k]).cuda() for k in ("atom_type", "bond_index", "bond_type", "batch")]
+    gen = torch.Generator().manual_seed(7)
+    pos_init = torch.randn(at.shape[0], 3, generator=gen)
+    noise = torch.randn(6, at.shape[0], 3, generator=gen)
+    kw = dict(extend_order=False, n_steps=6, w_global=1.0, global_start_sigma=0.5, clip=1000.0, noise=noise.cuda())
+    m.fused_front = True
+    pf, tf = m.langevin_dynamics_sample_diffusion(at, pos_init.cuda(), bi, bt, ba, b["num_graphs"], **kw)
+    assert _variants(m._batch_cache[2]) & _lib.DEFINES["AGDIFF_VAR_FUSED_FRONT"]
+    m.fused_front = False
+    pu, tu = m.langevin_dynamics_sample_diffusion(at, pos_init.cuda(), bi, bt, ba, b["num_graphs"], **kw)
+    assert not _variants(m._batch_cache[2]) & _lib.DEFINES["AGDIFF_VAR_FUSED_FRONT"]
+    assert float((torch.stack(tf) - torch.stack(tu)).abs().max()) < 2e-6 * float(torch.stack(tu).abs().max())
+    # structure: the graph phase alone, on the unfused run's final positions, next to agdiff_graph_build_scaled
+    topo, ws, pk = m._batch_cache[1], m._batch_cache[2], m.packed()
+    P, T, W, st = ctypes.byref(pk.struct), ctypes.byref(topo.struct), ctypes.byref(ws.struct), _lib.stream_ptr()
+    pos = pu.contiguous()
+    assert lib.agdiff_graph_build_scaled(P, T, W, _lib.ptr(pos), ctypes.c_float(cfg.cutoff), 1, st) == 0
+    torch.cuda.synchronize()
+    N = topo.N
+    ref = {k: getattr(ws, k).clone() for k in ("rad_cnt", "rad_src", "rad_len", "r_scale")}
+    C = int(ws.num_canon.item())
+    full_pos = ws.c_pos[:C].long()
+    ref_c = set(zip(ws.c_src[:C].tolist(), ws.c_dst[:C].tolist(), ws.c_len[:C].tolist(), (ws.c_mir[:C] >= 0).tolist()))
+    for k in ("rad_cnt", "rad_src", "rad_len", "r_scale"):
+        getattr(ws, k).fill_(0)
+    sa = _lib.StepArgs()
+    sa.pos_in = _lib.ptr(pos)
+    ws.canon_counter.zero_()
+    assert lib.agdiff_sampler_front(P, T, W, ctypes.byref(sa), 2, ctypes.c_float(cfg.cutoff), st) == 0        # (parity 0)
+    torch.cuda.synchronize()
+    cnt = ws.rad_cnt.cpu().numpy()
+    assert torch.equal(ws.rad_cnt, ref["rad_cnt"])
+    used = torch.zeros(N, RS, dtype=torch.bool)
+    for i in range(N):
+        used[i, :(cnt[i] + 15) // 16 * 16] = True
+    u = used.view(-1).cuda()
+    assert torch.equal(ws.rad_src[u], ref["rad_src"][u]) and torch.equal(ws.rad_len[u], ref["rad_len"][u])
+    for c in range(2 * cfg.num_convs):
+        assert torch.equal(ws.r_scale.view(-1, N * RS)[c][u], ref["r_scale"].view(-1, N * RS)[c][u])
+    live = np.arange(int(ws.canon_counter[0].item()))
+    got_c = set(zip(ws.c_src.cpu().numpy()[live].tolist(), ws.c_dst.cpu().numpy()[live].tolist(),
+                    ws.c_len.cpu().numpy()[live].tolist(), (ws.c_mir.cpu().numpy()[live] >= 0).tolist()))
+    assert live.size == C and got_c == ref_c

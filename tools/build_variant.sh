@@ -6,7 +6,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 name=$1; shift
 mkdir -p "$root/_ab/build_$name"
 cd "$root/agdiff_amd/csrc"
-for f in graph edge nodeconv node eval api; do
+for f in graph front edge nodeconv node eval api; do
   flags=""
   [ $f = edge ] && flags="-fno-honor-nans"
   [ $f = nodeconv ] && flags="-fno-honor-nans -fno-slp-vectorize"

@@ -8,7 +8,7 @@ f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
-idx = [i for i, n in enumerate(names) if "k_langevin_update" in n]
+idx = [i for i, n in enumerate(names) if "k_sampler_front" in n] or [i for i, n in enumerate(names) if "k_langevin_update" in n]
 a, b = idx[12], idx[13]
 t0 = int(rows[a]["Start_Timestamp"])
 for r in rows[a:b + 1]:
