@@ -72,14 +72,10 @@ __device__ unsigned long long ag_node_stamp_acc[8];
 // Everything a tile needs from memory (sources, lengths, the two scales, type slots; then the first x group) is requested
 // during the wave's previous tile; x groups are double-buffered inside a tile.
 // Lengths beyond the cutoff are clamped into the fitted range: their CFConv scale is exactly 0 (schnet.py:140-146).
-#ifndef AG_NODE_GRP
-#define AG_NODE_GRP 3                       // channel tiles per x / MFMA group
-#endif
-#ifndef AG_NODE_XD
-#define AG_NODE_XD 2                        // x groups in flight (ring of buffers; must divide the number of groups: static indices)
-#endif
+#define AG_NODE_GRP 2                       // channel tiles per x / MFMA group
+#define AG_NODE_XD 2                        // x groups in flight per tile
 #ifndef AG_NODE_ABL
-#define AG_NODE_ABL 0       // timing experiments only (wrong results): 1 no x gathers, 2 no filter MFMAs, 4 no features, 8 no sums, 16 one coefficient read per group
+#define AG_NODE_ABL 0       // timing experiments only (wrong results): 1 no x gathers, 2 no filter MFMAs, 4 no features, 8 no sums
 #endif
 template <int MODE, int NKT, int WAVES>
 __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvArgs a) {
@@ -113,133 +109,169 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
     r.nL = with_local ? a.lt_ptr[p + 1] - r.lt0 : 0;
     return r;
   };
-  // first row of tile j of a pair (order: local tiles, radius tiles of target 2 p, radius tiles of target 2 p + 1)
-  auto tile_rows = [&](const PairInfo& pi, int p, int j, bool& local) -> int {
-    local = j < pi.nL;
-    if (local) return (pi.lt0 + j) * AG_TW;
+  // Work items of a pair, in this order: its local tiles, then the radius UNITS of its first target, then those of its second.
+  // A unit is two consecutive 16-row tiles of ONE target (rows 32 u .. 32 u + 31 of its radius rows; the second tile absent
+  // when the target has no more rows): both tiles run against each coefficient block read from LDS -- the LDS reads of the
+  // coefficient sets were this kernel's busiest pipe with one tile per read -- and the MFMAs of one tile overlap the sums
+  // of the other inside the wave.
+  struct Item { bool local, hasY; int rowsX, rowsY; };
+  auto n_items = [&](const PairInfo& pi) { return pi.nL + (pi.nA + 1) / 2 + (pi.nB + 1) / 2; };
+  auto item_at = [&](const PairInfo& pi, int j) -> Item {
+    Item it;
+    it.local = j < pi.nL;
+    it.hasY = false;
+    it.rowsY = 0;
+    if (it.local) {
+      it.rowsX = (pi.lt0 + j) * AG_TW;
+      return it;
+    }
     j -= pi.nL;
-    return (j < pi.nA) ? pi.tA * AGDIFF_RAD_STRIDE + j * AG_TW : pi.tB * AGDIFF_RAD_STRIDE + (j - pi.nA) * AG_TW;
+    const int uA = (pi.nA + 1) / 2;
+    const int tgt = (j < uA) ? pi.tA : pi.tB, nt = (j < uA) ? pi.nA : pi.nB, u = (j < uA) ? j : j - uA;
+    it.rowsX = tgt * AGDIFF_RAD_STRIDE + 2 * u * AG_TW;
+    it.hasY = 2 * u + 1 < nt;
+    it.rowsY = it.rowsX + AG_TW;
+    return it;
   };
-  // per-row inputs of the wave's NEXT tile: length, the two scales and the type slot of row `col`, the sources of the lane's
-  // four rows 4 q .. 4 q + 3
-  float pf_d = 0.f, pf_s1 = 0.f, pf_s2 = 0.f;
+  // per-row inputs of one tile: length and the two scales of row `col`, the sources of the lane's four rows 4 q .. 4 q + 3
+  struct Meta { float d, s1, s2; int src[4]; };
+  Meta pfX = {0.f, 0.f, 0.f, {0, 0, 0, 0}}, pfY = {0.f, 0.f, 0.f, {0, 0, 0, 0}};
   int pf_slot = -1;
-  int pf_src[4] = {0, 0, 0, 0};
   // (uniform base pointer + 32-bit lane offset: the saddr form of global_load; 64-bit lane pointers per array cost a register
   // pair each and spilled)
   auto ldf = [](const float* base, uint32_t byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); };
   auto ldi = [](const int32_t* base, uint32_t byte_off) { return *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(base) + byte_off); };
-  auto prefetch_meta = [&](int rows, bool local) {
+  auto prefetch_rows = [&](Meta& m, int rows, bool local) {
     const uint32_t e4 = (uint32_t)(rows + col) * 4u;
     const uint32_t r16 = (uint32_t)(rows + 4 * q) * 4u;
     const int32_t* srcs = local ? a.lt_src : a.rad_src;
     const u32x4 s4 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(srcs) + r16);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) pf_src[r] = (int)s4[r];
+    for (int r = 0; r < 4; ++r) m.src[r] = (int)s4[r];
     if (local) {
       pf_slot = ldi(a.type_slot, (uint32_t)ldi(a.lt_type, e4) * 4u);
-      pf_d = ldf(a.lt_len, e4);
-      pf_s1 = ldf(a.l_scale1, e4);
-      pf_s2 = ldf(a.l_scale2, e4);
+      m.d = ldf(a.lt_len, e4);
+      m.s1 = ldf(a.l_scale1, e4);
+      m.s2 = ldf(a.l_scale2, e4);
     } else {
-      pf_slot = -1;
-      pf_d = ldf(a.rad_len, e4);
-      pf_s1 = ldf(a.r_scale1, e4);
-      pf_s2 = ldf(a.r_scale2, e4);
+      m.d = ldf(a.rad_len, e4);
+      m.s1 = ldf(a.r_scale1, e4);
+      m.s2 = ldf(a.r_scale2, e4);
     }
   };
-  // x[src] values of a group of AG_NODE_GRP channel tiles, two groups in flight
-  static_assert((AG_CONV_NCH / AG_NODE_GRP) % AG_NODE_XD == 0 && AG_NODE_XD >= 2, "ring of x buffers");
-  f32x4 xg[AG_NODE_XD][AG_NODE_GRP];
-  uint32_t xoff[4];
-  auto set_xoff = [&]() {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) xoff[r] = ((uint32_t)pf_src[r] * 192u + (uint32_t)col) * 4u;
+  auto prefetch_item = [&](const Item& it) {
+    prefetch_rows(pfX, it.rowsX, it.local);
+    if (it.hasY) prefetch_rows(pfY, it.rowsY, false);
   };
-  auto fetch_xg = [&](auto BUF, int g) {
-    constexpr int kb = decltype(BUF)::value;
+  // x[src] values of a group of AG_NODE_GRP channel tiles, two groups in flight per tile of the unit
+  static_assert(AG_NODE_GRP == 2 && AG_NODE_XD == 2, "unit pipeline: groups of two channel tiles, two x groups in flight");
+  f32x4 xX[2][AG_NODE_GRP], xY[2][AG_NODE_GRP];
+  uint32_t xoffX[4], xoffY[4];
+  auto set_xoff = [&](uint32_t (&xo)[4], const Meta& m) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xo[r] = ((uint32_t)m.src[r] * 192u + (uint32_t)col) * 4u;
+  };
+  auto fetch_g = [&](f32x4 (&x)[AG_NODE_GRP], const uint32_t (&xo)[4], int g) {
     const char* xb = reinterpret_cast<const char*>(a.xs);
 #pragma unroll
-    for (int j = 0; j < AG_NODE_GRP; ++j) {
+    for (int jj = 0; jj < AG_NODE_GRP; ++jj) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (AG_NODE_ABL & 1) xg[kb][j][r] = __uint_as_float(xoff[r] + (uint32_t)(AG_NODE_GRP * g + j));
-        else xg[kb][j][r] = *reinterpret_cast<const float*>(xb + (size_t)xoff[r] + 64 * (AG_NODE_GRP * g + j));
+        if (AG_NODE_ABL & 1) x[jj][r] = __uint_as_float(xo[r] + (uint32_t)(AG_NODE_GRP * g + jj));
+        else x[jj][r] = *reinterpret_cast<const float*>(xb + (size_t)xo[r] + 64 * (AG_NODE_GRP * g + jj));
       }
     }
-  };
-  // the first AG_NODE_XD - 1 x groups of a radius tile (requested before the tile starts)
-  auto fetch_first_groups = [&]() {
-    ag_static_for<0, AG_NODE_XD - 1>([&](auto G) { fetch_xg(G, decltype(G)::value); });
   };
   const lds_u32x4* wl_l = wl + lane;
-  // CN channel tiles C0 .. C0 + CN - 1 of one coefficient set (pk [12][NKT]: block nt * NKT + t) times the features:
-  // independent accumulator chains with their MFMA passes interleaved
-  auto mma_tiles = [&](auto base, auto C0_, const AgIn<MODE> (&ph)[NKT], auto& z, auto INIT_) {
+  // coefficient blocks of CN channel tiles C0 .. (pk [12][NKT]: block nt * NKT + t) of one set
+  auto load_w = [&](auto base, auto C0_, auto& w) {
     constexpr int C0 = decltype(C0_)::value;
-    constexpr int CN = sizeof(z) / sizeof(f32x4);
-    constexpr bool INIT = decltype(INIT_)::value;       // z starts from zero: the first MFMA takes the literal 0
-    u32x4 w[CN][NKT][2];
+    constexpr int CN = sizeof(w) / (sizeof(u32x4) * NKT * 2);
 #pragma unroll
-    for (int j = 0; j < CN; ++j) {
+    for (int jj = 0; jj < CN; ++jj) {
 #pragma unroll
       for (int t = 0; t < NKT; ++t) {
-        if ((AG_NODE_ABL & 16) && j > 0) {            // (timing experiment: one coefficient block read per group)
-          w[j][t][0] = w[0][t][0];
-          w[j][t][1] = w[0][t][1];
+        if ((AG_NODE_ABL & 16) && jj > 0) {            // (timing experiment: one coefficient block read per group)
+          w[jj][t][0] = w[0][t][0];
+          w[jj][t][1] = w[0][t][1];
           continue;
         }
-        w[j][t][0] = base[(((C0 + j) * NKT + t) * 2) * 64];
-        w[j][t][1] = base[(((C0 + j) * NKT + t) * 2 + 1) * 64];
+        w[jj][t][0] = base[(((C0 + jj) * NKT + t) * 2) * 64];
+        w[jj][t][1] = base[(((C0 + jj) * NKT + t) * 2 + 1) * 64];
       }
     }
+  };
+  // ... times the features: independent accumulator chains with their MFMA passes interleaved.  INIT: z starts from zero (the
+  // first MFMA takes the literal 0)
+  auto mma_w = [&](const auto& w, const AgIn<MODE> (&ph)[NKT], auto& z, auto INIT_) {
+    constexpr int CN = sizeof(z) / sizeof(f32x4);
+    constexpr bool INIT = decltype(INIT_)::value;
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
 #pragma unroll
       for (int part = 0; part < AgParts<MODE>::n; ++part) {
 #pragma unroll
-        for (int j = 0; j < CN; ++j) {
+        for (int jj = 0; jj < CN; ++jj) {
           if (AG_NODE_ABL & 2) {
             if (t == 0 && part == 0) {
               u32x4 pu;
               __builtin_memcpy(&pu, &ph[0], 16);
-              z[j] = (INIT ? f32x4{0.f, 0.f, 0.f, 0.f} : z[j]) + __builtin_bit_cast(f32x4, w[j][0][0]) * __uint_as_float(pu[0]);
+              z[jj] = (INIT ? f32x4{0.f, 0.f, 0.f, 0.f} : z[jj]) + __builtin_bit_cast(f32x4, w[jj][0][0]) * __uint_as_float(pu[0]);
             }
-          } else if (INIT && t == 0 && part == 0) z[j] = ag_block_mma_first<MODE, true>(ph[0], w[j][0]);
-          else ag_block_mma_part<MODE, true>(z[j], ph[t], w[j][t], part);
+          } else if (INIT && t == 0 && part == 0) z[jj] = ag_block_mma_first<MODE, true>(ph[0], w[jj][0]);
+          else ag_block_mma_part<MODE, true>(z[jj], ph[t], w[jj][t], part);
         }
       }
     }
+  };
+  auto mma_tiles = [&](auto base, auto C0_, const AgIn<MODE> (&ph)[NKT], auto& z, auto INIT_) {
+    constexpr int CN = sizeof(z) / sizeof(f32x4);
+    u32x4 w[CN][NKT][2];
+    load_w(base, C0_, w);
+    mma_w(w, ph, z, INIT_);
   };
   // x[src] values of four channel tiles C0 .. C0 + 3 (local tiles fetch their own)
   auto fetch_x4 = [&](f32x4 (&x)[4], int c0) {
     const char* xb = reinterpret_cast<const char*>(a.xs);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int jj = 0; jj < 4; ++jj) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) x[j][r] = *reinterpret_cast<const float*>(xb + (size_t)xoff[r] + 64 * (c0 + j));
+      for (int r = 0; r < 4; ++r) x[jj][r] = *reinterpret_cast<const float*>(xb + (size_t)xoffX[r] + 64 * (c0 + jj));
     }
   };
 
-  // features of the wave's next RADIUS tile (its rows' inputs are in pf_*): channel tiles 0..7 are conv1 (features x its lw C),
-  // 8..11 conv2
-  AgIn<MODE> ph1[NKT], ph2[NKT];
-  auto next_features = [&]() {
+  // features of the wave's next radius unit (its rows' inputs are in pfX / pfY): channel tiles 0..7 are conv1 (features x its
+  // lw C), 8..11 conv2
+  AgIn<MODE> phX1[NKT], phX2[NKT], phY1[NKT], phY2[NKT];
+  auto features_of = [&](const Meta& m, AgIn<MODE> (&p1)[NKT], AgIn<MODE> (&p2)[NKT]) {
     if (AG_NODE_ABL & 4) {
 #pragma unroll
       for (int t = 0; t < NKT; ++t) {
-        f32x4 v1[2] = {{pf_d, pf_s1, pf_d, pf_s1}, {pf_s1, pf_d, pf_s1, pf_d}}, v2[2] = {{pf_d, pf_s2, pf_d, pf_s2}, {pf_s2, pf_d, pf_s2, pf_d}};
-        __builtin_memcpy(&ph1[t], v1, 32);
-        __builtin_memcpy(&ph2[t], v2, 32);
+        f32x4 v1[2] = {{m.d, m.s1, m.d, m.s1}, {m.s1, m.d, m.s1, m.d}}, v2[2] = {{m.d, m.s2, m.d, m.s2}, {m.s2, m.d, m.s2, m.d}};
+        __builtin_memcpy(&p1[t], v1, 32);
+        __builtin_memcpy(&p2[t], v2, 32);
       }
     } else {
-      ag_poly_features<MODE, NKT>(pf_d, a.two_over_rc, q, ph1, pf_s1);
-      ag_poly_features<MODE, NKT>(pf_d, a.two_over_rc, q, ph2, pf_s2);
+      ag_poly_features<MODE, NKT>(m.d, a.two_over_rc, q, p1, m.s1);
+      ag_poly_features<MODE, NKT>(m.d, a.two_over_rc, q, p2, m.s2);
     }
+  };
+  // everything the next radius unit needs before it starts: gather offsets, its first two x groups, its features
+  auto start_unit = [&](const Item& it) {
+    set_xoff(xoffX, pfX);
+    fetch_g(xX[0], xoffX, 0);
+    fetch_g(xX[1], xoffX, 1);
+    if (it.hasY) {
+      set_xoff(xoffY, pfY);
+      fetch_g(xY[0], xoffY, 0);
+      fetch_g(xY[1], xoffY, 1);
+    }
+    features_of(pfX, phX1, phX2);
+    if (it.hasY) features_of(pfY, phY1, phY2);
   };
   float acc[AG_CONV_NCH], accL[AG_CONV_NCH];
   // the sums over the wave's quarters, once per target: quarter j of a reduce-scatter ends up with channel tile 4 g + j.
-  // `upper`: target 2 p + 1, whose local rows are rows 8..15 = quarters 2, 3 of the pair's local tiles
+  // `upper`: the pair's second target, whose local rows are rows 8..15 = quarters 2, 3 of the pair's local tiles
   auto finalize = [&](int tgt, bool upper) {
     char* dp = reinterpret_cast<char*>(a.agg + (size_t)tgt * 192);       // (uniform)
     const bool mine = (q >= 2) == upper;
@@ -247,7 +279,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
     for (int g = 0; g < AG_CONV_NCH / 4; ++g) {
       float v[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = acc[4 * g + j] + (mine ? accL[4 * g + j] : 0.0f);
+      for (int jj = 0; jj < 4; ++jj) v[jj] = acc[4 * g + jj] + (mine ? accL[4 * g + jj] : 0.0f);
       *reinterpret_cast<float*>(dp + (uint32_t)(16 * (4 * g + q) + col) * 4u) = ag_quarter_reduce_scatter4(v[0], v[1], v[2], v[3]);
     }
   };
@@ -264,114 +296,103 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
     const int pn = p + WAVES;
     PairInfo pin = {0, 0, 0, 0, 0, -1};
     if (pn < p_end) pin = pair_info(pn);
-    const int ntiles = pi.nL + pi.nA + pi.nB;
-    if (ntiles > 0 && !have_pf) {               // cold start (first pair of the wave, or the pair before had no tile)
-      bool loc;
-      const int rows = tile_rows(pi, p, 0, loc);
-      prefetch_meta(rows, loc);
-      if (!loc) {                               // (a local tile fetches its own x values and evaluates its own features)
-        set_xoff();
-        fetch_first_groups();
-        next_features();
-      }
+    const int nitems = n_items(pi);
+    if (nitems > 0 && !have_pf) {               // cold start (first pair of the wave, or the pair before had no item)
+      const Item it = item_at(pi, 0);
+      prefetch_item(it);
+      if (!it.local) start_unit(it);           // (a local tile fetches its own x values and evaluates its own features)
     }
 #pragma unroll
     for (int i = 0; i < AG_CONV_NCH; ++i) accL[i] = 0.0f;
-    // the wave's next tile after tile j (of this pair, or the first one of its next pair)
-    auto next_tile = [&](int j, bool& nloc, bool& has_next) -> int {
+    // the wave's next item after item j (of this pair, or the first one of its next pair)
+    auto next_item = [&](int j, bool& has_next) -> Item {
       has_next = true;
-      nloc = false;
-      if (j + 1 < ntiles) return tile_rows(pi, p, j + 1, nloc);
-      if (pin.nL + pin.nA + pin.nB > 0) return tile_rows(pin, pn, 0, nloc);
+      if (j + 1 < nitems) return item_at(pi, j + 1);
+      if (n_items(pin) > 0) return item_at(pin, 0);
       has_next = false;
-      return 0;
+      return Item{false, false, 0, 0};
     };
-    // A radius tile (one target) as a software pipeline over its four groups of three channel tiles: the MFMAs of group g + 1
-    // are issued BEFORE the sums of group g (acc += z x), so that the matrix pipe works while the wave's VALU does the
-    // sums; the x values of group g + 2 are requested into the buffer the sums have just freed; the next tile's per-row
-    // inputs are requested at the start, its first x group and -- behind the last group's MFMAs -- its features
-    // (ph1 / ph2 are carried from tile to tile) at the end.  A local tile fetches / evaluates its own.
-    auto radius_tile = [&](int j) {
-      bool nloc, has_next;
-      const int nrows = next_tile(j, nloc, has_next);
-      if (has_next) prefetch_meta(nrows, nloc);
-      auto mma_g = [&](auto GG, f32x4 (&z)[AG_NODE_GRP]) {
-        constexpr int c0 = AG_NODE_GRP * decltype(GG)::value;
-        // channel tiles 0..7 take conv1's features, 8..11 conv2's (a group of three straddles the boundary once: 6, 7 | 8)
-        if constexpr (c0 + AG_NODE_GRP <= 8) {
-          mma_tiles(wl_l, std::integral_constant<int, c0>{}, ph1, z, std::true_type{});
-        } else if constexpr (c0 >= 8) {
-          mma_tiles(wl_l, std::integral_constant<int, c0>{}, ph2, z, std::true_type{});
-        } else {
-          static_assert(AG_NODE_GRP == 3 && c0 == 6, "group layout");
-          f32x4 (&za)[2] = *reinterpret_cast<f32x4 (*)[2]>(&z[0]);
-          f32x4 (&zb)[1] = *reinterpret_cast<f32x4 (*)[1]>(&z[2]);
-          mma_tiles(wl_l, std::integral_constant<int, 6>{}, ph1, za, std::true_type{});
-          mma_tiles(wl_l, std::integral_constant<int, 8>{}, ph2, zb, std::true_type{});
-        }
-      };
-      auto sums = [&](auto GG, const f32x4 (&z)[AG_NODE_GRP]) {
-        constexpr int gg = decltype(GG)::value;
+    // A radius unit: per group of two channel tiles ONE read of the coefficient blocks, the MFMAs of tile X, those of tile Y,
+    // then the sums acc += z x of X (while Y's MFMAs run) and of Y; the x values two groups ahead go into the buffer the
+    // sums have just freed -- of this unit, or, for the last two groups, of the wave's next unit, whose per-row inputs were
+    // requested at the start and whose features follow at the end.
+    auto radius_unit = [&](int j, bool hasY) {
+      bool has_next;
+      const Item nx = next_item(j, has_next);
+      AG_NSTAMP(t0);
+      // (the current unit's inputs sit in xoff / x / ph already: pfX / pfY are free for the next item's)
+      if (has_next) prefetch_item(nx);
+      const bool next_unit = has_next && !nx.local;
+      ag_static_for<0, NG>([&](auto G) {
+        constexpr int g = decltype(G)::value;
+        constexpr int c0 = AG_NODE_GRP * g;
+        u32x4 w[AG_NODE_GRP][NKT][2];
+        load_w(wl_l, std::integral_constant<int, c0>{}, w);
+        f32x4 zX[AG_NODE_GRP], zY[AG_NODE_GRP];
+        mma_w(w, (c0 < 8) ? phX1 : phX2, zX, std::true_type{});
+        if (hasY) mma_w(w, (c0 < 8) ? phY1 : phY2, zY, std::true_type{});
 #pragma unroll
         for (int jj = 0; jj < AG_NODE_GRP; ++jj) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             if ((AG_NODE_ABL & 8) && r) continue;
-            acc[AG_NODE_GRP * gg + jj] = fmaf(z[jj][r], xg[gg % AG_NODE_XD][jj][r], acc[AG_NODE_GRP * gg + jj]);
+            acc[c0 + jj] = fmaf(zX[jj][r], xX[g & 1][jj][r], acc[c0 + jj]);
           }
-          // (pins the sum to this step: the optimiser otherwise sinks all 48 FMAs of a tile below its last MFMA -- nothing
+          // (pins the sum to this step: the optimiser otherwise sinks every FMA of a unit below its last MFMA -- nothing
           // needs acc before the target is complete -- and the wave then waits for x loads and MFMAs with nothing to do)
-          asm volatile("" : "+v"(acc[AG_NODE_GRP * gg + jj]));
+          asm volatile("" : "+v"(acc[c0 + jj]));
         }
-      };
-      f32x4 z[2][AG_NODE_GRP];
-      // (fences between the steps: the scheduler otherwise hoists every group's coefficient reads to the top of the tile and
-      // spills; inside a step it is free to run the sums beside the MFMAs)
-      AG_NSTAMP(t0);
-      constexpr int XD = AG_NODE_XD;
-      fetch_xg(std::integral_constant<int, XD - 1>{}, XD - 1);
-      mma_g(std::integral_constant<int, 0>{}, z[0]);
-      __builtin_amdgcn_sched_barrier(0);
-      AG_NSTAMP(t1);
-      ag_static_for<1, NG>([&](auto G) {
-        constexpr int g = decltype(G)::value;
-        mma_g(G, z[g & 1]);
-        sums(std::integral_constant<int, g - 1>{}, z[(g - 1) & 1]);
-        // the buffer the sums have just freed takes the group XD - 1 steps ahead: of this tile, or -- once all of this tile's
-        // gathers are out and xoff is free -- of the wave's next radius tile (whose features follow the last request)
-        if constexpr (g + XD - 1 < NG) {
-          fetch_xg(std::integral_constant<int, (g - 1) % XD>{}, g + XD - 1);
-        } else if (has_next && !nloc) {
-          if constexpr (g + XD - 1 == NG) set_xoff();
-          fetch_xg(std::integral_constant<int, (g - 1) % XD>{}, g + XD - 1 - NG);
-          if constexpr (g == NG - 1) next_features();
+        if constexpr (g + 2 < NG) fetch_g(xX[g & 1], xoffX, g + 2);
+        if (hasY) {
+#pragma unroll
+          for (int jj = 0; jj < AG_NODE_GRP; ++jj) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if ((AG_NODE_ABL & 8) && r) continue;
+              acc[c0 + jj] = fmaf(zY[jj][r], xY[g & 1][jj][r], acc[c0 + jj]);
+            }
+            asm volatile("" : "+v"(acc[c0 + jj]));
+          }
+          if constexpr (g + 2 < NG) fetch_g(xY[g & 1], xoffY, g + 2);
+        }
+        if constexpr (g + 2 >= NG) {             // (all of this unit's gathers of the buffer are out: the next unit's first groups)
+          if (next_unit) {
+            if constexpr (g + 2 == NG) {
+              set_xoff(xoffX, pfX);
+              if (nx.hasY) set_xoff(xoffY, pfY);
+            }
+            fetch_g(xX[g & 1], xoffX, g + 2 - NG);
+            if (nx.hasY) fetch_g(xY[g & 1], xoffY, g + 2 - NG);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       });
       AG_NSTAMP(t4);
-      sums(std::integral_constant<int, NG - 1>{}, z[(NG - 1) & 1]);
+      if (next_unit) {
+        features_of(pfX, phX1, phX2);
+        if (nx.hasY) features_of(pfY, phY1, phY2);
+      }
       have_pf = has_next;
 #ifdef AG_NODE_STAMPS
       __builtin_amdgcn_sched_barrier(0);
       const unsigned long long t5 = __builtin_amdgcn_s_memtime();
-      st_acc[0] += t1 - t0;
-      st_acc[1] += t4 - t1;
+      st_acc[0] += t4 - t0;
       st_acc[4] += t5 - t4;
       st_acc[5] += 1ull;
 #endif
     };
-    // A local tile (rows 0..7: target 2 p, rows 8..15: target 2 p + 1; several edge types): conv2's four channel tiles
-    // first, then conv1's eight; per conv the wave loops over the types present in the tile, each adding its masked
+    // A local tile (rows 0..7: the pair's first target, rows 8..15: its second; several edge types): conv2's four channel
+    // tiles first, then conv1's eight; per phase the wave loops over the types present in the tile, each adding its masked
     // features times its own coefficient set.  The tile is long enough to fetch its own x values behind its MFMAs.
     auto local_tile = [&](int j) {
-      const float d = pf_d, s1 = pf_s1, s2 = pf_s2;
+      const float d = pfX.d, s1 = pfX.s1, s2 = pfX.s2;
       const int my_slot = pf_slot;
-      bool nloc, has_next;
-      const int nrows = next_tile(j, nloc, has_next);
-      set_xoff();
+      bool has_next;
+      const Item nx = next_item(j, has_next);
+      set_xoff(xoffX, pfX);
       f32x4 xa[4];                              // one buffer: a phase's rounds are long enough for the next phase's values to land
       fetch_x4(xa, 8);
-      if (has_next) prefetch_meta(nrows, nloc);
+      if (has_next) prefetch_item(nx);
       const uint64_t rows_mask = __ballot(my_slot >= 0) & 0xFFFFull;      // one lane per row (the quarters hold copies)
       // z[...] = sum over the types present of (features of that type's rows) x (that type's coefficient blocks C0 ..)
       auto typed_rounds = [&](const AgIn<MODE> (&ph)[NKT], auto C0_, auto& z) {
@@ -434,38 +455,60 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
         fetch_x4(xa, 4);
         phase(ph1, std::integral_constant<int, 4>{}, xa);
       }
-      if (has_next && !nloc) {
-        set_xoff();
-        fetch_first_groups();
-        next_features();
+      if (has_next && !nx.local) {
+        start_unit(nx);
+        if (!nx.hasY) {                         // (definite writes keep the unused half out of this tile's live registers)
+          const u32x4 zero = {0u, 0u, 0u, 0u};
+          u32x4 zz[2] = {zero, zero};
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int jj = 0; jj < AG_NODE_GRP; ++jj) xY[b][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int t = 0; t < NKT; ++t) {
+            __builtin_memcpy(&phY1[t], zz, 32);
+            __builtin_memcpy(&phY2[t], zz, 32);
+          }
+        }
       } else {                                  // (definite writes: keep the buffers and the features out of this tile's live registers)
-#pragma unroll
-        for (int b = 0; b < AG_NODE_XD - 1; ++b)
-#pragma unroll
-          for (int jj = 0; jj < AG_NODE_GRP; ++jj) xg[b][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
         const u32x4 zero = {0u, 0u, 0u, 0u};
         u32x4 zz[2] = {zero, zero};
 #pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int jj = 0; jj < AG_NODE_GRP; ++jj) {
+            xX[b][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+            xY[b][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+#pragma unroll
         for (int t = 0; t < NKT; ++t) {
-          __builtin_memcpy(&ph1[t], zz, 32);
-          __builtin_memcpy(&ph2[t], zz, 32);
+          __builtin_memcpy(&phX1[t], zz, 32);
+          __builtin_memcpy(&phX2[t], zz, 32);
+          __builtin_memcpy(&phY1[t], zz, 32);
+          __builtin_memcpy(&phY2[t], zz, 32);
         }
       }
       have_pf = has_next;
     };
     int j = 0;
+#ifndef AG_NODE_NO_LOCAL        // (timing experiment: the kernel without its local-tile code -- fewer registers, more waves)
     for (; j < pi.nL; ++j) local_tile(j);
+#endif
 #pragma unroll
     for (int i = 0; i < AG_CONV_NCH; ++i) acc[i] = 0.0f;
+    const int first_b = pi.nL + (pi.nA + 1) / 2;
     bool first_done = false;
-    for (; j < ntiles; ++j) {
-      if (j == pi.nL + pi.nA) {                 // target 2 p is complete: write it, start target 2 p + 1
+    for (; j < nitems; ++j) {
+      if (j == first_b) {                       // the pair's first target is complete: write it, start the second
         finalize(pi.tA, false);
         first_done = true;
 #pragma unroll
         for (int i = 0; i < AG_CONV_NCH; ++i) acc[i] = 0.0f;
       }
-      radius_tile(j);
+      const int jr = j - pi.nL;
+      const int uA = (pi.nA + 1) / 2;
+      const bool hasY = (jr < uA) ? (2 * jr + 1 < pi.nA) : (2 * (jr - uA) + 1 < pi.nB);
+      radius_unit(j, hasY);
     }
     if (!first_done) {
       finalize(pi.tA, false);
@@ -473,7 +516,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
       for (int i = 0; i < AG_CONV_NCH; ++i) acc[i] = 0.0f;
     }
     if (pi.tB >= 0) finalize(pi.tB, true);
-    if (ntiles == 0) have_pf = false;
+    if (nitems == 0) have_pf = false;
     p = pn;
     pi = pin;
   }
