@@ -252,9 +252,18 @@ def drugs200_job(seed):
     return mols200, driver.num_confs("2x")
 
 
+def live_edges(run):
+    """Directed edges of the run's current graph.  The fused sampler front keeps no full edge list (and no `num_edges`): the
+    graph is the radius rows (`rad_cnt` per target) plus the local edges, which extend_graph_order_radius always keeps
+    (common.py:222-233)."""
+    if run._fused_front():
+        return int(run.ws.rad_cnt.sum().item()) + run.topo.L
+    return int(run.ws.num_edges.item())
+
+
 def load_pmc(precision, edges, kernels):
     """HBM traffic / SQ counters of the dominant kernel from the committed rocprofv3 --pmc summaries of this round
-    (tools/pmc_traffic.sh, tools/pmc_sq.sh; separate counter passes, never inside a timed run): used when they were taken
+    (tools/pmc_bench.sh; separate counter passes, never inside a timed run): used when they were taken
     on this workload (edge count of a launch within 2 %), else null."""
     tf = os.path.join(ROOT, "profiles", "%s_%s_pmc.json" % (PROFILE_ROUND, precision))
     if not os.path.exists(tf):
@@ -376,7 +385,7 @@ def main():
             ms = el / K_ * 1e3
             tot_ms += ms
             G_local += b["num_graphs"]
-            E_b = int(run.ws.num_edges.item())
+            E_b = live_edges(run)
             gl += gfrac
             if pr is not None and pr[1] > 0:
                 pm, pn = pm + pr[0], pn + pr[1]
@@ -426,7 +435,7 @@ def main():
                                                      rank, use_dist, profile=profile)
         G = b["num_graphs"]
         if pr is not None and pr[1] > 0:
-            E_b = int(run.ws.num_edges.item())
+            E_b = live_edges(run)
             prof_ms, prof_n, prof_flop, prof_edges = pr[0], pr[1], float(E_b) * FLOP_PER_EDGE_CFCONV * pr[1], float(E_b) * pr[1]
         if use_dist:
             tt = torch.tensor([el], dtype=torch.float64, device=dev)
@@ -447,7 +456,7 @@ def main():
         wl = ("%s-shaped synthetic molecules: %d molecules x %d conformers %s (this rank: %d atoms, %d edges, %d local "
               "edges), %s schedule, global branch active on %.0f%% of timed steps, %d-step job"
               % (kind, mols, copies, "in ONE global batch cut into per-rank graph ranges" if strong
-                 else "per GPU", run.topo.N, int(run.ws.num_edges.item()), run.topo.L, args.schedule, 100 * global_frac,
+                 else "per GPU", run.topo.N, live_edges(run), run.topo.L, args.schedule, 100 * global_frac,
                  JOB_STEPS))
 
     # ---- dominant operation = the two CFConvs of one InteractionBlock (encoder/schnet.py:136-162, 12 per forward).  With the
@@ -457,7 +466,7 @@ def main():
     # arithmetic (E x 90,112 FLOP per block) over that time.
     ws, topo, pk = run.ws, run.topo, run.pk
     stream = _lib.stream_ptr()
-    E = int(ws.num_edges.item())
+    E = live_edges(run)
     poly_info = {"mode": args.radius_poly, "poly_kt": pk.poly_kt, "local_type_slots": int(pk.struct.poly_num_slots),
                  "fit_errors_vs_float64_networks": {str(k): v for k, v in pk.poly_errors.items()}}
     roof = None
@@ -508,6 +517,9 @@ def main():
     agg_roof = None
     if E > 0 and rank == 0:
         F = 128
+        if run._fused_front():      # (the sampler kept radius rows only: the full destination-sorted list of the same positions)
+            lib.agdiff_graph_build(T_, W_, run.pos_p, ctypes.c_float(cfg.cutoff), stream)
+            E = int(ws.num_edges.item())
         Wt = torch.randn(E, F, device=dev)
         xin = torch.randn(topo.N, F, device=dev)
         outt = torch.empty(topo.N, F, device=dev)

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Interleaved timing of tools/nodeconv_time.py with every _ab/lib_*.so (and the tree's own library) on ONE box.
+# (The FIRST timing of a process runs on a colder chip: compare like positions only.)
 # Usage (GPU box): bash tools/nodeconv_ab.sh [reps] [harness args]
 reps=${1:-2}; shift
 cd "$GRAFT_REPO_ROOT"

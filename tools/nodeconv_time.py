@@ -52,6 +52,22 @@ cnt = ws.rad_cnt.cpu().numpy()
 out = {"N": topo.N, "E": int(ws.num_edges.item()), "L": topo.L, "R": int(cnt.sum()), "local_tiles": topo.T,
        "radius_tiles": int(((cnt + 15) // 16).sum()), "radius_rows_padded": int((((cnt + 15) // 16) * 16).sum()),
        "rad_cnt_hist": np.bincount((cnt + 15) // 16, minlength=4).tolist()}
+# how evenly the fixed pair -> wave assignment of k_cfconv_node spreads the work (cost model: a radius tile 1, a local tile 2)
+pt = topo.pair_tgt.cpu().numpy().reshape(-1, 2)
+ltp = topo.lt_ptr.cpu().numpy()
+tiles = (cnt + 15) // 16
+cost = tiles[pt[:, 0]] + np.where(pt[:, 1] >= 0, tiles[np.maximum(pt[:, 1], 0)], 0) + 2.0 * (ltp[1:] - ltp[:-1])
+Pn, wgs, W = cost.size, min(256, (cost.size + 11) // 12), 12
+per_wg = (Pn + wgs - 1) // wgs
+wave_cost, wg_cost = np.zeros((wgs, W)), np.zeros(wgs)
+for w in range(wgs):
+    c = cost[w * per_wg:min((w + 1) * per_wg, Pn)]
+    wg_cost[w] = c.sum()
+    for k in range(W):
+        wave_cost[w, k] = c[k::W].sum()
+xcd = wg_cost.reshape(8, -1).sum(1) if wgs % 8 == 0 else wg_cost
+out["balance"] = {"pair_cost_mean": float(cost.mean()), "pair_cost_std": float(cost.std()), "wave_max_over_mean": float(wave_cost.max() / wave_cost.mean()),
+                  "wg_max_over_mean": float(wg_cost.max() / wg_cost.mean()), "xcd_contiguous_max_over_mean": float(xcd.max() / xcd.mean())}
 if args.only:
     pk.set_tuning(local_poly_off=1 if args.only == "radius" else 0)
     out["%s_x%d_ms" % (args.only, nc)] = timeit(lambda: [lib.agdiff_cfconv_node(P, Tp, Wp, k, st) for k in range(nc)])
