@@ -25,4 +25,4 @@ for kind, cfgf in (("drugs", drugs_model_config), ("qm9", qm9_model_config)):
     same = torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     ws = m._batch_cache[2]
     print(kind, "400 steps over the whole schedule: finite", bool(torch.isfinite(outs[0][0]).all()), "bitwise reproducible", same,
-          "flagged local tiles at the end", int(ws.enc_flags[0].item()), "radius edges", int(ws.num_rad.item()))
+          "flagged local tiles at the end", int(ws.enc_flags[0].item()), "radius edges", int(ws.rad_cnt.sum().item()))
