@@ -30,8 +30,8 @@ struct NodeConvArgs {
   const float* rad_len;
   const float* r_scale1;      // lw(d)*C(d) of conv1 / conv2 of this block by radius row
   const float* r_scale2;
-  // local pair tiles (agdiff_topo_t.lt_*, agdiff_ws_t.lt_*)
-  const int32_t* pair_tgt;    // [2 P]: the two targets of a pair (second: -1 for none)
+  // local quad tiles (agdiff_topo_t.lt_*, agdiff_ws_t.lt_*)
+  const int32_t* quad_tgt;    // [4 Q]: the four targets of a quad (-1: none)
   const int32_t* lt_ptr;
   const int32_t* lt_src;
   const int32_t* lt_type;
@@ -41,37 +41,30 @@ struct NodeConvArgs {
   const float* xs;            // [N][192]
   float* agg;                 // [N][192]
   int32_t n;                  // N
-  int32_t num_pairs;          // ceil(N / 2)
+  int32_t num_quads;          // Q
   float two_over_rc;
 };
 
-#ifdef AG_NODE_STAMPS
-// diagnostic build (make EXTRA=-DAG_NODE_STAMPS): where a wave's time goes inside a radius tile -- s_memtime deltas of the
-// five steps summed over all waves ([0..4]), tiles stamped ([5]), s_memrealtime total ([6]) and s_memtime total ([7])
-__device__ unsigned long long ag_node_stamp_acc[8];
-#define AG_NSTAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-#else
-#define AG_NSTAMP(var) do { } while (0)
-#endif
-
 // encoder/schnet.py:136-162 for conv1 and conv2 of one InteractionBlock, filters from d-polynomials:
 //   W_e = nn(MLPEdgeEncoder(d_e, type_e)) = P_type(d_e);   agg[dst] += x[src] * W_e * (lw(d_e) C(d_e)).
-// One wave owns a PAIR of targets (topo->pair_tgt: two atoms of one molecule with like local in-lists) and walks, in this
-// order, the pair's local tiles (rows 0..7 = in-edges of its first target, rows 8..15 = of its second; static,
-// topo->lt_*), the radius tiles of the first, the radius tiles of the second
-// (every 16-row tile of the radius list belongs to one target, ws->rad_*).  Per tile: the K = 32 NKT polynomial features
-// of each row, SCALED by the row's lw C (one set per conv: the per-edge scale rides through the MFMAs), times the
-// LDS-resident coefficient blocks (flipped product: rows = edges, lanes = channels), then x[src] gathered per (row,
-// channel) and  acc[channel tile] += sum_r z[r] x[r]  -- four FMAs per channel tile, no masks, no list bounds, no
-// carries between waves: a lane's four rows (4 q + r) always belong to one target.  When a target's tiles are done the
-// sums over the wave's quarters are taken once (reduce-scatter over the quarters, three lane swaps per four channel
-// tiles) and the target's row of agg is written once, complete (zeros for a target without edges): no agg_first, no second
-// aggregate for the node stage to add, no atomics, fixed order => bitwise reproducible.
-// Local tiles: rows of several types; the wave loops over the types present (typically three), each adding its masked
-// features times its own coefficient set -- sets 0..lds_slots-1 from LDS, rarer ones straight from L2.
-// Everything a tile needs from memory (sources, lengths, the two scales, type slots; then the first x group) is requested
-// during the wave's previous tile; x groups are double-buffered inside a tile.
+// One wave owns a QUAD of targets (topo->quad_tgt: four atoms of one molecule whose local in-lists need like tiles) and
+// walks, in this order, the quad's local tiles (static, topo->lt_*: 16 rows of ONE edge type, rows 4 k .. 4 k + 3 = in-edges
+// of the quad's k-th target) and the radius tiles of its first, second, third and fourth target (every 16-row tile of the
+// radius rows belongs to one target, ws->rad_*).  EVERY tile runs the same body: the K = 32 NKT polynomial features of each
+// row, SCALED by the row's lw C (one set per conv: the per-edge scale rides through the MFMAs), times the coefficient
+// blocks of the tile's set (flipped product: rows = edges, lanes = channels), then x[src] gathered per (row, channel) and
+//   sum[channel tile] += sum_r z[r] x[r]  -- four FMAs per channel tile, no masks, no list bounds, no carries between waves:
+// a lane's four rows (4 q + r) always belong to one target.  Radius tiles add into acc (all four quarters = the current
+// target), local tiles into accL (quarter k = the quad's k-th target).  When a target's radius tiles are done, the sums
+// over the wave's quarters are taken once (reduce-scatter over the quarters, three lane swaps per four channel tiles) --
+// with accL entering from quarter k only -- and the target's row of agg is written once, complete (zeros for a target
+// without edges): no agg_first, no second aggregate for the node stage to add, no atomics, fixed order => bitwise
+// reproducible.  Coefficient sets: the radius edges' one and the first lds_slots typed ones in LDS, rarer ones from L2.
+// Everything a tile needs from memory (sources, lengths, the two scales, the type; then the first x groups) is requested
+// during the wave's previous tile, the features are evaluated there too; x groups are double-buffered inside a tile.
 // Lengths beyond the cutoff are clamped into the fitted range: their CFConv scale is exactly 0 (schnet.py:140-146).
+// A local tile whose type has no polynomial (mixed batches: agdiff_local_poly_enabled = 2) runs with scale 0: its edges
+// go through agdiff_cfconv_local.
 #ifndef AG_NODE_GRP
 #define AG_NODE_GRP 3                       // channel tiles per x / MFMA group
 #endif
@@ -95,33 +88,51 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
   const int q = lane >> 4, col = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wg = (gridDim.x % 8 == 0) ? (int)((blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8) : (int)blockIdx.x;
-  const int per_wg = (a.num_pairs + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int per_wg = (a.num_quads + (int)gridDim.x - 1) / (int)gridDim.x;
   const int p_begin = wg * per_wg;
-  const int p_end = (p_begin + per_wg < a.num_pairs) ? p_begin + per_wg : a.num_pairs;
+  const int p_end = (p_begin + per_wg < a.num_quads) ? p_begin + per_wg : a.num_quads;
   const bool with_local = a.num_slots > 0;
 
-  struct PairInfo { int nL, nA, nB, lt0, tA, tB; };
-  auto pair_info = [&](int p) -> PairInfo {
-    PairInfo r;
-    r.tA = a.pair_tgt[2 * p];
-    r.tB = a.pair_tgt[2 * p + 1];
-    const int cA = a.rad_cnt[r.tA];
-    const int cB = (r.tB >= 0) ? a.rad_cnt[r.tB] : 0;
-    r.nA = (cA + AG_TW - 1) / AG_TW;
-    r.nB = (cB + AG_TW - 1) / AG_TW;
-    r.lt0 = with_local ? a.lt_ptr[p] : 0;
-    r.nL = with_local ? a.lt_ptr[p + 1] - r.lt0 : 0;
-    return r;
+  // A quad's description in plain scalars (a struct of them ended up as a dynamically indexed stack object in scratch):
+  // nL local tiles from lt0, targets t0..t3 with n0..n3 radius tiles.
+#define AG_QUAD_DECL(P) int P##nL = 0, P##lt0 = 0, P##t0 = -1, P##t1 = -1, P##t2 = -1, P##t3 = -1, P##n0 = 0, P##n1 = 0, P##n2 = 0, P##n3 = 0
+#define AG_QUAD_LOAD(P, p)                                                              \
+  do {                                                                                  \
+    P##t0 = a.quad_tgt[4 * (p)];                                                        \
+    P##t1 = a.quad_tgt[4 * (p) + 1];                                                    \
+    P##t2 = a.quad_tgt[4 * (p) + 2];                                                    \
+    P##t3 = a.quad_tgt[4 * (p) + 3];                                                    \
+    P##n0 = tiles_of(P##t0);                                                            \
+    P##n1 = tiles_of(P##t1);                                                            \
+    P##n2 = tiles_of(P##t2);                                                            \
+    P##n3 = tiles_of(P##t3);                                                            \
+    P##lt0 = with_local ? a.lt_ptr[(p)] : 0;                                            \
+    P##nL = with_local ? a.lt_ptr[(p) + 1] - P##lt0 : 0;                                \
+  } while (0)
+#define AG_QUAD_ARGS(P) P##nL, P##lt0, P##t0, P##t1, P##t2, P##t3, P##n0, P##n1, P##n2
+  auto tiles_of = [&](int t) { return (t >= 0) ? (a.rad_cnt[t] + AG_TW - 1) / AG_TW : 0; };
+  // first row of tile j of a quad (order: local tiles, radius tiles of its first .. fourth target)
+  auto tile_rows = [&](int nL, int lt0, int t0, int t1, int t2, int t3, int n0, int n1, int n2, int j, bool& local) -> int {
+    local = j < nL;
+    if (local) return (lt0 + j) * AG_TW;
+    j -= nL;
+    int t = t0;
+    if (j >= n0) {
+      j -= n0;
+      t = t1;
+      if (j >= n1) {
+        j -= n1;
+        t = t2;
+        if (j >= n2) {
+          j -= n2;
+          t = t3;
+        }
+      }
+    }
+    return t * AGDIFF_RAD_STRIDE + j * AG_TW;
   };
-  // first row of tile j of a pair (order: local tiles, radius tiles of target 2 p, radius tiles of target 2 p + 1)
-  auto tile_rows = [&](const PairInfo& pi, int p, int j, bool& local) -> int {
-    local = j < pi.nL;
-    if (local) return (pi.lt0 + j) * AG_TW;
-    j -= pi.nL;
-    return (j < pi.nA) ? pi.tA * AGDIFF_RAD_STRIDE + j * AG_TW : pi.tB * AGDIFF_RAD_STRIDE + (j - pi.nA) * AG_TW;
-  };
-  // per-row inputs of the wave's NEXT tile: length, the two scales and the type slot of row `col`, the sources of the lane's
-  // four rows 4 q .. 4 q + 3
+  // per-row inputs of the wave's NEXT tile: length and the two scales of row `col`, the tile's type slot, the sources of the
+  // lane's four rows 4 q .. 4 q + 3
   float pf_d = 0.f, pf_s1 = 0.f, pf_s2 = 0.f;
   int pf_slot = -1;
   int pf_src[4] = {0, 0, 0, 0};
@@ -137,7 +148,8 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
 #pragma unroll
     for (int r = 0; r < 4; ++r) pf_src[r] = (int)s4[r];
     if (local) {
-      pf_slot = ldi(a.type_slot, (uint32_t)ldi(a.lt_type, e4) * 4u);
+      const int sl = ldi(a.type_slot, (uint32_t)ldi(a.lt_type, e4) * 4u);  // (the same for the 16 rows of a tile)
+      pf_slot = sl < 0 ? -2 : sl;                                           // (-2: a type without a polynomial)
       pf_d = ldf(a.lt_len, e4);
       pf_s1 = ldf(a.l_scale1, e4);
       pf_s2 = ldf(a.l_scale2, e4);
@@ -168,17 +180,16 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
       }
     }
   };
-  // the first AG_NODE_XD - 1 x groups of a radius tile (requested before the tile starts)
+  // the first AG_NODE_XD - 1 x groups of a tile (requested before the tile starts)
   auto fetch_first_groups = [&]() {
     ag_static_for<0, AG_NODE_XD - 1>([&](auto G) { fetch_xg(G, decltype(G)::value); });
   };
   const lds_u32x4* wl_l = wl + lane;
   // CN channel tiles C0 .. C0 + CN - 1 of one coefficient set (pk [12][NKT]: block nt * NKT + t) times the features:
-  // independent accumulator chains with their MFMA passes interleaved
-  auto mma_tiles = [&](auto base, auto C0_, const AgIn<MODE> (&ph)[NKT], auto& z, auto INIT_) {
+  // independent accumulator chains with their MFMA passes interleaved; z starts from zero (the first MFMA takes the literal 0)
+  auto mma_tiles = [&](auto base, auto C0_, const AgIn<MODE> (&ph)[NKT], auto& z) {
     constexpr int C0 = decltype(C0_)::value;
     constexpr int CN = sizeof(z) / sizeof(f32x4);
-    constexpr bool INIT = decltype(INIT_)::value;       // z starts from zero: the first MFMA takes the literal 0
     u32x4 w[CN][NKT][2];
 #pragma unroll
     for (int j = 0; j < CN; ++j) {
@@ -203,46 +214,39 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
             if (t == 0 && part == 0) {
               u32x4 pu;
               __builtin_memcpy(&pu, &ph[0], 16);
-              z[j] = (INIT ? f32x4{0.f, 0.f, 0.f, 0.f} : z[j]) + __builtin_bit_cast(f32x4, w[j][0][0]) * __uint_as_float(pu[0]);
+              z[j] = __builtin_bit_cast(f32x4, w[j][0][0]) * __uint_as_float(pu[0]);
             }
-          } else if (INIT && t == 0 && part == 0) z[j] = ag_block_mma_first<MODE, true>(ph[0], w[j][0]);
+          } else if (t == 0 && part == 0) z[j] = ag_block_mma_first<MODE, true>(ph[0], w[j][0]);
           else ag_block_mma_part<MODE, true>(z[j], ph[t], w[j][t], part);
         }
       }
     }
   };
-  // x[src] values of four channel tiles C0 .. C0 + 3 (local tiles fetch their own)
-  auto fetch_x4 = [&](f32x4 (&x)[4], int c0) {
-    const char* xb = reinterpret_cast<const char*>(a.xs);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) x[j][r] = *reinterpret_cast<const float*>(xb + (size_t)xoff[r] + 64 * (c0 + j));
-    }
-  };
 
-  // features of the wave's next RADIUS tile (its rows' inputs are in pf_*): channel tiles 0..7 are conv1 (features x its lw C),
-  // 8..11 conv2
+  // features of the wave's next tile (its rows' inputs are in pf_*): channel tiles 0..7 are conv1 (features x its lw C),
+  // 8..11 conv2.  A local tile whose type has no polynomial contributes nothing (scale 0)
   AgIn<MODE> ph1[NKT], ph2[NKT];
   auto next_features = [&]() {
+    const bool dead = with_local && pf_slot < -1;
+    const float s1 = dead ? 0.0f : pf_s1, s2 = dead ? 0.0f : pf_s2;
     if (AG_NODE_ABL & 4) {
 #pragma unroll
       for (int t = 0; t < NKT; ++t) {
-        f32x4 v1[2] = {{pf_d, pf_s1, pf_d, pf_s1}, {pf_s1, pf_d, pf_s1, pf_d}}, v2[2] = {{pf_d, pf_s2, pf_d, pf_s2}, {pf_s2, pf_d, pf_s2, pf_d}};
+        f32x4 v1[2] = {{pf_d, s1, pf_d, s1}, {s1, pf_d, s1, pf_d}}, v2[2] = {{pf_d, s2, pf_d, s2}, {s2, pf_d, s2, pf_d}};
         __builtin_memcpy(&ph1[t], v1, 32);
         __builtin_memcpy(&ph2[t], v2, 32);
       }
     } else {
-      ag_poly_features<MODE, NKT>(pf_d, a.two_over_rc, q, ph1, pf_s1);
-      ag_poly_features<MODE, NKT>(pf_d, a.two_over_rc, q, ph2, pf_s2);
+      ag_poly_features<MODE, NKT>(pf_d, a.two_over_rc, q, ph1, s1);
+      ag_poly_features<MODE, NKT>(pf_d, a.two_over_rc, q, ph2, s2);
     }
   };
   float acc[AG_CONV_NCH], accL[AG_CONV_NCH];
   // the sums over the wave's quarters, once per target: quarter j of a reduce-scatter ends up with channel tile 4 g + j.
-  // `upper`: target 2 p + 1, whose local rows are rows 8..15 = quarters 2, 3 of the pair's local tiles
-  auto finalize = [&](int tgt, bool upper) {
+  // `k`: the target's place in its quad -- its local rows are quarter k of the quad's local tiles
+  auto finalize = [&](int tgt, int k) {
     char* dp = reinterpret_cast<char*>(a.agg + (size_t)tgt * 192);       // (uniform)
-    const bool mine = (q >= 2) == upper;
+    const bool mine = q == k;
 #pragma unroll
     for (int g = 0; g < AG_CONV_NCH / 4; ++g) {
       float v[4];
@@ -254,44 +258,40 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
 
   int p = p_begin + wave;
   if (p >= p_end) return;                       // (no barrier below)
-#ifdef AG_NODE_STAMPS
-  const unsigned long long k_rt0 = __builtin_amdgcn_s_memrealtime(), k_t0 = __builtin_amdgcn_s_memtime();
-  unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
-#endif
-  PairInfo pi = pair_info(p);
+  AG_QUAD_DECL(c_);                             // the wave's current quad
+  AG_QUAD_LOAD(c_, p);
   bool have_pf = false;
   while (p < p_end) {
     const int pn = p + WAVES;
-    PairInfo pin = {0, 0, 0, 0, 0, -1};
-    if (pn < p_end) pin = pair_info(pn);
-    const int ntiles = pi.nL + pi.nA + pi.nB;
-    if (ntiles > 0 && !have_pf) {               // cold start (first pair of the wave, or the pair before had no tile)
+    AG_QUAD_DECL(x_);                           // ... and its next one
+    if (pn < p_end) AG_QUAD_LOAD(x_, pn);
+    const int ntiles = c_nL + c_n0 + c_n1 + c_n2 + c_n3;
+    const int ntiles_next = x_nL + x_n0 + x_n1 + x_n2 + x_n3;
+    if (ntiles > 0 && !have_pf) {               // cold start (first quad of the wave, or the quad before had no tile)
       bool loc;
-      const int rows = tile_rows(pi, p, 0, loc);
+      const int rows = tile_rows(AG_QUAD_ARGS(c_), 0, loc);
       prefetch_meta(rows, loc);
-      if (!loc) {                               // (a local tile fetches its own x values and evaluates its own features)
-        set_xoff();
-        fetch_first_groups();
-        next_features();
-      }
+      set_xoff();
+      fetch_first_groups();
+      next_features();
     }
 #pragma unroll
     for (int i = 0; i < AG_CONV_NCH; ++i) accL[i] = 0.0f;
-    // the wave's next tile after tile j (of this pair, or the first one of its next pair)
+    // the wave's next tile after tile j (of this quad, or the first one of its next quad)
     auto next_tile = [&](int j, bool& nloc, bool& has_next) -> int {
       has_next = true;
       nloc = false;
-      if (j + 1 < ntiles) return tile_rows(pi, p, j + 1, nloc);
-      if (pin.nL + pin.nA + pin.nB > 0) return tile_rows(pin, pn, 0, nloc);
+      if (j + 1 < ntiles) return tile_rows(AG_QUAD_ARGS(c_), j + 1, nloc);
+      if (ntiles_next > 0) return tile_rows(AG_QUAD_ARGS(x_), 0, nloc);
       has_next = false;
       return 0;
     };
-    // A radius tile (one target) as a software pipeline over its four groups of three channel tiles: the MFMAs of group g + 1
-    // are issued BEFORE the sums of group g (acc += z x), so that the matrix pipe works while the wave's VALU does the
-    // sums; the x values of group g + 2 are requested into the buffer the sums have just freed; the next tile's per-row
-    // inputs are requested at the start, its first x group and -- behind the last group's MFMAs -- its features
-    // (ph1 / ph2 are carried from tile to tile) at the end.  A local tile fetches / evaluates its own.
-    auto radius_tile = [&](int j) {
+    // One tile as a software pipeline over its four groups of three channel tiles: the MFMAs of group g + 1 are issued BEFORE
+    // the sums of group g (sum += z x), so that the matrix pipe works while the wave's VALU does the sums; the x values of
+    // group g + 2 are requested into the buffer the sums have just freed; the next tile's per-row inputs are requested at the
+    // start, its first x group and -- behind the last group's MFMAs -- its features (ph1 / ph2 are carried from tile to
+    // tile) at the end.  `base`: the tile's coefficient set (LDS or global), `S`: the sums it adds to.
+    auto tile = [&](int j, auto base, float (&S)[AG_CONV_NCH]) {
       bool nloc, has_next;
       const int nrows = next_tile(j, nloc, has_next);
       if (has_next) prefetch_meta(nrows, nloc);
@@ -299,15 +299,15 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
         constexpr int c0 = AG_NODE_GRP * decltype(GG)::value;
         // channel tiles 0..7 take conv1's features, 8..11 conv2's (a group of three straddles the boundary once: 6, 7 | 8)
         if constexpr (c0 + AG_NODE_GRP <= 8) {
-          mma_tiles(wl_l, std::integral_constant<int, c0>{}, ph1, z, std::true_type{});
+          mma_tiles(base, std::integral_constant<int, c0>{}, ph1, z);
         } else if constexpr (c0 >= 8) {
-          mma_tiles(wl_l, std::integral_constant<int, c0>{}, ph2, z, std::true_type{});
+          mma_tiles(base, std::integral_constant<int, c0>{}, ph2, z);
         } else {
           static_assert(AG_NODE_GRP == 3 && c0 == 6, "group layout");
           f32x4 (&za)[2] = *reinterpret_cast<f32x4 (*)[2]>(&z[0]);
           f32x4 (&zb)[1] = *reinterpret_cast<f32x4 (*)[1]>(&z[2]);
-          mma_tiles(wl_l, std::integral_constant<int, 6>{}, ph1, za, std::true_type{});
-          mma_tiles(wl_l, std::integral_constant<int, 8>{}, ph2, zb, std::true_type{});
+          mma_tiles(base, std::integral_constant<int, 6>{}, ph1, za);
+          mma_tiles(base, std::integral_constant<int, 8>{}, ph2, zb);
         }
       };
       auto sums = [&](auto GG, const f32x4 (&z)[AG_NODE_GRP]) {
@@ -317,173 +317,70 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             if ((AG_NODE_ABL & 8) && r) continue;
-            acc[AG_NODE_GRP * gg + jj] = fmaf(z[jj][r], xg[gg % AG_NODE_XD][jj][r], acc[AG_NODE_GRP * gg + jj]);
+            S[AG_NODE_GRP * gg + jj] = fmaf(z[jj][r], xg[gg % AG_NODE_XD][jj][r], S[AG_NODE_GRP * gg + jj]);
           }
           // (pins the sum to this step: the optimiser otherwise sinks all 48 FMAs of a tile below its last MFMA -- nothing
-          // needs acc before the target is complete -- and the wave then waits for x loads and MFMAs with nothing to do)
-          asm volatile("" : "+v"(acc[AG_NODE_GRP * gg + jj]));
+          // needs the sums before the target is complete -- and the wave then waits for x loads and MFMAs with nothing to do)
+          asm volatile("" : "+v"(S[AG_NODE_GRP * gg + jj]));
         }
       };
       f32x4 z[2][AG_NODE_GRP];
       // (fences between the steps: the scheduler otherwise hoists every group's coefficient reads to the top of the tile and
       // spills; inside a step it is free to run the sums beside the MFMAs)
-      AG_NSTAMP(t0);
       constexpr int XD = AG_NODE_XD;
       fetch_xg(std::integral_constant<int, XD - 1>{}, XD - 1);
       mma_g(std::integral_constant<int, 0>{}, z[0]);
       __builtin_amdgcn_sched_barrier(0);
-      AG_NSTAMP(t1);
       ag_static_for<1, NG>([&](auto G) {
         constexpr int g = decltype(G)::value;
         mma_g(G, z[g & 1]);
         sums(std::integral_constant<int, g - 1>{}, z[(g - 1) & 1]);
         // the buffer the sums have just freed takes the group XD - 1 steps ahead: of this tile, or -- once all of this tile's
-        // gathers are out and xoff is free -- of the wave's next radius tile (whose features follow the last request)
+        // gathers are out and xoff is free -- of the wave's next tile (whose features follow the last request)
         if constexpr (g + XD - 1 < NG) {
           fetch_xg(std::integral_constant<int, (g - 1) % XD>{}, g + XD - 1);
-        } else if (has_next && !nloc) {
+        } else if (has_next) {
           if constexpr (g + XD - 1 == NG) set_xoff();
           fetch_xg(std::integral_constant<int, (g - 1) % XD>{}, g + XD - 1 - NG);
           if constexpr (g == NG - 1) next_features();
         }
         __builtin_amdgcn_sched_barrier(0);
       });
-      AG_NSTAMP(t4);
       sums(std::integral_constant<int, NG - 1>{}, z[(NG - 1) & 1]);
-      have_pf = has_next;
-#ifdef AG_NODE_STAMPS
-      __builtin_amdgcn_sched_barrier(0);
-      const unsigned long long t5 = __builtin_amdgcn_s_memtime();
-      st_acc[0] += t1 - t0;
-      st_acc[1] += t4 - t1;
-      st_acc[4] += t5 - t4;
-      st_acc[5] += 1ull;
-#endif
-    };
-    // A local tile (rows 0..7: target 2 p, rows 8..15: target 2 p + 1; several edge types): conv2's four channel tiles
-    // first, then conv1's eight; per conv the wave loops over the types present in the tile, each adding its masked
-    // features times its own coefficient set.  The tile is long enough to fetch its own x values behind its MFMAs.
-    auto local_tile = [&](int j) {
-      const float d = pf_d, s1 = pf_s1, s2 = pf_s2;
-      const int my_slot = pf_slot;
-      bool nloc, has_next;
-      const int nrows = next_tile(j, nloc, has_next);
-      set_xoff();
-      f32x4 xa[4];                              // one buffer: a phase's rounds are long enough for the next phase's values to land
-      fetch_x4(xa, 8);
-      if (has_next) prefetch_meta(nrows, nloc);
-      const uint64_t rows_mask = __ballot(my_slot >= 0) & 0xFFFFull;      // one lane per row (the quarters hold copies)
-      // z[...] = sum over the types present of (features of that type's rows) x (that type's coefficient blocks C0 ..)
-      auto typed_rounds = [&](const AgIn<MODE> (&ph)[NKT], auto C0_, auto& z) {
-        constexpr int CN = sizeof(z) / sizeof(f32x4);
-#pragma unroll
-        for (int i = 0; i < CN; ++i) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        uint64_t todo = rows_mask;
-        while (todo) {
-          const int g = __builtin_amdgcn_readlane(my_slot, (int)__builtin_ctzll(todo));
-          const bool in = my_slot == g;
-          todo &= ~__ballot(in);
-          AgIn<MODE> m[NKT];                     // the group's operand: a copy with the other rows zeroed
-#pragma unroll
-          for (int t = 0; t < NKT; ++t) {
-            const u32x4 zero = {0u, 0u, 0u, 0u};
-            if constexpr (MODE == AG_F32) {
-              m[t].v[0] = in ? ph[t].v[0] : f32x4{0.f, 0.f, 0.f, 0.f};
-              m[t].v[1] = in ? ph[t].v[1] : f32x4{0.f, 0.f, 0.f, 0.f};
-            } else {
-              m[t].hi = __builtin_bit_cast(bf16x8, in ? __builtin_bit_cast(u32x4, ph[t].hi) : zero);
-              m[t].lo = __builtin_bit_cast(bf16x8, in ? __builtin_bit_cast(u32x4, ph[t].lo) : zero);
-            }
-          }
-          static_assert(CN == 4, "four channel tiles per phase");
-          auto run = [&](auto base) {            // (two blocks pairs at a time: 16 coefficient registers in flight, not 32)
-            f32x4 (&za)[2] = *reinterpret_cast<f32x4 (*)[2]>(&z[0]);
-            f32x4 (&zb)[2] = *reinterpret_cast<f32x4 (*)[2]>(&z[2]);
-            mma_tiles(base, std::integral_constant<int, decltype(C0_)::value>{}, m, za, std::false_type{});
-            __builtin_amdgcn_sched_barrier(0);
-            mma_tiles(base, std::integral_constant<int, decltype(C0_)::value + 2>{}, m, zb, std::false_type{});
-            __builtin_amdgcn_sched_barrier(0);
-          };
-          if (g < a.lds_slots) run(wl_l + (size_t)(1 + g) * SET);
-          else run(reinterpret_cast<const u32x4*>(a.poly_typed) + (size_t)g * SET + lane);   // a set that did not fit in LDS: from L2
-        }
-      };
-      // three phases of four channel tiles (conv2: 8..11; conv1: 0..3, 4..7): the accumulators of all twelve at once, next
-      // to the coefficient blocks in flight, do not fit the register budget of three waves per SIMD
-      auto phase = [&](const AgIn<MODE> (&ph)[NKT], auto C0_, const f32x4 (&x)[4]) {
-        constexpr int C0 = decltype(C0_)::value;
-        f32x4 z[4];
-        typed_rounds(ph, C0_, z);
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) accL[C0 + jj] = fmaf(z[jj][r], x[jj][r], accL[C0 + jj]);
-          asm volatile("" : "+v"(accL[C0 + jj]));
-        }
-      };
-      {
-        AgIn<MODE> ph2[NKT];
-        ag_poly_features<MODE, NKT>(d, a.two_over_rc, q, ph2, s2);
-        phase(ph2, std::integral_constant<int, 8>{}, xa);
-      }
-      fetch_x4(xa, 0);
-      {
-        AgIn<MODE> ph1[NKT];
-        ag_poly_features<MODE, NKT>(d, a.two_over_rc, q, ph1, s1);
-        phase(ph1, std::integral_constant<int, 0>{}, xa);
-        fetch_x4(xa, 4);
-        phase(ph1, std::integral_constant<int, 4>{}, xa);
-      }
-      if (has_next && !nloc) {
-        set_xoff();
-        fetch_first_groups();
-        next_features();
-      } else {                                  // (definite writes: keep the buffers and the features out of this tile's live registers)
-#pragma unroll
-        for (int b = 0; b < AG_NODE_XD - 1; ++b)
-#pragma unroll
-          for (int jj = 0; jj < AG_NODE_GRP; ++jj) xg[b][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const u32x4 zero = {0u, 0u, 0u, 0u};
-        u32x4 zz[2] = {zero, zero};
-#pragma unroll
-        for (int t = 0; t < NKT; ++t) {
-          __builtin_memcpy(&ph1[t], zz, 32);
-          __builtin_memcpy(&ph2[t], zz, 32);
-        }
-      }
       have_pf = has_next;
     };
     int j = 0;
-    for (; j < pi.nL; ++j) local_tile(j);
+#ifndef AG_NODE_NO_LOCAL        // (timing experiment: the kernel without its local tiles)
+    for (; j < c_nL; ++j) {
+      // the tile's set: one of the LDS-resident ones, or -- a rare type -- straight from L2; a type without a polynomial ran
+      // with scale 0 (next_features) against the radius set
+      const int slot = __builtin_amdgcn_readfirstlane(pf_slot);
+      if (slot >= a.lds_slots) tile(j, reinterpret_cast<const u32x4*>(a.poly_typed) + (size_t)slot * SET + lane, accL);
+      else tile(j, wl_l + (size_t)(slot >= 0 ? 1 + slot : 0) * SET, accL);
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < AG_CONV_NCH; ++i) acc[i] = 0.0f;
-    bool first_done = false;
-    for (; j < ntiles; ++j) {
-      if (j == pi.nL + pi.nA) {                 // target 2 p is complete: write it, start target 2 p + 1
-        finalize(pi.tA, false);
-        first_done = true;
+    // (the four targets one after the other through shifting copies: indexing the quad's fields by k would put it in scratch)
+    int ta = c_t0, tb = c_t1, tc = c_t2, td = c_t3, na = c_n0, nb = c_n1, nc = c_n2, nd = c_n3;
+#pragma nounroll
+    for (int k = 0; k < 4; ++k) {
+      if (ta >= 0) {
+        for (int u = 0; u < na; ++u, ++j) tile(j, wl_l, acc);
+        finalize(ta, k);                        // the quad's k-th target is complete: write it
 #pragma unroll
         for (int i = 0; i < AG_CONV_NCH; ++i) acc[i] = 0.0f;
       }
-      radius_tile(j);
+      ta = tb, tb = tc, tc = td, td = -1;
+      na = nb, nb = nc, nc = nd, nd = 0;
     }
-    if (!first_done) {
-      finalize(pi.tA, false);
-#pragma unroll
-      for (int i = 0; i < AG_CONV_NCH; ++i) acc[i] = 0.0f;
-    }
-    if (pi.tB >= 0) finalize(pi.tB, true);
     if (ntiles == 0) have_pf = false;
     p = pn;
-    pi = pin;
+    c_nL = x_nL, c_lt0 = x_lt0, c_t0 = x_t0, c_t1 = x_t1, c_t2 = x_t2, c_t3 = x_t3, c_n0 = x_n0, c_n1 = x_n1, c_n2 = x_n2, c_n3 = x_n3;
   }
-#ifdef AG_NODE_STAMPS
-  if (lane == 0) {
-    for (int i = 0; i < 6; ++i) atomicAdd(&ag_node_stamp_acc[i], st_acc[i]);
-    atomicAdd(&ag_node_stamp_acc[6], __builtin_amdgcn_s_memrealtime() - k_rt0);
-    atomicAdd(&ag_node_stamp_acc[7], __builtin_amdgcn_s_memtime() - k_t0);
-  }
-#endif
+#undef AG_QUAD_DECL
+#undef AG_QUAD_LOAD
+#undef AG_QUAD_ARGS
 }
 
 #ifndef AG_NODECONV_WAVES
@@ -503,8 +400,8 @@ extern "C" int agdiff_cfconv_node(const agdiff_params_t* p, const agdiff_topo_t*
                                   void* stream) {
   if (!p || !topo || !ws || k < 0 || k >= p->num_convs) return AGDIFF_ERR_ARG;
   if (p->poly_kt < 1 || p->poly_kt > AGDIFF_POLY_MAX_KT || !p->conv[k].filt_poly_pk) return AGDIFF_ERR_ARG;
-  if (!ws->rad_cnt || !ws->rad_src || !ws->rad_len || !ws->r_scale || !ws->xs || !ws->agg || !topo->pair_tgt ||
-      topo->num_pairs <= 0)
+  if (!ws->rad_cnt || !ws->rad_src || !ws->rad_len || !ws->r_scale || !ws->xs || !ws->agg || !topo->quad_tgt ||
+      topo->num_quads <= 0)
     return AGDIFF_ERR_ARG;
   if (topo->num_nodes <= 0) return AGDIFF_OK;
   if (topo->num_nodes * (int64_t)AGDIFF_RAD_STRIDE >= (1ll << 31)) return AGDIFF_ERR_LIMIT;
@@ -526,7 +423,7 @@ extern "C" int agdiff_cfconv_node(const agdiff_params_t* p, const agdiff_topo_t*
   const size_t rpad = (size_t)topo->num_nodes * AGDIFF_RAD_STRIDE;
   a.r_scale1 = ws->r_scale + (size_t)(2 * k) * rpad;
   a.r_scale2 = ws->r_scale + (size_t)(2 * k + 1) * rpad;
-  a.pair_tgt = topo->pair_tgt;
+  a.quad_tgt = topo->quad_tgt;
   a.lt_ptr = topo->lt_ptr;
   a.lt_src = topo->lt_src;
   a.lt_type = topo->lt_type;
@@ -537,9 +434,9 @@ extern "C" int agdiff_cfconv_node(const agdiff_params_t* p, const agdiff_topo_t*
   a.xs = ws->xs;
   a.agg = ws->agg;
   a.n = (int32_t)topo->num_nodes;
-  a.num_pairs = (int32_t)topo->num_pairs;
+  a.num_quads = (int32_t)topo->num_quads;
   a.two_over_rc = 2.0f / p->cutoff;
-  int64_t wgs = (a.num_pairs + AG_NODECONV_WAVES - 1) / AG_NODECONV_WAVES;
+  int64_t wgs = (a.num_quads + AG_NODECONV_WAVES - 1) / AG_NODECONV_WAVES;
   if (wgs > 256) wgs = 256;
   const size_t smem = (size_t)(1 + a.lds_slots) * set_bytes;
   ag_log_variant(ws, AGDIFF_VAR_CFCONV_NODE | (local ? AGDIFF_VAR_CFCONV_NODE_LOCAL : 0) |
@@ -549,13 +446,3 @@ extern "C" int agdiff_cfconv_node(const agdiff_params_t* p, const agdiff_topo_t*
   return p->poly_kt == 1 ? launch_cfconv_node_t<AG_F32, 1>(a, wgs, smem, stream) : launch_cfconv_node_t<AG_F32, 2>(a, wgs, smem, stream);
 }
 
-#ifdef AG_NODE_STAMPS
-extern "C" int agdiff_debug_node_stamps(unsigned long long* out, int reset) {
-  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(ag_node_stamp_acc), sizeof(ag_node_stamp_acc)) != hipSuccess) return AGDIFF_ERR_LAUNCH;
-  if (reset) {
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(ag_node_stamp_acc), z, sizeof(z)) != hipSuccess) return AGDIFF_ERR_LAUNCH;
-  }
-  return AGDIFF_OK;
-}
-#endif

@@ -132,60 +132,74 @@ class BatchTopology:
         self.lp_row = i32(np.where(real, loc_row[eid], -1) if L else np.zeros(Lp))
         self.lc_ppos = i32(ppos[lc_pos])
         self.lc_pmir = i32(np.where(lc_mir >= 0, ppos[np.maximum(lc_mir, 0)], -1))
-        # ... and as PAIR TILES for agdiff_cfconv_node (agdiff_topo_t.pair_tgt, lt_*): one wave owns two targets.  Atoms of a
-        # molecule are paired by (tiles their local in-list needs, set of local edge types, index): a pair's tile count is the
-        # larger of the two and a tile's cost grows with the distinct types in it.
-        deg_tiles = (locdeg + 7) // 8
-        sig_of = {}
-        sig = np.zeros(N, dtype=np.int64)
-        for i in range(N):
-            key = tuple(np.unique(typ[in_order[in_ptr[i]:in_ptr[i + 1]]]).tolist())
-            sig[i] = sig_of.setdefault(key, len(sig_of))
-        order_in_mol = np.lexsort((np.arange(N), sig, deg_tiles, ba))        # by molecule, then the pairing key
-        pair_tgt = []
+        # ... and as QUAD TILES for agdiff_cfconv_node (agdiff_topo_t.quad_tgt, lt_*): one wave owns four targets of one molecule,
+        # and a 16-row local tile holds rows of ONE edge type: rows 4 k .. 4 k + 3 are in-edges of the quad's k-th target (so
+        # the four rows a lane quarter holds belong to one target and the tile needs no masks and ONE filter set).  Per quad
+        # and type: max over its targets of ceil(in-edges of that type / 4) tiles; atoms are grouped by those needs so that
+        # a quad's targets need like tiles.
+        ltypes = np.unique(typ) if L else np.zeros(0, dtype=np.int64)
+        cnt_tt = np.zeros((N, max(ltypes.size, 1)), dtype=np.int64)
+        for k, ty in enumerate(ltypes):
+            cnt_tt[:, k] = np.bincount(dst[typ == ty], minlength=N)
+        need = (cnt_tt + 3) // 4
+        order_in_mol = np.lexsort(tuple(need[:, k] for k in range(need.shape[1] - 1, -1, -1)) + (ba,))    # by molecule, then the needs
+        quad_tgt = []
         for g in range(G):
             idx = order_in_mol[gptr[g]:gptr[g + 1]]
-            if idx.size % 2:
-                idx = np.concatenate([idx, [-1]])
-            pair_tgt.append(idx)
-        pair_tgt = np.concatenate(pair_tgt).astype(np.int64) if pair_tgt else np.zeros(0, dtype=np.int64)
-        P2 = pair_tgt.size // 2
-        tA, tB = pair_tgt[0::2], pair_tgt[1::2]
-        degA, degB = locdeg[tA], np.where(tB >= 0, locdeg[np.maximum(tB, 0)], 0)
-        nt_pair = (np.maximum(degA, degB) + 7) // 8
-        lt_ptr = np.concatenate([[0], np.cumsum(nt_pair)])
+            if idx.size % 4:
+                idx = np.concatenate([idx, np.full(4 - idx.size % 4, -1, dtype=idx.dtype)])
+            quad_tgt.append(idx)
+        quad_tgt = np.concatenate(quad_tgt).astype(np.int64) if quad_tgt else np.zeros(0, dtype=np.int64)
+        Q = quad_tgt.size // 4
+        qt = quad_tgt.reshape(Q, 4)
+        qneed = np.where(qt[:, :, None] >= 0, need[np.maximum(qt, 0)], 0).max(axis=1)        # [Q, types]: tiles of each type
+        nt_quad = qneed.sum(axis=1)
+        lt_ptr = np.concatenate([[0], np.cumsum(nt_quad)])
         T = int(lt_ptr[-1])
-        # a target's in-edges in order of (type, source): fewer distinct types per 8-row half
-        in_order_t = in_order.copy()
-        for i in range(N):
-            seg = in_order[in_ptr[i]:in_ptr[i + 1]]
-            in_order_t[in_ptr[i]:in_ptr[i + 1]] = seg[np.lexsort((src[seg], typ[seg]))]
-        trow = np.arange(16 * T)
-        tile_of = trow // 16
-        pair_of = np.repeat(np.arange(P2), nt_pair)[tile_of] if T else np.zeros(0, dtype=np.int64)
-        half = (trow % 16) // 8
-        tgt_t = np.where(half == 0, tA[pair_of], tB[pair_of]) if T else np.zeros(0, dtype=np.int64)      # (-1: no second target)
-        k_t = (tile_of - lt_ptr[pair_of]) * 8 + trow % 8                    # index inside the target's in-list
-        tgt_c = np.where(tgt_t >= 0, tgt_t, tA[pair_of]) if T else tgt_t
-        real_t = (tgt_t >= 0) & (k_t < locdeg[tgt_c])
-        slot_t = np.minimum(in_ptr[tgt_c] + k_t, max(L - 1, 0))
-        eid_t = in_order_t[slot_t] if L else np.zeros(16 * T, dtype=np.int64)
-        # pad rows: src = the target itself (a valid row of xs; a missing second target: the first), and the type of the
-        # tile's first real row (the kernel loops over the types present in a tile: pads must not add one)
-        first_real = np.full(max(T, 1), max(16 * T - 1, 0), dtype=np.int64)
+        # a target's in-edges of one type in order of source: position of every local edge inside its (target, type) list
+        by_tts = np.lexsort((src, typ, dst)) if L else np.zeros(0, dtype=np.int64)
+        rank_in = np.zeros(L, dtype=np.int64)
+        if L:
+            key = dst[by_tts] * 256 + typ[by_tts]
+            start = np.concatenate([[True], key[1:] != key[:-1]])
+            first_of = np.maximum.accumulate(np.where(start, np.arange(L), 0))
+            rank_in[by_tts] = np.arange(L) - first_of
+        # tiles of a quad: type ascending, then the tile index u inside the type
+        tile_quad = np.repeat(np.arange(Q), nt_quad)
+        tile_type_k = np.zeros(T, dtype=np.int64)
+        tile_u = np.zeros(T, dtype=np.int64)
         if T:
-            idx = np.nonzero(real_t)[0]
-            np.minimum.at(first_real, tile_of[idx], idx)                     # smallest real row of every tile
-        pad_type = typ[eid_t[first_real[tile_of]]] if (L and T) else np.zeros(16 * T, dtype=np.int64)
-        tpos = np.empty(L, dtype=np.int64)
-        tpos[eid_t[real_t]] = np.nonzero(real_t)[0]
-        self.T, self.P = T, int(P2)
-        self.pair_tgt = i32(pair_tgt)
+            flat = qneed.reshape(-1)                                          # (quad, type) -> tiles
+            kq = np.repeat(np.arange(flat.size), flat)                        # (quad, type) of every tile, in tile order
+            tile_type_k = kq % qneed.shape[1]
+            tile_u = np.arange(T) - np.concatenate([[0], np.cumsum(flat)])[kq]
+        tile_of_qk = np.concatenate([[0], np.cumsum(qneed.reshape(-1))])     # first tile of (quad, type)
+        quad_of = np.zeros(N, dtype=np.int64)
+        slot_of = np.zeros(N, dtype=np.int64)
+        valid = quad_tgt >= 0
+        quad_of[quad_tgt[valid]] = np.nonzero(valid)[0] // 4
+        slot_of[quad_tgt[valid]] = np.nonzero(valid)[0] % 4
+        tpos = np.zeros(L, dtype=np.int64)
+        if L:
+            k_of = np.searchsorted(ltypes, typ)
+            tile_e = tile_of_qk[quad_of[dst] * qneed.shape[1] + k_of] + rank_in // 4
+            tpos = tile_e * 16 + slot_of[dst] * 4 + rank_in % 4
+        real_t = np.zeros(16 * T, dtype=bool)
+        eid_t = np.full(16 * T, -1, dtype=np.int64)
+        real_t[tpos] = True
+        eid_t[tpos] = np.arange(L)
+        assert int(real_t.sum()) == L                                        # every local edge has its own row
+        trow = np.arange(16 * T)
+        tgt_t = qt[tile_quad[trow // 16], (trow % 16) // 4] if T else np.zeros(0, dtype=np.int64)
+        first_t = qt[tile_quad[trow // 16], 0] if T else tgt_t
+        tgt_c = np.where(tgt_t >= 0, tgt_t, first_t)                         # pad rows: src = the target itself (a missing one: the first)
+        self.T, self.Q = T, int(Q)
+        self.quad_tgt = i32(quad_tgt)
         self.lt_ptr = i32(lt_ptr)
-        self.lt_src = i32(np.where(real_t, src[eid_t], tgt_c) if L else np.zeros(16 * T))
-        self.lt_type = i32(np.where(real_t, typ[eid_t], pad_type) if L else np.zeros(16 * T))
+        self.lt_src = i32(np.where(real_t, src[np.maximum(eid_t, 0)], tgt_c) if L else np.zeros(16 * T))
+        self.lt_type = i32(ltypes[tile_type_k][trow // 16] if T else np.zeros(0))     # every row of a tile carries the tile's type
         self.lt_real = real_t
-        self.lt_eid = np.where(real_t, eid_t, -1)
+        self.lt_eid = eid_t
         self.lc_tpos = i32(tpos[lc_pos])
         self.lc_tmir = i32(np.where(lc_mir >= 0, tpos[np.maximum(lc_mir, 0)], -1))
         self.lcm_ptr = i32(np.searchsorted(ba[src[lc_pos]], np.arange(G + 1)) if L else np.zeros(G + 1))
@@ -202,7 +216,7 @@ class BatchTopology:
         t.num_local_canon = self.Lc
         t.num_local_padded = self.Lp
         t.num_local_tiles = self.T
-        t.num_pairs = self.P
+        t.num_quads = self.Q
         tm = [0, 0]
         for ty in self.local_types:
             tm[int(ty) >> 6] |= 1 << (int(ty) & 63)
@@ -211,7 +225,7 @@ class BatchTopology:
         for f in ("graph_ptr", "atom_type", "loc_src", "loc_dst", "loc_type", "loc_out_ptr", "loc_in_ptr", "loc_in_eid",
                   "lc_src", "lc_dst", "lc_type", "lc_pos", "lc_mir", "loc_row", "loc_in_src",
                   "loc_in_row", "lp_ptr", "lp_src", "lp_dst", "lp_type", "lp_row", "lc_ppos", "lc_pmir",
-                  "pair_tgt", "lt_ptr", "lt_src", "lt_type", "lc_tpos", "lc_tmir", "lcm_ptr"):
+                  "quad_tgt", "lt_ptr", "lt_src", "lt_type", "lc_tpos", "lc_tmir", "lcm_ptr"):
             setattr(t, f, _lib.ptr(getattr(self, f)))
         self.struct = t
 

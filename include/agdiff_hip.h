@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 33
+#define AGDIFF_ABI_VERSION 34
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -236,23 +236,23 @@ typedef struct agdiff_topo {
   const int32_t* lp_row;     /* [Lp]: canonical index (row of l_attr_rows) of the entry's edge, -1 for pad entries */
   const int32_t* lc_ppos;    /* [Lc]: padded-list position of the canonical edge */
   const int32_t* lc_pmir;    /* [Lc]: ... of its mirror, or -1 */
-  /* PAIRS of targets for agdiff_cfconv_node: one wave owns the two targets pair_tgt[2 p], pair_tgt[2 p + 1] (the second is -1
-   * for the odd atom of a molecule).  The host pairs atoms of ONE molecule with like numbers of local in-edges (both <= 8,
-   * both 9..16, ...) and like sets of local edge types.  The local edges once more as pair tiles: tile t of pair p holds
-   * local in-edges [8 t, 8 t + 8) of its first target in rows 0..7 and of its second in rows 8..15, a target's in-edges
-   * taken in order of (type, source) -- pad rows: src = the target itself, the type of a real row of the tile, and nothing
-   * ever writes their CFConv scale: they contribute exactly 0 --, so that the rows of one lane quarter belong to ONE target
-   * and the sum over a target's edges needs no masks, and a tile holds few distinct types */
-  int64_t num_pairs;         /* P */
-  const int32_t* pair_tgt;   /* [2 P] */
+  /* QUADS of targets for agdiff_cfconv_node: one wave owns the four targets quad_tgt[4 p .. 4 p + 3] of ONE molecule (-1: none,
+   * in the last quad of a molecule).  The local edges once more as quad tiles: a 16-row tile holds rows of ONE edge type;
+   * rows 4 k .. 4 k + 3 are in-edges of that type of the quad's k-th target (in order of source; a target with more than
+   * four gets another tile of the type), pad rows: src = the target itself, the tile's type, and nothing ever writes their
+   * CFConv scale: they contribute exactly 0.  The four rows one lane quarter holds then belong to ONE target, so the sum
+   * over a target's edges needs no masks, and a tile needs ONE filter set.  The host groups atoms whose in-lists need like
+   * numbers of tiles per type; tiles of quad p: type ascending */
+  int64_t num_quads;         /* Q */
+  const int32_t* quad_tgt;   /* [4 Q] */
   const int32_t* lcm_ptr;    /* [G+1]: the canonical local edges lc_*[lcm_ptr[g] .. lcm_ptr[g+1]) belong to molecule g (the list is
                                 sorted by source) */
   int64_t local_type_mask[2];/* bit t of the 128-bit mask: the batch has a local edge of type t */
-  int64_t num_local_tiles;   /* T = lt_ptr[P] */
-  const int32_t* lt_ptr;     /* [P + 1]: tiles of pair p are [lt_ptr[p], lt_ptr[p+1]) */
+  int64_t num_local_tiles;   /* T = lt_ptr[Q] */
+  const int32_t* lt_ptr;     /* [Q + 1]: tiles of quad p are [lt_ptr[p], lt_ptr[p+1]) */
   const int32_t* lt_src;     /* [16 T] */
-  const int32_t* lt_type;    /* [16 T] */
-  const int32_t* lc_tpos;    /* [Lc]: pair-tile row of the canonical edge */
+  const int32_t* lt_type;    /* [16 T] (the same for the 16 rows of a tile) */
+  const int32_t* lc_tpos;    /* [Lc]: quad-tile row of the canonical edge */
   const int32_t* lc_tmir;    /* [Lc]: ... of its mirror, or -1 */
 } agdiff_topo_t;
 

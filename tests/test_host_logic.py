@@ -301,60 +301,58 @@ def test_padded_local_list():
 
 
 @pytest.mark.parametrize("kind,mols,copies", [("drugs", 3, 2), ("qm9", 5, 1)])
-def test_local_pair_tiles(kind, mols, copies):
-    """agdiff_topo_t.pair_tgt / lt_* (agdiff_cfconv_node): every atom sits in exactly one pair, both atoms of a pair belong to
-    one molecule (the odd atom of a molecule pairs with -1), pairs are formed between atoms whose local in-lists need the
-    same number of tiles wherever possible; tile t of pair p holds in-edges [8 t, 8 t + 8) -- in (type, source) order -- of
-    its first target in rows 0..7 and of its second in rows 8..15; pad rows point at the target itself and carry the type
-    of a real row of their tile; every local edge sits in exactly one row."""
+def test_local_quad_tiles(kind, mols, copies):
+    """agdiff_topo_t.quad_tgt / lt_* (agdiff_cfconv_node): every atom sits in exactly one quad, the atoms of a quad belong to
+    one molecule (the last quad of a molecule is filled with -1); a tile holds rows of ONE edge type, rows 4 k .. 4 k + 3 of
+    tile u of that type are in-edges [4 u, 4 u + 4) -- of that type, in source order -- of the quad's k-th target; a quad
+    has max over its targets of ceil(in-edges of the type / 4) tiles per type, types ascending; pad rows point at the target
+    itself (a missing target: the quad's first) and carry the tile's type; every local edge sits in exactly one row."""
     from agdiff_amd import synth
     from agdiff_amd.topology import BatchTopology
     b = synth.make_packed_batch(kind, mols, copies, seed=5)
     tp = BatchTopology(b["atom_type"], b["bond_index"], b["bond_type"], b["batch"], device="cpu")
-    pt, ltp, src, typ = tp.pair_tgt.numpy(), tp.lt_ptr.numpy(), tp.lt_src.numpy(), tp.lt_type.numpy()
-    ip, eid = tp.loc_in_ptr.numpy(), tp.loc_in_eid.numpy()
-    lsrc, ltyp, ba = tp.loc_src.numpy(), tp.loc_type.numpy(), b["batch"]
-    P = tp.P
-    assert pt.shape[0] == 2 * P == tp.struct.num_pairs * 2 and ltp.shape[0] == P + 1 and ltp[-1] == tp.T == tp.struct.num_local_tiles
-    assert sorted(pt[pt >= 0].tolist()) == list(range(tp.N)) and np.all(pt[0::2] >= 0)
+    qt, ltp, src, typ = tp.quad_tgt.numpy().reshape(-1, 4), tp.lt_ptr.numpy(), tp.lt_src.numpy(), tp.lt_type.numpy()
+    lsrc, ldst, ltyp, ba = tp.loc_src.numpy(), tp.loc_dst.numpy(), tp.loc_type.numpy(), b["batch"]
+    Q = tp.Q
+    assert qt.shape[0] == Q == tp.struct.num_quads and ltp.shape[0] == Q + 1 and ltp[-1] == tp.T == tp.struct.num_local_tiles
+    assert sorted(qt[qt >= 0].tolist()) == list(range(tp.N)) and np.all(qt[:, 0] >= 0)
     sizes = np.bincount(ba)
-    assert int((pt < 0).sum()) == int((sizes % 2).sum())              # one unpaired atom per odd molecule
-    deg = np.diff(ip)
-    real = np.zeros(16 * tp.T, bool)
-    mixed_pairs = {}
-    for p_ in range(P):
-        tA, tB = int(pt[2 * p_]), int(pt[2 * p_ + 1])
-        if tB >= 0:
-            assert ba[tA] == ba[tB]
-            if (deg[tA] + 7) // 8 != (deg[tB] + 7) // 8:
-                mixed_pairs[ba[tA]] = mixed_pairs.get(ba[tA], 0) + 1
-        degs = [deg[tA], deg[tB] if tB >= 0 else 0]
-        assert ltp[p_ + 1] - ltp[p_] == (max(degs) + 7) // 8
-        for h, tgt in enumerate((tA, tB)):
-            want = eid[ip[tgt]:ip[tgt + 1]] if tgt >= 0 else np.zeros(0, int)
-            want = want[np.lexsort((lsrc[want], ltyp[want]))]          # (type, source) order
-            got_rows = []
-            for tl in range(ltp[p_], ltp[p_ + 1]):
-                rows = np.arange(16 * tl + 8 * h, 16 * tl + 8 * h + 8)
-                k0 = 8 * (tl - ltp[p_])
-                nreal = int(np.clip(degs[h] - k0, 0, 8))
-                got_rows += rows[:nreal].tolist()
-                assert np.all(src[rows[nreal:]] == (tgt if tgt >= 0 else tA))
-            assert np.array_equal(src[got_rows], lsrc[want]) and np.array_equal(typ[got_rows], ltyp[want])
-            assert np.array_equal(tp.lt_eid[got_rows], want)
-            real[got_rows] = True
-        for tl in range(ltp[p_], ltp[p_ + 1]):
-            tile_rows = np.arange(16 * tl, 16 * tl + 16)
-            assert real[tile_rows].any() and set(typ[tile_rows]) == set(typ[tile_rows][real[tile_rows]])
-    assert all(v <= 2 for v in mixed_pairs.values())                   # at most a boundary pair or two per molecule
-    assert real.sum() == tp.L and np.array_equal(real, tp.lt_real)
+    assert int((qt < 0).sum()) == int(((4 - sizes % 4) % 4).sum())
+    seen = np.zeros(tp.L, int)
+    tiles_per_target = []
+    for p_ in range(Q):
+        tg = qt[p_]
+        live = tg[tg >= 0]
+        assert np.all(ba[live] == ba[live[0]]) and np.all(np.diff((tg >= 0).astype(int)) <= 0)      # one molecule; -1 only at the end
+        want_tiles = []
+        types_here = np.unique(ltyp[np.isin(ldst, live)])
+        for ty in types_here:
+            per = [int(((ldst == t_) & (ltyp == ty)).sum()) for t_ in live]
+            want_tiles += [(int(ty), u) for u in range((max(per) + 3) // 4)]
+        assert ltp[p_ + 1] - ltp[p_] == len(want_tiles)
+        for tl, (ty, u) in zip(range(ltp[p_], ltp[p_ + 1]), want_tiles):
+            assert np.all(typ[16 * tl:16 * tl + 16] == ty)
+            for k in range(4):
+                rows = np.arange(16 * tl + 4 * k, 16 * tl + 4 * k + 4)
+                tgt = int(tg[k])
+                if tgt < 0:
+                    assert np.all(src[rows] == tg[0]) and not tp.lt_real[rows].any()
+                    continue
+                e = np.nonzero((ldst == tgt) & (ltyp == ty))[0]
+                e = e[np.argsort(lsrc[e], kind="stable")][4 * u:4 * u + 4]
+                n = e.size
+                assert np.array_equal(tp.lt_eid[rows[:n]], e) and np.array_equal(src[rows[:n]], lsrc[e]) and tp.lt_real[rows[:n]].all()
+                assert np.all(src[rows[n:]] == tgt) and not tp.lt_real[rows[n:]].any() and np.all(tp.lt_eid[rows[n:]] == -1)
+                seen[e] += 1
+        tiles_per_target.append((ltp[p_ + 1] - ltp[p_]) / max(live.size, 1))
+    assert np.all(seen == 1)
+    # the mapping the per-step kernels write lengths and scales through
+    lc_pos, lc_mir = tp.lc_pos.numpy(), tp.lc_mir.numpy()
     tpos, tmir = tp.lc_tpos.numpy(), tp.lc_tmir.numpy()
-    mk = tmir >= 0
-    cover = np.zeros(16 * tp.T, int)
-    np.add.at(cover, tpos, 1); np.add.at(cover, tmir[mk], 1)
-    assert np.array_equal(cover, real.astype(int))
-    assert np.array_equal(src[tpos], tp.lc_src.numpy()) and np.array_equal(src[tmir[mk]], tp.lc_dst.numpy()[mk])
-    assert np.array_equal(typ[tpos], tp.lc_type.numpy())
+    assert np.array_equal(tp.lt_eid[tpos], lc_pos)
+    assert np.array_equal(tp.lt_eid[tmir[lc_mir >= 0]], lc_mir[lc_mir >= 0]) and np.all(tmir[lc_mir < 0] == -1)
+    # grouping by needs keeps the padding moderate: about one tile per target on these molecules (pair tiles took ~2 type rounds)
+    assert tp.T / tp.N < 1.35
 
 
 def test_distance_weighting_segments():

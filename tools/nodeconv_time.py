@@ -52,11 +52,11 @@ cnt = ws.rad_cnt.cpu().numpy()
 out = {"N": topo.N, "E": int(ws.num_edges.item()), "L": topo.L, "R": int(cnt.sum()), "local_tiles": topo.T,
        "radius_tiles": int(((cnt + 15) // 16).sum()), "radius_rows_padded": int((((cnt + 15) // 16) * 16).sum()),
        "rad_cnt_hist": np.bincount((cnt + 15) // 16, minlength=4).tolist()}
-# how evenly the fixed pair -> wave assignment of k_cfconv_node spreads the work (cost model: a radius tile 1, a local tile 2)
-pt = topo.pair_tgt.cpu().numpy().reshape(-1, 2)
+# how evenly the fixed pair -> wave assignment of k_cfconv_node spreads the work (cost model: every tile 1)
+pt = topo.quad_tgt.cpu().numpy().reshape(-1, 4)
 ltp = topo.lt_ptr.cpu().numpy()
 tiles = (cnt + 15) // 16
-cost = tiles[pt[:, 0]] + np.where(pt[:, 1] >= 0, tiles[np.maximum(pt[:, 1], 0)], 0) + 2.0 * (ltp[1:] - ltp[:-1])
+cost = np.where(pt >= 0, tiles[np.maximum(pt, 0)], 0).sum(1) + 1.0 * (ltp[1:] - ltp[:-1])
 Pn, wgs, W = cost.size, min(256, (cost.size + 11) // 12), 12
 per_wg = (Pn + wgs - 1) // wgs
 wave_cost, wg_cost = np.zeros((wgs, W)), np.zeros(wgs)
