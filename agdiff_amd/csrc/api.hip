@@ -123,7 +123,7 @@ ForkJoin& fork_join_for_current_device() {
 // `rows_from_global`: the global branch's encoder pass writes ws->l_attr_rows itself (the local edges are a subset of
 // the edge set it walks and dualenc.py:214-216 evaluates the SAME encoder on them), so the pass over the local list is
 // skipped and everything after it waits for `rows_ready`.
-// `split` (CFConv by filter polynomials): the local edges' CFConv inputs are prepared here too -- their scales by pair-tile row
+// `split` (CFConv by filter polynomials): the local edges' CFConv inputs are prepared here too -- their scales by quad-tile row
 // (ws->lt_scale) when agdiff_cfconv_node takes their filters from polynomials, else their operand-form attributes and
 // scales by padded-list position (ws->l_attr_frag, ws->l_scale) for agdiff_cfconv_local; `split_ready` is recorded once
 // they are enqueued (the CFConv launches on the other stream wait for it).
@@ -134,7 +134,7 @@ int local_branch(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdi
   const int64_t ctiles = (topo->num_local_canon + AG_TW - 1) / AG_TW;
   // caller-supplied lengths (forward(edge_length=...)) need not be symmetric: then every local edge is evaluated
   const bool canon = !(flags & AGDIFF_FWD_GRAPH_GIVEN) && topo->num_local_canon > 0;
-  // (the fused sampler front has written the lengths -- and the pair-tile scales -- already)
+  // (the fused sampler front has written the lengths -- and the quad-tile scales -- already)
   const bool front_did_local = (flags & AGDIFF_FWD_GRAPH_READY) != 0;
   if (!(flags & AGDIFF_FWD_GRAPH_GIVEN) && !front_did_local) AG_TRY(agdiff_local_lengths(topo, ws, pos, stream));
   if (rows_from_global) {
@@ -142,7 +142,7 @@ int local_branch(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdi
   } else if (topo->num_local > 0) {
     if (canon && split) {
       const int lp = agdiff_local_poly_enabled(p, topo, ws);
-      if (lp != 0 && !front_did_local) AG_TRY(agdiff_edge_scales_split(p, topo, ws, 2, stream));   // scales by pair-tile row (agdiff_cfconv_node)
+      if (lp != 0 && !front_did_local) AG_TRY(agdiff_edge_scales_split(p, topo, ws, 2, stream));   // scales by quad-tile row (agdiff_cfconv_node)
       if (lp == 1) {        // the local CFConv takes every filter from polynomials: only the rows are needed
         AG_TRY(agdiff_local_edge_rows(p, topo, ws, stream));
       } else {              // (some) local edges through the filter MLPs: rows and the operand-form copy at the padded-list

@@ -1142,7 +1142,7 @@ extern "C" int agdiff_edge_scales_split(const agdiff_params_t* p, const agdiff_t
                               ws->l_scale, ((topo->num_local_padded + AG_TW - 1) / AG_TW) * AG_TW, stream,
                               agdiff_local_poly_enabled(p, topo, ws) == 2 ? topo->lc_type : nullptr);
   }
-  // ... in the pair tiles (agdiff_cfconv_node)
+  // ... in the quad tiles (agdiff_cfconv_node)
   if (!ws->lt_scale || !topo->lc_tpos || !topo->lc_tmir) return AGDIFF_ERR_ARG;
   return launch_edge_scales(p, ws->num_local_canon, topo->num_local_canon, ws->lc_len, topo->lc_tpos, topo->lc_tmir,
                             ws->lt_scale, topo->num_local_tiles * AG_TW, stream);
@@ -1209,7 +1209,7 @@ extern "C" int agdiff_cfconv_fused(const agdiff_params_t* p, const agdiff_topo_t
                              ws->xs, ws->agg, ws->agg_first, stream);
 }
 
-// Local edges by per-type filter polynomials?  (all of: slots built by the host, the pair-tile inputs present)
+// Local edges by per-type filter polynomials?  (all of: slots built by the host, the quad-tile inputs present)
 extern "C" int agdiff_local_poly_enabled(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws) {
   const bool on = p && topo && ws && !p->tune_local_poly_off && p->poly_kt >= 1 && p->poly_kt <= AGDIFF_POLY_MAX_KT &&
                   p->poly_num_slots > 0 && p->poly_num_slots <= AGDIFF_POLY_MAX_SLOTS && p->poly_type_slot && topo->lt_ptr &&

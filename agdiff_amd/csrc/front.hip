@@ -49,7 +49,7 @@ struct FrontArgs {
   int32_t* c_pos;              // radius row of the entry's edge
   int32_t* c_mir;              // radius row of its mirror, or -1
   // local phase (do_local): lengths of the molecule's canonical local edges to every layout that holds them, and their CFConv
-  // scales by pair-tile row -- everything the first CFConv of the next forward needs from the local edges
+  // scales by quad-tile row -- everything the first CFConv of the next forward needs from the local edges
   int32_t do_local;
   const int32_t* lcm_ptr;      // [G + 1] canonical local edges of a molecule
   const int32_t* lc_src;
@@ -58,7 +58,7 @@ struct FrontArgs {
   const int32_t* lc_mir;
   const int32_t* lc_ppos;      // (with l_len_p) padded-list positions
   const int32_t* lc_pmir;
-  const int32_t* lc_tpos;      // (with lt_len / lt_scale) pair-tile rows
+  const int32_t* lc_tpos;      // (with lt_len / lt_scale) quad-tile rows
   const int32_t* lc_tmir;
   float* l_len_w;
   float* lc_len;
@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(AG_FRONT_THREADS) k_sampler_front(FrontArgs a)
   __syncthreads();
   // ================================================================== local edges of the next forward
   // get_distance on the static local edges (geometry.py:5-6), one evaluation per canonical local edge written to the edge's
-  // and its mirror's slot of every layout, and lw(d) C(d) of all CFConvs by pair-tile row (agdiff_cfconv_node)
+  // and its mirror's slot of every layout, and lw(d) C(d) of all CFConvs by quad-tile row (agdiff_cfconv_node)
   if (a.do_local) {
     for (int c = a.lcm_ptr[g] + (int)threadIdx.x; c < a.lcm_ptr[g + 1]; c += blockDim.x) {
       const int sl = a.lc_src[c] - g0, dl = a.lc_dst[c] - g0;

@@ -390,7 +390,7 @@ __global__ void k_local_lengths(const int32_t* __restrict__ src, const int32_t* 
     len_in[inpos[c]] = v;
     if (inmir[c] >= 0) len_in[inmir[c]] = v;
   }
-  if (len_t) {           // ... and by pair-tile row (agdiff_topo_t.lt_*)
+  if (len_t) {           // ... and by quad-tile row (agdiff_topo_t.lt_*)
     len_t[tpos[c]] = v;
     if (tmir[c] >= 0) len_t[tmir[c]] = v;
   }

@@ -1,4 +1,4 @@
-// The two CFConvs of an InteractionBlock with their filters from d-polynomials, one wave per pair of targets
+// The two CFConvs of an InteractionBlock with their filters from d-polynomials, one wave per quad of targets
 // (include/agdiff_hip.h: agdiff_cfconv_node).  Its own translation unit: built with -fno-slp-vectorize -- the SLP
 // vectoriser turns the per-row accumulation FMAs into v_pk_fma_f32 fed by register shuffles (358 v_mov per kernel), and
 // packed fp32 next to MFMAs costs issue time instead of saving it (MI355X_MICROARCH.md, per-instruction cycle constants).

@@ -272,7 +272,7 @@ class Workspace:
         self.hl, self.hl2 = f32(N * 128), f32(N * 128)
         self.nan_flag = i32(1 + G)
         self.scratch = f32(N * 3)
-        # CFConv by filter polynomials: radius rows by target (agdiff_ws_t.rad_*), local pair tiles (lt_*), padded local list
+        # CFConv by filter polynomials: radius rows by target (agdiff_ws_t.rad_*), local quad tiles (lt_*), padded local list
         RS = _lib.DEFINES["AGDIFF_RAD_STRIDE"]
         Lp = topo.Lp
         ptiles = (Lp + TW - 1) // TW

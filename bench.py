@@ -460,7 +460,7 @@ def main():
                  JOB_STEPS))
 
     # ---- dominant operation = the two CFConvs of one InteractionBlock (encoder/schnet.py:136-162, 12 per forward).  With the
-    # filter polynomials on it is ONE launch (k_cfconv_node: radius rows + local pair tiles per pair of targets), else one
+    # filter polynomials on it is ONE launch (k_cfconv_node: radius rows + local quad tiles per quad of targets), else one
     # k_cfconv_fused.  avg_launch_ms = HIP-event pairs around every such launch of the TIMED region (agdiff_profile_cfconv:
     # events on the launch stream, side-stream kernels running beside them as in the step); `achieved` prices the REFERENCE's
     # arithmetic (E x 90,112 FLOP per block) over that time.
@@ -482,7 +482,7 @@ def main():
         pmc = load_pmc(args.precision, e_avg, kern)
         if node_path:
             kernel = ("k_cfconv_node<NKT=%d> (one launch per InteractionBlock: radius rows by target%s)"
-                      % (pk.poly_kt, " + local pair tiles, %d local types" % pk.struct.poly_num_slots if local_poly
+                      % (pk.poly_kt, " + local quad tiles, %d local types" % pk.struct.poly_num_slots if local_poly
                          else "; local edges through k_cfconv_fused on the padded local list, second launch"))
             issued = prof_edges * 192 * 32 * pk.poly_kt * 2 * MFMA_PASSES[args.precision] / (prof_ms * 1e-3) / 1e12
             note = ("achieved = the REFERENCE's arithmetic for this op -- it evaluates the 128->192->192 filter network on every "

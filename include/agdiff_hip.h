@@ -178,8 +178,8 @@ typedef struct agdiff_params {
 } agdiff_params_t;
 
 /* bits of agdiff_ws_t.variant_log: which kernel variants the launchers chose since the host last cleared it */
-#define AGDIFF_VAR_CFCONV_NODE 1        /* agdiff_cfconv_node: radius rows (+ local pair tiles) by filter polynomials */
-#define AGDIFF_VAR_CFCONV_NODE_LOCAL 2  /* ... its local pair tiles ran (every local type has a polynomial) */
+#define AGDIFF_VAR_CFCONV_NODE 1        /* agdiff_cfconv_node: radius rows (+ local quad tiles) by filter polynomials */
+#define AGDIFF_VAR_CFCONV_NODE_LOCAL 2  /* ... its local quad tiles ran (every local type has a polynomial) */
 #define AGDIFF_VAR_CFCONV_LOCAL_MLP 4   /* agdiff_cfconv_local: local edges through the filter MLPs */
 #define AGDIFF_VAR_CFCONV_FUSED 8       /* agdiff_cfconv_fused: every edge through the filter MLPs */
 #define AGDIFF_VAR_NODE_LDSW 16         /* node stage with workgroup-shared LDS weights */
@@ -332,8 +332,8 @@ typedef struct agdiff_ws {
   float*   xs0;              /* [N][192] ... and of its xs (block 0's lin1 / BN / LeakyReLU outputs) */
   float*   agg_loc;          /* [N][192] CFConv aggregates over the local edges (agdiff_cfconv_local) */
   float*   agg_first_loc;    /* [ceil(ceil(Lp/16) / agdiff_conv_chunk_tiles(Lp))][192] */
-  float*   lt_len;           /* [16 T] lengths of the local edges by pair-tile row (agdiff_local_lengths; pads stay 0) */
-  float*   lt_scale;         /* [2*num_convs][16 T]: lw(d)*C(d) by pair-tile row (pad rows stay 0) */
+  float*   lt_len;           /* [16 T] lengths of the local edges by quad-tile row (agdiff_local_lengths; pads stay 0) */
+  float*   lt_scale;         /* [2*num_convs][16 T]: lw(d)*C(d) by quad-tile row (pad rows stay 0) */
   float*   inv_r;            /* [N * AGDIFF_RAD_STRIDE] grad_global_dist_mlp output by radius row (fused sampler front) */
   int32_t* canon_counter;    /* [2] live length of the fused sampler front's canonical radius list, by step parity: every molecule
                                 claims its range of ws->c_* with one atomic add on [parity] (and molecule 0 zeroes the other) */
@@ -384,7 +384,7 @@ int agdiff_graph_build_scaled(const agdiff_params_t* p, const agdiff_topo_t* top
 
 /* get_distance on the static local edges (geometry.py:5-6 applied to edge_index[:, local_edge_mask]): one evaluation per
  * canonical local edge, written to l_len of the edge and of its mirror, to lc_len and -- where the workspace has them --
- * to l_len_p (padded-list positions) and lt_len (pair-tile rows). */
+ * to l_len_p (padded-list positions) and lt_len (quad-tile rows). */
 int agdiff_local_lengths(const agdiff_topo_t* topo, const agdiff_ws_t* ws, const float* pos, void* stream);
 
 /* DistanceWeightingNetwork x cutoff envelope of all 2*num_convs CFConvs (encoder/schnet.py:83-100, 138-149):
@@ -427,9 +427,9 @@ int agdiff_schnet_node_stage_split(const agdiff_params_t* p, const agdiff_topo_t
  * (encoder/schnet.py:138-162; PyG MessagePassing.propagate): ws->agg / ws->agg_first. */
 int agdiff_cfconv_fused(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k, void* stream);
 
-/* The same two CFConvs with the filters from d-polynomials (agdiff_params_t.poly_kt > 0), one launch, one wave per PAIR of
+/* The same two CFConvs with the filters from d-polynomials (agdiff_params_t.poly_kt > 0), one launch, one wave per QUAD of
  * targets: the radius rows of each (ws->rad_*, ws->r_scale; p->conv[k].filt_poly_pk) and -- when agdiff_local_poly_enabled
- * -- the pair's local tiles (topo->lt_*, ws->lt_len, ws->lt_scale; per-type sets p->conv[k].filt_poly_typed_pk) are
+ * -- the quad's local tiles (topo->lt_*, ws->lt_len, ws->lt_scale; per-type sets p->conv[k].filt_poly_typed_pk) are
  * summed in registers and ws->agg[i] is written once, complete, for every node (zeros for a node without edges).  Without
  * local polynomials the local edges' part comes from agdiff_cfconv_local: the filter MLPs over the padded local list
  * (topo->lp_*, ws->l_scale, ws->l_attr_frag) -> ws->agg_loc / ws->agg_first_loc, added by the node stage (split bit 8).
@@ -498,7 +498,7 @@ int agdiff_cfconv_aggregate(const float* x, const float* W, const int32_t* in_pt
 #define AGDIFF_FWD_STAGE0_CACHED 16
 /*   AGDIFF_FWD_GRAPH_READY  (with AGDIFF_FWD_SAMPLER, poly_kt > 0) agdiff_sampler_front has already built this step's radius rows,
  *                           their scales and its canonical radius list from `pos` (and written the local edges' lengths and
- *                           pair-tile scales): no graph build here; the global head's outputs go to ws->inv_r (by radius
+ *                           quad-tile scales): no graph build here; the global head's outputs go to ws->inv_r (by radius
  *                           row), where the next agdiff_sampler_front reads them.  AGDIFF_FWD_PARITY: the step's parity bit
  *                           (which of ws->canon_counter[2] holds the list's length) */
 #define AGDIFF_FWD_GRAPH_READY 32
@@ -519,7 +519,7 @@ int agdiff_score_forward(const agdiff_params_t* p, const agdiff_topo_t* topo, co
  *             c_src / c_dst / c_pos / c_mir (c_pos / c_mir = radius rows) of live length ws->canon_counter[parity], parity =
  *             (mode >> 4) & 1 alternating from step to step.  `cutoff` = p->cutoff, or 0 for extend_radius = False;
  *   mode & 4  and, on the same positions, what agdiff_local_lengths and agdiff_edge_scales_split(which = 2) write: the local
- *             edges' lengths in every layout (ws->l_len, lc_len, l_len_p, lt_len) and their CFConv scales by pair-tile row
+ *             edges' lengths in every layout (ws->l_len, lc_len, l_len_p, lt_len) and their CFConv scales by quad-tile row
  *             (ws->lt_scale) -- agdiff_score_forward then skips both (AGDIFF_FWD_GRAPH_READY).
  * The following agdiff_score_forward takes AGDIFF_FWD_SAMPLER | AGDIFF_FWD_GRAPH_READY.  Replaces agdiff_langevin_update +
  * agdiff_graph_build_scaled inside the denoising loop (models/common.py:208-233 is rebuilt every step). */

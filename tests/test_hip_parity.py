@@ -382,7 +382,7 @@ def _bench_size_oracle():
 def test_oracle_parity_at_natural_thresholds(precision, mode):
     """the kernels the bench times, against the ORACLE, at a size where they are chosen by the
     library's own thresholds -- no tuning override, no environment variable -- with agdiff_ws_t.variant_log asserting which
-    variants ran: the per-target polynomial CFConv with its local pair tiles (`auto`) or the one-list MLP CFConv with the
+    variants ran: the per-target polynomial CFConv with its local quad tiles (`auto`) or the one-list MLP CFConv with the
     local rows shared from the global encoder pass (`off`), the LDS-shared node stage and GIN layer, the side stream.
     Matches dualenc.py:142-251 (forward) and :478-545 (two denoising steps)."""
     import os

@@ -1,5 +1,5 @@
-"""GPU (MI355X): the filter-polynomial kernels (csrc/nodeconv.hip k_cfconv_node: one wave per pair of targets, radius rows +
-local pair tiles; k_pair_head_poly; k_edge_attr_poly) and every fallback around them, against the reference fixtures and
+"""GPU (MI355X): the filter-polynomial kernels (csrc/nodeconv.hip k_cfconv_node: one wave per quad of targets, radius rows +
+local quad tiles; k_pair_head_poly; k_edge_attr_poly) and every fallback around them, against the reference fixtures and
 against the one-list kernels that evaluate the filter MLPs for every edge.  `radius_poly` (agdiff_amd/packing.py):
   auto    radius edges and every local edge type from d-polynomials (the default the other test files run)
   radius  polynomials for the radius edges only, local edges through the filter MLPs on the padded local list
@@ -113,7 +113,7 @@ def test_sampler_every_filter_mode(case, mode, precision):
 @pytest.mark.parametrize("kind,mols,copies", [("drugs", 5, 4), ("qm9", 7, 5)])
 def test_node_cfconv_equals_one_list_kernel(kind, mols, copies):
     """Kernel level, through the C ABI: on the same graph, node inputs and block, agdiff_cfconv_node (polynomial filters;
-    radius rows + local pair tiles, one complete row of agg per node) equals what agdiff_cfconv_fused (filter MLPs on
+    radius rows + local quad tiles, one complete row of agg per node) equals what agdiff_cfconv_fused (filter MLPs on
     every edge of the full list) aggregates; the radius rows of a target are the type-0 subsequence of its list, the pad
     rows that complete its last tile contribute exactly nothing; and the same with the local edges through the filter MLPs
     (agdiff_cfconv_local's second aggregate) and with the typed sets read from L2."""
