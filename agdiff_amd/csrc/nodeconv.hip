@@ -42,6 +42,7 @@ struct NodeConvArgs {
   float* agg;                 // [N][192]
   int32_t n;                  // N
   int32_t num_quads;          // Q
+  int32_t qshift;             // a local tile's rows of lane quarter q belong to the quad's (q >> qshift)-th target (GT = 4 >> qshift)
   float two_over_rc;
 };
 
@@ -243,10 +244,10 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
   };
   float acc[AG_CONV_NCH], accL[AG_CONV_NCH];
   // the sums over the wave's quarters, once per target: quarter j of a reduce-scatter ends up with channel tile 4 g + j.
-  // `k`: the target's place in its quad -- its local rows are quarter k of the quad's local tiles
+  // `k`: the target's place in its quad -- its local rows are the quarters q with q >> qshift == k of the quad's local tiles
   auto finalize = [&](int tgt, int k) {
     char* dp = reinterpret_cast<char*>(a.agg + (size_t)tgt * 192);       // (uniform)
-    const bool mine = q == k;
+    const bool mine = (q >> a.qshift) == k;
 #pragma unroll
     for (int g = 0; g < AG_CONV_NCH / 4; ++g) {
       float v[4];
@@ -401,7 +402,7 @@ extern "C" int agdiff_cfconv_node(const agdiff_params_t* p, const agdiff_topo_t*
   if (!p || !topo || !ws || k < 0 || k >= p->num_convs) return AGDIFF_ERR_ARG;
   if (p->poly_kt < 1 || p->poly_kt > AGDIFF_POLY_MAX_KT || !p->conv[k].filt_poly_pk) return AGDIFF_ERR_ARG;
   if (!ws->rad_cnt || !ws->rad_src || !ws->rad_len || !ws->r_scale || !ws->xs || !ws->agg || !topo->quad_tgt ||
-      topo->num_quads <= 0)
+      topo->num_quads <= 0 || (topo->group_targets != 4 && topo->group_targets != 2 && topo->group_targets != 1))
     return AGDIFF_ERR_ARG;
   if (topo->num_nodes <= 0) return AGDIFF_OK;
   if (topo->num_nodes * (int64_t)AGDIFF_RAD_STRIDE >= (1ll << 31)) return AGDIFF_ERR_LIMIT;
@@ -435,6 +436,7 @@ extern "C" int agdiff_cfconv_node(const agdiff_params_t* p, const agdiff_topo_t*
   a.agg = ws->agg;
   a.n = (int32_t)topo->num_nodes;
   a.num_quads = (int32_t)topo->num_quads;
+  a.qshift = topo->group_targets == 4 ? 0 : topo->group_targets == 2 ? 1 : 2;
   a.two_over_rc = 2.0f / p->cutoff;
   int64_t wgs = (a.num_quads + AG_NODECONV_WAVES - 1) / AG_NODECONV_WAVES;
   if (wgs > 256) wgs = 256;

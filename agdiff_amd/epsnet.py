@@ -217,6 +217,7 @@ class DualEncoderEpsNetwork(nn.Module):
         # kernel-variant thresholds (PackedParams.set_tuning; include/agdiff_hip.h: agdiff_params_t.tune_*), e.g.
         # model.tuning["node_ldsw_min_tiles"] = 1 -- tests reach every variant on small fixtures this way
         self.tuning = {}
+        self.group_targets = None            # targets per wave of agdiff_cfconv_node: None = by batch size (BatchTopology.GROUP_MIN_NODES)
         self.poly_refuse_types = ()          # (tests: local edge types to treat as if their polynomial fit had been refused)
         self._packed = None
         self._packed_key = None
@@ -267,7 +268,8 @@ class DualEncoderEpsNetwork(nn.Module):
         tests and tools can inspect the device buffers; never reused across calls)."""
         key = None
         topo = BatchTopology(atom_type, bond_index, bond_type, batch, num_graphs=num_graphs,
-                             extend_order=extend_order, order=self.config.edge_order, device=self._device())
+                             extend_order=extend_order, order=self.config.edge_order, device=self._device(),
+                             group_targets=getattr(self, "group_targets", None))
         ws = Workspace(topo)
         if self._packed is not None and topo.L:
             self._packed.ensure_local_types(topo.local_types)     # filter polynomials for this batch's local edge types
@@ -329,7 +331,7 @@ class DualEncoderEpsNetwork(nn.Module):
         with torch.no_grad():
             pk = self._renorm_embedding(atom_type)
             topo = BatchTopology(atom_type, ei[:, loc], et[loc], batch, num_graphs=None, extend_order=False,
-                                 device=dev)
+                                 device=dev, group_targets=getattr(self, "group_targets", None))
             if topo.L != loc.shape[0]:
                 raise NotImplementedError("duplicate local edges in a caller-supplied edge list")
             ws = Workspace(topo, max_edges=E)

@@ -19,8 +19,13 @@ def _to_np(x):
 
 
 class BatchTopology:
+    # agdiff_cfconv_node gives a wave a GROUP of targets (quad_tgt): four for batches that fill the chip that way (one
+    # 16-row local tile then serves four targets: fewest tiles), two or one for small batches, where there are more wave
+    # slots (3,072 on an MI355X) than groups and the wave's chain of tiles is what a launch lasts
+    GROUP_MIN_NODES = ((6144, 4), (3072, 2))        # N > 6144: 4 targets per group, N > 3072: 2, else 1
+
     def __init__(self, atom_type, bond_index, bond_type, batch, num_graphs=None, extend_order=False,
-                 order=3, device="cuda"):
+                 order=3, device="cuda", group_targets=None):
         import torch
         at = _to_np(atom_type).astype(np.int64)
         bi = _to_np(bond_index).astype(np.int64).reshape(2, -1)
@@ -132,23 +137,30 @@ class BatchTopology:
         self.lp_row = i32(np.where(real, loc_row[eid], -1) if L else np.zeros(Lp))
         self.lc_ppos = i32(ppos[lc_pos])
         self.lc_pmir = i32(np.where(lc_mir >= 0, ppos[np.maximum(lc_mir, 0)], -1))
-        # ... and as QUAD TILES for agdiff_cfconv_node (agdiff_topo_t.quad_tgt, lt_*): one wave owns four targets of one molecule,
-        # and a 16-row local tile holds rows of ONE edge type: rows 4 k .. 4 k + 3 are in-edges of the quad's k-th target (so
-        # the four rows a lane quarter holds belong to one target and the tile needs no masks and ONE filter set).  Per quad
-        # and type: max over its targets of ceil(in-edges of that type / 4) tiles; atoms are grouped by those needs so that
-        # a quad's targets need like tiles.
+        # ... and as QUAD TILES for agdiff_cfconv_node (agdiff_topo_t.quad_tgt, lt_*): one wave owns GT = 4 (2, 1) targets of one
+        # molecule, and a 16-row local tile holds rows of ONE edge type: rows RT k .. RT k + RT - 1 (RT = 16 / GT) are in-edges of
+        # the group's k-th target (so the four rows a lane quarter holds belong to one target and the tile needs no masks and
+        # ONE filter set).  Per group and type: max over its targets of ceil(in-edges of that type / RT) tiles; atoms are
+        # grouped by those needs so that a group's targets need like tiles.
         ltypes = np.unique(typ) if L else np.zeros(0, dtype=np.int64)
         cnt_tt = np.zeros((N, max(ltypes.size, 1)), dtype=np.int64)
         for k, ty in enumerate(ltypes):
             cnt_tt[:, k] = np.bincount(dst[typ == ty], minlength=N)
-        need = (cnt_tt + 3) // 4
+        if group_targets is None:
+            group_targets = next((g for n, g in self.GROUP_MIN_NODES if N > n), 1)
+        if group_targets not in (1, 2, 4):
+            raise ValueError("group_targets must be 1, 2 or 4")
+        GT, RT = int(group_targets), 16 // int(group_targets)               # targets per group, rows per target in a tile
+        need = (cnt_tt + RT - 1) // RT
         order_in_mol = np.lexsort(tuple(need[:, k] for k in range(need.shape[1] - 1, -1, -1)) + (ba,))    # by molecule, then the needs
         quad_tgt = []
         for g in range(G):
             idx = order_in_mol[gptr[g]:gptr[g + 1]]
-            if idx.size % 4:
-                idx = np.concatenate([idx, np.full(4 - idx.size % 4, -1, dtype=idx.dtype)])
-            quad_tgt.append(idx)
+            if idx.size % GT:
+                idx = np.concatenate([idx, np.full(GT - idx.size % GT, -1, dtype=idx.dtype)])
+            grp = np.full((idx.size // GT, 4), -1, dtype=np.int64)              # (always four entries per group: -1 = none)
+            grp[:, :GT] = idx.reshape(-1, GT)
+            quad_tgt.append(grp.reshape(-1))
         quad_tgt = np.concatenate(quad_tgt).astype(np.int64) if quad_tgt else np.zeros(0, dtype=np.int64)
         Q = quad_tgt.size // 4
         qt = quad_tgt.reshape(Q, 4)
@@ -182,18 +194,18 @@ class BatchTopology:
         tpos = np.zeros(L, dtype=np.int64)
         if L:
             k_of = np.searchsorted(ltypes, typ)
-            tile_e = tile_of_qk[quad_of[dst] * qneed.shape[1] + k_of] + rank_in // 4
-            tpos = tile_e * 16 + slot_of[dst] * 4 + rank_in % 4
+            tile_e = tile_of_qk[quad_of[dst] * qneed.shape[1] + k_of] + rank_in // RT
+            tpos = tile_e * 16 + slot_of[dst] * RT + rank_in % RT
         real_t = np.zeros(16 * T, dtype=bool)
         eid_t = np.full(16 * T, -1, dtype=np.int64)
         real_t[tpos] = True
         eid_t[tpos] = np.arange(L)
         assert int(real_t.sum()) == L                                        # every local edge has its own row
         trow = np.arange(16 * T)
-        tgt_t = qt[tile_quad[trow // 16], (trow % 16) // 4] if T else np.zeros(0, dtype=np.int64)
+        tgt_t = qt[tile_quad[trow // 16], (trow % 16) // RT] if T else np.zeros(0, dtype=np.int64)
         first_t = qt[tile_quad[trow // 16], 0] if T else tgt_t
         tgt_c = np.where(tgt_t >= 0, tgt_t, first_t)                         # pad rows: src = the target itself (a missing one: the first)
-        self.T, self.Q = T, int(Q)
+        self.T, self.Q, self.group_targets = T, int(Q), GT
         self.quad_tgt = i32(quad_tgt)
         self.lt_ptr = i32(lt_ptr)
         self.lt_src = i32(np.where(real_t, src[np.maximum(eid_t, 0)], tgt_c) if L else np.zeros(16 * T))
@@ -217,6 +229,7 @@ class BatchTopology:
         t.num_local_padded = self.Lp
         t.num_local_tiles = self.T
         t.num_quads = self.Q
+        t.group_targets = self.group_targets
         tm = [0, 0]
         for ty in self.local_types:
             tm[int(ty) >> 6] |= 1 << (int(ty) & 63)

@@ -244,6 +244,9 @@ typedef struct agdiff_topo {
    * over a target's edges needs no masks, and a tile needs ONE filter set.  The host groups atoms whose in-lists need like
    * numbers of tiles per type; tiles of quad p: type ascending */
   int64_t num_quads;         /* Q */
+  int64_t group_targets;     /* GT = 4, 2 or 1: targets per quad that are used (small batches: fewer targets per wave, more waves).
+                                A tile then gives each target 16 / GT rows: rows (16 / GT) k .. of the k-th target; entries
+                                quad_tgt[4 p + GT ..] are -1 */
   const int32_t* quad_tgt;   /* [4 Q] */
   const int32_t* lcm_ptr;    /* [G+1]: the canonical local edges lc_*[lcm_ptr[g] .. lcm_ptr[g+1]) belong to molecule g (the list is
                                 sorted by source) */

@@ -110,24 +110,27 @@ def test_sampler_every_filter_mode(case, mode, precision):
     check_close("poly[%s] pos[%s]" % (mode, case), pos.cpu().numpy(), g["pos_final"], precision)
 
 
+@pytest.mark.parametrize("gt", [4, 2, 1])
 @pytest.mark.parametrize("kind,mols,copies", [("drugs", 5, 4), ("qm9", 7, 5)])
-def test_node_cfconv_equals_one_list_kernel(kind, mols, copies):
+def test_node_cfconv_equals_one_list_kernel(kind, mols, copies, gt):
     """Kernel level, through the C ABI: on the same graph, node inputs and block, agdiff_cfconv_node (polynomial filters;
     radius rows + local quad tiles, one complete row of agg per node) equals what agdiff_cfconv_fused (filter MLPs on
     every edge of the full list) aggregates; the radius rows of a target are the type-0 subsequence of its list, the pad
     rows that complete its last tile contribute exactly nothing; and the same with the local edges through the filter MLPs
-    (agdiff_cfconv_local's second aggregate) and with the typed sets read from L2."""
+    (agdiff_cfconv_local's second aggregate) and with the typed sets read from L2; for four, two and one target per wave."""
     from agdiff_amd import _lib, drugs_model_config, qm9_model_config, synth
     lib = _lib.load()
     RS = _lib.DEFINES["AGDIFF_RAD_STRIDE"]
     cfg = (qm9_model_config if kind == "qm9" else drugs_model_config)(num_diffusion_timesteps=50, beta_end=2e-5)
     for precision in ("f32", "bf16x3"):
         m = _model(cfg, "auto", precision=precision)
+        m.group_targets = gt                    # targets per wave: 4 (what large batches take), 2, 1
         b = synth.make_packed_batch(kind, mols, copies, seed=17)
         at, bi, bt, ba = [t(b[k]).cuda() for k in ("atom_type", "bond_index", "bond_type", "batch")]
         pos = (torch.randn(at.shape[0], 3, generator=torch.Generator().manual_seed(2)) * 2.0).cuda()
         m(at, pos, bi, bt, ba, None, return_edges=True, extend_order=False)     # full forward: e_attr, scales of every list
         topo, ws, pk = m._batch_cache[1], m._batch_cache[2], m.packed()
+        assert topo.group_targets == gt == topo.struct.group_targets
         assert pk.struct.poly_num_slots > 0 and lib.agdiff_local_poly_enabled(
             ctypes.byref(pk.struct), ctypes.byref(topo.struct), ctypes.byref(ws.struct)) == 1
         P, T, W, st = ctypes.byref(pk.struct), ctypes.byref(topo.struct), ctypes.byref(ws.struct), _lib.stream_ptr()

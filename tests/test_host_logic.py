@@ -300,24 +300,30 @@ def test_padded_local_list():
     assert np.array_equal(cover, row >= 0)
 
 
+@pytest.mark.parametrize("gt", [4, 2, 1])
 @pytest.mark.parametrize("kind,mols,copies", [("drugs", 3, 2), ("qm9", 5, 1)])
-def test_local_quad_tiles(kind, mols, copies):
-    """agdiff_topo_t.quad_tgt / lt_* (agdiff_cfconv_node): every atom sits in exactly one quad, the atoms of a quad belong to
-    one molecule (the last quad of a molecule is filled with -1); a tile holds rows of ONE edge type, rows 4 k .. 4 k + 3 of
-    tile u of that type are in-edges [4 u, 4 u + 4) -- of that type, in source order -- of the quad's k-th target; a quad
-    has max over its targets of ceil(in-edges of the type / 4) tiles per type, types ascending; pad rows point at the target
-    itself (a missing target: the quad's first) and carry the tile's type; every local edge sits in exactly one row."""
+def test_local_quad_tiles(kind, mols, copies, gt):
+    """agdiff_topo_t.quad_tgt / lt_* (agdiff_cfconv_node), for GT = 4, 2, 1 targets per group (RT = 16 / GT rows per target and
+    tile): every atom sits in exactly one group, the atoms of a group belong to one molecule (unused entries are -1); a tile
+    holds rows of ONE edge type, rows RT k .. RT k + RT - 1 of tile u of that type are in-edges [RT u, RT u + RT) -- of that
+    type, in source order -- of the group's k-th target; a group has max over its targets of ceil(in-edges of the type / RT)
+    tiles per type, types ascending; pad rows point at the target itself (a missing target: the group's first) and carry
+    the tile's type; every local edge sits in exactly one row.  The default group size follows the batch size."""
     from agdiff_amd import synth
     from agdiff_amd.topology import BatchTopology
     b = synth.make_packed_batch(kind, mols, copies, seed=5)
-    tp = BatchTopology(b["atom_type"], b["bond_index"], b["bond_type"], b["batch"], device="cpu")
+    tp = BatchTopology(b["atom_type"], b["bond_index"], b["bond_type"], b["batch"], device="cpu", group_targets=gt)
+    rt = 16 // gt
+    assert tp.struct.group_targets == gt
+    auto = BatchTopology(b["atom_type"], b["bond_index"], b["bond_type"], b["batch"], device="cpu")
+    assert auto.group_targets == (4 if tp.N > 6144 else 2 if tp.N > 3072 else 1)
     qt, ltp, src, typ = tp.quad_tgt.numpy().reshape(-1, 4), tp.lt_ptr.numpy(), tp.lt_src.numpy(), tp.lt_type.numpy()
     lsrc, ldst, ltyp, ba = tp.loc_src.numpy(), tp.loc_dst.numpy(), tp.loc_type.numpy(), b["batch"]
     Q = tp.Q
     assert qt.shape[0] == Q == tp.struct.num_quads and ltp.shape[0] == Q + 1 and ltp[-1] == tp.T == tp.struct.num_local_tiles
     assert sorted(qt[qt >= 0].tolist()) == list(range(tp.N)) and np.all(qt[:, 0] >= 0)
     sizes = np.bincount(ba)
-    assert int((qt < 0).sum()) == int(((4 - sizes % 4) % 4).sum())
+    assert np.all(qt[:, gt:] < 0) and int((qt[:, :gt] < 0).sum()) == int(((gt - sizes % gt) % gt).sum())
     seen = np.zeros(tp.L, int)
     tiles_per_target = []
     for p_ in range(Q):
@@ -328,18 +334,18 @@ def test_local_quad_tiles(kind, mols, copies):
         types_here = np.unique(ltyp[np.isin(ldst, live)])
         for ty in types_here:
             per = [int(((ldst == t_) & (ltyp == ty)).sum()) for t_ in live]
-            want_tiles += [(int(ty), u) for u in range((max(per) + 3) // 4)]
+            want_tiles += [(int(ty), u) for u in range((max(per) + rt - 1) // rt)]
         assert ltp[p_ + 1] - ltp[p_] == len(want_tiles)
         for tl, (ty, u) in zip(range(ltp[p_], ltp[p_ + 1]), want_tiles):
             assert np.all(typ[16 * tl:16 * tl + 16] == ty)
-            for k in range(4):
-                rows = np.arange(16 * tl + 4 * k, 16 * tl + 4 * k + 4)
+            for k in range(gt):
+                rows = np.arange(16 * tl + rt * k, 16 * tl + rt * k + rt)
                 tgt = int(tg[k])
                 if tgt < 0:
                     assert np.all(src[rows] == tg[0]) and not tp.lt_real[rows].any()
                     continue
                 e = np.nonzero((ldst == tgt) & (ltyp == ty))[0]
-                e = e[np.argsort(lsrc[e], kind="stable")][4 * u:4 * u + 4]
+                e = e[np.argsort(lsrc[e], kind="stable")][rt * u:rt * u + rt]
                 n = e.size
                 assert np.array_equal(tp.lt_eid[rows[:n]], e) and np.array_equal(src[rows[:n]], lsrc[e]) and tp.lt_real[rows[:n]].all()
                 assert np.all(src[rows[n:]] == tgt) and not tp.lt_real[rows[n:]].any() and np.all(tp.lt_eid[rows[n:]] == -1)
@@ -352,7 +358,7 @@ def test_local_quad_tiles(kind, mols, copies):
     assert np.array_equal(tp.lt_eid[tpos], lc_pos)
     assert np.array_equal(tp.lt_eid[tmir[lc_mir >= 0]], lc_mir[lc_mir >= 0]) and np.all(tmir[lc_mir < 0] == -1)
     # grouping by needs keeps the padding moderate: about one tile per target on these molecules (pair tiles took ~2 type rounds)
-    assert tp.T / tp.N < 1.35
+    assert gt != 4 or tp.T / tp.N < 1.35
 
 
 def test_distance_weighting_segments():

@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT
+for cp in 25 70 100 140 200 280; do for g in 4 2 1; do
+python3 tools/nodeconv_time.py --mols 1 --copies $cp --group $g --only node 2>/dev/null | tail -1 | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('copies $cp N',d['N'],'group',d['group_targets'],'tiles',d['local_tiles'],'node_x6_ms %.4f'%d['node_x6_ms'])"
+done; done

@@ -15,6 +15,7 @@ ap.add_argument("--copies", type=int, default=128)
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--kind", default="drugs")
 ap.add_argument("--precision", default="bf16x3")
+ap.add_argument("--group", type=int, default=None, help="targets per wave (BatchTopology group_targets): 4, 2, 1; default by batch size")
 ap.add_argument("--only", default=None, choices=["node", "radius"], help="time one variant only (counter passes)")
 args = ap.parse_args()
 lib = _lib.load()
@@ -22,6 +23,7 @@ dev = torch.device("cuda", 0)
 cfg = (qm9_model_config if args.kind == "qm9" else drugs_model_config)(beta_end=2e-5)
 m = get_model(cfg)
 m.precision = args.precision
+m.group_targets = args.group
 m.load_state_dict(synth.synth_state_dict(m.state_dict()))
 m = m.to(dev).eval()
 b = synth.make_packed_batch(args.kind, args.mols, args.copies, seed=2021)
@@ -49,7 +51,7 @@ def timeit(fn, reps=args.reps):
 
 
 cnt = ws.rad_cnt.cpu().numpy()
-out = {"N": topo.N, "E": int(ws.num_edges.item()), "L": topo.L, "R": int(cnt.sum()), "local_tiles": topo.T,
+out = {"group_targets": topo.group_targets, "N": topo.N, "E": int(ws.num_edges.item()), "L": topo.L, "R": int(cnt.sum()), "local_tiles": topo.T,
        "radius_tiles": int(((cnt + 15) // 16).sum()), "radius_rows_padded": int((((cnt + 15) // 16) * 16).sum()),
        "rad_cnt_hist": np.bincount((cnt + 15) // 16, minlength=4).tolist()}
 # how evenly the fixed pair -> wave assignment of k_cfconv_node spreads the work (cost model: every tile 1)
