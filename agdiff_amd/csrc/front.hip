@@ -31,6 +31,7 @@ struct FrontArgs {
   int32_t* rad_src;
   float* rad_len;
   float* r_scale;
+  const float* dist_union;   // agdiff_params_t.dist_union or null (then: one search per conv in dw[])
   int64_t rpad;
   const float* inv_r;          // [N * AGDIFF_RAD_STRIDE] global head output by radius row
   const float* dw[2 * AGDIFF_MAX_CONVS];
@@ -101,6 +102,10 @@ __global__ void __launch_bounds__(AG_FRONT_THREADS) k_sampler_front(FrontArgs a)
   int* scan_c = reinterpret_cast<int*>(snew + 3 * nmax);
   uint32_t* radbits = reinterpret_cast<uint32_t*>(scan_c + nmax);
   uint32_t* locbits = radbits + nmax * words;
+  // the distance-weighting networks over their common segments (a.dist_union): 512 kinks + 385 x n_scales lines
+  float* skink = reinterpret_cast<float*>(locbits + nmax * words);
+  const float2* sline = reinterpret_cast<const float2*>(skink + 512);
+  const bool by_union = a.dist_union != nullptr;
   __shared__ float red[3][AG_FRONT_THREADS / 64];
   __shared__ int nanw[AG_FRONT_THREADS / 64];
   __shared__ float sseg[2 * AGDIFF_MAX_CONVS * 100];
@@ -115,8 +120,24 @@ __global__ void __launch_bounds__(AG_FRONT_THREADS) k_sampler_front(FrontArgs a)
   };
 
   for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) spos[i] = a.s.pos_in[3 * (size_t)g0 + i];
-  if (a.do_graph || a.do_local)
+  if ((a.do_graph || a.do_local) && !by_union)
     for (int i = threadIdx.x; i < a.n_scales * 100; i += blockDim.x) sseg[i] = a.dw[i / 100][i % 100];
+  if ((a.do_graph || a.do_local) && by_union) {
+    const int words16 = (512 + 385 * 2 * a.n_scales) / 4;
+    ag_copy_lds<4>((lds_u32x4*)(ag_front_smem + (7 * nmax + 2 * nmax * words)), reinterpret_cast<const u32x4*>(a.dist_union), words16);
+  }
+  // lw_cc(d) C(d) of every CFConv for one length: ONE search among the union of the networks' kinks (9 steps), then per conv
+  // the line its own table would have selected (the same floats: bit-identical to cf_dist_weight) and the sigmoid
+  auto union_segment = [&](float d) -> int {
+    int u = 0;
+#pragma unroll
+    for (int step = 256; step >= 1; step >>= 1) u += (skink[u + step - 1] <= d) ? step : 0;
+    return u;
+  };
+  auto scale_of = [&](int u, int cc, float d) -> float {
+    const float2 ab = sline[u * a.n_scales + cc];
+    return ag_sigmoid(fmaf(ab.x, d, ab.y));
+  };
 
   // ================================================================== update of step t
   if (a.do_update) {
@@ -297,8 +318,9 @@ __global__ void __launch_bounds__(AG_FRONT_THREADS) k_sampler_front(FrontArgs a)
         a.lt_len[tp] = v;
         if (tm >= 0) a.lt_len[tm] = v;
         const float C = cf_envelope(v, a.cutoff, a.smooth);
+        const int u = by_union ? union_segment(v) : 0;
         for (int cc = 0; cc < a.n_scales; ++cc) {
-          const float sc = cf_dist_weight(sseg + cc * 100, v) * C;
+          const float sc = (by_union ? scale_of(u, cc, v) : cf_dist_weight(sseg + cc * 100, v)) * C;
           a.lt_scale[(size_t)cc * a.tpad + tp] = sc;
           if (tm >= 0) a.lt_scale[(size_t)cc * a.tpad + tm] = sc;
         }
@@ -390,7 +412,16 @@ __global__ void __launch_bounds__(AG_FRONT_THREADS) k_sampler_front(FrontArgs a)
         a.rad_src[rp] = g0 + j;
         a.rad_len[rp] = len;
         const float C = cf_envelope(len, a.cutoff, a.smooth);
-        for (int cc = 0; cc < a.n_scales; ++cc) a.r_scale[(size_t)cc * a.rpad + rp] = cf_dist_weight(sseg + cc * 100, len) * C;
+#ifdef AG_FRONT_ABL      // (timing experiment: the radius rows' scales without their evaluation -- wrong results)
+        for (int cc = 0; cc < a.n_scales; ++cc) a.r_scale[(size_t)cc * a.rpad + rp] = C;
+#else
+        if (by_union) {
+          const int u = union_segment(len);
+          for (int cc = 0; cc < a.n_scales; ++cc) a.r_scale[(size_t)cc * a.rpad + rp] = scale_of(u, cc, len) * C;
+        } else {
+          for (int cc = 0; cc < a.n_scales; ++cc) a.r_scale[(size_t)cc * a.rpad + rp] = cf_dist_weight(sseg + cc * 100, len) * C;
+        }
+#endif
         if (canon) {
           const int cp = cp0 + __popcll(cmask & lt);
           a.c_len[cp] = len;
@@ -454,6 +485,7 @@ extern "C" int agdiff_sampler_front(const agdiff_params_t* p, const agdiff_topo_
     a.dw[2 * k + 1] = p->conv[k].dist_seg + 100;
   }
   a.n_scales = 2 * p->num_convs;
+  a.dist_union = p->dist_union;
   a.cutoff = p->cutoff;
   a.r2 = cutoff * cutoff;
   a.smooth = p->smooth;
@@ -490,10 +522,13 @@ extern "C" int agdiff_sampler_front(const agdiff_params_t* p, const agdiff_topo_
   int parts = 1;
   while (parts < 16 && 2 * parts * max_atoms <= bd) parts *= 2;
   a.parts = parts;
-  const size_t smem = (size_t)(3 * nmax + 3 * nmax + nmax + 2 * nmax * a.words) * 4;
+  const size_t smem = (size_t)(3 * nmax + 3 * nmax + nmax + 2 * nmax * a.words) * 4 +
+                      (a.dist_union ? (size_t)(512 + 385 * 2 * a.n_scales) * 4 : 0);
   if (smem > 48 * 1024) {
     static std::atomic<uint64_t> attr_done{0};
-    if (!ag_allow_big_lds(attr_done, (size_t)160 * 1024, k_sampler_front)) return AGDIFF_ERR_LAUNCH;
+    // (the kernel also has ~6 KiB of static LDS: the dynamic part may not claim all 160 KiB)
+    if (smem > (size_t)152 * 1024) return AGDIFF_ERR_LIMIT;
+    if (!ag_allow_big_lds(attr_done, (size_t)152 * 1024, k_sampler_front)) return AGDIFF_ERR_LAUNCH;
   }
   ag_log_variant(ws, AGDIFF_VAR_FUSED_FRONT);
   k_sampler_front<<<dim3((unsigned)topo->num_graphs), dim3(bd), smem, (hipStream_t)stream>>>(a);

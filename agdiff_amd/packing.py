@@ -303,6 +303,28 @@ def dist_segments(w1, b1, w2, b2):
     return np.concatenate([bp, alpha, beta, np.zeros(2)])
 
 
+def dist_union_table(segs):
+    """agdiff_params_t.dist_union from the per-conv tables (dist_segments, two per InteractionBlock, rounded to float32 as the
+    kernels read them): the union of all kinks ascending in [0..511] (+inf padded) and, for union segment u = number of
+    those kinks <= d, the line every conv's own table selects for such a d -- conv kinks <= d are exactly the conv's kinks
+    among the first u union kinks -- at [512 + (u * n + cc) * 2], cc = 2 k + (0 | 1), n = 2 num_convs."""
+    tabs = [np.asarray(t, dtype=np.float64).astype(np.float32).reshape(2, 100) for t in segs]
+    rows = [tabs[k][h] for k in range(len(tabs)) for h in (0, 1)]
+    n = len(rows)
+    kinks = np.unique(np.concatenate([r[:32][np.isfinite(r[:32])] for r in rows])) if n else np.zeros(0, np.float32)
+    U = kinks.size
+    assert U <= 384
+    out = np.zeros(512 + 385 * 2 * n, dtype=np.float32)
+    out[:512] = np.inf
+    out[:U] = kinks
+    for u in range(385):
+        for cc, r in enumerate(rows):
+            s_ = int(np.count_nonzero(r[:32] <= kinks[u - 1])) if (0 < u <= U) else (0 if u == 0 else int(np.count_nonzero(np.isfinite(r[:32]))))
+            out[512 + (u * n + cc) * 2] = r[32 + s_]
+            out[512 + (u * n + cc) * 2 + 1] = r[65 + s_]
+    return out
+
+
 PRECISIONS = {"f32": 0, "bf16x3": 1}
 EDGE_ENCODERS = {"mlp": 0, "gaussian": 1}       # agdiff_params_t.edge_encoder
 
@@ -425,6 +447,9 @@ class PackedParams:
             arrays[n + "scale1_pk"] = pack_blocks(_np(sd, s + ".fc.0.weight"))
             arrays[n + "scale2_pk"] = pack_blocks(_np(sd, s + ".fc.2.weight"))
 
+        # the DistanceWeightingNetworks of all CFConvs over their common segments (agdiff_params_t.dist_union)
+        arrays["dist_union"] = dist_union_table([arrays["conv%d.dist_seg" % k] for k in range(cfg.num_convs)])
+
         # ---------------- GIN (gin.py:38-69, 112-148)
         for k in range(cfg.num_convs_local):
             p = "encoder_local.convs.%d" % k
@@ -474,7 +499,7 @@ class PackedParams:
 
         prm = _lib.Params()
         for f in ("ee_fe_w", "ee_fe_b", "ee_t1", "ee_w1_pk", "ee_t3", "ee_w23_pk", "ee_w4_pk", "ee_b4",
-                  "ge_offset", "ge_emb", "schnet_emb", "gin_emb"):
+                  "ge_offset", "ge_emb", "schnet_emb", "gin_emb", "dist_union"):
             if f in offs:
                 setattr(prm, f, P(f))
         prm.edge_encoder = EDGE_ENCODERS[cfg.edge_encoder]

@@ -133,6 +133,11 @@ typedef struct agdiff_params {
   const float* schnet_emb;   /* [100][128] encoder_global.embedding (max_norm renorm applied to used rows) */
   const float* gin_emb;      /* [100][128] encoder_local.node_emb */
   const int32_t* poly_type_slot; /* [100] or null: slot of an edge type in filt_poly_typed_pk, -1 = none */
+  const float* dist_union;   /* [512 + 385 * 2 * 2 num_convs] or null: the DistanceWeightingNetworks of all CFConvs (conv[k].dist_seg)
+                                over their COMMON segments: [0..511] the union of their kinks ascending (+inf padded; at most 384),
+                                then for union segment u = number of those kinks <= d and scale cc = 2 k + (0: conv1, 1: conv2)
+                                the line (alpha, beta) at [512 + (u * 2 num_convs + cc) * 2]: the same floats dist_seg selects
+                                for that d, found with ONE search instead of one per conv (agdiff_sampler_front) */
   const float* attr_poly_typed_pk; /* [poly_num_slots] x pk [8][1] or null: edge_attr itself (128 features) of a local edge of a
                                 slotted type as a polynomial in d on [0, cutoff] (agdiff_local_edge_rows) */
   agdiff_conv_params_t conv[AGDIFF_MAX_CONVS];

@@ -393,3 +393,35 @@ def test_distance_weighting_segments():
                                      sd[p + ".layer2.weight"].double(), sd[p + ".layer2.bias"].double())[:, 0].numpy()
     s = (seg[None, :32] <= d.numpy()[:, None]).sum(1)
     assert np.abs(seg[32:65][s] * d.numpy() + seg[65:98][s] - ref).max() < 1e-12
+
+
+def test_dist_union_table_selects_the_lines_of_the_per_conv_tables():
+    """agdiff_params_t.dist_union (packing.dist_union_table): for any length d the union segment u = number of union kinks
+    <= d carries, for every conv, exactly the (alpha, beta) floats that conv's own table (dist_segments: s = number of its
+    kinks <= d) selects -- so the fused front's ONE search gives bit-identical scales."""
+    from agdiff_amd.packing import dist_segments, dist_union_table
+    rng = np.random.default_rng(3)
+    segs = []
+    for k in range(6):
+        two = []
+        for h in range(2):
+            w1 = rng.normal(size=32)
+            w1[rng.integers(0, 32, 3)] = 0.0                      # (units without a kink)
+            b1 = rng.normal(size=32) * 3.0
+            if k == 2:
+                b1[:4] = -w1[:4] * 2.5                             # (coinciding kinks, also across convs below)
+            two.append(dist_segments(w1, b1, rng.normal(size=32), float(rng.normal())))
+        segs.append(np.concatenate(two))
+    segs[3][:32] = segs[2][:32]                                    # conv1 of block 3 shares every kink with block 2's
+    tab = dist_union_table(segs)
+    n = 12
+    assert tab.shape[0] == 512 + 385 * 2 * n and np.all(np.diff(tab[:512][np.isfinite(tab[:512])]) > 0)
+    rows = [np.asarray(segs[k], np.float64).astype(np.float32).reshape(2, 100)[h] for k in range(6) for h in (0, 1)]
+    kinks = tab[:512]
+    ds = np.concatenate([rng.uniform(-1.0, 12.0, 4000).astype(np.float32), kinks[np.isfinite(kinks)],
+                         np.nextafter(kinks[np.isfinite(kinks)], np.float32(-np.inf))])
+    for d in ds:
+        u = int(np.count_nonzero(kinks <= d))
+        for cc, r in enumerate(rows):
+            s_ = int(np.count_nonzero(r[:32] <= d))
+            assert tab[512 + (u * n + cc) * 2] == r[32 + s_] and tab[512 + (u * n + cc) * 2 + 1] == r[65 + s_], (d, cc)
