@@ -373,8 +373,6 @@ def main():
         for bidx, bm in enumerate(batches):
             if bidx % every:
                 continue
-            if not strong and (bidx // every) % world != rank:
-                continue
             b = driver.pack_batch(bm, confs_of)
             if strong:
                 b, _, _ = shard_of(b, rank, world)
@@ -406,7 +404,9 @@ def main():
         return float(tt.item()), (G_all_if_strong if strong else int(gt.item()))
 
     if d200:
-        mols200, confs_of = drugs200_job(args.seed)
+        # weak scaling (default): every rank samples its OWN 200-molecule job (per-GPU work fixed, no data-path collective);
+        # strong: ONE job, every packed batch cut into per-rank graph ranges with the per-step all-gather
+        mols200, confs_of = drugs200_job(args.seed + (0 if strong else 1000 * rank))
         batches = driver.plan_batches(mols200, confs_of, args.max_atoms * (world if strong else 1))
         G_job = sum(confs_of(m["num_refs"]) for m in mols200)
         tot_ms, G_local, per_batch, global_frac, run, (prof_ms, prof_n, prof_flop, prof_edges) = run_job(
@@ -419,7 +419,7 @@ def main():
               "%d warm-up + %d timed steps per batch, %s schedule, global branch active on %.0f%% of timed steps; "
               "ms_per_step = one step of every batch"
               % (G_job, len(batches), args.max_atoms * (world if strong else 1),
-                 " cut into per-rank graph ranges" if strong else "", len(per_batch), sum(r["atoms"] for r in per_batch),
+                 " cut into per-rank graph ranges" if strong else (" -- one such job per rank" if world > 1 else ""), len(per_batch), sum(r["atoms"] for r in per_batch),
                  sum(r["edges"] for r in per_batch), W, K, args.schedule, 100 * global_frac))
     else:
         copies = args.copies if kind != "large" else 1
