@@ -88,6 +88,9 @@ class BatchTopology:
         has_m = (mpos < L) & (uniq[mpos_c] == mkey) & (typ[mpos_c] == typ) if L else np.zeros(0, dtype=bool)
         canon = ~has_m | (src < dst)
         lc_pos = np.nonzero(canon)[0]
+        # ... in order of (molecule, type, source): a 16-entry tile of the list then mostly holds ONE type (agdiff_local_edge_rows
+        # runs one masked MFMA round per type present in a tile), and a molecule's entries stay contiguous (lcm_ptr)
+        lc_pos = lc_pos[np.lexsort((src[lc_pos], typ[lc_pos], ba[src[lc_pos]]))]
         lc_mir = np.where(has_m[lc_pos], mpos_c[lc_pos], -1)
         loc_row = np.full(L, -1, dtype=np.int64)          # canonical index (row of l_attr_rows) of every local edge
         loc_row[lc_pos] = np.arange(lc_pos.shape[0])

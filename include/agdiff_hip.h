@@ -254,7 +254,7 @@ typedef struct agdiff_topo {
                                 quad_tgt[4 p + GT ..] are -1 */
   const int32_t* quad_tgt;   /* [4 Q] */
   const int32_t* lcm_ptr;    /* [G+1]: the canonical local edges lc_*[lcm_ptr[g] .. lcm_ptr[g+1]) belong to molecule g (the list is
-                                sorted by source) */
+                                sorted by molecule, then edge type, then source) */
   int64_t local_type_mask[2];/* bit t of the 128-bit mask: the batch has a local edge of type t */
   int64_t num_local_tiles;   /* T = lt_ptr[Q] */
   const int32_t* lt_ptr;     /* [Q + 1]: tiles of quad p are [lt_ptr[p], lt_ptr[p+1]) */
