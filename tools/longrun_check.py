@@ -26,3 +26,23 @@ for kind, cfgf in (("drugs", drugs_model_config), ("qm9", qm9_model_config)):
     ws = m._batch_cache[2]
     print(kind, "400 steps over the whole schedule: finite", bool(torch.isfinite(outs[0][0]).all()), "bitwise reproducible", same,
           "flagged local tiles at the end", int(ws.enc_flags[0].item()), "radius edges", int(ws.rad_cnt.sum().item()))
+
+# a COMPLETE 5000-step job at the reference's schedule (scripts/test.py defaults), twice: finite, bitwise reproducible, centred
+cfg = drugs_model_config()
+m = get_model(cfg); m.load_state_dict(synth.synth_state_dict(m.state_dict())); m = m.cuda().eval()
+b = synth.make_packed_batch("drugs", 8, 16, seed=99)
+T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+at, bi, bt, ba = T(b["atom_type"]), T(b["bond_index"]), T(b["bond_type"]), T(b["batch"])
+pos_init = torch.randn(at.shape[0], 3, generator=torch.Generator().manual_seed(7)).cuda()
+res = []
+for rep in range(2):
+    torch.manual_seed(123)
+    p, _ = m.langevin_dynamics_sample_diffusion(at, pos_init, bi, bt, ba, b["num_graphs"], False, n_steps=cfg.num_diffusion_timesteps,
+                                                step_lr=1e-6, clip=1000.0, global_start_sigma=0.5, w_global=1.0, save_traj=False)
+    res.append(p.clone())
+com = torch.zeros(b["num_graphs"], 3, device="cuda").index_add_(0, ba, res[0]) / torch.bincount(ba).unsqueeze(1)
+# (the synthetic checkpoint has no restoring force: at the top of the reference schedule the random scores drive the atoms far
+# apart -- the centre of mass is judged against the size of the positions)
+print("full %d-step job, %d atoms: finite %s, bitwise reproducible %s, max |pos| %.2e, max |centre of mass| / max |pos| %.2e"
+      % (cfg.num_diffusion_timesteps, at.shape[0], bool(torch.isfinite(res[0]).all()), torch.equal(res[0], res[1]),
+         float(res[0].abs().max()), float(com.abs().max() / res[0].abs().max())))
