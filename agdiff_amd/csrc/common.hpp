@@ -318,6 +318,13 @@ __device__ __forceinline__ void ag_dense_lds(const AgIn<MODE> (&x)[NX], f32x4 (&
       for (int g = 0; g < G; ++g) {
         const int ot = og * G + g;
         const int s = KOUTER ? t * OT + ot : ot * KT + t;
+#ifdef AG_DENSE_LDS_HALF      // (timing experiment: every second weight block read from LDS, the others reused -- wrong results)
+        if (g & 1) {
+          w[g][0] = w[g - 1][0];
+          w[g][1] = w[g - 1][1];
+          continue;
+        }
+#endif
         w[g][0] = wl[(s * 2) * 64 + lane];
         w[g][1] = wl[(s * 2 + 1) * 64 + lane];
       }
