@@ -76,6 +76,13 @@ if args.only:
     print(json.dumps(out))
     sys.exit(0)
 out["node_x%d_ms" % nc] = timeit(lambda: [lib.agdiff_cfconv_node(P, Tp, Wp, k, st) for k in range(nc)])
+# all tiles / radius tiles only, interleaved (the first timing of a process runs on a colder chip)
+ab = {"all": [], "radius_only": []}
+for _ in range(3):
+    for lp in (0, 1):
+        pk.set_tuning(local_poly_off=lp)
+        ab["radius_only" if lp else "all"].append(round(timeit(lambda: [lib.agdiff_cfconv_node(P, Tp, Wp, k, st) for k in range(nc)]), 4))
+out["interleaved_x%d_ms" % nc] = ab
 pk.set_tuning(local_poly_off=1)
 out["node_radius_only_x%d_ms" % nc] = timeit(lambda: [lib.agdiff_cfconv_node(P, Tp, Wp, k, st) for k in range(nc)])
 pk.set_tuning(local_poly_off=0, poly_lds_sets=1)
