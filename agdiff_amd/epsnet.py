@@ -210,10 +210,11 @@ class DualEncoderEpsNetwork(nn.Module):
             raise NotImplementedError("model type %r: only 'diffusion' is on the HIP path" % (self.model_type,))
         # arithmetic of the HIP kernels: "f32" = exact fp32 MFMA; "bf16x3" = split-bf16 MFMA (hi+lo operands,
         # three passes, fp32 accumulation, ~2^-16 relative per product).  Both meet the 1e-4 parity bar.
-        self.precision = getattr(config, "precision", None) or os.environ.get("AGDIFF_PRECISION", "bf16x3")
+        # (config field or attribute; nothing is read from the environment)
+        self.precision = getattr(config, "precision", None) or "bf16x3"
         # "auto": radius edges take their CFConv filters / head inputs from d-polynomials when packing.py accepts the
         # fit for these weights (<= 1e-6 of the networks they replace), "off": every edge through the MLPs
-        self.radius_poly = getattr(config, "radius_poly", None) or os.environ.get("AGDIFF_RADIUS_POLY", "auto")
+        self.radius_poly = getattr(config, "radius_poly", None) or "auto"
         # kernel-variant thresholds (PackedParams.set_tuning; include/agdiff_hip.h: agdiff_params_t.tune_*), e.g.
         # model.tuning["node_ldsw_min_tiles"] = 1 -- tests reach every variant on small fixtures this way
         self.tuning = {}
@@ -439,10 +440,12 @@ class DualEncoderEpsNetwork(nn.Module):
           on_step          callback(k, i, pos) after each step is enqueued (data-parallel gather)
           raise_on_nan     False -> never raise FloatingPointError; the caller reads LangevinRun.nan_graphs()
                            (graphs are independent, so the others' results stay valid: agdiff_amd/driver.py)
-        Random draws: without `noise`, standard normals come from torch.randn on the module's device generator in
-        chunks of 128 steps ([128, N, 3] per call) instead of one torch.randn_like(pos) per step (dualenc.py:529);
-        same distribution, but a different consumption of the Philox stream -- runs with equal seeds are not
-        sample-for-sample comparable with the reference (parity tests inject `noise` on both sides).
+          noise_mode       "chunked" (default): without `noise`, standard normals come from torch.randn on the module's
+                           device generator in chunks of 128 steps ([128, N, 3] per call) -- same distribution as the
+                           reference's draws but another consumption of the Philox stream;
+                           "per_step": one torch.randn_like(pos) per step, exactly the reference's call (dualenc.py:529):
+                           with equal seeds and equal generator state the SAME normals as the reference draws on this
+                           device, hence seed-for-seed comparable runs (one small launch more per step)
         """
         run = self.begin_sampling(atom_type, pos_init, bond_index, bond_type, batch, num_graphs, extend_order,
                                   extend_radius, n_steps, step_lr, clip, clip_local, clip_pos, global_start_sigma,
@@ -467,7 +470,7 @@ class LangevinRun:
     def __init__(self, model, atom_type, pos_init, bond_index, bond_type, batch, num_graphs, extend_order,
                  n_steps, step_lr, clip, clip_local, clip_pos, global_start_sigma, w_global, noise=None,
                  save_traj=True, skip_discarded_global=True, nan_check_every=64, step_indices=None, on_step=None,
-                 extend_radius=True, raise_on_nan=True, **_ignored):
+                 extend_radius=True, raise_on_nan=True, noise_mode="chunked", **_ignored):
         self.model, self.lib = model, _lib.load()
         dev = model._device()
         self.sigmas = ((1.0 - model.alphas).sqrt() / model.alphas.sqrt()).detach().cpu()
@@ -487,6 +490,9 @@ class LangevinRun:
         self.step_lr, self.global_start_sigma = step_lr, global_start_sigma
         self.skip_discarded, self.nan_every = bool(skip_discarded_global), int(nan_check_every)
         self.raise_on_nan = bool(raise_on_nan)
+        if noise_mode not in ("chunked", "per_step"):
+            raise ValueError("noise_mode must be 'chunked' or 'per_step'")
+        self.noise_mode = noise_mode
         self.k = 0
         self.ws.nan_flag.zero_()
         self._quarantine_non_finite_input()
@@ -531,6 +537,8 @@ class LangevinRun:
     def _noise_for(self, k, dev, N):
         if self.noise is not None:
             return self.noise[k].to(dev, torch.float32).contiguous()
+        if self.noise_mode == "per_step":          # dualenc.py:529: noise = torch.randn_like(pos), one draw per step
+            return torch.randn_like(self.pos)
         chunk = 128
         if self._nz is None or k >= self._nz_base + self._nz.shape[0]:
             self._nz = torch.randn((min(chunk, len(self.steps) - k), N, 3), dtype=torch.float32, device=dev)

@@ -44,7 +44,7 @@ FLOP_PER_EDGE_CFCONV = 2 * (128 * 192 + 128 * 128 + 64 * 64)     # filter MLP of
 PEAK = {"f32": 157.3, "bf16x3": 2500.0}      # dense MFMA TFLOP/s (f32-input MFMA; bf16 MFMA), MI355X_MICROARCH.md
 HBM_PEAK_GBPS = 8000.0
 MFMA_PASSES = {"f32": 1, "bf16x3": 3}        # MFMA FLOPs issued per algorithmic FLOP
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 
 def build_batch(kind, mols, copies, seed):
@@ -188,7 +188,7 @@ def cpu_baseline(kind, schedule, seed):
 
 
 # ------------------------------------------------------------------------------------------ timed GPU runs
-def timed_run(model, dev, b, cfg, W, K, schedule, skip, save_traj, seed, rank, use_dist, profile=False):
+def timed_run(model, dev, b, cfg, W, K, schedule, skip, save_traj, seed, rank, use_dist, profile=False, nan_every=64):
     """W untimed + K timed denoising steps of one packed batch; returns (seconds, run, global-branch share, gather,
     (cfconv ms summed over the timed region's bracketed launches, launches) or None)."""
     import torch
@@ -201,8 +201,18 @@ def timed_run(model, dev, b, cfg, W, K, schedule, skip, save_traj, seed, rank, u
     pos_init = torch.randn(at.shape[0], 3, generator=g).to(dev)
     Tn = cfg.num_diffusion_timesteps
     if schedule == "default" and W + K < Tn:
-        # visit the whole schedule evenly so that the share of global-active steps is the job's
-        idx = np.linspace(Tn - 1, 0, W + K).round().astype(int).tolist()
+        # visit the whole schedule so that the share of global-active steps (sigma < global_start_sigma = 0.5: 2012 of the
+        # reference's 5000 steps) is the JOB's among the K timed steps: the two ranges are sampled evenly, each with its share
+        sig = ((1.0 - model.alphas).sqrt() / model.alphas.sqrt()).detach().cpu().numpy()
+        act = np.nonzero(sig < 0.5)[0]
+        ina = np.nonzero(sig >= 0.5)[0]
+        pick = lambda pool, m: pool[np.linspace(0, pool.size - 1, m).round().astype(int)] if (m > 0 and pool.size) else pool[:0]
+        ka = int(round(K * act.size / float(Tn)))
+        ka = min(max(ka, 1 if act.size else 0), K - (1 if ina.size else 0))
+        wa = int(round(W * act.size / float(Tn)))
+        timed = np.sort(np.concatenate([pick(act, ka), pick(ina, K - ka)]))[::-1]
+        warm = np.sort(np.concatenate([pick(act, wa), pick(ina, W - wa)]))[::-1]
+        idx = warm.tolist() + timed.tolist()
     else:
         idx = list(reversed(range(Tn - (W + K), Tn)))
     gather = None
@@ -211,7 +221,7 @@ def timed_run(model, dev, b, cfg, W, K, schedule, skip, save_traj, seed, rank, u
         gather = StepAllGather(at.shape[0], dev)
     run = model.begin_sampling(at, pos_init, bi, bt, ba, b["num_graphs"], False, n_steps=W + K, step_lr=1e-6,
                                clip=1000.0, global_start_sigma=0.5, w_global=1.0, step_indices=idx,
-                               save_traj=save_traj, skip_discarded_global=skip, nan_check_every=10 ** 9)
+                               save_traj=save_traj, skip_discarded_global=skip, nan_check_every=nan_every)
     if gather is not None:
         run.on_step = lambda k, i, pos: gather(k, i, pos, run.ws.nan_flag)
     run.advance(W)
@@ -240,6 +250,59 @@ def timed_run(model, dev, b, cfg, W, K, schedule, skip, save_traj, seed, rank, u
     return el, run, (run.global_steps - g0) / max(K, 1), gather, prof
 
 
+def run_job_steps(mdl, mcfg, batches, confs_of, schedule, sk, W_, K_, prof, *, dev, rank, world, seed, save_traj, use_dist, strong,
+                  every=1, gcalls=None, tile_acc=None, timed=None, edges_of=None, tiles_of=None):
+    """W_ + K_ denoising steps of every `every`-th packed batch of the job on this rank: (ms of one step summed over the batches,
+    conformers, records, global-branch share, last run, CFConv profile sums).  With `use_dist` the ranks' positions (+ NaN
+    flag) are all-gathered after EVERY step of every batch -- north_star's collective, weak and strong scaling alike (strong:
+    every batch is first cut into per-rank graph ranges); the number of collectives is asserted: one per step.
+    `timed` / `edges_of` / `tiles_of`: stand-ins for timed_run / live_edges / tile_stats (tests/test_dist_cpu.py runs this
+    function with a CPU sampler stub over gloo)."""
+    import torch
+    from agdiff_amd import driver
+    from agdiff_amd.dist import shard_of
+    timed = timed or timed_run
+    edges_of = edges_of or live_edges
+    tiles_of = tiles_of or tile_stats
+    gcalls = gcalls if gcalls is not None else [0]
+    tile_acc = tile_acc if tile_acc is not None else {}
+    tot_ms, G_local, recs, gl, last = 0.0, 0, [], 0.0, None
+    pm = pn = pf = pe = 0.0
+    for bidx, bm in enumerate(batches):
+        if bidx % every:
+            continue
+        b = driver.pack_batch(bm, confs_of)
+        if strong:
+            b, _, _ = shard_of(b, rank, world)
+        last = None
+        el, run, gfrac, gather, pr = timed(mdl, dev, b, mcfg, W_, K_, schedule, sk, save_traj, seed + bidx, rank, use_dist,
+                                           profile=prof)
+        run.check_nan()
+        if use_dist:
+            assert gather is not None and gather.calls == W_ + K_, "one all-gather per denoising step"
+            gcalls[0] += gather.calls
+            parts, any_nan = gather.result()
+            assert len(parts) == world and torch.equal(parts[rank], run.pos) and not any_nan
+        ms = el / K_ * 1e3
+        tot_ms += ms
+        G_local += b["num_graphs"]
+        E_b = edges_of(run)
+        gl += gfrac
+        if pr is not None and pr[1] > 0:
+            pm, pn = pm + pr[0], pn + pr[1]
+            pf += float(E_b) * FLOP_PER_EDGE_CFCONV * pr[1]
+            pe += float(E_b) * pr[1]
+            ts = tiles_of(run)
+            if ts:
+                for kk, vv in ts.items():
+                    tile_acc[kk] = tile_acc.get(kk, 0.0) + vv * pr[1]
+                tile_acc["launches"] = tile_acc.get("launches", 0.0) + pr[1]
+        recs.append({"molecules": len(bm), "conformers": int(b["num_graphs"]), "atoms": run.topo.N,
+                     "edges": E_b, "ms_per_step": ms})
+        last = run
+    return tot_ms, G_local, recs, gl / max(len(recs), 1), last, (pm, pn, pf, pe)
+
+
 def drugs200_job(seed):
     """configs[2]: 200 molecules, G = 2 x U{50..500} conformers each (utils/datasets.py:720-721,763; scripts/test.py:135-141)."""
     from agdiff_amd import driver, synth
@@ -259,6 +322,17 @@ def live_edges(run):
     if run._fused_front():
         return int(run.ws.rad_cnt.sum().item()) + run.topo.L
     return int(run.ws.num_edges.item())
+
+
+def tile_stats(run):
+    """16-row tiles one k_cfconv_node launch walks on the run's current graph: radius tiles (every target's rows padded to
+    whole tiles) and local quad tiles, live rows and executed rows."""
+    if not run._fused_front():
+        return None
+    cnt = run.ws.rad_cnt.to("cpu").numpy().astype(np.int64)
+    rt = int(((cnt + 15) // 16).sum())
+    R, L, T = int(cnt.sum()), int(run.topo.L), int(run.topo.T)
+    return {"radius_tiles": rt, "local_tiles": T, "radius_rows_live": R, "local_rows_live": L}
 
 
 def load_pmc(precision, edges, kernels):
@@ -290,6 +364,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the runs reported under `extra`")
     ap.add_argument("--no-traj", action="store_true")
+    ap.add_argument("--no-full-job", action="store_true", help="skip extra.full_job (one complete 5000-step job, ~40 s)")
+    ap.add_argument("--no-gather-extra", action="store_true", help="skip extra.all_gather_world1")
+    ap.add_argument("--no-qm9-extra", action="store_true", help="skip extra.configs1_qm9")
     ap.add_argument("--no-profile", action="store_true", help="no event pairs around the CFConv launches of the timed region")
     ap.add_argument("--breakdown", default=None, help="write per-op timings (ms) to this JSON file")
     ap.add_argument("--seed", type=int, default=2021)
@@ -299,6 +376,8 @@ def main():
     ap.add_argument("--front", default="fused", choices=["fused", "split", "unfused"],
                     help="serial front of a step: one launch (update + local edges + radius graph), the same with the graph "
                          "phase launched after the local branch's fork, or the unfused kernels (A/B runs)")
+    ap.add_argument("--serial", action="store_true", help="local and global branch on ONE stream (tune_serial_branches): per-kernel "
+                    "stand-alone times under rocprofv3")
     ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL all-gather path even with one rank")
     ap.add_argument("--job-steps", type=int, default=JOB_STEPS, help="denoising steps of one sampling job (5000; the "
                     "alanine dipeptide example runs 100)")
@@ -355,6 +434,8 @@ def main():
         m.precision = args.precision
         m.radius_poly = radius_poly or args.radius_poly
         m.fused_front, m.front_split_graph = args.front != "unfused", args.front == "split"
+        if args.serial:
+            m.tuning["serial_branches"] = 1
         m.load_state_dict(synth.synth_state_dict(m.state_dict()))
         return m.to(dev).eval(), cfg
     model, cfg = make_model(args.schedule)
@@ -366,33 +447,13 @@ def main():
     per_batch = None
     strong = args.scaling == "strong"
 
-    def run_job(mdl, mcfg, batches, confs_of, schedule, sk, W_, K_, prof, every=1):
-        """One step of every `every`-th batch of the job on this rank: (ms summed, conformers, records, last run, prof sums)."""
-        tot_ms, G_local, recs, gl, last = 0.0, 0, [], 0.0, None
-        pm = pn = pf = pe = 0.0
-        for bidx, bm in enumerate(batches):
-            if bidx % every:
-                continue
-            b = driver.pack_batch(bm, confs_of)
-            if strong:
-                b, _, _ = shard_of(b, rank, world)
-            last = None
-            el, run, gfrac, gather, pr = timed_run(mdl, dev, b, mcfg, W_, K_, schedule, sk, save_traj, args.seed + bidx,
-                                                   rank, use_dist and strong, profile=prof)
-            run.check_nan()
-            ms = el / K_ * 1e3
-            tot_ms += ms
-            G_local += b["num_graphs"]
-            E_b = live_edges(run)
-            gl += gfrac
-            if pr is not None and pr[1] > 0:
-                pm, pn = pm + pr[0], pn + pr[1]
-                pf += float(E_b) * FLOP_PER_EDGE_CFCONV * pr[1]
-                pe += float(E_b) * pr[1]
-            recs.append({"molecules": len(bm), "conformers": int(b["num_graphs"]), "atoms": run.topo.N,
-                         "edges": E_b, "ms_per_step": ms})
-            last = run
-        return tot_ms, G_local, recs, gl / max(len(recs), 1), last, (pm, pn, pf, pe)
+    gcalls = [0]          # all-gathers this rank issued in run_job (one per step per batch)
+    tile_acc = {}         # tile statistics of the profiled CFConv launches (weighted by launches)
+
+    def run_job(mdl, mcfg, batches, confs_of, schedule, sk, W_, K_, prof, every=1, dist_here=True):
+        return run_job_steps(mdl, mcfg, batches, confs_of, schedule, sk, W_, K_, prof, every=every, dev=dev, rank=rank, world=world,
+                             seed=args.seed, save_traj=save_traj, use_dist=use_dist and dist_here, strong=strong, gcalls=gcalls,
+                             tile_acc=tile_acc)
 
     def reduce_job(tot_ms, G_local, G_all_if_strong):
         tt = torch.tensor([tot_ms], dtype=torch.float64, device=dev)
@@ -404,9 +465,12 @@ def main():
         return float(tt.item()), (G_all_if_strong if strong else int(gt.item()))
 
     if d200:
-        # weak scaling (default): every rank samples its OWN 200-molecule job (per-GPU work fixed, no data-path collective);
-        # strong: ONE job, every packed batch cut into per-rank graph ranges with the per-step all-gather
-        mols200, confs_of = drugs200_job(args.seed + (0 if strong else 1000 * rank))
+        # weak scaling (default): every rank samples its OWN copy of the 200-molecule job (per-GPU work fixed); strong: ONE
+        # job, every packed batch cut into per-rank graph ranges.  Either way the ranks' positions are all-gathered over RCCL
+        # after every denoising step (north_star), on a side stream
+        # (weak: every rank takes the SAME 200 molecules -- the number of batches, hence of collectives, must agree over the
+        # ranks -- with its own initial positions and noise: seed + rank in timed_run)
+        mols200, confs_of = drugs200_job(args.seed)
         batches = driver.plan_batches(mols200, confs_of, args.max_atoms * (world if strong else 1))
         G_job = sum(confs_of(m["num_refs"]) for m in mols200)
         tot_ms, G_local, per_batch, global_frac, run, (prof_ms, prof_n, prof_flop, prof_edges) = run_job(
@@ -437,6 +501,10 @@ def main():
         if pr is not None and pr[1] > 0:
             E_b = live_edges(run)
             prof_ms, prof_n, prof_flop, prof_edges = pr[0], pr[1], float(E_b) * FLOP_PER_EDGE_CFCONV * pr[1], float(E_b) * pr[1]
+            ts = tile_stats(run)
+            if ts:
+                tile_acc.update({kk: vv * pr[1] for kk, vv in ts.items()})
+                tile_acc["launches"] = pr[1]
         if use_dist:
             tt = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -473,43 +541,82 @@ def main():
     P_, T_, W_ = ctypes.byref(pk.struct), ctypes.byref(topo.struct), ctypes.byref(ws.struct)
     node_path = pk.poly_kt > 0
     local_poly = bool(node_path and lib.agdiff_local_poly_enabled(P_, T_, W_))
+    pads_info = None
+    if tile_acc.get("launches"):
+        nl = tile_acc["launches"]
+        rt, lt_ = tile_acc["radius_tiles"] / nl, tile_acc["local_tiles"] / nl
+        rl, ll = tile_acc["radius_rows_live"] / nl, tile_acc["local_rows_live"] / nl
+        lt_used = lt_ if local_poly else 0.0
+        pads_info = {"tiles_per_launch": rt + lt_used, "radius_tiles": rt, "local_tiles": lt_used,
+                     "rows_live": rl + (ll if local_poly else 0.0), "rows_executed": 16.0 * (rt + lt_used),
+                     "radius_pad_frac": 1.0 - rl / max(16.0 * rt, 1.0),
+                     "local_pad_frac": (1.0 - ll / max(16.0 * lt_, 1.0)) if local_poly else None}
     if rank == 0 and prof_n > 0:
         avg_ms = prof_ms / prof_n
-        ach = prof_flop / (prof_ms * 1e-3) / 1e12
+        t_s = prof_ms * 1e-3
+        ref_priced = prof_flop / t_s / 1e12          # the REFERENCE's arithmetic for this op over the measured time
         pk_ = PEAK[args.precision]
         e_avg = prof_edges / prof_n
         kern = ["k_cfconv_node"] if (node_path and local_poly) else (["k_cfconv_node", "k_cfconv_fused"] if node_path else ["k_cfconv_fused"])
         pmc = load_pmc(args.precision, e_avg, kern)
+        passes = MFMA_PASSES[args.precision]
+        n_avg = e_avg / max(E, 1) * topo.N
+        # HBM bytes one launch has to move at least: per edge src + length + 2 scales (16 B), xs read once, one aggregate row
+        # written per node (the node kernel; the MLP kernel also streams 512 B of edge_attr per edge)
+        alg_bytes = e_avg * (16 if node_path else 528) + n_avg * 192 * 4 * 2
         if node_path:
+            # What the kernel EXECUTES: per 16-row tile 12 channel tiles x poly_kt k-tiles x `passes` MFMAs of
+            # 16x16x32 (16,384 FLOP each).  `achieved` = the MFMA FLOPs the ALGORITHM needs in this arithmetic mode (live rows
+            # only: E x 192 channels x 32 poly_kt terms x 2 x passes) over the in-step launch time; the pad rows that complete a
+            # target's / a type's last tile are executed too and reported beside it, as is the reference-priced figure of rounds 1-3.
+            tiles = pads_info["tiles_per_launch"] if pads_info else None
+            issued = prof_edges * 192 * 32 * pk.poly_kt * 2 * passes / t_s / 1e12
+            executed = issued * (pads_info["rows_executed"] / max(pads_info["rows_live"], 1) if pads_info else 1.0)
             kernel = ("k_cfconv_node<NKT=%d> (one launch per InteractionBlock: radius rows by target%s)"
                       % (pk.poly_kt, " + local quad tiles, %d local types" % pk.struct.poly_num_slots if local_poly
                          else "; local edges through k_cfconv_fused on the padded local list, second launch"))
-            issued = prof_edges * 192 * 32 * pk.poly_kt * 2 * MFMA_PASSES[args.precision] / (prof_ms * 1e-3) / 1e12
-            note = ("achieved = the REFERENCE's arithmetic for this op -- it evaluates the 128->192->192 filter network on every "
-                    "directed edge: E x 90,112 FLOP per block (SURVEY 8d) -- over the in-step launch time (event pairs around "
-                    "every CFConv launch of the timed region; profiles/%s_*kernel_stats.csv holds rocprofv3's figure for the "
-                    "same command).  The kernel itself evaluates each edge's filter as a 32-term polynomial in its length "
-                    "(fitted to the networks in float64 at load time, accepted at <= 1e-6; DESIGN.md 4a): mfma_issued_frac is "
-                    "what the matrix pipe really does, hbm_frac the algorithmic bytes against 8 TB/s; the kernel is bound by "
-                    "VALU issue + x[src] gathers through L1 (DESIGN.md 4b)" % PROFILE_ROUND)
+            # issue-slot model of one SIMD: an MFMA holds the issue port 8 cycles, any other VALU instruction 4 (wave64 on 16
+            # lanes); VALU / tile from the SQ counter pass when one was taken on this workload
+            cnts = pmc["kernels"][kern[0]].get("counters", {}) if pmc else {}
+            model = None
+            if cnts.get("SQ_INSTS_VALU") and cnts.get("SQ_INSTS_MFMA") and tiles:
+                n_mfma, n_other = cnts["SQ_INSTS_MFMA"], cnts["SQ_INSTS_VALU"] - cnts["SQ_INSTS_MFMA"]
+                cyc = 8.0 * n_mfma + 4.0 * n_other
+                model = {"mfma_per_tile": n_mfma / tiles, "other_valu_per_tile": n_other / tiles,
+                         "issue_cycles_per_tile": cyc / tiles, "simds": 1024, "clock_ghz_assumed": 2.4,
+                         "issue_slot_frac": cyc / (1024 * 2.4e9 * avg_ms * 1e-3),
+                         "source": "SQ_INSTS_VALU / SQ_INSTS_MFMA of profiles/%s_%s_pmc.json (separate counter passes of this command)" % (PROFILE_ROUND, args.precision)}
+            note = ("frac = MFMA FLOPs the kernel's algorithm needs (a 32-term d-polynomial per filter channel and live row, "
+                    "split-bf16 = 3 MFMA passes; fitted to the reference's encoder + filter networks in float64 at load time, "
+                    "accepted at <= 1e-6, DESIGN.md 4a) over the in-step launch time (HIP event pairs around every CFConv launch "
+                    "of the timed region on its own stream; profiles/%s_*kernel_stats.csv holds rocprofv3's figure for the same "
+                    "command) against the dense bf16 MFMA peak.  executed_mfma_frac adds the pad rows.  reference_priced_* is the "
+                    "figure rounds 1-3 reported as frac: the REFERENCE's arithmetic for this op (it evaluates the 128->192->192 "
+                    "filter network on every directed edge: E x 90,112 FLOP per block, SURVEY 8d) over the same time -- work this "
+                    "kernel does not execute.  The kernel is a balanced wave program (VALU issue ~50 %%, matrix pipe ~28 %%, "
+                    "L1 gathers, LDS coefficient reads; DESIGN.md 4b): issue_model prices its instruction stream" % PROFILE_ROUND)
+            ach = issued
         else:
             kernel = "k_cfconv_fused"
-            issued = ach * MFMA_PASSES[args.precision]
-            note = ("achieved = algorithmic FLOPs (E x 90,112: the reference evaluates the filter network on every "
-                    "directed edge) / in-step launch time; bf16x3 issues 3 bf16 MFMA FLOPs per algorithmic FLOP (hi.hi + "
-                    "lo.hi + hi.lo), fp32 accumulate")
-        # HBM bytes one launch has to move at least: per edge src + length + 2 scales (16 B), xs read once, one aggregate row
-        # written per node (the node kernel; the MLP kernel also streams 512 B of edge_attr per edge)
-        n_avg = e_avg / max(E, 1) * topo.N
-        alg_bytes = e_avg * (16 if node_path else 528) + n_avg * 192 * 4 * 2
+            issued = ref_priced * passes
+            executed = issued
+            model = None
+            ach = issued
+            note = ("achieved = MFMA FLOPs issued: algorithmic FLOPs (E x 90,112: the reference evaluates the filter network on "
+                    "every directed edge) x 3 bf16 passes (hi.hi + lo.hi + hi.lo; 1 in f32 mode), fp32 accumulate, over the "
+                    "in-step launch time")
         roof = {"kernel": kernel, "bound": "mfma", "achieved": ach, "peak": pk_, "unit": "TFLOP/s", "frac": ach / pk_,
                 "traffic": pmc["kernels"][kern[0]]["hbm_bytes_per_launch"] if pmc else None,
                 "avg_launch_ms": avg_ms, "launches_timed": int(prof_n), "edges_per_launch": e_avg,
-                "mfma_issued_tflops": issued, "mfma_issued_frac": issued / pk_,
+                "executed_mfma_tflops": executed, "executed_mfma_frac": executed / pk_,
+                "useful_fp32_equivalent_tflops": issued / passes,
+                "reference_priced_tflops": ref_priced, "reference_priced_frac": ref_priced / pk_,
                 "hbm_frac": alg_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": alg_bytes,
                 "traffic_over_algorithmic": (pmc["kernels"][kern[0]]["hbm_bytes_per_launch"] / alg_bytes) if pmc else None,
+                "hbm_frac_by_counters": (pmc["kernels"][kern[0]]["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if pmc else None,
                 "valu_issue_busy": pmc["kernels"][kern[0]].get("valu_issue_busy") if pmc else None,
-                "valu_per_tile": pmc["kernels"][kern[0]].get("valu_per_tile") if pmc else None,
+                "mfma_pipe_busy": pmc["kernels"][kern[0]].get("mfma_pipe_busy") if pmc else None,
+                "issue_model": model, "tiles": pads_info if node_path else None,
                 "note": note}
 
     # ---- stand-alone CFConv aggregate (PyG propagate x_j * W, schnet.py:156-162) on the last batch's graph: the HBM-bound
@@ -586,6 +693,76 @@ def main():
     # ---- `extra`: the reference's own schedule on the same job, with and without simplification (vii) (skipping
     # the global branch on steps whose result the sampler discards changes the work per step, not the outputs), and the
     # headline's fallback: the same saturated job with the filter polynomials off (every edge through the MLP kernels)
+    def full_job(mdl, mcfg, batches_, confs_of_):
+        """ONE complete sampling job, wall clock: the largest packed batch of the default job x all 5000 denoising steps at the
+        saturated schedule, trajectory kept on the device and copied to the host by finish() as the reference returns it
+        (dualenc.py:545-547), the driver's default NaN polling (every 64 steps) -- next to the 20-step extrapolation."""
+        bm = max(batches_, key=lambda bb: sum(len(m_["atom_type"]) * confs_of_(m_["num_refs"]) for m_ in bb))
+        b_ = driver.pack_batch(bm, confs_of_)
+        Tt = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+        at, bi, bt, ba = Tt(b_["atom_type"]), Tt(b_["bond_index"]), Tt(b_["bond_type"]), Tt(b_["batch"])
+        g_ = torch.Generator(device="cpu").manual_seed(args.seed + 77)
+        pos_init = torch.randn(at.shape[0], 3, generator=g_).to(dev)
+        kw = dict(n_steps=JOB_STEPS, step_lr=1e-6, clip=1000.0, global_start_sigma=0.5, w_global=1.0, save_traj=save_traj,
+                  skip_discarded_global=skip)
+        # short run of the same batch for the extrapolated figure (same code path as the headline)
+        el_s, r_s, _, _, _ = timed_run(mdl, dev, b_, mcfg, W, K, args.schedule, skip, save_traj, args.seed + 77, rank, False)
+        del r_s
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_ = mdl.begin_sampling(at, pos_init, bi, bt, ba, b_["num_graphs"], False, **kw)
+        run_.advance(run_.remaining())
+        torch.cuda.synchronize()
+        t_loop = time.perf_counter() - t0
+        pos_f, traj_f = run_.finish()          # trajectory D2H: n_steps x N x 12 B
+        t_all = time.perf_counter() - t0
+        finite = bool(torch.isfinite(pos_f).all().item())
+        rec = {"batch_atoms": int(at.shape[0]), "conformers": int(b_["num_graphs"]), "steps": JOB_STEPS,
+               "full_job_s": t_all, "denoising_loop_s": t_loop, "finish_trajectory_d2h_s": t_all - t_loop,
+               "trajectory_bytes": int(len(traj_f)) * int(at.shape[0]) * 12,
+               "extrapolated_s": el_s / K * JOB_STEPS, "ratio_full_over_extrapolated": t_all / (el_s / K * JOB_STEPS),
+               "conformers_per_s_full_job": b_["num_graphs"] / t_all, "nan_check_every": 64,
+               "positions_finite": finite, "max_abs_pos": float(pos_f.abs().max().item())}
+        del run_, traj_f
+        return rec
+
+    def qm9_extra():
+        """BASELINE configs[1] in the driver-run line: 200 QM9-shaped molecules x 2 * U{50..500} conformers, saturated
+        schedule, the driver's batch plan, 2 + 10 steps per batch on every 4th batch."""
+        rng = np.random.default_rng(args.seed + 9)
+        molsq = []
+        for i in range(200):
+            at_, r_, c_, t_ = synth.random_molecule(rng, synth.sample_n_atoms(rng, "qm9"))
+            molsq.append(dict(atom_type=at_, edge_index=np.stack([r_, c_]), edge_type=t_, num_refs=int(rng.integers(50, 501)),
+                              name="q%d" % i, index=i))
+        cq = driver.num_confs("2x")
+        bq = driver.plan_batches(molsq, cq, args.max_atoms)
+        cfgq = make_cfg("qm9", "saturated")
+        mq = get_model(cfgq)
+        mq.precision, mq.radius_poly = args.precision, args.radius_poly
+        mq.load_state_dict(synth.synth_state_dict(mq.state_dict()))
+        mq = mq.to(dev).eval()
+        tms, Gl, nb, pms, pn, pe = 0.0, 0, 0, 0.0, 0.0, 0.0
+        for bidx, bm in enumerate(bq):
+            if bidx % 4:
+                continue
+            b_ = driver.pack_batch(bm, cq)
+            el_, r_, _, _, pr = timed_run(mq, dev, b_, cfgq, 2, 10, "saturated", True, save_traj, args.seed + bidx, rank, False, profile=True)
+            r_.check_nan()
+            tms += el_ / 10 * 1e3
+            Gl += b_["num_graphs"]
+            nb += 1
+            if pr and pr[1] > 0:
+                pms, pn, pe = pms + pr[0], pn + pr[1], pe + float(live_edges(r_)) * pr[1]
+            del r_
+        G_all = sum(cq(m_["num_refs"]) for m_ in molsq)
+        passes = MFMA_PASSES[args.precision]
+        return {"workload": "BASELINE configs[1]: 200 QM9-shaped synthetic molecules x 2*U{50..500} conformers = %d conformers, "
+                            "%d packed batches of <= %d atoms, every 4th timed (2 warm-up + 10 steps), saturated schedule" % (G_all, len(bq), args.max_atoms),
+                "value": Gl / (tms * JOB_STEPS / 1e3), "unit": "conformers/s", "ms_per_step_timed_batches": tms, "batches_timed": nb,
+                "cfconv_avg_launch_ms": (pms / pn) if pn else None,
+                "cfconv_mfma_frac": (pe * 192 * 32 * mq.packed().poly_kt * 2 * passes / (pms * 1e-3) / 1e12 / PEAK[args.precision]) if pn else None}
+
     extra = None
     if rank == 0 and world == 1 and not args.no_extra and args.schedule == "saturated" and kind != "alanine":
         del run
@@ -610,7 +787,8 @@ def main():
         for name, sk in (("default_schedule_skip_discarded_global", True), ("default_schedule_no_skip", False)):
             v, ms2, gf2, nb = side_run(m2, cfg2, "default", sk)
             extra[name] = {"value": v, "unit": "conformers/s", "ms_per_step": ms2, "steps": Ke, "batches": nb,
-                           "global_branch_share_of_steps": gf2}
+                           "global_branch_share_of_steps": gf2,
+                           "note": "timed steps drawn from the two ranges of the schedule (sigma < 0.5 / >= 0.5) in the job's own proportion 2012 : 2988"}
         del m2
         if args.radius_poly != "off":
             m3, cfg3 = make_model(args.schedule, radius_poly="off")
@@ -618,6 +796,42 @@ def main():
             extra["fallback_filter_polynomials_off"] = {"value": v, "unit": "conformers/s", "ms_per_step": ms3, "steps": Ke,
                                                         "batches": nb}
             del m3
+        if args.radius_poly == "auto":
+            # the same job with 64-term polynomials (what a checkpoint whose first encoder layer is 2-8 x sharper gets)
+            m4, cfg4 = make_model(args.schedule, radius_poly="kt2")
+            v, ms4, gf4, nb = side_run(m4, cfg4, args.schedule, skip)
+            extra["filter_polynomials_64_terms"] = {"value": v, "unit": "conformers/s", "ms_per_step": ms4, "steps": Ke,
+                                                    "batches": nb, "fraction_of_headline": v / value}
+            del m4
+        if d200 and not use_dist and not args.no_gather_extra:
+            # cost of north_star's per-step collective on this box: the same batches with a one-rank RCCL group and the
+            # all-gather of [positions | NaN flag] issued after every step (what every rank of a multi-GPU run does)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ["MASTER_PORT"] = str(_free_port())
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            try:
+                tg = tn = 0.0
+                calls0 = gcalls[0]
+                for bidx, bm in enumerate(batches):
+                    if bidx % every:
+                        continue
+                    b_ = driver.pack_batch(bm, confs_of)
+                    el_, r_, _, ga, _ = timed_run(model, dev, b_, cfg, We, Ke, args.schedule, skip, save_traj, args.seed + bidx, rank, True)
+                    r_.check_nan()
+                    assert ga.calls == We + Ke
+                    parts, any_nan = ga.result()
+                    assert torch.equal(parts[0], r_.pos) and not any_nan
+                    tg += el_ / Ke * 1e3
+                    tn += per_batch[bidx]["ms_per_step"]
+                    del r_, ga
+                extra["all_gather_world1"] = {"ms_per_step_with_gather": tg, "ms_per_step_without": tn, "batches": len(batches[::every]),
+                                              "note": "one all_gather_into_tensor of [pos | nan flag] per denoising step on a side stream (agdiff_amd/dist.py: StepAllGather), one-rank RCCL group"}
+            finally:
+                dist.destroy_process_group()
+        if d200 and not args.no_full_job:
+            extra["full_job"] = full_job(model, cfg, batches, confs_of)
+        if d200 and not args.no_qm9_extra:
+            extra["configs1_qm9"] = qm9_extra()
         if cpu is not None:
             extra["x_vs_cpu_whole_host"] = value / cpu["value"]
             extra["x_vs_cpu_single_process"] = value / cpu["single_process"]["value"]
@@ -632,7 +846,8 @@ def main():
             "vs_baseline": None,      # the reference publishes no number for this metric
             "dtype": args.precision, "data": "synthetic", "rccl_ranks": world,
             "config": {"workload": wl, "conformers_total": G_total, "parallelism": "dp%d" % world,
-                       "all_gather_per_step": bool(use_dist), "trajectory_saved": save_traj,
+                       "all_gather_per_step": bool(use_dist), "all_gather_calls_rank0": int(gcalls[0]) if d200 else (gather.calls if use_dist else 0),
+                       "trajectory_saved": save_traj, "nan_check_every": 64,
                        "skip_discarded_global": skip, "filter_polynomials": poly_info},
             "roofline": roof, "roofline_cfconv_aggregate": agg_roof, "cpu_baseline": cpu, "extra": extra,
         }

@@ -46,8 +46,8 @@ def elem_err(a, b, floor_frac=1e-3):
 # turns the suite red.  A call site that needs more room says why and passes `scale`.
 TOL_NORM = {"f32": 5e-6, "bf16x3": 3e-5}
 TOL_ELEM = {"f32": 2e-3, "bf16x3": 3e-2}
-# measuring runs only: AGDIFF_PARITY_GATE_SCALE=100 records the figures without gating them at the product tolerances
-_GATE_SCALE = float(os.environ.get("AGDIFF_PARITY_GATE_SCALE", "1"))
+# (No environment switch loosens these gates: tests/conftest.py refuses to start a session in which
+# AGDIFF_PARITY_GATE_SCALE -- the measuring knob of rounds 2-3 -- is set.)
 _RECORDS = []
 
 
@@ -59,7 +59,6 @@ def check_close(name, got, ref, precision, scale=1.0):
         got = got.detach().cpu().numpy()
     if hasattr(ref, "detach"):
         ref = ref.detach().cpu().numpy()
-    scale = scale * _GATE_SCALE
     rn, re_ = rel_err(got, ref), elem_err(got, ref)
     _RECORDS.append({"name": name, "precision": precision, "normwise": rn, "elementwise": re_,
                      "gate_norm": TOL_NORM[precision] * scale, "gate_elem": TOL_ELEM[precision] * scale})

@@ -194,3 +194,79 @@ def test_bench_launcher_spawns_ranks_and_fails_cleanly():
                              capture_output=True, text=True, timeout=300, env=env)
         assert out.returncode == 2 and "GPU(s) visible" in out.stderr and "nothing was measured" in out.stderr
         assert out.stdout.strip() == ""
+
+
+# ---------------------------------------------------------------------------------------------------- bench.py's job loop
+class _StubRun:
+    """What bench.run_job_steps reads of a LangevinRun."""
+
+    class _Topo:
+        def __init__(self, n):
+            self.N = n
+
+    def __init__(self, pos):
+        self.pos, self.topo = pos, _StubRun._Topo(pos.shape[0])
+
+    def check_nan(self):
+        pass
+
+
+def _stub_timed(model, dev, b, cfg, W, K, schedule, skip, save_traj, seed, rank, use_dist, profile=False):
+    """Stand-in for bench.timed_run on CPU: W + K "denoising steps" that move the positions deterministically and call the
+    sampler's on_step hook exactly as LangevinRun does -- with the REAL StepAllGather behind it."""
+    n = int(np.asarray(b["atom_type"]).shape[0])
+    pos = torch.full((n, 3), float(seed))
+    gather = StepAllGather(n, "cpu") if use_dist else None
+    for k in range(W + K):
+        pos = pos + 1.0 + rank
+        if gather is not None:
+            gather(k, k, pos, torch.zeros(1, dtype=torch.int32))
+    return 1e-3 * K, _StubRun(pos), 1.0, gather, None
+
+
+def _bench_job_worker(rank, world, port, out, strong):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import bench
+    from agdiff_amd import driver
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(5)
+        mols = []
+        for i in range(6):
+            at_, r_, c_, t_ = synth.random_molecule(rng, synth.sample_n_atoms(rng, "qm9"))
+            mols.append(dict(atom_type=at_, edge_index=np.stack([r_, c_]), edge_type=t_, num_refs=2 + i, name="m%d" % i, index=i))
+        confs_of = driver.num_confs("2x")
+        batches = driver.plan_batches(mols, confs_of, 400)
+        assert len(batches) >= 2
+        gcalls = [0]
+        W, K = 2, 5
+        tot, G_local, recs, gf, last, prof = bench.run_job_steps(
+            None, None, batches, confs_of, "saturated", True, W, K, False, dev="cpu", rank=rank, world=world, seed=11,
+            save_traj=False, use_dist=True, strong=strong, gcalls=gcalls, timed=_stub_timed, edges_of=lambda r: 0,
+            tiles_of=lambda r: None)
+        G_job = sum(confs_of(m["num_refs"]) for m in mols)
+        ok = gcalls[0] == len(batches) * (W + K) and len(recs) == len(batches)       # ONE gather per step per batch per rank
+        ok = ok and (G_local == G_job if not strong else 0 < G_local < G_job)
+        out[rank] = (int(ok), G_local, gcalls[0])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_job_loop_gathers_every_step_world2_gloo():
+    """bench.py's own per-batch loop (run_job_steps) over gloo with two ranks, weak AND strong scaling: every rank issues
+    exactly one all-gather per denoising step per batch (north_star) and the gathered shard of each
+    rank equals its positions (asserted inside run_job_steps)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    for strong in (False, True):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        mgr = mp.Manager()
+        out = mgr.dict()
+        mp.spawn(_bench_job_worker, args=(2, port, out, strong), nprocs=2, join=True)
+        assert out[0][0] == 1 and out[1][0] == 1, (strong, dict(out))
+        assert out[0][2] == out[1][2]
+        if strong:
+            G = sum(2 * (2 + i) for i in range(6))
+            assert out[0][1] + out[1][1] == G

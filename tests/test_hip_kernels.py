@@ -8,6 +8,10 @@ six-block end-to-end `schnet_out` comparison alone.
        checked as BN(lin2(agg)) against the reference's CFConv.forward outputs (the fixtures hold those)
   agdiff_schnet_node_stage(k=1)  -> h   = h0 + AdaptiveScaling(InteractionBlock(h0))         (schnet.py:201-234, 280)
        fed with a reference aggregate, checked against h0 + the reference's scaling_modules[0](interactions[0](h0))
+  agdiff_graph_build_scaled + agdiff_cfconv_node(k=0)  -> the same aggregate from the kernel the sampler (and bench.py)
+       runs: radius rows by target + local quad tiles, filters from d-polynomials; checked like agdiff_cfconv_fused
+  agdiff_langevin_update / agdiff_sampler_front  -> eq_transform, clip_norm, center_pos against the G4 fixtures
+       (geometry.py:9-17, dualenc.py:581-589), fed with the reference's own edge scores
 """
 import ctypes
 import math
@@ -150,3 +154,144 @@ def test_node_stage_block0_vs_reference_modules(case, precision):
                 g["scaled_b0"], precision, scale=4.0)      # difference of two O(1) fp32 numbers, |result| ~ 0.3
     xs1 = _xs_ref(sd, "encoder_global.interactions.1", torch.from_numpy(h1_ref))
     check_close("node_stage1 xs[%s]" % case, ws.xs.view(-1, 192), xs1.float(), precision)
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("case", STAGE_CASES[:2])
+def test_cfconv_node_block0_vs_reference_modules(case, precision):
+    """The CFConv kernel bench.py times (k_cfconv_node: polynomial filters, radius rows by target + local quad tiles)
+    against the reference's CFConv modules of block 0 -- not only against the MLP kernel (tests/test_hip_poly.py)."""
+    from agdiff_amd import _lib
+    g, cfg, sd, m, lib, topo, ws, (P, Tp, Wp, st) = _setup(case, precision)
+    if "cfconv1_b0" not in g:
+        pytest.skip("fixture without per-module outputs")
+    pk = m.packed()
+    assert pk.poly_kt >= 1 and lib.agdiff_local_poly_enabled(P, Tp, Wp) == 1
+    blk = "encoder_global.interactions.0"
+    pos = t(g["pos"]).cuda().contiguous()
+    assert lib.agdiff_graph_build_scaled(P, Tp, Wp, _lib.ptr(pos), ctypes.c_float(cfg.cutoff), 0, st) == 0
+    assert lib.agdiff_local_lengths(Tp, Wp, _lib.ptr(pos), st) == 0
+    assert lib.agdiff_edge_scales_split(P, Tp, Wp, 2, st) == 0
+    assert lib.agdiff_schnet_node_stage(P, Tp, Wp, 0, st) == 0
+    ws.agg.fill_(float("nan"))
+    assert lib.agdiff_cfconv_node(P, Tp, Wp, 0, st) == 0
+    torch.cuda.synchronize()
+    agg = ws.agg.view(-1, 192)[: topo.N].cpu().double()
+    xs_ref = _xs_ref(sd, blk, t(g["schnet_h0"]).double())
+    agg_ref = _agg_ref(sd, cfg, blk, g, xs_ref)
+    for c, lo, hi, key in ((1, 0, 128, "cfconv1_b0"), (2, 128, 192, "cfconv2_b0")):
+        p = "%s.conv%d" % (blk, c)
+        post = lambda a: _bn(sd, p + ".norm2", _lin(sd, p + ".lin2", a[:, lo:hi])).float().numpy()
+        check_close("cfconv_node conv%d out[%s]" % (c, case), post(agg), g[key], precision)
+    check_close("cfconv_node agg[%s]" % case, agg.float().numpy(), agg_ref.float().numpy(), precision)
+    # ... and the node stage fed with THIS aggregate (split bit 1: one complete row per node) closes block 0
+    assert lib.agdiff_schnet_node_stage_split(P, Tp, Wp, 1, 1, st) == 0
+    torch.cuda.synchronize()
+    h1_ref = g["schnet_h0"].astype(np.float64) + g["scaled_b0"].astype(np.float64)
+    check_close("cfconv_node -> node_stage1 h[%s]" % case, ws.h.view(-1, 128), h1_ref.astype(np.float32), precision)
+
+
+# ---------------------------------------------------------------------------------------------------- G4 fixtures
+def _center_np(x, batch):
+    out = x.copy()
+    for gidx in np.unique(batch):
+        sel = batch == gidx
+        out[sel] -= x[sel].mean(axis=0, keepdims=True)
+    return out
+
+
+def _step_args(pos, out, scratch, noise, *, step_size, use_global, clip, clip_local, w_global=1.0):
+    from agdiff_amd import _lib
+    sa = _lib.StepArgs()
+    sa.pos_in, sa.pos_out, sa.scratch, sa.noise = _lib.ptr(pos), _lib.ptr(out), _lib.ptr(scratch), _lib.ptr(noise)
+    sa.traj_out = ctypes.c_void_p(0)
+    sa.sigma, sa.step_size, sa.noise_scale = 1.0, float(step_size), 0.0
+    sa.w_global, sa.clip, sa.clip_local, sa.clip_pos = float(w_global), float(clip), float(clip_local), -1.0
+    sa.use_global = int(use_global)
+    return sa
+
+
+@pytest.mark.parametrize("front", ["unfused", "fused"])
+@pytest.mark.parametrize("case", ["g3_forward_qm9_small", "g3_forward_drugs_capped"])
+def test_update_kernels_vs_reference_geometry_fixtures(case, front):
+    """agdiff_langevin_update (unfused) and the update phase of agdiff_sampler_front (fused) against the reference's own
+    eq_transform / clip_norm / center_pos outputs (G4: `eq_local`, `eq_global`, `clip_local_20`, `center` of the forward
+    fixtures, tests/golden/make_golden.py:113-116), fed with the REFERENCE's edge scores -- not only through sampler
+    trajectories.  With sigma = 1, zero noise and step size S the kernels return center_pos(pos + S * term): S = 2^16
+    makes the term the whole result (S * |term| >> |pos|), S = 0 leaves center_pos alone."""
+    from agdiff_amd import _lib
+    g, cfg, sd, m, lib, topo, ws, (P, Tp, Wp, st) = _setup(case, "f32")
+    RS = _lib.DEFINES["AGDIFF_RAD_STRIDE"]
+    N, batch = topo.N, g["batch"]
+    pos = t(g["pos"]).cuda().contiguous()
+    E = int(ws.num_edges.item())
+    assert E == g["edge_type"].shape[0]
+    inv_g_ref = t(g["edge_inv_global"]).view(-1).cuda()
+    inv_l_ref = t(g["edge_inv_local"]).view(-1).cuda()
+    assert lib.agdiff_local_lengths(Tp, Wp, _lib.ptr(pos), st) == 0
+    if front == "fused":
+        sa0 = _lib.StepArgs()
+        sa0.pos_in = _lib.ptr(pos)
+        ws.canon_counter.zero_()
+        assert lib.agdiff_sampler_front(P, Tp, Wp, ctypes.byref(sa0), 2 | 4, ctypes.c_float(cfg.cutoff), st) == 0
+        torch.cuda.synchronize()
+        # the reference's global scores by radius row: row (i, k) is the k-th radius (type 0) in-edge of target i
+        where = {(int(s_), int(d_)): q_ for q_, (s_, d_) in enumerate(zip(g["edge_index"][0], g["edge_index"][1]))}
+        cnt, rsrc = ws.rad_cnt.cpu().numpy(), ws.rad_src.view(N, RS).cpu().numpy()
+        inv_r = np.zeros((N, RS), dtype=np.float32)
+        for i in range(N):
+            for k in range(cnt[i]):
+                q_ = where[(int(rsrc[i, k]), i)]
+                assert g["edge_type"][q_] == 0
+                inv_r[i, k] = g["edge_inv_global"][q_, 0]
+        assert int(cnt.sum()) == int((g["edge_type"] == 0).sum())
+        ws.inv_r.view(N, RS).copy_(t(inv_r).cuda())
+    else:
+        ws.e_inv_global.zero_()
+        ws.e_inv_global[ws.ref2dst[:E].long()] = inv_g_ref           # reference (row, col) order -> destination-sorted
+    out, scratch, zero = torch.empty_like(pos), torch.empty_like(pos), torch.zeros_like(pos)
+
+    def run(l_scores, S, use_global, clip_local):
+        ws.l_inv[: topo.L].copy_(l_scores)
+        ws.nan_flag.zero_()
+        sa = _step_args(pos, out, scratch, zero, step_size=S, use_global=use_global, clip=1e30, clip_local=clip_local)
+        if front == "fused":
+            assert lib.agdiff_sampler_front(P, Tp, Wp, ctypes.byref(sa), 1, ctypes.c_float(cfg.cutoff), st) == 0
+        else:
+            assert lib.agdiff_langevin_update(Tp, Wp, ctypes.byref(sa), st) == 0
+        torch.cuda.synchronize()
+        assert int(ws.nan_flag[0].item()) == 0
+        return out.cpu().double().numpy()
+
+    S = 65536.0
+    p64 = g["pos"].astype(np.float64)
+    expect = lambda term: _center_np(p64 + S * term.astype(np.float64), batch)
+    check_close("%s update eq_local[%s]" % (front, case), run(inv_l_ref, S, 0, -1.0), expect(g["eq_local"]), "f32")
+    check_close("%s update eq_global[%s]" % (front, case), run(torch.zeros_like(inv_l_ref), S, 1, -1.0), expect(g["eq_global"]), "f32")
+    # clip_norm(eq_local * 1e4, 20): eq_transform is linear in the scores
+    check_close("%s update clip_local_20[%s]" % (front, case), run(inv_l_ref * 1e4, S, 0, 20.0), expect(g["clip_local_20"]), "f32")
+    check_close("%s update center[%s]" % (front, case), run(inv_l_ref, 0.0, 0, -1.0), g["center"], "f32")
+
+
+def test_noise_mode_per_step_consumes_the_generator_like_the_reference():
+    """noise_mode="per_step": one torch.randn_like(pos) per denoising step, the reference's own call (dualenc.py:529) --
+    so a run equals, bit for bit, the run with those same draws injected, and the generator ends where the reference's
+    would (missing item 3)."""
+    from agdiff_amd import get_model, qm9_model_config, synth
+    cfg = qm9_model_config(num_diffusion_timesteps=12)
+    m = get_model(cfg)
+    m.load_state_dict(synth.synth_state_dict(m.state_dict()))
+    m = m.to("cuda:0").eval()
+    b = synth.make_packed_batch("qm9", 3, 2, seed=7)
+    at, bi, bt, ba = [t(b[k]).cuda() for k in ("atom_type", "bond_index", "bond_type", "batch")]
+    pos_init = torch.randn(at.shape[0], 3, generator=torch.Generator().manual_seed(3)).cuda()
+    kw = dict(extend_order=False, n_steps=5, w_global=1.0, global_start_sigma=0.5, clip=1000.0)
+    torch.manual_seed(1234)
+    p1, t1 = m.langevin_dynamics_sample_diffusion(at, pos_init, bi, bt, ba, b["num_graphs"], noise_mode="per_step", **kw)
+    after1 = torch.randn(4, device="cuda:0")
+    torch.manual_seed(1234)
+    draws = torch.stack([torch.randn_like(pos_init) for _ in range(5)])
+    after2 = torch.randn(4, device="cuda:0")
+    p2, t2 = m.langevin_dynamics_sample_diffusion(at, pos_init, bi, bt, ba, b["num_graphs"], noise=draws, **kw)
+    assert torch.equal(p1, p2) and all(torch.equal(a, b_) for a, b_ in zip(t1, t2))
+    assert torch.equal(after1, after2)
