@@ -68,7 +68,7 @@ __device__ __forceinline__ void ag_agg_slice(const AggSrc& r, int k, int q, f32x
 
 // Stage k of SchNetEncoder.forward (schnet.py:268-282):
 //   finish: p1 = BN(lin2_1(agg1)), p2 = BN(lin2_2(agg2))         (schnet.py:157-158, BN folded)
-//           x  = lin(ssp(cat[p1,p2]));  x *= sigmoid(att(x))      (schnet.py:206-214)
+//           x  = lin(ssp(cat[p1,p2]));  x *= sigmoid(att(x))      (schnet.py:206-214; ssp in base 2, its constants in lin2 / lin)
 //           h += x * sigmoid(fc2(relu(fc1(x))))                   (schnet.py:230-234, 280)
 //   prep:   xs = LeakyReLU(BN(lin1(h))) for conv1 | conv2         (schnet.py:153-155)
 //   stage 0 (finish == 0): h = embedding[z]                       (schnet.py:271)
@@ -113,11 +113,28 @@ __global__ void __launch_bounds__(LDSW ? 1024 : 256, LDSW ? 1 : 2) k_schnet_node
   const int64_t nd = valid ? node : 0;
 
   f32x4 hv[8];
+#ifdef AG_NODE_TOUCH
+  float touch0 = 0.f, touch1 = 0.f, touch2 = 0.f;
+#endif
   if (!a.finish) {
     if (a.prep) stage_in(12, a.next.lin1_pk, 48);
     if (active) ag_load_row<8, 0>(hv, a.emb + (size_t)a.atom_type[nd] * 128, q);
     sync();
   } else {
+#ifdef AG_NODE_TOUCH
+    // (experiment) one dword of every 128-byte line of the tile's aggregate rows (16 x 768 B, contiguous) and h rows
+    // (16 x 512 B) requested BEFORE the weights are staged: the lines travel from HBM while the workgroup copies 160 KiB
+    // of weights, and the six dependent slice loads of the first layer then hit L2
+    if (LDSW && active && !a.in_ptr) {
+      const char* ab = reinterpret_cast<const char*>(a.agg + (size_t)tile * AG_TW * 192);
+      const char* hb = reinterpret_cast<const char*>(a.h_in + (size_t)tile * AG_TW * 128);
+      const int64_t last = (a.n - tile * AG_TW < AG_TW ? a.n - tile * AG_TW : AG_TW);
+      const int la = (int)(last * 768 / 128), lh = (int)(last * 512 / 128);
+      touch0 = *reinterpret_cast<const float*>(ab + 128 * (lane < la ? lane : 0));
+      touch1 = *reinterpret_cast<const float*>(ab + 128 * (lane + 64 < la ? lane + 64 : 0));
+      touch2 = *reinterpret_cast<const float*>(hb + 128 * (lane < lh ? lane : 0));
+    }
+#endif
     stage_in(0, a.prev.lin2a_pk, 32);
     stage_in(32, a.prev.lin2b_pk, 16);
     stage_in(48, a.prev.lin_pk, 32);
@@ -158,10 +175,8 @@ __global__ void __launch_bounds__(LDSW ? 1024 : 256, LDSW ? 1 : 2) k_schnet_node
           }
         }
       }
-      {
-        const float beta = a.prev.act_beta;
-        AG_FOR_TILE(u, 16, ag_ssp(beta, v));
-      }
+      // InteractionBlock.act in base 2: act.beta log2(e) rides in lin2, ln 2 and the -ln 2 shift in lin (packing.py)
+      AG_FOR_TILE(u, 16, ag_ssp_base2(v));
       ag_cvt_tiles<MODE, 8, 0>(u, ub);
       ag_init_vec<8>(xc, a.prev.lin_b, q);
       AG_NODE_DENSE(false, 8, 4, 0, 0, ub, xc, a.prev.lin_pk, 48);                             // output tiles 0..3
@@ -214,6 +229,9 @@ __global__ void __launch_bounds__(LDSW ? 1024 : 256, LDSW ? 1 : 2) k_schnet_node
     }
   }
   if (!active) return;                     // no barrier below this point
+#ifdef AG_NODE_TOUCH
+  if (a.finish) asm volatile("" ::"v"(touch0), "v"(touch1), "v"(touch2));
+#endif
   if (valid) ag_store_row<8, 0>(hv, a.h + (size_t)node * 128, q);
   if (a.prep) {
     f32x4 xo[12];
@@ -353,8 +371,7 @@ __global__ void __launch_bounds__(256, 2) k_schnet_node_stage_split(NodeStageArg
 #pragma unroll
     for (int i = 0; i < 4; ++i) AG_SPLIT_STEP(8 + i, u4[2 + (i & 1)], gk[4 + (i >> 1)]);
     {
-      const float beta = a.prev.act_beta;
-      AG_FOR_TILE(u4, 4, ag_ssp(beta, v));
+      AG_FOR_TILE(u4, 4, ag_ssp_base2(v));
       AgIn<MODE> k0, k1;
       ag_cvt(u4[0], u4[1], k0);
       ag_cvt(u4[2], u4[3], k1);

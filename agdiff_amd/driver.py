@@ -289,9 +289,10 @@ def main(argv=None):
     ap.add_argument("--save-traj", action="store_true")
     ap.add_argument("--resume", action="store_true")
     ap.add_argument("--extend-order", action="store_true", help="input holds raw bonds: extend to order 3 first")
-    ap.add_argument("--max-atoms", type=int, default=200000,
+    ap.add_argument("--max-atoms", type=int, default=196608,
                     help="atoms per packed batch and GPU (≈200 k is where an MI355X samples fastest: fixed per-launch costs are "
-                         "amortised and the node features still live in L2 / MALL; --save-traj keeps n_steps x atoms x 12 bytes)")
+                         "amortised and the node features still live in L2 / MALL; 196,608 = 3 full rounds of the node kernels' "
+                         "256 x 16 x 16-node workgroups; --save-traj keeps n_steps x atoms x 12 bytes)")
     ap.add_argument("--seed", type=int, default=2021)
     ap.add_argument("--precision", default=None, choices=[None, "f32", "bf16x3"])
     ap.add_argument("--dist-mode", default="shard", choices=["shard", "batches"],

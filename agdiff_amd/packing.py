@@ -433,11 +433,16 @@ class PackedParams:
             arrays[n + "lin1_b"] = np.concatenate([b1a, b1b])
             W2a, b2a = fold_bn(_np(sd, c1 + ".lin2.weight"), _np(sd, c1 + ".lin2.bias"), sd, c1 + ".norm2")
             W2b, b2b = fold_bn(_np(sd, c2_ + ".lin2.weight"), _np(sd, c2_ + ".lin2.bias"), sd, c2_ + ".norm2")
-            arrays[n + "lin2a_pk"] = pack_blocks(W2a, kouter=True)
-            arrays[n + "lin2b_pk"] = pack_blocks(W2b, kouter=True)
-            arrays[n + "lin2_b"] = np.concatenate([b2a, b2b])
-            arrays[n + "lin_pk"] = pack_blocks(_np(sd, p + ".lin.weight"))
-            arrays[n + "lin_b"] = _np(sd, p + ".lin.bias")
+            # InteractionBlock.act (ShiftedSoftplus, schnet.py:71-80,206) in base 2 like the filter networks' one: with
+            # kb = act.beta * log2(e) the (BN-folded) lin2 layers yield u = kb (W2 agg + b2); the kernel forms
+            # s = max(u, log2(1 + 2^u)); softplus(beta x) - ln 2 = ln 2 (s - 1), so `lin` takes ln2 * W and b - ln2 * W 1
+            kb = float(_np(sd, p + ".act.beta")) / LN2
+            Wl, bl = f64(p + ".lin.weight"), f64(p + ".lin.bias")
+            arrays[n + "lin2a_pk"] = pack_blocks(kb * W2a.astype(np.float64), kouter=True)
+            arrays[n + "lin2b_pk"] = pack_blocks(kb * W2b.astype(np.float64), kouter=True)
+            arrays[n + "lin2_b"] = kb * np.concatenate([b2a, b2b]).astype(np.float64)
+            arrays[n + "lin_pk"] = pack_blocks(LN2 * Wl)
+            arrays[n + "lin_b"] = bl - LN2 * Wl.sum(1)
             arrays[n + "gate1_pk"] = pack_blocks(_np(sd, p + ".attention.0.weight"))
             arrays[n + "gate1_b"] = _np(sd, p + ".attention.0.bias")
             arrays[n + "gate2_w"] = _np(sd, p + ".attention.2.weight")[0]

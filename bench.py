@@ -357,7 +357,7 @@ def main():
     ap.add_argument("--workload", default="drugs200", choices=["drugs", "drugs200", "qm9", "large", "alanine"])
     ap.add_argument("--mols", type=int, default=8)
     ap.add_argument("--copies", type=int, default=128)
-    ap.add_argument("--max-atoms", type=int, default=200000, help="drugs200: atoms per packed batch (driver.plan_batches; measured on the default job: 50 k / 100 k / 200 k / 400 k / 800 k atoms -> 125 / 134 / 139 / 137 / 131 conformers/s)")
+    ap.add_argument("--max-atoms", type=int, default=196608, help="drugs200: atoms per packed batch (driver.plan_batches; measured on the default job in round 3: 50 k / 100 k / 200 k / 400 k / 800 k atoms -> 125 / 134 / 139 / 137 / 131 conformers/s).  196,608 = 3 x 256 CUs x 16 waves x 16 nodes: the node kernels (one 16-wave workgroup per CU and round) then run exactly three full rounds; 200,000 left a fourth round of 7 workgroups")
     ap.add_argument("--schedule", default="saturated", choices=["saturated", "default"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-skip", action="store_true", help="run the global encoder even where its result is discarded")
@@ -578,11 +578,11 @@ def main():
             # issue-slot model of one SIMD: an MFMA holds the issue port 8 cycles, any other VALU instruction 4 (wave64 on 16
             # lanes); VALU / tile from the SQ counter pass when one was taken on this workload
             cnts = pmc["kernels"][kern[0]].get("counters", {}) if pmc else {}
-            model = None
+            issue_model = None
             if cnts.get("SQ_INSTS_VALU") and cnts.get("SQ_INSTS_MFMA") and tiles:
                 n_mfma, n_other = cnts["SQ_INSTS_MFMA"], cnts["SQ_INSTS_VALU"] - cnts["SQ_INSTS_MFMA"]
                 cyc = 8.0 * n_mfma + 4.0 * n_other
-                model = {"mfma_per_tile": n_mfma / tiles, "other_valu_per_tile": n_other / tiles,
+                issue_model = {"mfma_per_tile": n_mfma / tiles, "other_valu_per_tile": n_other / tiles,
                          "issue_cycles_per_tile": cyc / tiles, "simds": 1024, "clock_ghz_assumed": 2.4,
                          "issue_slot_frac": cyc / (1024 * 2.4e9 * avg_ms * 1e-3),
                          "source": "SQ_INSTS_VALU / SQ_INSTS_MFMA of profiles/%s_%s_pmc.json (separate counter passes of this command)" % (PROFILE_ROUND, args.precision)}
@@ -600,7 +600,7 @@ def main():
             kernel = "k_cfconv_fused"
             issued = ref_priced * passes
             executed = issued
-            model = None
+            issue_model = None
             ach = issued
             note = ("achieved = MFMA FLOPs issued: algorithmic FLOPs (E x 90,112: the reference evaluates the filter network on "
                     "every directed edge) x 3 bf16 passes (hi.hi + lo.hi + hi.lo; 1 in f32 mode), fp32 accumulate, over the "
@@ -616,7 +616,7 @@ def main():
                 "hbm_frac_by_counters": (pmc["kernels"][kern[0]]["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if pmc else None,
                 "valu_issue_busy": pmc["kernels"][kern[0]].get("valu_issue_busy") if pmc else None,
                 "mfma_pipe_busy": pmc["kernels"][kern[0]].get("mfma_pipe_busy") if pmc else None,
-                "issue_model": model, "tiles": pads_info if node_path else None,
+                "issue_model": issue_model, "tiles": pads_info if node_path else None,
                 "note": note}
 
     # ---- stand-alone CFConv aggregate (PyG propagate x_j * W, schnet.py:156-162) on the last batch's graph: the HBM-bound

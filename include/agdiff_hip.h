@@ -72,11 +72,14 @@ typedef struct agdiff_conv_params {
   /* node side of the block (schnet.py:153-158, 201-216, 219-234) */
   const float* lin1_pk;      /* pk [12][4]: BN-folded conv1.lin1 (rows 0..127) and conv2.lin1 (128..191) */
   const float* lin1_b;       /* [192] */
-  const float* lin2a_pk;     /* pkk [4][8]: BN-folded conv1.lin2 */
-  const float* lin2b_pk;     /* pkk [2][8]: BN-folded conv2.lin2 */
-  const float* lin2_b;       /* [256] */
-  const float* lin_pk;       /* pk [8][8]: InteractionBlock.lin (256->128) */
-  const float* lin_b;        /* [128] */
+  /* InteractionBlock.act (ShiftedSoftplus with learnable beta, schnet.py:71-80,206) is evaluated in base 2 like the filter
+   * networks' one: kb = act.beta * log2(e) is folded into lin2 (u = kb (W2 agg + b2)), the kernel forms
+   * s = max(u, log2(1 + 2^u)), and lin takes ln2 * W with bias b - ln2 * W 1  (softplus(beta x) - ln 2 = ln 2 (s - 1)) */
+  const float* lin2a_pk;     /* pkk [4][8]: kb * BN-folded conv1.lin2 */
+  const float* lin2b_pk;     /* pkk [2][8]: kb * BN-folded conv2.lin2 */
+  const float* lin2_b;       /* [256] kb * (BN-folded biases) */
+  const float* lin_pk;       /* pk [8][8]: ln2 * InteractionBlock.lin (256->128) */
+  const float* lin_b;        /* [128] lin.bias - ln2 * rowsum(lin.weight) */
   const float* gate1_pk;     /* pk [4][4]: attention.0 (128->64) */
   const float* gate1_b;      /* [64] */
   const float* gate2_w;      /* [64]  attention.2 */
@@ -89,7 +92,7 @@ typedef struct agdiff_conv_params {
                                 a slot (agdiff_params_t.poly_type_slot), d in [0, cutoff] (beyond it the CFConv's cutoff factor
                                 C(d) is exactly 0, schnet.py:140-146) */
   float gate2_b;
-  float act_beta;            /* InteractionBlock.act.beta */
+  float act_beta;            /* InteractionBlock.act.beta (informational: folded into lin2 / lin above) */
 } agdiff_conv_params_t;
 
 typedef struct agdiff_gin_params {
