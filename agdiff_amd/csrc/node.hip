@@ -113,28 +113,11 @@ __global__ void __launch_bounds__(LDSW ? 1024 : 256, LDSW ? 1 : 2) k_schnet_node
   const int64_t nd = valid ? node : 0;
 
   f32x4 hv[8];
-#ifdef AG_NODE_TOUCH
-  float touch0 = 0.f, touch1 = 0.f, touch2 = 0.f;
-#endif
   if (!a.finish) {
     if (a.prep) stage_in(12, a.next.lin1_pk, 48);
     if (active) ag_load_row<8, 0>(hv, a.emb + (size_t)a.atom_type[nd] * 128, q);
     sync();
   } else {
-#ifdef AG_NODE_TOUCH
-    // (experiment) one dword of every 128-byte line of the tile's aggregate rows (16 x 768 B, contiguous) and h rows
-    // (16 x 512 B) requested BEFORE the weights are staged: the lines travel from HBM while the workgroup copies 160 KiB
-    // of weights, and the six dependent slice loads of the first layer then hit L2
-    if (LDSW && active && !a.in_ptr) {
-      const char* ab = reinterpret_cast<const char*>(a.agg + (size_t)tile * AG_TW * 192);
-      const char* hb = reinterpret_cast<const char*>(a.h_in + (size_t)tile * AG_TW * 128);
-      const int64_t last = (a.n - tile * AG_TW < AG_TW ? a.n - tile * AG_TW : AG_TW);
-      const int la = (int)(last * 768 / 128), lh = (int)(last * 512 / 128);
-      touch0 = *reinterpret_cast<const float*>(ab + 128 * (lane < la ? lane : 0));
-      touch1 = *reinterpret_cast<const float*>(ab + 128 * (lane + 64 < la ? lane + 64 : 0));
-      touch2 = *reinterpret_cast<const float*>(hb + 128 * (lane < lh ? lane : 0));
-    }
-#endif
     stage_in(0, a.prev.lin2a_pk, 32);
     stage_in(32, a.prev.lin2b_pk, 16);
     stage_in(48, a.prev.lin_pk, 32);
@@ -229,9 +212,6 @@ __global__ void __launch_bounds__(LDSW ? 1024 : 256, LDSW ? 1 : 2) k_schnet_node
     }
   }
   if (!active) return;                     // no barrier below this point
-#ifdef AG_NODE_TOUCH
-  if (a.finish) asm volatile("" ::"v"(touch0), "v"(touch1), "v"(touch2));
-#endif
   if (valid) ag_store_row<8, 0>(hv, a.h + (size_t)node * 128, q);
   if (a.prep) {
     f32x4 xo[12];

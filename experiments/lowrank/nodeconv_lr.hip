@@ -1,0 +1,878 @@
+// The two CFConvs of an InteractionBlock with their filters from d-polynomials, one wave per quad of targets
+// (include/agdiff_hip.h: agdiff_cfconv_node).  Its own translation unit: built with -fno-slp-vectorize -- the SLP
+// vectoriser turns the per-row accumulation FMAs into v_pk_fma_f32 fed by register shuffles (358 v_mov per kernel), and
+// packed fp32 next to MFMAs costs issue time instead of saving it (MI355X_MICROARCH.md, per-instruction cycle constants).
+#include "common.hpp"
+#include <type_traits>
+
+#define AG_CONV_NCH 12          // 16-channel tiles of the 192 filter channels (conv1: 0..7, conv2: 8..11)
+
+namespace {
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void ag_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    ag_static_for<I + 1, N>(f);
+  }
+}
+
+// ------------------------------------------------------------------------------ CFConv by filter polynomials, per target
+struct NodeConvArgs {
+  const float* poly_rad;      // pk [12][NKT]: filter polynomials of conv1 (channel tiles 0..7) and conv2 (8..11), bias included
+  const float* poly_typed;    // [num_slots] x pk [12][NKT]: the same per local edge type, or null
+  const int32_t* type_slot;   // [100] edge type -> set
+  int32_t num_slots;          // 0: no local tiles in this launch
+  int32_t lds_slots;          // typed sets 0..lds_slots-1 are copied to LDS, the others are read from L2
+  // radius rows, AGDIFF_RAD_STRIDE per target (agdiff_ws_t.rad_*)
+  const int32_t* rad_cnt;
+  const int32_t* rad_src;
+  const float* rad_len;
+  const float* r_scale1;      // lw(d)*C(d) of conv1 / conv2 of this block by radius row
+  const float* r_scale2;
+  // local quad tiles (agdiff_topo_t.lt_*, agdiff_ws_t.lt_*)
+  const int32_t* quad_tgt;    // [4 Q]: the four targets of a quad (-1: none)
+  const int32_t* lt_ptr;
+  const int32_t* lt_src;
+  const int32_t* lt_type;
+  const float* lt_len;
+  const float* l_scale1;
+  const float* l_scale2;
+  const float* xs;            // [N][192]
+  const float* xsp;           // [N][192] split-bf16 words of xs (low-rank radius path) or null
+  const float* lr_u;          // pk [1][1]: U^T of the low-rank radius form (agdiff_conv_params_t.filt_lr_u_pk) or null
+  const float* lr_c;          // [12][64][4]: its C by lane (filt_lr_c)
+  float* agg;                 // [N][192]
+  int32_t n;                  // N
+  int32_t num_quads;          // Q
+  int32_t qshift;             // a local tile's rows of lane quarter q belong to the quad's (q >> qshift)-th target (GT = 4 >> qshift)
+  float two_over_rc;
+};
+
+// encoder/schnet.py:136-162 for conv1 and conv2 of one InteractionBlock, filters from d-polynomials:
+//   W_e = nn(MLPEdgeEncoder(d_e, type_e)) = P_type(d_e);   agg[dst] += x[src] * W_e * (lw(d_e) C(d_e)).
+// One wave owns a QUAD of targets (topo->quad_tgt: four atoms of one molecule whose local in-lists need like tiles) and
+// walks, in this order, the quad's local tiles (static, topo->lt_*: 16 rows of ONE edge type, rows 4 k .. 4 k + 3 = in-edges
+// of the quad's k-th target) and the radius tiles of its first, second, third and fourth target (every 16-row tile of the
+// radius rows belongs to one target, ws->rad_*).  EVERY tile runs the same body: the K = 32 NKT polynomial features of each
+// row, SCALED by the row's lw C (one set per conv: the per-edge scale rides through the MFMAs), times the coefficient
+// blocks of the tile's set (flipped product: rows = edges, lanes = channels), then x[src] gathered per (row, channel) and
+//   sum[channel tile] += sum_r z[r] x[r]  -- four FMAs per channel tile, no masks, no list bounds, no carries between waves:
+// a lane's four rows (4 q + r) always belong to one target.  Radius tiles add into acc (all four quarters = the current
+// target), local tiles into accL (quarter k = the quad's k-th target).  When a target's radius tiles are done, the sums
+// over the wave's quarters are taken once (reduce-scatter over the quarters, three lane swaps per four channel tiles) --
+// with accL entering from quarter k only -- and the target's row of agg is written once, complete (zeros for a target
+// without edges): no agg_first, no second aggregate for the node stage to add, no atomics, fixed order => bitwise
+// reproducible.  Coefficient sets: the radius edges' one and the first lds_slots typed ones in LDS, rarer ones from L2.
+// Everything a tile needs from memory (sources, lengths, the two scales, the type; then the first x groups) is requested
+// during the wave's previous tile, the features are evaluated there too; x groups are double-buffered inside a tile.
+// Lengths beyond the cutoff are clamped into the fitted range: their CFConv scale is exactly 0 (schnet.py:140-146).
+// A local tile whose type has no polynomial (mixed batches: agdiff_local_poly_enabled = 2) runs with scale 0: its edges
+// go through agdiff_cfconv_local.
+#ifndef AG_NODE_GRP
+#define AG_NODE_GRP 3                       // channel tiles per x / MFMA group
+#endif
+#ifndef AG_NODE_XD
+#define AG_NODE_XD 2                        // x groups in flight (ring of buffers; must divide the number of groups: static indices)
+#endif
+#ifndef AG_NODE_ABL
+#define AG_NODE_ABL 0       // timing experiments only (wrong results): 1 no x gathers, 2 no filter MFMAs, 4 no features, 8 no sums, 16 one coefficient read per group
+#endif
+template <int MODE, int NKT, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvArgs a) {
+  extern __shared__ u32x4 ag_nodeconv_smem[];
+  lds_u32x4* wl = (lds_u32x4*)ag_nodeconv_smem;
+  constexpr int SET = AG_CONV_NCH * NKT * 128;          // 16-byte units per coefficient set
+  constexpr int NG = AG_CONV_NCH / AG_NODE_GRP;
+  ag_copy_lds(wl, reinterpret_cast<const u32x4*>(a.poly_rad), SET);
+  if (a.lds_slots > 0) ag_copy_lds(wl + SET, reinterpret_cast<const u32x4*>(a.poly_typed), a.lds_slots * SET);
+  __syncthreads();
+  int lane = ag_lane();
+  asm volatile("" : "+v"(lane));
+  const int q = lane >> 4, col = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wg = (gridDim.x % 8 == 0) ? (int)((blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8) : (int)blockIdx.x;
+  const int per_wg = (a.num_quads + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int p_begin = wg * per_wg;
+  const int p_end = (p_begin + per_wg < a.num_quads) ? p_begin + per_wg : a.num_quads;
+  const bool with_local = a.num_slots > 0;
+
+  // A quad's description in plain scalars (a struct of them ended up as a dynamically indexed stack object in scratch):
+  // nL local tiles from lt0, targets t0..t3 with n0..n3 radius tiles.
+#define AG_QUAD_DECL(P) int P##nL = 0, P##lt0 = 0, P##t0 = -1, P##t1 = -1, P##t2 = -1, P##t3 = -1, P##n0 = 0, P##n1 = 0, P##n2 = 0, P##n3 = 0
+#define AG_QUAD_LOAD(P, p)                                                              \
+  do {                                                                                  \
+    P##t0 = a.quad_tgt[4 * (p)];                                                        \
+    P##t1 = a.quad_tgt[4 * (p) + 1];                                                    \
+    P##t2 = a.quad_tgt[4 * (p) + 2];                                                    \
+    P##t3 = a.quad_tgt[4 * (p) + 3];                                                    \
+    P##n0 = tiles_of(P##t0);                                                            \
+    P##n1 = tiles_of(P##t1);                                                            \
+    P##n2 = tiles_of(P##t2);                                                            \
+    P##n3 = tiles_of(P##t3);                                                            \
+    P##lt0 = with_local ? a.lt_ptr[(p)] : 0;                                            \
+    P##nL = with_local ? a.lt_ptr[(p) + 1] - P##lt0 : 0;                                \
+  } while (0)
+#define AG_QUAD_ARGS(P) P##nL, P##lt0, P##t0, P##t1, P##t2, P##t3, P##n0, P##n1, P##n2
+  auto tiles_of = [&](int t) { return (t >= 0) ? (a.rad_cnt[t] + AG_TW - 1) / AG_TW : 0; };
+  // first row of tile j of a quad (order: local tiles, radius tiles of its first .. fourth target)
+  auto tile_rows = [&](int nL, int lt0, int t0, int t1, int t2, int t3, int n0, int n1, int n2, int j, bool& local) -> int {
+    local = j < nL;
+    if (local) return (lt0 + j) * AG_TW;
+    j -= nL;
+    int t = t0;
+    if (j >= n0) {
+      j -= n0;
+      t = t1;
+      if (j >= n1) {
+        j -= n1;
+        t = t2;
+        if (j >= n2) {
+          j -= n2;
+          t = t3;
+        }
+      }
+    }
+    return t * AGDIFF_RAD_STRIDE + j * AG_TW;
+  };
+  // per-row inputs of the wave's NEXT tile: length and the two scales of row `col`, the tile's type slot, the sources of the
+  // lane's four rows 4 q .. 4 q + 3
+  float pf_d = 0.f, pf_s1 = 0.f, pf_s2 = 0.f;
+  int pf_slot = -1;
+  int pf_src[4] = {0, 0, 0, 0};
+  // (uniform base pointer + 32-bit lane offset: the saddr form of global_load; 64-bit lane pointers per array cost a register
+  // pair each and spilled)
+  auto ldf = [](const float* base, uint32_t byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); };
+  auto ldi = [](const int32_t* base, uint32_t byte_off) { return *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(base) + byte_off); };
+  auto prefetch_meta = [&](int rows, bool local) {
+    const uint32_t e4 = (uint32_t)(rows + col) * 4u;
+    const uint32_t r16 = (uint32_t)(rows + 4 * q) * 4u;
+    const int32_t* srcs = local ? a.lt_src : a.rad_src;
+    const u32x4 s4 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(srcs) + r16);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pf_src[r] = (int)s4[r];
+    if (local) {
+      const int sl = ldi(a.type_slot, (uint32_t)ldi(a.lt_type, e4) * 4u);  // (the same for the 16 rows of a tile)
+      pf_slot = sl < 0 ? -2 : sl;                                           // (-2: a type without a polynomial)
+      pf_d = ldf(a.lt_len, e4);
+      pf_s1 = ldf(a.l_scale1, e4);
+      pf_s2 = ldf(a.l_scale2, e4);
+    } else {
+      pf_slot = -1;
+      pf_d = ldf(a.rad_len, e4);
+      pf_s1 = ldf(a.r_scale1, e4);
+      pf_s2 = ldf(a.r_scale2, e4);
+    }
+  };
+  // x[src] values of a group of AG_NODE_GRP channel tiles, two groups in flight
+  static_assert((AG_CONV_NCH / AG_NODE_GRP) % AG_NODE_XD == 0 && AG_NODE_XD >= 2, "ring of x buffers");
+  f32x4 xg[AG_NODE_XD][AG_NODE_GRP];
+  uint32_t xoff[4];
+  auto set_xoff = [&]() {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xoff[r] = ((uint32_t)pf_src[r] * 192u + (uint32_t)col) * 4u;
+  };
+  auto fetch_xg = [&](auto BUF, int g) {
+    constexpr int kb = decltype(BUF)::value;
+    const char* xb = reinterpret_cast<const char*>(a.xs);
+#pragma unroll
+    for (int j = 0; j < AG_NODE_GRP; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (AG_NODE_ABL & 1) xg[kb][j][r] = __uint_as_float(xoff[r] + (uint32_t)(AG_NODE_GRP * g + j));
+        else xg[kb][j][r] = *reinterpret_cast<const float*>(xb + (size_t)xoff[r] + 64 * (AG_NODE_GRP * g + j));
+      }
+    }
+  };
+  // the first AG_NODE_XD - 1 x groups of a tile (requested before the tile starts)
+  auto fetch_first_groups = [&]() {
+    ag_static_for<0, AG_NODE_XD - 1>([&](auto G) { fetch_xg(G, decltype(G)::value); });
+  };
+  const lds_u32x4* wl_l = wl + lane;
+  // CN channel tiles C0 .. C0 + CN - 1 of one coefficient set (pk [12][NKT]: block nt * NKT + t) times the features:
+  // independent accumulator chains with their MFMA passes interleaved; z starts from zero (the first MFMA takes the literal 0)
+  auto mma_tiles = [&](auto base, auto C0_, const AgIn<MODE> (&ph)[NKT], auto& z) {
+    constexpr int C0 = decltype(C0_)::value;
+    constexpr int CN = sizeof(z) / sizeof(f32x4);
+    u32x4 w[CN][NKT][2];
+#pragma unroll
+    for (int j = 0; j < CN; ++j) {
+#pragma unroll
+      for (int t = 0; t < NKT; ++t) {
+        if ((AG_NODE_ABL & 16) && j > 0) {            // (timing experiment: one coefficient block read per group)
+          w[j][t][0] = w[0][t][0];
+          w[j][t][1] = w[0][t][1];
+          continue;
+        }
+        w[j][t][0] = base[(((C0 + j) * NKT + t) * 2) * 64];
+        w[j][t][1] = base[(((C0 + j) * NKT + t) * 2 + 1) * 64];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+      for (int part = 0; part < AgParts<MODE>::n; ++part) {
+#pragma unroll
+        for (int j = 0; j < CN; ++j) {
+          if (AG_NODE_ABL & 2) {
+            if (t == 0 && part == 0) {
+              u32x4 pu;
+              __builtin_memcpy(&pu, &ph[0], 16);
+              z[j] = __builtin_bit_cast(f32x4, w[j][0][0]) * __uint_as_float(pu[0]);
+            }
+          } else if (t == 0 && part == 0) z[j] = ag_block_mma_first<MODE, true>(ph[0], w[j][0]);
+          else ag_block_mma_part<MODE, true>(z[j], ph[t], w[j][t], part);
+        }
+      }
+    }
+  };
+
+  // features of the wave's next tile (its rows' inputs are in pf_*): channel tiles 0..7 are conv1 (features x its lw C),
+  // 8..11 conv2.  A local tile whose type has no polynomial contributes nothing (scale 0)
+  AgIn<MODE> ph1[NKT], ph2[NKT];
+  auto next_features = [&]() {
+    const bool dead = with_local && pf_slot < -1;
+    const float s1 = dead ? 0.0f : pf_s1, s2 = dead ? 0.0f : pf_s2;
+    if (AG_NODE_ABL & 4) {
+#pragma unroll
+      for (int t = 0; t < NKT; ++t) {
+        f32x4 v1[2] = {{pf_d, s1, pf_d, s1}, {s1, pf_d, s1, pf_d}}, v2[2] = {{pf_d, s2, pf_d, s2}, {s2, pf_d, s2, pf_d}};
+        __builtin_memcpy(&ph1[t], v1, 32);
+        __builtin_memcpy(&ph2[t], v2, 32);
+      }
+    } else {
+      ag_poly_features<MODE, NKT>(pf_d, a.two_over_rc, q, ph1, s1);
+      ag_poly_features<MODE, NKT>(pf_d, a.two_over_rc, q, ph2, s2);
+    }
+  };
+  float acc[AG_CONV_NCH], accL[AG_CONV_NCH];
+  // the sums over the wave's quarters, once per target: quarter j of a reduce-scatter ends up with channel tile 4 g + j.
+  // `k`: the target's place in its quad -- its local rows are the quarters q with q >> qshift == k of the quad's local tiles
+  auto finalize = [&](int tgt, int k) {
+    char* dp = reinterpret_cast<char*>(a.agg + (size_t)tgt * 192);       // (uniform)
+    const bool mine = (q >> a.qshift) == k;
+#pragma unroll
+    for (int g = 0; g < AG_CONV_NCH / 4; ++g) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = acc[4 * g + j] + (mine ? accL[4 * g + j] : 0.0f);
+      *reinterpret_cast<float*>(dp + (uint32_t)(16 * (4 * g + q) + col) * 4u) = ag_quarter_reduce_scatter4(v[0], v[1], v[2], v[3]);
+    }
+  };
+
+  int p = p_begin + wave;
+  if (p >= p_end) return;                       // (no barrier below)
+  AG_QUAD_DECL(c_);                             // the wave's current quad
+  AG_QUAD_LOAD(c_, p);
+  bool have_pf = false;
+  while (p < p_end) {
+    const int pn = p + WAVES;
+    AG_QUAD_DECL(x_);                           // ... and its next one
+    if (pn < p_end) AG_QUAD_LOAD(x_, pn);
+    const int ntiles = c_nL + c_n0 + c_n1 + c_n2 + c_n3;
+    const int ntiles_next = x_nL + x_n0 + x_n1 + x_n2 + x_n3;
+    if (ntiles > 0 && !have_pf) {               // cold start (first quad of the wave, or the quad before had no tile)
+      bool loc;
+      const int rows = tile_rows(AG_QUAD_ARGS(c_), 0, loc);
+      prefetch_meta(rows, loc);
+      set_xoff();
+      fetch_first_groups();
+      next_features();
+    }
+#pragma unroll
+    for (int i = 0; i < AG_CONV_NCH; ++i) accL[i] = 0.0f;
+    // the wave's next tile after tile j (of this quad, or the first one of its next quad)
+    auto next_tile = [&](int j, bool& nloc, bool& has_next) -> int {
+      has_next = true;
+      nloc = false;
+      if (j + 1 < ntiles) return tile_rows(AG_QUAD_ARGS(c_), j + 1, nloc);
+      if (ntiles_next > 0) return tile_rows(AG_QUAD_ARGS(x_), 0, nloc);
+      has_next = false;
+      return 0;
+    };
+    // One tile as a software pipeline over its four groups of three channel tiles: the MFMAs of group g + 1 are issued BEFORE
+    // the sums of group g (sum += z x), so that the matrix pipe works while the wave's VALU does the sums; the x values of
+    // group g + 2 are requested into the buffer the sums have just freed; the next tile's per-row inputs are requested at the
+    // start, its first x group and -- behind the last group's MFMAs -- its features (ph1 / ph2 are carried from tile to
+    // tile) at the end.  `base`: the tile's coefficient set (LDS or global), `S`: the sums it adds to.
+    auto tile = [&](int j, auto base, float (&S)[AG_CONV_NCH]) {
+      bool nloc, has_next;
+      const int nrows = next_tile(j, nloc, has_next);
+      if (has_next) prefetch_meta(nrows, nloc);
+      auto mma_g = [&](auto GG, f32x4 (&z)[AG_NODE_GRP]) {
+        constexpr int c0 = AG_NODE_GRP * decltype(GG)::value;
+        // channel tiles 0..7 take conv1's features, 8..11 conv2's (a group of three straddles the boundary once: 6, 7 | 8)
+        if constexpr (c0 + AG_NODE_GRP <= 8) {
+          mma_tiles(base, std::integral_constant<int, c0>{}, ph1, z);
+        } else if constexpr (c0 >= 8) {
+          mma_tiles(base, std::integral_constant<int, c0>{}, ph2, z);
+        } else {
+          static_assert(AG_NODE_GRP == 3 && c0 == 6, "group layout");
+          f32x4 (&za)[2] = *reinterpret_cast<f32x4 (*)[2]>(&z[0]);
+          f32x4 (&zb)[1] = *reinterpret_cast<f32x4 (*)[1]>(&z[2]);
+          mma_tiles(base, std::integral_constant<int, 6>{}, ph1, za);
+          mma_tiles(base, std::integral_constant<int, 8>{}, ph2, zb);
+        }
+      };
+      auto sums = [&](auto GG, const f32x4 (&z)[AG_NODE_GRP]) {
+        constexpr int gg = decltype(GG)::value;
+#pragma unroll
+        for (int jj = 0; jj < AG_NODE_GRP; ++jj) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if ((AG_NODE_ABL & 8) && r) continue;
+            S[AG_NODE_GRP * gg + jj] = fmaf(z[jj][r], xg[gg % AG_NODE_XD][jj][r], S[AG_NODE_GRP * gg + jj]);
+          }
+          // (pins the sum to this step: the optimiser otherwise sinks all 48 FMAs of a tile below its last MFMA -- nothing
+          // needs the sums before the target is complete -- and the wave then waits for x loads and MFMAs with nothing to do)
+          asm volatile("" : "+v"(S[AG_NODE_GRP * gg + jj]));
+        }
+      };
+      f32x4 z[2][AG_NODE_GRP];
+      // (fences between the steps: the scheduler otherwise hoists every group's coefficient reads to the top of the tile and
+      // spills; inside a step it is free to run the sums beside the MFMAs)
+      constexpr int XD = AG_NODE_XD;
+      fetch_xg(std::integral_constant<int, XD - 1>{}, XD - 1);
+      mma_g(std::integral_constant<int, 0>{}, z[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      ag_static_for<1, NG>([&](auto G) {
+        constexpr int g = decltype(G)::value;
+        mma_g(G, z[g & 1]);
+        sums(std::integral_constant<int, g - 1>{}, z[(g - 1) & 1]);
+        // the buffer the sums have just freed takes the group XD - 1 steps ahead: of this tile, or -- once all of this tile's
+        // gathers are out and xoff is free -- of the wave's next tile (whose features follow the last request)
+        if constexpr (g + XD - 1 < NG) {
+          fetch_xg(std::integral_constant<int, (g - 1) % XD>{}, g + XD - 1);
+        } else if (has_next) {
+          if constexpr (g + XD - 1 == NG) set_xoff();
+          fetch_xg(std::integral_constant<int, (g - 1) % XD>{}, g + XD - 1 - NG);
+          if constexpr (g == NG - 1) next_features();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      sums(std::integral_constant<int, NG - 1>{}, z[(NG - 1) & 1]);
+      have_pf = has_next;
+    };
+    int j = 0;
+#ifndef AG_NODE_NO_LOCAL        // (timing experiment: the kernel without its local tiles)
+    for (; j < c_nL; ++j) {
+      // the tile's set: one of the LDS-resident ones, or -- a rare type -- straight from L2; a type without a polynomial ran
+      // with scale 0 (next_features) against the radius set
+      const int slot = __builtin_amdgcn_readfirstlane(pf_slot);
+      if (slot >= a.lds_slots) tile(j, reinterpret_cast<const u32x4*>(a.poly_typed) + (size_t)slot * SET + lane, accL);
+      else tile(j, wl_l + (size_t)(slot >= 0 ? 1 + slot : 0) * SET, accL);
+    }
+#endif
+#pragma unroll
+    for (int i = 0; i < AG_CONV_NCH; ++i) acc[i] = 0.0f;
+    // (the four targets one after the other through shifting copies: indexing the quad's fields by k would put it in scratch)
+    int ta = c_t0, tb = c_t1, tc = c_t2, td = c_t3, na = c_n0, nb = c_n1, nc = c_n2, nd = c_n3;
+#pragma nounroll
+    for (int k = 0; k < 4; ++k) {
+      if (ta >= 0) {
+        for (int u = 0; u < na; ++u, ++j) tile(j, wl_l, acc);
+        finalize(ta, k);                        // the quad's k-th target is complete: write it
+#pragma unroll
+        for (int i = 0; i < AG_CONV_NCH; ++i) acc[i] = 0.0f;
+      }
+      ta = tb, tb = tc, tc = td, td = -1;
+      na = nb, nb = nc, nc = nd, nd = 0;
+    }
+    if (ntiles == 0) have_pf = false;
+    p = pn;
+    c_nL = x_nL, c_lt0 = x_lt0, c_t0 = x_t0, c_t1 = x_t1, c_t2 = x_t2, c_t3 = x_t3, c_n0 = x_n0, c_n1 = x_n1, c_n2 = x_n2, c_n3 = x_n3;
+  }
+#undef AG_QUAD_DECL
+#undef AG_QUAD_LOAD
+#undef AG_QUAD_ARGS
+}
+
+
+// ------------------------------------------------------------------------------ the same with the radius rows in low-rank form
+// (include/agdiff_hip.h: agdiff_conv_params_t.filt_lr_*; split-bf16 mode, 32 terms).  The 192 filter functions of a block lie,
+// to 1e-6, in the span of 16 functions B_j(d) = sum_k phi_k(d) U[k][j]:  W_c(d) = sum_j B_j(d) C[j][c].  Then
+//     agg[i][c] = sum_e s_e W_c(d_e) x[src_e][c] = sum_j C[j][c] * M[j][c],     M[j][c] = sum_e (s_e B_j(d_e)) x[src_e][c]
+// and M -- a contraction over the target's EDGES -- is what the matrix cores do.  Per 16-row radius tile (all rows of one
+// target) and 16-channel tile ONE v_mfma_f32_16x16x32_bf16 per operand part:
+//   * K = 32 = the tile's 16 rows x {hi, lo}: the B operand of lane (q, col) is the four split-bf16 WORDS it gathers,
+//     x[src of row 4 q + r][16 c + col] from ws->xsp (bits 31:16 = bf16(x), 15:0 = bf16(x - hi); written by the node stage) --
+//     each word IS two consecutive K elements, nothing to shuffle or convert;
+//   * the A operand holds the scaled basis value a = s_e B_j(d_e) of row 4 q + r in BOTH K slots of that row, so one MFMA
+//     yields a (x_hi + x_lo); two passes, A = (bf16(a), bf16(a)) and (bf16(a - hi), same), give all four partial products.
+//     a comes straight out of the first stage: the flipped product Phi . U leaves lane (q, j) with rows 4 q .. 4 q + 3 of basis
+//     function j, which are exactly the K elements of k-group q;
+//   * per tile 3 MFMAs (first stage) + 24 (second stage) instead of 36, NO per-row arithmetic on the VALU between the gathers
+//     and the MFMAs (the full form spends 48 FMAs per tile there), 2 coefficient reads from LDS instead of 24; per TARGET one
+//     contraction with C (48 FMAs, 12 LDS reads) in front of the reduce-scatter over the quarters the full form needs as well.
+// Local quad tiles keep the full per-type polynomial form (k_cfconv_node's tile body: their 16 rows belong to four targets,
+// so a contraction over the rows would mix them) and add into accL as before.  A wave walks the items of its quads in order --
+// local tiles, then the radius tiles of the first .. fourth target -- and requests the per-row inputs of the NEXT item at the
+// top of the current one; the working set of a kind is (re)built where that kind's phase starts, so that it does not stay
+// alive through the other kind's phase.
+#ifndef AG_LR_DEPTH
+#define AG_LR_DEPTH 4            // channel tiles of x gathers in flight per radius tile (ring of buffers; must divide 12)
+#endif
+template <int WAVES>
+__global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node_lr(NodeConvArgs a) {
+  constexpr int MODE = AG_BF3, NKT = 1;
+  extern __shared__ u32x4 ag_nodeconv_lr_smem[];
+  lds_u32x4* Lc = (lds_u32x4*)ag_nodeconv_lr_smem;      // C by lane: 12 x 64 units
+  lds_u32x4* Lu = Lc + AG_CONV_NCH * 64;                // U block: 128 units
+  lds_u32x4* wl = Lu + 128;                             // typed sets
+  constexpr int SET = AG_CONV_NCH * NKT * 128;
+  constexpr int NG = AG_CONV_NCH / AG_NODE_GRP;
+  constexpr int D = AG_LR_DEPTH;
+  static_assert(AG_CONV_NCH % D == 0, "ring of gather buffers");
+  ag_copy_lds(Lc, reinterpret_cast<const u32x4*>(a.lr_c), AG_CONV_NCH * 64);
+  ag_copy_lds(Lu, reinterpret_cast<const u32x4*>(a.lr_u), 128);
+  if (a.lds_slots > 0) ag_copy_lds(wl, reinterpret_cast<const u32x4*>(a.poly_typed), a.lds_slots * SET);
+  __syncthreads();
+  int lane = ag_lane();
+  asm volatile("" : "+v"(lane));
+  const int q = lane >> 4, col = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wg = (gridDim.x % 8 == 0) ? (int)((blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8) : (int)blockIdx.x;
+  const int per_wg = (a.num_quads + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int p_begin = wg * per_wg;
+  const int p_end = (p_begin + per_wg < a.num_quads) ? p_begin + per_wg : a.num_quads;
+  const bool with_local = a.num_slots > 0;
+  auto tiles_of = [&](int t) { return (t >= 0) ? (a.rad_cnt[t] + AG_TW - 1) / AG_TW : 0; };
+  auto ldf = [](const float* base, uint32_t byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); };
+  auto ldi = [](const int32_t* base, uint32_t byte_off) { return *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(base) + byte_off); };
+
+#define AG_QUAD_DECL(P) int P##nL = 0, P##lt0 = 0, P##t0 = -1, P##t1 = -1, P##t2 = -1, P##t3 = -1, P##n0 = 0, P##n1 = 0, P##n2 = 0, P##n3 = 0
+#define AG_QUAD_LOAD(P, p)                                                              \
+  do {                                                                                  \
+    P##t0 = a.quad_tgt[4 * (p)];                                                        \
+    P##t1 = a.quad_tgt[4 * (p) + 1];                                                    \
+    P##t2 = a.quad_tgt[4 * (p) + 2];                                                    \
+    P##t3 = a.quad_tgt[4 * (p) + 3];                                                    \
+    P##n0 = tiles_of(P##t0);                                                            \
+    P##n1 = tiles_of(P##t1);                                                            \
+    P##n2 = tiles_of(P##t2);                                                            \
+    P##n3 = tiles_of(P##t3);                                                            \
+    P##lt0 = with_local ? a.lt_ptr[(p)] : 0;                                            \
+    P##nL = with_local ? a.lt_ptr[(p) + 1] - P##lt0 : 0;                                \
+  } while (0)
+  // An ITEM of a wave's walk: kind 0 none, 1 a local quad tile (first row in topo->lt_*), 2 a radius tile (first row in
+  // ws->rad_*).  first_rad: the first radius tile of targets t0.. of a quad (kind 0: none has one).
+  auto first_rad = [&](int t0, int t1, int t2, int t3, int n0, int n1, int n2, int n3, int& kind, int& r0) {
+    int t = -1;
+    if (n0 > 0) t = t0;
+    else if (n1 > 0) t = t1;
+    else if (n2 > 0) t = t2;
+    else if (n3 > 0) t = t3;
+    kind = (t >= 0) ? 2 : 0;
+    r0 = t * AGDIFF_RAD_STRIDE;
+  };
+
+  // ---- per-row inputs of the wave's NEXT item, requested at the top of the current one.  ONE set of registers for both kinds
+  // (an item has one successor): a local tile's length, two scales, type slot and four sources -- or a radius tile's length and
+  // four sources (its scales are requested when its operands are built).
+  uint32_t nx[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) nx[i] = 0u;
+  auto prefetch_local = [&](int rows) {
+    const uint32_t e4 = (uint32_t)(rows + col) * 4u;
+    const uint32_t r16 = (uint32_t)(rows + 4 * q) * 4u;
+    const u32x4 s4 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.lt_src) + r16);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) nx[4 + r] = s4[r];
+    const int sl = ldi(a.type_slot, (uint32_t)ldi(a.lt_type, e4) * 4u);
+    nx[3] = (uint32_t)(sl < 0 ? -2 : sl);
+    nx[0] = __float_as_uint(ldf(a.lt_len, e4));
+    nx[1] = __float_as_uint(ldf(a.l_scale1, e4));
+    nx[2] = __float_as_uint(ldf(a.l_scale2, e4));
+  };
+  // inputs of a radius tile: R[0] its length (row `col`), R[1..4] the sources, R[5..8] / R[9..12] the two scales of rows
+  // 4 q .. 4 q + 3.  R1 = the wave's NEXT radius tile, R2 = the one after it (inside a quad the inputs are requested two tiles
+  // ahead: a radius tile is short -- 24 MFMAs -- and these rows are streamed once from HBM)
+  uint32_t R1[13], R2[13];
+#pragma unroll
+  for (int i = 0; i < 13; ++i) R1[i] = R2[i] = 0u;
+  auto load_rad = [&](uint32_t (&R)[13], int r0) {
+    R[0] = __float_as_uint(ldf(a.rad_len, (uint32_t)(r0 + col) * 4u));
+    const uint32_t o = (uint32_t)(r0 + 4 * q) * 4u;
+    const u32x4 s0 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.rad_src) + o);
+    const u32x4 s1 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.r_scale1) + o);
+    const u32x4 s2 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.r_scale2) + o);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      R[1 + r] = s0[r];
+      R[5 + r] = s1[r];
+      R[9 + r] = s2[r];
+    }
+  };
+  auto prefetch_item = [&](int kind, int r0) {
+    if (kind == 1) prefetch_local(r0);
+    else if (kind == 2) load_rad(R1, r0);
+  };
+  // ---- working set of the local tiles (k_cfconv_node's): x groups, byte offsets, features of the tile about to run
+  f32x4 xg[AG_NODE_XD][AG_NODE_GRP];
+  uint32_t xoff[4];
+  float lt_d = 0.f, lt_s1 = 0.f, lt_s2 = 0.f;
+  int lt_slot = -1;
+  auto take_local = [&]() {              // nx -> the tile about to run: offsets of its four rows, its scalars
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xoff[r] = (nx[4 + r] * 192u + (uint32_t)col) * 4u;
+    lt_d = __uint_as_float(nx[0]);
+    lt_s1 = __uint_as_float(nx[1]);
+    lt_s2 = __uint_as_float(nx[2]);
+    lt_slot = (int)nx[3];
+  };
+  auto fetch_xg = [&](auto BUF, int g) {
+    constexpr int kb = decltype(BUF)::value;
+    const char* xb = reinterpret_cast<const char*>(a.xs);
+#pragma unroll
+    for (int j = 0; j < AG_NODE_GRP; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xg[kb][j][r] = *reinterpret_cast<const float*>(xb + (size_t)xoff[r] + 64 * (AG_NODE_GRP * g + j));
+    }
+  };
+  auto fetch_first_groups = [&]() {
+    ag_static_for<0, AG_NODE_XD - 1>([&](auto G) { fetch_xg(G, decltype(G)::value); });
+  };
+  AgIn<MODE> ph1[NKT], ph2[NKT];
+  auto local_features = [&]() {
+    const bool dead = lt_slot < -1;
+    ag_poly_features<MODE, NKT>(lt_d, a.two_over_rc, q, ph1, dead ? 0.0f : lt_s1);
+    ag_poly_features<MODE, NKT>(lt_d, a.two_over_rc, q, ph2, dead ? 0.0f : lt_s2);
+  };
+  // ---- working set of the radius tiles: A operands for conv1 (channel tiles 0..7) and conv2 (8..11), hi and lo part (dword r =
+  // the value of row 4 q + r in both of its K slots), byte offsets of the lane's four rows into xsp, the ring of gathered words
+  uint32_t A1h[4], A1l[4], A2h[4], A2l[4];
+  uint32_t po[4];
+  uint32_t gw[D][4];
+  const lds_u32x4* Lu_l = Lu + lane;
+  auto dup_split = [&](float v, uint32_t& hw, uint32_t& lw) {          // (bf16(v), bf16(v)) and the same of v - hi
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    hw = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{v, v}, bf16x2));
+    const float l = v - __uint_as_float(hw & 0xFFFF0000u);
+    lw = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{l, l}, bf16x2));
+  };
+  auto gather_c = [&](auto SLOT, int c) {
+    constexpr int sl = decltype(SLOT)::value;
+    const char* xb = reinterpret_cast<const char*>(a.xsp);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gw[sl][r] = *reinterpret_cast<const uint32_t*>(xb + (size_t)po[r] + 64 * c);
+  };
+  // R1 -> the radius tile about to run: byte offsets, the first D gathers, features -> first stage (basis values of the rows)
+  // -> scaled operand words
+  auto rad_bottom = [&]() {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) po[r] = (R1[1 + r] * 192u + (uint32_t)col) * 4u;
+    ag_static_for<0, D>([&](auto S) { gather_c(S, decltype(S)::value); });
+    u32x4 wu[2];
+    wu[0] = Lu_l[0];
+    wu[1] = Lu_l[64];
+    AgIn<MODE> f[1];
+    ag_poly_features<MODE, 1>(__uint_as_float(R1[0]), a.two_over_rc, q, f);
+    f32x4 B = ag_block_mma_first<MODE, true>(f[0], wu);
+    ag_block_mma_part<MODE, true>(B, f[0], wu, 1);
+    ag_block_mma_part<MODE, true>(B, f[0], wu, 2);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      dup_split(B[r] * __uint_as_float(R1[5 + r]), A1h[r], A1l[r]);
+      dup_split(B[r] * __uint_as_float(R1[9 + r]), A2h[r], A2l[r]);
+    }
+  };
+
+  float accL[AG_CONV_NCH];
+  const lds_u32x4* Lc_l = Lc + lane;
+  // target complete: contraction with C, the local tiles' share from this target's quarter(s), reduce-scatter over the quarters
+  auto finalize = [&](int tgt, int k, bool have_m, const f32x4 (&M)[AG_CONV_NCH]) {
+    char* dp = reinterpret_cast<char*>(a.agg + (size_t)tgt * 192);
+    const bool mine = (q >> a.qshift) == k;
+#pragma unroll
+    for (int g = 0; g < AG_CONV_NCH / 4; ++g) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = 4 * g + j;
+        float s = mine ? accL[c] : 0.0f;
+        if (have_m) {
+          const f32x4 cc = __builtin_bit_cast(f32x4, Lc_l[c * 64]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s = fmaf(cc[r], M[c][r], s);
+        }
+        v[j] = s;
+      }
+      *reinterpret_cast<float*>(dp + (uint32_t)(16 * (4 * g + q) + col) * 4u) = ag_quarter_reduce_scatter4(v[0], v[1], v[2], v[3]);
+    }
+  };
+
+  int p = p_begin + wave;
+  if (p >= p_end) return;
+  AG_QUAD_DECL(c_);
+  AG_QUAD_LOAD(c_, p);
+  const lds_u32x4* wl_l = wl + lane;
+  bool ready = false;          // nx holds the inputs of the current quad's first item (requested by the item before it)
+  while (p < p_end) {
+    const int pn = p + WAVES;
+    AG_QUAD_DECL(x_);
+    if (pn < p_end) AG_QUAD_LOAD(x_, pn);
+    // first item of the wave's next quad, first radius tile of this one
+    int xk = 0, xr0 = 0;
+    if (x_nL > 0) xk = 1, xr0 = x_lt0 * AG_TW;
+    else first_rad(x_t0, x_t1, x_t2, x_t3, x_n0, x_n1, x_n2, x_n3, xk, xr0);
+    int fk, fr0;
+    first_rad(c_t0, c_t1, c_t2, c_t3, c_n0, c_n1, c_n2, c_n3, fk, fr0);
+    const int e3l = c_n0 + c_n1 + c_n2 + c_n3;
+#pragma unroll
+    for (int i = 0; i < AG_CONV_NCH; ++i) accL[i] = 0.0f;
+
+    // ---- a local quad tile (k_cfconv_node's tile body); (nk, nr0) = the item after it: its inputs are requested here; a
+    // following LOCAL tile is also prepared here (offsets, first x groups, features)
+    auto local_tile = [&](auto base, int nk, int nr0) {
+      prefetch_item(nk, nr0);
+      auto mma_tiles = [&](auto C0_, const AgIn<MODE> (&ph)[NKT], auto& z) {
+        constexpr int C0 = decltype(C0_)::value;
+        constexpr int CN = sizeof(z) / sizeof(f32x4);
+        u32x4 w[CN][2];
+#pragma unroll
+        for (int j = 0; j < CN; ++j) {
+          w[j][0] = base[((C0 + j) * 2) * 64];
+          w[j][1] = base[((C0 + j) * 2 + 1) * 64];
+        }
+#pragma unroll
+        for (int part = 0; part < AgParts<MODE>::n; ++part) {
+#pragma unroll
+          for (int j = 0; j < CN; ++j) {
+            if (part == 0) z[j] = ag_block_mma_first<MODE, true>(ph[0], w[j]);
+            else ag_block_mma_part<MODE, true>(z[j], ph[0], w[j], part);
+          }
+        }
+      };
+      auto mma_g = [&](auto GG, f32x4 (&z)[AG_NODE_GRP]) {
+        constexpr int c0 = AG_NODE_GRP * decltype(GG)::value;
+        if constexpr (c0 + AG_NODE_GRP <= 8) {
+          mma_tiles(std::integral_constant<int, c0>{}, ph1, z);
+        } else if constexpr (c0 >= 8) {
+          mma_tiles(std::integral_constant<int, c0>{}, ph2, z);
+        } else {
+          static_assert(AG_NODE_GRP == 3 && c0 == 6, "group layout");
+          f32x4 (&za)[2] = *reinterpret_cast<f32x4 (*)[2]>(&z[0]);
+          f32x4 (&zb)[1] = *reinterpret_cast<f32x4 (*)[1]>(&z[2]);
+          mma_tiles(std::integral_constant<int, 6>{}, ph1, za);
+          mma_tiles(std::integral_constant<int, 8>{}, ph2, zb);
+        }
+      };
+      auto sums = [&](auto GG, const f32x4 (&z)[AG_NODE_GRP]) {
+        constexpr int gg = decltype(GG)::value;
+#pragma unroll
+        for (int jj = 0; jj < AG_NODE_GRP; ++jj) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) accL[AG_NODE_GRP * gg + jj] = fmaf(z[jj][r], xg[gg % AG_NODE_XD][jj][r], accL[AG_NODE_GRP * gg + jj]);
+          asm volatile("" : "+v"(accL[AG_NODE_GRP * gg + jj]));
+        }
+      };
+      f32x4 z[2][AG_NODE_GRP];
+      constexpr int XD = AG_NODE_XD;
+      fetch_xg(std::integral_constant<int, XD - 1>{}, XD - 1);
+      mma_g(std::integral_constant<int, 0>{}, z[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      ag_static_for<1, NG>([&](auto G) {
+        constexpr int g = decltype(G)::value;
+        mma_g(G, z[g & 1]);
+        sums(std::integral_constant<int, g - 1>{}, z[(g - 1) & 1]);
+        if constexpr (g + XD - 1 < NG) {
+          fetch_xg(std::integral_constant<int, (g - 1) % XD>{}, g + XD - 1);
+        } else if (nk == 1) {
+          if constexpr (g + XD - 1 == NG) take_local();
+          fetch_xg(std::integral_constant<int, (g - 1) % XD>{}, g + XD - 1 - NG);
+          if constexpr (g == NG - 1) local_features();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      sums(std::integral_constant<int, NG - 1>{}, z[(NG - 1) & 1]);
+    };
+    // ---- a radius tile; FIRST: the target's first one (M starts from zero).  `has1`: another radius tile of this quad follows
+    // (its inputs are in R1; its operands and first gathers are produced at the bottom); `r2`: first row of the tile after
+    // that one (its inputs are requested here into R2), or -1; without a following tile (nk, nr0) = the next quad's first item
+    auto rad_tile = [&](auto FIRST, f32x4 (&M)[AG_CONV_NCH], bool has1, int r2, int nk, int nr0) {
+      constexpr bool first = decltype(FIRST)::value;
+      const bf16x8 a1h = __builtin_bit_cast(bf16x8, u32x4{A1h[0], A1h[1], A1h[2], A1h[3]});
+      const bf16x8 a1l = __builtin_bit_cast(bf16x8, u32x4{A1l[0], A1l[1], A1l[2], A1l[3]});
+      const bf16x8 a2h = __builtin_bit_cast(bf16x8, u32x4{A2h[0], A2h[1], A2h[2], A2h[3]});
+      const bf16x8 a2l = __builtin_bit_cast(bf16x8, u32x4{A2l[0], A2l[1], A2l[2], A2l[3]});
+      if (r2 >= 0) load_rad(R2, r2);
+      else if (!has1) prefetch_item(nk, nr0);
+      ag_static_for<0, AG_CONV_NCH>([&](auto CC) {
+        constexpr int c = decltype(CC)::value;
+        constexpr int sl = c % D;
+        const bf16x8 xw = __builtin_bit_cast(bf16x8, u32x4{gw[sl][0], gw[sl][1], gw[sl][2], gw[sl][3]});
+        if constexpr (first) M[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c < 8 ? a1h : a2h, xw, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        else M[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c < 8 ? a1h : a2h, xw, M[c], 0, 0, 0);
+        M[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c < 8 ? a1l : a2l, xw, M[c], 0, 0, 0);
+        if constexpr (c + D < AG_CONV_NCH) gather_c(std::integral_constant<int, sl>{}, c + D);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if (has1) {
+        rad_bottom();                       // the next radius tile of this quad, from R1
+        if (r2 >= 0) {
+#pragma unroll
+          for (int i = 0; i < 13; ++i) R1[i] = R2[i];
+        }
+      }
+    };
+
+    // ---- local tiles of the quad
+    if (c_nL > 0) {
+      if (!ready) prefetch_local(c_lt0 * AG_TW);       // cold: the wave's first quad, or the quad before had no item
+      take_local();
+      fetch_first_groups();
+      local_features();
+      for (int j = 0; j < c_nL; ++j) {
+        int nk, nr0;
+        if (j + 1 < c_nL) nk = 1, nr0 = (c_lt0 + j + 1) * AG_TW;
+        else if (e3l > 0) nk = 2, nr0 = fr0;
+        else nk = xk, nr0 = xr0;
+        // the tile's set: LDS-resident or -- a rare type -- from L2; a type without a polynomial runs with scale 0
+        // (local_features) against set 0
+        const int slot = __builtin_amdgcn_readfirstlane(lt_slot);
+        const int sset = slot >= 0 ? slot : 0;
+        if (sset >= a.lds_slots) local_tile(reinterpret_cast<const u32x4*>(a.poly_typed) + (size_t)sset * SET + lane, nk, nr0);
+        else local_tile(wl_l + (size_t)sset * SET, nk, nr0);
+      }
+    }
+    // ---- radius tiles: a flat walk over the quad's e3 = n0 + n1 + n2 + n3 tiles (tile i of the walk: rad_row(i)); a target is
+    // written when its last tile is done, targets without radius tiles when their turn comes (local share only, or zeros).
+    // (The tiles' working set is built in front of the loop that uses it -- the register allocator then sees it defined on
+    // every path to its uses and does not keep it alive through the local tiles.)
+    const int e0 = c_n0, e1 = e0 + c_n1, e2 = e1 + c_n2, e3 = e2 + c_n3;
+    auto rad_row = [&](int i) -> int {
+      if (i < e0) return c_t0 * AGDIFF_RAD_STRIDE + AG_TW * i;
+      if (i < e1) return c_t1 * AGDIFF_RAD_STRIDE + AG_TW * (i - e0);
+      if (i < e2) return c_t2 * AGDIFF_RAD_STRIDE + AG_TW * (i - e1);
+      return c_t3 * AGDIFF_RAD_STRIDE + AG_TW * (i - e2);
+    };
+    const f32x4 none[AG_CONV_NCH] = {};
+    int kdone = 0;                        // targets of the quad written so far
+    auto flush_empty = [&](int upto) {     // targets kdone .. upto - 1 have no radius tile
+      for (; kdone < upto; ++kdone) {
+        const int t = kdone == 0 ? c_t0 : kdone == 1 ? c_t1 : kdone == 2 ? c_t2 : c_t3;
+        if (t >= 0) finalize(t, kdone, false, none);
+      }
+    };
+    if (e3 > 0) {
+      if (c_nL == 0 && !ready) load_rad(R1, rad_row(0));       // cold
+      rad_bottom();                                            // operands and first gathers of the quad's first radius tile
+      if (e3 > 1) load_rad(R1, rad_row(1));                    // (R1 from now on: the tile after the current one)
+      f32x4 M[AG_CONV_NCH];
+      for (int i = 0; i < e3; ++i) {
+        const bool first_t = i == 0 || i == e0 || i == e1 || i == e2;
+        const bool has1 = i + 1 < e3;
+        const int r2 = (i + 2 < e3) ? rad_row(i + 2) : -1;
+        if (first_t) rad_tile(std::true_type{}, M, has1, r2, xk, xr0);
+        else rad_tile(std::false_type{}, M, has1, r2, xk, xr0);
+        if (i + 1 == e0 || i + 1 == e1 || i + 1 == e2 || i + 1 == e3) {       // the tile's target is complete
+          const int kk = i < e0 ? 0 : i < e1 ? 1 : i < e2 ? 2 : 3;
+          flush_empty(kk);
+          finalize(kk == 0 ? c_t0 : kk == 1 ? c_t1 : kk == 2 ? c_t2 : c_t3, kk, true, M);
+          kdone = kk + 1;
+        }
+      }
+    }
+    flush_empty(4);
+    ready = (c_nL > 0 || e3 > 0) && xk != 0;       // (the quad's last item requested the next quad's first item's inputs)
+    p = pn;
+    c_nL = x_nL, c_lt0 = x_lt0, c_t0 = x_t0, c_t1 = x_t1, c_t2 = x_t2, c_t3 = x_t3, c_n0 = x_n0, c_n1 = x_n1, c_n2 = x_n2, c_n3 = x_n3;
+  }
+#undef AG_QUAD_DECL
+#undef AG_QUAD_LOAD
+}
+
+#ifndef AG_NODECONV_WAVES
+#define AG_NODECONV_WAVES 12     // ~165 VGPRs: three waves per SIMD
+#endif
+#ifndef AG_NODECONV_LR_WAVES
+#define AG_NODECONV_LR_WAVES 8
+#endif
+int launch_cfconv_node_lr(const NodeConvArgs& a, int64_t wgs, size_t smem, void* stream) {
+  static std::atomic<uint64_t> attr_done{0};
+  if (!ag_allow_big_lds(attr_done, (size_t)160 * 1024, k_cfconv_node_lr<AG_NODECONV_LR_WAVES>)) return AGDIFF_ERR_LAUNCH;
+  k_cfconv_node_lr<AG_NODECONV_LR_WAVES><<<dim3((unsigned)wgs), dim3(64 * AG_NODECONV_LR_WAVES), smem, (hipStream_t)stream>>>(a);
+  AG_CHECK_LAUNCH();
+  return AGDIFF_OK;
+}
+template <int MODE, int NKT>
+int launch_cfconv_node_t(const NodeConvArgs& a, int64_t wgs, size_t smem, void* stream) {
+  static std::atomic<uint64_t> attr_done{0};
+  if (!ag_allow_big_lds(attr_done, (size_t)160 * 1024, k_cfconv_node<MODE, NKT, AG_NODECONV_WAVES>)) return AGDIFF_ERR_LAUNCH;
+  k_cfconv_node<MODE, NKT, AG_NODECONV_WAVES><<<dim3((unsigned)wgs), dim3(64 * AG_NODECONV_WAVES), smem, (hipStream_t)stream>>>(a);
+  AG_CHECK_LAUNCH();
+  return AGDIFF_OK;
+}
+}  // namespace
+
+extern "C" int agdiff_cfconv_node(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t k,
+                                  void* stream) {
+  if (!p || !topo || !ws || k < 0 || k >= p->num_convs) return AGDIFF_ERR_ARG;
+  if (p->poly_kt < 1 || p->poly_kt > AGDIFF_POLY_MAX_KT || !p->conv[k].filt_poly_pk) return AGDIFF_ERR_ARG;
+  if (!ws->rad_cnt || !ws->rad_src || !ws->rad_len || !ws->r_scale || !ws->xs || !ws->agg || !topo->quad_tgt ||
+      topo->num_quads <= 0 || (topo->group_targets != 4 && topo->group_targets != 2 && topo->group_targets != 1))
+    return AGDIFF_ERR_ARG;
+  if (topo->num_nodes <= 0) return AGDIFF_OK;
+  if (topo->num_nodes * (int64_t)AGDIFF_RAD_STRIDE >= (1ll << 31)) return AGDIFF_ERR_LIMIT;
+  const bool local = topo->num_local > 0 && agdiff_local_poly_enabled(p, topo, ws) != 0;   // (1 all, 2 the slotted types' edges)
+  if (local && !p->conv[k].filt_poly_typed_pk) return AGDIFF_ERR_ARG;
+  NodeConvArgs a;
+  a.poly_rad = p->conv[k].filt_poly_pk;
+  a.poly_typed = local ? p->conv[k].filt_poly_typed_pk : nullptr;
+  a.type_slot = p->poly_type_slot;
+  a.num_slots = local ? p->poly_num_slots : 0;
+  // coefficient sets in LDS: the radius edges' one, then as many typed ones as fit (5 of 24 KiB at poly_kt 1, 2 of 48 KiB at 2)
+  const size_t set_bytes = (size_t)AG_CONV_NCH * p->poly_kt * 2048;
+  int max_sets = (int)(((size_t)160 * 1024) / set_bytes);
+  if (p->tune_poly_lds_sets > 0 && p->tune_poly_lds_sets < max_sets) max_sets = p->tune_poly_lds_sets;
+  a.lds_slots = a.num_slots < max_sets - 1 ? a.num_slots : max_sets - 1;
+  a.rad_cnt = ws->rad_cnt;
+  a.rad_src = ws->rad_src;
+  a.rad_len = ws->rad_len;
+  const size_t rpad = (size_t)topo->num_nodes * AGDIFF_RAD_STRIDE;
+  a.r_scale1 = ws->r_scale + (size_t)(2 * k) * rpad;
+  a.r_scale2 = ws->r_scale + (size_t)(2 * k + 1) * rpad;
+  a.quad_tgt = topo->quad_tgt;
+  a.lt_ptr = topo->lt_ptr;
+  a.lt_src = topo->lt_src;
+  a.lt_type = topo->lt_type;
+  a.lt_len = ws->lt_len;
+  const size_t tpad = (size_t)topo->num_local_tiles * AG_TW;
+  a.l_scale1 = local ? ws->lt_scale + (size_t)(2 * k) * tpad : nullptr;
+  a.l_scale2 = local ? ws->lt_scale + (size_t)(2 * k + 1) * tpad : nullptr;
+  a.xs = ws->xs;
+  a.xsp = nullptr;
+  a.lr_u = a.lr_c = nullptr;
+  a.agg = ws->agg;
+  a.n = (int32_t)topo->num_nodes;
+  a.num_quads = (int32_t)topo->num_quads;
+  a.qshift = topo->group_targets == 4 ? 0 : topo->group_targets == 2 ? 1 : 2;
+  a.two_over_rc = 2.0f / p->cutoff;
+  int64_t wgs = (a.num_quads + AG_NODECONV_WAVES - 1) / AG_NODECONV_WAVES;
+  if (wgs > 256) wgs = 256;
+  // radius rows in low-rank form (split-bf16, 32 terms, factors accepted by the host, x available as split words)
+  const bool lowrank = p->poly_lowrank && !p->tune_lowrank_off && p->precision == AG_BF3 && p->poly_kt == 1 && ws->xsp &&
+                       p->conv[k].filt_lr_u_pk && p->conv[k].filt_lr_c;
+  if (lowrank) {
+    a.xsp = ws->xsp;
+    a.lr_u = p->conv[k].filt_lr_u_pk;
+    a.lr_c = p->conv[k].filt_lr_c;
+    const size_t fixed = (size_t)(AG_CONV_NCH * 64 + 128) * 16;           // C by lane + the U block
+    int fit = (int)(((size_t)160 * 1024 - fixed) / set_bytes);
+    if (p->tune_poly_lds_sets > 0 && p->tune_poly_lds_sets - 1 < fit) fit = p->tune_poly_lds_sets - 1;
+    a.lds_slots = a.num_slots < fit ? a.num_slots : fit;
+    ag_log_variant(ws, AGDIFF_VAR_CFCONV_NODE | AGDIFF_VAR_CFCONV_LOWRANK | (local ? AGDIFF_VAR_CFCONV_NODE_LOCAL : 0) |
+                           (a.lds_slots < a.num_slots ? AGDIFF_VAR_POLY_L2_SETS : 0));
+    int64_t wgs_lr = (a.num_quads + AG_NODECONV_LR_WAVES - 1) / AG_NODECONV_LR_WAVES;
+    if (wgs_lr > 256) wgs_lr = 256;
+    return launch_cfconv_node_lr(a, wgs_lr, fixed + (size_t)a.lds_slots * set_bytes, stream);
+  }
+  const size_t smem = (size_t)(1 + a.lds_slots) * set_bytes;
+  ag_log_variant(ws, AGDIFF_VAR_CFCONV_NODE | (local ? AGDIFF_VAR_CFCONV_NODE_LOCAL : 0) |
+                         (a.lds_slots < a.num_slots ? AGDIFF_VAR_POLY_L2_SETS : 0));
+  if (p->precision == AG_BF3)
+    return p->poly_kt == 1 ? launch_cfconv_node_t<AG_BF3, 1>(a, wgs, smem, stream) : launch_cfconv_node_t<AG_BF3, 2>(a, wgs, smem, stream);
+  return p->poly_kt == 1 ? launch_cfconv_node_t<AG_F32, 1>(a, wgs, smem, stream) : launch_cfconv_node_t<AG_F32, 2>(a, wgs, smem, stream);
+}
+
