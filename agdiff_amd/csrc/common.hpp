@@ -20,6 +20,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 
@@ -152,11 +153,24 @@ __device__ __forceinline__ float ag_dot_vec(const f32x4 (&y)[NY], const float* _
 // One weight block = 16 outputs x 32 inputs = 2 x 16 B per lane in both modes (2 KiB):
 //   lane l holds W[16*ot + (l&15)][32*t + {4q..4q+3} U {16+4q..16+4q+3}], q = l>>4
 //   AG_F32: unit u = the four fp32 of half u;  AG_BF3: unit 0 = the eight bf16 hi, unit 1 = the eight lo.
-enum { AG_F32 = 0, AG_BF3 = 1 };
+//   AG_H3:  "split fp16": the same three-pass scheme with hi = fp16(x), lo = fp16(x - hi) on v_mfma_f32_16x16x32_f16 (the
+//           rate of the bf16 form): 11 + 11 mantissa bits per operand instead of 8 + 8, i.e. ~2^-21 per product while |x| stays
+//           inside fp16's range (values beyond 65504 saturate, parts below 6e-8 are lost: an ABSOLUTE floor ~2^-24, harmless
+//           next to O(1) operands).  Used for the local branch (GIN layers, local head, local edge_attr rows), whose outputs
+//           carry the 64 -> 1 cancellation of the head and were the thin spot of the split-bf16 parity.
+enum { AG_F32 = 0, AG_BF3 = 1, AG_H3 = 2 };
 
 template <int MODE> struct AgIn;
 template <> struct AgIn<AG_F32> { f32x4 v[2]; };
 template <> struct AgIn<AG_BF3> { bf16x8 hi, lo; };
+template <> struct AgIn<AG_H3> { f16x8 hi, lo; };
+// the 16-bit MFMA of a split mode
+__device__ __forceinline__ f32x4 ag_mfma16(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 ag_mfma16(const f16x8& a, const f16x8& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
 
 __device__ __forceinline__ void ag_cvt(const f32x4& a0, const f32x4& a1, AgIn<AG_F32>& o) { o.v[0] = a0; o.v[1] = a1; }
 __device__ __forceinline__ void ag_cvt(const f32x4& a0, const f32x4& a1, AgIn<AG_BF3>& o) {
@@ -167,6 +181,20 @@ __device__ __forceinline__ void ag_cvt(const f32x4& a0, const f32x4& a1, AgIn<AG
     o.hi[j] = hb;
     o.lo[j] = (__bf16)(v - (float)hb);
   }
+}
+// split fp16: one v_cvt_pkrtz_f16_f32 per pair and part (round toward zero: hi never exceeds |x|, so lo keeps the sign and the
+// remainder; a value beyond fp16's range saturates at 65504 instead of becoming infinite)
+__device__ __forceinline__ void ag_cvt_pair(AgIn<AG_H3>& o, int j, float v0, float v1) {
+  const auto hp = __builtin_amdgcn_cvt_pkrtz(v0, v1);
+  const auto lp = __builtin_amdgcn_cvt_pkrtz(v0 - (float)hp[0], v1 - (float)hp[1]);
+  o.hi[j] = (_Float16)hp[0];
+  o.hi[j + 1] = (_Float16)hp[1];
+  o.lo[j] = (_Float16)lp[0];
+  o.lo[j + 1] = (_Float16)lp[1];
+}
+__device__ __forceinline__ void ag_cvt(const f32x4& a0, const f32x4& a1, AgIn<AG_H3>& o) {
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) ag_cvt_pair(o, j, (j < 4) ? a0[j & 3] : a1[j & 3], (j < 4) ? a0[(j & 3) + 1] : a1[(j & 3) + 1]);
 }
 // Elements j, j + 1 (j even) of a k-tile from two fp32 values: the piecewise form of ag_cvt, for callers that
 // spread the conversion between other work.
@@ -217,15 +245,16 @@ __device__ __forceinline__ void ag_block_mma(f32x4& o, const AgIn<MODE>& x, cons
                  : __builtin_amdgcn_mfma_f32_16x16x4f32(wf[r], x.v[u][r], o, 0, 0, 0);
     }
   } else {
-    const bf16x8 whi = __builtin_bit_cast(bf16x8, w[0]), wlo = __builtin_bit_cast(bf16x8, w[1]);
+    using V = decltype(x.hi);
+    const V whi = __builtin_bit_cast(V, w[0]), wlo = __builtin_bit_cast(V, w[1]);
     if (FLIP) {
-      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x.hi, whi, o, 0, 0, 0);
-      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x.lo, whi, o, 0, 0, 0);
-      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x.hi, wlo, o, 0, 0, 0);
+      o = ag_mfma16(x.hi, whi, o);
+      o = ag_mfma16(x.lo, whi, o);
+      o = ag_mfma16(x.hi, wlo, o);
     } else {
-      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, x.hi, o, 0, 0, 0);
-      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, x.lo, o, 0, 0, 0);
-      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, x.hi, o, 0, 0, 0);
+      o = ag_mfma16(whi, x.hi, o);
+      o = ag_mfma16(whi, x.lo, o);
+      o = ag_mfma16(wlo, x.hi, o);
     }
   }
 }
@@ -241,10 +270,10 @@ __device__ __forceinline__ void ag_block_mma_part(f32x4& o, const AgIn<MODE>& x,
     o = FLIP ? __builtin_amdgcn_mfma_f32_16x16x4f32(x.v[u][r], wf[r], o, 0, 0, 0)
              : __builtin_amdgcn_mfma_f32_16x16x4f32(wf[r], x.v[u][r], o, 0, 0, 0);
   } else {
-    const bf16x8 wv = __builtin_bit_cast(bf16x8, w[part == 2 ? 1 : 0]);
-    const bf16x8 xv = (part == 1) ? x.lo : x.hi;
-    o = FLIP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(xv, wv, o, 0, 0, 0)
-             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, xv, o, 0, 0, 0);
+    using V = decltype(x.hi);
+    const V wv = __builtin_bit_cast(V, w[part == 2 ? 1 : 0]);
+    const V xv = (part == 1) ? x.lo : x.hi;
+    o = FLIP ? ag_mfma16(xv, wv, o) : ag_mfma16(wv, xv, o);
   }
 }
 
@@ -258,9 +287,9 @@ __device__ __forceinline__ f32x4 ag_block_mma_first(const AgIn<MODE>& x, const u
     return FLIP ? __builtin_amdgcn_mfma_f32_16x16x4f32(x.v[0][0], wf[0], zero, 0, 0, 0)
                 : __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0], x.v[0][0], zero, 0, 0, 0);
   } else {
-    const bf16x8 wv = __builtin_bit_cast(bf16x8, w[0]);
-    return FLIP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(x.hi, wv, zero, 0, 0, 0)
-                : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, x.hi, zero, 0, 0, 0);
+    using V = decltype(x.hi);
+    const V wv = __builtin_bit_cast(V, w[0]);
+    return FLIP ? ag_mfma16(x.hi, wv, zero) : ag_mfma16(wv, x.hi, zero);
   }
 }
 
@@ -386,6 +415,16 @@ __device__ __forceinline__ void ag_store_attr(const AgIn<AG_BF3>& x, float* frag
   u32x4* p = reinterpret_cast<u32x4*>(frag);
   p[ag_attr_unit(tile, t, 0, lane)] = __builtin_bit_cast(u32x4, x.hi);
   p[ag_attr_unit(tile, t, 1, lane)] = __builtin_bit_cast(u32x4, x.lo);
+}
+__device__ __forceinline__ void ag_store_attr(const AgIn<AG_H3>& x, float* frag, int64_t tile, int t, int lane) {
+  u32x4* p = reinterpret_cast<u32x4*>(frag);
+  p[ag_attr_unit(tile, t, 0, lane)] = __builtin_bit_cast(u32x4, x.hi);
+  p[ag_attr_unit(tile, t, 1, lane)] = __builtin_bit_cast(u32x4, x.lo);
+}
+__device__ __forceinline__ void ag_load_attr(AgIn<AG_H3>& x, const float* frag, int64_t tile, int t, int lane) {
+  const u32x4* p = reinterpret_cast<const u32x4*>(frag);
+  x.hi = __builtin_bit_cast(f16x8, p[ag_attr_unit(tile, t, 0, lane)]);
+  x.lo = __builtin_bit_cast(f16x8, p[ag_attr_unit(tile, t, 1, lane)]);
 }
 __device__ __forceinline__ void ag_load_attr(AgIn<AG_F32>& x, const float* frag, int64_t tile, int t, int lane) {
   const u32x4* p = reinterpret_cast<const u32x4*>(frag);

@@ -867,8 +867,8 @@ __global__ void __launch_bounds__(64 * AG_ATTRP_WAVES, 2) k_edge_attr_poly(AttrP
         ph[0].v[0] = in ? phall[0].v[0] : f32x4{0.f, 0.f, 0.f, 0.f};
         ph[0].v[1] = in ? phall[0].v[1] : f32x4{0.f, 0.f, 0.f, 0.f};
       } else {
-        ph[0].hi = __builtin_bit_cast(bf16x8, in ? __builtin_bit_cast(u32x4, phall[0].hi) : zero);
-        ph[0].lo = __builtin_bit_cast(bf16x8, in ? __builtin_bit_cast(u32x4, phall[0].lo) : zero);
+        ph[0].hi = __builtin_bit_cast(decltype(ph[0].hi), in ? __builtin_bit_cast(u32x4, phall[0].hi) : zero);
+        ph[0].lo = __builtin_bit_cast(decltype(ph[0].lo), in ? __builtin_bit_cast(u32x4, phall[0].lo) : zero);
       }
       const lds_u32x4* wg_ = wl_l + (size_t)g * (8 * 128);
       u32x4 w[8][2];
@@ -1049,7 +1049,9 @@ extern "C" int agdiff_edge_encoder(const agdiff_params_t* p, const int32_t* n_ed
     GaussArgs g{p->ge_offset, p->ge_emb, n_edges_dev, e_len, e_type, attr_frag, attr_rows, row_index, pos_index, mir_index,
                 max_tiles, p->ge_coeff * 1.44269504088896340736f};
     const dim3 grid((unsigned)((max_tiles + 3) / 4));
-    if (p->precision == AG_BF3)
+    if (p->precision == AG_H3)
+      k_edge_gaussian<AG_H3><<<grid, dim3(256), 0, (hipStream_t)stream>>>(g);
+    else if (p->precision == AG_BF3)
       k_edge_gaussian<AG_BF3><<<grid, dim3(256), 0, (hipStream_t)stream>>>(g);
     else
       k_edge_gaussian<AG_F32><<<grid, dim3(256), 0, (hipStream_t)stream>>>(g);
@@ -1064,8 +1066,10 @@ extern "C" int agdiff_edge_encoder(const agdiff_params_t* p, const int32_t* n_ed
   if (wgs > 256) wgs = 256;
   const size_t smem = (size_t)80 * 2048;     // w1 (32 blocks) + w23 (32) + unit 0 of w4's 32 blocks
   static std::atomic<uint64_t> attr_done{0};
-  if (!ag_allow_big_lds(attr_done, smem, k_edge_encoder<AG_BF3>, k_edge_encoder<AG_F32>)) return AGDIFF_ERR_LAUNCH;
-  if (p->precision == AG_BF3)
+  if (!ag_allow_big_lds(attr_done, smem, k_edge_encoder<AG_BF3>, k_edge_encoder<AG_F32>, k_edge_encoder<AG_H3>)) return AGDIFF_ERR_LAUNCH;
+  if (p->precision == AG_H3)
+    k_edge_encoder<AG_H3><<<dim3((unsigned)wgs), dim3(64 * AG_PERSIST_WAVES), smem, (hipStream_t)stream>>>(a);
+  else if (p->precision == AG_BF3)
     k_edge_encoder<AG_BF3><<<dim3((unsigned)wgs), dim3(64 * AG_PERSIST_WAVES), smem, (hipStream_t)stream>>>(a);
   else
     k_edge_encoder<AG_F32><<<dim3((unsigned)wgs), dim3(64 * AG_PERSIST_WAVES), smem, (hipStream_t)stream>>>(a);
@@ -1190,8 +1194,10 @@ int launch_cfconv_fused(const agdiff_params_t* p, int32_t k, int64_t max_e, cons
   if (wgs > 256) wgs = 256;
   const size_t smem = (size_t)AG_CONV_LDS_BLOCKS * 2048;
   static std::atomic<uint64_t> attr_done{0};
-  if (!ag_allow_big_lds(attr_done, smem, k_cfconv_fused<AG_BF3>, k_cfconv_fused<AG_F32>)) return AGDIFF_ERR_LAUNCH;
-  if (p->precision == AG_BF3)
+  if (!ag_allow_big_lds(attr_done, smem, k_cfconv_fused<AG_BF3>, k_cfconv_fused<AG_F32>, k_cfconv_fused<AG_H3>)) return AGDIFF_ERR_LAUNCH;
+  if (p->precision == AG_H3)
+    k_cfconv_fused<AG_H3><<<dim3((unsigned)wgs), dim3(64 * AG_CONV_WAVES), smem, (hipStream_t)stream>>>(a);
+  else if (p->precision == AG_BF3)
     k_cfconv_fused<AG_BF3><<<dim3((unsigned)wgs), dim3(64 * AG_CONV_WAVES), smem, (hipStream_t)stream>>>(a);
   else
     k_cfconv_fused<AG_F32><<<dim3((unsigned)wgs), dim3(64 * AG_CONV_WAVES), smem, (hipStream_t)stream>>>(a);
@@ -1285,11 +1291,15 @@ int launch_pair_head_poly(const agdiff_params_t* p, const int32_t* n_edges_dev, 
   const size_t smem = (size_t)(48 + 8 * p->poly_kt) * 2048;
   static std::atomic<uint64_t> attr_done{0};
   if (!ag_allow_big_lds(attr_done, (size_t)(48 + 8 * AGDIFF_POLY_MAX_KT) * 2048, k_pair_head_poly<AG_BF3, 1>,
-                        k_pair_head_poly<AG_BF3, 2>, k_pair_head_poly<AG_F32, 1>, k_pair_head_poly<AG_F32, 2>))
+                        k_pair_head_poly<AG_BF3, 2>, k_pair_head_poly<AG_F32, 1>, k_pair_head_poly<AG_F32, 2>,
+                        k_pair_head_poly<AG_H3, 1>, k_pair_head_poly<AG_H3, 2>))
     return AGDIFF_ERR_LAUNCH;
   const dim3 grid((unsigned)wgs), block(64 * AG_PERSIST_WAVES);
   hipStream_t st = (hipStream_t)stream;
-  if (p->precision == AG_BF3) {
+  if (p->precision == AG_H3) {
+    if (p->poly_kt == 1) k_pair_head_poly<AG_H3, 1><<<grid, block, smem, st>>>(a);
+    else k_pair_head_poly<AG_H3, 2><<<grid, block, smem, st>>>(a);
+  } else if (p->precision == AG_BF3) {
     if (p->poly_kt == 1) k_pair_head_poly<AG_BF3, 1><<<grid, block, smem, st>>>(a);
     else k_pair_head_poly<AG_BF3, 2><<<grid, block, smem, st>>>(a);
   } else {
@@ -1331,9 +1341,13 @@ extern "C" int agdiff_local_edge_rows(const agdiff_params_t* p, const agdiff_top
   if (wgs > 512) wgs = 512;
   const size_t smem = (size_t)p->poly_num_slots * 8 * 2048;
   static std::atomic<uint64_t> attr_done{0};
-  if (!ag_allow_big_lds(attr_done, (size_t)AG_ATTRP_MAX_SLOTS * 8 * 2048, k_edge_attr_poly<AG_BF3>, k_edge_attr_poly<AG_F32>))
+  if (!ag_allow_big_lds(attr_done, (size_t)AG_ATTRP_MAX_SLOTS * 8 * 2048, k_edge_attr_poly<AG_BF3>, k_edge_attr_poly<AG_F32>,
+                        k_edge_attr_poly<AG_H3>))
     return AGDIFF_ERR_LAUNCH;
-  if (p->precision == AG_BF3)
+  // (the local branch's arithmetic mode: attr_poly_typed_pk is packed in it)
+  if (p->precision_local == AG_H3)
+    k_edge_attr_poly<AG_H3><<<dim3((unsigned)wgs), dim3(64 * AG_ATTRP_WAVES), smem, st>>>(a);
+  else if (p->precision_local == AG_BF3)
     k_edge_attr_poly<AG_BF3><<<dim3((unsigned)wgs), dim3(64 * AG_ATTRP_WAVES), smem, st>>>(a);
   else
     k_edge_attr_poly<AG_F32><<<dim3((unsigned)wgs), dim3(64 * AG_ATTRP_WAVES), smem, st>>>(a);
@@ -1371,8 +1385,12 @@ extern "C" int agdiff_pair_head(const agdiff_head_params_t* hp, const int32_t* n
   if (wgs > 256) wgs = 256;
   const size_t smem = (size_t)80 * 2048;     // w1 (64 blocks) + w2 (16 blocks)
   static std::atomic<uint64_t> attr_done{0};
-  if (!ag_allow_big_lds(attr_done, smem, k_pair_head<AG_BF3>, k_pair_head<AG_F32>)) return AGDIFF_ERR_LAUNCH;
-  if (hp->precision == AG_BF3)
+  if (!ag_allow_big_lds(attr_done, smem, k_pair_head<AG_BF3>, k_pair_head<AG_F32>, k_pair_head<AG_H3>)) return AGDIFF_ERR_LAUNCH;
+  // (operand-form edge_attr tiles must have been written in the head's mode: the global encoder writes them in p->precision,
+  // which is what head_global carries; head_local reads fp32 rows)
+  if (hp->precision == AG_H3)
+    k_pair_head<AG_H3><<<dim3((unsigned)wgs), dim3(64 * AG_PERSIST_WAVES), smem, (hipStream_t)stream>>>(a);
+  else if (hp->precision == AG_BF3)
     k_pair_head<AG_BF3><<<dim3((unsigned)wgs), dim3(64 * AG_PERSIST_WAVES), smem, (hipStream_t)stream>>>(a);
   else
     k_pair_head<AG_F32><<<dim3((unsigned)wgs), dim3(64 * AG_PERSIST_WAVES), smem, (hipStream_t)stream>>>(a);

@@ -251,8 +251,8 @@ __device__ __forceinline__ void ag_xch_get(const lds_u32x4* x, int kt, AgIn<MODE
     v.v[0] = __builtin_bit_cast(f32x4, x[(kt * 2) * 64 + lane]);
     v.v[1] = __builtin_bit_cast(f32x4, x[(kt * 2 + 1) * 64 + lane]);
   } else {
-    v.hi = __builtin_bit_cast(bf16x8, x[(kt * 2) * 64 + lane]);
-    v.lo = __builtin_bit_cast(bf16x8, x[(kt * 2 + 1) * 64 + lane]);
+    v.hi = __builtin_bit_cast(decltype(v.hi), x[(kt * 2) * 64 + lane]);
+    v.lo = __builtin_bit_cast(decltype(v.lo), x[(kt * 2 + 1) * 64 + lane]);
   }
 }
 
@@ -985,7 +985,8 @@ extern "C" int agdiff_schnet_node_stage_split(const agdiff_params_t* p, const ag
       else if (a.finish) k_schnet_node_stage_split<M, true, false><<<grid, block, 0, st>>>(a);            \
       else k_schnet_node_stage_split<M, false, true><<<grid, block, 0, st>>>(a);                          \
     } while (0)
-    if (p->precision == AG_BF3) AG_LAUNCH_SPLIT(AG_BF3);
+    if (p->precision == AG_H3) AG_LAUNCH_SPLIT(AG_H3);
+    else if (p->precision == AG_BF3) AG_LAUNCH_SPLIT(AG_BF3);
     else AG_LAUNCH_SPLIT(AG_F32);
 #undef AG_LAUNCH_SPLIT
     AG_CHECK_LAUNCH();
@@ -997,10 +998,13 @@ extern "C" int agdiff_schnet_node_stage_split(const agdiff_params_t* p, const ag
   const size_t smem = ldsw ? (size_t)AG_NODE_LDS_BLOCKS * 2048 : 0;
   static std::atomic<uint64_t> attr_done{0};
   if (!ag_allow_big_lds(attr_done, (size_t)AG_NODE_LDS_BLOCKS * 2048, k_schnet_node_stage<AG_BF3, true>,
-                        k_schnet_node_stage<AG_F32, true>))
+                        k_schnet_node_stage<AG_F32, true>, k_schnet_node_stage<AG_H3, true>))
     return AGDIFF_ERR_LAUNCH;
   const dim3 grid((unsigned)((tiles + waves - 1) / waves)), block(64 * waves);
-  if (p->precision == AG_BF3) {
+  if (p->precision == AG_H3) {
+    if (ldsw) k_schnet_node_stage<AG_H3, true><<<grid, block, smem, st>>>(a);
+    else k_schnet_node_stage<AG_H3, false><<<grid, block, 0, st>>>(a);
+  } else if (p->precision == AG_BF3) {
     if (ldsw) k_schnet_node_stage<AG_BF3, true><<<grid, block, smem, st>>>(a);
     else k_schnet_node_stage<AG_BF3, false><<<grid, block, 0, st>>>(a);
   } else {
@@ -1023,7 +1027,7 @@ extern "C" int agdiff_gin_encoder(const agdiff_params_t* p, const agdiff_topo_t*
   if (ldsw) ag_log_variant(ws, AGDIFF_VAR_GIN_LDSW);
   const size_t smem = ldsw ? (size_t)64 * 2048 : 0;
   static std::atomic<uint64_t> attr_done{0};
-  if (!ag_allow_big_lds(attr_done, (size_t)64 * 2048, k_gin_layer<AG_BF3, true>, k_gin_layer<AG_F32, true>))
+  if (!ag_allow_big_lds(attr_done, (size_t)64 * 2048, k_gin_layer<AG_BF3, true>, k_gin_layer<AG_F32, true>, k_gin_layer<AG_H3, true>))
     return AGDIFF_ERR_LAUNCH;
   const dim3 grid((unsigned)((tiles + waves - 1) / waves)), block(64 * waves);
   // ping-pong so that the final layer lands in ws->hl
@@ -1045,7 +1049,10 @@ extern "C" int agdiff_gin_encoder(const agdiff_params_t* p, const agdiff_topo_t*
     hipStream_t st = (hipStream_t)stream;
     k_gin_gather<<<dim3((unsigned)((((topo->num_nodes + 7) / 8) + 7) / 8 * 8)), dim3(256), 0, st>>>(a);   // grid: multiple of 8 (XCD ranges)
     AG_CHECK_LAUNCH();
-    if (p->precision == AG_BF3) {
+    if (p->precision_local == AG_H3) {
+      if (ldsw) k_gin_layer<AG_H3, true><<<grid, block, smem, st>>>(a);
+      else k_gin_layer<AG_H3, false><<<grid, block, 0, st>>>(a);
+    } else if (p->precision_local == AG_BF3) {
       if (ldsw) k_gin_layer<AG_BF3, true><<<grid, block, smem, st>>>(a);
       else k_gin_layer<AG_BF3, false><<<grid, block, 0, st>>>(a);
     } else {

@@ -443,6 +443,8 @@ extern "C" int agdiff_cfconv_node(const agdiff_params_t* p, const agdiff_topo_t*
   const size_t smem = (size_t)(1 + a.lds_slots) * set_bytes;
   ag_log_variant(ws, AGDIFF_VAR_CFCONV_NODE | (local ? AGDIFF_VAR_CFCONV_NODE_LOCAL : 0) |
                          (a.lds_slots < a.num_slots ? AGDIFF_VAR_POLY_L2_SETS : 0));
+  if (p->precision == AG_H3)
+    return p->poly_kt == 1 ? launch_cfconv_node_t<AG_H3, 1>(a, wgs, smem, stream) : launch_cfconv_node_t<AG_H3, 2>(a, wgs, smem, stream);
   if (p->precision == AG_BF3)
     return p->poly_kt == 1 ? launch_cfconv_node_t<AG_BF3, 1>(a, wgs, smem, stream) : launch_cfconv_node_t<AG_BF3, 2>(a, wgs, smem, stream);
   return p->poly_kt == 1 ? launch_cfconv_node_t<AG_F32, 1>(a, wgs, smem, stream) : launch_cfconv_node_t<AG_F32, 2>(a, wgs, smem, stream);

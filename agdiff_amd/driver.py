@@ -294,7 +294,7 @@ def main(argv=None):
                          "amortised and the node features still live in L2 / MALL; 196,608 = 3 full rounds of the node kernels' "
                          "256 x 16 x 16-node workgroups; --save-traj keeps n_steps x atoms x 12 bytes)")
     ap.add_argument("--seed", type=int, default=2021)
-    ap.add_argument("--precision", default=None, choices=[None, "f32", "bf16x3"])
+    ap.add_argument("--precision", default=None, choices=[None, "f32", "bf16x3", "f16x3"])
     ap.add_argument("--dist-mode", default="shard", choices=["shard", "batches"],
                     help="with several ranks: 'shard' = every packed batch (max-atoms x world atoms) is split into "
                          "contiguous graph ranges, one per rank, with an RCCL all-gather of the positions after each "

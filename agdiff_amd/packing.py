@@ -46,6 +46,7 @@ def pack_blocks(W, kouter=False, mode=0):
     (include/agdiff_hip.h): lane l of block (ot, t) holds W[16*ot + (l & 15)][32*t + cols[l][0..7]].
       mode 0 (fp32):   unit u = fp32 of elements 4u..4u+3                      -> [2][64][4] floats
       mode 1 (bf16x3): unit 0 = bf16(w) of the 8 elements, unit 1 = bf16(w - hi) -> [2][64][8] bf16
+      mode 2 (f16x3):  the same with fp16 (local branch, agdiff_params_t.precision_local)
     Blocks are ordered [OT][KT] ("pk") or [KT][OT] ("pkk", kouter).  Returned as a float32 array
     (bf16 bit patterns viewed as float32 in mode 1)."""
     W = np.asarray(W, dtype=np.float64)
@@ -66,6 +67,12 @@ def pack_blocks(W, kouter=False, mode=0):
     if mode == 0:
         # [block][lane][u][4] -> [block][u][lane][4]
         return np.ascontiguousarray(vals.reshape(nb, 64, 2, 4).transpose(0, 2, 1, 3)).reshape(-1)
+    if mode == 2:            # split fp16: hi = fp16(w), lo = fp16(w - hi) (values beyond fp16's range saturate)
+        v = np.clip(vals.astype(np.float64), -65504.0, 65504.0)
+        hi = v.astype(np.float16)
+        lo = (v - hi.astype(np.float64)).astype(np.float16)
+        blk = np.stack([hi.reshape(nb, 64, 8), lo.reshape(nb, 64, 8)], axis=1)
+        return np.ascontiguousarray(blk).reshape(-1).view(np.float32)
     hb, hv = bf16_round(vals)
     lb, _ = bf16_round(vals - hv)
     blk = np.stack([hb.reshape(nb, 64, 8), lb.reshape(nb, 64, 8)], axis=1)      # [block][part][lane][8]
@@ -78,6 +85,9 @@ def unpack_blocks(flat, out, inn, kouter=False, mode=0):
     nb = OT * KT
     if mode == 0:
         vals = np.asarray(flat, dtype=np.float32).reshape(nb, 2, 64, 4).transpose(0, 2, 1, 3).reshape(nb, 64, 8)
+    elif mode == 2:
+        h = np.ascontiguousarray(flat).view(np.float16).reshape(nb, 2, 64, 8).astype(np.float32)
+        vals = h[:, 0] + h[:, 1]
     else:
         u = np.ascontiguousarray(flat).view(np.uint16).reshape(nb, 2, 64, 8).astype(np.uint32)
         v = (u << 16).view(np.float32)
@@ -325,14 +335,15 @@ def dist_union_table(segs):
     return out
 
 
-PRECISIONS = {"f32": 0, "bf16x3": 1}
+PRECISIONS = {"f32": 0, "bf16x3": 1, "f16x3": 2}
+LOCAL_PRECISIONS = {"f32": 0, "bf16x3": 1, "f16x3": 2}      # agdiff_params_t.precision_local
 EDGE_ENCODERS = {"mlp": 0, "gaussian": 1}       # agdiff_params_t.edge_encoder
 
 
 class PackedParams:
     """Owns the device copies of all packed weights and the agdiff_params_t that points at them."""
 
-    def __init__(self, sd, cfg, device, precision="f32", radius_poly="auto", refuse_types=()):
+    def __init__(self, sd, cfg, device, precision="f32", radius_poly="auto", refuse_types=(), precision_local=None):
         """radius_poly: "auto" -- radius edges take their filters from d-polynomials when the fit is accepted
         (radius_polynomials above), and so do the local edges, per type (ensure_local_types); "off" -- every edge goes
         through the encoder + filter MLPs; "radius" -- polynomials for the radius edges only; "kt2" -- as "auto" but
@@ -355,7 +366,19 @@ class PackedParams:
             raise ValueError("precision must be one of %s" % (list(PRECISIONS),))
         self.precision = precision
         mode = PRECISIONS[precision]
+        # the local branch's MFMA kernels (GIN layers, local head, local edge_attr rows by polynomial): split-fp16 next to a
+        # split-bf16 global branch by default (same rate, 11 + 11 instead of 8 + 8 mantissa bits per operand)
+        if precision_local is None:
+            precision_local = "f16x3" if precision in ("bf16x3", "f16x3") else precision
+        if precision_local not in LOCAL_PRECISIONS:
+            raise ValueError("precision_local must be one of %s" % (list(LOCAL_PRECISIONS),))
+        self.precision_local = precision_local
+        self._mode_local = lmode = LOCAL_PRECISIONS[precision_local]
         _pack = globals()["pack_blocks"]
+
+        def pack_local(W, kouter=False):
+            return _pack(W, kouter=kouter, mode=lmode)
+        self._pack_local = pack_local
 
         def pack_blocks(W, kouter=False):      # every matrix of this model is packed in the chosen mode
             return _pack(W, kouter=kouter, mode=mode)
@@ -459,20 +482,21 @@ class PackedParams:
         for k in range(cfg.num_convs_local):
             p = "encoder_local.convs.%d" % k
             n = "gin%d." % k
-            arrays[n + "w1_pk"] = pack_blocks(_np(sd, p + ".nn.layers.0.weight"))
+            arrays[n + "w1_pk"] = self._pack_local(_np(sd, p + ".nn.layers.0.weight"))
             arrays[n + "b1"] = _np(sd, p + ".nn.layers.0.bias")
             W, b = fold_bn(_np(sd, p + ".nn.layers.1.weight"), _np(sd, p + ".nn.layers.1.bias"), sd,
                            "encoder_local.batch_norms.%d" % k)
-            arrays[n + "w2_pk"] = pack_blocks(W)
+            arrays[n + "w2_pk"] = self._pack_local(W)
             arrays[n + "b2"] = b
             scalars[n + "one_plus_eps"] = 1.0 + float(_np(sd, p + ".eps")[0])
 
         # ---------------- heads (common.py:44-103; dualenc.py:88-98)
         for name, p in (("head_global", "grad_global_dist_mlp"), ("head_local", "grad_local_dist_mlp")):
             n = name + "."
-            arrays[n + "w1_pk"] = pack_blocks(_np(sd, p + ".layers.0.weight"), kouter=True)
+            pb = self._pack_local if name == "head_local" else pack_blocks
+            arrays[n + "w1_pk"] = pb(_np(sd, p + ".layers.0.weight"), kouter=True)
             arrays[n + "b1"] = _np(sd, p + ".layers.0.bias")
-            arrays[n + "w2_pk"] = pack_blocks(_np(sd, p + ".layers.1.weight"))
+            arrays[n + "w2_pk"] = pb(_np(sd, p + ".layers.1.weight"))
             arrays[n + "b2"] = _np(sd, p + ".layers.1.bias")
             arrays[n + "w3"] = _np(sd, p + ".layers.2.weight")[0]
             scalars[n + "b3"] = float(_np(sd, p + ".layers.2.bias")[0])
@@ -530,12 +554,13 @@ class PackedParams:
                 hp.attr_poly_pk = P(n + "attr_poly_pk")
             hp.b3 = scalars[n + "b3"]
             hp.act = 0
-            hp.precision = mode
+            hp.precision = self._mode_local if name == "head_local" else mode
         prm.num_convs = cfg.num_convs
         prm.num_convs_local = cfg.num_convs_local
         prm.cutoff = float(cfg.cutoff)
         prm.smooth = 1 if cfg.smooth_conv else 0
         prm.precision = mode
+        prm.precision_local = self._mode_local
         prm.poly_kt = self.poly_kt
         prm.poly_num_slots = 0
         self.struct = prm
@@ -576,7 +601,7 @@ class PackedParams:
                     for k in range(nc)]
         # edge_attr itself per type (agdiff_local_edge_rows): pk [8][kt] -- the kernel takes one k-tile, so only with kt == 1
         if kt == 1:
-            attr_sets = np.concatenate([pack_blocks(self._typed_mats[t]["edge_attr_poly_pk"], mode=self._mode) for t in by_slot])
+            attr_sets = np.concatenate([pack_blocks(self._typed_mats[t]["edge_attr_poly_pk"], mode=self._mode_local) for t in by_slot])
             self.typed_attr_flat = torch.from_numpy(attr_sets).to(self.device)
             prm.attr_poly_typed_pk = ctypes.c_void_p(self.typed_attr_flat.data_ptr())
         self.typed_flat = torch.from_numpy(np.concatenate(per_conv)).to(self.device)     # (the old buffer may still be in

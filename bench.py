@@ -41,9 +41,9 @@ sys.path.insert(0, ROOT)
 
 JOB_STEPS = 5000
 FLOP_PER_EDGE_CFCONV = 2 * (128 * 192 + 128 * 128 + 64 * 64)     # filter MLP of conv1+conv2, one block
-PEAK = {"f32": 157.3, "bf16x3": 2500.0}      # dense MFMA TFLOP/s (f32-input MFMA; bf16 MFMA), MI355X_MICROARCH.md
+PEAK = {"f32": 157.3, "bf16x3": 2500.0, "f16x3": 2500.0}      # dense MFMA TFLOP/s (f32-input MFMA; bf16 MFMA), MI355X_MICROARCH.md
 HBM_PEAK_GBPS = 8000.0
-MFMA_PASSES = {"f32": 1, "bf16x3": 3}        # MFMA FLOPs issued per algorithmic FLOP
+MFMA_PASSES = {"f32": 1, "bf16x3": 3, "f16x3": 3}        # MFMA FLOPs issued per algorithmic FLOP
 PROFILE_ROUND = "r04"
 
 
@@ -370,7 +370,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="no event pairs around the CFConv launches of the timed region")
     ap.add_argument("--breakdown", default=None, help="write per-op timings (ms) to this JSON file")
     ap.add_argument("--seed", type=int, default=2021)
-    ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"])
+    ap.add_argument("--precision", default="f16x3", choices=["f32", "bf16x3", "f16x3"])
     ap.add_argument("--radius-poly", default="auto", choices=["auto", "radius", "kt2", "off"],
                     help="filter polynomials (agdiff_amd/packing.py): off = every edge through the encoder + filter MLPs")
     ap.add_argument("--front", default="fused", choices=["fused", "split", "unfused"],

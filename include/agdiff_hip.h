@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 34
+#define AGDIFF_ABI_VERSION 35
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -52,6 +52,7 @@ enum agdiff_status {
  * (ot, t) holds the eight weights W[16*ot + (l&15)][32*t + c], c in {4q..4q+3, 16+4q..16+4q+3}, q = l>>4:
  *   precision 0: two 16-byte units [u][lane][4 fp32] (elements 4u..4u+3)
  *   precision 1: two 16-byte units [part][lane][8 bf16], part 0 = bf16(w), part 1 = bf16(w - hi)
+ *   precision 2: the same with fp16 (agdiff_params_t.precision_local)
  * Dimensions in the field comments below are [OT][KT] block counts.  Vectors are in natural feature order. */
 typedef struct agdiff_conv_params {
   /* CFConv filter networks of one InteractionBlock (schnet.py:169-186), conv1 (F=128) and conv2 (F=64) fused.
@@ -114,7 +115,7 @@ typedef struct agdiff_head_params {
                                 (agdiff_params_t.poly_kt) */
   float b3;
   int32_t act;               /* 0 relu (configs: mlp_act relu) */
-  int32_t precision;         /* as agdiff_params_t.precision */
+  int32_t precision;         /* as agdiff_params_t.precision, or 2 (split-fp16: only with attr_rows) */
   int32_t pad0;
 } agdiff_head_params_t;
 
@@ -151,8 +152,10 @@ typedef struct agdiff_params {
   int32_t num_convs_local;
   float cutoff;
   int32_t smooth;            /* config.smooth_conv */
-  int32_t precision;         /* 0: exact fp32 MFMA; 1: split-bf16 (hi+lo, 3 MFMA passes, fp32 accumulate) -- selects
-                                both the kernels and the layout of every packed matrix and of e_attr / l_attr */
+  int32_t precision;         /* 0: exact fp32 MFMA; 1: split-bf16 (hi+lo, 3 MFMA passes, fp32 accumulate); 2: split-fp16 (the same scheme
+                                on v_mfma_f32_16x16x32_f16: 11 + 11 mantissa bits per operand at the same rate; operands beyond
+                                fp16's range saturate) -- selects both the kernels and the layout of every packed matrix and
+                                of e_attr / l_attr */
   int32_t edge_encoder;      /* config.edge_encoder: 0 'mlp' (edge.py:45-103), 1 'gaussian' (edge.py:17-42) */
   float ge_coeff;            /* -0.5 / (offset[1] - offset[0])^2 (schnet.py:22) */
   int32_t poly_num_slots;    /* 0, or 1..AGDIFF_POLY_MAX_SLOTS: local edge types whose CFConv filters are d-polynomials too
@@ -160,7 +163,11 @@ typedef struct agdiff_params {
                                 edges through the filter MLPs.  A batch that brings a type without a slot (fit refused, or more
                                 than AGDIFF_POLY_MAX_SLOTS types) runs MIXED: the slotted types' edges by polynomials inside
                                 agdiff_cfconv_node, the others through agdiff_cfconv_local (topo->local_type_mask tells) */
-  int32_t pad1;
+  int32_t precision_local;   /* arithmetic of the LOCAL branch's MFMA kernels (GIN layers, local head, local edge_attr rows by
+                                polynomial): 0 / 1 as `precision`, 2: split-fp16 (hi + lo fp16, three passes of
+                                v_mfma_f32_16x16x32_f16: ~2^-21 per product at the split-bf16 rate) -- gin[].w*_pk, head_local.w*_pk
+                                and attr_poly_typed_pk are packed in THIS mode; the encoder MLP of flagged tiles stays in
+                                `precision` */
   int32_t poly_kt;           /* 0: off.  1..AGDIFF_POLY_MAX_KT: radius edges (type 0: no bond embedding; d < cutoff by
                                 construction) take their CFConv filters and the edge_attr half of the global head's first layer
                                 from polynomials in d instead of the encoder + filter MLPs: both are smooth functions of the ONE

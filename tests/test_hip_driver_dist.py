@@ -13,7 +13,7 @@ from helpers import check_close, t
 pytestmark = pytest.mark.gpu
 
 
-def _gpu_model(cfg, head_scale=1e-3, precision="bf16x3"):
+def _gpu_model(cfg, head_scale=1e-3, precision="f16x3"):
     from agdiff_amd import get_model
     from oracle import agdiff_oracle as O
     sd = O.synth_state_dict_for(cfg, head_scale=head_scale)
@@ -33,7 +33,7 @@ def _three_molecules(seed=5):
     return mols
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x3"])
 def test_driver_sample_batch_matches_oracle_per_molecule(precision):
     """every molecule's pos_gen out of driver.sample_batch (packed batch, injected pos_init / noise)
     against the oracle's langevin_dynamics_sample_diffusion with scripts/test.py's arguments."""

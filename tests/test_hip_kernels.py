@@ -24,7 +24,7 @@ import torch.nn.functional as F
 from helpers import FORWARD_CASES, STAGE_CASES, check_close, load_golden, rel_err, t
 
 pytestmark = pytest.mark.gpu
-PRECISIONS = ["f32", "bf16x3"]
+PRECISIONS = ["f32", "bf16x3", "f16x3"]
 
 
 def _setup(case, precision):

@@ -16,10 +16,10 @@ from helpers import (FORWARD_CASES, SAMPLER_CASES, STAGE_CASES, check_close, loa
 pytestmark = pytest.mark.gpu
 
 
-PRECISIONS = ["f32", "bf16x3"]
+PRECISIONS = ["f32", "bf16x3", "f16x3"]
 
 
-def _gpu_model(cfg, head_scale=1e-3, precision="bf16x3"):
+def _gpu_model(cfg, head_scale=1e-3, precision="f16x3"):
     from agdiff_amd import get_model
     from oracle import agdiff_oracle as O
     sd = O.synth_state_dict_for(cfg, head_scale=head_scale)
@@ -36,9 +36,12 @@ def unfrag(frag, n, precision):
     if precision == "f32":      # [tile][t][u][edge][q][r], feature = 32t + 16u + 4q + r
         x = frag.view(tiles, 4, 2, 16, 4, 4).permute(0, 3, 1, 2, 4, 5).reshape(tiles * 16, 128)
         return x[:n]
-    # bf16x3: [tile][t][part][edge][q][u][r] bf16, feature = 32t + 16u + 4q + r, value = hi + lo
-    u = frag.view(torch.int16).view(tiles, 4, 2, 16, 4, 2, 4).to(torch.int32)
-    val = ((u & 0xFFFF) << 16).view(torch.float32)
+    # bf16x3 / f16x3: [tile][t][part][edge][q][u][r] 16-bit floats, feature = 32t + 16u + 4q + r, value = hi + lo
+    if precision == "f16x3":
+        val = frag.view(torch.float16).view(tiles, 4, 2, 16, 4, 2, 4).to(torch.float32)
+    else:
+        u = frag.view(torch.int16).view(tiles, 4, 2, 16, 4, 2, 4).to(torch.int32)
+        val = ((u & 0xFFFF) << 16).view(torch.float32)
     val = val[:, :, 0] + val[:, :, 1]                           # [tile][t][edge][q][u][r]
     x = val.permute(0, 2, 1, 4, 3, 5).reshape(tiles * 16, 128)
     return x[:n]
@@ -329,14 +332,14 @@ def test_oracle_parity_on_seeded_batches_and_wrapper_defaults():
         got = m(at.cuda(), pos.cuda(), bi.cuda(), bt.cuda(), ba.cuda(), None, return_edges=True, extend_order=False)
         assert np.array_equal(got[2].cpu().numpy(), ref[2].numpy())
         assert np.array_equal(got[3].cpu().numpy(), ref[3].numpy())
-        check_close("oracle_parity_on_seeded_batches_and_wrapper_defaults got[0]", got[0].cpu().numpy(), ref[0].numpy(), "bf16x3")
-        check_close("oracle_parity_on_seeded_batches_and_wrapper_defaults got[1]", got[1].cpu().numpy(), ref[1].numpy(), "bf16x3")
+        check_close("oracle_parity_on_seeded_batches_and_wrapper_defaults got[0]", got[0].cpu().numpy(), ref[0].numpy(), "f16x3")
+        check_close("oracle_parity_on_seeded_batches_and_wrapper_defaults got[1]", got[1].cpu().numpy(), ref[1].numpy(), "f16x3")
         noise = torch.randn(5, at.shape[0], 3, generator=gen)
         rpos, _ = O.langevin_dynamics_sample_diffusion(sd, cfg, at, pos, bi, bt, ba, b["num_graphs"], False,
                                                        n_steps=5, noise=noise)
         gpos, gtraj = m.langevin_dynamics_sample(at.cuda(), pos.cuda(), bi.cuda(), bt.cuda(), ba.cuda(),
                                                  b["num_graphs"], False, n_steps=5, noise=noise.cuda())
-        check_close("oracle_parity_on_seeded_batches_and_wrapper_defaults gpos", gpos.cpu().numpy(), rpos.numpy(), "bf16x3")
+        check_close("oracle_parity_on_seeded_batches_and_wrapper_defaults gpos", gpos.cpu().numpy(), rpos.numpy(), "f16x3")
         assert len(gtraj) == 5
 
 
@@ -582,10 +585,11 @@ def test_default_initialised_weights(precision):
     ref = O.forward(sd, cfg, at, pos, bi, bt, ba, extend_order=False)
     got = m(at.cuda(), pos.cuda(), bi.cuda(), bt.cuda(), ba.cuda(), None, return_edges=True, extend_order=False)
     assert np.array_equal(got[2].cpu().numpy(), ref[2].numpy())
-    # kaiming-uniform heads without the synthetic filler's damping: the 64 -> 1 output layer cancels to ~1 % of its
-    # terms' size, which is where the relative figure loses a factor ~3 (still inside north_star's 1e-4)
-    check_close("default_initialised_weights got[0]", got[0].cpu().numpy(), ref[0].numpy(), precision, scale=3.0)
-    check_close("default_initialised_weights got[1]", got[1].cpu().numpy(), ref[1].numpy(), precision, scale=3.0)
+    # kaiming-uniform heads without the synthetic filler's damping: the 64 -> 1 output layer cancels to ~1 % of its terms'
+    # size.  Rounds 2-3 needed scale = 3 here in split-bf16 (7.1e-5 on the local head's output); since round 4 the local
+    # branch computes in split-fp16 in both split modes (1.1e-5): the plain gates hold
+    check_close("default_initialised_weights got[0]", got[0].cpu().numpy(), ref[0].numpy(), precision)
+    check_close("default_initialised_weights got[1]", got[1].cpu().numpy(), ref[1].numpy(), precision)
     # the max_norm renormalisation touched the module's own embedding exactly as the oracle's copy
     assert rel_err(m.encoder_global.embedding.weight.detach().cpu().numpy(), sd["encoder_global.embedding.weight"].numpy()) < 1e-6
 
@@ -609,21 +613,21 @@ def test_molecule_larger_than_a_workgroup():
     ref = O.forward(sd, cfg, at, pos, bi, bt, ba, extend_order=False)
     got = m(at.cuda(), pos.cuda(), bi.cuda(), bt.cuda(), ba.cuda(), None, return_edges=True, extend_order=False)
     assert np.array_equal(got[2].cpu().numpy(), ref[2].numpy()) and np.array_equal(got[3].cpu().numpy(), ref[3].numpy())
-    check_close("molecule_larger_than_a_workgroup got[0]", got[0].cpu().numpy(), ref[0].numpy(), "bf16x3")
-    check_close("molecule_larger_than_a_workgroup got[1]", got[1].cpu().numpy(), ref[1].numpy(), "bf16x3")
+    check_close("molecule_larger_than_a_workgroup got[0]", got[0].cpu().numpy(), ref[0].numpy(), "f16x3")
+    check_close("molecule_larger_than_a_workgroup got[1]", got[1].cpu().numpy(), ref[1].numpy(), "f16x3")
     noise = torch.randn(3, 323, 3, generator=gen)
     kw = dict(n_steps=3, w_global=1.0, global_start_sigma=float("inf"), clip=1000.0)
     rpos, _ = O.langevin_dynamics_sample_diffusion(sd, cfg, at, pos, bi, bt, ba, 2, False, noise=noise, **kw)
     gpos, _ = m.langevin_dynamics_sample_diffusion(at.cuda(), pos.cuda(), bi.cuda(), bt.cuda(), ba.cuda(), 2, False,
                                                    noise=noise.cuda(), **kw)
-    check_close("molecule_larger_than_a_workgroup gpos", gpos.cpu().numpy(), rpos.numpy(), "bf16x3")
+    check_close("molecule_larger_than_a_workgroup gpos", gpos.cpu().numpy(), rpos.numpy(), "f16x3")
     ts = torch.tensor([3, 7])
     pn = torch.randn(323, 3, generator=gen)
     rl = O.get_loss_diffusion(sd, cfg, at, pos, bi, bt, ba, 2, ts, pn, extend_order=False)
     gl = m.get_loss(at.cuda(), pos.cuda(), bi.cuda(), bt.cuda(), ba.cuda(), None, 2, return_unreduced_loss=True,
                     extend_order=False, time_step=ts.cuda(), pos_noise=pn.cuda())
     for a_, b_ in zip(gl, rl):
-        check_close("molecule_larger_than_a_workgroup a_", a_.cpu().numpy(), b_.numpy(), "bf16x3")
+        check_close("molecule_larger_than_a_workgroup a_", a_.cpu().numpy(), b_.numpy(), "f16x3")
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 MODES = ["auto", "radius", "kt2", "off"]
 
 
-def _model(cfg, mode, head_scale=1e-3, precision="bf16x3"):
+def _model(cfg, mode, head_scale=1e-3, precision="f16x3"):
     from agdiff_amd import get_model
     from oracle import agdiff_oracle as O
     sd = O.synth_state_dict_for(cfg, head_scale=head_scale)
@@ -61,7 +61,7 @@ def _expect(pk, mode):
     assert (pk.struct.poly_num_slots > 0) == want_slots, (mode, pk.struct.poly_num_slots, pk.poly_errors)
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x3"])
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("case", ["g3_forward_qm9_small", "g3_forward_drugs_capped"])
 def test_forward_every_filter_mode(case, mode, precision):
@@ -78,7 +78,7 @@ def test_forward_every_filter_mode(case, mode, precision):
     check_close("poly[%s] inv_l[%s]" % (mode, case), out[1].cpu().numpy(), g["edge_inv_local"], precision)
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x3"])
 @pytest.mark.parametrize("mode", MODES + ["auto-l2", "auto-mixed"])
 @pytest.mark.parametrize("case", ["g5_sampler_lowT_global", "g5_sampler_mixed_cliplocal"])
 def test_sampler_every_filter_mode(case, mode, precision):
@@ -122,7 +122,7 @@ def test_node_cfconv_equals_one_list_kernel(kind, mols, copies, gt):
     lib = _lib.load()
     RS = _lib.DEFINES["AGDIFF_RAD_STRIDE"]
     cfg = (qm9_model_config if kind == "qm9" else drugs_model_config)(num_diffusion_timesteps=50, beta_end=2e-5)
-    for precision in ("f32", "bf16x3"):
+    for precision in ("f32", "bf16x3", "f16x3"):
         m = _model(cfg, "auto", precision=precision)
         m.group_targets = gt                    # targets per wave: 4 (what large batches take), 2, 1
         b = synth.make_packed_batch(kind, mols, copies, seed=17)
@@ -201,7 +201,7 @@ def test_node_cfconv_equals_one_list_kernel(kind, mols, copies, gt):
             pk.set_tuning(local_poly_off=0)
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x3"])
 def test_sharper_first_layer_takes_64_terms_at_bench_scale(precision):
     """a feature_expansion layer 8 x sharper than the synthetic checkpoint's is not a 32-term polynomial
     at 1e-6 but a 64-term one: in mode `auto` the radius edges AND every local type run on two-k-tile sets (48 KiB each:
@@ -261,7 +261,7 @@ def test_rejected_fit_falls_back_to_the_mlps():
                                                   b["num_graphs"], noise=noise.cuda(), **kw)
     pk = m.packed()
     assert pk.poly_kt == 0 and pk.struct.poly_num_slots == 0 and min(pk.poly_errors.values()) > 1e-6, pk.poly_errors
-    check_close("rejected_fit sampler", got.cpu().numpy(), ref.numpy(), "bf16x3")
+    check_close("rejected_fit sampler", got.cpu().numpy(), ref.numpy(), "f16x3")
 
 
 def _chain_with_bond_types(n_types):
@@ -298,7 +298,7 @@ def test_many_local_edge_types(n_types, slots_kept):
     assert pk.poly_refused_types == (set() if slots_kept else {17})
     assert var & V["AGDIFF_VAR_POLY_L2_SETS"] and var & V["AGDIFF_VAR_CFCONV_NODE_LOCAL"]
     assert bool(var & V["AGDIFF_VAR_CFCONV_LOCAL_MLP"]) == (not slots_kept)      # the seventeenth type alone takes the MLPs
-    check_close("many_local_types[%d] sampler" % n_types, got.cpu().numpy(), ref.numpy(), "bf16x3")
+    check_close("many_local_types[%d] sampler" % n_types, got.cpu().numpy(), ref.numpy(), "f16x3")
 
 
 @pytest.mark.parametrize("kind,mols,copies", [("drugs", 4, 3), ("qm9", 6, 4)])
@@ -333,7 +333,7 @@ def test_radius_only_canonical_list_of_the_sampler(kind, mols, copies):
     assert R == int((ety == 0).sum()) and np.array_equal(cover, (ety == 0).astype(cover.dtype))
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x3"])
 def test_local_edge_rows_polynomial_and_flagged_tiles(precision):
     """agdiff_local_edge_rows against agdiff_edge_encoder (the MLP) on the same canonical local list, through the C ABI:
     compact molecules (every length inside the cutoff: all tiles by polynomial, none flagged), stretched ones (bonded atoms
@@ -379,7 +379,7 @@ def test_local_edge_rows_polynomial_and_flagged_tiles(precision):
 
 
 @pytest.mark.parametrize("kind,mols,copies", [("drugs", 4, 3), ("qm9", 6, 4)])
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x3"])
 def test_fused_front_equals_the_unfused_loop(kind, mols, copies, precision):
     """agdiff_sampler_front (update of step t + radius graph of step t + 1 in one launch, scores by radius row) against the
     unfused loop (agdiff_langevin_update + agdiff_graph_build_scaled, scores by position in the full list): the graph phase

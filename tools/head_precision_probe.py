@@ -21,9 +21,9 @@ pos = torch.randn(at.shape[0], 3, generator=torch.Generator().manual_seed(5)) * 
 ref = O.forward({k: v.clone() for k, v in sd.items()}, cfg, at, pos, bi, bt, ba, extend_order=False)
 
 
-def run(precision, head_f32=False, poly="auto"):
+def run(precision, head_f32=False, poly="auto", local=None):
     m = get_model(cfg)
-    m.precision, m.radius_poly = precision, poly
+    m.precision, m.radius_poly, m.precision_local = precision, poly, local
     m.load_state_dict({k: v.clone() for k, v in sd.items()})
     m = m.to("cuda:0").eval()
     pk = m.packed()
@@ -41,8 +41,10 @@ def run(precision, head_f32=False, poly="auto"):
     return [(rel_err(got[i].cpu().numpy(), ref[i].numpy()), elem_err(got[i].cpu().numpy(), ref[i].numpy())) for i in (0, 1)]
 
 
-for label, kw in (("all bf16x3", dict(precision="bf16x3")), ("bf16x3 + local head fp32", dict(precision="bf16x3", head_f32=True)),
-                  ("all fp32", dict(precision="f32")), ("bf16x3 poly off", dict(precision="bf16x3", poly="off")),
-                  ("bf16x3 poly off + local head fp32", dict(precision="bf16x3", poly="off", head_f32=True))):
+for label, kw in (("bf16x3, local branch f16x3 (default)", dict(precision="bf16x3")),
+                  ("all bf16x3", dict(precision="bf16x3", local="bf16x3")), ("bf16x3 + local head fp32", dict(precision="bf16x3", head_f32=True, local="bf16x3")),
+                  ("bf16x3 global, local branch f32", dict(precision="bf16x3", local="f32")),
+                  ("all fp32", dict(precision="f32")), ("bf16x3 poly off", dict(precision="bf16x3", poly="off", local="bf16x3")),
+                  ("bf16x3 poly off, local f16x3", dict(precision="bf16x3", poly="off"))):
     r = run(**kw)
     print("%-36s inv_g normwise %.2e elem %.2e | inv_l normwise %.2e elem %.2e" % (label, r[0][0], r[0][1], r[1][0], r[1][1]))

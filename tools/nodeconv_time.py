@@ -14,7 +14,7 @@ ap.add_argument("--mols", type=int, default=8)
 ap.add_argument("--copies", type=int, default=128)
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--kind", default="drugs")
-ap.add_argument("--precision", default="bf16x3")
+ap.add_argument("--precision", default="f16x3")
 ap.add_argument("--group", type=int, default=None, help="targets per wave (BatchTopology group_targets): 4, 2, 1; default by batch size")
 ap.add_argument("--only", default=None, choices=["node", "radius"], help="time one variant only (counter passes)")
 args = ap.parse_args()

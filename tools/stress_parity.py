@@ -13,7 +13,7 @@ from helpers import elem_err, rel_err   # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--seeds", type=int, default=12)
-ap.add_argument("--precision", default="bf16x3")
+ap.add_argument("--precision", default="f16x3")
 args = ap.parse_args()
 t = lambda x: torch.from_numpy(np.ascontiguousarray(x))
 worst = {}
