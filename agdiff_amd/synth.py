@@ -110,6 +110,127 @@ def synth_state_dict(template, head_scale=1e-3):
     return out
 
 
+# ----------------------------------------------------------------------------- a checkpoint with a restoring force
+# The closed-form filler above gives a score network without any attraction between bonded atoms: over a full reference
+# schedule (sigma up to 12) the atoms random-walk apart and the radius graph empties -- not the work a trained model does.
+# restoring_state_dict() carves ONE channel through the same 854-key layout so that the local head returns, for every local
+# edge (bond / 2-hop / 3-hop), a spring score  s_e = -kappa (d_e - d0[type_e])  on top of the filler's (small) output:
+#   feature_expansion unit 0           x0 = gelu(d + B) = d + B           (B = 20: gelu is the identity to fp32 there)
+#   edge_feature_mlp.0 unit 0          gelu(x0 + bond_emb[type][0]) = d - d0[type] + B        (bond_emb[:, 0] = -d0)
+#   edge_feature_mlp.2 / combination_mlp.0 / .2 unit 0   pass it on:  edge_attr[0] = d - d0[type] + B
+#   grad_local_dist_mlp.layers.0 units 0 / 1   relu(+-(edge_attr[0] - B)),  layers.1 units 0 / 1 pass them on,
+#   layers.2                           -kappa z0 + kappa z1 = -kappa (d - d0)
+# and takes channel 0 out of everything else that reads edge_attr or the spring units (filter networks, GIN layers, global
+# head, the other head units), so that the rest of the network computes what the filler alone would on 127 channels.  With
+# eq_transform (geometry.py:9-17) s_e < 0 pulls the two atoms together: every local edge is a spring of rest length d0.
+# kappa = 0.1 keeps the explicit Langevin update stable at sigma_max (step / sigma * 4 kappa * degree = 0.12 * 0.4 * 8 < 2).
+RESTORING_D0 = {"bond": 1.5, 23: 2.5, 24: 3.5}      # rest lengths (Angstrom) by edge type: bonds, 2-hop (22 + 2 - 1), 3-hop
+RESTORING_B = 20.0
+
+
+def restoring_state_dict(template, kappa=0.1, head_scale=1e-3):
+    """synth_state_dict(template) with the spring channel described above (same keys, shapes, dtypes)."""
+    return apply_restoring(synth_state_dict(template, head_scale), kappa)
+
+
+def apply_restoring(sd, kappa=0.1):
+    """The spring channel, written into a filler state_dict in place (aliased entries that share storage are edited once
+    more with the same values: harmless)."""
+    B = RESTORING_B
+
+    def edit(ckey, fn):                       # apply fn to the tensor under its attribute name AND its ModuleList alias
+        for k in sd:
+            if canonical_key(k) == ckey:
+                fn(sd[k])
+
+    e = "edge_encoder_global."
+
+    def fe_w(t):
+        t[0, 0] = 1.0
+    def fe_b(t):
+        t[0] = B
+    edit(e + "feature_expansion.weight", fe_w)
+    edit(e + "feature_expansion.bias", fe_b)
+
+    def emb(t):                               # column 0: minus the rest length of the type (type 0 = radius edges: unused)
+        t[:, 0] = -RESTORING_D0["bond"]
+        t[0, 0] = 0.0
+        for ty in (23, 24):
+            t[ty, 0] = -RESTORING_D0[ty]
+    edit(e + "bond_emb.weight", emb)
+
+    def first_of_pair(t):                     # Linear(256 -> 128) on [x || bond_emb]: unit 0 = x0 + emb0; nobody else reads them
+        t[:, 0] = 0.0
+        t[:, 128] = 0.0
+        t[0, :] = 0.0
+        t[0, 0] = 1.0
+        t[0, 128] = 1.0
+    def pass_on(t):                           # Linear(128 -> 128): unit 0 <- unit 0 only
+        t[:, 0] = 0.0
+        t[0, :] = 0.0
+        t[0, 0] = 1.0
+    def zero0(t):
+        t[0] = 0.0
+    edit(e + "edge_feature_mlp.0.weight", first_of_pair)
+    edit(e + "edge_feature_mlp.0.bias", zero0)
+    edit(e + "edge_feature_mlp.2.weight", pass_on)
+    edit(e + "edge_feature_mlp.2.bias", zero0)
+
+    def comb0(t):                             # Linear(256 -> 128) on [p || bond_emb]: unit 0 = p0 (emb0 already applied)
+        t[:, 0] = 0.0
+        t[:, 128] = 0.0
+        t[0, :] = 0.0
+        t[0, 0] = 1.0
+    edit(e + "combination_mlp.0.weight", comb0)
+    edit(e + "combination_mlp.0.bias", zero0)
+    edit(e + "combination_mlp.2.weight", pass_on)
+    edit(e + "combination_mlp.2.bias", zero0)
+    # consumers of edge_attr other than the local head's spring units: channel 0 out
+    def col0(t):
+        t[:, 0] = 0.0
+    def col128(t):
+        t[:, 128] = 0.0
+    for k in list(sd):
+        ck = canonical_key(k)
+        if ck.startswith("encoder_global.interactions.") and ck.endswith(".nn.0.weight"):
+            col0(sd[k])
+        if ck.startswith("encoder_local.convs.") and ck.endswith(".nn.layers.0.weight"):
+            col0(sd[k])                       # (GIN adds edge_attr to h_j: channel 0 of the messages is not read)
+        if ck == "grad_global_dist_mlp.layers.0.weight":
+            col128(sd[k])
+
+    h = "grad_local_dist_mlp."
+
+    def l0w(t):                               # Linear(256 -> 128): units 0 / 1 = +-(edge_attr[0] - B); the others ignore it
+        t[:, 128] = 0.0
+        t[0, :] = 0.0
+        t[1, :] = 0.0
+        t[0, 128] = 1.0
+        t[1, 128] = -1.0
+    def l0b(t):
+        t[0] = -B
+        t[1] = B
+    def l1w(t):                               # Linear(128 -> 64): units 0 / 1 pass the spring units on
+        t[:, 0] = 0.0
+        t[:, 1] = 0.0
+        t[0, :] = 0.0
+        t[1, :] = 0.0
+        t[0, 0] = 1.0
+        t[1, 1] = 1.0
+    def l1b(t):
+        t[0] = 0.0
+        t[1] = 0.0
+    def l2w(t):
+        t[0, 0] = -kappa
+        t[0, 1] = kappa
+    edit(h + "layers.0.weight", l0w)
+    edit(h + "layers.0.bias", l0b)
+    edit(h + "layers.1.weight", l1w)
+    edit(h + "layers.1.bias", l1b)
+    edit(h + "layers.2.weight", l2w)
+    return sd
+
+
 # ----------------------------------------------------------------------------- molecules
 NUM_BOND_TYPES = 22          # len(BOND_TYPES), utils/chem.py:17 / edge.py:21
 _ATOM_CHOICES = np.array([1, 6, 7, 8, 9, 16, 17])

@@ -428,7 +428,7 @@ def main():
 
     # The measured path never touches oracle/: the synthetic checkpoint comes from the product-side closed-form
     # filler (agdiff_amd/synth.py; the oracle fills its own copy with the same function in the cpu_baseline leg).
-    def make_model(schedule, radius_poly=None):
+    def make_model(schedule, radius_poly=None, weights="filler"):
         cfg = make_cfg(kind, schedule)
         m = get_model(cfg)
         m.precision = args.precision
@@ -436,7 +436,8 @@ def main():
         m.fused_front, m.front_split_graph = args.front != "unfused", args.front == "split"
         if args.serial:
             m.tuning["serial_branches"] = 1
-        m.load_state_dict(synth.synth_state_dict(m.state_dict()))
+        fill = synth.restoring_state_dict if weights == "restoring" else synth.synth_state_dict
+        m.load_state_dict(fill(m.state_dict()))
         return m.to(dev).eval(), cfg
     model, cfg = make_model(args.schedule)
 
@@ -693,7 +694,7 @@ def main():
     # ---- `extra`: the reference's own schedule on the same job, with and without simplification (vii) (skipping
     # the global branch on steps whose result the sampler discards changes the work per step, not the outputs), and the
     # headline's fallback: the same saturated job with the filter polynomials off (every edge through the MLP kernels)
-    def full_job(mdl, mcfg, batches_, confs_of_):
+    def full_job(mdl, mcfg, batches_, confs_of_, schedule=None, extrapolate=True):
         """ONE complete sampling job, wall clock: the largest packed batch of the default job x all 5000 denoising steps at the
         saturated schedule, trajectory kept on the device and copied to the host by finish() as the reference returns it
         (dualenc.py:545-547), the driver's default NaN polling (every 64 steps) -- next to the 20-step extrapolation."""
@@ -705,9 +706,12 @@ def main():
         pos_init = torch.randn(at.shape[0], 3, generator=g_).to(dev)
         kw = dict(n_steps=JOB_STEPS, step_lr=1e-6, clip=1000.0, global_start_sigma=0.5, w_global=1.0, save_traj=save_traj,
                   skip_discarded_global=skip)
+        schedule = schedule or args.schedule
         # short run of the same batch for the extrapolated figure (same code path as the headline)
-        el_s, r_s, _, _, _ = timed_run(mdl, dev, b_, mcfg, W, K, args.schedule, skip, save_traj, args.seed + 77, rank, False)
-        del r_s
+        el_s = None
+        if extrapolate:
+            el_s, r_s, _, _, _ = timed_run(mdl, dev, b_, mcfg, W, K, schedule, skip, save_traj, args.seed + 77, rank, False)
+            del r_s
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         run_ = mdl.begin_sampling(at, pos_init, bi, bt, ba, b_["num_graphs"], False, **kw)
@@ -717,12 +721,15 @@ def main():
         pos_f, traj_f = run_.finish()          # trajectory D2H: n_steps x N x 12 B
         t_all = time.perf_counter() - t0
         finite = bool(torch.isfinite(pos_f).all().item())
-        rec = {"batch_atoms": int(at.shape[0]), "conformers": int(b_["num_graphs"]), "steps": JOB_STEPS,
+        rec = {"schedule": schedule, "batch_atoms": int(at.shape[0]), "conformers": int(b_["num_graphs"]), "steps": JOB_STEPS,
+               "global_branch_steps": int(run_.global_steps),
                "full_job_s": t_all, "denoising_loop_s": t_loop, "finish_trajectory_d2h_s": t_all - t_loop,
                "trajectory_bytes": int(len(traj_f)) * int(at.shape[0]) * 12,
-               "extrapolated_s": el_s / K * JOB_STEPS, "ratio_full_over_extrapolated": t_all / (el_s / K * JOB_STEPS),
                "conformers_per_s_full_job": b_["num_graphs"] / t_all, "nan_check_every": 64,
-               "positions_finite": finite, "max_abs_pos": float(pos_f.abs().max().item())}
+               "positions_finite": finite, "max_abs_pos": float(pos_f.abs().max().item()),
+               "radius_in_degree_at_the_end": float(run_.ws.rad_cnt.float().mean().item())}
+        if el_s is not None:
+            rec.update(extrapolated_s=el_s / K * JOB_STEPS, ratio_full_over_extrapolated=t_all / (el_s / K * JOB_STEPS))
         del run_, traj_f
         return rec
 
@@ -768,10 +775,8 @@ def main():
         del run
         Ke, We = min(K, 200), min(W, 10)
         every = 4 if d200 else 1
-        extra = {"note": "same job and checkpoint%s; reference schedule = beta_end 2e-3 (sigma < 0.5 on 2012 of 5000 steps), "
-                         "%d timed steps per batch spread evenly over the schedule -- the synthetic model has no restoring "
-                         "force, so at high sigma the molecules spread out and the radius graph thins; fallback = saturated "
-                         "schedule with --radius-poly off" % (" on every 4th packed batch" if d200 else "", Ke)}
+        extra = {"note": "same job%s; reference schedule = beta_end 2e-3 (sigma < 0.5 on 2012 of 5000 steps), %d timed steps per "
+                         "batch; fallback = saturated schedule with --radius-poly off" % (" on every 4th packed batch" if d200 else "", Ke)}
 
         def side_run(mdl, mcfg, schedule, sk):
             if d200:
@@ -783,12 +788,17 @@ def main():
             ms2 = el2 / Ke * 1e3
             del r2
             return b["num_graphs"] / (ms2 * JOB_STEPS / 1e3), ms2, gf, 1
-        m2, cfg2 = make_model("default")
+        # the reference's schedule on the synthetic checkpoint WITH a restoring force (agdiff_amd/synth.py: every local edge a
+        # spring; reference-pinned by tests/golden/g14_*): molecules stay compact at every sigma, so the steps below sigma = 0.5
+        # see the dense radius graph a trained model would see
+        m2, cfg2 = make_model("default", weights="restoring")
         for name, sk in (("default_schedule_skip_discarded_global", True), ("default_schedule_no_skip", False)):
             v, ms2, gf2, nb = side_run(m2, cfg2, "default", sk)
             extra[name] = {"value": v, "unit": "conformers/s", "ms_per_step": ms2, "steps": Ke, "batches": nb,
-                           "global_branch_share_of_steps": gf2,
-                           "note": "timed steps drawn from the two ranges of the schedule (sigma < 0.5 / >= 0.5) in the job's own proportion 2012 : 2988"}
+                           "global_branch_share_of_steps": gf2, "checkpoint": "synthetic filler + restoring force",
+                           "note": "timed steps drawn from the two ranges of the schedule (sigma < 0.5 / >= 0.5) in the job's own proportion 2012 : 2988; "
+                                   "each batch starts from N(0, sigma_T^2) positions, so the few timed steps at low sigma still see a spread-out "
+                                   "graph: the full-schedule figure for compact molecules is extra.default_schedule_full_job"}
         del m2
         if args.radius_poly != "off":
             m3, cfg3 = make_model(args.schedule, radius_poly="off")
@@ -830,6 +840,12 @@ def main():
                 dist.destroy_process_group()
         if d200 and not args.no_full_job:
             extra["full_job"] = full_job(model, cfg, batches, confs_of)
+            # ... and the REFERENCE's schedule end to end on the restoring-force checkpoint: 2012 steps with the global branch on
+            # a dense radius graph, 2988 local-only steps -- what a trained model's 5000-step job costs
+            m5, cfg5 = make_model("default", weights="restoring")
+            extra["default_schedule_full_job"] = full_job(m5, cfg5, batches, confs_of, schedule="default", extrapolate=False)
+            extra["default_schedule_full_job"]["checkpoint"] = "synthetic filler + restoring force (agdiff_amd/synth.py; tests/golden/g14_*)"
+            del m5
         if d200 and not args.no_qm9_extra:
             extra["configs1_qm9"] = qm9_extra()
         if cpu is not None:

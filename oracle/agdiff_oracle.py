@@ -393,9 +393,10 @@ def langevin_dynamics_sample_diffusion(sd, cfg, atom_type, pos_init, bond_index,
     return pos, pos_traj
 
 
-def synth_state_dict_for(cfg, head_scale=1e-3):
+def synth_state_dict_for(cfg, head_scale=1e-3, weights="filler"):
     """Build the 854-key state_dict (SURVEY §8b / tests/golden/g7_state_dict_keys.txt) with the
-    shared closed-form filler; used by tests and bench to give oracle and product equal weights."""
+    shared closed-form filler; used by tests and bench to give oracle and product equal weights.
+    weights="restoring": plus the spring channel of agdiff_amd.synth.apply_restoring."""
     from agdiff_amd import synth  # pure-numpy helper shared by tests/bench (not a compute path)
     import os
     keys = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden",
@@ -424,4 +425,8 @@ def synth_state_dict_for(cfg, head_scale=1e-3):
         c = synth.canonical_key(k)
         if c != k:
             sd[k] = sd[c]
+    if weights == "restoring":
+        synth.apply_restoring(sd)
+    elif weights != "filler":
+        raise ValueError("weights must be 'filler' or 'restoring'")
     return sd

@@ -49,9 +49,10 @@ def T(x, dtype=None):
     return t if dtype is None else t.to(dtype)
 
 
-def build_ref(cfg, head_scale=1e-3):
+def build_ref(cfg, head_scale=1e-3, weights="filler"):
     model = get_model(cfg)
-    sd = synth.synth_state_dict(model.state_dict(), head_scale=head_scale)
+    fill = synth.restoring_state_dict if weights == "restoring" else synth.synth_state_dict
+    sd = fill(model.state_dict(), head_scale=head_scale)
     model.load_state_dict(sd)
     model.eval()
     return model
@@ -156,8 +157,8 @@ class NoiseInjector:
         torch.randn_like = self.orig
 
 
-def g_sampler(name, cfg, kind, seed, nmol, copies, n_steps, head_scale=1e-3, **kw):
-    m = build_ref(cfg, head_scale=head_scale)
+def g_sampler(name, cfg, kind, seed, nmol, copies, n_steps, head_scale=1e-3, weights="filler", **kw):
+    m = build_ref(cfg, head_scale=head_scale, weights=weights)
     b, _ = small_batch(kind, seed, nmol, copies, 1.0)
     at, bi, bt, ba = T(b["atom_type"]), T(b["bond_index"]), T(b["bond_type"]), T(b["batch"])
     g = torch.Generator().manual_seed(seed + 7)
@@ -174,6 +175,22 @@ def g_sampler(name, cfg, kind, seed, nmol, copies, n_steps, head_scale=1e-3, **k
          pos_init=pos_init, noise=noise, pos_final=pos, traj=torch.stack(traj), n_steps=n_steps,
          sigmas=sig, head_scale=head_scale,
          cfg_T=cfg.num_diffusion_timesteps, cfg_beta_end=cfg.beta_end, cfg_smooth=int(cfg.smooth_conv), **kwn)
+
+
+def g_restoring():
+    """The synthetic checkpoint with a restoring force (agdiff_amd/synth.py: restoring_state_dict): one forward with all six
+    outputs and a 14-step sampler run across the whole sigma range of a 14-step schedule (global branch on and off)."""
+    cfg = drugs_model_config(num_diffusion_timesteps=14, beta_end=0.7)
+    m = build_ref(cfg, weights="restoring")
+    b, pos = small_batch("drugs", 41, 2, 2, 2.5)
+    at, bi, bt, ba = T(b["atom_type"]), T(b["bond_index"]), T(b["bond_type"]), T(b["batch"])
+    with torch.no_grad():
+        eg, el, ei, et, elen, lmask = m(at, pos, bi, bt, ba, None, return_edges=True, extend_order=False, extend_radius=True)
+    save("g14_forward_restoring", atom_type=at, pos=pos, bond_index=bi, bond_type=bt, batch=ba, edge_inv_global=eg,
+         edge_inv_local=el, edge_index=ei, edge_type=et, edge_length=elen, local_edge_mask=lmask,
+         cfg_T=cfg.num_diffusion_timesteps, cfg_beta_end=cfg.beta_end)
+    g_sampler("g14_sampler_restoring", cfg, "drugs", 42, 2, 2, n_steps=14, weights="restoring",
+              step_lr=1e-6, w_global=1.0, global_start_sigma=0.5, clip=1000.0)
 
 
 def g_alanine():
@@ -408,10 +425,10 @@ def g_losses():
 
 
 if __name__ == "__main__":
-    if sys.argv[1:] and all(a in ("gaussian", "alanine", "loss", "variants", "extend", "covmat") for a in sys.argv[1:]):   # add without touching the others
+    if sys.argv[1:] and all(a in ("gaussian", "alanine", "loss", "variants", "extend", "covmat", "restoring") for a in sys.argv[1:]):   # add without touching the others
         for a in sys.argv[1:]:
             {"gaussian": g_gaussian, "alanine": g_alanine, "loss": g_losses, "variants": g_forward_variants,
-             "extend": g_extend_order_forward, "covmat": g_covmat}[a]()
+             "extend": g_extend_order_forward, "covmat": g_covmat, "restoring": g_restoring}[a]()
         sys.exit(0)
     g_schedule_and_keys()
     # G2+G3 uncapped QM9-shaped batch with per-stage outputs (small: 3 molecules x 1 copy)
@@ -436,3 +453,4 @@ if __name__ == "__main__":
     g_forward_variants()
     g_extend_order_forward()
     g_covmat()
+    g_restoring()

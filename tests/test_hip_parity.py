@@ -668,3 +668,67 @@ def test_ragged_and_degenerate_graphs(precision):
                                                    n_steps=3, noise=noise.cuda(), w_global=1.0,
                                                    global_start_sigma=float("inf"))
     check_close("ragged_and_degenerate_graphs gpos", gpos.cpu().numpy(), rpos.numpy(), precision)
+
+
+# ---------------------------------------------------------------------------------------------------- restoring checkpoint
+def _restoring_model(cfg, precision="f16x3"):
+    from agdiff_amd import get_model, synth
+    m = get_model(cfg)
+    m.precision = precision
+    m.load_state_dict(synth.restoring_state_dict(m.state_dict()), strict=True)
+    return m.to("cuda:0").eval()
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_restoring_checkpoint_matches_reference_golden(precision):
+    """Forward and sampler on the synthetic checkpoint with a restoring force (agdiff_amd/synth.py: restoring_state_dict)
+    against the REFERENCE's outputs on the same weights (tests/golden/make_golden.py:g_restoring)."""
+    from agdiff_amd import drugs_model_config
+    g = load_golden("g14_forward_restoring")
+    cfg = drugs_model_config(num_diffusion_timesteps=int(g["cfg_T"]), beta_end=float(g["cfg_beta_end"]))
+    m = _restoring_model(cfg, precision)
+    out = m(t(g["atom_type"]).cuda(), t(g["pos"]).cuda(), t(g["bond_index"]).cuda(), t(g["bond_type"]).cuda(),
+            t(g["batch"]).cuda(), None, return_edges=True, extend_order=False)
+    assert np.array_equal(out[2].cpu().numpy(), g["edge_index"]) and np.array_equal(out[3].cpu().numpy(), g["edge_type"])
+    check_close("restoring forward inv_g", out[0].cpu().numpy(), g["edge_inv_global"], precision)
+    check_close("restoring forward inv_l", out[1].cpu().numpy(), g["edge_inv_local"], precision)
+    gs = load_golden("g14_sampler_restoring")
+    pos, traj = m.langevin_dynamics_sample_diffusion(
+        t(gs["atom_type"]).cuda(), t(gs["pos_init"]).cuda(), t(gs["bond_index"]).cuda(), t(gs["bond_type"]).cuda(),
+        t(gs["batch"]).cuda(), int(gs["num_graphs"]), extend_order=False, n_steps=int(gs["n_steps"]),
+        noise=t(gs["noise"]).cuda(), **sampler_case_kwargs(gs))
+    check_close("restoring sampler traj", torch.stack(traj).numpy(), gs["traj"], precision)
+    check_close("restoring sampler pos", pos.cpu().numpy(), gs["pos_final"], precision)
+
+
+def test_restoring_checkpoint_keeps_molecules_compact_over_the_reference_schedule():
+    """What the restoring checkpoint is for: over the reference's own schedule (sigma 12.2 -> 0.002; 500 of
+    its 5000 steps, evenly spaced) Drugs-shaped molecules stay compact -- the filler alone lets them random-walk apart -- and
+    end with their bonds near the springs' rest length, so that the radius graph the global branch sees below sigma = 0.5 is
+    the dense one a trained model would see."""
+    from agdiff_amd import drugs_model_config, get_model, synth
+    cfg = drugs_model_config()
+    b = synth.make_packed_batch("drugs", 4, 3, seed=11)
+    at, bi, bt, ba = [t(b[k]).cuda() for k in ("atom_type", "bond_index", "bond_type", "batch")]
+    pos_init = torch.randn(at.shape[0], 3, generator=torch.Generator().manual_seed(4)).cuda()
+    idx = np.linspace(cfg.num_diffusion_timesteps - 1, 0, 500).round().astype(int).tolist()
+    kw = dict(extend_order=False, n_steps=500, step_indices=idx, w_global=1.0, global_start_sigma=0.5, clip=1000.0, save_traj=False)
+    torch.manual_seed(7)
+    m = _restoring_model(cfg)
+    pos, _ = m.langevin_dynamics_sample_diffusion(at, pos_init, bi, bt, ba, b["num_graphs"], **kw)
+    assert bool(torch.isfinite(pos).all())
+    p = pos.cpu().numpy()
+    bonds = b["bond_type"] < 22                            # true bonds (2-/3-hop edges carry 23 / 24)
+    i, j = b["bond_index"][0][bonds], b["bond_index"][1][bonds]
+    d = np.linalg.norm(p[i] - p[j], axis=1)
+    assert np.abs(p).max() < 25.0, np.abs(p).max()         # compact: a 44-atom chain of 1.5 A bonds spans < 2 x 25 A
+    assert 1.0 < np.median(d) < 2.0 and d.max() < 4.0, (np.median(d), d.max())
+    rad_cnt = m._batch_cache[2].rad_cnt.cpu().numpy()
+    assert rad_cnt.mean() > 10                              # the radius graph of the last steps is dense
+    # the plain filler on the same job: atoms far apart, (almost) no radius edges left
+    m2 = get_model(cfg)
+    m2.load_state_dict(synth.synth_state_dict(m2.state_dict()))
+    m2 = m2.to("cuda:0").eval()
+    torch.manual_seed(7)
+    pos2, _ = m2.langevin_dynamics_sample_diffusion(at, pos_init, bi, bt, ba, b["num_graphs"], **kw)
+    assert np.abs(pos2.cpu().numpy()).max() > 4 * np.abs(p).max()

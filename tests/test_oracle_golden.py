@@ -195,3 +195,25 @@ def test_forward_and_sampler_with_extend_order_g12():
         step_lr=1e-6, w_global=1.0, global_start_sigma=0.5, clip=1000.0, noise=t(g["noise"]))
     assert rel_err(torch.stack(traj).numpy(), g["traj"]) < TOL
     assert rel_err(pos.numpy(), g["pos_final"]) < TOL
+
+
+def test_restoring_checkpoint_g14():
+    """The synthetic checkpoint with a restoring force (agdiff_amd/synth.py: apply_restoring): the oracle against the
+    reference's own forward and 14-step sampler run on those weights, and the spring identity itself."""
+    from agdiff_amd.config import drugs_model_config
+    g = load_golden("g14_forward_restoring")
+    cfg = drugs_model_config(num_diffusion_timesteps=int(g["cfg_T"]), beta_end=float(g["cfg_beta_end"]))
+    sd = O.synth_state_dict_for(cfg, weights="restoring")
+    inv_g, inv_l, ei, et, elen, lm = O.forward(sd, cfg, t(g["atom_type"]), t(g["pos"]), t(g["bond_index"]), t(g["bond_type"]),
+                                                t(g["batch"]), extend_order=False)
+    assert np.array_equal(ei.numpy(), g["edge_index"]) and np.array_equal(et.numpy(), g["edge_type"])
+    assert rel_err(inv_g.numpy(), g["edge_inv_global"]) < TOL and rel_err(inv_l.numpy(), g["edge_inv_local"]) < TOL
+    # every local edge is a spring of rest length d0[type]: s = -kappa (d - d0) up to the filler's small output
+    d, ty = g["edge_length"][g["local_edge_mask"], 0].astype(np.float64), g["edge_type"][g["local_edge_mask"]]
+    d0 = np.where(ty == 23, 2.5, np.where(ty == 24, 3.5, 1.5))
+    assert np.abs(g["edge_inv_local"][:, 0] + 0.1 * (d - d0)).max() < 2e-2
+    gs = load_golden("g14_sampler_restoring")
+    pos, traj = O.langevin_dynamics_sample_diffusion(
+        sd, cfg, t(gs["atom_type"]), t(gs["pos_init"]), t(gs["bond_index"]), t(gs["bond_type"]), t(gs["batch"]),
+        int(gs["num_graphs"]), extend_order=False, n_steps=int(gs["n_steps"]), noise=t(gs["noise"]), **sampler_case_kwargs(gs))
+    assert rel_err(torch.stack(traj).numpy(), gs["traj"]) < 2e-5 and rel_err(pos.numpy(), gs["pos_final"]) < 2e-5
