@@ -256,6 +256,33 @@ class DualEncoderEpsNetwork(nn.Module):
         self._packed.set_tuning(**{k: self.tuning.get(k, 0) for k in PackedParams.TUNING})
         return self._packed
 
+    # Range watch of the split-fp16 modes.  fp16 operands saturate at 65504 (a saturated operand gives a finite but wrong
+    # product), and the pair heads multiply two node features, so the node tensors every MFMA chain starts from are watched:
+    # |h|, |hl| (SchNet / GIN node states) <= 255 keeps h_i * h_j inside the range, |agg|, |xs| <= 60000 themselves.  A trained
+    # AGDIFF (max_norm-10 embedding, BatchNorm'd CFConvs and GIN layers) sits two to three orders of magnitude below; what
+    # trips the watch is a diverging run or a degenerate checkpoint, for which precision="bf16x3" has fp32's range.
+    RANGE_LIMITS = (("h", 255.0), ("hl", 255.0), ("agg", 60000.0), ("xs", 60000.0))
+
+    def _uses_split_fp16(self):
+        return self.precision == "f16x3" or (self.precision == "bf16x3" and getattr(self, "precision_local", None) in (None, "f16x3"))
+
+    def check_range(self, ws):
+        """Raise AgdiffRangeError when a watched node tensor of workspace `ws` has left the split-fp16 range (one small
+        device reduction and one host synchronisation: called where the NaN flag is polled)."""
+        if not self._uses_split_fp16():
+            return
+        names = [n for n, _ in self.RANGE_LIMITS if self.precision == "f16x3" or n == "hl"]
+        mx = torch.stack([getattr(ws, n).abs().max() for n in names]).cpu().tolist()
+        for n, v in zip(names, mx):
+            lim = dict(self.RANGE_LIMITS)[n]
+            if not (v <= lim):          # (also a NaN)
+                if v != v:
+                    continue            # NaNs are the NaN flag's business (dualenc.py:539-541)
+                raise _lib.AgdiffRangeError(
+                    "max |%s| = %.3g exceeds %.0f: outside the range in which the split-fp16 arithmetic mode is valid (fp16 "
+                    "operands saturate at 65504; the pair heads multiply two node features) -- set model.precision = 'bf16x3'"
+                    % (n, v, lim))
+
     def _renorm_embedding(self, atom_type):
         # nn.Embedding(max_norm=10) renormalises looked-up rows in place on every forward, also in
         # eval mode (schnet.py:254,271); same ATen op, same side effect on the state_dict.
@@ -298,6 +325,7 @@ class DualEncoderEpsNetwork(nn.Module):
                                                 self._fwd_flags(topo, extend_radius), _lib.stream_ptr()),
                        "agdiff_score_forward")
             E = int(ws.num_edges.item())
+            self.check_range(ws)
             perm = ws.ref2dst[:E].long()                     # reference (row, col)-sorted order
             inv_g = ws.e_inv_global[:E][perm].unsqueeze(-1)
             inv_l = ws.l_inv[:topo.L].clone().unsqueeze(-1)
@@ -654,6 +682,7 @@ class LangevinRun:
         if self.raise_on_nan and int(self.ws.nan_flag[0].item()) != 0:
             print("NaN detected. Please restart.")
             raise FloatingPointError()
+        self.model.check_range(self.ws)
 
     def nan_graphs(self):
         """Bool tensor [G] (host): graphs in which a position became NaN so far (ws.nan_flag[1 + g])."""

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""How the headline depends on the sharpness of the checkpoint's first encoder layer: the synthetic
+checkpoint with edge_encoder_global.feature_expansion.weight scaled by 1, 2, 5, 8, 16, 40 -- per scale the number of
+polynomial terms the host accepts for the radius edges (32 / 64 / refused -> filter MLPs), the fit error against the float64
+networks, how many local edge types got a polynomial, parity of one forward against the oracle (small batch) and the
+throughput of the saturated sampler on the round-1/2 bench batch (8 Drugs-shaped molecules x 128 conformers).
+   python tools/sharpness_sweep.py [--out profiles/r04_sharpness_sweep.json]"""
+import argparse, json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+from agdiff_amd import drugs_model_config, get_model, synth
+from oracle import agdiff_oracle as O
+from helpers import rel_err
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--out", default=None)
+ap.add_argument("--steps", type=int, default=60)
+ap.add_argument("--scales", default="1,2,5,8,16,40")
+args = ap.parse_args()
+dev = torch.device("cuda", 0)
+T = lambda x: torch.from_numpy(np.ascontiguousarray(x))
+cfg = drugs_model_config(beta_end=2e-5)
+small = synth.make_packed_batch("drugs", 2, 2, seed=77)
+big = synth.make_packed_batch("drugs", 8, 128, seed=2021)
+pos_small = torch.randn(small["atom_type"].shape[0], 3, generator=torch.Generator().manual_seed(5)) * 2.0
+rows = []
+for scale in [float(x) for x in args.scales.split(",")]:
+    m = get_model(cfg)
+    sd = synth.synth_state_dict(m.state_dict())
+    for k in sd:
+        if synth.canonical_key(k) == "edge_encoder_global.feature_expansion.weight":
+            sd[k] = sd[k] * scale
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    at, bi, bt, ba = [T(small[k]) for k in ("atom_type", "bond_index", "bond_type", "batch")]
+    ref = O.forward({k: v.clone() for k, v in sd.items()}, cfg, at, pos_small, bi, bt, ba, extend_order=False)
+    got = m(at.to(dev), pos_small.to(dev), bi.to(dev), bt.to(dev), ba.to(dev), None, return_edges=True, extend_order=False)
+    pk = m.packed()
+    rec = {"first_layer_scale": scale, "poly_kt": int(pk.poly_kt), "terms": 32 * int(pk.poly_kt),
+           "fit_errors": {str(k): float(v) for k, v in pk.poly_errors.items()},
+           "local_type_slots": int(pk.struct.poly_num_slots), "refused_local_types": sorted(int(t_) for t_ in pk.poly_refused_types),
+           "parity_inv_g": rel_err(got[0].cpu().numpy(), ref[0].numpy()), "parity_inv_l": rel_err(got[1].cpu().numpy(), ref[1].numpy())}
+    at, bi, bt, ba = [T(big[k]).to(dev) for k in ("atom_type", "bond_index", "bond_type", "batch")]
+    pos_init = torch.randn(at.shape[0], 3, generator=torch.Generator().manual_seed(2021)).to(dev)
+    n = 10 + args.steps
+    run = m.begin_sampling(at, pos_init, bi, bt, ba, big["num_graphs"], False, n_steps=n, step_lr=1e-6, clip=1000.0,
+                           global_start_sigma=0.5, w_global=1.0, save_traj=False)
+    run.advance(10)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run.advance(args.steps)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    run.check_nan()
+    rec.update(ms_per_step_8x128=ms, conformers_per_s_8x128=big["num_graphs"] / (ms * 5000 / 1e3),
+               path="filter polynomials, %d terms" % (32 * pk.poly_kt) if pk.poly_kt else "filter MLPs (fit refused at 32 and 64 terms)")
+    rows.append(rec)
+    print(json.dumps(rec), flush=True)
+    del run, m
+base = rows[0]["conformers_per_s_8x128"]
+for r in rows:
+    r["fraction_of_scale_1"] = r["conformers_per_s_8x128"] / base
+if args.out:
+    json.dump({"workload": "8 Drugs-shaped molecules x 128 conformers, saturated schedule, %d timed steps; parity: one forward of a 2 x 2 batch against the oracle (normwise)" % args.steps,
+               "rows": rows}, open(args.out, "w"), indent=1)
