@@ -26,19 +26,31 @@ small = synth.make_packed_batch("drugs", 2, 2, seed=77)
 big = synth.make_packed_batch("drugs", 8, 128, seed=2021)
 pos_small = torch.randn(small["atom_type"].shape[0], 3, generator=torch.Generator().manual_seed(5)) * 2.0
 rows = []
+from agdiff_amd import _lib
 for scale in [float(x) for x in args.scales.split(",")]:
-    m = get_model(cfg)
-    sd = synth.synth_state_dict(m.state_dict())
-    for k in sd:
-        if synth.canonical_key(k) == "edge_encoder_global.feature_expansion.weight":
-            sd[k] = sd[k] * scale
-    m.load_state_dict(sd)
-    m = m.to(dev).eval()
+    def build(precision):
+        m_ = get_model(cfg)
+        m_.precision = precision
+        sd_ = synth.synth_state_dict(m_.state_dict())
+        for k in sd_:
+            if synth.canonical_key(k) == "edge_encoder_global.feature_expansion.weight":
+                sd_[k] = sd_[k] * scale
+        m_.load_state_dict(sd_)
+        return m_.to(dev).eval(), sd_
     at, bi, bt, ba = [T(small[k]) for k in ("atom_type", "bond_index", "bond_type", "batch")]
+    precision = "f16x3"
+    m, sd = build(precision)
     ref = O.forward({k: v.clone() for k, v in sd.items()}, cfg, at, pos_small, bi, bt, ba, extend_order=False)
-    got = m(at.to(dev), pos_small.to(dev), bi.to(dev), bt.to(dev), ba.to(dev), None, return_edges=True, extend_order=False)
+    try:
+        got = m(at.to(dev), pos_small.to(dev), bi.to(dev), bt.to(dev), ba.to(dev), None, return_edges=True, extend_order=False)
+    except _lib.AgdiffRangeError as e:         # node features beyond the split-fp16 range: the range-safe mode
+        precision = "bf16x3"
+        m, sd = build(precision)
+        m.precision_local = "bf16x3"
+        got = m(at.to(dev), pos_small.to(dev), bi.to(dev), bt.to(dev), ba.to(dev), None, return_edges=True, extend_order=False)
     pk = m.packed()
-    rec = {"first_layer_scale": scale, "poly_kt": int(pk.poly_kt), "terms": 32 * int(pk.poly_kt),
+    rec = {"first_layer_scale": scale, "precision": precision, "max_abs_reference_inv_g": float(ref[0].abs().max()),
+           "poly_kt": int(pk.poly_kt), "terms": 32 * int(pk.poly_kt),
            "fit_errors": {str(k): float(v) for k, v in pk.poly_errors.items()},
            "local_type_slots": int(pk.struct.poly_num_slots), "refused_local_types": sorted(int(t_) for t_ in pk.poly_refused_types),
            "parity_inv_g": rel_err(got[0].cpu().numpy(), ref[0].numpy()), "parity_inv_l": rel_err(got[1].cpu().numpy(), ref[1].numpy())}
