@@ -44,9 +44,10 @@ def elem_err(a, b, floor_frac=1e-3):
 # measure on MI355X (profiles/r02_parity_errors.json: exact-fp32 MFMA ~1e-6 normwise on the fixtures, split-bf16
 # ~1.5e-5; element-wise with the 1e-3 floor 5e-4 / 1.2e-2), so that a regression of half an order of magnitude
 # turns the suite red.  A call site that needs more room says why and passes `scale`.
-# split-fp16 ("f16x3", the default mode since round 4): measured <= 4.8e-6 normwise on the reference fixtures, 1.1e-5 on
-# default-initialised weights, element-wise <= 3.0e-3 (profiles/r04_parity_errors.json)
-TOL_NORM = {"f32": 5e-6, "bf16x3": 3e-5, "f16x3": 1.5e-5}
+# split-fp16 ("f16x3", the default mode since round 4): measured <= 5.7e-6 normwise on the reference fixtures, 1.1e-5 on
+# default-initialised weights, 1.5e-5 after three sampler steps of a 300-atom molecule, element-wise <= 3.4e-3
+# (profiles/r04_parity_errors.json)
+TOL_NORM = {"f32": 5e-6, "bf16x3": 3e-5, "f16x3": 2e-5}
 TOL_ELEM = {"f32": 2e-3, "bf16x3": 3e-2, "f16x3": 5e-3}
 # (No environment switch loosens these gates: tests/conftest.py refuses to start a session in which
 # AGDIFF_PARITY_GATE_SCALE -- the measuring knob of rounds 2-3 -- is set.)
