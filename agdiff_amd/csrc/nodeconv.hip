@@ -141,11 +141,14 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
   // pair each and spilled)
   auto ldf = [](const float* base, uint32_t byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); };
   auto ldi = [](const int32_t* base, uint32_t byte_off) { return *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(base) + byte_off); };
+  // (the radius rows are written by the front kernel and read once per launch: non-temporal, so that they do not evict x rows)
+  auto ldf_nt = [](const float* base, uint32_t byte_off) { return __builtin_nontemporal_load(reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off)); };
   auto prefetch_meta = [&](int rows, bool local) {
     const uint32_t e4 = (uint32_t)(rows + col) * 4u;
     const uint32_t r16 = (uint32_t)(rows + 4 * q) * 4u;
-    const int32_t* srcs = local ? a.lt_src : a.rad_src;
-    const u32x4 s4 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(srcs) + r16);
+    u32x4 s4;
+    if (!local) s4 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.rad_src) + r16));
+    else s4 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.lt_src) + r16);
 #pragma unroll
     for (int r = 0; r < 4; ++r) pf_src[r] = (int)s4[r];
     if (local) {
@@ -156,9 +159,9 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
       pf_s2 = ldf(a.l_scale2, e4);
     } else {
       pf_slot = -1;
-      pf_d = ldf(a.rad_len, e4);
-      pf_s1 = ldf(a.r_scale1, e4);
-      pf_s2 = ldf(a.r_scale2, e4);
+      pf_d = ldf_nt(a.rad_len, e4);
+      pf_s1 = ldf_nt(a.r_scale1, e4);
+      pf_s2 = ldf_nt(a.r_scale2, e4);
     }
   };
   // x[src] values of a group of AG_NODE_GRP channel tiles, two groups in flight
@@ -253,7 +256,8 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
       float v[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = acc[4 * g + j] + (mine ? accL[4 * g + j] : 0.0f);
-      *reinterpret_cast<float*>(dp + (uint32_t)(16 * (4 * g + q) + col) * 4u) = ag_quarter_reduce_scatter4(v[0], v[1], v[2], v[3]);
+      // (one 768-byte row per node, read once by the node stage: streamed past the caches like the radius rows)
+      __builtin_nontemporal_store(ag_quarter_reduce_scatter4(v[0], v[1], v[2], v[3]), reinterpret_cast<float*>(dp + (uint32_t)(16 * (4 * g + q) + col) * 4u));
     }
   };
 
