@@ -7,9 +7,22 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from agdiff_amd import drugs_model_config, qm9_model_config, get_model, synth
-for kind, cfgf in (("drugs", drugs_model_config), ("qm9", qm9_model_config)):
+# two checkpoints: the restoring-force one in the default split-fp16 mode (molecules stay compact: what a trained model's job
+# looks like), and the plain filler -- no attraction, atoms fly apart at high sigma, bonded lengths of 100+ A drive the GIN state
+# past the split-fp16 range watch -- in split-bf16, which has fp32's range
+def make(cfg, weights):
+    m_ = get_model(cfg)
+    if weights == "restoring":
+        m_.load_state_dict(synth.restoring_state_dict(m_.state_dict()))
+    else:
+        m_.load_state_dict(synth.synth_state_dict(m_.state_dict()))
+        m_.precision, m_.precision_local = "bf16x3", "bf16x3"
+    return m_.cuda().eval()
+
+
+for kind, cfgf, weights in (("drugs", drugs_model_config, "restoring"), ("qm9", qm9_model_config, "restoring"), ("drugs", drugs_model_config, "filler")):
     cfg = cfgf()
-    m = get_model(cfg); m.load_state_dict(synth.synth_state_dict(m.state_dict())); m = m.cuda().eval()
+    m = make(cfg, weights)
     b = synth.make_packed_batch(kind, 6, 20, seed=77)
     T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
     at, bi, bt, ba = T(b["atom_type"]), T(b["bond_index"]), T(b["bond_type"]), T(b["batch"])
@@ -24,12 +37,12 @@ for kind, cfgf in (("drugs", drugs_model_config), ("qm9", qm9_model_config)):
         outs.append((p.clone(), torch.stack(tr)))
     same = torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     ws = m._batch_cache[2]
-    print(kind, "400 steps over the whole schedule: finite", bool(torch.isfinite(outs[0][0]).all()), "bitwise reproducible", same,
+    print(kind, weights, m.precision, "400 steps over the whole schedule: finite", bool(torch.isfinite(outs[0][0]).all()), "bitwise reproducible", same,
           "flagged local tiles at the end", int(ws.enc_flags[0].item()), "radius edges", int(ws.rad_cnt.sum().item()))
 
 # a COMPLETE 5000-step job at the reference's schedule (scripts/test.py defaults), twice: finite, bitwise reproducible, centred
 cfg = drugs_model_config()
-m = get_model(cfg); m.load_state_dict(synth.synth_state_dict(m.state_dict())); m = m.cuda().eval()
+m = make(cfg, "restoring")
 b = synth.make_packed_batch("drugs", 8, 16, seed=99)
 T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
 at, bi, bt, ba = T(b["atom_type"]), T(b["bond_index"]), T(b["bond_type"]), T(b["batch"])
@@ -41,8 +54,6 @@ for rep in range(2):
                                                 step_lr=1e-6, clip=1000.0, global_start_sigma=0.5, w_global=1.0, save_traj=False)
     res.append(p.clone())
 com = torch.zeros(b["num_graphs"], 3, device="cuda").index_add_(0, ba, res[0]) / torch.bincount(ba).unsqueeze(1)
-# (the synthetic checkpoint has no restoring force: at the top of the reference schedule the random scores drive the atoms far
-# apart -- the centre of mass is judged against the size of the positions)
-print("full %d-step job, %d atoms: finite %s, bitwise reproducible %s, max |pos| %.2e, max |centre of mass| / max |pos| %.2e"
+print("full %d-step job (restoring-force checkpoint, split-fp16), %d atoms: finite %s, bitwise reproducible %s, max |pos| %.2e, max |centre of mass| / max |pos| %.2e"
       % (cfg.num_diffusion_timesteps, at.shape[0], bool(torch.isfinite(res[0]).all()), torch.equal(res[0], res[1]),
          float(res[0].abs().max()), float(com.abs().max() / res[0].abs().max())))
