@@ -224,6 +224,28 @@ __device__ __forceinline__ void ag_cvt_pair(AgIn<AG_BF3>& o, int j, float v0, fl
   o.lo[j + 1] = lp[1];
 #endif
 }
+// The mixed second operand of agdiff_params_t.poly_plan 1 (ag_poly_features): hi = the split's hi of (v0, v1) as above; lo =
+// the hi part of (m0, m1) - own * (hi as float): with own = 1 and m = v the usual lo part, with own = 0 the hi part of m.
+__device__ __forceinline__ void ag_cvt_pair_mixed(AgIn<AG_H3>& o, int j, float v0, float v1, float m0, float m1, float own) {
+  const auto hp = __builtin_amdgcn_cvt_pkrtz(v0, v1);
+  const auto lp = __builtin_amdgcn_cvt_pkrtz(fmaf(-own, (float)hp[0], m0), fmaf(-own, (float)hp[1], m1));
+  o.hi[j] = (_Float16)hp[0];
+  o.hi[j + 1] = (_Float16)hp[1];
+  o.lo[j] = (_Float16)lp[0];
+  o.lo[j + 1] = (_Float16)lp[1];
+}
+__device__ __forceinline__ void ag_cvt_pair_mixed(AgIn<AG_BF3>& o, int j, float v0, float v1, float m0, float m1, float own) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  const bf16x2 hp = __builtin_convertvector(f32x2{v0, v1}, bf16x2);
+  const uint32_t hw = __builtin_bit_cast(uint32_t, hp);
+  const float h0 = __uint_as_float(hw << 16), h1 = __uint_as_float(hw & 0xFFFF0000u);
+  const bf16x2 lp = __builtin_convertvector(f32x2{fmaf(-own, h0, m0), fmaf(-own, h1, m1)}, bf16x2);
+  o.hi[j] = hp[0];
+  o.hi[j + 1] = hp[1];
+  o.lo[j] = lp[0];
+  o.lo[j + 1] = lp[1];
+}
 // NK k-tiles from accumulator tiles A0, A0+1, ...
 template <int MODE, int NK, int A0, int NA, int NO>
 __device__ __forceinline__ void ag_cvt_tiles(const f32x4 (&a)[NA], AgIn<MODE> (&o)[NO]) {
@@ -275,6 +297,16 @@ __device__ __forceinline__ void ag_block_mma_part(f32x4& o, const AgIn<MODE>& x,
     const V xv = (part == 1) ? x.lo : x.hi;
     o = FLIP ? ag_mfma16(xv, wv, o) : ag_mfma16(wv, xv, o);
   }
+}
+
+// agdiff_params_t.poly_plan 1 at poly_kt 1: the second of two passes -- the operand's `lo` member holds [lo of terms 0..15 |
+// hi of terms 0..15] (ag_poly_features<.., true>) and unit 1 of the block [hi | lo] of their coefficients
+template <int MODE, bool FLIP>
+__device__ __forceinline__ void ag_block_mma_mixed(f32x4& o, const AgIn<MODE>& x, const u32x4 (&w)[2]) {
+  static_assert(MODE != AG_F32, "split modes only");
+  using V = decltype(x.hi);
+  const V wv = __builtin_bit_cast(V, w[1]);
+  o = FLIP ? ag_mfma16(x.lo, wv, o) : ag_mfma16(wv, x.lo, o);
 }
 
 // The first part of a product that starts from zero: the accumulator input is the literal 0 (an inline constant of the
@@ -470,9 +502,13 @@ __device__ __forceinline__ float cf_envelope(float d, float cutoff, int smooth) 
 // T_0..T_8 by the three-term recurrence, T_16 .. T_56 from the product rule 2 T_a T_b = T_{a+b} + T_{|a-b|}: ~25 VALU
 // instructions + the operand split per k-tile, instead of a 128-wide MLP chain per edge.
 // `gmask` (1 or 0) multiplies every element: edges outside the group being evaluated contribute nothing.
-template <int MODE, int NKT>
+// MIXED (agdiff_params_t.poly_plan 1 at one k-tile, split modes): o[0].lo is the operand of the SECOND of two passes instead
+// of the lo parts: lanes of quarters 0, 1 keep the lo parts of their terms f = 8 q + j < 16, quarters 2, 3 hold the hi parts
+// of terms 8 (q - 2) + j -- the K = 32 slots of one instruction then carry lo(phi_f) hi(c_f) + hi(phi_f) lo(c_f), f < 16.
+template <int MODE, int NKT, bool MIXED = false>
 __device__ __forceinline__ void ag_poly_features(float d, float two_over_rc, int q, AgIn<MODE> (&o)[NKT], float gmask = 1.0f) {
   static_assert(NKT >= 1 && NKT <= AGDIFF_POLY_MAX_KT, "poly_kt");
+  static_assert(!MIXED || (NKT == 1 && MODE != AG_F32), "mixed operand: one k-tile, split modes");
   const float x = fminf(fmaxf(fmaf(d, two_over_rc, -1.0f), -1.0f), 1.0f);
   const float x2 = x + x;
   float T[9];
@@ -492,10 +528,17 @@ __device__ __forceinline__ void ag_poly_features(float d, float two_over_rc, int
     const float g7 = fmaf(g6 + g6, t8, -g5);       // T56
     G[1] = gmask * ((q == 0) ? g4 : (q == 1) ? g5 : (q == 2) ? g6 : g7);
   }
+  if constexpr (MIXED) {
+    const float Gm = gmask * ((q & 1) ? t8 : 1.0f);          // T_{8 (q & 1)}: the lane's own factor in quarters 0, 1
+    const float own = (q < 2) ? 1.0f : 0.0f;
 #pragma unroll
-  for (int t = 0; t < NKT; ++t) {
+    for (int j = 0; j < 8; j += 2) ag_cvt_pair_mixed(o[0], j, G[0] * T[j], G[0] * T[j + 1], Gm * T[j], Gm * T[j + 1], own);
+  } else {
 #pragma unroll
-    for (int j = 0; j < 8; j += 2) ag_cvt_pair(o[t], j, G[t] * T[j], G[t] * T[j + 1]);
+    for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) ag_cvt_pair(o[t], j, G[t] * T[j], G[t] * T[j + 1]);
+    }
   }
 }
 

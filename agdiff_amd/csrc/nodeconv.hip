@@ -44,6 +44,7 @@ struct NodeConvArgs {
   int32_t num_quads;          // Q
   int32_t qshift;             // a local tile's rows of lane quarter q belong to the quad's (q >> qshift)-th target (GT = 4 >> qshift)
   float two_over_rc;
+  float unscale;              // conv[k].filt_poly_unscale: the coefficient sets carry its inverse
 };
 
 // encoder/schnet.py:136-162 for conv1 and conv2 of one InteractionBlock, filters from d-polynomials:
@@ -75,8 +76,13 @@ struct NodeConvArgs {
 #ifndef AG_NODE_ABL
 #define AG_NODE_ABL 0       // timing experiments only (wrong results): 1 no x gathers, 2 no filter MFMAs, 4 no features, 8 no sums, 16 one coefficient read per group
 #endif
-template <int MODE, int NKT, int WAVES>
+// PLAN (agdiff_params_t.poly_plan): 0 three passes for every term; 1 one pass for the high terms, whose coefficients the
+// host has bounded -- at NKT 1 two MFMAs per channel tile (hi x hi of all 32 terms, then both cross terms of terms 0..15 in
+// one instruction: ag_poly_features<.., true> / the mixed unit 1 of the blocks), at NKT 2 k-tile 1 by its hi x hi pass alone.
+template <int MODE, int NKT, int WAVES, int PLAN>
 __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvArgs a) {
+  static_assert(PLAN == 0 || MODE != AG_F32, "poly_plan needs a split mode");
+  constexpr bool MIXED = PLAN == 1 && NKT == 1;           // unit 1 of a block / the operand's `lo` hold the mixed halves
   extern __shared__ u32x4 ag_nodeconv_smem[];
   lds_u32x4* wl = (lds_u32x4*)ag_nodeconv_smem;
   constexpr int SET = AG_CONV_NCH * NKT * 128;          // 16-byte units per coefficient set
@@ -205,15 +211,22 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
           continue;
         }
         w[j][t][0] = base[(((C0 + j) * NKT + t) * 2) * 64];
-        w[j][t][1] = base[(((C0 + j) * NKT + t) * 2 + 1) * 64];
+        if (PLAN == 0 || t == 0) w[j][t][1] = base[(((C0 + j) * NKT + t) * 2 + 1) * 64];
       }
     }
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
+      const int parts = (PLAN == 0) ? AgParts<MODE>::n : MIXED ? 2 : (t == 0) ? AgParts<MODE>::n : 1;
 #pragma unroll
-      for (int part = 0; part < AgParts<MODE>::n; ++part) {
+      for (int part = 0; part < parts; ++part) {
 #pragma unroll
         for (int j = 0; j < CN; ++j) {
+          if constexpr (MIXED) {
+            if (part == 1) {
+              ag_block_mma_mixed<MODE, true>(z[j], ph[0], w[j][0]);
+              continue;
+            }
+          }
           if (AG_NODE_ABL & 2) {
             if (t == 0 && part == 0) {
               u32x4 pu;
@@ -241,8 +254,8 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
         __builtin_memcpy(&ph2[t], v2, 32);
       }
     } else {
-      ag_poly_features<MODE, NKT>(pf_d, a.two_over_rc, q, ph1, s1);
-      ag_poly_features<MODE, NKT>(pf_d, a.two_over_rc, q, ph2, s2);
+      ag_poly_features<MODE, NKT, MIXED>(pf_d, a.two_over_rc, q, ph1, s1);
+      ag_poly_features<MODE, NKT, MIXED>(pf_d, a.two_over_rc, q, ph2, s2);
     }
   };
   float acc[AG_CONV_NCH], accL[AG_CONV_NCH];
@@ -257,7 +270,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = acc[4 * g + j] + (mine ? accL[4 * g + j] : 0.0f);
       // (one 768-byte row per node, read once by the node stage: streamed past the caches like the radius rows)
-      __builtin_nontemporal_store(ag_quarter_reduce_scatter4(v[0], v[1], v[2], v[3]), reinterpret_cast<float*>(dp + (uint32_t)(16 * (4 * g + q) + col) * 4u));
+      __builtin_nontemporal_store(a.unscale * ag_quarter_reduce_scatter4(v[0], v[1], v[2], v[3]), reinterpret_cast<float*>(dp + (uint32_t)(16 * (4 * g + q) + col) * 4u));
     }
   };
 
@@ -391,13 +404,20 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
 #ifndef AG_NODECONV_WAVES
 #define AG_NODECONV_WAVES 12     // ~165 VGPRs: three waves per SIMD
 #endif
-template <int MODE, int NKT>
-int launch_cfconv_node_t(const NodeConvArgs& a, int64_t wgs, size_t smem, void* stream) {
+template <int MODE, int NKT, int PLAN>
+int launch_cfconv_node_p(const NodeConvArgs& a, int64_t wgs, size_t smem, void* stream) {
   static std::atomic<uint64_t> attr_done{0};
-  if (!ag_allow_big_lds(attr_done, (size_t)160 * 1024, k_cfconv_node<MODE, NKT, AG_NODECONV_WAVES>)) return AGDIFF_ERR_LAUNCH;
-  k_cfconv_node<MODE, NKT, AG_NODECONV_WAVES><<<dim3((unsigned)wgs), dim3(64 * AG_NODECONV_WAVES), smem, (hipStream_t)stream>>>(a);
+  if (!ag_allow_big_lds(attr_done, (size_t)160 * 1024, k_cfconv_node<MODE, NKT, AG_NODECONV_WAVES, PLAN>)) return AGDIFF_ERR_LAUNCH;
+  k_cfconv_node<MODE, NKT, AG_NODECONV_WAVES, PLAN><<<dim3((unsigned)wgs), dim3(64 * AG_NODECONV_WAVES), smem, (hipStream_t)stream>>>(a);
   AG_CHECK_LAUNCH();
   return AGDIFF_OK;
+}
+template <int MODE, int NKT>
+int launch_cfconv_node_t(const NodeConvArgs& a, int plan, int64_t wgs, size_t smem, void* stream) {
+  if constexpr (MODE != AG_F32) {
+    if (plan == 1) return launch_cfconv_node_p<MODE, NKT, 1>(a, wgs, smem, stream);
+  }
+  return launch_cfconv_node_p<MODE, NKT, 0>(a, wgs, smem, stream);
 }
 }  // namespace
 
@@ -405,6 +425,8 @@ extern "C" int agdiff_cfconv_node(const agdiff_params_t* p, const agdiff_topo_t*
                                   void* stream) {
   if (!p || !topo || !ws || k < 0 || k >= p->num_convs) return AGDIFF_ERR_ARG;
   if (p->poly_kt < 1 || p->poly_kt > AGDIFF_POLY_MAX_KT || !p->conv[k].filt_poly_pk) return AGDIFF_ERR_ARG;
+  if (p->poly_plan < 0 || p->poly_plan > 1 || (p->poly_plan && p->precision == AG_F32)) return AGDIFF_ERR_ARG;
+  if (!(p->conv[k].filt_poly_unscale > 0.0f)) return AGDIFF_ERR_ARG;
   if (!ws->rad_cnt || !ws->rad_src || !ws->rad_len || !ws->r_scale || !ws->xs || !ws->agg || !topo->quad_tgt ||
       topo->num_quads <= 0 || (topo->group_targets != 4 && topo->group_targets != 2 && topo->group_targets != 1))
     return AGDIFF_ERR_ARG;
@@ -442,15 +464,17 @@ extern "C" int agdiff_cfconv_node(const agdiff_params_t* p, const agdiff_topo_t*
   a.num_quads = (int32_t)topo->num_quads;
   a.qshift = topo->group_targets == 4 ? 0 : topo->group_targets == 2 ? 1 : 2;
   a.two_over_rc = 2.0f / p->cutoff;
+  a.unscale = p->conv[k].filt_poly_unscale;
   int64_t wgs = (a.num_quads + AG_NODECONV_WAVES - 1) / AG_NODECONV_WAVES;
   if (wgs > 256) wgs = 256;
   const size_t smem = (size_t)(1 + a.lds_slots) * set_bytes;
   ag_log_variant(ws, AGDIFF_VAR_CFCONV_NODE | (local ? AGDIFF_VAR_CFCONV_NODE_LOCAL : 0) |
                          (a.lds_slots < a.num_slots ? AGDIFF_VAR_POLY_L2_SETS : 0));
+  const int plan = p->poly_plan;
   if (p->precision == AG_H3)
-    return p->poly_kt == 1 ? launch_cfconv_node_t<AG_H3, 1>(a, wgs, smem, stream) : launch_cfconv_node_t<AG_H3, 2>(a, wgs, smem, stream);
+    return p->poly_kt == 1 ? launch_cfconv_node_t<AG_H3, 1>(a, plan, wgs, smem, stream) : launch_cfconv_node_t<AG_H3, 2>(a, plan, wgs, smem, stream);
   if (p->precision == AG_BF3)
-    return p->poly_kt == 1 ? launch_cfconv_node_t<AG_BF3, 1>(a, wgs, smem, stream) : launch_cfconv_node_t<AG_BF3, 2>(a, wgs, smem, stream);
-  return p->poly_kt == 1 ? launch_cfconv_node_t<AG_F32, 1>(a, wgs, smem, stream) : launch_cfconv_node_t<AG_F32, 2>(a, wgs, smem, stream);
+    return p->poly_kt == 1 ? launch_cfconv_node_t<AG_BF3, 1>(a, plan, wgs, smem, stream) : launch_cfconv_node_t<AG_BF3, 2>(a, plan, wgs, smem, stream);
+  return p->poly_kt == 1 ? launch_cfconv_node_t<AG_F32, 1>(a, 0, wgs, smem, stream) : launch_cfconv_node_t<AG_F32, 2>(a, 0, wgs, smem, stream);
 }
 

@@ -221,6 +221,9 @@ class DualEncoderEpsNetwork(nn.Module):
         # arithmetic of the local branch's MFMA kernels: None = "f16x3" (split-fp16) next to a split-bf16 global branch, else
         # the global mode; "bf16x3" / "f32" / "f16x3" force one (packing.LOCAL_PRECISIONS)
         self.precision_local = getattr(config, "precision_local", None)
+        # "auto": the high terms of the filter polynomials take one MFMA pass instead of three when the host can bound what
+        # that costs by the fit tolerance (packing.PackedParams.poly_pass_plan); "full": three passes for every term
+        self.poly_passes = getattr(config, "poly_passes", None) or "auto"
         # kernel-variant thresholds (PackedParams.set_tuning; include/agdiff_hip.h: agdiff_params_t.tune_*), e.g.
         # model.tuning["node_ldsw_min_tiles"] = 1 -- tests reach every variant on small fixtures this way
         self.tuning = {}
@@ -243,7 +246,8 @@ class DualEncoderEpsNetwork(nn.Module):
         return _lib.load()
 
     def _weights_key(self):
-        return (str(self._device()), self.precision, self.radius_poly, tuple(self.poly_refuse_types), getattr(self, "precision_local", None)) + tuple(int(p._version) for p in self.state_dict(keep_vars=True).values())
+        return (str(self._device()), self.precision, self.radius_poly, tuple(self.poly_refuse_types), getattr(self, "precision_local", None),
+                getattr(self, "poly_passes", "auto")) + tuple(int(p._version) for p in self.state_dict(keep_vars=True).values())
 
     def packed(self):
         """Packed device weights, rebuilt when any parameter / buffer changed (load_state_dict, .to)."""
@@ -251,7 +255,8 @@ class DualEncoderEpsNetwork(nn.Module):
         if self._packed is None or self._packed_key != key:
             sd = {k: v for k, v in self.state_dict().items()}
             self._packed = PackedParams(sd, self.config, self._device(), self.precision, self.radius_poly,
-                                        refuse_types=self.poly_refuse_types, precision_local=getattr(self, "precision_local", None))
+                                        refuse_types=self.poly_refuse_types, precision_local=getattr(self, "precision_local", None),
+                                        poly_passes=getattr(self, "poly_passes", "auto"))
             self._packed_key = key
         self._packed.set_tuning(**{k: self.tuning.get(k, 0) for k in PackedParams.TUNING})
         return self._packed

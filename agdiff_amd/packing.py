@@ -281,6 +281,39 @@ def radius_polynomials(sd, cfg, tol=POLY_TOL, max_kt=POLY_MAX_KT, min_kt=1):
     return 0, {}, errors
 
 
+# Passes of the split arithmetic over a filter polynomial's terms (include/agdiff_hip.h: agdiff_params_t.poly_plan).  The lo
+# parts of the split operands buy 2^-21 per product; a term whose coefficient is small against the filter's size does not
+# need them.  The Chebyshev coefficients of an analytic function decay geometrically, so the HIGH half of the accepted
+# expansion (f >= 16 at 32 terms, f >= 32 at 64) usually carries 1e-4 .. 1e-7 of the weight, and one hi x hi pass over it
+# costs POLY_EPS1 times that -- the two operand roundings of a single product (fp16 features are rounded toward zero: 2^-11,
+# coefficients to nearest: 2^-12; bf16: 2^-9 + 2^-9).  Plan 1 is taken only when fit error + that bound stays within POLY_TOL
+# for EVERY coefficient set in use.
+POLY_EPS1 = {1: 2.0 ** -8, 2: 1.5 * 2.0 ** -11}
+
+
+def poly_high_weight(c_nat, kt):
+    """max over outputs of sum_{high f} |c[out][f]| relative to the largest value the polynomials take on [0, cutoff]
+    (|phi_f| <= 1): c_nat [out, 32 kt] in natural packed column order (fit_type)."""
+    K = 32 * kt
+    c_f = np.empty_like(np.asarray(c_nat, dtype=np.float64))
+    c_f[:, poly_feature_order(kt)] = c_nat
+    scale = np.abs(poly_features(np.linspace(-1.0, 1.0, 1025), K) @ c_f.T).max()
+    return float(np.abs(c_f[:, K // 2:]).sum(1).max() / max(scale, 1e-300))
+
+
+def mix_units(packed, kt):
+    """pack_blocks output (split modes, pk [OT][kt]) -> the layout of agdiff_params_t.poly_plan 1 at kt 1: unit 1 of every
+    block = [unit 0 of lanes 0..31 | the LO elements of lanes 0..31] (lane 32 + l holds lo of lane l: same row, quarter - 2).
+    kt 2 keeps the layout (the kernel does not read unit 1 of the k-tile-1 blocks)."""
+    if kt != 1:
+        return packed
+    b = np.ascontiguousarray(packed).view(np.uint16).reshape(-1, 2, 64, 8).copy()
+    hi, lo = b[:, 0].copy(), b[:, 1].copy()
+    b[:, 1, :32] = hi[:, :32]
+    b[:, 1, 32:] = lo[:, :32]
+    return b.reshape(-1).view(np.float32)
+
+
 def dist_segments(w1, b1, w2, b2):
     """DistanceWeightingNetwork before its sigmoid, layer2(relu(layer1(d))) (schnet.py:83-100), as a piecewise linear
     function of d (agdiff_conv_params_t.dist_seg): kinks bp[32] ascending (+inf padded), alpha[33], beta[33], 2 unused.
@@ -343,13 +376,19 @@ EDGE_ENCODERS = {"mlp": 0, "gaussian": 1}       # agdiff_params_t.edge_encoder
 class PackedParams:
     """Owns the device copies of all packed weights and the agdiff_params_t that points at them."""
 
-    def __init__(self, sd, cfg, device, precision="f32", radius_poly="auto", refuse_types=(), precision_local=None):
+    def __init__(self, sd, cfg, device, precision="f32", radius_poly="auto", refuse_types=(), precision_local=None,
+                 poly_passes="auto"):
         """radius_poly: "auto" -- radius edges take their filters from d-polynomials when the fit is accepted
         (radius_polynomials above), and so do the local edges, per type (ensure_local_types); "off" -- every edge goes
         through the encoder + filter MLPs; "radius" -- polynomials for the radius edges only; "kt2" -- as "auto" but
-        starting at 64 terms (the variants exist for tests and A/B runs)."""
+        starting at 64 terms (the variants exist for tests and A/B runs).
+        poly_passes: "auto" -- one pass over the high terms of the filter polynomials when their coefficients allow it
+        (poly_pass_plan); "full" -- three passes for every term."""
         import torch
         self.device = device
+        if poly_passes not in ("auto", "full"):
+            raise ValueError("poly_passes must be 'auto' or 'full'")
+        self.poly_passes = poly_passes
         if radius_poly not in ("auto", "off", "radius", "kt2"):
             raise ValueError("radius_poly must be one of 'auto', 'off', 'radius', 'kt2'")
         self.poly_kt, self._poly, self.poly_errors = (0, {}, {}) if radius_poly == "off" else \
@@ -503,7 +542,8 @@ class PackedParams:
 
         # ---------------- radius-edge polynomials (include/agdiff_hip.h: agdiff_params_t.poly_kt)
         for name, c in self._poly.items():
-            arrays[name] = pack_blocks(c, kouter=name.startswith("head_"))
+            if name.startswith("head_"):        # (the CFConv filter sets are packed by _pack_filter_sets: their layout
+                arrays[name] = pack_blocks(c, kouter=True)      # depends on the pass plan)
 
         # one flat device buffer, every section 256-byte aligned
         offs, total = {}, 0
@@ -538,7 +578,7 @@ class PackedParams:
             for f, _ in _lib.ConvParams._fields_:
                 if (n + f) in offs:
                     setattr(cp, f, P(n + f))
-                elif f not in ("filt_poly_pk", "filt_poly_typed_pk"):          # (null when the polynomials are off)
+                elif f not in ("filt_poly_pk", "filt_poly_typed_pk", "filt_poly_unscale", "pad0"):   # (set by _pack_filter_sets / null)
                     setattr(cp, f, scalars[n + f])
         for k in range(cfg.num_convs_local):
             gp, n = prm.gin[k], "gin%d." % k
@@ -564,6 +604,62 @@ class PackedParams:
         prm.poly_kt = self.poly_kt
         prm.poly_num_slots = 0
         self.struct = prm
+        self.poly_plan, self.poly_high_bound, self.rad_poly_flat = 0, {}, None
+        for k in range(cfg.num_convs):
+            prm.conv[k].filt_poly_unscale = 1.0
+        if self.poly_kt >= 1:
+            self._pack_filter_sets()
+
+    def poly_pass_plan(self):
+        """agdiff_params_t.poly_plan for the coefficient sets in use (radius edges + slotted local types): 1 when, for each
+        of them, fit error + POLY_EPS1[mode] * (weight of the high terms) <= POLY_TOL; self.poly_high_bound records the
+        second summand per set."""
+        if self._mode not in POLY_EPS1 or self.poly_kt < 1:
+            return 0
+        eps, ok = POLY_EPS1[self._mode], self.poly_passes == "auto"
+        sets = [("radius", self._poly, self.poly_errors[self.poly_kt])] + \
+               [("type%d" % t, self._typed_mats[t], self.poly_errors["type%d" % t]) for t in sorted(self.local_slots)]
+        for name, mats, err in sets:
+            if name not in self.poly_high_bound:
+                self.poly_high_bound[name] = eps * max(poly_high_weight(mats["conv%d.filt_poly_pk" % k], self.poly_kt)
+                                                       for k in range(self._cfg.num_convs))
+            ok = ok and err + self.poly_high_bound[name] <= POLY_TOL
+        return 1 if ok else 0
+
+    def _pack_filter_sets(self):
+        """(Re)pack the CFConv filter polynomials -- the radius edges' set and the slotted local types' -- in the layout of
+        the pass plan that holds for all of them, and point the conv structs at the new buffers (the old ones may still be in
+        use by enqueued launches: torch's allocator keeps them alive in stream order)."""
+        import torch
+        prm, nc, kt = self.struct, self._cfg.num_convs, self.poly_kt
+        plan = self.poly_pass_plan()
+
+        by_slot = sorted(self.local_slots, key=self.local_slots.get)
+        # split-fp16: coefficients times 2^S per conv (conv[k].filt_poly_unscale = 2^-S; the largest one ends up in
+        # [512, 1024]): their lo parts leave fp16's subnormal range, whose quantum of 6e-8 otherwise costs up to 1e-6 of a
+        # filter of size 0.2.  bf16 parts have fp32's exponent range and fp32 operands no parts: S = 0
+        up = []
+        for k in range(nc):
+            name = "conv%d.filt_poly_pk" % k
+            cmax = max([np.abs(self._poly[name]).max()] + [np.abs(self._typed_mats[t][name]).max() for t in by_slot])
+            S = int(np.clip(np.floor(np.log2(1024.0 / max(cmax, 1e-30))), 0, 24)) if self._mode == 2 else 0
+            up.append(2.0 ** S)
+            prm.conv[k].filt_poly_unscale = 2.0 ** -S
+        self.filt_poly_upscale = up
+
+        def pk(c, k):
+            v = pack_blocks(np.asarray(c, dtype=np.float64) * up[k], mode=self._mode)
+            return mix_units(v, kt) if plan == 1 else v
+        rad = [pk(self._poly["conv%d.filt_poly_pk" % k], k) for k in range(nc)]
+        self.rad_poly_flat = torch.from_numpy(np.concatenate(rad)).to(self.device)
+        for k in range(nc):
+            prm.conv[k].filt_poly_pk = ctypes.c_void_p(self.rad_poly_flat.data_ptr() + 4 * rad[0].size * k)
+        if by_slot:
+            per_conv = [np.concatenate([pk(self._typed_mats[t]["conv%d.filt_poly_pk" % k], k) for t in by_slot]) for k in range(nc)]
+            self.typed_flat = torch.from_numpy(np.concatenate(per_conv)).to(self.device)
+            for k in range(nc):
+                prm.conv[k].filt_poly_typed_pk = ctypes.c_void_p(self.typed_flat.data_ptr() + 4 * per_conv[0].size * k)
+        self.poly_plan = prm.poly_plan = plan
 
     def ensure_local_types(self, types):
         """Give every local edge type of a batch (BatchTopology.local_types) a filter-polynomial slot, so that
@@ -596,22 +692,16 @@ class PackedParams:
         if not added:
             return not any(int(t) in self.poly_refused_types for t in types)
         by_slot = sorted(self.local_slots, key=self.local_slots.get)
-        nc = self._cfg.num_convs
-        per_conv = [np.concatenate([pack_blocks(self._typed_mats[t]["conv%d.filt_poly_pk" % k], mode=self._mode) for t in by_slot])
-                    for k in range(nc)]
+        self._pack_filter_sets()           # (a new type may end the one-pass plan: every set is repacked then)
         # edge_attr itself per type (agdiff_local_edge_rows): pk [8][kt] -- the kernel takes one k-tile, so only with kt == 1
         if kt == 1:
             attr_sets = np.concatenate([pack_blocks(self._typed_mats[t]["edge_attr_poly_pk"], mode=self._mode_local) for t in by_slot])
             self.typed_attr_flat = torch.from_numpy(attr_sets).to(self.device)
             prm.attr_poly_typed_pk = ctypes.c_void_p(self.typed_attr_flat.data_ptr())
-        self.typed_flat = torch.from_numpy(np.concatenate(per_conv)).to(self.device)     # (the old buffer may still be in
-        table = np.full(100, -1, dtype=np.int32)                                         #  use by enqueued launches: torch's
-        for t, sl in self.local_slots.items():                                           #  allocator keeps it alive in stream order)
+        table = np.full(100, -1, dtype=np.int32)
+        for t, sl in self.local_slots.items():
             table[t] = sl
         self.slot_table = torch.from_numpy(table).to(self.device)
-        stride = per_conv[0].size
-        for k in range(nc):
-            prm.conv[k].filt_poly_typed_pk = ctypes.c_void_p(self.typed_flat.data_ptr() + 4 * stride * k)
         prm.poly_type_slot = ctypes.c_void_p(self.slot_table.data_ptr())
         prm.poly_num_slots = len(by_slot)
         sm = [0, 0]

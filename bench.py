@@ -373,6 +373,9 @@ def main():
     ap.add_argument("--precision", default="f16x3", choices=["f32", "bf16x3", "f16x3"])
     ap.add_argument("--radius-poly", default="auto", choices=["auto", "radius", "kt2", "off"],
                     help="filter polynomials (agdiff_amd/packing.py): off = every edge through the encoder + filter MLPs")
+    ap.add_argument("--poly-passes", default="auto", choices=["auto", "full"],
+                    help="MFMA passes over the filter polynomials' high terms: auto = one when the host's bound allows it "
+                         "(agdiff_params_t.poly_plan), full = three for every term (A/B runs)")
     ap.add_argument("--front", default="fused", choices=["fused", "split", "unfused"],
                     help="serial front of a step: one launch (update + local edges + radius graph), the same with the graph "
                          "phase launched after the local branch's fork, or the unfused kernels (A/B runs)")
@@ -433,6 +436,7 @@ def main():
         m = get_model(cfg)
         m.precision = args.precision
         m.radius_poly = radius_poly or args.radius_poly
+        m.poly_passes = args.poly_passes
         m.fused_front, m.front_split_graph = args.front != "unfused", args.front == "split"
         if args.serial:
             m.tuning["serial_branches"] = 1
@@ -537,6 +541,7 @@ def main():
     stream = _lib.stream_ptr()
     E = live_edges(run)
     poly_info = {"mode": args.radius_poly, "poly_kt": pk.poly_kt, "local_type_slots": int(pk.struct.poly_num_slots),
+                 "pass_plan": int(pk.poly_plan), "one_pass_bound_of_high_terms": {k: float(v) for k, v in pk.poly_high_bound.items()},
                  "fit_errors_vs_float64_networks": {str(k): v for k, v in pk.poly_errors.items()}}
     roof = None
     P_, T_, W_ = ctypes.byref(pk.struct), ctypes.byref(topo.struct), ctypes.byref(ws.struct)
@@ -746,7 +751,7 @@ def main():
         bq = driver.plan_batches(molsq, cq, args.max_atoms)
         cfgq = make_cfg("qm9", "saturated")
         mq = get_model(cfgq)
-        mq.precision, mq.radius_poly = args.precision, args.radius_poly
+        mq.precision, mq.radius_poly, mq.poly_passes = args.precision, args.radius_poly, args.poly_passes
         mq.load_state_dict(synth.synth_state_dict(mq.state_dict()))
         mq = mq.to(dev).eval()
         tms, Gl, nb, pms, pn, pe = 0.0, 0, 0, 0.0, 0.0, 0.0

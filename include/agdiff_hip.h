@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 35
+#define AGDIFF_ABI_VERSION 36
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -94,6 +94,11 @@ typedef struct agdiff_conv_params {
                                 C(d) is exactly 0, schnet.py:140-146) */
   float gate2_b;
   float act_beta;            /* InteractionBlock.act.beta (informational: folded into lin2 / lin above) */
+  float filt_poly_unscale;   /* 2^-S (1 when unused): filt_poly_pk and filt_poly_typed_pk hold 2^S times the coefficients and
+                                agdiff_cfconv_node multiplies a target's finished sums by 2^-S -- exact, and it lifts the lo
+                                parts of small split-fp16 coefficients out of fp16's subnormal range (quantum 6e-8, i.e. up
+                                to 1e-6 of a filter of size 0.2 over 32 terms); the host picks S with max |c| 2^S <= 1024 */
+  float pad0;
 } agdiff_conv_params_t;
 
 typedef struct agdiff_gin_params {
@@ -177,6 +182,19 @@ typedef struct agdiff_params {
                                   phi[8 g + j](x) = T_{8 g}(x) T_j(x),  x = 2 d / cutoff - 1,  g < 4 poly_kt,  j < 8
                                 (T_n = Chebyshev polynomials; spans all polynomials of degree < K); operand element j of lane
                                 quarter q in k-tile t is phi[8 (4 t + q) + j], and the packed blocks are ordered to match. */
+  int32_t poly_plan;         /* passes of the split arithmetic over the filter polynomials' terms in agdiff_cfconv_node (0 when
+                                precision == 0).  0: every term three passes (hi hi, lo hi, hi lo).  1: the HIGH terms -- f >= 16
+                                at poly_kt 1, f >= 32 at poly_kt 2 -- take ONE pass (hi x hi): the host sets it only when
+                                  fit error + eps1 * max_out sum_{high f} |c[out][f]| <= 1e-6 of the largest filter value
+                                for every coefficient set (|phi_f| <= 1; eps1 = 1.5 * 2^-11 split-fp16, 2^-8 split-bf16: the
+                                two operand roundings of a single product), agdiff_amd/packing.py poly_pass_plan.
+                                  poly_kt 1: TWO MFMAs per 16-channel tile instead of three -- unit 1 of every block of
+                                  conv[].filt_poly_pk / filt_poly_typed_pk then holds, for lanes 0..31, their hi elements again
+                                  and, for lanes 32..63, the LO elements of lane - 32 (same row, terms 8 (q - 2) + j), and the
+                                  kernel's second operand is [lo(phi_f), f < 16 | hi(phi_f), f < 16]: both cross terms of the
+                                  low 16 terms in one K = 32 instruction.
+                                  poly_kt 2: k-tile 0 three passes, k-tile 1 one (unit 1 of its blocks is not read). */
+  int32_t pad1;
   /* Kernel-variant thresholds: batch-size crossovers measured on MI355X.  0 selects the library default in
    * brackets; tests set them to reach every variant on small fixtures, agdiff_ws_t.variant_log reports what ran. */
   int64_t poly_slot_mask[2]; /* bit t of the 128-bit mask: edge type t has a slot in poly_type_slot */

@@ -6,7 +6,8 @@ against the one-list kernels that evaluate the filter MLPs for every edge.  `rad
   kt2     64-term expansions (two k-tiles) for radius edges and local types alike
   off     one list, every edge through the encoder + filter MLPs (rounds 1-2a product path)
 plus `auto-l2`: as auto with every local type's coefficient set read from L2 instead of LDS (tune_poly_lds_sets = 1: the
-path types beyond the LDS-resident sets take)."""
+path types beyond the LDS-resident sets take), and `auto-full` / `kt2-full`: three MFMA passes for every polynomial term
+(model.poly_passes = "full"; the other split-mode runs take one pass for the high terms: agdiff_params_t.poly_plan 1)."""
 import ctypes
 
 import numpy as np
@@ -62,14 +63,18 @@ def _expect(pk, mode):
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x3"])
-@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("mode", MODES + ["auto-full", "kt2-full"])
 @pytest.mark.parametrize("case", ["g3_forward_qm9_small", "g3_forward_drugs_capped"])
 def test_forward_every_filter_mode(case, mode, precision):
     g = load_golden(case)
+    full = mode.endswith("-full")
+    mode = mode[:-5] if full else mode
     m = _model(FORWARD_CASES[case](), mode, precision=precision)
+    m.poly_passes = "full" if full else "auto"
     out = m(t(g["atom_type"]).cuda(), t(g["pos"]).cuda(), t(g["bond_index"]).cuda(), t(g["bond_type"]).cuda(),
             t(g["batch"]).cuda(), None, return_edges=True, extend_order=False)
     _expect(m.packed(), mode)
+    assert m.packed().struct.poly_plan == (1 if (mode != "off" and precision != "f32" and not full) else 0), m.packed().poly_high_bound
     ws = m._batch_cache[2]
     assert np.array_equal(out[2].cpu().numpy(), g["edge_index"]) and np.array_equal(out[3].cpu().numpy(), g["edge_type"])
     if "schnet_out" in g:

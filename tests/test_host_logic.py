@@ -261,6 +261,79 @@ def test_filter_polynomials_reproduce_the_networks(which):
             assert np.abs(ph @ m["head_global.attr_poly_pk"][:, inv].T - ref).max() < 2e-6 * np.abs(ref).max()
 
 
+def _emulate_poly_mfma(c_nat, d, cutoff, plan, np16):
+    """The filter values agdiff_cfconv_node's MFMAs produce for lengths d in split-fp16, operand by operand (csrc/common.hpp
+    ag_poly_features / ag_cvt_pair_mixed, csrc/nodeconv.hip mma_tiles; include/agdiff_hip.h poly_plan), kt = 1: lane
+    (row r, quarter q) element j is term f = 8 q + j; products in float64, i.e. the fp32 accumulation error left out."""
+    from agdiff_amd import packing
+    def rtz(x):                                  # v_cvt_pkrtz_f16_f32: toward zero
+        h = x.astype(np.float16)
+        over = np.abs(h.astype(np.float64)) > np.abs(x)
+        return np.where(over, np.nextafter(h, np.float16(0)), h).astype(np.float16)
+    blk = packing.pack_blocks(c_nat, mode=2)
+    blk = (packing.mix_units(blk, 1) if plan == 1 else blk).view(np.float16).reshape(-1, 2, 64, 8).astype(np.float64)
+    ph = packing.poly_features(2.0 * d / cutoff - 1.0, 32).astype(np.float32).astype(np.float64)      # [M, f]
+    hi = rtz(ph)
+    lo = rtz(ph - hi.astype(np.float64))
+    hi, lo = hi.astype(np.float64), lo.astype(np.float64)
+    M, OT = d.shape[0], blk.shape[0]
+    out = np.zeros((M, 16 * OT))
+    for ot in range(OT):
+        for q in range(4):
+            f = 8 * q + np.arange(8)
+            u0, u1 = blk[ot, 0, 16 * q:16 * q + 16], blk[ot, 1, 16 * q:16 * q + 16]          # [o, j]
+            if plan == 0:
+                acc = hi[:, f] @ u0.T + lo[:, f] @ u0.T + hi[:, f] @ u1.T
+            else:
+                a1 = lo[:, f] if q < 2 else hi[:, f - 16]
+                acc = hi[:, f] @ u0.T + a1 @ u1.T
+            out[:, 16 * ot:16 * ot + 16] += acc
+    return out
+
+
+@pytest.mark.parametrize("which", ["synth", "default_init"])
+def test_one_pass_plan_for_the_high_terms_is_bounded(which):
+    """agdiff_params_t.poly_plan 1: the host's bound (PackedParams.poly_pass_plan) against an operand-level emulation of
+    the two-MFMA scheme -- the mixed unit of the packed blocks and the mixed feature operand reproduce the float64
+    polynomial as closely as the three-pass scheme does, and the difference of the two stays below the bound."""
+    import torch
+    from agdiff_amd import drugs_model_config, get_model, packing
+    from oracle import agdiff_oracle as O
+    cfg = drugs_model_config()
+    if which == "synth":
+        sd = O.synth_state_dict_for(cfg)
+    else:
+        torch.manual_seed(1)
+        sd = get_model(cfg).state_dict()
+    pk = packing.PackedParams(sd, cfg, "cpu", "f16x3")
+    assert pk.poly_kt == 1 and pk.poly_plan == 1 and pk.struct.poly_plan == 1
+    assert pk.poly_errors[1] + pk.poly_high_bound["radius"] <= packing.POLY_TOL
+    full = packing.PackedParams(sd, cfg, "cpu", "f16x3", poly_passes="full")
+    assert full.poly_plan == 0 and full.struct.poly_plan == 0
+    assert packing.PackedParams(sd, cfg, "cpu", "f32").poly_plan == 0
+    d = np.random.default_rng(3).uniform(0.0, cfg.cutoff, 193)
+    inv = np.argsort(packing.poly_feature_order(1))
+    for k in (0, cfg.num_convs - 1):
+        c = pk._poly["conv%d.filt_poly_pk" % k]
+        exact = packing.poly_features(2.0 * d / cfg.cutoff - 1.0, 32) @ c[:, inv].T
+        scale = np.abs(exact).max()
+        three, two = (_emulate_poly_mfma(c, d, cfg.cutoff, plan, np.float16) for plan in (0, 1))
+        assert np.abs(three - exact).max() < 2e-6 * scale     # (the split itself: fp32 features, fp16 lo parts down to 6e-8)
+        assert np.abs(two - exact).max() < 2e-6 * scale
+        assert np.abs(two - three).max() <= pk.poly_high_bound["radius"] * scale + 1e-9 * scale
+        # what is packed: 2^S times the coefficients (conv[k].filt_poly_unscale = 2^-S) -- the lo parts leave the subnormals
+        up = pk.filt_poly_upscale[k]
+        assert 512.0 <= np.abs(c).max() * up <= 1024.0 and pk.struct.conv[k].filt_poly_unscale == 1.0 / up
+        assert full.struct.conv[k].filt_poly_unscale == 1.0 / up
+        assert np.abs(_emulate_poly_mfma(c * up, d, cfg.cutoff, 1, np.float16) / up - exact).max() < 3e-7 * scale
+    # a type whose high terms are too heavy ends the plan for every set
+    pk.ensure_local_types([1, 2])
+    assert pk.poly_plan == 1
+    pk.poly_high_bound["type2"] = 1.0
+    pk._pack_filter_sets()
+    assert pk.poly_plan == 0 and pk.struct.poly_plan == 0
+
+
 def test_sharp_networks_need_more_terms_or_are_refused():
     from agdiff_amd import packing, qm9_model_config
     from oracle import agdiff_oracle as O
