@@ -576,7 +576,10 @@ def main():
             # only: E x 192 channels x 32 poly_kt terms x 2 x passes) over the in-step launch time; the pad rows that complete a
             # target's / a type's last tile are executed too and reported beside it, as is the reference-priced figure of rounds 1-3.
             tiles = pads_info["tiles_per_launch"] if pads_info else None
-            issued = prof_edges * 192 * 32 * pk.poly_kt * 2 * passes / t_s / 1e12
+            # MFMAs per 16-channel tile and 16 rows: poly_kt k-tiles x passes; with the pass plan (agdiff_params_t.poly_plan 1) two
+            # at 32 terms (hi x hi of all terms + both cross terms of the low 16 in one instruction), 3 + 1 at 64
+            mfma_ct = pk.poly_kt * passes if not pk.poly_plan else (2 if pk.poly_kt == 1 else 4)
+            issued = prof_edges * 192 * 32 * 2 * mfma_ct / t_s / 1e12
             executed = issued * (pads_info["rows_executed"] / max(pads_info["rows_live"], 1) if pads_info else 1.0)
             kernel = ("k_cfconv_node<NKT=%d> (one launch per InteractionBlock: radius rows by target%s)"
                       % (pk.poly_kt, " + local quad tiles, %d local types" % pk.struct.poly_num_slots if local_poly
@@ -592,8 +595,10 @@ def main():
                          "issue_cycles_per_tile": cyc / tiles, "simds": 1024, "clock_ghz_assumed": 2.4,
                          "issue_slot_frac": cyc / (1024 * 2.4e9 * avg_ms * 1e-3),
                          "source": "SQ_INSTS_VALU / SQ_INSTS_MFMA of profiles/%s_%s_pmc.json (separate counter passes of this command)" % (PROFILE_ROUND, args.precision)}
-            note = ("frac = MFMA FLOPs the kernel's algorithm needs (a 32-term d-polynomial per filter channel and live row, "
-                    "split-bf16 = 3 MFMA passes; fitted to the reference's encoder + filter networks in float64 at load time, "
+            note = ("frac = MFMA FLOPs the kernel's algorithm needs (a 32-term d-polynomial per filter channel and live row in "
+                    "split 16-bit operands: mfma_per_channel_tile instructions of 16x16x32 per 16 rows x 16 channels -- three passes "
+                    "per k-tile, or with the host-bounded pass plan two at 32 terms / four at 64, DESIGN.md 4c; fitted to the "
+                    "reference's encoder + filter networks in float64 at load time, "
                     "accepted at <= 1e-6, DESIGN.md 4a) over the in-step launch time (HIP event pairs around every CFConv launch "
                     "of the timed region on its own stream; profiles/%s_*kernel_stats.csv holds rocprofv3's figure for the same "
                     "command) against the dense bf16 MFMA peak.  executed_mfma_frac adds the pad rows.  reference_priced_* is the "
@@ -615,7 +620,8 @@ def main():
                 "traffic": pmc["kernels"][kern[0]]["hbm_bytes_per_launch"] if pmc else None,
                 "avg_launch_ms": avg_ms, "launches_timed": int(prof_n), "edges_per_launch": e_avg,
                 "executed_mfma_tflops": executed, "executed_mfma_frac": executed / pk_,
-                "useful_fp32_equivalent_tflops": issued / passes,
+                "useful_fp32_equivalent_tflops": (prof_edges * 192 * 32 * pk.poly_kt * 2 / t_s / 1e12) if node_path else issued / passes,
+                "mfma_per_channel_tile": mfma_ct if node_path else None,
                 "reference_priced_tflops": ref_priced, "reference_priced_frac": ref_priced / pk_,
                 "hbm_frac": alg_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": alg_bytes,
                 "traffic_over_algorithmic": (pmc["kernels"][kern[0]]["hbm_bytes_per_launch"] / alg_bytes) if pmc else None,
@@ -773,7 +779,8 @@ def main():
                             "%d packed batches of <= %d atoms, every 4th timed (2 warm-up + 10 steps), saturated schedule" % (G_all, len(bq), args.max_atoms),
                 "value": Gl / (tms * JOB_STEPS / 1e3), "unit": "conformers/s", "ms_per_step_timed_batches": tms, "batches_timed": nb,
                 "cfconv_avg_launch_ms": (pms / pn) if pn else None,
-                "cfconv_mfma_frac": (pe * 192 * 32 * mq.packed().poly_kt * 2 * passes / (pms * 1e-3) / 1e12 / PEAK[args.precision]) if pn else None}
+                "cfconv_mfma_frac": (pe * 192 * 32 * 2 * ((mq.packed().poly_kt * passes) if not mq.packed().poly_plan else (2 if mq.packed().poly_kt == 1 else 4))
+                                     / (pms * 1e-3) / 1e12 / PEAK[args.precision]) if pn else None}
 
     extra = None
     if rank == 0 and world == 1 and not args.no_extra and args.schedule == "saturated" and kind != "alanine":

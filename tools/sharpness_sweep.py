@@ -50,7 +50,8 @@ for scale in [float(x) for x in args.scales.split(",")]:
         got = m(at.to(dev), pos_small.to(dev), bi.to(dev), bt.to(dev), ba.to(dev), None, return_edges=True, extend_order=False)
     pk = m.packed()
     rec = {"first_layer_scale": scale, "precision": precision, "max_abs_reference_inv_g": float(ref[0].abs().max()),
-           "poly_kt": int(pk.poly_kt), "terms": 32 * int(pk.poly_kt),
+           "poly_kt": int(pk.poly_kt), "terms": 32 * int(pk.poly_kt), "pass_plan": int(pk.poly_plan),
+           "one_pass_bound_of_high_terms": max(pk.poly_high_bound.values()) if pk.poly_high_bound else None,
            "fit_errors": {str(k): float(v) for k, v in pk.poly_errors.items()},
            "local_type_slots": int(pk.struct.poly_num_slots), "refused_local_types": sorted(int(t_) for t_ in pk.poly_refused_types),
            "parity_inv_g": rel_err(got[0].cpu().numpy(), ref[0].numpy()), "parity_inv_l": rel_err(got[1].cpu().numpy(), ref[1].numpy())}
