@@ -186,7 +186,15 @@ __device__ __forceinline__ void ag_cvt(const f32x4& a0, const f32x4& a1, AgIn<AG
 // remainder; a value beyond fp16's range saturates at 65504 instead of becoming infinite)
 __device__ __forceinline__ void ag_cvt_pair(AgIn<AG_H3>& o, int j, float v0, float v1) {
   const auto hp = __builtin_amdgcn_cvt_pkrtz(v0, v1);
+  // v - float(hi) as fma(v, one, -float(hi)) with a 1.0 the optimiser cannot see through: ONE v_fma_mix_f32 that reads the
+  // fp16 half directly instead of v_cvt_f32_f16 + v_sub_f32 (the same single rounding: v * 1 is exact)
+#ifdef AG_NO_FMA_MIX        // (A/B builds: the two-instruction form)
   const auto lp = __builtin_amdgcn_cvt_pkrtz(v0 - (float)hp[0], v1 - (float)hp[1]);
+#else
+  float one = 1.0f;
+  asm("" : "+s"(one));
+  const auto lp = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf(v0, one, -(float)hp[0]), __builtin_fmaf(v1, one, -(float)hp[1]));
+#endif
   o.hi[j] = (_Float16)hp[0];
   o.hi[j + 1] = (_Float16)hp[1];
   o.lo[j] = (_Float16)lp[0];
