@@ -67,11 +67,31 @@ struct NodeConvArgs {
 // Lengths beyond the cutoff are clamped into the fitted range: their CFConv scale is exactly 0 (schnet.py:140-146).
 // A local tile whose type has no polynomial (mixed batches: agdiff_local_poly_enabled = 2) runs with scale 0: its edges
 // go through agdiff_cfconv_local.
-#ifndef AG_NODE_GRP
-#define AG_NODE_GRP 3                       // channel tiles per x / MFMA group
+// Channel tiles per x / MFMA group and waves per workgroup (= per CU) of an instantiation.  At one k-tile, groups of TWO channel
+// tiles need 135 VGPRs (one-pass plan; groups of three: 156): under the 128-VGPR cap of FOUR waves per SIMD that leaves 5..7
+// spilled registers (reloaded once per local tile, none in the radius loop) and takes 15 % less time than three waves per SIMD
+// at groups of three (six launches on 196 k atoms: 3.53 -> 3.00 ms; groups of two at three waves: 3.83; groups of three at four
+// waves, 27 spills: 3.32).  Two k-tiles hold twice the coefficient registers and stay at 168 VGPRs, three waves per SIMD.
+// -DAG_NODE_GRP / -DAG_NODECONV_WAVES force one shape on every instantiation (A/B builds).
+template <int MODE, int NKT, int PLAN>
+struct NodeConvShape {
+  static constexpr bool four = NKT == 1;
+#ifdef AG_NODE_GRP
+  static constexpr int GRP = AG_NODE_GRP;
+#else
+  static constexpr int GRP = four ? 2 : 3;
 #endif
+#ifdef AG_NODECONV_WAVES
+  static constexpr int WAVES = AG_NODECONV_WAVES;
+#else
+  static constexpr int WAVES = four ? 16 : 12;
+#endif
+};
 #ifndef AG_NODE_XD
 #define AG_NODE_XD 2                        // x groups in flight (ring of buffers; must divide the number of groups: static indices)
+#endif
+#ifndef AG_NODE_XD_FOUR
+#define AG_NODE_XD_FOUR AG_NODE_XD          // ... of the four-waves-per-SIMD shape (six groups of two channel tiles: 2 or 3)
 #endif
 #ifndef AG_NODE_ABL
 #define AG_NODE_ABL 0       // timing experiments only (wrong results): 1 no x gathers, 2 no filter MFMAs, 4 no features, 8 no sums, 16 one coefficient read per group
@@ -79,14 +99,14 @@ struct NodeConvArgs {
 // PLAN (agdiff_params_t.poly_plan): 0 three passes for every term; 1 one pass for the high terms, whose coefficients the
 // host has bounded -- at NKT 1 two MFMAs per channel tile (hi x hi of all 32 terms, then both cross terms of terms 0..15 in
 // one instruction: ag_poly_features<.., true> / the mixed unit 1 of the blocks), at NKT 2 k-tile 1 by its hi x hi pass alone.
-template <int MODE, int NKT, int WAVES, int PLAN>
+template <int MODE, int NKT, int WAVES, int PLAN, int GRP>
 __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvArgs a) {
   static_assert(PLAN == 0 || MODE != AG_F32, "poly_plan needs a split mode");
   constexpr bool MIXED = PLAN == 1 && NKT == 1;           // unit 1 of a block / the operand's `lo` hold the mixed halves
   extern __shared__ u32x4 ag_nodeconv_smem[];
   lds_u32x4* wl = (lds_u32x4*)ag_nodeconv_smem;
   constexpr int SET = AG_CONV_NCH * NKT * 128;          // 16-byte units per coefficient set
-  constexpr int NG = AG_CONV_NCH / AG_NODE_GRP;
+  constexpr int NG = AG_CONV_NCH / GRP;
   ag_copy_lds(wl, reinterpret_cast<const u32x4*>(a.poly_rad), SET);
   if (a.lds_slots > 0) ag_copy_lds(wl + SET, reinterpret_cast<const u32x4*>(a.poly_typed), a.lds_slots * SET);
   __syncthreads();
@@ -170,9 +190,10 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
       pf_s2 = ldf_nt(a.r_scale2, e4);
     }
   };
-  // x[src] values of a group of AG_NODE_GRP channel tiles, two groups in flight
-  static_assert((AG_CONV_NCH / AG_NODE_GRP) % AG_NODE_XD == 0 && AG_NODE_XD >= 2, "ring of x buffers");
-  f32x4 xg[AG_NODE_XD][AG_NODE_GRP];
+  // x[src] values of a group of GRP channel tiles, two groups in flight
+  constexpr int XD = (GRP == 2) ? AG_NODE_XD_FOUR : AG_NODE_XD;
+  static_assert((AG_CONV_NCH / GRP) % XD == 0 && XD >= 2, "ring of x buffers");
+  f32x4 xg[XD][GRP];
   uint32_t xoff[4];
   auto set_xoff = [&]() {
 #pragma unroll
@@ -182,17 +203,17 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
     constexpr int kb = decltype(BUF)::value;
     const char* xb = reinterpret_cast<const char*>(a.xs);
 #pragma unroll
-    for (int j = 0; j < AG_NODE_GRP; ++j) {
+    for (int j = 0; j < GRP; ++j) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (AG_NODE_ABL & 1) xg[kb][j][r] = __uint_as_float(xoff[r] + (uint32_t)(AG_NODE_GRP * g + j));
-        else xg[kb][j][r] = *reinterpret_cast<const float*>(xb + (size_t)xoff[r] + 64 * (AG_NODE_GRP * g + j));
+        if (AG_NODE_ABL & 1) xg[kb][j][r] = __uint_as_float(xoff[r] + (uint32_t)(GRP * g + j));
+        else xg[kb][j][r] = *reinterpret_cast<const float*>(xb + (size_t)xoff[r] + 64 * (GRP * g + j));
       }
     }
   };
-  // the first AG_NODE_XD - 1 x groups of a tile (requested before the tile starts)
+  // the first XD - 1 x groups of a tile (requested before the tile starts)
   auto fetch_first_groups = [&]() {
-    ag_static_for<0, AG_NODE_XD - 1>([&](auto G) { fetch_xg(G, decltype(G)::value); });
+    ag_static_for<0, XD - 1>([&](auto G) { fetch_xg(G, decltype(G)::value); });
   };
   const lds_u32x4* wl_l = wl + lane;
   // CN channel tiles C0 .. C0 + CN - 1 of one coefficient set (pk [12][NKT]: block nt * NKT + t) times the features:
@@ -313,39 +334,38 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
       bool nloc, has_next;
       const int nrows = next_tile(j, nloc, has_next);
       if (has_next) prefetch_meta(nrows, nloc);
-      auto mma_g = [&](auto GG, f32x4 (&z)[AG_NODE_GRP]) {
-        constexpr int c0 = AG_NODE_GRP * decltype(GG)::value;
+      auto mma_g = [&](auto GG, f32x4 (&z)[GRP]) {
+        constexpr int c0 = GRP * decltype(GG)::value;
         // channel tiles 0..7 take conv1's features, 8..11 conv2's (a group of three straddles the boundary once: 6, 7 | 8)
-        if constexpr (c0 + AG_NODE_GRP <= 8) {
+        if constexpr (c0 + GRP <= 8) {
           mma_tiles(base, std::integral_constant<int, c0>{}, ph1, z);
         } else if constexpr (c0 >= 8) {
           mma_tiles(base, std::integral_constant<int, c0>{}, ph2, z);
         } else {
-          static_assert(AG_NODE_GRP == 3 && c0 == 6, "group layout");
+          static_assert(GRP == 3 && c0 == 6, "group layout");
           f32x4 (&za)[2] = *reinterpret_cast<f32x4 (*)[2]>(&z[0]);
           f32x4 (&zb)[1] = *reinterpret_cast<f32x4 (*)[1]>(&z[2]);
           mma_tiles(base, std::integral_constant<int, 6>{}, ph1, za);
           mma_tiles(base, std::integral_constant<int, 8>{}, ph2, zb);
         }
       };
-      auto sums = [&](auto GG, const f32x4 (&z)[AG_NODE_GRP]) {
+      auto sums = [&](auto GG, const f32x4 (&z)[GRP]) {
         constexpr int gg = decltype(GG)::value;
 #pragma unroll
-        for (int jj = 0; jj < AG_NODE_GRP; ++jj) {
+        for (int jj = 0; jj < GRP; ++jj) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             if ((AG_NODE_ABL & 8) && r) continue;
-            S[AG_NODE_GRP * gg + jj] = fmaf(z[jj][r], xg[gg % AG_NODE_XD][jj][r], S[AG_NODE_GRP * gg + jj]);
+            S[GRP * gg + jj] = fmaf(z[jj][r], xg[gg % XD][jj][r], S[GRP * gg + jj]);
           }
           // (pins the sum to this step: the optimiser otherwise sinks all 48 FMAs of a tile below its last MFMA -- nothing
           // needs the sums before the target is complete -- and the wave then waits for x loads and MFMAs with nothing to do)
-          asm volatile("" : "+v"(S[AG_NODE_GRP * gg + jj]));
+          asm volatile("" : "+v"(S[GRP * gg + jj]));
         }
       };
-      f32x4 z[2][AG_NODE_GRP];
+      f32x4 z[2][GRP];
       // (fences between the steps: the scheduler otherwise hoists every group's coefficient reads to the top of the tile and
       // spills; inside a step it is free to run the sums beside the MFMAs)
-      constexpr int XD = AG_NODE_XD;
       fetch_xg(std::integral_constant<int, XD - 1>{}, XD - 1);
       mma_g(std::integral_constant<int, 0>{}, z[0]);
       __builtin_amdgcn_sched_barrier(0);
@@ -401,23 +421,25 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
 #undef AG_QUAD_ARGS
 }
 
-#ifndef AG_NODECONV_WAVES
-#define AG_NODECONV_WAVES 12     // ~165 VGPRs: three waves per SIMD
-#endif
 template <int MODE, int NKT, int PLAN>
-int launch_cfconv_node_p(const NodeConvArgs& a, int64_t wgs, size_t smem, void* stream) {
+int launch_cfconv_node_p(const NodeConvArgs& a, size_t smem, void* stream) {
+  using Shape = NodeConvShape<MODE, NKT, PLAN>;
+  constexpr int WAVES = Shape::WAVES;
   static std::atomic<uint64_t> attr_done{0};
-  if (!ag_allow_big_lds(attr_done, (size_t)160 * 1024, k_cfconv_node<MODE, NKT, AG_NODECONV_WAVES, PLAN>)) return AGDIFF_ERR_LAUNCH;
-  k_cfconv_node<MODE, NKT, AG_NODECONV_WAVES, PLAN><<<dim3((unsigned)wgs), dim3(64 * AG_NODECONV_WAVES), smem, (hipStream_t)stream>>>(a);
+  auto kern = k_cfconv_node<MODE, NKT, WAVES, PLAN, Shape::GRP>;
+  if (!ag_allow_big_lds(attr_done, (size_t)160 * 1024, kern)) return AGDIFF_ERR_LAUNCH;
+  int64_t wgs = (a.num_quads + WAVES - 1) / WAVES;        // persistent: one workgroup per CU, quads dealt in contiguous ranges
+  if (wgs > 256) wgs = 256;
+  kern<<<dim3((unsigned)wgs), dim3(64 * WAVES), smem, (hipStream_t)stream>>>(a);
   AG_CHECK_LAUNCH();
   return AGDIFF_OK;
 }
 template <int MODE, int NKT>
-int launch_cfconv_node_t(const NodeConvArgs& a, int plan, int64_t wgs, size_t smem, void* stream) {
+int launch_cfconv_node_t(const NodeConvArgs& a, int plan, size_t smem, void* stream) {
   if constexpr (MODE != AG_F32) {
-    if (plan == 1) return launch_cfconv_node_p<MODE, NKT, 1>(a, wgs, smem, stream);
+    if (plan == 1) return launch_cfconv_node_p<MODE, NKT, 1>(a, smem, stream);
   }
-  return launch_cfconv_node_p<MODE, NKT, 0>(a, wgs, smem, stream);
+  return launch_cfconv_node_p<MODE, NKT, 0>(a, smem, stream);
 }
 }  // namespace
 
@@ -465,16 +487,14 @@ extern "C" int agdiff_cfconv_node(const agdiff_params_t* p, const agdiff_topo_t*
   a.qshift = topo->group_targets == 4 ? 0 : topo->group_targets == 2 ? 1 : 2;
   a.two_over_rc = 2.0f / p->cutoff;
   a.unscale = p->conv[k].filt_poly_unscale;
-  int64_t wgs = (a.num_quads + AG_NODECONV_WAVES - 1) / AG_NODECONV_WAVES;
-  if (wgs > 256) wgs = 256;
   const size_t smem = (size_t)(1 + a.lds_slots) * set_bytes;
   ag_log_variant(ws, AGDIFF_VAR_CFCONV_NODE | (local ? AGDIFF_VAR_CFCONV_NODE_LOCAL : 0) |
                          (a.lds_slots < a.num_slots ? AGDIFF_VAR_POLY_L2_SETS : 0));
   const int plan = p->poly_plan;
   if (p->precision == AG_H3)
-    return p->poly_kt == 1 ? launch_cfconv_node_t<AG_H3, 1>(a, plan, wgs, smem, stream) : launch_cfconv_node_t<AG_H3, 2>(a, plan, wgs, smem, stream);
+    return p->poly_kt == 1 ? launch_cfconv_node_t<AG_H3, 1>(a, plan, smem, stream) : launch_cfconv_node_t<AG_H3, 2>(a, plan, smem, stream);
   if (p->precision == AG_BF3)
-    return p->poly_kt == 1 ? launch_cfconv_node_t<AG_BF3, 1>(a, plan, wgs, smem, stream) : launch_cfconv_node_t<AG_BF3, 2>(a, plan, wgs, smem, stream);
-  return p->poly_kt == 1 ? launch_cfconv_node_t<AG_F32, 1>(a, 0, wgs, smem, stream) : launch_cfconv_node_t<AG_F32, 2>(a, 0, wgs, smem, stream);
+    return p->poly_kt == 1 ? launch_cfconv_node_t<AG_BF3, 1>(a, plan, smem, stream) : launch_cfconv_node_t<AG_BF3, 2>(a, plan, smem, stream);
+  return p->poly_kt == 1 ? launch_cfconv_node_t<AG_F32, 1>(a, 0, smem, stream) : launch_cfconv_node_t<AG_F32, 2>(a, 0, smem, stream);
 }
 
