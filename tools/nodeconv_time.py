@@ -59,7 +59,8 @@ pt = topo.quad_tgt.cpu().numpy().reshape(-1, 4)
 ltp = topo.lt_ptr.cpu().numpy()
 tiles = (cnt + 15) // 16
 cost = np.where(pt >= 0, tiles[np.maximum(pt, 0)], 0).sum(1) + 1.0 * (ltp[1:] - ltp[:-1])
-Pn, wgs, W = cost.size, min(256, (cost.size + 11) // 12), 12
+W = 16 if pk.poly_kt == 1 else 12          # waves per workgroup of the instantiation (csrc/nodeconv.hip NodeConvShape)
+Pn, wgs = cost.size, min(256, (cost.size + W - 1) // W)
 per_wg = (Pn + wgs - 1) // wgs
 wave_cost, wg_cost = np.zeros((wgs, W)), np.zeros(wgs)
 for w in range(wgs):
