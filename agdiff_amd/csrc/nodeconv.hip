@@ -72,19 +72,21 @@ struct NodeConvArgs {
 // spilled registers (reloaded once per local tile, none in the radius loop) and takes 15 % less time than three waves per SIMD
 // at groups of three (six launches on 196 k atoms: 3.53 -> 3.00 ms; groups of two at three waves: 3.83; groups of three at four
 // waves, 27 spills: 3.32).  Two k-tiles hold twice the coefficient registers and stay at 168 VGPRs, three waves per SIMD.
-// -DAG_NODE_GRP / -DAG_NODECONV_WAVES force one shape on every instantiation (A/B builds).
-template <int MODE, int NKT, int PLAN>
+// Small launches (fewer than two quads per wave of a full grid: tune_cfconv_four_min_quads) keep the 12-wave shape: more
+// workgroups for the same quads (23 k atoms: even; 4 k atoms: 12 waves 3 % ahead).  -DAG_NODE_GRP / -DAG_NODECONV_WAVES force one
+// shape on every instantiation (A/B builds).
+template <int NKT, bool FOUR>
 struct NodeConvShape {
-  static constexpr bool four = NKT == 1;
+  static_assert(!FOUR || NKT == 1, "four waves per SIMD: one k-tile");
 #ifdef AG_NODE_GRP
   static constexpr int GRP = AG_NODE_GRP;
 #else
-  static constexpr int GRP = four ? 2 : 3;
+  static constexpr int GRP = FOUR ? 2 : 3;
 #endif
 #ifdef AG_NODECONV_WAVES
   static constexpr int WAVES = AG_NODECONV_WAVES;
 #else
-  static constexpr int WAVES = four ? 16 : 12;
+  static constexpr int WAVES = FOUR ? 16 : 12;
 #endif
 };
 #ifndef AG_NODE_XD
@@ -421,9 +423,9 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
 #undef AG_QUAD_ARGS
 }
 
-template <int MODE, int NKT, int PLAN>
-int launch_cfconv_node_p(const NodeConvArgs& a, size_t smem, void* stream) {
-  using Shape = NodeConvShape<MODE, NKT, PLAN>;
+template <int MODE, int NKT, int PLAN, bool FOUR>
+int launch_cfconv_node_s(const NodeConvArgs& a, size_t smem, void* stream) {
+  using Shape = NodeConvShape<NKT, FOUR>;
   constexpr int WAVES = Shape::WAVES;
   static std::atomic<uint64_t> attr_done{0};
   auto kern = k_cfconv_node<MODE, NKT, WAVES, PLAN, Shape::GRP>;
@@ -434,12 +436,19 @@ int launch_cfconv_node_p(const NodeConvArgs& a, size_t smem, void* stream) {
   AG_CHECK_LAUNCH();
   return AGDIFF_OK;
 }
-template <int MODE, int NKT>
-int launch_cfconv_node_t(const NodeConvArgs& a, int plan, size_t smem, void* stream) {
-  if constexpr (MODE != AG_F32) {
-    if (plan == 1) return launch_cfconv_node_p<MODE, NKT, 1>(a, smem, stream);
+template <int MODE, int NKT, int PLAN>
+int launch_cfconv_node_p(const NodeConvArgs& a, bool four, size_t smem, void* stream) {
+  if constexpr (NKT == 1) {
+    if (four) return launch_cfconv_node_s<MODE, NKT, PLAN, true>(a, smem, stream);
   }
-  return launch_cfconv_node_p<MODE, NKT, 0>(a, smem, stream);
+  return launch_cfconv_node_s<MODE, NKT, PLAN, false>(a, smem, stream);
+}
+template <int MODE, int NKT>
+int launch_cfconv_node_t(const NodeConvArgs& a, int plan, bool four, size_t smem, void* stream) {
+  if constexpr (MODE != AG_F32) {
+    if (plan == 1) return launch_cfconv_node_p<MODE, NKT, 1>(a, four, smem, stream);
+  }
+  return launch_cfconv_node_p<MODE, NKT, 0>(a, four, smem, stream);
 }
 }  // namespace
 
@@ -488,13 +497,16 @@ extern "C" int agdiff_cfconv_node(const agdiff_params_t* p, const agdiff_topo_t*
   a.two_over_rc = 2.0f / p->cutoff;
   a.unscale = p->conv[k].filt_poly_unscale;
   const size_t smem = (size_t)(1 + a.lds_slots) * set_bytes;
+  // shape: four waves per SIMD pay from two quads per wave of a full grid on (below, 12-wave workgroups spread the quads wider)
+  const int64_t four_min = p->tune_cfconv_four_min_quads ? p->tune_cfconv_four_min_quads : 8192;
+  const bool four = p->poly_kt == 1 && four_min >= 0 && a.num_quads >= four_min;
   ag_log_variant(ws, AGDIFF_VAR_CFCONV_NODE | (local ? AGDIFF_VAR_CFCONV_NODE_LOCAL : 0) |
-                         (a.lds_slots < a.num_slots ? AGDIFF_VAR_POLY_L2_SETS : 0));
+                         (a.lds_slots < a.num_slots ? AGDIFF_VAR_POLY_L2_SETS : 0) | (four ? AGDIFF_VAR_CFCONV_NODE_FOUR : 0));
   const int plan = p->poly_plan;
   if (p->precision == AG_H3)
-    return p->poly_kt == 1 ? launch_cfconv_node_t<AG_H3, 1>(a, plan, smem, stream) : launch_cfconv_node_t<AG_H3, 2>(a, plan, smem, stream);
+    return p->poly_kt == 1 ? launch_cfconv_node_t<AG_H3, 1>(a, plan, four, smem, stream) : launch_cfconv_node_t<AG_H3, 2>(a, plan, four, smem, stream);
   if (p->precision == AG_BF3)
-    return p->poly_kt == 1 ? launch_cfconv_node_t<AG_BF3, 1>(a, plan, smem, stream) : launch_cfconv_node_t<AG_BF3, 2>(a, plan, smem, stream);
-  return p->poly_kt == 1 ? launch_cfconv_node_t<AG_F32, 1>(a, 0, smem, stream) : launch_cfconv_node_t<AG_F32, 2>(a, 0, smem, stream);
+    return p->poly_kt == 1 ? launch_cfconv_node_t<AG_BF3, 1>(a, plan, four, smem, stream) : launch_cfconv_node_t<AG_BF3, 2>(a, plan, four, smem, stream);
+  return p->poly_kt == 1 ? launch_cfconv_node_t<AG_F32, 1>(a, 0, four, smem, stream) : launch_cfconv_node_t<AG_F32, 2>(a, 0, four, smem, stream);
 }
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 36
+#define AGDIFF_ABI_VERSION 37
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -208,6 +208,9 @@ typedef struct agdiff_params {
   int32_t tune_attr_poly_off;         /* [0] 1: agdiff_local_edge_rows evaluates the encoder MLP for every tile */
   int32_t tune_poly_lds_sets;         /* [0 = as many as fit in 160 KiB] agdiff_cfconv_node: at most this many coefficient sets in
                                          LDS, the radius edges' one included (1: every local type's set is read from L2) */
+  int64_t tune_cfconv_four_min_quads; /* [8192] agdiff_cfconv_node at poly_kt 1: from this many quads on (two per wave of 256 x 16),
+                                         16-wave workgroups at 128 VGPRs = four waves per SIMD, groups of two channel tiles;
+                                         below, the 12-wave shape (more workgroups for the same quads); -1: never */
 } agdiff_params_t;
 
 /* bits of agdiff_ws_t.variant_log: which kernel variants the launchers chose since the host last cleared it */
@@ -225,6 +228,7 @@ typedef struct agdiff_params {
 #define AGDIFF_VAR_SIDE_STREAM 2048     /* local branch forked onto the side stream */
 #define AGDIFF_VAR_POLY_L2_SETS 4096    /* agdiff_cfconv_node: some local types' coefficient sets did not fit in LDS (read from L2) */
 #define AGDIFF_VAR_FUSED_FRONT 8192     /* agdiff_sampler_front: update of step t + radius graph of step t + 1 in one launch */
+#define AGDIFF_VAR_CFCONV_NODE_FOUR 16384 /* agdiff_cfconv_node ran its four-waves-per-SIMD shape (tune_cfconv_four_min_quads) */
 
 /* ---- static topology of one packed batch (host builds it once per batch) ---------------------
  * Graphs are contiguous node ranges (PyG Batch, utils/misc.py:88-90).  "Local" edges are the
