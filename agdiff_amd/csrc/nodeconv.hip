@@ -59,7 +59,7 @@ struct NodeConvArgs {
 // a lane's four rows (4 q + r) always belong to one target.  Radius tiles add into acc (all four quarters = the current
 // target), local tiles into accL (quarter k = the quad's k-th target).  When a target's radius tiles are done, the sums
 // over the wave's quarters are taken once (reduce-scatter over the quarters, three lane swaps per four channel tiles) --
-// with accL entering from quarter k only -- and the target's row of agg is written once, complete (zeros for a target
+// with accL entering from quarter k only (as the start value of that quarter's sums) -- and the target's row of agg is written once, complete (zeros for a target
 // without edges): no agg_first, no second aggregate for the node stage to add, no atomics, fixed order => bitwise
 // reproducible.  Coefficient sets: the radius edges' one and the first lds_slots typed ones in LDS, rarer ones from L2.
 // Everything a tile needs from memory (sources, lengths, the two scales, the type; then the first x groups) is requested
@@ -286,12 +286,11 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
   // `k`: the target's place in its quad -- its local rows are the quarters q with q >> qshift == k of the quad's local tiles
   auto finalize = [&](int tgt, int k) {
     char* dp = reinterpret_cast<char*>(a.agg + (size_t)tgt * 192);       // (uniform)
-    const bool mine = (q >> a.qshift) == k;
 #pragma unroll
     for (int g = 0; g < AG_CONV_NCH / 4; ++g) {
       float v[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = acc[4 * g + j] + (mine ? accL[4 * g + j] : 0.0f);
+      for (int j = 0; j < 4; ++j) v[j] = acc[4 * g + j];
       // (one 768-byte row per node, read once by the node stage: streamed past the caches like the radius rows)
       __builtin_nontemporal_store(a.unscale * ag_quarter_reduce_scatter4(v[0], v[1], v[2], v[3]), reinterpret_cast<float*>(dp + (uint32_t)(16 * (4 * g + q) + col) * 4u));
     }
@@ -399,17 +398,17 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
       else tile(j, wl_l + (size_t)(slot >= 0 ? 1 + slot : 0) * SET, accL);
     }
 #endif
-#pragma unroll
-    for (int i = 0; i < AG_CONV_NCH; ++i) acc[i] = 0.0f;
     // (the four targets one after the other through shifting copies: indexing the quad's fields by k would put it in scratch)
     int ta = c_t0, tb = c_t1, tc = c_t2, td = c_t3, na = c_n0, nb = c_n1, nc = c_n2, nd = c_n3;
 #pragma nounroll
     for (int k = 0; k < 4; ++k) {
       if (ta >= 0) {
+        // the target's sums start from its local rows' (the quarters q with q >> qshift == k of the quad's local tiles)
+        const bool mine = (q >> a.qshift) == k;
+#pragma unroll
+        for (int i = 0; i < AG_CONV_NCH; ++i) acc[i] = mine ? accL[i] : 0.0f;
         for (int u = 0; u < na; ++u, ++j) tile(j, wl_l, acc);
         finalize(ta, k);                        // the quad's k-th target is complete: write it
-#pragma unroll
-        for (int i = 0; i < AG_CONV_NCH; ++i) acc[i] = 0.0f;
       }
       ta = tb, tb = tc, tc = td, td = -1;
       na = nb, nb = nc, nc = nd, nd = 0;
