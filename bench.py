@@ -542,6 +542,7 @@ def main():
     E = live_edges(run)
     poly_info = {"mode": args.radius_poly, "poly_kt": pk.poly_kt, "local_type_slots": int(pk.struct.poly_num_slots),
                  "pass_plan": int(pk.poly_plan), "one_pass_bound_of_high_terms": {k: float(v) for k, v in pk.poly_high_bound.items()},
+                 "cfconv_waves_per_simd": 4 if (int(ws.variant_log.item()) & _lib.DEFINES["AGDIFF_VAR_CFCONV_NODE_FOUR"]) else 3,
                  "fit_errors_vs_float64_networks": {str(k): v for k, v in pk.poly_errors.items()}}
     roof = None
     P_, T_, W_ = ctypes.byref(pk.struct), ctypes.byref(topo.struct), ctypes.byref(ws.struct)
