@@ -9,9 +9,9 @@ mkdir -p $out
 cd $GRAFT_REPO_ROOT
 say() { echo "$(date +%T) $*"; }
 if [ $part = default ]; then
-  say "default bench (drugs200)"; t0=$SECONDS; python bench.py 2>$out/${R}_bench_default.err | tail -1 > $out/${R}_${PREC}_bench.json; say "default bench took $((SECONDS - t0)) s wall"
+  say "default bench (drugs200)"; t0=$SECONDS; python bench.py --gpus 1 --steps 20 --warmup 5 2>$out/${R}_bench_default.err | tail -1 > $out/${R}_${PREC}_bench.json; say "default bench took $((SECONDS - t0)) s wall"
 elif [ $part = bench ]; then
-  say "default bench (drugs200)"; t0=$SECONDS; python bench.py 2>$out/${R}_bench_default.err | tail -1 > $out/${R}_${PREC}_bench.json; say "default bench took $((SECONDS - t0)) s wall"
+  say "default bench (drugs200)"; t0=$SECONDS; python bench.py --gpus 1 --steps 20 --warmup 5 2>$out/${R}_bench_default.err | tail -1 > $out/${R}_${PREC}_bench.json; say "default bench took $((SECONDS - t0)) s wall"
   say "drugs 8x128 + breakdown"; python bench.py --workload drugs --breakdown $out/${R}_${PREC}_breakdown.json --no-cpu-baseline 2>/dev/null | tail -1 > $out/${R}_bench_drugs_8x128.json
   say "8x128 unfused front"; python bench.py --workload drugs --front unfused --steps 500 --no-cpu-baseline --no-extra 2>/dev/null | tail -1 > $out/${R}_bench_drugs_8x128_unfused_front.json
   say "8x128 poly off"; python bench.py --workload drugs --radius-poly off --steps 300 --no-cpu-baseline --no-extra 2>/dev/null | tail -1 > $out/${R}_bench_poly_off.json
