@@ -208,12 +208,13 @@ def test_node_cfconv_equals_one_list_kernel(kind, mols, copies, gt):
 
 @pytest.mark.parametrize("passes", ["auto", "full"])
 @pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x3"])
-@pytest.mark.parametrize("kind,mols,copies", [("drugs", 3, 6), ("qm9", 5, 9)])
-def test_cfconv_node_shapes_agree_bitwise(kind, mols, copies, precision, passes):
+@pytest.mark.parametrize("kind,mols,copies,mode", [("drugs", 3, 6, "auto"), ("qm9", 5, 9, "auto"), ("drugs", 2, 5, "kt2")])
+def test_cfconv_node_shapes_agree_bitwise(kind, mols, copies, mode, precision, passes):
     """agdiff_cfconv_node has two shapes at one k-tile (csrc/nodeconv.hip NodeConvShape): 12-wave workgroups with groups of three
-    channel tiles, and -- from tune_cfconv_four_min_quads quads on -- 16-wave workgroups at 128 VGPRs with groups of two.  A
-    target's sums are taken by ONE wave in the same tile and row order in both, so the aggregates, and everything downstream,
-    must be identical bit for bit; variant_log says which shape ran."""
+    channel tiles, and -- from tune_cfconv_four_min_quads quads on -- 16-wave workgroups at 128 VGPRs with groups of two (two
+    k-tiles: groups of one, and only under the one-pass plan).  A target's sums are taken by ONE wave in the same tile and row
+    order in both, so the aggregates, and everything downstream, must be identical bit for bit; variant_log says which shape
+    ran."""
     from agdiff_amd import _lib, drugs_model_config, qm9_model_config, synth
     cfg = (drugs_model_config if kind == "drugs" else qm9_model_config)(num_diffusion_timesteps=20)
     b = synth.make_packed_batch(kind, mols, copies, seed=23)
@@ -221,12 +222,13 @@ def test_cfconv_node_shapes_agree_bitwise(kind, mols, copies, precision, passes)
     pos = (torch.randn(at.shape[0], 3, generator=torch.Generator().manual_seed(3)) * 1.5).cuda()
     outs = {}
     for four in (1, -1):
-        m = _model(cfg, "auto", precision=precision)
+        m = _model(cfg, mode, precision=precision)
         m.poly_passes = passes
         m.tuning["cfconv_four_min_quads"] = four
         out = m(at, pos, bi, bt, ba, None, return_edges=True, extend_order=False)
         ws, var = m._batch_cache[2], _variants(m._batch_cache[2])
-        assert bool(var & _lib.DEFINES["AGDIFF_VAR_CFCONV_NODE_FOUR"]) == (four == 1), (four, var)
+        has_four = mode == "auto" or m.packed().poly_plan == 1          # (two k-tiles at three passes: one shape only)
+        assert bool(var & _lib.DEFINES["AGDIFF_VAR_CFCONV_NODE_FOUR"]) == (four == 1 and has_four), (four, var)
         assert var & _lib.DEFINES["AGDIFF_VAR_CFCONV_NODE"]
         outs[four] = (out[0].clone(), out[1].clone(), ws.h.clone(), ws.agg.clone())
     for a_, b_ in zip(outs[1], outs[-1]):
