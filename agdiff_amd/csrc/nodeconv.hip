@@ -71,9 +71,9 @@ struct NodeConvArgs {
 // tiles need 135 VGPRs (one-pass plan; groups of three: 156): under the 128-VGPR cap of FOUR waves per SIMD that leaves 5..7
 // spilled registers (reloaded once per local tile, none in the radius loop) and takes 15 % less time than three waves per SIMD
 // at groups of three (six launches on 196 k atoms: 3.53 -> 3.00 ms; groups of two at three waves: 3.83; groups of three at four
-// waves, 27 spills: 3.32).  Two k-tiles hold twice the coefficient registers: under the one-pass plan they fit the cap with ONE
-// channel tile per group (5 spills; 0.993 against 1.026 ms per launch at groups of three / 12 waves; groups of two: 28 spills,
-// 1.14), with three passes they stay at 168 VGPRs, three waves per SIMD.
+// waves, 27 spills: 3.32).  Two k-tiles hold twice the coefficient registers and stay at 168 VGPRs, three waves per SIMD: groups
+// of two spill 28 registers at 16 waves (1.14 against 1.01 ms per launch); ONE channel tile per group fits with 5 spills under the
+// one-pass plan and wins 4 % on a 36-molecule batch but LOSES 6 % on the default job's batches (0.976 against 0.920 ms).
 // Small launches (fewer than two quads per wave of a full grid: tune_cfconv_four_min_quads) keep the 12-wave shape: more
 // workgroups for the same quads (23 k atoms: even; 4 k atoms: 12 waves 3 % ahead).  -DAG_NODE_GRP / -DAG_NODECONV_WAVES force one
 // shape on every instantiation (A/B builds).
@@ -82,7 +82,8 @@ struct NodeConvShape {
 #ifdef AG_NODE_GRP
   static constexpr int GRP = AG_NODE_GRP;
 #else
-  static constexpr int GRP = FOUR ? (NKT == 1 ? 2 : 1) : 3;      // (two k-tiles under the cap: one channel tile per group, 5 spills)
+  static_assert(!FOUR || NKT == 1, "four waves per SIMD: one k-tile");
+  static constexpr int GRP = FOUR ? 2 : 3;
 #endif
 #ifdef AG_NODECONV_WAVES
   static constexpr int WAVES = AG_NODECONV_WAVES;
@@ -438,8 +439,7 @@ int launch_cfconv_node_s(const NodeConvArgs& a, size_t smem, void* stream) {
 }
 template <int MODE, int NKT, int PLAN>
 int launch_cfconv_node_p(const NodeConvArgs& a, bool four, size_t smem, void* stream) {
-  // (two k-tiles: only the one-pass plan fits the cap -- three passes hold a second coefficient unit per block: 20 spills)
-  if constexpr (NKT == 1 || PLAN == 1) {
+  if constexpr (NKT == 1) {
     if (four) return launch_cfconv_node_s<MODE, NKT, PLAN, true>(a, smem, stream);
   }
   return launch_cfconv_node_s<MODE, NKT, PLAN, false>(a, smem, stream);
@@ -500,7 +500,7 @@ extern "C" int agdiff_cfconv_node(const agdiff_params_t* p, const agdiff_topo_t*
   const size_t smem = (size_t)(1 + a.lds_slots) * set_bytes;
   // shape: four waves per SIMD pay from two quads per wave of a full grid on (below, 12-wave workgroups spread the quads wider)
   const int64_t four_min = p->tune_cfconv_four_min_quads ? p->tune_cfconv_four_min_quads : 8192;
-  const bool four = (p->poly_kt == 1 || p->poly_plan == 1) && four_min >= 0 && a.num_quads >= four_min;
+  const bool four = p->poly_kt == 1 && four_min >= 0 && a.num_quads >= four_min;
   ag_log_variant(ws, AGDIFF_VAR_CFCONV_NODE | (local ? AGDIFF_VAR_CFCONV_NODE_LOCAL : 0) |
                          (a.lds_slots < a.num_slots ? AGDIFF_VAR_POLY_L2_SETS : 0) | (four ? AGDIFF_VAR_CFCONV_NODE_FOUR : 0));
   const int plan = p->poly_plan;

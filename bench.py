@@ -376,6 +376,8 @@ def main():
     ap.add_argument("--poly-passes", default="auto", choices=["auto", "full"],
                     help="MFMA passes over the filter polynomials' high terms: auto = one when the host's bound allows it "
                          "(agdiff_params_t.poly_plan), full = three for every term (A/B runs)")
+    ap.add_argument("--tune", action="append", default=[], metavar="FIELD=VALUE",
+                    help="kernel-variant threshold (agdiff_params_t.tune_*; PackedParams.TUNING), e.g. cfconv_four_min_quads=-1 (A/B runs)")
     ap.add_argument("--front", default="fused", choices=["fused", "split", "unfused"],
                     help="serial front of a step: one launch (update + local edges + radius graph), the same with the graph "
                          "phase launched after the local branch's fork, or the unfused kernels (A/B runs)")
@@ -440,6 +442,8 @@ def main():
         m.fused_front, m.front_split_graph = args.front != "unfused", args.front == "split"
         if args.serial:
             m.tuning["serial_branches"] = 1
+        for kv in args.tune:
+            m.tuning[kv.split("=")[0]] = int(kv.split("=")[1])
         fill = synth.restoring_state_dict if weights == "restoring" else synth.synth_state_dict
         m.load_state_dict(fill(m.state_dict()))
         return m.to(dev).eval(), cfg

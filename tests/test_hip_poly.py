@@ -212,7 +212,7 @@ def test_node_cfconv_equals_one_list_kernel(kind, mols, copies, gt):
 def test_cfconv_node_shapes_agree_bitwise(kind, mols, copies, mode, precision, passes):
     """agdiff_cfconv_node has two shapes at one k-tile (csrc/nodeconv.hip NodeConvShape): 12-wave workgroups with groups of three
     channel tiles, and -- from tune_cfconv_four_min_quads quads on -- 16-wave workgroups at 128 VGPRs with groups of two (two
-    k-tiles: groups of one, and only under the one-pass plan).  A target's sums are taken by ONE wave in the same tile and row
+    k-tiles keep the first shape).  A target's sums are taken by ONE wave in the same tile and row
     order in both, so the aggregates, and everything downstream, must be identical bit for bit; variant_log says which shape
     ran."""
     from agdiff_amd import _lib, drugs_model_config, qm9_model_config, synth
@@ -227,7 +227,7 @@ def test_cfconv_node_shapes_agree_bitwise(kind, mols, copies, mode, precision, p
         m.tuning["cfconv_four_min_quads"] = four
         out = m(at, pos, bi, bt, ba, None, return_edges=True, extend_order=False)
         ws, var = m._batch_cache[2], _variants(m._batch_cache[2])
-        has_four = mode == "auto" or m.packed().poly_plan == 1          # (two k-tiles at three passes: one shape only)
+        has_four = mode == "auto"                    # (two k-tiles: one shape only; the tuning field must not matter)
         assert bool(var & _lib.DEFINES["AGDIFF_VAR_CFCONV_NODE_FOUR"]) == (four == 1 and has_four), (four, var)
         assert var & _lib.DEFINES["AGDIFF_VAR_CFCONV_NODE"]
         outs[four] = (out[0].clone(), out[1].clone(), ws.h.clone(), ws.agg.clone())
