@@ -277,7 +277,8 @@ class DualEncoderEpsNetwork(nn.Module):
         if not self._uses_split_fp16():
             return
         names = [n for n, _ in self.RANGE_LIMITS if self.precision == "f16x3" or n == "hl"]
-        mx = torch.stack([getattr(ws, n).abs().max() for n in names]).cpu().tolist()
+        mm = [torch.aminmax(getattr(ws, n)) for n in names]           # (one pass per tensor, no |x| temporary)
+        mx = torch.stack([torch.maximum(a.max, -a.min) for a in mm]).cpu().tolist()
         for n, v in zip(names, mx):
             lim = dict(self.RANGE_LIMITS)[n]
             if not (v <= lim):          # (also a NaN)
@@ -553,6 +554,9 @@ class LangevinRun:
         step = self.step_lr * (sig / 0.01) ** 2
         self._sched = list(zip(sig.tolist(), step.tolist(), torch.sqrt(step * 2).tolist(),
                                (sig < self.global_start_sigma).tolist()))
+        # the range watch once on the fresh workspace: what it polls later (check_nan) is then loaded and sized before the
+        # first step (its first use in a process otherwise lands ~20 ms of lazy kernel loading inside the run's last step)
+        model.check_range(self.ws)
 
     def _quarantine_non_finite_input(self):
         """Graphs whose INITIAL positions hold a NaN / inf are flagged like graphs that diverge later (k_langevin_update) and
