@@ -376,6 +376,8 @@ def main():
     ap.add_argument("--poly-passes", default="auto", choices=["auto", "full"],
                     help="MFMA passes over the filter polynomials' high terms: auto = one when the host's bound allows it "
                          "(agdiff_params_t.poly_plan), full = three for every term (A/B runs)")
+    ap.add_argument("--group-targets", type=int, default=None, choices=[1, 2, 4],
+                    help="targets per wave of agdiff_cfconv_node (BatchTopology.group_targets; default by batch size; A/B runs)")
     ap.add_argument("--tune", action="append", default=[], metavar="FIELD=VALUE",
                     help="kernel-variant threshold (agdiff_params_t.tune_*; PackedParams.TUNING), e.g. cfconv_four_min_quads=-1 (A/B runs)")
     ap.add_argument("--front", default="fused", choices=["fused", "split", "unfused"],
@@ -444,6 +446,8 @@ def main():
             m.tuning["serial_branches"] = 1
         for kv in args.tune:
             m.tuning[kv.split("=")[0]] = int(kv.split("=")[1])
+        if args.group_targets:
+            m.group_targets = args.group_targets
         fill = synth.restoring_state_dict if weights == "restoring" else synth.synth_state_dict
         m.load_state_dict(fill(m.state_dict()))
         return m.to(dev).eval(), cfg
