@@ -1,6 +1,7 @@
 // Whole-path entry points: ABI self-description, the score network (dualenc.py:142-251) and one
 // denoising step (dualenc.py:478-545), composed from the per-op launchers.
 #include "common.hpp"
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -14,6 +15,85 @@ extern "C" int agdiff_conv_chunk_tiles(int64_t max_edges) {
   int c = 1;
   while (c < AGDIFF_MAX_CHUNK_TILES && tiles / (2 * c) >= 16 * 2048) c *= 2;
   return c;
+}
+
+// include/agdiff_hip.h: agdiff_group_order (host only).  Sizes are a molecule's: n <= 512 atoms, k <= ~8 types.
+extern "C" int agdiff_group_order(const int32_t* need, int32_t n, int32_t k, int32_t gt, int32_t* order_out) {
+  if (n < 0 || k < 0 || (gt != 1 && gt != 2 && gt != 4) || (n > 0 && (!need || !order_out))) return AGDIFF_ERR_ARG;
+  if (n == 0) return AGDIFF_OK;
+  auto row = [&](int i) { return need + (size_t)i * k; };
+  std::vector<int> total(n, 0);
+  for (int i = 0; i < n; ++i)
+    for (int t = 0; t < k; ++t) total[i] += row(i)[t];
+  // start r < k: ascending by the need vector read from type r on, cyclically; start k: ascending by total need (stable)
+  auto start_order = [&](int r, std::vector<int>& o) {
+    o.resize(n);
+    for (int i = 0; i < n; ++i) o[i] = i;
+    std::stable_sort(o.begin(), o.end(), [&](int a, int b) {
+      if (r == k) return total[a] < total[b];
+      for (int t = 0; t < k; ++t) {
+        const int c = (r + t) % k;
+        if (row(a)[c] != row(b)[c]) return row(a)[c] < row(b)[c];
+      }
+      return false;
+    });
+  };
+  const int ng = (n + gt - 1) / gt;
+  std::vector<int> grp((size_t)ng * gt), best;
+  long best_cost = -1;
+  auto cost = [&](const int* g) {            // sum over the types of the max over the group's atoms (-1: unused slot)
+    long c = 0;
+    for (int t = 0; t < k; ++t) {
+      int m = 0;
+      for (int s = 0; s < gt; ++s)
+        if (g[s] >= 0 && row(g[s])[t] > m) m = row(g[s])[t];
+      c += m;
+    }
+    return c;
+  };
+  std::vector<int> o;
+  std::vector<long> costs(ng);
+  for (int r = 0; r <= k; ++r) {
+    if (r == k && k == 0) break;
+    start_order(r, o);
+    for (size_t i = 0; i < grp.size(); ++i) grp[i] = i < (size_t)n ? o[i] : -1;
+    if (gt > 1 && n > gt) {
+      for (int g = 0; g < ng; ++g) costs[g] = cost(&grp[(size_t)g * gt]);
+      for (int pass = 0; pass < 16; ++pass) {
+        bool improved = false;
+        for (int a = 0; a < ng; ++a)
+          for (int b = a + 1; b < ng; ++b) {
+            int* ga = &grp[(size_t)a * gt];
+            int* gb = &grp[(size_t)b * gt];
+            for (int ia = 0; ia < gt; ++ia)
+              for (int ib = 0; ib < gt; ++ib) {
+                if (ga[ia] < 0 || gb[ib] < 0) continue;
+                std::swap(ga[ia], gb[ib]);
+                const long ca = cost(ga), cb = cost(gb);
+                if (ca + cb < costs[a] + costs[b]) {
+                  costs[a] = ca;
+                  costs[b] = cb;
+                  improved = true;
+                } else {
+                  std::swap(ga[ia], gb[ib]);
+                }
+              }
+          }
+        if (!improved) break;
+      }
+    }
+    long c = 0;
+    for (int g = 0; g < ng; ++g) c += cost(&grp[(size_t)g * gt]);
+    if (best_cost < 0 || c < best_cost) {
+      best_cost = c;
+      best = grp;
+    }
+    if (k == 0) break;
+  }
+  int w = 0;
+  for (size_t i = 0; i < best.size(); ++i)
+    if (best[i] >= 0) order_out[w++] = best[i];
+  return w == n ? AGDIFF_OK : AGDIFF_ERR_ARG;
 }
 
 extern "C" int agdiff_struct_sizes(int64_t* out) {

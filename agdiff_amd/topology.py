@@ -18,6 +18,29 @@ def _to_np(x):
     return np.asarray(x)
 
 
+_GROUP_ORDER_CACHE = {}
+
+
+def _group_order(need, GT):
+    """agdiff_group_order (include/agdiff_hip.h; a host function of the library): the order of a molecule's atoms (local
+    indices) in which consecutive runs of GT atoms form the groups agdiff_cfconv_node's waves own -- atoms with like per-type
+    tile needs together.  On the bench job: 6 % fewer local tiles than sorting by the need vectors alone.  Cached per need
+    matrix: the conformers of a molecule, and a molecule met again, cost one look-up."""
+    need = np.ascontiguousarray(need, dtype=np.int32)
+    key = (GT, need.shape, need.tobytes())
+    hit = _GROUP_ORDER_CACHE.get(key)
+    if hit is None:
+        import ctypes
+        hit = np.zeros(need.shape[0], dtype=np.int32)
+        _lib.check(_lib.load().agdiff_group_order(need.ctypes.data_as(ctypes.c_void_p), need.shape[0], need.shape[1], GT,
+                                                  hit.ctypes.data_as(ctypes.c_void_p)), "agdiff_group_order")
+        hit = hit.astype(np.int64)
+        if len(_GROUP_ORDER_CACHE) > 4096:
+            _GROUP_ORDER_CACHE.clear()
+        _GROUP_ORDER_CACHE[key] = hit
+    return hit
+
+
 class BatchTopology:
     # agdiff_cfconv_node gives a wave a GROUP of targets (quad_tgt): four for batches that fill the chip that way (one
     # 16-row local tile then serves four targets: fewest tiles), two or one for small batches, where there are more wave
@@ -155,10 +178,10 @@ class BatchTopology:
             raise ValueError("group_targets must be 1, 2 or 4")
         GT, RT = int(group_targets), 16 // int(group_targets)               # targets per group, rows per target in a tile
         need = (cnt_tt + RT - 1) // RT
-        order_in_mol = np.lexsort(tuple(need[:, k] for k in range(need.shape[1] - 1, -1, -1)) + (ba,))    # by molecule, then the needs
         quad_tgt = []
         for g in range(G):
-            idx = order_in_mol[gptr[g]:gptr[g + 1]]
+            # (conformers of one molecule share the grouping: cached by the molecule's need matrix)
+            idx = int(gptr[g]) + _group_order(need[gptr[g]:gptr[g + 1]], GT)
             if idx.size % GT:
                 idx = np.concatenate([idx, np.full(GT - idx.size % GT, -1, dtype=idx.dtype)])
             grp = np.full((idx.size // GT, 4), -1, dtype=np.int64)              # (always four entries per group: -1 = none)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 37
+#define AGDIFF_ABI_VERSION 38
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -399,6 +399,14 @@ typedef struct agdiff_step_args {
 /* Tiles per chunk the fused CFConv kernel and the node stage use for a workspace of `max_edges` edges (1..8):
  * small batches get short chunks so that every wave slot of the chip has work. */
 int agdiff_conv_chunk_tiles(int64_t max_edges);
+
+/* Host helper of the topology builder (no GPU work): the order of a molecule's n atoms in which consecutive runs of `gt`
+ * atoms form the target groups agdiff_cfconv_node's waves own (agdiff_topo_t.quad_tgt).  need [n][k] (row-major): local
+ * 16-row tiles atom i needs of local edge type k = ceil(in-edges of that type / (16 / gt)); a group costs the sum over the
+ * types of the MAX of its atoms' needs, so atoms with like needs belong together.  Search: the atoms sorted by their need
+ * vectors with each type in turn as the leading key, or by total need; from every start, swaps of two atoms between two
+ * groups while the total falls; the cheapest result wins (ties: the earliest start).  Deterministic.  order_out [n]. */
+int agdiff_group_order(const int32_t* need /* [host] */, int32_t n, int32_t k, int32_t gt, int32_t* order_out /* [host] */);
 
 /* Build stamp / ABI check. */
 int agdiff_abi_version(void);
