@@ -350,6 +350,41 @@ def test_sharp_networks_need_more_terms_or_are_refused():
     assert 1 in seen and 0 in seen          # smooth weights: 32 terms; a 40x sharper first layer: refused
 
 
+def test_group_order_is_a_permutation_and_beats_the_plain_sort():
+    """agdiff_group_order (host function of the library behind BatchTopology's target groups): a permutation of the molecule's
+    atoms, deterministic, never more tiles than cutting the lexicographically sorted need vectors into runs of GT, and fewer on
+    the synthetic Drugs-shaped molecules; GT = 1 and molecules of at most GT atoms keep the sorted order."""
+    from agdiff_amd import synth, topology
+    from agdiff_amd.topology import BatchTopology
+    rng = np.random.default_rng(11)
+    tot_sort = tot_new = 0
+    for trial in range(12):
+        at_, r_, c_, t_ = synth.random_molecule(rng, synth.sample_n_atoms(rng, "drugs"))
+        b = dict(atom_type=at_, bond_index=np.stack([r_, c_]), bond_type=t_, batch=np.zeros(at_.shape[0], dtype=np.int64))
+        tp = BatchTopology(b["atom_type"], b["bond_index"], b["bond_type"], b["batch"], device="cpu", group_targets=4)
+        dst, typ, N = tp.loc_dst.numpy(), tp.loc_type.numpy(), tp.N
+        types = np.unique(typ)
+        cnt = np.stack([np.bincount(dst[typ == ty], minlength=N) for ty in types], 1)
+        for gt in (4, 2, 1):
+            need = ((cnt + 16 // gt - 1) // (16 // gt)).astype(np.int32)
+            cost = lambda order: sum(need[order[j:j + gt]].max(axis=0).sum() for j in range(0, N, gt))
+            plain = np.lexsort(tuple(need[:, k] for k in range(need.shape[1] - 1, -1, -1)))
+            topology._GROUP_ORDER_CACHE.clear()
+            o1 = topology._group_order(need, gt)
+            topology._GROUP_ORDER_CACHE.clear()
+            o2 = topology._group_order(need, gt)
+            assert np.array_equal(o1, o2) and sorted(o1.tolist()) == list(range(N))
+            assert cost(o1) <= cost(plain)
+            if gt == 1:
+                assert cost(o1) == cost(plain)
+            if gt == 4:
+                tot_sort += cost(plain); tot_new += cost(o1)
+                assert cost(o1) == tp.T          # (what the topology built)
+    assert tot_new < 0.97 * tot_sort, (tot_new, tot_sort)
+    tiny = np.array([[1, 0], [0, 2], [1, 1]], dtype=np.int32)
+    assert sorted(topology._group_order(tiny, 4).tolist()) == [0, 1, 2]
+
+
 def test_padded_local_list():
     """agdiff_topo_t.lp_*: every target's local list padded to at least 8 entries, real entries first and in in-slot order."""
     from agdiff_amd import synth
