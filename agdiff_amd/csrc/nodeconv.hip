@@ -97,6 +97,15 @@ struct NodeConvShape {
 #ifndef AG_NODE_XD_FOUR
 #define AG_NODE_XD_FOUR AG_NODE_XD          // ... of the four-waves-per-SIMD shape (six groups of two channel tiles: 2 or 3)
 #endif
+#ifndef AG_QUAD_META_NT
+#define AG_QUAD_META_NT 0     // radius rows' inputs of k_cfconv_quad: 1 non-temporal loads (as k_cfconv_node), 0 cached
+#endif
+#ifndef AG_QUAD_WAHEAD
+#define AG_QUAD_WAHEAD 1       // k_cfconv_quad: coefficient blocks read one group ahead of their MFMAs
+#endif
+#ifndef AG_QUAD_STORE_NT
+#define AG_QUAD_STORE_NT 1
+#endif
 #ifndef AG_NODE_ABL
 #define AG_NODE_ABL 0       // timing experiments only (wrong results): 1 no x gathers, 2 no filter MFMAs, 4 no features, 8 no sums, 16 one coefficient read per group
 #endif
@@ -424,12 +433,284 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
 #undef AG_QUAD_ARGS
 }
 
-template <int MODE, int NKT, int PLAN, bool FOUR>
+
+// ------------------------------------------------------------------------------ the same CFConv, radius rows in QUAD tiles too
+// k_cfconv_node gives every target its own radius tiles (ceil(cnt / 16) of them, the last one padded: 24 % of the radius rows a
+// launch of the default job executes are pads) and keeps two sets of sums (a target's, the quad's local rows').  Here a radius
+// tile is laid out like a local one: quarter k of tile t holds rows 4 t .. 4 t + 3 of the quad's k-th target (the target's own
+// rows AGDIFF_RAD_STRIDE i + 4 t + r of ws->rad_*: the memory layout does not change, only which rows a wave puts into one MFMA
+// tile), a quad walks max_k ceil(cnt_k / 4) radius tiles (-8 % on the default job: counted by tools/tile_layouts.py), every lane
+// keeps ONE set of sums -- its quarter's target, local and radius rows alike -- and a finished quad is written without any
+// exchange between the quarters: lane (q, col) stores channel 16 ct + col of target q.  Rows 4 t + r >= cnt_k run with scale 0
+// (the front kernel pads a target's rows only to the end of the last 16-row tile it used: what lies beyond is older, finite
+// data of the same molecule).  Needs quads (topo->group_targets == 4); summation order per target: its local rows by tile,
+// then its radius rows by source -- fixed, hence bitwise reproducible, but not the order of k_cfconv_node.
+template <int MODE, int NKT, int WAVES, int PLAN, int GRP>
+__global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_quad(NodeConvArgs a) {
+  static_assert(PLAN == 0 || MODE != AG_F32, "poly_plan needs a split mode");
+  constexpr bool MIXED = PLAN == 1 && NKT == 1;
+  extern __shared__ u32x4 ag_nodeconv_smem[];
+  lds_u32x4* wl = (lds_u32x4*)ag_nodeconv_smem;
+  constexpr int SET = AG_CONV_NCH * NKT * 128;
+  constexpr int NG = AG_CONV_NCH / GRP;
+  ag_copy_lds(wl, reinterpret_cast<const u32x4*>(a.poly_rad), SET);
+  if (a.lds_slots > 0) ag_copy_lds(wl + SET, reinterpret_cast<const u32x4*>(a.poly_typed), a.lds_slots * SET);
+  __syncthreads();
+  int lane = ag_lane();
+  asm volatile("" : "+v"(lane));
+  const int q = lane >> 4, col = lane & 15;
+  const int cq = col >> 2, cr = col & 3;              // the lane's row `col` of a tile: quarter cq, row cr of it
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wg = (gridDim.x % 8 == 0) ? (int)((blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8) : (int)blockIdx.x;
+  const int per_wg = (a.num_quads + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int p_begin = wg * per_wg;
+  const int p_end = (p_begin + per_wg < a.num_quads) ? p_begin + per_wg : a.num_quads;
+  const bool with_local = a.num_slots > 0;
+
+  // a quad: nL local tiles from lt0 and nR radius tiles in scalars.  What differs by quarter -- the first radius row of the
+  // quarter's target (a missing target borrows the quad's first: its count is 0), its number of radius rows, its row of agg -- lives
+  // in a few wave-private LDS words (two slots: the current quad's and the next one's), written once per quad by lanes 0..3 and
+  // read back per tile with the quarter as the index: as per-lane registers these values were spilled around every tile at the
+  // 128-VGPR cap, and a scratch reload waits for every outstanding gather
+  typedef __attribute__((address_space(3))) int lds_int;
+  lds_int* qi = reinterpret_cast<lds_int*>(wl + (size_t)(1 + (a.lds_slots > 0 ? a.lds_slots : 0)) * SET) + wave * 32;
+#define AG_RQ_DECL(P) int P##nL = 0, P##lt0 = 0, P##nR = 0
+#define AG_RQ_LOAD(P, p, slot)                                                          \
+  do {                                                                                  \
+    const int t0_ = a.quad_tgt[4 * (p)], t1_ = a.quad_tgt[4 * (p) + 1], t2_ = a.quad_tgt[4 * (p) + 2], t3_ = a.quad_tgt[4 * (p) + 3]; \
+    const int c0_ = cnt_of(t0_), c1_ = cnt_of(t1_), c2_ = cnt_of(t2_), c3_ = cnt_of(t3_); \
+    const int m01 = c0_ > c1_ ? c0_ : c1_, m23 = c2_ > c3_ ? c2_ : c3_;               \
+    P##nR = ((m01 > m23 ? m01 : m23) + 3) >> 2;                                         \
+    P##lt0 = with_local ? a.lt_ptr[(p)] : 0;                                            \
+    P##nL = with_local ? a.lt_ptr[(p) + 1] - P##lt0 : 0;                                \
+    if (lane < 4) {                                                                     \
+      const int tk = lane == 0 ? t0_ : lane == 1 ? t1_ : lane == 2 ? t2_ : t3_;         \
+      const int ck = lane == 0 ? c0_ : lane == 1 ? c1_ : lane == 2 ? c2_ : c3_;         \
+      qi[(slot) * 16 + lane] = (tk < 0 ? t0_ : tk) * AGDIFF_RAD_STRIDE;                 \
+      qi[(slot) * 16 + 4 + lane] = ck;                                                  \
+      qi[(slot) * 16 + 8 + lane] = tk < 0 ? -1 : tk * 768;                              \
+    }                                                                                   \
+  } while (0)
+  auto cnt_of = [&](int t) { return (t >= 0) ? a.rad_cnt[t] : 0; };
+  // per-row inputs of the wave's NEXT tile: length and the two scales of row `col`, the tile's type slot (-1: radius rows),
+  // whether the row is live, the sources of the lane's four rows 4 q .. 4 q + 3
+  float pf_d = 0.f, pf_s1 = 0.f, pf_s2 = 0.f;
+  int pf_slot = -1;
+  bool pf_dead = false;
+  int pf_src[4] = {0, 0, 0, 0};
+  auto ldf = [](const float* base, uint32_t byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); };
+  auto ldi = [](const int32_t* base, uint32_t byte_off) { return *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(base) + byte_off); };
+  auto ldf_nt = [](const float* base, uint32_t byte_off) { return __builtin_nontemporal_load(reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off)); };
+  auto prefetch_local = [&](int rows) {
+    const uint32_t e4 = (uint32_t)(rows + col) * 4u;
+    const uint32_t r16 = (uint32_t)(rows + 4 * q) * 4u;
+    const u32x4 s4 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.lt_src) + r16);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pf_src[r] = (int)s4[r];
+    const int sl = ldi(a.type_slot, (uint32_t)ldi(a.lt_type, e4) * 4u);
+    pf_slot = sl < 0 ? -2 : sl;
+    pf_dead = sl < 0;
+    pf_d = ldf(a.lt_len, e4);
+    pf_s1 = ldf(a.l_scale1, e4);
+    pf_s2 = ldf(a.l_scale2, e4);
+  };
+  // radius tile t of the quad in slot `slot`
+  auto prefetch_radius = [&](int t, int slot) {
+    const int rbq = qi[slot * 16 + q], rbc = qi[slot * 16 + cq], cnt = qi[slot * 16 + 4 + cq];
+    const uint32_t e4 = (uint32_t)(rbc + 4 * t + cr) * 4u;
+    const uint32_t r16 = (uint32_t)(rbq + 4 * t) * 4u;
+#if AG_QUAD_META_NT
+    const u32x4 s4 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.rad_src) + r16));
+    pf_d = ldf_nt(a.rad_len, e4);
+    pf_s1 = ldf_nt(a.r_scale1, e4);
+    pf_s2 = ldf_nt(a.r_scale2, e4);
+#else
+    // (cached: a quarter's four rows are a quarter of a line, the next three tiles read the rest of it)
+    const u32x4 s4 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.rad_src) + r16);
+    pf_d = ldf(a.rad_len, e4);
+    pf_s1 = ldf(a.r_scale1, e4);
+    pf_s2 = ldf(a.r_scale2, e4);
+#endif
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pf_src[r] = (int)s4[r];
+    pf_slot = -1;
+    pf_dead = 4 * t + cr >= cnt;
+  };
+  constexpr int XD = (GRP == 2) ? AG_NODE_XD_FOUR : AG_NODE_XD;
+  static_assert((AG_CONV_NCH / GRP) % XD == 0 && XD >= 2, "ring of x buffers");
+  f32x4 xg[XD][GRP];
+  uint32_t xoff[4];
+  auto set_xoff = [&]() {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xoff[r] = ((uint32_t)pf_src[r] * 192u + (uint32_t)col) * 4u;
+  };
+  auto fetch_xg = [&](auto BUF, int g) {
+    constexpr int kb = decltype(BUF)::value;
+    const char* xb = reinterpret_cast<const char*>(a.xs);
+#pragma unroll
+    for (int j = 0; j < GRP; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xg[kb][j][r] = *reinterpret_cast<const float*>(xb + (size_t)xoff[r] + 64 * (GRP * g + j));
+    }
+  };
+  auto fetch_first_groups = [&]() {
+    ag_static_for<0, XD - 1>([&](auto G) { fetch_xg(G, decltype(G)::value); });
+  };
+  const lds_u32x4* wl_l = wl + lane;
+  // The coefficient blocks of a group of GRP channel tiles (pk [12][NKT]: block ct * NKT + t) are read into `w` ONE GROUP AHEAD of
+  // their MFMAs -- straight after the MFMAs of the group before have issued, into the registers those have just read -- so that the
+  // LDS round trip runs beside the sums of the group before instead of in front of the MFMAs that wait for it.
+  u32x4 w[GRP][NKT][2];
+  auto load_w = [&](auto base, auto GG) {
+    constexpr int C0 = GRP * decltype(GG)::value;
+#pragma unroll
+    for (int j = 0; j < GRP; ++j) {
+#pragma unroll
+      for (int t = 0; t < NKT; ++t) {
+        w[j][t][0] = base[(((C0 + j) * NKT + t) * 2) * 64];
+        if (PLAN == 0 || t == 0) w[j][t][1] = base[(((C0 + j) * NKT + t) * 2 + 1) * 64];
+      }
+    }
+  };
+  AgIn<MODE> ph1[NKT], ph2[NKT];
+  // z[j] = features x block of channel tile C0 + j (channel tiles 0..7: conv1's features, 8..11: conv2's); independent accumulator
+  // chains with their MFMA passes interleaved, the first MFMA of a chain takes the literal 0
+  auto mma_w = [&](auto GG, f32x4 (&z)[GRP]) {
+    constexpr int C0 = GRP * decltype(GG)::value;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+      const int parts = (PLAN == 0) ? AgParts<MODE>::n : MIXED ? 2 : (t == 0) ? AgParts<MODE>::n : 1;
+#pragma unroll
+      for (int part = 0; part < parts; ++part) {
+#pragma unroll
+        for (int j = 0; j < GRP; ++j) {
+          const AgIn<MODE> (&ph)[NKT] = (C0 + j < 8) ? ph1 : ph2;
+          if constexpr (MIXED) {
+            if (part == 1) {
+              ag_block_mma_mixed<MODE, true>(z[j], ph[0], w[j][0]);
+              continue;
+            }
+          }
+          if (t == 0 && part == 0) z[j] = ag_block_mma_first<MODE, true>(ph[0], w[j][0]);
+          else ag_block_mma_part<MODE, true>(z[j], ph[t], w[j][t], part);
+        }
+      }
+    }
+  };
+  auto next_features = [&]() {
+    const float s1 = pf_dead ? 0.0f : pf_s1, s2 = pf_dead ? 0.0f : pf_s2;
+    ag_poly_features<MODE, NKT, MIXED>(pf_d, a.two_over_rc, q, ph1, s1);
+    ag_poly_features<MODE, NKT, MIXED>(pf_d, a.two_over_rc, q, ph2, s2);
+  };
+  float acc[AG_CONV_NCH];
+
+  int p = p_begin + wave;
+  if (p >= p_end) return;                       // (no barrier below)
+  AG_RQ_DECL(c_);
+  int cslot = 0;                                // (uniform) the LDS slot of the current quad
+  AG_RQ_LOAD(c_, p, 0);
+  bool have_pf = false;
+  while (p < p_end) {
+    const int pn = p + WAVES;
+    AG_RQ_DECL(x_);
+    if (pn < p_end) AG_RQ_LOAD(x_, pn, cslot ^ 1);
+    const int ntiles = c_nL + c_nR;
+    const int ntiles_next = x_nL + x_nR;
+    // requests the per-row inputs of tile j of the current quad (j < ntiles) or of the first tile of the next one
+    // (ONE call of either kind whose arguments are selected by the uniform `nxt`: with a branch per quad the compiler hoisted the next
+    // quad's loop-invariant row addresses out of the tile loop as nine 64-bit lane pointers and spilled)
+    auto prefetch_tile = [&](int j) {
+      const bool nxt = j >= ntiles;
+      const int jj = nxt ? 0 : j, nL = nxt ? x_nL : c_nL;
+      if (jj < nL) prefetch_local(((nxt ? x_lt0 : c_lt0) + jj) * AG_TW);
+      else prefetch_radius(jj - nL, nxt ? (cslot ^ 1) : cslot);
+    };
+    if (ntiles > 0 && !have_pf) {               // cold start
+      prefetch_tile(0);
+      set_xoff();
+      fetch_first_groups();
+      next_features();
+    }
+#pragma unroll
+    for (int i = 0; i < AG_CONV_NCH; ++i) acc[i] = 0.0f;
+    // One tile: group 0's coefficient blocks are requested first, then the per-row inputs of the wave's next tile and the last x
+    // group of this one; per group g: its MFMAs, the blocks of group g + 1, the sums of group g - 1 (sum += z x), the x values XD - 1
+    // groups ahead -- of this tile or, once all of its gathers are out, of the next one, whose features follow the last request.
+    // The last tile of a wave's last quad "prefetches" itself again (no branch, hence no join in front of the last sums at which
+    // every outstanding load would have to land).
+    auto tile = [&](int j, auto base) {
+      const bool has_next = (j + 1 < ntiles) || ntiles_next > 0;
+      if (AG_QUAD_WAHEAD) load_w(base, std::integral_constant<int, 0>{});
+      prefetch_tile(has_next ? j + 1 : j);
+      auto sums = [&](auto GG, const f32x4 (&z)[GRP]) {
+        constexpr int gg = decltype(GG)::value;
+#pragma unroll
+        for (int jj = 0; jj < GRP; ++jj) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[GRP * gg + jj] = fmaf(z[jj][r], xg[gg % XD][jj][r], acc[GRP * gg + jj]);
+          asm volatile("" : "+v"(acc[GRP * gg + jj]));
+        }
+      };
+      f32x4 z[2][GRP];
+      fetch_xg(std::integral_constant<int, XD - 1>{}, XD - 1);
+      if (!AG_QUAD_WAHEAD) load_w(base, std::integral_constant<int, 0>{});
+      mma_w(std::integral_constant<int, 0>{}, z[0]);
+      if (AG_QUAD_WAHEAD) load_w(base, std::integral_constant<int, 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      ag_static_for<1, NG>([&](auto G) {
+        constexpr int g = decltype(G)::value;
+        if (!AG_QUAD_WAHEAD) load_w(base, G);
+        mma_w(G, z[g & 1]);
+        if constexpr (g + 1 < NG) {
+          if (AG_QUAD_WAHEAD) load_w(base, std::integral_constant<int, g + 1>{});
+        }
+        sums(std::integral_constant<int, g - 1>{}, z[(g - 1) & 1]);
+        if constexpr (g + XD - 1 < NG) {
+          fetch_xg(std::integral_constant<int, (g - 1) % XD>{}, g + XD - 1);
+        } else {
+          if constexpr (g + XD - 1 == NG) set_xoff();
+          fetch_xg(std::integral_constant<int, (g - 1) % XD>{}, g + XD - 1 - NG);
+          if constexpr (g == NG - 1) next_features();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      sums(std::integral_constant<int, NG - 1>{}, z[(NG - 1) & 1]);
+      have_pf = has_next;
+    };
+    int j = 0;
+    for (; j < c_nL; ++j) {
+      const int slot = __builtin_amdgcn_readfirstlane(pf_slot);
+      if (slot >= a.lds_slots) tile(j, reinterpret_cast<const u32x4*>(a.poly_typed) + (size_t)slot * SET + lane);
+      else tile(j, wl_l + (size_t)(slot >= 0 ? 1 + slot : 0) * SET);
+    }
+    for (; j < ntiles; ++j) tile(j, wl_l);
+    // the quad is complete: lane (q, col) holds channel 16 ct + col of its quarter's target (zeros for a target without edges)
+    const int aoff = qi[cslot * 16 + 8 + q];
+    if (aoff >= 0) {
+      char* dp = reinterpret_cast<char*>(a.agg) + (uint32_t)(aoff + col * 4);
+#pragma unroll
+      for (int ct = 0; ct < AG_CONV_NCH; ++ct)
+#if AG_QUAD_STORE_NT
+        __builtin_nontemporal_store(a.unscale * acc[ct], reinterpret_cast<float*>(dp + 64 * ct));
+#else
+        *reinterpret_cast<float*>(dp + 64 * ct) = a.unscale * acc[ct];
+#endif
+    }
+    if (ntiles == 0) have_pf = false;
+    p = pn;
+    c_nL = x_nL, c_lt0 = x_lt0, c_nR = x_nR;
+    cslot ^= 1;
+  }
+#undef AG_RQ_DECL
+#undef AG_RQ_LOAD
+}
+
+template <int MODE, int NKT, int PLAN, bool FOUR, bool QUAD>
 int launch_cfconv_node_s(const NodeConvArgs& a, size_t smem, void* stream) {
   using Shape = NodeConvShape<NKT, FOUR>;
   constexpr int WAVES = Shape::WAVES;
   static std::atomic<uint64_t> attr_done{0};
-  auto kern = k_cfconv_node<MODE, NKT, WAVES, PLAN, Shape::GRP>;
+  auto kern = QUAD ? k_cfconv_quad<MODE, NKT, WAVES, PLAN, Shape::GRP> : k_cfconv_node<MODE, NKT, WAVES, PLAN, Shape::GRP>;
   if (!ag_allow_big_lds(attr_done, (size_t)160 * 1024, kern)) return AGDIFF_ERR_LAUNCH;
   int64_t wgs = (a.num_quads + WAVES - 1) / WAVES;        // persistent: one workgroup per CU, quads dealt in contiguous ranges
   if (wgs > 256) wgs = 256;
@@ -438,18 +719,20 @@ int launch_cfconv_node_s(const NodeConvArgs& a, size_t smem, void* stream) {
   return AGDIFF_OK;
 }
 template <int MODE, int NKT, int PLAN>
-int launch_cfconv_node_p(const NodeConvArgs& a, bool four, size_t smem, void* stream) {
+int launch_cfconv_node_p(const NodeConvArgs& a, bool four, bool quad, size_t smem, void* stream) {
   if constexpr (NKT == 1) {
-    if (four) return launch_cfconv_node_s<MODE, NKT, PLAN, true>(a, smem, stream);
+    if (four) return quad ? launch_cfconv_node_s<MODE, NKT, PLAN, true, true>(a, smem, stream)
+                          : launch_cfconv_node_s<MODE, NKT, PLAN, true, false>(a, smem, stream);
   }
-  return launch_cfconv_node_s<MODE, NKT, PLAN, false>(a, smem, stream);
+  return quad ? launch_cfconv_node_s<MODE, NKT, PLAN, false, true>(a, smem, stream)
+              : launch_cfconv_node_s<MODE, NKT, PLAN, false, false>(a, smem, stream);
 }
 template <int MODE, int NKT>
-int launch_cfconv_node_t(const NodeConvArgs& a, int plan, bool four, size_t smem, void* stream) {
+int launch_cfconv_node_t(const NodeConvArgs& a, int plan, bool four, bool quad, size_t smem, void* stream) {
   if constexpr (MODE != AG_F32) {
-    if (plan == 1) return launch_cfconv_node_p<MODE, NKT, 1>(a, four, smem, stream);
+    if (plan == 1) return launch_cfconv_node_p<MODE, NKT, 1>(a, four, quad, smem, stream);
   }
-  return launch_cfconv_node_p<MODE, NKT, 0>(a, four, smem, stream);
+  return launch_cfconv_node_p<MODE, NKT, 0>(a, four, quad, smem, stream);
 }
 }  // namespace
 
@@ -497,17 +780,20 @@ extern "C" int agdiff_cfconv_node(const agdiff_params_t* p, const agdiff_topo_t*
   a.qshift = topo->group_targets == 4 ? 0 : topo->group_targets == 2 ? 1 : 2;
   a.two_over_rc = 2.0f / p->cutoff;
   a.unscale = p->conv[k].filt_poly_unscale;
-  const size_t smem = (size_t)(1 + a.lds_slots) * set_bytes;
+  const size_t smem = (size_t)(1 + a.lds_slots) * set_bytes + 2048;       // (+ k_cfconv_quad's per-wave quad words)
   // shape: four waves per SIMD pay from two quads per wave of a full grid on (below, 12-wave workgroups spread the quads wider)
   const int64_t four_min = p->tune_cfconv_four_min_quads ? p->tune_cfconv_four_min_quads : 8192;
   const bool four = p->poly_kt == 1 && four_min >= 0 && a.num_quads >= four_min;
+  // radius rows in quad tiles (k_cfconv_quad) wherever the topology has quads
+  const bool quad = topo->group_targets == 4 && p->tune_cfconv_quad_tiles >= 0;
   ag_log_variant(ws, AGDIFF_VAR_CFCONV_NODE | (local ? AGDIFF_VAR_CFCONV_NODE_LOCAL : 0) |
-                         (a.lds_slots < a.num_slots ? AGDIFF_VAR_POLY_L2_SETS : 0) | (four ? AGDIFF_VAR_CFCONV_NODE_FOUR : 0));
+                         (a.lds_slots < a.num_slots ? AGDIFF_VAR_POLY_L2_SETS : 0) | (four ? AGDIFF_VAR_CFCONV_NODE_FOUR : 0) |
+                         (quad ? AGDIFF_VAR_CFCONV_NODE_QUAD : 0));
   const int plan = p->poly_plan;
   if (p->precision == AG_H3)
-    return p->poly_kt == 1 ? launch_cfconv_node_t<AG_H3, 1>(a, plan, four, smem, stream) : launch_cfconv_node_t<AG_H3, 2>(a, plan, four, smem, stream);
+    return p->poly_kt == 1 ? launch_cfconv_node_t<AG_H3, 1>(a, plan, four, quad, smem, stream) : launch_cfconv_node_t<AG_H3, 2>(a, plan, four, quad, smem, stream);
   if (p->precision == AG_BF3)
-    return p->poly_kt == 1 ? launch_cfconv_node_t<AG_BF3, 1>(a, plan, four, smem, stream) : launch_cfconv_node_t<AG_BF3, 2>(a, plan, four, smem, stream);
-  return p->poly_kt == 1 ? launch_cfconv_node_t<AG_F32, 1>(a, 0, four, smem, stream) : launch_cfconv_node_t<AG_F32, 2>(a, 0, four, smem, stream);
+    return p->poly_kt == 1 ? launch_cfconv_node_t<AG_BF3, 1>(a, plan, four, quad, smem, stream) : launch_cfconv_node_t<AG_BF3, 2>(a, plan, four, quad, smem, stream);
+  return p->poly_kt == 1 ? launch_cfconv_node_t<AG_F32, 1>(a, 0, four, quad, smem, stream) : launch_cfconv_node_t<AG_F32, 2>(a, 0, four, quad, smem, stream);
 }
 

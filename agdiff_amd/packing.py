@@ -712,7 +712,7 @@ class PackedParams:
         return not any(int(t) in self.poly_refused_types for t in types)
 
     TUNING = ("share_rows_min_nodes", "node_ldsw_min_tiles", "node_split_max_tiles", "serial_branches", "local_poly_off",
-              "attr_poly_off", "poly_lds_sets", "cfconv_four_min_quads")
+              "attr_poly_off", "poly_lds_sets", "cfconv_four_min_quads", "cfconv_quad_tiles")
 
     def set_tuning(self, **kw):
         """Kernel-variant thresholds (include/agdiff_hip.h: agdiff_params_t.tune_*; 0 = library default)."""

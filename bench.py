@@ -325,14 +325,21 @@ def live_edges(run):
 
 
 def tile_stats(run):
-    """16-row tiles one k_cfconv_node launch walks on the run's current graph: radius tiles (every target's rows padded to
-    whole tiles) and local quad tiles, live rows and executed rows."""
+    """16-row tiles one agdiff_cfconv_node launch walks on the run's current graph, live rows and executed rows.  Radius tiles:
+    on quads (topo.group_targets == 4, tune_cfconv_quad_tiles >= 0: k_cfconv_quad) max over a quad's targets of ceil(rows / 4) --
+    quarter k of a tile holds four rows of the quad's k-th target --, else every target's rows padded to whole tiles; local quad
+    tiles as the topology built them."""
     if not run._fused_front():
         return None
     cnt = run.ws.rad_cnt.to("cpu").numpy().astype(np.int64)
-    rt = int(((cnt + 15) // 16).sum())
+    quad = run.topo.group_targets == 4 and int(run.pk.struct.tune_cfconv_quad_tiles) >= 0
+    if quad:
+        qt = run.topo.quad_tgt.to("cpu").numpy().astype(np.int64).reshape(-1, 4)
+        rt = int(((np.where(qt >= 0, cnt[np.maximum(qt, 0)], 0) + 3) // 4).max(axis=1).sum())
+    else:
+        rt = int(((cnt + 15) // 16).sum())
     R, L, T = int(cnt.sum()), int(run.topo.L), int(run.topo.T)
-    return {"radius_tiles": rt, "local_tiles": T, "radius_rows_live": R, "local_rows_live": L}
+    return {"radius_tiles": rt, "local_tiles": T, "radius_rows_live": R, "local_rows_live": L, "radius_rows_in_quad_tiles": int(quad)}
 
 
 def load_pmc(precision, edges, kernels):

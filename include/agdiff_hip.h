@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 38
+#define AGDIFF_ABI_VERSION 39
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -194,7 +194,9 @@ typedef struct agdiff_params {
                                   kernel's second operand is [lo(phi_f), f < 16 | hi(phi_f), f < 16]: both cross terms of the
                                   low 16 terms in one K = 32 instruction.
                                   poly_kt 2: k-tile 0 three passes, k-tile 1 one (unit 1 of its blocks is not read). */
-  int32_t pad1;
+  int32_t tune_cfconv_quad_tiles;    /* [0] agdiff_cfconv_node on quads (topo->group_targets == 4): radius rows in quad tiles too -- quarter k
+                                        of a tile = four rows of the quad's k-th target, one set of sums per lane, no exchange between
+                                        the quarters (k_cfconv_quad); -1: every target its own radius tiles (k_cfconv_node) */
   /* Kernel-variant thresholds: batch-size crossovers measured on MI355X.  0 selects the library default in
    * brackets; tests set them to reach every variant on small fixtures, agdiff_ws_t.variant_log reports what ran. */
   int64_t poly_slot_mask[2]; /* bit t of the 128-bit mask: edge type t has a slot in poly_type_slot */
@@ -229,6 +231,7 @@ typedef struct agdiff_params {
 #define AGDIFF_VAR_POLY_L2_SETS 4096    /* agdiff_cfconv_node: some local types' coefficient sets did not fit in LDS (read from L2) */
 #define AGDIFF_VAR_FUSED_FRONT 8192     /* agdiff_sampler_front: update of step t + radius graph of step t + 1 in one launch */
 #define AGDIFF_VAR_CFCONV_NODE_FOUR 16384 /* agdiff_cfconv_node ran its four-waves-per-SIMD shape (tune_cfconv_four_min_quads) */
+#define AGDIFF_VAR_CFCONV_NODE_QUAD 32768 /* agdiff_cfconv_node walked the radius rows in quad tiles (tune_cfconv_quad_tiles) */
 
 /* ---- static topology of one packed batch (host builds it once per batch) ---------------------
  * Graphs are contiguous node ranges (PyG Batch, utils/misc.py:88-90).  "Local" edges are the

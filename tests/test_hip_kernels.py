@@ -27,7 +27,7 @@ pytestmark = pytest.mark.gpu
 PRECISIONS = ["f32", "bf16x3", "f16x3"]
 
 
-def _setup(case, precision):
+def _setup(case, precision, group_targets=None, tuning=None):
     from agdiff_amd import _lib, get_model
     from oracle import agdiff_oracle as O
     g = load_golden(case)
@@ -35,6 +35,8 @@ def _setup(case, precision):
     sd = O.synth_state_dict_for(cfg)
     m = get_model(cfg)
     m.precision = precision
+    m.group_targets = group_targets
+    m.tuning.update(tuning or {})
     m.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
     m = m.to("cuda:0").eval()
     lib = _lib.load()
@@ -156,17 +158,23 @@ def test_node_stage_block0_vs_reference_modules(case, precision):
     check_close("node_stage1 xs[%s]" % case, ws.xs.view(-1, 192), xs1.float(), precision)
 
 
+@pytest.mark.parametrize("layout", ["by_batch_size", "quad_tiles", "quads_per_target"])
 @pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("case", STAGE_CASES[:2])
-def test_cfconv_node_block0_vs_reference_modules(case, precision):
-    """The CFConv kernel bench.py times (k_cfconv_node: polynomial filters, radius rows by target + local quad tiles)
-    against the reference's CFConv modules of block 0 -- not only against the MLP kernel (tests/test_hip_poly.py)."""
+def test_cfconv_node_block0_vs_reference_modules(case, precision, layout):
+    """The CFConv kernels bench.py times (polynomial filters; k_cfconv_quad: radius rows and local rows in quad tiles, what every
+    batch above 6,144 atoms runs -- forced onto the small fixture by group_targets = 4; k_cfconv_node: every target its own
+    radius tiles + local quad tiles, what small batches and tune_cfconv_quad_tiles = -1 run) against the reference's CFConv
+    modules of block 0 -- not only against the MLP kernel (tests/test_hip_poly.py)."""
     from agdiff_amd import _lib
-    g, cfg, sd, m, lib, topo, ws, (P, Tp, Wp, st) = _setup(case, precision)
+    gt = None if layout == "by_batch_size" else 4
+    g, cfg, sd, m, lib, topo, ws, (P, Tp, Wp, st) = _setup(case, precision, group_targets=gt,
+                                                             tuning={"cfconv_quad_tiles": -1} if layout == "quads_per_target" else None)
     if "cfconv1_b0" not in g:
         pytest.skip("fixture without per-module outputs")
     pk = m.packed()
     assert pk.poly_kt >= 1 and lib.agdiff_local_poly_enabled(P, Tp, Wp) == 1
+    ws.variant_log.zero_()
     blk = "encoder_global.interactions.0"
     pos = t(g["pos"]).cuda().contiguous()
     assert lib.agdiff_graph_build_scaled(P, Tp, Wp, _lib.ptr(pos), ctypes.c_float(cfg.cutoff), 0, st) == 0
@@ -176,6 +184,7 @@ def test_cfconv_node_block0_vs_reference_modules(case, precision):
     ws.agg.fill_(float("nan"))
     assert lib.agdiff_cfconv_node(P, Tp, Wp, 0, st) == 0
     torch.cuda.synchronize()
+    assert bool(int(ws.variant_log.item()) & _lib.DEFINES["AGDIFF_VAR_CFCONV_NODE_QUAD"]) == (layout == "quad_tiles")
     agg = ws.agg.view(-1, 192)[: topo.N].cpu().double()
     xs_ref = _xs_ref(sd, blk, t(g["schnet_h0"]).double())
     agg_ref = _agg_ref(sd, cfg, blk, g, xs_ref)

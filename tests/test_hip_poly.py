@@ -214,25 +214,36 @@ def test_cfconv_node_shapes_agree_bitwise(kind, mols, copies, mode, precision, p
     channel tiles, and -- from tune_cfconv_four_min_quads quads on -- 16-wave workgroups at 128 VGPRs with groups of two (two
     k-tiles keep the first shape).  A target's sums are taken by ONE wave in the same tile and row
     order in both, so the aggregates, and everything downstream, must be identical bit for bit; variant_log says which shape
-    ran."""
+    ran.  The same holds inside each of the two row layouts on quads (radius rows in quad tiles: k_cfconv_quad; every target its
+    own radius tiles: k_cfconv_node); BETWEEN the layouts the order of a target's additions differs, so they agree to rounding."""
     from agdiff_amd import _lib, drugs_model_config, qm9_model_config, synth
     cfg = (drugs_model_config if kind == "drugs" else qm9_model_config)(num_diffusion_timesteps=20)
     b = synth.make_packed_batch(kind, mols, copies, seed=23)
     at, bi, bt, ba = [t(b[k]).cuda() for k in ("atom_type", "bond_index", "bond_type", "batch")]
     pos = (torch.randn(at.shape[0], 3, generator=torch.Generator().manual_seed(3)) * 1.5).cuda()
-    outs = {}
-    for four in (1, -1):
-        m = _model(cfg, mode, precision=precision)
-        m.poly_passes = passes
-        m.tuning["cfconv_four_min_quads"] = four
-        out = m(at, pos, bi, bt, ba, None, return_edges=True, extend_order=False)
-        ws, var = m._batch_cache[2], _variants(m._batch_cache[2])
-        has_four = mode == "auto"                    # (two k-tiles: one shape only; the tuning field must not matter)
-        assert bool(var & _lib.DEFINES["AGDIFF_VAR_CFCONV_NODE_FOUR"]) == (four == 1 and has_four), (four, var)
-        assert var & _lib.DEFINES["AGDIFF_VAR_CFCONV_NODE"]
-        outs[four] = (out[0].clone(), out[1].clone(), ws.h.clone(), ws.agg.clone())
-    for a_, b_ in zip(outs[1], outs[-1]):
-        assert torch.equal(a_, b_)
+    by_layout = {}
+    for group, quad in ((None, 0), (4, 0), (4, -1)):
+        outs = {}
+        for four in (1, -1):
+            m = _model(cfg, mode, precision=precision)
+            m.poly_passes = passes
+            m.group_targets = group
+            m.tuning["cfconv_four_min_quads"] = four
+            m.tuning["cfconv_quad_tiles"] = quad
+            out = m(at, pos, bi, bt, ba, None, return_edges=True, extend_order=False)
+            ws, var = m._batch_cache[2], _variants(m._batch_cache[2])
+            has_four = mode == "auto"                    # (two k-tiles: one shape only; the tuning field must not matter)
+            assert bool(var & _lib.DEFINES["AGDIFF_VAR_CFCONV_NODE_FOUR"]) == (four == 1 and has_four), (four, var)
+            assert var & _lib.DEFINES["AGDIFF_VAR_CFCONV_NODE"]
+            assert bool(var & _lib.DEFINES["AGDIFF_VAR_CFCONV_NODE_QUAD"]) == (group == 4 and quad == 0), (group, quad, var)
+            outs[four] = (out[0].clone(), out[1].clone(), ws.h.clone(), ws.agg.clone())
+        for a_, b_ in zip(outs[1], outs[-1]):
+            assert torch.equal(a_, b_)
+        by_layout[(group, quad)] = outs[1]
+    for name, a_, b_ in zip(("edge_inv_global", "edge_inv_local", "h", "agg"), by_layout[(4, 0)], by_layout[(4, -1)]):
+        assert torch.isfinite(a_).all()
+        err = float((a_ - b_).abs().max() / b_.abs().max().clamp_min(1e-30))
+        assert err <= 2e-6, (name, err)
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x3"])
