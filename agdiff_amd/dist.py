@@ -126,7 +126,7 @@ def sample_batch_sharded(model, packed, device, sampler_kwargs, save_traj=False,
     Returns (pos [N,3] cpu, traj or None, ok [num molecules]) like driver.sample_batch; pos and ok are identical on all
     ranks, the trajectories [steps, N, 3] are gathered to rank 0 only (None elsewhere).  A rank that raises while the
     others sample keeps issuing its collectives, then every rank raises."""
-    from .driver import subset_batch
+    from .driver import SAMPLE_STATS, _arithmetic, subset_batch
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)
     spans = packed["spans"]
@@ -134,7 +134,7 @@ def sample_batch_sharded(model, packed, device, sampler_kwargs, save_traj=False,
     pos_out = torch.full((N, 3), float("nan"))
     traj_out = None
     ok = np.zeros(n_mol, dtype=bool)
-    todo, clip_local = list(range(n_mol)), None
+    todo, clip_local, wide = list(range(n_mol)), None, False
     # collectives per attempt = steps LangevinRun will take (epsnet.py: len(step_indices) if given, else n_steps): a rank
     # without graphs must issue exactly as many gathers as the ranks that sample
     si = sampler_kwargs.get("step_indices")
@@ -145,19 +145,21 @@ def sample_batch_sharded(model, packed, device, sampler_kwargs, save_traj=False,
         first = attempt == 0
         gather = StepAllGather(hi - lo, device, group)
         empty, zero = torch.zeros(0, 3, device=device), torch.zeros(1, dtype=torch.int32, device=device)
-        err, traj, bad_local = None, None, np.zeros(0, dtype=bool)
+        err, traj, bad_local, range_local = None, None, np.zeros(0, dtype=bool), 0
         if mine is not None:
             try:
                 p0 = pos_init[lo:hi].to(device) if (first and pos_init is not None) else torch.randn(hi - lo, 3).to(device)
-                run = model.begin_sampling(T(mine["atom_type"]), p0, T(mine["bond_index"]), T(mine["bond_type"]),
-                                           T(mine["batch"]), mine["num_graphs"], False, clip_local=clip_local,
-                                           save_traj=save_traj, raise_on_nan=False,
-                                           noise=(noise[:, lo:hi] if (first and noise is not None) else None),
-                                           **sampler_kwargs)
-                run.on_step = lambda k, i, pos: gather(k, i, pos, run.ws.nan_flag)
-                run.advance(run.remaining())
-                _, traj = run.finish()
+                with _arithmetic(model, wide):
+                    run = model.begin_sampling(T(mine["atom_type"]), p0, T(mine["bond_index"]), T(mine["bond_type"]),
+                                               T(mine["batch"]), mine["num_graphs"], False, clip_local=clip_local,
+                                               save_traj=save_traj, raise_on_nan=False,
+                                               noise=(noise[:, lo:hi] if (first and noise is not None) else None),
+                                               **sampler_kwargs)
+                    run.on_step = lambda k, i, pos: gather(k, i, pos, run.ws.nan_flag)
+                    run.advance(run.remaining())
+                    _, traj = run.finish()
                 bad_local = run.nan_graphs().numpy()
+                range_local = len(getattr(run, "range_graphs", ()))
             except Exception as e:            # (AgdiffLimitError, out of memory, ...): the other ranks are inside the
                 err = e                       # per-step collectives -- keep this rank's count whole, fail together below
         # a rank without graphs (more ranks than graphs) or one that failed takes part in the collectives only
@@ -174,8 +176,10 @@ def sample_batch_sharded(model, packed, device, sampler_kwargs, save_traj=False,
         parts, _ = gather.result()
         pos = torch.cat([p.cpu() for p in parts], dim=0)            # rank order == graph order
         bad_all = [None] * world
-        dist.all_gather_object(bad_all, bad_local.tolist(), group=group)
-        bad_graph = np.array([b for part in bad_all for b in part], dtype=bool)
+        dist.all_gather_object(bad_all, (bad_local.tolist(), range_local), group=group)
+        bad_graph = np.array([b for part, _ in bad_all for b in part], dtype=bool)
+        out_of_range = sum(r for _, r in bad_all)              # conformers that left the split-fp16 range, on any rank
+        SAMPLE_STATS["range_trips"] += out_of_range
         if save_traj:                          # [steps, N_r, 3] per rank: to rank 0 only (it writes them)
             trajs = [None] * world if rank == 0 else None
             dist.gather_object(None if traj is None else torch.stack(traj).numpy(), trajs, dst=0, group=group)
@@ -198,6 +202,12 @@ def sample_batch_sharded(model, packed, device, sampler_kwargs, save_traj=False,
         if not todo:
             break
         clip_local = 20
-        if attempt + 1 < max_retry and rank == 0:
-            log("NaN in %d of %d molecules: retrying those with local clipping." % (len(todo), len(sub["spans"])))
+        if attempt + 1 < max_retry:
+            if out_of_range and not wide:                      # (the same decision on every rank: the counts were gathered)
+                wide = True
+                SAMPLE_STATS["bf16x3_retries"] += 1
+            if rank == 0:
+                log(("%d conformers left the split-fp16 range: retrying their molecules (%d of %d) in split-bf16 with local clipping."
+                     % (out_of_range, len(todo), len(sub["spans"]))) if (out_of_range and wide) else
+                    ("NaN in %d of %d molecules: retrying those with local clipping." % (len(todo), len(sub["spans"]))))
     return pos_out, traj_out, ok

@@ -131,18 +131,21 @@ def sample_batch(model, packed, device, sampler_kwargs, save_traj=False, max_ret
     ok = np.zeros(n_mol, dtype=bool)
     todo = list(range(n_mol))                      # molecule slots of `packed` still to be sampled
     clip_local = None
+    wide = False                                   # retry in split-bf16: a molecule left the split-fp16 range (epsnet.check_nan)
     for attempt in range(max_retry):
         sub = packed if len(todo) == n_mol else subset_batch(packed, todo)
         at, bi, bt, ba = T(sub["atom_type"]), T(sub["bond_index"]), T(sub["bond_type"]), T(sub["batch"])
         first = attempt == 0
         p0 = pos_init.to(device) if (first and pos_init is not None) else torch.randn(at.shape[0], 3).to(device)
-        run = model.begin_sampling(at, p0, bi, bt, ba, sub["num_graphs"], False, clip_local=clip_local,
-                                   save_traj=save_traj, raise_on_nan=False,
-                                   noise=(noise if first else None), **sampler_kwargs)
-        run.advance(run.remaining())
-        pos, traj = run.finish()
+        with _arithmetic(model, wide):
+            run = model.begin_sampling(at, p0, bi, bt, ba, sub["num_graphs"], False, clip_local=clip_local,
+                                       save_traj=save_traj, raise_on_nan=False,
+                                       noise=(noise if first else None), **sampler_kwargs)
+            run.advance(run.remaining())
+            pos, traj = run.finish()
         pos = pos.cpu()
         bad_graph = run.nan_graphs().numpy()
+        out_of_range = sorted(getattr(run, "range_graphs", ()))
         if save_traj:
             traj = torch.stack(traj)
             if traj_out is None:
@@ -159,12 +162,32 @@ def sample_batch(model, packed, device, sampler_kwargs, save_traj=False, max_ret
                     traj_out[:, off:off + n * g] = traj[:, off_s:off_s + n * g]
             g_off += g
         todo = failed
+        if out_of_range:
+            SAMPLE_STATS["range_trips"] += len(out_of_range)
         if not todo:
             break
         clip_local = 20
         if attempt + 1 < max_retry:
-            log("NaN in %d of %d molecules: retrying those with local clipping." % (len(todo), len(sub["spans"])))
+            if out_of_range and not wide:
+                wide = True
+                SAMPLE_STATS["bf16x3_retries"] += 1
+                log("%d conformers left the split-fp16 range: retrying their molecules (%d of %d) in split-bf16 with local clipping."
+                    % (len(out_of_range), len(todo), len(sub["spans"])))
+            else:
+                log("NaN in %d of %d molecules: retrying those with local clipping." % (len(todo), len(sub["spans"])))
     return pos_out, traj_out, ok
+
+
+# what sample_batch / sample_batch_sharded met since the process started (run_job logs it with the job's summary)
+SAMPLE_STATS = {"range_trips": 0, "bf16x3_retries": 0}
+
+
+def _arithmetic(model, wide):
+    """`wide`: the model in split-bf16 for both branches (fp32's exponent range) for the duration of one attempt."""
+    import contextlib
+    if wide and hasattr(model, "arithmetic"):
+        return model.arithmetic("bf16x3", "bf16x3")
+    return contextlib.nullcontext(model)
 
 
 def subset_batch(packed, slots):
@@ -271,6 +294,9 @@ def run_job(model, mols, out_dir, confs_of, max_atoms, sampler_kwargs, device, s
                                                                                int(ok.sum()), len(bmols), packed["num_graphs"]))
     if world > 1:
         dist.barrier()                       # every rank's batch files are on disk
+    if SAMPLE_STATS["range_trips"]:
+        log("rank %d: %d conformers left the split-fp16 range and were re-sampled in split-bf16 (%d batch retries)"
+            % (rank, SAMPLE_STATS["range_trips"], SAMPLE_STATS["bf16x3_retries"]))
     return merge_outputs(out_dir) if rank == 0 else None
 
 

@@ -17,7 +17,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from .packing import PackedParams
+from .packing import SPLIT_FP16_MAX_ERR, PackedParams
 from .topology import BatchTopology, Workspace
 
 H_FIXED = 128
@@ -250,14 +250,36 @@ class DualEncoderEpsNetwork(nn.Module):
                 getattr(self, "poly_passes", "auto")) + tuple(int(p._version) for p in self.state_dict(keep_vars=True).values())
 
     def packed(self):
-        """Packed device weights, rebuilt when any parameter / buffer changed (load_state_dict, .to)."""
+        """Packed device weights, rebuilt when any parameter / buffer changed (load_state_dict, .to).  A branch asked to run
+        in split-fp16 whose matrices that mode cannot hold -- packing.split_fp16_error above SPLIT_FP16_MAX_ERR (weights far
+        below O(1): lo parts in fp16's subnormals) or a value beyond 65504 -- is packed in split-bf16 instead (fp32's exponent
+        range, same speed, ~2^-16 per product), with a warning; `effective_precision` / `effective_precision_local` say what
+        runs.  (The ReLU chains -- both heads, the GIN MLPs -- are normalised by exact powers of two first, packing.pow2_norm.)"""
         key = self._weights_key()
         if self._packed is None or self._packed_key != key:
             sd = {k: v for k, v in self.state_dict().items()}
-            self._packed = PackedParams(sd, self.config, self._device(), self.precision, self.radius_poly,
-                                        refuse_types=self.poly_refuse_types, precision_local=getattr(self, "precision_local", None),
-                                        poly_passes=getattr(self, "poly_passes", "auto"))
-            self._packed_key = key
+            prec, prec_l = self.precision, getattr(self, "precision_local", None)
+            for _ in range(3):
+                pk = PackedParams(sd, self.config, self._device(), prec, self.radius_poly,
+                                  refuse_types=self.poly_refuse_types, precision_local=prec_l,
+                                  poly_passes=getattr(self, "poly_passes", "auto"))
+                rep, again = pk.split_fp16_report, False
+                for branch in ("global", "local"):
+                    r = rep[branch]
+                    if r["err"] > SPLIT_FP16_MAX_ERR or r["clipped"]:
+                        import warnings
+                        warnings.warn("agdiff_amd: the %s branch's weights do not fit split-fp16 (%s: normwise error %.2g%s); "
+                                      "that branch runs in split-bf16" % (branch, r["worst"], r["err"], ", clipped" if r["clipped"] else ""))
+                        if branch == "global":
+                            prec, prec_l = "bf16x3", (prec_l or pk.precision_local)
+                        else:
+                            prec_l = "bf16x3"
+                        again = True
+                if not again:
+                    break
+            self._packed, self._packed_key = pk, key
+            self.effective_precision, self.effective_precision_local = pk.precision, pk.precision_local
+        # (keys of self.tuning that are not library thresholds are host-side choices: "group_radius_column")
         self._packed.set_tuning(**{k: self.tuning.get(k, 0) for k in PackedParams.TUNING})
         return self._packed
 
@@ -269,25 +291,56 @@ class DualEncoderEpsNetwork(nn.Module):
     RANGE_LIMITS = (("h", 255.0), ("hl", 255.0), ("agg", 60000.0), ("xs", 60000.0))
 
     def _uses_split_fp16(self):
-        return self.precision == "f16x3" or (self.precision == "bf16x3" and getattr(self, "precision_local", None) in (None, "f16x3"))
+        p = self._packed
+        prec, prec_l = (p.precision, p.precision_local) if p is not None else (self.precision, getattr(self, "precision_local", None) or "f16x3")
+        return prec == "f16x3" or (prec == "bf16x3" and prec_l == "f16x3")
 
-    def check_range(self, ws):
-        """Raise AgdiffRangeError when a watched node tensor of workspace `ws` has left the split-fp16 range (one small
-        device reduction and one host synchronisation: called where the NaN flag is polled)."""
+    def range_report(self, ws, batch=None):
+        """(name, max |x|, limit, graphs) of the first watched node tensor of workspace `ws` that has left the split-fp16 range,
+        or None.  NaNs are masked (they are the NaN flag's business, dualenc.py:539-541: a quarantined molecule must not blind
+        the watch for the others); `graphs` = the graphs (ids of `batch` [N]) that own the offending rows, or None without
+        `batch`.  One small device reduction per tensor and one host synchronisation: called where the NaN flag is polled."""
         if not self._uses_split_fp16():
-            return
-        names = [n for n, _ in self.RANGE_LIMITS if self.precision == "f16x3" or n == "hl"]
-        mm = [torch.aminmax(getattr(ws, n)) for n in names]           # (one pass per tensor, no |x| temporary)
-        mx = torch.stack([torch.maximum(a.max, -a.min) for a in mm]).cpu().tolist()
+            return None
+        glob = (self._packed.precision if self._packed is not None else self.precision) == "f16x3"
+        names = [n for n, _ in self.RANGE_LIMITS if glob or n == "hl"]
+        lims = dict(self.RANGE_LIMITS)
+        mx = torch.stack([torch.nan_to_num(getattr(ws, n), nan=0.0).abs().max() for n in names]).cpu().tolist()
         for n, v in zip(names, mx):
-            lim = dict(self.RANGE_LIMITS)[n]
-            if not (v <= lim):          # (also a NaN)
-                if v != v:
-                    continue            # NaNs are the NaN flag's business (dualenc.py:539-541)
-                raise _lib.AgdiffRangeError(
-                    "max |%s| = %.3g exceeds %.0f: outside the range in which the split-fp16 arithmetic mode is valid (fp16 "
-                    "operands saturate at 65504; the pair heads multiply two node features) -- set model.precision = 'bf16x3'"
-                    % (n, v, lim))
+            if not (v <= lims[n]):
+                graphs = None
+                if batch is not None:
+                    x = torch.nan_to_num(getattr(ws, n), nan=0.0).view(batch.shape[0], -1)
+                    graphs = torch.unique(batch[(x.abs() > lims[n]).any(dim=1)]).cpu().tolist()
+                return n, v, lims[n], graphs
+        return None
+
+    def check_range(self, ws, batch=None):
+        """Raise AgdiffRangeError (with .tensor, .value, .limit, .graphs) when range_report finds a violation."""
+        rep = self.range_report(ws, batch)
+        if rep is not None:
+            n, v, lim, graphs = rep
+            e = _lib.AgdiffRangeError(
+                "max |%s| = %.3g exceeds %.0f: outside the range in which the split-fp16 arithmetic mode is valid (fp16 "
+                "operands saturate at 65504; the pair heads multiply two node features) -- set model.precision = 'bf16x3' "
+                "(agdiff_amd.driver re-samples the affected molecules that way by itself)" % (n, v, lim))
+            e.tensor, e.value, e.limit, e.graphs = n, v, lim, graphs
+            raise e
+
+    def arithmetic(self, precision=None, precision_local=None):
+        """Context manager: run with another arithmetic mode (the driver's bf16x3 retry of molecules that left the split-fp16
+        range); the packed weights of the mode left behind are rebuilt on the next call."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            old = (self.precision, self.precision_local)
+            self.precision, self.precision_local = precision or old[0], precision_local if precision_local is not None else old[1]
+            try:
+                yield self
+            finally:
+                self.precision, self.precision_local = old
+        return cm()
 
     def _renorm_embedding(self, atom_type):
         # nn.Embedding(max_norm=10) renormalises looked-up rows in place on every forward, also in
@@ -309,7 +362,8 @@ class DualEncoderEpsNetwork(nn.Module):
         key = None
         topo = BatchTopology(atom_type, bond_index, bond_type, batch, num_graphs=num_graphs,
                              extend_order=extend_order, order=self.config.edge_order, device=self._device(),
-                             group_targets=getattr(self, "group_targets", None))
+                             group_targets=getattr(self, "group_targets", None),
+                             radius_column=bool(self.tuning.get("group_radius_column", 1)))
         ws = Workspace(topo)
         if self._packed is not None and topo.L:
             self._packed.ensure_local_types(topo.local_types)     # filter polynomials for this batch's local edge types
@@ -534,6 +588,7 @@ class LangevinRun:
             raise ValueError("noise_mode must be 'chunked' or 'per_step'")
         self.noise_mode = noise_mode
         self.k = 0
+        self.range_graphs = set()              # graphs taken out of the run because they left the split-fp16 range (check_nan)
         self.ws.nan_flag.zero_()
         self._quarantine_non_finite_input()
         self.pos_p = _lib.ptr(self.pos)
@@ -640,13 +695,13 @@ class LangevinRun:
             keep = [self._fill_args(a, k, dev, N)[0]]
             a.use_global = 1 if self._sched[k][3] else 0
             self.k += 1
-            if self.raise_on_nan and self.k % self.nan_every == 0 and self.k < end:
+            if self.k % self.nan_every == 0 and self.k < end:
                 self.check_nan()
         if end > first:     # the chunk's last update
             _lib.check(lib.agdiff_sampler_front(P, T, W, ctypes.byref(a), 1, cutoff, stream), "agdiff_sampler_front")
             if self.on_step is not None:
                 self.on_step(end - 1, self.steps[end - 1], self.pos)
-            if self.raise_on_nan and (self.k % self.nan_every == 0 or self.k == len(self.steps)):
+            if self.k % self.nan_every == 0 or self.k == len(self.steps):
                 self.check_nan()
         del keep
 
@@ -683,19 +738,38 @@ class LangevinRun:
                 self.k += 1
                 if self.on_step is not None:
                     self.on_step(k, i, self.pos)
-                if self.raise_on_nan and (self.k % self.nan_every == 0 or self.k == len(self.steps)):
+                if self.k % self.nan_every == 0 or self.k == len(self.steps):
                     self.check_nan()
 
     def check_nan(self):
-        """dualenc.py:539-541.  ws.nan_flag[0] is set by the update kernel as soon as any position is NaN."""
+        """dualenc.py:539-541.  ws.nan_flag[0] is set by the update kernel as soon as any position is NaN.  Polled every
+        nan_check_every steps in BOTH modes, together with the split-fp16 range watch (model.range_report).  raise_on_nan
+        (the reference's behaviour, dualenc.py:531-533): a NaN raises FloatingPointError and a range violation AgdiffRangeError
+        for the whole call.  Otherwise (agdiff_amd.driver: per-molecule retry): the graphs that own out-of-range rows are
+        taken out of the run like diverged ones -- their positions are set to NaN, which the next update quarantines and flags
+        per graph (nan_graphs) -- and recorded in `range_graphs`, so that the driver re-samples exactly those molecules in
+        split-bf16 (fp32's range) while the others run on."""
         if self.raise_on_nan and int(self.ws.nan_flag[0].item()) != 0:
             print("NaN detected. Please restart.")
             raise FloatingPointError()
-        self.model.check_range(self.ws)
+        if self.raise_on_nan:
+            self.model.check_range(self.ws, self.topo.batch64)
+            return
+        rep = self.model.range_report(self.ws, self.topo.batch64)
+        if rep is not None:
+            graphs = [g for g in rep[3] if g not in self.range_graphs]
+            self.range_graphs.update(graphs)
+            if graphs and self.k < len(self.steps):
+                rows = torch.isin(self.topo.batch64, torch.as_tensor(graphs, device=self.topo.batch64.device))
+                self.pos[rows] = float("nan")
 
     def nan_graphs(self):
-        """Bool tensor [G] (host): graphs in which a position became NaN so far (ws.nan_flag[1 + g])."""
-        return self.ws.nan_flag[1:1 + self.topo.G].cpu() != 0
+        """Bool tensor [G] (host): graphs in which a position became NaN so far (ws.nan_flag[1 + g]) or that left the
+        split-fp16 range (range_graphs: also when that showed at the very last poll, after the last update)."""
+        bad = self.ws.nan_flag[1:1 + self.topo.G].cpu() != 0
+        if self.range_graphs:
+            bad[torch.as_tensor(sorted(self.range_graphs), dtype=torch.long)] = True
+        return bad
 
     def finish(self):
         """(pos on device, pos_traj list of CPU tensors) as dualenc.py:547 returns them."""

@@ -104,6 +104,31 @@ def unpack_blocks(flat, out, inn, kouter=False, mode=0):
     return W[:out, :inn]
 
 
+def pow2_norm(W):
+    """The power of two n with max |n W| in (0.5, 1] (1 for an all-zero matrix): exact to apply and to undo."""
+    m = float(np.abs(np.asarray(W, dtype=np.float64)).max())
+    return 1.0 if not (m > 0.0) or not np.isfinite(m) else 2.0 ** -int(np.ceil(np.log2(m)))
+
+
+def split_fp16_error(W):
+    """(normwise error of the split-fp16 image of W: max |w - (hi + lo)| / max |w|, whether a value was clipped at fp16's range):
+    what packing a matrix in mode 2 costs.  11 + 11 mantissa bits give 2^-22 while the lo parts are normal fp16 numbers; a lo part
+    below 6e-5 has fewer bits and one below 6e-8 is lost, an ABSOLUTE floor -- so the figure grows as max |w| falls below ~0.1."""
+    W = np.asarray(W, dtype=np.float64)
+    m = float(np.abs(W).max()) if W.size else 0.0
+    if not (m > 0.0):
+        return 0.0, False
+    v = np.clip(W, -65504.0, 65504.0)
+    hi = v.astype(np.float32).astype(np.float16)
+    lo = (v - hi.astype(np.float64)).astype(np.float32).astype(np.float16)
+    return float(np.abs(W - hi.astype(np.float64) - lo.astype(np.float64)).max() / m), bool(m > 65504.0)
+
+
+# split-fp16 is taken for a branch only while every matrix it packs keeps this normwise accuracy (2^-19: an eighth of what the
+# mode gives O(1) weights, ~10 x better than split-bf16's 2^-16) and nothing is clipped; otherwise the branch runs in split-bf16
+SPLIT_FP16_MAX_ERR = 2.0 ** -19
+
+
 def fold_bn(W, b, sd, p, eps=1e-5):
     """Linear(W, b) followed by eval BatchNorm1d `p` -> one Linear."""
     s = _np(sd, p + ".weight") / np.sqrt(_np(sd, p + ".running_var") + eps)
@@ -414,12 +439,27 @@ class PackedParams:
         self.precision_local = precision_local
         self._mode_local = lmode = LOCAL_PRECISIONS[precision_local]
         _pack = globals()["pack_blocks"]
+        # what split-fp16 costs the matrices of each branch (split_fp16_error): worst normwise error, clipping, which matrix
+        self.split_fp16_report = {"global": {"err": 0.0, "clipped": False, "worst": None, "matrices": 0},
+                                  "local": {"err": 0.0, "clipped": False, "worst": None, "matrices": 0}}
+
+        def note(branch, W):
+            e, c = split_fp16_error(W)
+            r = self.split_fp16_report[branch]
+            r["matrices"] += 1
+            r["clipped"] = r["clipped"] or c
+            if e > r["err"]:
+                r["err"], r["worst"] = e, "matrix #%d %s, max |w| = %.3g" % (r["matrices"], tuple(np.shape(W)), float(np.abs(W).max()))
 
         def pack_local(W, kouter=False):
+            if lmode == 2:
+                note("local", W)
             return _pack(W, kouter=kouter, mode=lmode)
         self._pack_local = pack_local
 
         def pack_blocks(W, kouter=False):      # every matrix of this model is packed in the chosen mode
+            if mode == 2:
+                note("global", W)
             return _pack(W, kouter=kouter, mode=mode)
 
         if cfg.hidden_dim != H:
@@ -521,11 +561,17 @@ class PackedParams:
         for k in range(cfg.num_convs_local):
             p = "encoder_local.convs.%d" % k
             n = "gin%d." % k
-            arrays[n + "w1_pk"] = self._pack_local(_np(sd, p + ".nn.layers.0.weight"))
-            arrays[n + "b1"] = _np(sd, p + ".nn.layers.0.bias")
+            W1, b1 = _np(sd, p + ".nn.layers.0.weight"), _np(sd, p + ".nn.layers.0.bias")
             W, b = fold_bn(_np(sd, p + ".nn.layers.1.weight"), _np(sd, p + ".nn.layers.1.bias"), sd,
                            "encoder_local.batch_norms.%d" % k)
-            arrays[n + "w2_pk"] = self._pack_local(W)
+            # relu(n x) = n relu(x) for n > 0: the hidden layer may carry any power of two n (W1, b1 times n; W2 by n), exact in
+            # fp32 and free for the kernel.  n balances the two matrices' magnitudes, so that neither's split-fp16 lo parts sit in
+            # fp16's subnormals (split_fp16_error) and the hidden activations stay in fp16's range when a checkpoint's layers
+            # are far from O(1); the layer's output keeps its scale (it is added to h, gin.py:143-147).
+            nb = 2.0 ** int(np.round(0.5 * (np.log2(pow2_norm(W1)) - np.log2(pow2_norm(W))))) if self._mode_local != 0 else 1.0
+            arrays[n + "w1_pk"] = self._pack_local(W1.astype(np.float64) * nb)
+            arrays[n + "b1"] = b1.astype(np.float64) * nb
+            arrays[n + "w2_pk"] = self._pack_local(W.astype(np.float64) / nb)
             arrays[n + "b2"] = b
             scalars[n + "one_plus_eps"] = 1.0 + float(_np(sd, p + ".eps")[0])
 
@@ -533,17 +579,27 @@ class PackedParams:
         for name, p in (("head_global", "grad_global_dist_mlp"), ("head_local", "grad_local_dist_mlp")):
             n = name + "."
             pb = self._pack_local if name == "head_local" else pack_blocks
-            arrays[n + "w1_pk"] = pb(_np(sd, p + ".layers.0.weight"), kouter=True)
-            arrays[n + "b1"] = _np(sd, p + ".layers.0.bias")
-            arrays[n + "w2_pk"] = pb(_np(sd, p + ".layers.1.weight"))
-            arrays[n + "b2"] = _np(sd, p + ".layers.1.bias")
-            arrays[n + "w3"] = _np(sd, p + ".layers.2.weight")[0]
+            W0, W1 = _np(sd, p + ".layers.0.weight").astype(np.float64), _np(sd, p + ".layers.1.weight").astype(np.float64)
+            # The heads are ReLU chains (common.py:62-66 with mlp_act = relu) ending in an fp32 dot product: every hidden layer may
+            # carry a power of two (relu(n x) = n relu(x)), which the last layer's fp32 weights take out again.  Both matrices
+            # are normalised to max |w| in (0.5, 1] -- exact, free for the kernels -- so that a checkpoint whose head weights
+            # are ~1e-3 (lo parts in fp16's subnormals) or ~1e+2 (hidden activations beyond fp16's range) runs split-fp16
+            # at its nominal accuracy.  Other activations are not homogeneous: no normalisation (n = 1).
+            n0, n1 = (pow2_norm(W0), pow2_norm(W1)) if (cfg.mlp_act == "relu" and (self._mode_local if name == "head_local" else mode) != 0) else (1.0, 1.0)
+            self.head_norm = getattr(self, "head_norm", {})
+            self.head_norm[name] = (n0, n1)
+            arrays[n + "w1_pk"] = pb(W0 * n0, kouter=True)
+            arrays[n + "b1"] = _np(sd, p + ".layers.0.bias").astype(np.float64) * n0
+            arrays[n + "w2_pk"] = pb(W1 * n1)
+            arrays[n + "b2"] = _np(sd, p + ".layers.1.bias").astype(np.float64) * (n0 * n1)
+            arrays[n + "w3"] = _np(sd, p + ".layers.2.weight")[0].astype(np.float64) / (n0 * n1)
             scalars[n + "b3"] = float(_np(sd, p + ".layers.2.bias")[0])
 
         # ---------------- radius-edge polynomials (include/agdiff_hip.h: agdiff_params_t.poly_kt)
         for name, c in self._poly.items():
             if name.startswith("head_"):        # (the CFConv filter sets are packed by _pack_filter_sets: their layout
-                arrays[name] = pack_blocks(c, kouter=True)      # depends on the pass plan)
+                # depends on the pass plan); the edge_attr half of the global head's first layer carries that layer's n0
+                arrays[name] = pack_blocks(np.asarray(c, dtype=np.float64) * self.head_norm["head_global"][0], kouter=True)
 
         # one flat device buffer, every section 256-byte aligned
         offs, total = {}, 0

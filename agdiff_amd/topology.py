@@ -48,7 +48,7 @@ class BatchTopology:
     GROUP_MIN_NODES = ((6144, 4), (3072, 2))        # N > 6144: 4 targets per group, N > 3072: 2, else 1
 
     def __init__(self, atom_type, bond_index, bond_type, batch, num_graphs=None, extend_order=False,
-                 order=3, device="cuda", group_targets=None):
+                 order=3, device="cuda", group_targets=None, radius_column=True):
         import torch
         at = _to_np(atom_type).astype(np.int64)
         bi = _to_np(bond_index).astype(np.int64).reshape(2, -1)
@@ -178,10 +178,23 @@ class BatchTopology:
             raise ValueError("group_targets must be 1, 2 or 4")
         GT, RT = int(group_targets), 16 // int(group_targets)               # targets per group, rows per target in a tile
         need = (cnt_tt + RT - 1) // RT
+        # On quads the radius rows go in quad tiles too (csrc/nodeconv.hip k_cfconv_quad: a quad walks max over its targets of
+        # ceil(radius rows / 4) tiles), so the grouping also counts a radius column: the rows a target has while its molecule
+        # lies inside the cutoff -- radius_graph keeps the first 33 candidates in index order, self included and then dropped
+        # (models/common.py:217; AGDIFF_RADIUS_CAP), minus those that are local edges.  Only an ordering heuristic: the kernels
+        # take the row counts of the graph that was built.
+        need_order = need
+        if GT == 4 and radius_column:
+            li = np.arange(N) - gptr[ba]
+            m = np.minimum(n_of_node, _lib.RADIUS_CAP)
+            cand = np.where(li < m, m - 1, m)
+            loc_in_cand = np.bincount(dst[(src - gptr[ba[src]]) < m[dst]], minlength=N) if L else np.zeros(N, dtype=np.int64)
+            rad_est = np.maximum(cand - loc_in_cand, 0)
+            need_order = np.concatenate([need, ((rad_est + 3) // 4)[:, None]], axis=1)
         quad_tgt = []
         for g in range(G):
             # (conformers of one molecule share the grouping: cached by the molecule's need matrix)
-            idx = int(gptr[g]) + _group_order(need[gptr[g]:gptr[g + 1]], GT)
+            idx = int(gptr[g]) + _group_order(need_order[gptr[g]:gptr[g + 1]], GT)
             if idx.size % GT:
                 idx = np.concatenate([idx, np.full(GT - idx.size % GT, -1, dtype=idx.dtype)])
             grp = np.full((idx.size // GT, 4), -1, dtype=np.int64)              # (always four entries per group: -1 = none)

@@ -133,6 +133,56 @@ def test_only_the_diverging_molecule_is_resampled():
     assert ok.tolist() == [True, True, False, True] and torch.isnan(pos[off:off + n * g]).all()
 
 
+class _RangeSampler(_FakeSampler):
+    """A sampler whose runs report the graphs of molecule fingerprint `nan_type` as out of the split-fp16 range (and failed) while
+    the model is not in split-bf16: what epsnet.LangevinRun.check_nan does with raise_on_nan=False."""
+
+    def __init__(self, nan_type):
+        super().__init__(nan_type)
+        self.precision, self.precision_local, self.modes = "f16x3", None, []
+
+    def arithmetic(self, precision=None, precision_local=None):
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            old = (self.precision, self.precision_local)
+            self.precision, self.precision_local = precision, precision_local
+            try:
+                yield self
+            finally:
+                self.precision, self.precision_local = old
+        return cm()
+
+    def begin_sampling(self, *a, **kw):
+        run = super().begin_sampling(*a, **kw)
+        self.modes.append((self.precision, self.precision_local))
+        wide = self.precision == "bf16x3"
+        bad = run.nan_graphs() if not wide else torch.zeros(run.G, dtype=torch.bool)
+        run.range_graphs = set(torch.nonzero(bad).view(-1).tolist())
+        run.nan_graphs = lambda: bad
+        return run
+
+
+def test_molecules_that_leave_the_split_fp16_range_are_resampled_in_split_bf16():
+    """a range trip must not abort the job -- the affected molecules (and only they) are sampled again with the
+    model in split-bf16 for that attempt; the healthy ones keep their first result; the mode is restored afterwards."""
+    mols = _mols(4)
+    mols[1]["atom_type"] = mols[1]["atom_type"].copy()
+    mols[1]["atom_type"][:] = 9
+    packed = driver.pack_batch(mols, driver.num_confs("2"))
+    m = _RangeSampler(nan_type=9)
+    before = dict(driver.SAMPLE_STATS)
+    logs = []
+    pos, _, ok = driver.sample_batch(m, packed, "cpu", dict(n_steps=2), log=logs.append)
+    assert ok.all() and torch.isfinite(pos).all()
+    assert m.calls == [(8, None), (2, 20)] and m.modes == [("f16x3", None), ("bf16x3", "bf16x3")]
+    assert (m.precision, m.precision_local) == ("f16x3", None)
+    assert driver.SAMPLE_STATS["range_trips"] - before["range_trips"] == 2
+    assert driver.SAMPLE_STATS["bf16x3_retries"] - before["bf16x3_retries"] == 1
+    assert any("split-bf16" in l for l in logs)
+
+
 def test_subset_batch_rebases():
     mols = _mols(5)
     confs = driver.num_confs("2x")

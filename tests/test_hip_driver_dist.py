@@ -88,6 +88,57 @@ def test_driver_resamples_only_the_diverging_molecule():
                                              packed["num_graphs"], extend_order=False, n_steps=3)
 
 
+def test_a_molecule_that_leaves_the_split_fp16_range_mid_job_is_resampled_in_split_bf16():
+    """VERDICT r4 item 2 / ADVICE: the split-fp16 range watch (|hl| <= 255, ...) used to be polled only at the end of a driver
+    run and raised AgdiffRangeError for the whole packed batch.  Now it is polled every nan_check_every steps in the driver's
+    mode too, NaN-masked; the graphs that own the offending rows are taken out of the run like diverged ones and their
+    molecule alone is sampled again with the model in split-bf16 (fp32's range).  Here one molecule carries an atom type whose
+    GIN embedding row is 300: its conformers trip the watch at the first poll; its neighbours keep, bit for bit, what they get
+    in a batch without that atom type; the job ends with finite pos_gen for every molecule."""
+    from agdiff_amd import driver, get_model, qm9_model_config, synth
+    from oracle import agdiff_oracle as O
+    cfg = qm9_model_config(num_diffusion_timesteps=12)
+    sd = O.synth_state_dict_for(cfg)
+    for k in list(sd):
+        if synth.canonical_key(k) == "encoder_local.node_emb.weight":
+            sd[k] = sd[k].clone()
+            sd[k][17] = 300.0
+    m = get_model(cfg)
+    m.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+    m = m.to("cuda:0").eval()
+    mols = _three_molecules(seed=8)
+    for mol in mols:
+        assert not (mol["atom_type"] == 17).any()
+    clean = driver.pack_batch(mols, driver.num_confs("2"))
+    mols[1]["atom_type"] = mols[1]["atom_type"].copy()
+    mols[1]["atom_type"][0] = 17
+    packed = driver.pack_batch(mols, driver.num_confs("2"))
+    N = packed["atom_type"].shape[0]
+    gen = torch.Generator().manual_seed(4)
+    pos_init, noise = torch.randn(N, 3, generator=gen), torch.randn(12, N, 3, generator=gen)
+    kw = dict(n_steps=12, step_lr=1e-6, w_global=1.0, global_start_sigma=0.5, clip=1000.0, nan_check_every=4)
+    ref, _, ok0 = driver.sample_batch(m, clean, "cuda:0", kw, pos_init=pos_init, noise=noise)
+    assert ok0.all()
+    before, logs = dict(driver.SAMPLE_STATS), []
+    pos, traj, ok = driver.sample_batch(m, packed, "cuda:0", kw, pos_init=pos_init, noise=noise, log=logs.append, save_traj=True)
+    off, n, g = packed["spans"][1]
+    assert ok.all() and torch.isfinite(pos).all() and torch.isfinite(traj).all()
+    assert driver.SAMPLE_STATS["range_trips"] - before["range_trips"] == g
+    assert driver.SAMPLE_STATS["bf16x3_retries"] - before["bf16x3_retries"] == 1
+    assert len(logs) == 1 and "split-bf16" in logs[0] and "1 of 3" in logs[0]
+    assert (m.precision, m.precision_local) == ("f16x3", None)               # restored after the retry
+    keep = torch.ones(N, dtype=torch.bool)
+    keep[off:off + n * g] = False
+    assert torch.equal(pos[keep], ref[keep])
+    # the module API keeps raising for the whole call (reference contract: one call, one batch)
+    from agdiff_amd import _lib
+    with pytest.raises(_lib.AgdiffRangeError) as e:
+        m.langevin_dynamics_sample_diffusion(t(packed["atom_type"]).cuda(), pos_init.cuda(), t(packed["bond_index"]).cuda(),
+                                             t(packed["bond_type"]).cuda(), t(packed["batch"]).cuda(),
+                                             packed["num_graphs"], extend_order=False, n_steps=12, nan_check_every=4)
+    assert e.value.tensor == "hl" and sorted(e.value.graphs) == [2, 3]
+
+
 @pytest.mark.parametrize("mode", ["auto", "radius", "off"])
 def test_a_graph_that_goes_nan_mid_run_never_touches_its_neighbours(mode):
     """with raise_on_nan=False a diverged graph stays in the batch for the rest of the job.  One conformer's noise

@@ -594,6 +594,75 @@ def test_default_initialised_weights(precision):
     assert rel_err(m.encoder_global.embedding.weight.detach().cpu().numpy(), sd["encoder_global.embedding.weight"].numpy()) < 1e-6
 
 
+def _scaled_relu_chains(sd, f):
+    """The synthetic checkpoint with both heads' hidden layers times f and, in every GIN layer, the first matrix times f and
+    the second divided by f (both names of every tensor: attribute path and ModuleList alias)."""
+    from agdiff_amd import synth
+    out = {}
+    for k, v in sd.items():
+        c = synth.canonical_key(k)
+        if c.endswith((".layers.0.weight", ".layers.1.weight")) and "dist_mlp" in c:
+            v = v * f
+        elif "encoder_local.convs" in c and c.endswith("nn.layers.0.weight"):
+            v = v * f
+        elif "encoder_local.convs" in c and c.endswith("nn.layers.1.weight"):
+            v = v / f
+        out[k] = v.clone()
+    return out
+
+
+@pytest.mark.parametrize("f", [1e-3, 1e2])
+def test_head_and_gin_weights_far_from_unit_scale_keep_split_fp16_accuracy(f):
+    """split-fp16 parts below 6e-5 lose bits and parts below 6e-8 vanish, so a matrix of size 1e-3 packed
+    as it is carries ~3e-5 per operand, and hidden activations 1e4 x larger than usual leave fp16's range.  Both heads and the
+    GIN MLPs are ReLU chains: the host normalises their matrices by exact powers of two (packing.pow2_norm; the fp32 output layer /
+    the second matrix takes the factor out again).  Forward against the oracle at the plain split-fp16 gates, no fallback."""
+    from agdiff_amd import drugs_model_config, get_model, synth
+    from oracle import agdiff_oracle as O
+    cfg = drugs_model_config()
+    sd = _scaled_relu_chains(O.synth_state_dict_for(cfg), f)
+    m = get_model(cfg)
+    m.precision = "f16x3"
+    m.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+    m = m.to("cuda:0").eval()
+    b = synth.make_packed_batch("drugs", 3, 2, seed=78)
+    at, bi, bt, ba = t(b["atom_type"]), t(b["bond_index"]), t(b["bond_type"]), t(b["batch"])
+    pos = torch.randn(at.shape[0], 3, generator=torch.Generator().manual_seed(6)) * 2.0
+    ref = O.forward(sd, cfg, at, pos, bi, bt, ba, extend_order=False)
+    got = m(at.cuda(), pos.cuda(), bi.cuda(), bt.cuda(), ba.cuda(), None, return_edges=True, extend_order=False)
+    assert (m.effective_precision, m.effective_precision_local) == ("f16x3", "f16x3")
+    rep = m.packed().split_fp16_report
+    assert max(rep["global"]["err"], rep["local"]["err"]) <= 2.0 ** -19
+    check_close("relu_chains_x%g got[0]" % f, got[0].cpu().numpy(), ref[0].numpy(), "f16x3")
+    check_close("relu_chains_x%g got[1]" % f, got[1].cpu().numpy(), ref[1].numpy(), "f16x3")
+
+
+def test_weights_that_do_not_fit_split_fp16_run_in_split_bf16():
+    """A matrix outside the ReLU chains whose magnitude split-fp16 cannot hold (InteractionBlock.lin times 1e-4, its BatchNorm'd
+    successor... none: the block's output simply shrinks): the host measures what packing costs (packing.split_fp16_error), warns
+    and packs that branch in split-bf16; the forward then meets the split-bf16 gates against the oracle."""
+    from agdiff_amd import drugs_model_config, get_model, synth
+    from oracle import agdiff_oracle as O
+    cfg = drugs_model_config()
+    sd = O.synth_state_dict_for(cfg)
+    for k in list(sd):
+        if synth.canonical_key(k).endswith("interactions.2.lin.weight"):
+            sd[k] = sd[k] * 1e-4
+    m = get_model(cfg)
+    m.precision = "f16x3"
+    m.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+    m = m.to("cuda:0").eval()
+    b = synth.make_packed_batch("drugs", 3, 2, seed=79)
+    at, bi, bt, ba = t(b["atom_type"]), t(b["bond_index"]), t(b["bond_type"]), t(b["batch"])
+    pos = torch.randn(at.shape[0], 3, generator=torch.Generator().manual_seed(7)) * 2.0
+    ref = O.forward(sd, cfg, at, pos, bi, bt, ba, extend_order=False)
+    with pytest.warns(UserWarning, match="split-bf16"):
+        got = m(at.cuda(), pos.cuda(), bi.cuda(), bt.cuda(), ba.cuda(), None, return_edges=True, extend_order=False)
+    assert (m.effective_precision, m.effective_precision_local) == ("bf16x3", "f16x3")
+    check_close("lin_x1e-4 got[0]", got[0].cpu().numpy(), ref[0].numpy(), "bf16x3")
+    check_close("lin_x1e-4 got[1]", got[1].cpu().numpy(), ref[1].numpy(), "f16x3")
+
+
 def test_molecule_larger_than_a_workgroup():
     """A 300-atom molecule (more atoms than the 256 threads of the per-molecule kernels: graph build, Langevin
     update, loss) next to a small one: forward and three sampler steps against the oracle."""

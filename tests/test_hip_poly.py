@@ -243,7 +243,9 @@ def test_cfconv_node_shapes_agree_bitwise(kind, mols, copies, mode, precision, p
     for name, a_, b_ in zip(("edge_inv_global", "edge_inv_local", "h", "agg"), by_layout[(4, 0)], by_layout[(4, -1)]):
         assert torch.isfinite(a_).all()
         err = float((a_ - b_).abs().max() / b_.abs().max().clamp_min(1e-30))
-        assert err <= 2e-6, (name, err)
+        # (two chains of the same arithmetic whose aggregates differ in the last fp32 bits: six blocks and a head later the
+        # operand roundings of the mode have amplified that -- the figure tests/helpers.py allows two split chains)
+        assert err <= {"f32": 2e-6, "f16x3": 6e-6, "bf16x3": 6e-5}[precision], (name, err)
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x3"])

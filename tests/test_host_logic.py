@@ -361,7 +361,8 @@ def test_group_order_is_a_permutation_and_beats_the_plain_sort():
     for trial in range(12):
         at_, r_, c_, t_ = synth.random_molecule(rng, synth.sample_n_atoms(rng, "drugs"))
         b = dict(atom_type=at_, bond_index=np.stack([r_, c_]), bond_type=t_, batch=np.zeros(at_.shape[0], dtype=np.int64))
-        tp = BatchTopology(b["atom_type"], b["bond_index"], b["bond_type"], b["batch"], device="cpu", group_targets=4)
+        tp = BatchTopology(b["atom_type"], b["bond_index"], b["bond_type"], b["batch"], device="cpu", group_targets=4,
+                           radius_column=False)
         dst, typ, N = tp.loc_dst.numpy(), tp.loc_type.numpy(), tp.N
         types = np.unique(typ)
         cnt = np.stack([np.bincount(dst[typ == ty], minlength=N) for ty in types], 1)
@@ -381,6 +382,23 @@ def test_group_order_is_a_permutation_and_beats_the_plain_sort():
                 tot_sort += cost(plain); tot_new += cost(o1)
                 assert cost(o1) == tp.T          # (what the topology built)
     assert tot_new < 0.97 * tot_sort, (tot_new, tot_sort)
+    # with the radius column (the default on quads: k_cfconv_quad walks max over a quad's targets of ceil(radius rows / 4) tiles)
+    # the grouping trades a few local tiles for fewer radius tiles: local + radius tiles of a compact molecule do not grow
+    rng = np.random.default_rng(12)
+    tot = {False: 0, True: 0}
+    for trial in range(8):
+        n = synth.sample_n_atoms(rng, "drugs")
+        at_, r_, c_, t_ = synth.random_molecule(rng, n)
+        for col in (False, True):
+            tp = BatchTopology(at_, np.stack([r_, c_]), t_, np.zeros(n, dtype=np.int64), device="cpu", group_targets=4, radius_column=col)
+            m = min(n, 33)
+            cand = np.where(np.arange(n) < m, m - 1, m)
+            src, dst = tp.loc_src.numpy(), tp.loc_dst.numpy()
+            rad = cand - np.bincount(dst[src < m], minlength=n)
+            qt = tp.quad_tgt.numpy().reshape(-1, 4)
+            assert sorted(qt[qt >= 0].tolist()) == list(range(n))
+            tot[col] += tp.T + int(((np.where(qt >= 0, rad[np.maximum(qt, 0)], 0) + 3) // 4).max(axis=1).sum())
+    assert tot[True] < tot[False], tot
     tiny = np.array([[1, 0], [0, 2], [1, 1]], dtype=np.int32)
     assert sorted(topology._group_order(tiny, 4).tolist()) == [0, 1, 2]
 
