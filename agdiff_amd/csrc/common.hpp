@@ -140,6 +140,28 @@ __device__ __forceinline__ float ag_dot_vec(const f32x4 (&y)[NY], const float* _
   _Pragma("unroll") for (int _t = 0; _t < (NT); ++_t)  \
   _Pragma("unroll") for (int _r = 0; _r < 4; ++_r) { float v = (y)[_t][_r]; (y)[_t][_r] = (expr); }
 
+// MultiLayerPerceptron's activation (models/common.py:62-66: getattr(F, config.mlp_act)) between the layers of the two heads;
+// agdiff_head_params_t.act (AGDIFF_ACT_*).  `act` is uniform: one scalar branch per layer and tile.
+__device__ __forceinline__ float ag_tanh(float x) {            // 1 - 2 / (1 + e^{2x}): absolute error ~1e-7
+  return 1.0f - 2.0f * ag_rcp(1.0f + ag_exp2(fminf(x * 2.88539008177792681472f, 126.0f)));
+}
+__device__ __forceinline__ float ag_softplus(float x) {        // F.softplus(beta = 1, threshold = 20)
+  return fmaxf(x, ag_log2(1.0f + ag_exp2(fminf(x * 1.44269504088896340736f, 126.0f))) * 0.69314718055994530942f);
+}
+template <int NT, int NY>
+__device__ __forceinline__ void ag_head_act(f32x4 (&y)[NY], int act) {
+  switch (act) {
+    case AGDIFF_ACT_GELU: AG_FOR_TILE(y, NT, ag_gelu(v)); break;
+    case AGDIFF_ACT_SILU: AG_FOR_TILE(y, NT, v * ag_sigmoid(v)); break;
+    case AGDIFF_ACT_TANH: AG_FOR_TILE(y, NT, ag_tanh(v)); break;
+    case AGDIFF_ACT_SIGMOID: AG_FOR_TILE(y, NT, ag_sigmoid(v)); break;
+    case AGDIFF_ACT_SOFTPLUS: AG_FOR_TILE(y, NT, ag_softplus(v)); break;
+    case AGDIFF_ACT_LEAKY_RELU: AG_FOR_TILE(y, NT, (v > 0.0f ? v : 0.01f * v)); break;
+    case AGDIFF_ACT_ELU: AG_FOR_TILE(y, NT, (v > 0.0f ? v : ag_exp2(v * 1.44269504088896340736f) - 1.0f)); break;
+    default: AG_FOR_TILE(y, NT, ag_relu(v)); break;
+  }
+}
+
 // ---------------------------------------------------------------------------------- MFMA operands
 // Two arithmetic modes share every kernel (template parameter MODE):
 //   AG_F32: v_mfma_f32_16x16x4_f32, exact fp32 (k-ordered fmaf chain).
@@ -154,7 +176,7 @@ __device__ __forceinline__ float ag_dot_vec(const f32x4 (&y)[NY], const float* _
 //   lane l holds W[16*ot + (l&15)][32*t + {4q..4q+3} U {16+4q..16+4q+3}], q = l>>4
 //   AG_F32: unit u = the four fp32 of half u;  AG_BF3: unit 0 = the eight bf16 hi, unit 1 = the eight lo.
 //   AG_H3:  "split fp16": the same three-pass scheme with hi = fp16(x), lo = fp16(x - hi) on v_mfma_f32_16x16x32_f16 (the
-//           rate of the bf16 form): 11 + 11 mantissa bits per operand instead of 8 + 8, i.e. ~2^-21 per product while |x| stays
+//           rate of the bf16 form): 11 + 11 mantissa bits per operand instead of 8 + 8, i.e. ~2^-20 per product (both parts truncated) while |x| stays
 //           inside fp16's range (values beyond 65504 saturate, parts below 6e-8 are lost: an ABSOLUTE floor ~2^-24, harmless
 //           next to O(1) operands).  Used for the local branch (GIN layers, local head, local edge_attr rows), whose outputs
 //           carry the 64 -> 1 cancellation of the head and were the thin spot of the split-bf16 parity.

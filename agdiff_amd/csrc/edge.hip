@@ -746,7 +746,7 @@ __global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_pair_head(HeadArgs
         else ag_dense_lds<MODE, false, true, 1, 8, 0, 0>(sl, y1, wk, 0);
       }
     }
-    AG_FOR_TILE(y1, 8, ag_relu(v));
+    ag_head_act<8>(y1, a.hp.act);
     f32x4 y2[4];
     ag_init_vec<4>(y2, a.hp.b2, q);
     {
@@ -754,7 +754,7 @@ __global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_pair_head(HeadArgs
       ag_cvt_tiles<MODE, 4, 0>(y1, y1b);
       ag_dense_lds<MODE, false, false, 4, 4, 0, 0>(y1b, y2, ag_lds_base(lw2, lane), 0);
     }
-    AG_FOR_TILE(y2, 4, ag_relu(v));
+    ag_head_act<4>(y2, a.hp.act);
     const float o = ag_dot_vec<4>(y2, a.hp.w3, q) + a.hp.b3;
     if (valid && q == 0) {
       a.out[pe] = o;
@@ -974,7 +974,7 @@ __global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_pair_head_poly(Hea
       ag_poly_features<MODE, NKT>(d, a.two_over_rc, q, ph);
       ag_dense_lds<MODE, false, true, NKT, 8, 0, 0>(ph, y1, ag_lds_base(lwp, lane), 0);
     }
-    AG_FOR_TILE(y1, 8, ag_relu(v));
+    ag_head_act<8>(y1, a.hp.act);
     f32x4 y2[4];
     ag_init_vec<4>(y2, a.hp.b2, q);
     {
@@ -982,7 +982,7 @@ __global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_pair_head_poly(Hea
       ag_cvt_tiles<MODE, 4, 0>(y1, y1b);
       ag_dense_lds<MODE, false, false, 4, 4, 0, 0>(y1b, y2, ag_lds_base(lw2, lane), 0);
     }
-    AG_FOR_TILE(y2, 4, ag_relu(v));
+    ag_head_act<4>(y2, a.hp.act);
     const float o = ag_dot_vec<4>(y2, a.hp.w3, q) + a.hp.b3;
     if (valid && q == 0) {
       a.out[pe] = o;

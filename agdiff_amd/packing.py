@@ -310,10 +310,17 @@ def radius_polynomials(sd, cfg, tol=POLY_TOL, max_kt=POLY_MAX_KT, min_kt=1):
 # parts of the split operands buy 2^-21 per product; a term whose coefficient is small against the filter's size does not
 # need them.  The Chebyshev coefficients of an analytic function decay geometrically, so the HIGH half of the accepted
 # expansion (f >= 16 at 32 terms, f >= 32 at 64) usually carries 1e-4 .. 1e-7 of the weight, and one hi x hi pass over it
-# costs POLY_EPS1 times that -- the two operand roundings of a single product (fp16 features are rounded toward zero: 2^-11,
-# coefficients to nearest: 2^-12; bf16: 2^-9 + 2^-9).  Plan 1 is taken only when fit error + that bound stays within POLY_TOL
-# for EVERY coefficient set in use.
-POLY_EPS1 = {1: 2.0 ** -8, 2: 1.5 * 2.0 ** -11}
+# costs POLY_EPS1 times that -- the two operand roundings of a single product: fp16 has 11 significant bits, so features rounded
+# toward zero (v_cvt_pkrtz) are off by < 2^-10 and coefficients rounded to nearest by <= 2^-11; bf16 has 8: 2^-8 + 2^-8
+# (the earlier constants were a factor 2 too small).  Plan 1 is taken only when fit error + that bound stays within
+# POLY_TOL for the sets the plan is decided on (PackedParams.poly_pass_plan).
+POLY_EPS1 = {1: 2.0 ** -7, 2: 1.5 * 2.0 ** -10}
+# edge types every batch brings (bonds of order 1..3 and aromatic ones, 2- and 3-hop edges at edge_order 3): the pass plan and
+# the coefficient scale are decided on the radius set + these ONCE per model, so that a process's numerics do not depend on
+# which batches it has seen; a later type that does not fit that decision keeps the filter MLPs for its edges
+POLY_PLAN_TYPES = (1, 2, 3, 12, 23, 24)
+POLY_COEF_TARGET = 128.0        # split-fp16: coefficients are stored times 2^S with max |c| 2^S in (64, 128] over the radius set
+POLY_COEF_LIMIT = 32768.0       # ... and a typed set must stay below this at the same S
 
 
 def poly_high_weight(c_nat, kt):
@@ -394,7 +401,11 @@ def dist_union_table(segs):
 
 
 PRECISIONS = {"f32": 0, "bf16x3": 1, "f16x3": 2}
-LOCAL_PRECISIONS = {"f32": 0, "bf16x3": 1, "f16x3": 2}      # agdiff_params_t.precision_local
+# config.mlp_act (models/common.py:62-66: getattr(F, name)) -> agdiff_head_params_t.act (include/agdiff_hip.h AGDIFF_ACT_*)
+HEAD_ACTS = {"relu": 0, "gelu": 1, "silu": 2, "tanh": 3, "sigmoid": 4, "softplus": 5, "leaky_relu": 6, "elu": 7}
+LOCAL_PRECISIONS = {"f32": 0, "bf16x3": 1, "f16x3": 2}
+# config.mlp_act (models/common.py:62-66: getattr(F, name)) -> agdiff_head_params_t.act (include/agdiff_hip.h AGDIFF_ACT_*)
+HEAD_ACTS = {"relu": 0, "gelu": 1, "silu": 2, "tanh": 3, "sigmoid": 4, "softplus": 5, "leaky_relu": 6, "elu": 7}      # agdiff_params_t.precision_local
 EDGE_ENCODERS = {"mlp": 0, "gaussian": 1}       # agdiff_params_t.edge_encoder
 
 
@@ -466,8 +477,9 @@ class PackedParams:
             raise NotImplementedError("hidden_dim must be 128 (InteractionBlock.lin is Linear(256, hidden), schnet.py:190)")
         if cfg.edge_encoder not in EDGE_ENCODERS:
             raise NotImplementedError("Unknown edge encoder: %s" % cfg.edge_encoder)
-        if cfg.mlp_act != "relu":
-            raise NotImplementedError("mlp_act=%s (HIP heads implement relu, configs/*.yml:8)" % cfg.mlp_act)
+        if cfg.mlp_act not in HEAD_ACTS:
+            raise NotImplementedError("mlp_act=%s: the HIP heads implement %s (models/common.py:62-66 takes any torch.nn.functional "
+                                      "name; configs/*.yml:8: relu)" % (cfg.mlp_act, ", ".join(sorted(HEAD_ACTS))))
         if cfg.num_convs > _lib.DEFINES["AGDIFF_MAX_CONVS"] or cfg.num_convs_local > _lib.DEFINES["AGDIFF_MAX_CONVS_LOCAL"]:
             raise NotImplementedError("too many conv layers for this build")
         arrays = {}      # name -> np.float32 array
@@ -585,7 +597,7 @@ class PackedParams:
             # are normalised to max |w| in (0.5, 1] -- exact, free for the kernels -- so that a checkpoint whose head weights
             # are ~1e-3 (lo parts in fp16's subnormals) or ~1e+2 (hidden activations beyond fp16's range) runs split-fp16
             # at its nominal accuracy.  Other activations are not homogeneous: no normalisation (n = 1).
-            n0, n1 = (pow2_norm(W0), pow2_norm(W1)) if (cfg.mlp_act == "relu" and (self._mode_local if name == "head_local" else mode) != 0) else (1.0, 1.0)
+            n0, n1 = (pow2_norm(W0), pow2_norm(W1)) if (cfg.mlp_act in ("relu", "leaky_relu") and (self._mode_local if name == "head_local" else mode) != 0) else (1.0, 1.0)
             self.head_norm = getattr(self, "head_norm", {})
             self.head_norm[name] = (n0, n1)
             arrays[n + "w1_pk"] = pb(W0 * n0, kouter=True)
@@ -649,7 +661,7 @@ class PackedParams:
             if (n + "attr_poly_pk") in offs:
                 hp.attr_poly_pk = P(n + "attr_poly_pk")
             hp.b3 = scalars[n + "b3"]
-            hp.act = 0
+            hp.act = HEAD_ACTS[cfg.mlp_act]
             hp.precision = self._mode_local if name == "head_local" else mode
         prm.num_convs = cfg.num_convs
         prm.num_convs_local = cfg.num_convs_local
@@ -661,55 +673,82 @@ class PackedParams:
         prm.poly_num_slots = 0
         self.struct = prm
         self.poly_plan, self.poly_high_bound, self.rad_poly_flat = 0, {}, None
+        self._plan_fixed, self.filt_poly_upscale = None, None
         for k in range(cfg.num_convs):
             prm.conv[k].filt_poly_unscale = 1.0
         if self.poly_kt >= 1:
             self._pack_filter_sets()
 
+    def _set_bound(self, name, mats):
+        if name not in self.poly_high_bound:
+            self.poly_high_bound[name] = POLY_EPS1[self._mode] * max(poly_high_weight(mats["conv%d.filt_poly_pk" % k], self.poly_kt)
+                                                                      for k in range(self._cfg.num_convs))
+        return self.poly_high_bound[name]
+
     def poly_pass_plan(self):
-        """agdiff_params_t.poly_plan for the coefficient sets in use (radius edges + slotted local types): 1 when, for each
-        of them, fit error + POLY_EPS1[mode] * (weight of the high terms) <= POLY_TOL; self.poly_high_bound records the
-        second summand per set."""
-        if self._mode not in POLY_EPS1 or self.poly_kt < 1:
-            return 0
-        eps, ok = POLY_EPS1[self._mode], self.poly_passes == "auto"
-        sets = [("radius", self._poly, self.poly_errors[self.poly_kt])] + \
-               [("type%d" % t, self._typed_mats[t], self.poly_errors["type%d" % t]) for t in sorted(self.local_slots)]
-        for name, mats, err in sets:
-            if name not in self.poly_high_bound:
-                self.poly_high_bound[name] = eps * max(poly_high_weight(mats["conv%d.filt_poly_pk" % k], self.poly_kt)
-                                                       for k in range(self._cfg.num_convs))
-            ok = ok and err + self.poly_high_bound[name] <= POLY_TOL
-        return 1 if ok else 0
+        """agdiff_params_t.poly_plan, decided ONCE per model: 1 when, for the radius set and for each of POLY_PLAN_TYPES whose
+        fit is accepted at all, fit error + POLY_EPS1[mode] * (weight of the high terms) <= POLY_TOL; self.poly_high_bound
+        records the second summand per set.  (Until round 4 the plan followed the types met so far and could flip mid-process.)"""
+        if self._plan_fixed is not None:
+            return self._plan_fixed
+        plan = 0
+        if self._mode in POLY_EPS1 and self.poly_kt >= 1 and self.poly_passes == "auto":
+            ok = self.poly_errors[self.poly_kt] + self._set_bound("radius", self._poly) <= POLY_TOL
+            if ok and self._typed_ok:
+                for t in POLY_PLAN_TYPES:
+                    if t in self.poly_refused_types:
+                        continue
+                    mats, err = fit_type(self._sd, self._cfg, t, self.poly_kt, False)
+                    if err <= POLY_TOL:
+                        ok = ok and err + self._set_bound("type%d" % t, mats) <= POLY_TOL
+            plan = 1 if ok else 0
+        self._plan_fixed = plan
+        return plan
+
+    def _type_fits_plan(self, t, mats, err):
+        """Whether a local type's accepted fit can join the sets already packed: under plan 1 its own one-pass bound must hold,
+        and in split-fp16 its coefficients must stay in range at the model's scale 2^S."""
+        if self.poly_pass_plan() == 1 and err + self._set_bound("type%d" % t, mats) > POLY_TOL:
+            return False
+        if self._mode == 2:
+            for k in range(self._cfg.num_convs):
+                if np.abs(mats["conv%d.filt_poly_pk" % k]).max() * self.filt_poly_upscale[k] > POLY_COEF_LIMIT:
+                    return False
+        return True
 
     def _pack_filter_sets(self):
-        """(Re)pack the CFConv filter polynomials -- the radius edges' set and the slotted local types' -- in the layout of
-        the pass plan that holds for all of them, and point the conv structs at the new buffers (the old ones may still be in
-        use by enqueued launches: torch's allocator keeps them alive in stream order)."""
+        """(Re)pack the CFConv filter polynomials -- the radius edges' set and the slotted local types' -- and point the conv
+        structs at the new buffers (the old ones may still be in use by enqueued launches: torch's allocator keeps them alive
+        in stream order).  Layout (pass plan) and scale are the model's, fixed at the first call: a new slot adds a set, it
+        never changes the others' bits."""
         import torch
         prm, nc, kt = self.struct, self._cfg.num_convs, self.poly_kt
         plan = self.poly_pass_plan()
 
         by_slot = sorted(self.local_slots, key=self.local_slots.get)
-        # split-fp16: coefficients times 2^S per conv (conv[k].filt_poly_unscale = 2^-S; the largest one ends up in
-        # [512, 1024]): their lo parts leave fp16's subnormal range, whose quantum of 6e-8 otherwise costs up to 1e-6 of a
-        # filter of size 0.2.  bf16 parts have fp32's exponent range and fp32 operands no parts: S = 0
-        up = []
+        # split-fp16: coefficients times 2^S per conv (conv[k].filt_poly_unscale = 2^-S): their lo parts leave fp16's subnormal
+        # range, whose quantum of 6e-8 otherwise costs up to 1e-6 of a filter of size 0.2.  S comes from the RADIUS set alone
+        # (max |c| 2^S in (64, 128]: typed sets up to 256 x larger still fit, _type_fits_plan).  bf16 parts have fp32's exponent
+        # range and fp32 operands no parts: S = 0
+        if self.filt_poly_upscale is None:
+            up = []
+            for k in range(nc):
+                cmax = np.abs(self._poly["conv%d.filt_poly_pk" % k]).max()
+                S = int(np.clip(np.floor(np.log2(POLY_COEF_TARGET / max(cmax, 1e-30))), 0, 24)) if self._mode == 2 else 0
+                up.append(2.0 ** S)
+            self.filt_poly_upscale = up
+        up = self.filt_poly_upscale
         for k in range(nc):
-            name = "conv%d.filt_poly_pk" % k
-            cmax = max([np.abs(self._poly[name]).max()] + [np.abs(self._typed_mats[t][name]).max() for t in by_slot])
-            S = int(np.clip(np.floor(np.log2(1024.0 / max(cmax, 1e-30))), 0, 24)) if self._mode == 2 else 0
-            up.append(2.0 ** S)
-            prm.conv[k].filt_poly_unscale = 2.0 ** -S
-        self.filt_poly_upscale = up
+            prm.conv[k].filt_poly_unscale = 1.0 / up[k]
 
         def pk(c, k):
             v = pack_blocks(np.asarray(c, dtype=np.float64) * up[k], mode=self._mode)
             return mix_units(v, kt) if plan == 1 else v
-        rad = [pk(self._poly["conv%d.filt_poly_pk" % k], k) for k in range(nc)]
-        self.rad_poly_flat = torch.from_numpy(np.concatenate(rad)).to(self.device)
-        for k in range(nc):
-            prm.conv[k].filt_poly_pk = ctypes.c_void_p(self.rad_poly_flat.data_ptr() + 4 * rad[0].size * k)
+        if self.rad_poly_flat is None:
+            rad = [pk(self._poly["conv%d.filt_poly_pk" % k], k) for k in range(nc)]
+            self.rad_poly_flat = torch.from_numpy(np.concatenate(rad)).to(self.device)
+            for k in range(nc):
+                prm.conv[k].filt_poly_pk = ctypes.c_void_p(self.rad_poly_flat.data_ptr() + 4 * rad[0].size * k)
         if by_slot:
             per_conv = [np.concatenate([pk(self._typed_mats[t]["conv%d.filt_poly_pk" % k], k) for t in by_slot]) for k in range(nc)]
             self.typed_flat = torch.from_numpy(np.concatenate(per_conv)).to(self.device)
@@ -738,7 +777,7 @@ class PackedParams:
         for t in new:
             mats, err = fit_type(self._sd, self._cfg, t, kt, False)
             self.poly_errors["type%d" % t] = err
-            if err > POLY_TOL or len(self.local_slots) >= max_slots:
+            if err > POLY_TOL or len(self.local_slots) >= max_slots or not self._type_fits_plan(t, mats, err):
                 # THIS type keeps the filter MLPs (agdiff_cfconv_local in a mixed batch); the slotted ones keep their polynomials
                 self.poly_refused_types.add(t)
                 continue
@@ -748,7 +787,7 @@ class PackedParams:
         if not added:
             return not any(int(t) in self.poly_refused_types for t in types)
         by_slot = sorted(self.local_slots, key=self.local_slots.get)
-        self._pack_filter_sets()           # (a new type may end the one-pass plan: every set is repacked then)
+        self._pack_filter_sets()           # (the typed sets are packed again with the new one; the radius set, the plan and 2^S stay)
         # edge_attr itself per type (agdiff_local_edge_rows): pk [8][kt] -- the kernel takes one k-tile, so only with kt == 1
         if kt == 1:
             attr_sets = np.concatenate([pack_blocks(self._typed_mats[t]["edge_attr_poly_pk"], mode=self._mode_local) for t in by_slot])

@@ -110,6 +110,15 @@ typedef struct agdiff_gin_params {
   int32_t relu_out;          /* 1 for all but the last layer (gin.py:134) */
 } agdiff_gin_params_t;
 
+/* agdiff_head_params_t.act: torch.nn.functional names the heads' MultiLayerPerceptron may be built with (models/common.py:62-66) */
+#define AGDIFF_ACT_RELU 0
+#define AGDIFF_ACT_GELU 1        /* erf form (F.gelu default) */
+#define AGDIFF_ACT_SILU 2
+#define AGDIFF_ACT_TANH 3
+#define AGDIFF_ACT_SIGMOID 4
+#define AGDIFF_ACT_SOFTPLUS 5    /* beta 1, threshold 20 */
+#define AGDIFF_ACT_LEAKY_RELU 6  /* negative_slope 0.01 */
+#define AGDIFF_ACT_ELU 7         /* alpha 1 */
 typedef struct agdiff_head_params {
   const float* w1_pk;        /* pkk [8][8] layers.0 (256->128) */
   const float* b1;           /* [128] */
@@ -119,7 +128,8 @@ typedef struct agdiff_head_params {
   const float* attr_poly_pk; /* pkk [poly_kt][8] or null: layers.0.weight[:, 128:] @ edge_attr(d, type 0) as a polynomial in d
                                 (agdiff_params_t.poly_kt) */
   float b3;
-  int32_t act;               /* 0 relu (configs: mlp_act relu) */
+  int32_t act;               /* AGDIFF_ACT_*: config.mlp_act, the activation between the head's layers (models/common.py:62-66:
+                                getattr(F, name); configs/*.yml: relu) */
   int32_t precision;         /* as agdiff_params_t.precision, or 2 (split-fp16: only with attr_rows) */
   int32_t pad0;
 } agdiff_head_params_t;
@@ -170,7 +180,7 @@ typedef struct agdiff_params {
                                 agdiff_cfconv_node, the others through agdiff_cfconv_local (topo->local_type_mask tells) */
   int32_t precision_local;   /* arithmetic of the LOCAL branch's MFMA kernels (GIN layers, local head, local edge_attr rows by
                                 polynomial): 0 / 1 as `precision`, 2: split-fp16 (hi + lo fp16, three passes of
-                                v_mfma_f32_16x16x32_f16: ~2^-21 per product at the split-bf16 rate) -- gin[].w*_pk, head_local.w*_pk
+                                v_mfma_f32_16x16x32_f16: ~2^-20 per product (both parts truncated: one-sided) at the split-bf16 rate) -- gin[].w*_pk, head_local.w*_pk
                                 and attr_poly_typed_pk are packed in THIS mode; the encoder MLP of flagged tiles stays in
                                 `precision` */
   int32_t poly_kt;           /* 0: off.  1..AGDIFF_POLY_MAX_KT: radius edges (type 0: no bond embedding; d < cutoff by
@@ -186,7 +196,7 @@ typedef struct agdiff_params {
                                 precision == 0).  0: every term three passes (hi hi, lo hi, hi lo).  1: the HIGH terms -- f >= 16
                                 at poly_kt 1, f >= 32 at poly_kt 2 -- take ONE pass (hi x hi): the host sets it only when
                                   fit error + eps1 * max_out sum_{high f} |c[out][f]| <= 1e-6 of the largest filter value
-                                for every coefficient set (|phi_f| <= 1; eps1 = 1.5 * 2^-11 split-fp16, 2^-8 split-bf16: the
+                                for the radius set and the common local types (|phi_f| <= 1; eps1 = 1.5 * 2^-10 split-fp16, 2^-7 split-bf16: the
                                 two operand roundings of a single product), agdiff_amd/packing.py poly_pass_plan.
                                   poly_kt 1: TWO MFMAs per 16-channel tile instead of three -- unit 1 of every block of
                                   conv[].filt_poly_pk / filt_poly_typed_pk then holds, for lanes 0..31, their hi elements again

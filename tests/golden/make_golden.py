@@ -318,6 +318,20 @@ def g_forward_variants():
     save("g11_forward_variants", **rec)
 
 
+def g_mlp_act():
+    """config.mlp_act other than relu (models/common.py:62-66 builds the heads' MultiLayerPerceptron with getattr(F, name)):
+    one small forward per activation the HIP heads implement."""
+    for act in ("gelu", "silu", "tanh", "sigmoid", "softplus", "leaky_relu", "elu"):
+        cfg = qm9_model_config(mlp_act=act)
+        m = build_ref(cfg, head_scale=1.0)
+        b, pos = small_batch("qm9", 51, 2, 2, 1.5)
+        at, bi, bt, ba = T(b["atom_type"]), T(b["bond_index"]), T(b["bond_type"]), T(b["batch"])
+        with torch.no_grad():
+            out = m(at, pos, bi, bt, ba, None, return_edges=True, extend_order=False, extend_radius=True)
+        save("g15_forward_act_" + act, atom_type=at, pos=pos, bond_index=bi, bond_type=bt, batch=ba,
+             edge_inv_global=out[0], edge_inv_local=out[1], edge_index=out[2], edge_type=out[3])
+
+
 def g_extend_order_forward():
     """§8f-1 on the model path: RAW bonds + extend_order=True (forward's default, dualenc.py:153,167-177 ->
     _extend_graph_order, common.py:135-205, applied to the whole batch) for one forward and one sampler run."""
@@ -425,10 +439,10 @@ def g_losses():
 
 
 if __name__ == "__main__":
-    if sys.argv[1:] and all(a in ("gaussian", "alanine", "loss", "variants", "extend", "covmat", "restoring") for a in sys.argv[1:]):   # add without touching the others
+    if sys.argv[1:] and all(a in ("gaussian", "alanine", "loss", "variants", "extend", "covmat", "restoring", "mlp_act") for a in sys.argv[1:]):   # add without touching the others
         for a in sys.argv[1:]:
             {"gaussian": g_gaussian, "alanine": g_alanine, "loss": g_losses, "variants": g_forward_variants,
-             "extend": g_extend_order_forward, "covmat": g_covmat, "restoring": g_restoring}[a]()
+             "extend": g_extend_order_forward, "covmat": g_covmat, "restoring": g_restoring, "mlp_act": g_mlp_act}[a]()
         sys.exit(0)
     g_schedule_and_keys()
     # G2+G3 uncapped QM9-shaped batch with per-stage outputs (small: 3 molecules x 1 copy)
@@ -454,3 +468,4 @@ if __name__ == "__main__":
     g_extend_order_forward()
     g_covmat()
     g_restoring()
+    g_mlp_act()

@@ -147,6 +147,33 @@ def test_forward_matches_reference_golden(case, precision):
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("act", ["gelu", "silu", "tanh", "sigmoid", "softplus", "leaky_relu", "elu"])
+def test_forward_other_mlp_act_matches_reference_golden(act, precision):
+    """config.mlp_act is any torch.nn.functional name in the reference (models/common.py:62-66); both heads
+    (k_pair_head, and k_pair_head_poly inside the sampler) switch on agdiff_head_params_t.act.  Forward against the reference's
+    fixture per activation, and two sampler steps (polynomial head) against the oracle."""
+    from agdiff_amd import qm9_model_config
+    from oracle import agdiff_oracle as O
+    g = load_golden("g15_forward_act_" + act)
+    cfg = qm9_model_config(mlp_act=act)
+    m, sd = _gpu_model(cfg, head_scale=1.0, precision=precision)
+    at, bi, bt, ba = [t(g[k]) for k in ("atom_type", "bond_index", "bond_type", "batch")]
+    out = m(at.cuda(), t(g["pos"]).cuda(), bi.cuda(), bt.cuda(), ba.cuda(), None, return_edges=True, extend_order=False)
+    assert np.array_equal(out[2].cpu().numpy(), g["edge_index"]) and np.array_equal(out[3].cpu().numpy(), g["edge_type"])
+    check_close("mlp_act %s inv_g" % act, out[0].cpu().numpy(), g["edge_inv_global"], precision)
+    check_close("mlp_act %s inv_l" % act, out[1].cpu().numpy(), g["edge_inv_local"], precision)
+    cfg2 = qm9_model_config(mlp_act=act, num_diffusion_timesteps=6, beta_end=2e-3)
+    m2, sd2 = _gpu_model(cfg2, head_scale=1e-2, precision=precision)
+    gen = torch.Generator().manual_seed(9)
+    pos_init, noise = torch.randn(at.shape[0], 3, generator=gen), torch.randn(2, at.shape[0], 3, generator=gen)
+    kw = dict(n_steps=2, step_lr=1e-6, w_global=1.0, global_start_sigma=float("inf"), clip=1000.0)
+    pos, _ = m2.langevin_dynamics_sample_diffusion(at.cuda(), pos_init.cuda(), bi.cuda(), bt.cuda(), ba.cuda(), int(ba.max()) + 1,
+                                                   extend_order=False, noise=noise.cuda(), **kw)
+    ref, _ = O.langevin_dynamics_sample_diffusion(sd2, cfg2, at, pos_init, bi, bt, ba, int(ba.max()) + 1, False, noise=noise, **kw)
+    check_close("mlp_act %s sampler pos" % act, pos.cpu().numpy(), ref.numpy(), precision)
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("case", SAMPLER_CASES)
 def test_sampler_matches_reference_golden(case, precision):
     g = load_golden(case)
@@ -595,16 +622,16 @@ def test_default_initialised_weights(precision):
 
 
 def _scaled_relu_chains(sd, f):
-    """The synthetic checkpoint with both heads' hidden layers times f and, in every GIN layer, the first matrix times f and
-    the second divided by f (both names of every tensor: attribute path and ModuleList alias)."""
+    """The synthetic checkpoint with both heads' hidden layers times f and, in every GIN layer, the first layer times f and
+    the second matrix divided by f (both names of every tensor: attribute path and ModuleList alias)."""
     from agdiff_amd import synth
     out = {}
     for k, v in sd.items():
         c = synth.canonical_key(k)
         if c.endswith((".layers.0.weight", ".layers.1.weight")) and "dist_mlp" in c:
             v = v * f
-        elif "encoder_local.convs" in c and c.endswith("nn.layers.0.weight"):
-            v = v * f
+        elif "encoder_local.convs" in c and c.endswith(("nn.layers.0.weight", "nn.layers.0.bias")):
+            v = v * f                  # (weight AND bias: with the second matrix divided by f the layer computes what it did)
         elif "encoder_local.convs" in c and c.endswith("nn.layers.1.weight"):
             v = v / f
         out[k] = v.clone()

@@ -66,6 +66,23 @@ def test_forward_g3(case):
         assert np.abs(g["emb_rows_after"] - g["emb_rows_before"]).max() > 1e-3
 
 
+MLP_ACTS = ["gelu", "silu", "tanh", "sigmoid", "softplus", "leaky_relu", "elu"]
+
+
+@pytest.mark.parametrize("act", MLP_ACTS)
+def test_forward_other_mlp_act_g15(act):
+    """config.mlp_act other than relu (models/common.py:62-66: getattr(F, name) between the heads' layers): the reference's
+    forward on a small QM9-shaped batch per activation, heads at full scale."""
+    from helpers import qm9_model_config
+    g = load_golden("g15_forward_act_" + act)
+    cfg = qm9_model_config(mlp_act=act)
+    sd = O.synth_state_dict_for(cfg, head_scale=1.0)
+    out = O.forward(sd, cfg, t(g["atom_type"]), t(g["pos"]), t(g["bond_index"]), t(g["bond_type"]), t(g["batch"]), extend_order=False)
+    assert np.array_equal(out[2].numpy(), g["edge_index"]) and np.array_equal(out[3].numpy(), g["edge_type"])
+    assert rel_err(out[0].numpy(), g["edge_inv_global"]) < TOL
+    assert rel_err(out[1].numpy(), g["edge_inv_local"]) < TOL
+
+
 def test_forward_stage_modules_g2():
     g = load_golden("g3_forward_qm9_small")
     cfg = FORWARD_CASES["g3_forward_qm9_small"]()
