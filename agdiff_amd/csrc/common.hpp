@@ -572,6 +572,40 @@ __device__ __forceinline__ void ag_poly_features(float d, float two_over_rc, int
   }
 }
 
+// The same for the TWO scaled feature sets a CFConv tile needs (conv1's rows scaled by s1, conv2's by s2) at one k-tile under
+// agdiff_params_t.poly_plan 1 (MIXED), sharing everything that does not depend on the scale: the recurrence, the lane's two
+// Chebyshev factors and the selects.  The selects are written on values that are already computed (and opaque to the optimiser):
+// left to itself it sinks T16 / T24 into the arms of `q == k ? ... : ...` and emits divergent branches -- ~45 of the ~125 VALU
+// instructions the two calls of ag_poly_features cost per tile.  Bit-identical to two calls of ag_poly_features<MODE, 1, true>.
+template <int MODE>
+__device__ __forceinline__ void ag_poly_features2_mixed(float d, float two_over_rc, int q, AgIn<MODE>& o1, float s1, AgIn<MODE>& o2, float s2) {
+  static_assert(MODE != AG_F32, "mixed operand: split modes");
+  const float x = fminf(fmaxf(fmaf(d, two_over_rc, -1.0f), -1.0f), 1.0f);
+  const float x2 = x + x;
+  float T[9];
+  T[0] = 1.0f;
+  T[1] = x;
+#pragma unroll
+  for (int n = 2; n <= 8; ++n) T[n] = fmaf(x2, T[n - 1], -T[n - 2]);
+  float t8 = T[8];
+  float g2 = fmaf(t8 + t8, t8, -1.0f);             // T16
+  float g3 = fmaf(g2 + g2, t8, -t8);               // T24
+  asm volatile("" : "+v"(t8), "+v"(g2), "+v"(g3));
+  float G = 1.0f;
+  G = (q == 1) ? t8 : G;
+  G = (q == 2) ? g2 : G;
+  G = (q == 3) ? g3 : G;
+  float Gm = (q & 1) ? t8 : 1.0f;                  // T_{8 (q & 1)}: the lane's own factor in quarters 0, 1
+  asm volatile("" : "+v"(G), "+v"(Gm));
+  const float own = (q < 2) ? 1.0f : 0.0f;
+  const float a1 = G * s1, b1 = Gm * s1, a2 = G * s2, b2 = Gm * s2;
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    ag_cvt_pair_mixed(o1, j, a1 * T[j], a1 * T[j + 1], b1 * T[j], b1 * T[j + 1], own);
+    ag_cvt_pair_mixed(o2, j, a2 * T[j], a2 * T[j + 1], b2 * T[j], b2 * T[j + 1], own);
+  }
+}
+
 // global -> LDS copy of n 16-byte units by the whole workgroup (weights that stay resident for a launch or a phase).
 // The loads of U units per thread are issued back to back and stored afterwards: the plain loop `dst[i] = src[i]`
 // compiles to load, s_waitcnt vmcnt(0), ds_write per iteration -- one exposed L2 round trip per 16 bytes and thread,

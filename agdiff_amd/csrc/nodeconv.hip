@@ -103,6 +103,9 @@ struct NodeConvShape {
 #ifndef AG_QUAD_WAHEAD
 #define AG_QUAD_WAHEAD 1       // k_cfconv_quad: coefficient blocks read one group ahead of their MFMAs
 #endif
+#ifndef AG_QUAD_FEATURES2
+#define AG_QUAD_FEATURES2 1    // k_cfconv_quad: both feature sets of a tile from one routine (ag_poly_features2_mixed)
+#endif
 #ifndef AG_QUAD_STORE_NT
 #define AG_QUAD_STORE_NT 1
 #endif
@@ -599,8 +602,12 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_quad(NodeConvA
   };
   auto next_features = [&]() {
     const float s1 = pf_dead ? 0.0f : pf_s1, s2 = pf_dead ? 0.0f : pf_s2;
-    ag_poly_features<MODE, NKT, MIXED>(pf_d, a.two_over_rc, q, ph1, s1);
-    ag_poly_features<MODE, NKT, MIXED>(pf_d, a.two_over_rc, q, ph2, s2);
+    if constexpr (MIXED && AG_QUAD_FEATURES2) {
+      ag_poly_features2_mixed<MODE>(pf_d, a.two_over_rc, q, ph1[0], s1, ph2[0], s2);
+    } else {
+      ag_poly_features<MODE, NKT, MIXED>(pf_d, a.two_over_rc, q, ph1, s1);
+      ag_poly_features<MODE, NKT, MIXED>(pf_d, a.two_over_rc, q, ph2, s2);
+    }
   };
   float acc[AG_CONV_NCH];
 

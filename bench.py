@@ -44,7 +44,7 @@ FLOP_PER_EDGE_CFCONV = 2 * (128 * 192 + 128 * 128 + 64 * 64)     # filter MLP of
 PEAK = {"f32": 157.3, "bf16x3": 2500.0, "f16x3": 2500.0}      # dense MFMA TFLOP/s (f32-input MFMA; bf16 MFMA), MI355X_MICROARCH.md
 HBM_PEAK_GBPS = 8000.0
 MFMA_PASSES = {"f32": 1, "bf16x3": 3, "f16x3": 3}        # MFMA FLOPs issued per algorithmic FLOP
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 
 def build_batch(kind, mols, copies, seed):
@@ -592,7 +592,9 @@ def main():
         ref_priced = prof_flop / t_s / 1e12          # the REFERENCE's arithmetic for this op over the measured time
         pk_ = PEAK[args.precision]
         e_avg = prof_edges / prof_n
-        kern = ["k_cfconv_node"] if (node_path and local_poly) else (["k_cfconv_node", "k_cfconv_fused"] if node_path else ["k_cfconv_fused"])
+        quad_tiles = bool(int(ws.variant_log.item()) & _lib.DEFINES["AGDIFF_VAR_CFCONV_NODE_QUAD"])
+        kname = "k_cfconv_quad" if quad_tiles else "k_cfconv_node"
+        kern = [kname] if (node_path and local_poly) else ([kname, "k_cfconv_fused"] if node_path else ["k_cfconv_fused"])
         pmc = load_pmc(args.precision, e_avg, kern)
         passes = MFMA_PASSES[args.precision]
         n_avg = e_avg / max(E, 1) * topo.N
@@ -610,8 +612,9 @@ def main():
             mfma_ct = pk.poly_kt * passes if not pk.poly_plan else (2 if pk.poly_kt == 1 else 4)
             issued = prof_edges * 192 * 32 * 2 * mfma_ct / t_s / 1e12
             executed = issued * (pads_info["rows_executed"] / max(pads_info["rows_live"], 1) if pads_info else 1.0)
-            kernel = ("k_cfconv_node<NKT=%d> (one launch per InteractionBlock: radius rows by target%s)"
-                      % (pk.poly_kt, " + local quad tiles, %d local types" % pk.struct.poly_num_slots if local_poly
+            kernel = ("%s<NKT=%d> (one launch per InteractionBlock: radius rows %s%s)"
+                      % (kname, pk.poly_kt, "in quad tiles" if quad_tiles else "by target",
+                         " + local quad tiles, %d local types" % pk.struct.poly_num_slots if local_poly
                          else "; local edges through k_cfconv_fused on the padded local list, second launch"))
             # issue-slot model of one SIMD: an MFMA holds the issue port 8 cycles, any other VALU instruction 4 (wave64 on 16
             # lanes); VALU / tile from the SQ counter pass when one was taken on this workload
@@ -633,8 +636,7 @@ def main():
                     "command) against the dense bf16 MFMA peak.  executed_mfma_frac adds the pad rows.  reference_priced_* is the "
                     "figure rounds 1-3 reported as frac: the REFERENCE's arithmetic for this op (it evaluates the 128->192->192 "
                     "filter network on every directed edge: E x 90,112 FLOP per block, SURVEY 8d) over the same time -- work this "
-                    "kernel does not execute.  The kernel is a balanced wave program (VALU issue ~50 %%, matrix pipe ~28 %%, "
-                    "L1 gathers, LDS coefficient reads; DESIGN.md 4b): issue_model prices its instruction stream" % PROFILE_ROUND)
+                    "kernel does not execute.  issue_model prices its instruction stream (SQ counters of profiles/%s_*_pmc.json)" % (PROFILE_ROUND, PROFILE_ROUND))
             ach = issued
         else:
             kernel = "k_cfconv_fused"

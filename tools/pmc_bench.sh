@@ -10,7 +10,7 @@ mkdir -p $out
 tmp=$(mktemp -d /tmp/pmcbench.XXXXXX)
 cd /tmp && export TMPDIR=/tmp
 i=0
-for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_LDS" "SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS"; do
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_LDS" "SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" "SQ_WAIT_ANY SQ_INST_LEVEL_VMEM TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum"; do
   i=$((i+1))
   echo "$(date +%T) pmc pass $i start: $set" | tee -a $GRAFT_REPO_ROOT/gpurun_out/pmc_progress.txt
   timeout -k 10 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $tmp/set$i -- python3 $GRAFT_REPO_ROOT/bench.py --precision $PREC --steps 1 --warmup 1 --no-cpu-baseline --no-traj --no-extra > $tmp/bench$i.json 2>/dev/null
@@ -19,7 +19,7 @@ done
 python3 - <<PY
 import csv, glob, collections, json
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-names = ("k_cfconv_node", "k_cfconv_fused", "k_sampler_front", "k_schnet_node_stage", "k_pair_head_poly", "k_pair_head", "k_gin_layer",
+names = ("k_cfconv_quad", "k_cfconv_node", "k_cfconv_fused", "k_sampler_front", "k_schnet_node_stage", "k_pair_head_poly", "k_pair_head", "k_gin_layer",
          "k_gin_gather", "k_edge_attr_poly", "k_edge_encoder")
 for f in glob.glob("$tmp/set*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
@@ -56,7 +56,7 @@ with open("$out/${R}_${PREC}_pmc.txt", "w") as txt:
                 e["valu_issue_busy"] = 4 * m["SQ_ACTIVE_INST_VALU"] / cyc
             if "SQ_VALU_MFMA_BUSY_CYCLES" in m:
                 e["mfma_pipe_busy"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / cyc
-        if k == "k_cfconv_node" and edges and "SQ_INSTS_VALU" in m:
+        if k in ("k_cfconv_node", "k_cfconv_quad") and edges and "SQ_INSTS_VALU" in m:
             e["valu_per_tile"] = (m["SQ_INSTS_VALU"] - m.get("SQ_INSTS_MFMA", 0)) / (edges / 16)
             e["lds_per_tile"] = m.get("SQ_INSTS_LDS", 0) / (edges / 16)
         rec["kernels"][k] = e
