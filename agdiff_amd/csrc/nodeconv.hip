@@ -101,7 +101,7 @@ struct NodeConvShape {
 #define AG_QUAD_META_NT 0     // radius rows' inputs of k_cfconv_quad: 1 non-temporal loads (as k_cfconv_node), 0 cached
 #endif
 #ifndef AG_QUAD_WAHEAD
-#define AG_QUAD_WAHEAD 1       // k_cfconv_quad: coefficient blocks read one group ahead of their MFMAs
+#define AG_QUAD_WAHEAD 0       // k_cfconv_quad: 1 = coefficient blocks read one group ahead of their MFMAs (measured: no gain, 2 spills)
 #endif
 #ifndef AG_QUAD_FEATURES2
 #define AG_QUAD_FEATURES2 1    // k_cfconv_quad: both feature sets of a tile from one routine (ag_poly_features2_mixed)

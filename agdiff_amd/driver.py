@@ -55,6 +55,14 @@ def load_testset(path):
     return mols
 
 
+def sharded_capacity(max_atoms, world):
+    """Atoms of one global batch that `world` ranks share by contiguous graph ranges (dist.shard_graphs balances EDGES, so the
+    ranks' atom counts differ by a few per cent: profiles/r05_shard_balance.json): 3 % below max_atoms x world, so that no rank's
+    share crosses max_atoms -- 196,608 by default = three full rounds of the node kernels' workgroups; a rank 2 % above it ran a
+    fourth round and 4 % longer than its peers."""
+    return max_atoms * world if world <= 1 else int(max_atoms * world * 0.97)
+
+
 def plan_batches(mols, confs_of, max_atoms):
     """First-fit decreasing: molecules sorted by their atom count x conformers (largest first), each put into the first
     batch it still fits into (a molecule larger than `max_atoms` gets a batch of its own).  Packing in input order
@@ -265,7 +273,7 @@ def run_job(model, mols, out_dir, confs_of, max_atoms, sampler_kwargs, device, s
             dist.broadcast_object_list(box, src=0)
         done = set(box[0])
     mols = [m for m in mols if m["index"] not in done]
-    batches = plan_batches(mols, confs_of, max_atoms * (world if shard else 1))
+    batches = plan_batches(mols, confs_of, sharded_capacity(max_atoms, world) if shard else max_atoms)
     for bidx, bmols in enumerate(batches):
         if not shard and bidx % world != rank:
             continue

@@ -206,8 +206,14 @@ class DualEncoderEpsNetwork(nn.Module):
             alphas = (1.0 - betas).cumprod(dim=0)
             self.alphas = nn.Parameter(alphas, requires_grad=False)
             self.num_timesteps = self.betas.size(0)
-        else:
-            raise NotImplementedError("model type %r: only 'diffusion' is on the HIP path" % (self.model_type,))
+        elif self.model_type == "dsm":
+            # denoising score matching (dualenc.py:127-140): the noise levels as a parameter; forward() does not depend on the type,
+            # and the reference's samplers handle 'diffusion' only (langevin_dynamics_sample returns None for 'dsm', dualenc.py:418)
+            sigmas = torch.tensor(np.exp(np.linspace(np.log(config.sigma_begin), np.log(config.sigma_end), config.num_noise_level)),
+                                  dtype=torch.float32)
+            self.sigmas = nn.Parameter(sigmas, requires_grad=False)
+            self.num_timesteps = self.sigmas.size(0)
+        # (any other type: the reference builds the module without a schedule, dualenc.py:110-140; so does this)
         # arithmetic of the HIP kernels: "f32" = exact fp32 MFMA; "bf16x3" = split-bf16 MFMA (hi+lo operands,
         # three passes, fp32 accumulation, ~2^-16 relative per product).  Both meet the 1e-4 parity bar.
         # (config field or attribute; nothing is read from the environment)
@@ -373,6 +379,10 @@ class DualEncoderEpsNetwork(nn.Module):
     # ------------------------------------------------------------------ forward (dualenc.py:142-251)
     def forward(self, atom_type, pos, bond_index, bond_type, batch, time_step, edge_index=None, edge_type=None,
                 edge_length=None, return_edges=False, extend_order=True, extend_radius=True):
+        if self.model_type != "diffusion":
+            # dualenc.py:184-186,210: sigma_edge is only bound for 'diffusion'; the reference's forward raises UnboundLocalError
+            raise NotImplementedError("forward() of a %r model: the reference's own forward fails for this type "
+                                      "(sigma_edge undefined, dualenc.py:184-210); only 'diffusion' computes" % (self.model_type,))
         lib = self._require_gpu()
         if edge_index is not None and edge_type is not None and edge_length is not None:
             return self._forward_given_graph(lib, atom_type, pos, batch, edge_index, edge_type, edge_length, return_edges)

@@ -52,11 +52,11 @@ def _u(key, shape, lo, hi, salt=0):
 
 def synth_tensor(key, shape, head_scale=1e-3):
     """Closed-form value for one state_dict entry, or None to keep the module's own value
-    (betas / alphas / num_batches_tracked / GIN eps / rbf.offset)."""
+    (betas / alphas / the dsm sigmas / num_batches_tracked / GIN eps / rbf.offset)."""
     key = canonical_key(key)
     shape = tuple(shape)
     leaf = key.split(".")[-1]
-    if key in ("betas", "alphas") or leaf in ("num_batches_tracked", "eps", "offset"):
+    if key in ("betas", "alphas", "sigmas") or leaf in ("num_batches_tracked", "eps", "offset"):
         return None
     if leaf == "running_var":
         return _u(key, shape, 0.6, 1.4)

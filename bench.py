@@ -504,7 +504,7 @@ def main():
         # (weak: every rank takes the SAME 200 molecules -- the number of batches, hence of collectives, must agree over the
         # ranks -- with its own initial positions and noise: seed + rank in timed_run)
         mols200, confs_of = drugs200_job(args.seed)
-        batches = driver.plan_batches(mols200, confs_of, args.max_atoms * (world if strong else 1))
+        batches = driver.plan_batches(mols200, confs_of, driver.sharded_capacity(args.max_atoms, world) if strong else args.max_atoms)
         G_job = sum(confs_of(m["num_refs"]) for m in mols200)
         tot_ms, G_local, per_batch, global_frac, run, (prof_ms, prof_n, prof_flop, prof_edges) = run_job(
             model, cfg, batches, confs_of, args.schedule, skip, W, K, profile)
@@ -515,7 +515,7 @@ def main():
               "(scripts/test.py:40-61,130-141), %d packed batches of <= %d atoms%s (this rank: %d batches, %d atoms, %d edges), "
               "%d warm-up + %d timed steps per batch, %s schedule, global branch active on %.0f%% of timed steps; "
               "ms_per_step = one step of every batch"
-              % (G_job, len(batches), args.max_atoms * (world if strong else 1),
+              % (G_job, len(batches), driver.sharded_capacity(args.max_atoms, world) if strong else args.max_atoms,
                  " cut into per-rank graph ranges" if strong else (" -- one such job per rank" if world > 1 else ""), len(per_batch), sum(r["atoms"] for r in per_batch),
                  sum(r["edges"] for r in per_batch), W, K, args.schedule, 100 * global_frac))
     else:

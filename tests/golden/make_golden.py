@@ -332,6 +332,28 @@ def g_mlp_act():
              edge_inv_global=out[0], edge_inv_local=out[1], edge_index=out[2], edge_type=out[3])
 
 
+def g_dsm():
+    """config.type 'dsm' (dualenc.py:127-140): the module carries `sigmas` instead of betas / alphas; forward() is the same
+    function of the weights (it never looks at the type).  Key list + one forward."""
+    cfg = qm9_model_config(type="dsm", sigma_begin=10.0, sigma_end=0.01, num_noise_level=50)
+    m = build_ref(cfg)
+    with open(os.path.join(HERE, "g7_state_dict_keys_dsm.txt"), "w") as f:
+        for k, v in m.state_dict().items():
+            f.write("%s %s %s\n" % (k, "x".join(map(str, v.shape)) or "-", str(v.dtype).replace("torch.", "")))
+    b, pos = small_batch("qm9", 61, 2, 2, 1.5)
+    at, bi, bt, ba = T(b["atom_type"]), T(b["bond_index"]), T(b["bond_type"]), T(b["batch"])
+    # the reference's forward does not run for this type: sigma_edge is only defined for 'diffusion' (dualenc.py:184-186, 210)
+    try:
+        with torch.no_grad():
+            m(at, pos, bi, bt, ba, None, return_edges=True, extend_order=False, extend_radius=True)
+        fwd = "ok"
+    except UnboundLocalError as e:
+        fwd = "UnboundLocalError"
+    none = m.langevin_dynamics_sample(at, pos, bi, bt, ba, 4, False, n_steps=2)
+    assert none is None
+    save("g16_dsm", sigmas=m.sigmas, num_timesteps=m.num_timesteps, forward=np.str_(fwd))
+
+
 def g_extend_order_forward():
     """§8f-1 on the model path: RAW bonds + extend_order=True (forward's default, dualenc.py:153,167-177 ->
     _extend_graph_order, common.py:135-205, applied to the whole batch) for one forward and one sampler run."""
@@ -439,10 +461,10 @@ def g_losses():
 
 
 if __name__ == "__main__":
-    if sys.argv[1:] and all(a in ("gaussian", "alanine", "loss", "variants", "extend", "covmat", "restoring", "mlp_act") for a in sys.argv[1:]):   # add without touching the others
+    if sys.argv[1:] and all(a in ("gaussian", "alanine", "loss", "variants", "extend", "covmat", "restoring", "mlp_act", "dsm") for a in sys.argv[1:]):   # add without touching the others
         for a in sys.argv[1:]:
             {"gaussian": g_gaussian, "alanine": g_alanine, "loss": g_losses, "variants": g_forward_variants,
-             "extend": g_extend_order_forward, "covmat": g_covmat, "restoring": g_restoring, "mlp_act": g_mlp_act}[a]()
+             "extend": g_extend_order_forward, "covmat": g_covmat, "restoring": g_restoring, "mlp_act": g_mlp_act, "dsm": g_dsm}[a]()
         sys.exit(0)
     g_schedule_and_keys()
     # G2+G3 uncapped QM9-shaped batch with per-stage outputs (small: 3 molecules x 1 copy)
@@ -469,3 +491,4 @@ if __name__ == "__main__":
     g_covmat()
     g_restoring()
     g_mlp_act()
+    g_dsm()

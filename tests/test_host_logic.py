@@ -35,6 +35,27 @@ def test_state_dict_layout_matches_reference_g7(enc, fname, nkeys):
         assert abs(m.edge_encoder_global.rbf.coeff - (-4.9612)) < 1e-3
 
 
+def test_dsm_model_type_layout_g16():
+    """config.type 'dsm' (dualenc.py:127-140): the module carries `sigmas` (exp of a log-linear grid) instead of betas / alphas --
+    853 keys in the reference's order --, langevin_dynamics_sample returns None for it (dualenc.py:418: only 'diffusion' is
+    handled), and the reference's own forward() does not run for the type (UnboundLocalError, dualenc.py:184-186,210: recorded in
+    the fixture), so forward() here refuses with a message instead of inventing semantics."""
+    cfg = qm9_model_config(type="dsm", sigma_begin=10.0, sigma_end=0.01, num_noise_level=50)
+    m = get_model(cfg)
+    sd = m.state_dict()
+    ref = [l.split() for l in open(os.path.join(GOLDEN, "g7_state_dict_keys_dsm.txt"))]
+    assert len(sd) == len(ref) == 853
+    for (k, v), (rk, rshape, rdt) in zip(sd.items(), ref):
+        assert k == rk and ("x".join(map(str, v.shape)) or "-") == rshape and str(v.dtype).replace("torch.", "") == rdt, k
+    g = np.load(os.path.join(GOLDEN, "g16_dsm.npz"))
+    assert m.num_timesteps == int(g["num_timesteps"]) and np.array_equal(m.sigmas.detach().numpy(), g["sigmas"])
+    assert str(g["forward"]) == "UnboundLocalError"
+    z = torch.zeros(4, dtype=torch.long)
+    assert m.langevin_dynamics_sample(z, torch.zeros(4, 3), torch.zeros(2, 0, dtype=torch.long), z[:0], z, 1, False) is None
+    with pytest.raises(NotImplementedError, match="dsm"):
+        m(z, torch.zeros(4, 3), torch.zeros(2, 0, dtype=torch.long), z[:0], z, None)
+
+
 def test_factory_errors():
     with pytest.raises(NotImplementedError):
         get_model(qm9_model_config(network="nope"))

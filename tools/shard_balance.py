@@ -64,7 +64,7 @@ for i in range(1000):
     at_, r_, c_, t_ = synth.random_molecule(rng, synth.sample_n_atoms(rng, "drugs"))
     mols.append(dict(atom_type=at_, edge_index=np.stack([r_, c_]), edge_type=t_, num_refs=int(rng.integers(50, 501)), name="m%d" % i, index=i))
 confs_of = driver.num_confs("2x")
-batches = driver.plan_batches(mols, confs_of, args.max_atoms * world)
+batches = driver.plan_batches(mols, confs_of, driver.sharded_capacity(args.max_atoms, world))
 model, cfg = model_for("drugs")
 order = sorted(range(len(batches)), key=lambda i: sum(len(m["atom_type"]) * confs_of(m["num_refs"]) for m in batches[i]))
 out["configs3_drugs_1000"] = {"global_batches": len(batches), "max_atoms_per_global_batch": args.max_atoms * world, "measured": {}}
