@@ -590,6 +590,11 @@ class LangevinRun:
             self.pos = (pos_init.detach().to(dev, torch.float32) * self.sigmas[-1].to(dev)).contiguous()
         N = self.topo.N
         self.traj = torch.empty((len(self.steps), N, 3), dtype=torch.float32, device=dev) if save_traj else None
+        # The trajectory goes to the host WHILE the run samples (the reference copies every step: pos_traj.append(pos.clone().cpu()),
+        # dualenc.py:545): at every poll the steps finished since the last one are copied device -> pinned staging buffer on a side
+        # stream and from there into the host tensor finish() returns -- one 11.8 GB pageable copy at the end of a 196 k-atom job
+        # took 1.1 s (4 % of the job; profiles/r05_f16x3_bench.json: extra.full_jobs)
+        self._traj_host, self._traj_sent, self._traj_pending, self._traj_stage, self._traj_stream = None, 0, None, None, None
         self.noise, self.on_step = noise, on_step
         self.step_lr, self.global_start_sigma = step_lr, global_start_sigma
         self.skip_discarded, self.nan_every = bool(skip_discarded_global), int(nan_check_every)
@@ -759,6 +764,8 @@ class LangevinRun:
         taken out of the run like diverged ones -- their positions are set to NaN, which the next update quarantines and flags
         per graph (nan_graphs) -- and recorded in `range_graphs`, so that the driver re-samples exactly those molecules in
         split-bf16 (fp32's range) while the others run on."""
+        self._traj_land()                    # (before the first synchronisation: the device still has the interval's steps queued)
+        self._traj_send(self.k)
         if self.raise_on_nan and int(self.ws.nan_flag[0].item()) != 0:
             print("NaN detected. Please restart.")
             raise FloatingPointError()
@@ -773,6 +780,39 @@ class LangevinRun:
                 rows = torch.isin(self.topo.batch64, torch.as_tensor(graphs, device=self.topo.batch64.device))
                 self.pos[rows] = float("nan")
 
+    def _traj_land(self):
+        """The chunk whose device -> pinned copy was issued at the last poll: pinned -> the host tensor (a host memcpy: called where
+        the host is about to block on the device anyway, with the steps of the next interval already enqueued)."""
+        if self._traj_pending is not None:
+            ev, lo, hi, buf = self._traj_pending
+            ev.synchronize()
+            self._traj_host[lo:hi].copy_(buf[:hi - lo])
+            self._traj_pending = None
+
+    def _traj_send(self, upto):
+        """Steps [_traj_sent, upto) of the device trajectory -> pinned staging on the side stream (see __init__)."""
+        if self.traj is None or upto <= self._traj_sent:
+            return
+        if self._traj_host is None:
+            self._traj_host = torch.empty((len(self.steps),) + tuple(self.traj.shape[1:]), dtype=torch.float32)
+            chunk = max(1, min(len(self.steps), max(self.nan_every, 1)))
+            self._traj_stage = [torch.empty((chunk,) + tuple(self.traj.shape[1:]), dtype=torch.float32, pin_memory=True) for _ in range(2)]
+            self._traj_stream = torch.cuda.Stream(device=self.traj.device)
+        chunk = self._traj_stage[0].shape[0]
+        while self._traj_sent < upto:
+            self._traj_land()
+            lo, hi = self._traj_sent, min(upto, self._traj_sent + chunk)
+            buf = self._traj_stage[(lo // chunk) & 1]
+            ready = torch.cuda.Event()
+            ready.record()                                  # the steps up to `hi` are enqueued on the compute stream
+            with torch.cuda.stream(self._traj_stream):
+                self._traj_stream.wait_event(ready)
+                buf[:hi - lo].copy_(self.traj[lo:hi], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self._traj_stream)
+            self._traj_pending = (ev, lo, hi, buf)
+            self._traj_sent = hi
+
     def nan_graphs(self):
         """Bool tensor [G] (host): graphs in which a position became NaN so far (ws.nan_flag[1 + g]) or that left the
         split-fp16 range (range_graphs: also when that showed at the very last poll, after the last update)."""
@@ -784,7 +824,10 @@ class LangevinRun:
     def finish(self):
         """(pos on device, pos_traj list of CPU tensors) as dualenc.py:547 returns them."""
         self.check_nan()
-        pos_traj = list(self.traj[:self.k].cpu().unbind(0)) if self.traj is not None else []
+        if self.traj is not None:
+            self._traj_send(self.k)
+            self._traj_land()
+        pos_traj = list(self._traj_host[:self.k].unbind(0)) if self.traj is not None else []
         return self.pos, pos_traj
 
 
