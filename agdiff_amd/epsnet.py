@@ -594,7 +594,11 @@ class LangevinRun:
         # dualenc.py:545): at every poll the steps finished since the last one are copied device -> pinned staging buffer on a side
         # stream and from there into the host tensor finish() returns -- one 11.8 GB pageable copy at the end of a 196 k-atom job
         # took 1.1 s (4 % of the job; profiles/r05_f16x3_bench.json: extra.full_jobs)
+        # (only where it pays: a poll interval's chunk of >= 16 MiB, i.e. batches of ~22 k atoms or more at 64 steps per poll.  On a
+        # 4,300-atom batch -- the reference driver's one-molecule calls, a launch-bound 0.32 ms step -- the side-stream copies made
+        # every poll 13 ms longer (tools/poll_probe.py), while its whole trajectory is a 0.1 s copy at the end)
         self._traj_host, self._traj_sent, self._traj_pending, self._traj_stage, self._traj_stream = None, 0, None, None, None
+        self._traj_overlap = save_traj and max(self.nan_every, 1) * N * 12 >= (16 << 20)
         self.noise, self.on_step = noise, on_step
         self.step_lr, self.global_start_sigma = step_lr, global_start_sigma
         self.skip_discarded, self.nan_every = bool(skip_discarded_global), int(nan_check_every)
@@ -791,7 +795,7 @@ class LangevinRun:
 
     def _traj_send(self, upto):
         """Steps [_traj_sent, upto) of the device trajectory -> pinned staging on the side stream (see __init__)."""
-        if self.traj is None or upto <= self._traj_sent:
+        if self.traj is None or upto <= self._traj_sent or not self._traj_overlap:
             return
         if self._traj_host is None:
             self._traj_host = torch.empty((len(self.steps),) + tuple(self.traj.shape[1:]), dtype=torch.float32)
@@ -824,10 +828,12 @@ class LangevinRun:
     def finish(self):
         """(pos on device, pos_traj list of CPU tensors) as dualenc.py:547 returns them."""
         self.check_nan()
-        if self.traj is not None:
+        if self.traj is not None and self._traj_overlap:
             self._traj_send(self.k)
             self._traj_land()
-        pos_traj = list(self._traj_host[:self.k].unbind(0)) if self.traj is not None else []
+            pos_traj = list(self._traj_host[:self.k].unbind(0))
+        else:
+            pos_traj = list(self.traj[:self.k].cpu().unbind(0)) if self.traj is not None else []
         return self.pos, pos_traj
 
 
