@@ -550,6 +550,8 @@ class DualEncoderEpsNetwork(nn.Module):
                            "per_step": one torch.randn_like(pos) per step, exactly the reference's call (dualenc.py:529):
                            with equal seeds and equal generator state the SAME normals as the reference draws on this
                            device, hence seed-for-seed comparable runs (one small launch more per step)
+          traj_overlap_min_bytes  the trajectory goes to the host while the run samples when a poll interval's chunk
+                           (nan_check_every x N x 12 B) is at least this large (default 16 MiB); else one copy at the end
         """
         run = self.begin_sampling(atom_type, pos_init, bond_index, bond_type, batch, num_graphs, extend_order,
                                   extend_radius, n_steps, step_lr, clip, clip_local, clip_pos, global_start_sigma,
@@ -574,7 +576,7 @@ class LangevinRun:
     def __init__(self, model, atom_type, pos_init, bond_index, bond_type, batch, num_graphs, extend_order,
                  n_steps, step_lr, clip, clip_local, clip_pos, global_start_sigma, w_global, noise=None,
                  save_traj=True, skip_discarded_global=True, nan_check_every=64, step_indices=None, on_step=None,
-                 extend_radius=True, raise_on_nan=True, noise_mode="chunked", **_ignored):
+                 extend_radius=True, raise_on_nan=True, noise_mode="chunked", traj_overlap_min_bytes=16 << 20, **_ignored):
         self.model, self.lib = model, _lib.load()
         dev = model._device()
         self.sigmas = ((1.0 - model.alphas).sqrt() / model.alphas.sqrt()).detach().cpu()
@@ -598,7 +600,7 @@ class LangevinRun:
         # 4,300-atom batch -- the reference driver's one-molecule calls, a launch-bound 0.32 ms step -- the side-stream copies made
         # every poll 13 ms longer (tools/poll_probe.py), while its whole trajectory is a 0.1 s copy at the end)
         self._traj_host, self._traj_sent, self._traj_pending, self._traj_stage, self._traj_stream = None, 0, None, None, None
-        self._traj_overlap = save_traj and max(self.nan_every, 1) * N * 12 >= (16 << 20)
+        self._traj_overlap = save_traj and max(self.nan_every, 1) * N * 12 >= int(traj_overlap_min_bytes)
         self.noise, self.on_step = noise, on_step
         self.step_lr, self.global_start_sigma = step_lr, global_start_sigma
         self.skip_discarded, self.nan_every = bool(skip_discarded_global), int(nan_check_every)

@@ -146,6 +146,27 @@ def test_forward_matches_reference_golden(case, precision):
     assert len(two) == 2 and np.array_equal(two[0].cpu().numpy(), inv_g)
 
 
+def test_trajectory_copied_while_sampling_equals_the_copy_at_the_end():
+    """LangevinRun sends the trajectory to the host at every poll (pinned staging on a side stream) when a poll interval's chunk
+    is >= 16 MiB; forced onto a small fixture (traj_overlap_min_bytes = 0, polls every 3 steps, 14 steps: full and partial chunks,
+    both staging buffers) it must return the same bits as the single copy at the end, entry by entry."""
+    g = load_golden(SAMPLER_CASES[0])
+    cfg = sampler_case_cfg(g, SAMPLER_CASES[0])
+    m, _ = _gpu_model(cfg, head_scale=float(g["head_scale"]))
+    kw = sampler_case_kwargs(g)
+    args = (t(g["atom_type"]).cuda(), t(g["pos_init"]).cuda(), t(g["bond_index"]).cuda(), t(g["bond_type"]).cuda(),
+            t(g["batch"]).cuda(), int(g["num_graphs"]))
+    n = int(g["n_steps"])
+    outs = []
+    for min_bytes in (1 << 40, 0):
+        pos, traj = m.langevin_dynamics_sample_diffusion(*args, extend_order=False, n_steps=n, noise=t(g["noise"]).cuda(),
+                                                         nan_check_every=3, traj_overlap_min_bytes=min_bytes, **kw)
+        assert len(traj) == n and all(not x.is_cuda for x in traj)
+        outs.append((pos.cpu(), torch.stack(traj)))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[1][1][-1], outs[1][0])
+
+
 @pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("act", ["gelu", "silu", "tanh", "sigmoid", "softplus", "leaky_relu", "elu"])
 def test_forward_other_mlp_act_matches_reference_golden(act, precision):
