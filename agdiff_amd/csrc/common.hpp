@@ -546,20 +546,38 @@ __device__ __forceinline__ void ag_poly_features(float d, float two_over_rc, int
   T[1] = x;
 #pragma unroll
   for (int n = 2; n <= 8; ++n) T[n] = fmaf(x2, T[n - 1], -T[n - 2]);
-  const float t8 = T[8], t8x2 = t8 + t8;
-  const float g2 = fmaf(t8x2, t8, -1.0f);          // T16
-  const float g3 = fmaf(g2 + g2, t8, -t8);         // T24
+  // (every candidate of the per-quarter selects below is computed first and made opaque: left to itself the optimiser sinks the
+  // evaluation of T16 .. T56 into the arms of `q == k ? ... : ...` and emits divergent branches for them)
+  float t8 = T[8];
+  float g2 = fmaf(t8 + t8, t8, -1.0f);             // T16
+  float g3 = fmaf(g2 + g2, t8, -t8);               // T24
+  asm volatile("" : "+v"(t8), "+v"(g2), "+v"(g3));
   float G[NKT];
-  G[0] = gmask * ((q == 0) ? 1.0f : (q == 1) ? t8 : (q == 2) ? g2 : g3);
+  {
+    float sel = 1.0f;
+    sel = (q == 1) ? t8 : sel;
+    sel = (q == 2) ? g2 : sel;
+    sel = (q == 3) ? g3 : sel;
+    asm volatile("" : "+v"(sel));
+    G[0] = gmask * sel;
+  }
   if constexpr (NKT == 2) {
-    const float g4 = fmaf(g2 + g2, g2, -1.0f);     // T32
-    const float g5 = fmaf(g4 + g4, t8, -g3);       // T40
-    const float g6 = fmaf(g3 + g3, g3, -1.0f);     // T48
-    const float g7 = fmaf(g6 + g6, t8, -g5);       // T56
-    G[1] = gmask * ((q == 0) ? g4 : (q == 1) ? g5 : (q == 2) ? g6 : g7);
+    float g4 = fmaf(g2 + g2, g2, -1.0f);           // T32
+    float g5 = fmaf(g4 + g4, t8, -g3);             // T40
+    float g6 = fmaf(g3 + g3, g3, -1.0f);           // T48
+    float g7 = fmaf(g6 + g6, t8, -g5);             // T56
+    asm volatile("" : "+v"(g4), "+v"(g5), "+v"(g6), "+v"(g7));
+    float sel = g4;
+    sel = (q == 1) ? g5 : sel;
+    sel = (q == 2) ? g6 : sel;
+    sel = (q == 3) ? g7 : sel;
+    asm volatile("" : "+v"(sel));
+    G[1] = gmask * sel;
   }
   if constexpr (MIXED) {
-    const float Gm = gmask * ((q & 1) ? t8 : 1.0f);          // T_{8 (q & 1)}: the lane's own factor in quarters 0, 1
+    float Gsel = (q & 1) ? t8 : 1.0f;                        // T_{8 (q & 1)}: the lane's own factor in quarters 0, 1
+    asm volatile("" : "+v"(Gsel));
+    const float Gm = gmask * Gsel;
     const float own = (q < 2) ? 1.0f : 0.0f;
 #pragma unroll
     for (int j = 0; j < 8; j += 2) ag_cvt_pair_mixed(o[0], j, G[0] * T[j], G[0] * T[j + 1], Gm * T[j], Gm * T[j + 1], own);

@@ -600,7 +600,7 @@ class LangevinRun:
         # 4,300-atom batch -- the reference driver's one-molecule calls, a launch-bound 0.32 ms step -- the side-stream copies made
         # every poll 13 ms longer (tools/poll_probe.py), while its whole trajectory is a 0.1 s copy at the end)
         self._traj_host, self._traj_sent, self._traj_pending, self._traj_stage, self._traj_stream = None, 0, None, None, None
-        self._traj_overlap = save_traj and max(self.nan_every, 1) * N * 12 >= int(traj_overlap_min_bytes)
+        self._traj_overlap = bool(save_traj) and max(int(nan_check_every), 1) * N * 12 >= int(traj_overlap_min_bytes)
         self.noise, self.on_step = noise, on_step
         self.step_lr, self.global_start_sigma = step_lr, global_start_sigma
         self.skip_discarded, self.nan_every = bool(skip_discarded_global), int(nan_check_every)
