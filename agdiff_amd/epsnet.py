@@ -600,6 +600,7 @@ class LangevinRun:
         # 4,300-atom batch -- the reference driver's one-molecule calls, a launch-bound 0.32 ms step -- the side-stream copies made
         # every poll 13 ms longer (tools/poll_probe.py), while its whole trajectory is a 0.1 s copy at the end)
         self._traj_host, self._traj_sent, self._traj_pending, self._traj_stage, self._traj_stream = None, 0, None, None, None
+        self._traj_ready = 0                   # trajectory rows whose writing launch has been enqueued
         self._traj_overlap = bool(save_traj) and max(int(nan_check_every), 1) * N * 12 >= int(traj_overlap_min_bytes)
         self.noise, self.on_step = noise, on_step
         self.step_lr, self.global_start_sigma = step_lr, global_start_sigma
@@ -705,6 +706,8 @@ class LangevinRun:
             # stays alive in `keep`).  With `front_split_graph` the graph phase is launched by the forward, after the fork.
             mode = (1 if k > first else 0) | (2 if (run_global and not pending) else 0) | 4 | (par << 4)
             _lib.check(lib.agdiff_sampler_front(P, T, W, ctypes.byref(a), mode, cutoff, stream), "agdiff_sampler_front")
+            if k > first:
+                self._traj_ready = k          # (the update of step k - 1 -- the launch above -- writes trajectory row k - 1)
             if k > first and self.on_step is not None:
                 self.on_step(k - 1, self.steps[k - 1], self.pos)
             self.global_steps += run_global
@@ -720,6 +723,7 @@ class LangevinRun:
                 self.check_nan()
         if end > first:     # the chunk's last update
             _lib.check(lib.agdiff_sampler_front(P, T, W, ctypes.byref(a), 1, cutoff, stream), "agdiff_sampler_front")
+            self._traj_ready = end
             if self.on_step is not None:
                 self.on_step(end - 1, self.steps[end - 1], self.pos)
             if self.k % self.nan_every == 0 or self.k == len(self.steps):
@@ -757,6 +761,7 @@ class LangevinRun:
                 _lib.check(lib.agdiff_langevin_update(ctypes.byref(topo.struct), ctypes.byref(ws.struct),
                                                       ctypes.byref(a), stream), "agdiff_langevin_update")
                 self.k += 1
+                self._traj_ready = self.k
                 if self.on_step is not None:
                     self.on_step(k, i, self.pos)
                 if self.k % self.nan_every == 0 or self.k == len(self.steps):
@@ -771,7 +776,7 @@ class LangevinRun:
         per graph (nan_graphs) -- and recorded in `range_graphs`, so that the driver re-samples exactly those molecules in
         split-bf16 (fp32's range) while the others run on."""
         self._traj_land()                    # (before the first synchronisation: the device still has the interval's steps queued)
-        self._traj_send(self.k)
+        self._traj_send(self._traj_ready)    # (rows whose update is enqueued: with the fused front the last step's is still pending)
         if self.raise_on_nan and int(self.ws.nan_flag[0].item()) != 0:
             print("NaN detected. Please restart.")
             raise FloatingPointError()
