@@ -811,13 +811,18 @@ struct AttrPolyArgs {
   int32_t* flags;             // [1 + tiles]
   int64_t max_tiles;
   int32_t num_slots;
+  int32_t far_slots;          // far sets behind the num_slots near ones: edge_attr on (cutoff, far_hi]
+  const int32_t* type_far;    // [100] edge type -> its far set (index into poly_pk) or -1; null without far sets
   float cutoff;
   float two_over_rc;
+  float far_hi;
+  float two_over_far;         // 2 / (far_hi - cutoff)
 };
 
-// edge_attr rows (fp32, natural feature order) of the canonical local edges from the per-type polynomials: a tile whose
-// 16 lengths all lie in [0, cutoff] and whose types all have a slot is evaluated here (features once, one masked MFMA
-// round per type present); any other tile is flagged for the encoder MLP (agdiff_local_edge_rows).
+// edge_attr rows (fp32, natural feature order) of the canonical local edges from the per-type polynomials: every row whose
+// length lies in [0, cutoff] -- or in (cutoff, far_hi] when its type has a far set -- and whose type has a slot is evaluated
+// here (features once, one masked MFMA round per coefficient set present in the tile); the other rows are flagged for the
+// encoder MLP (agdiff_local_edge_rows).
 #define AG_ATTRP_WAVES 8
 #define AG_ATTRP_MAX_SLOTS 9         // 9 x 16 KiB of coefficients in LDS
 template <int MODE>
@@ -826,7 +831,7 @@ __global__ void __launch_bounds__(64 * AG_ATTRP_WAVES, 2) k_edge_attr_poly(AttrP
   lds_u32x4* wl = (lds_u32x4*)ag_attrp_smem;
   __shared__ int wg_flagged;
   if (threadIdx.x == 0) wg_flagged = 0;
-  ag_copy_lds(wl, reinterpret_cast<const u32x4*>(a.poly_pk), a.num_slots * 8 * 128);
+  ag_copy_lds(wl, reinterpret_cast<const u32x4*>(a.poly_pk), (a.num_slots + a.far_slots) * 8 * 128);
   __syncthreads();
   const int lane0 = ag_lane();
   const int E = *a.n_dev;
@@ -840,11 +845,16 @@ __global__ void __launch_bounds__(64 * AG_ATTRP_WAVES, 2) k_edge_attr_poly(AttrP
     const int64_t e = tile * AG_TW + (lane & 15);
     const bool valid = e < E;
     const float d = valid ? a.e_len[e] : 0.0f;
-    const int slot = valid ? a.type_slot[a.e_type[e]] : -1;
+    const int ety = valid ? a.e_type[e] : 0;
+    const int tslot = valid ? a.type_slot[ety] : -1;
+    const int fset = (valid && a.far_slots > 0) ? a.type_far[ety] : -1;
     // (NaN lengths by their bit pattern: this file is built with -fno-honor-nans, under which `!(d >= 0 && d <= rc)` may be
     // rewritten into comparisons that a NaN passes)
     const bool is_nan = (__float_as_uint(d) & 0x7FFFFFFFu) > 0x7F800000u;
-    const bool hard = valid && (is_nan || d < 0.0f || d > a.cutoff || slot < 0);
+    // beyond the cutoff: the type's far set (encoder/edge.py:84-103 on (cutoff, far_hi]), where it has one
+    const bool far = d > a.cutoff && d <= a.far_hi && tslot >= 0 && fset >= 0;
+    const int slot = far ? fset : tslot;
+    const bool hard = valid && (is_nan || d < 0.0f || (d > a.cutoff && !far) || tslot < 0);
     // rows the polynomials do not cover (longer than the cutoff, a type without a slot) are left to the encoder MLP: the
     // tile's flag word is the mask of those rows, everything else is stored here -- per edge, whatever its tile-mates are
     const int hard_rows = (int)(__ballot(hard) & 0xFFFFull);
@@ -852,7 +862,7 @@ __global__ void __launch_bounds__(64 * AG_ATTRP_WAVES, 2) k_edge_attr_poly(AttrP
     if (hard_rows) ++my_flagged;
     if (hard_rows == (int)(__ballot(valid) & 0xFFFFull)) continue;        // nothing for the polynomials in this tile
     AgIn<MODE> phall[1], ph[1];
-    ag_poly_features<MODE, 1>(d, a.two_over_rc, q, phall);
+    ag_poly_features<MODE, 1>(far ? d - a.cutoff : d, far ? a.two_over_far : a.two_over_rc, q, phall);
     f32x4 y[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) y[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1319,6 +1329,10 @@ extern "C" int agdiff_local_edge_rows(const agdiff_params_t* p, const agdiff_top
   // (all slots' 16-KiB sets sit in LDS: up to AG_ATTRP_MAX_SLOTS local edge types, else the encoder MLP for every tile)
   const bool poly = !p->tune_attr_poly_off && p->edge_encoder == 0 && p->poly_kt == 1 && p->poly_num_slots > 0 &&
                     p->poly_num_slots <= AG_ATTRP_MAX_SLOTS && p->attr_poly_typed_pk && p->poly_type_slot && ws->enc_flags;
+  if (p->attr_poly_far_slots < 0 ||
+      (p->attr_poly_far_slots > 0 && (p->poly_num_slots + p->attr_poly_far_slots > AG_ATTRP_MAX_SLOTS || !p->attr_poly_far_set ||
+                                      !(p->attr_poly_far_hi > p->cutoff))))
+    return AGDIFF_ERR_ARG;
   if (!poly)
     return agdiff_edge_encoder(p, ws->num_local_canon, ctiles, ws->lc_len, topo->lc_type, nullptr, ws->l_attr_rows, nullptr,
                                nullptr, nullptr, stream);
@@ -1335,11 +1349,15 @@ extern "C" int agdiff_local_edge_rows(const agdiff_params_t* p, const agdiff_top
   a.flags = ws->enc_flags;
   a.max_tiles = ctiles;
   a.num_slots = p->poly_num_slots;
+  a.far_slots = poly ? p->attr_poly_far_slots : 0;
+  a.type_far = p->attr_poly_far_set;
   a.cutoff = p->cutoff;
   a.two_over_rc = 2.0f / p->cutoff;
+  a.far_hi = a.far_slots > 0 ? p->attr_poly_far_hi : p->cutoff;
+  a.two_over_far = a.far_slots > 0 ? 2.0f / (p->attr_poly_far_hi - p->cutoff) : 0.0f;
   int64_t wgs = (ctiles + AG_ATTRP_WAVES - 1) / AG_ATTRP_WAVES;
   if (wgs > 512) wgs = 512;
-  const size_t smem = (size_t)p->poly_num_slots * 8 * 2048;
+  const size_t smem = (size_t)(p->poly_num_slots + a.far_slots) * 8 * 2048;
   static std::atomic<uint64_t> attr_done{0};
   if (!ag_allow_big_lds(attr_done, (size_t)AG_ATTRP_MAX_SLOTS * 8 * 2048, k_edge_attr_poly<AG_BF3>, k_edge_attr_poly<AG_F32>,
                         k_edge_attr_poly<AG_H3>))

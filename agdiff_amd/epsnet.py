@@ -235,6 +235,9 @@ class DualEncoderEpsNetwork(nn.Module):
         self.tuning = {}
         self.group_targets = None            # targets per wave of agdiff_cfconv_node: None = by batch size (BatchTopology.GROUP_MIN_NODES)
         self.poly_refuse_types = ()          # (tests: local edge types to treat as if their polynomial fit had been refused)
+        # local edges LONGER than the cutoff take their edge_attr rows from a second polynomial per type on [cutoff, 10 cutoff]
+        # (packing.fit_attr_far) instead of the encoder MLP; False keeps the MLP for them
+        self.attr_far_rows = True
         self._packed = None
         self._packed_key = None
         self._batch_cache = None
@@ -253,7 +256,7 @@ class DualEncoderEpsNetwork(nn.Module):
 
     def _weights_key(self):
         return (str(self._device()), self.precision, self.radius_poly, tuple(self.poly_refuse_types), getattr(self, "precision_local", None),
-                getattr(self, "poly_passes", "auto")) + tuple(int(p._version) for p in self.state_dict(keep_vars=True).values())
+                getattr(self, "poly_passes", "auto"), getattr(self, "attr_far_rows", True)) + tuple(int(p._version) for p in self.state_dict(keep_vars=True).values())
 
     def packed(self):
         """Packed device weights, rebuilt when any parameter / buffer changed (load_state_dict, .to).  A branch asked to run
@@ -268,7 +271,7 @@ class DualEncoderEpsNetwork(nn.Module):
             for _ in range(3):
                 pk = PackedParams(sd, self.config, self._device(), prec, self.radius_poly,
                                   refuse_types=self.poly_refuse_types, precision_local=prec_l,
-                                  poly_passes=getattr(self, "poly_passes", "auto"))
+                                  poly_passes=getattr(self, "poly_passes", "auto"), attr_far=getattr(self, "attr_far_rows", True))
                 rep, again = pk.split_fp16_report, False
                 for branch in ("global", "local"):
                     r = rep[branch]

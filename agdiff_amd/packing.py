@@ -189,18 +189,39 @@ def poly_features(x, K):
     return np.stack([G[f // 8] * T[f % 8] for f in range(K)], axis=-1)
 
 
-def fit_poly(fn, cutoff, K):
+def fit_poly(fn, cutoff, K, lo=0.0):
     """Coefficients C[out, K] (product basis) of the degree-(K-1) interpolant of fn: d[M] -> [M, out] at the K Chebyshev
-    nodes of [0, cutoff], and its largest error on a dense grid relative to the largest |fn|."""
+    nodes of [lo, cutoff] (x = 2 (d - lo) / (cutoff - lo) - 1), and its largest error on a dense grid relative to the
+    largest |fn|."""
     k = np.arange(K)
     xn = np.cos(np.pi * (k + 0.5) / K)
-    fv = fn((xn + 1.0) * (cutoff / 2.0))                                   # [K, out]
+    half = (cutoff - lo) / 2.0
+    fv = fn(lo + (xn + 1.0) * half)                                         # [K, out]
     b = np.polynomial.chebyshev.chebfit(xn, fv, K - 1)                      # [K, out] Chebyshev coefficients
     c = np.linalg.solve(poly_basis_matrix(K), b)                            # product-basis coefficients
-    dg = np.linspace(0.0, cutoff, 4097)
+    dg = np.linspace(lo, cutoff, 4097)
     ref = fn(dg)
-    err = np.abs(poly_features(2.0 * dg / cutoff - 1.0, K) @ c - ref).max() / max(np.abs(ref).max(), 1e-300)
+    err = np.abs(poly_features((dg - lo) / half - 1.0, K) @ c - ref).max() / max(np.abs(ref).max(), 1e-300)
     return c.T, float(err)
+
+
+# Local edges LONGER than the cutoff (bonded atoms far apart at high sigma: every local edge of the local-only steps early in
+# the schedule) contribute nothing to the CFConvs (envelope 0, schnet.py:140-146) but the GIN layers and the local head read
+# their edge_attr rows at any length (dualenc.py:214-239).  Beyond the cutoff the encoder's GELUs are saturated and edge_attr(d)
+# is very smooth: a 32-term fit on [cutoff, 10 cutoff] reproduces it to ~1e-9 (synthetic and default-initialised weights), so
+# those rows come from a second, "far" coefficient set per type instead of the encoder MLP (agdiff_params_t.attr_poly_far_slots).
+ATTR_FAR_FACTOR = 10.0
+ATTR_POLY_MAX_SETS = 9           # csrc/edge.hip AG_ATTRP_MAX_SLOTS: near + far sets the kernel holds in LDS
+
+
+def fit_attr_far(sd, cfg, typ):
+    """(coefficients [128, 32] in natural packed column order, error) of edge_attr(d, typ) on [cutoff, ATTR_FAR_FACTOR cutoff]."""
+    key = (_poly_weights_digest(sd, cfg), float(cfg.cutoff), int(typ), "attr_far")
+    if key not in _FIT_CACHE:
+        fn = _edge_attr_fn(sd, "edge_encoder_global", typ)
+        c, err = fit_poly(lambda d: fn(d).numpy(), ATTR_FAR_FACTOR * float(cfg.cutoff), 32, lo=float(cfg.cutoff))
+        _FIT_CACHE[key] = (c[:, poly_feature_order(1)], err)
+    return _FIT_CACHE[key]
 
 
 def _edge_attr_fn(sd, e, typ):
@@ -413,7 +434,7 @@ class PackedParams:
     """Owns the device copies of all packed weights and the agdiff_params_t that points at them."""
 
     def __init__(self, sd, cfg, device, precision="f32", radius_poly="auto", refuse_types=(), precision_local=None,
-                 poly_passes="auto"):
+                 poly_passes="auto", attr_far=True):
         """radius_poly: "auto" -- radius edges take their filters from d-polynomials when the fit is accepted
         (radius_polynomials above), and so do the local edges, per type (ensure_local_types); "off" -- every edge goes
         through the encoder + filter MLPs; "radius" -- polynomials for the radius edges only; "kt2" -- as "auto" but
@@ -422,6 +443,7 @@ class PackedParams:
         (poly_pass_plan); "full" -- three passes for every term."""
         import torch
         self.device = device
+        self.attr_far = bool(attr_far)  # False keeps the encoder MLP for local edges beyond the cutoff (tests, A/B runs)
         if poly_passes not in ("auto", "full"):
             raise ValueError("poly_passes must be 'auto' or 'full'")
         self.poly_passes = poly_passes
@@ -790,9 +812,30 @@ class PackedParams:
         self._pack_filter_sets()           # (the typed sets are packed again with the new one; the radius set, the plan and 2^S stay)
         # edge_attr itself per type (agdiff_local_edge_rows): pk [8][kt] -- the kernel takes one k-tile, so only with kt == 1
         if kt == 1:
-            attr_sets = np.concatenate([pack_blocks(self._typed_mats[t]["edge_attr_poly_pk"], mode=self._mode_local) for t in by_slot])
+            sets = [pack_blocks(self._typed_mats[t]["edge_attr_poly_pk"], mode=self._mode_local) for t in by_slot]
+            # far sets (edge_attr on [cutoff, 10 cutoff]): as many as the kernel's LDS holds next to the near sets, the types
+            # that carry most local edges first (3-hop, 2-hop, single bonds, then the rest); a type whose far fit misses
+            # POLY_TOL keeps the encoder MLP beyond the cutoff
+            far_table = np.full(100, -1, dtype=np.int32)
+            room = max(0, ATTR_POLY_MAX_SETS - len(by_slot)) if self.attr_far else 0
+            prio = {24: 0, 23: 1, 1: 2}
+            for t in sorted(by_slot, key=lambda ty: (prio.get(ty, 3), ty)):
+                if room <= 0:
+                    break
+                c, err = fit_attr_far(self._sd, self._cfg, t)
+                self.poly_errors["type%d_far" % t] = err
+                if err > POLY_TOL:
+                    continue
+                far_table[t] = len(sets)
+                sets.append(pack_blocks(c, mode=self._mode_local))
+                room -= 1
+            attr_sets = np.concatenate(sets)
             self.typed_attr_flat = torch.from_numpy(attr_sets).to(self.device)
             prm.attr_poly_typed_pk = ctypes.c_void_p(self.typed_attr_flat.data_ptr())
+            self.attr_far_table = torch.from_numpy(far_table).to(self.device)
+            prm.attr_poly_far_set = ctypes.c_void_p(self.attr_far_table.data_ptr())
+            prm.attr_poly_far_slots = int((far_table >= 0).sum())
+            prm.attr_poly_far_hi = ATTR_FAR_FACTOR * float(self._cfg.cutoff)
         table = np.full(100, -1, dtype=np.int32)
         for t, sl in self.local_slots.items():
             table[t] = sl

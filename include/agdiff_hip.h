@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 39
+#define AGDIFF_ABI_VERSION 40
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -157,8 +157,9 @@ typedef struct agdiff_params {
                                 then for union segment u = number of those kinks <= d and scale cc = 2 k + (0: conv1, 1: conv2)
                                 the line (alpha, beta) at [512 + (u * 2 num_convs + cc) * 2]: the same floats dist_seg selects
                                 for that d, found with ONE search instead of one per conv (agdiff_sampler_front) */
-  const float* attr_poly_typed_pk; /* [poly_num_slots] x pk [8][1] or null: edge_attr itself (128 features) of a local edge of a
-                                slotted type as a polynomial in d on [0, cutoff] (agdiff_local_edge_rows) */
+  const float* attr_poly_typed_pk; /* [poly_num_slots + attr_poly_far_slots] x pk [8][1] or null: edge_attr itself (128 features) of a
+                                local edge of a slotted type as a polynomial in d on [0, cutoff] (agdiff_local_edge_rows); then, for
+                                the first attr_poly_far_slots slots, the same on [cutoff, attr_poly_far_hi] (below) */
   agdiff_conv_params_t conv[AGDIFF_MAX_CONVS];
   agdiff_gin_params_t gin[AGDIFF_MAX_CONVS_LOCAL];
   agdiff_head_params_t head_global;
@@ -220,6 +221,16 @@ typedef struct agdiff_params {
   int32_t tune_attr_poly_off;         /* [0] 1: agdiff_local_edge_rows evaluates the encoder MLP for every tile */
   int32_t tune_poly_lds_sets;         /* [0 = as many as fit in 160 KiB] agdiff_cfconv_node: at most this many coefficient sets in
                                          LDS, the radius edges' one included (1: every local type's set is read from L2) */
+  int32_t attr_poly_far_slots; /* 0, or the number of FAR sets that follow the poly_num_slots near sets in attr_poly_typed_pk: edge_attr
+                                  of a local edge type on [cutoff, attr_poly_far_hi].  Local edges LONGER than the cutoff -- bonded
+                                  atoms far apart at high sigma, every local edge of a local-only step early in the schedule --
+                                  then take their rows from it instead of the encoder MLP (beyond the cutoff the encoder's GELUs are
+                                  saturated: a 32-term fit on [rc, 10 rc] is good to ~1e-9; accepted at <= 1e-6 like every fit).
+                                  attr_poly_far_set[type] = index of the type's far set in attr_poly_typed_pk, or -1; the kernel's
+                                  LDS limits poly_num_slots + attr_poly_far_slots to 9 (the host gives the 2-/3-hop types and the
+                                  single bonds their far sets first) */
+  const int32_t* attr_poly_far_set; /* [100] or null */
+  float attr_poly_far_hi;      /* upper end of that range (agdiff_amd/packing.py: 10 x cutoff); longer edges keep the encoder MLP */
   int64_t tune_cfconv_four_min_quads; /* [8192] agdiff_cfconv_node at poly_kt 1: from this many quads on (two per wave of 256 x 16),
                                          16-wave workgroups at 128 VGPRs = four waves per SIMD, groups of two channel tiles;
                                          below, the 12-wave shape (more workgroups for the same quads); -1: never */

@@ -380,15 +380,20 @@ def test_radius_only_canonical_list_of_the_sampler(kind, mols, copies):
     assert R == int((ety == 0).sum()) and np.array_equal(cover, (ety == 0).astype(cover.dtype))
 
 
+@pytest.mark.parametrize("far", [False, True])
 @pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x3"])
-def test_local_edge_rows_polynomial_and_flagged_tiles(precision):
+def test_local_edge_rows_polynomial_and_flagged_tiles(precision, far):
     """agdiff_local_edge_rows against agdiff_edge_encoder (the MLP) on the same canonical local list, through the C ABI:
-    compact molecules (every length inside the cutoff: all tiles by polynomial, none flagged), stretched ones (bonded atoms
-    far apart, as at high sigma: those tiles are flagged and go through the MLP), and a mix."""
+    compact molecules (every length inside the cutoff: all rows by polynomial, none flagged), stretched ones (bonded atoms
+    far apart, as at high sigma) and a mix.  far = False: every row longer than the cutoff is flagged and goes through the MLP;
+    far = True (the default build): rows in (cutoff, 10 cutoff] of a type with a far set come from that polynomial too
+    (packing.fit_attr_far: edge_attr beyond the cutoff is a 32-term polynomial to ~1e-9), only rows beyond it -- the
+    "exploded" case -- or of a type without a far set (the kernel holds 9 sets: here type 12 has none) keep the MLP."""
     from agdiff_amd import _lib, drugs_model_config, synth
     lib = _lib.load()
     cfg = drugs_model_config(num_diffusion_timesteps=20, beta_end=2e-5)
     m = _model(cfg, "auto", precision=precision)
+    m.attr_far_rows = far
     b = synth.make_packed_batch("drugs", 5, 3, seed=31)
     at, bi, bt, ba = [t(b[k]).cuda() for k in ("atom_type", "bond_index", "bond_type", "batch")]
     gen = torch.Generator().manual_seed(8)
@@ -396,10 +401,12 @@ def test_local_edge_rows_polynomial_and_flagged_tiles(precision):
     G = b["num_graphs"]
     stretch = torch.ones(G)
     stretch[G // 2:] = 9.0                       # the second half of the molecules blown up: lengths far beyond 10 A
-    for name, pos in (("compact", base * 1.5), ("stretched", base * 12.0), ("mixed", base * 1.5 * stretch[t(b["batch"])].unsqueeze(1))):
+    cases = [("compact", base * 1.5), ("stretched", base * 12.0), ("mixed", base * 1.5 * stretch[t(b["batch"])].unsqueeze(1)),
+             ("exploded", base * 60.0)]
+    for name, pos in cases:
         m(at, pos.cuda(), bi, bt, ba, None, extend_order=False)
         topo, ws, pk = m._batch_cache[1], m._batch_cache[2], m.packed()
-        assert pk.struct.poly_num_slots > 0
+        assert pk.struct.poly_num_slots > 0 and (pk.struct.attr_poly_far_slots > 0) == far
         P, T, W, st = ctypes.byref(pk.struct), ctypes.byref(topo.struct), ctypes.byref(ws.struct), _lib.stream_ptr()
         ct = (topo.Lc + _lib.TILE - 1) // _lib.TILE
         assert lib.agdiff_edge_encoder(P, _lib.ptr(ws.num_local_canon), ct, _lib.ptr(ws.lc_len), _lib.ptr(topo.lc_type), None,
@@ -412,17 +419,26 @@ def test_local_edge_rows_polynomial_and_flagged_tiles(precision):
         got = ws.l_attr_rows.view(-1, 128)[:topo.Lc]
         flags = ws.enc_flags.cpu().numpy()
         lens = ws.lc_len[:topo.Lc].cpu().numpy()
-        want = np.array([np.any(lens[16 * k:16 * k + 16] > cfg.cutoff) for k in range(ct)])
-        masks = np.array([sum(1 << r for r in range(16) if 16 * k + r < topo.Lc and lens[16 * k + r] > cfg.cutoff) for k in range(ct)])
+        types = topo.lc_type[:topo.Lc].cpu().numpy()
+        has_far = (pk.attr_far_table.cpu().numpy()[types] >= 0) if far else np.zeros(topo.Lc, dtype=bool)
+        hard = (lens > cfg.cutoff) & ~(has_far & (lens <= float(pk.struct.attr_poly_far_hi)))
+        want = np.array([hard[16 * k:16 * k + 16].any() for k in range(ct)])
+        masks = np.array([sum(1 << r for r in range(16) if 16 * k + r < topo.Lc and hard[16 * k + r]) for k in range(ct)])
         assert np.array_equal(flags[1:1 + ct], masks) and flags[0] == want.sum(), name
-        assert {"compact": want.sum() == 0, "stretched": want.sum() > ct // 2, "mixed": 0 < want.sum() < ct}[name]
-        check_close("local_edge_rows[%s]" % name, got.cpu().numpy(), ref.cpu().numpy(), precision,
+        long_rows = int((lens > cfg.cutoff).sum())
+        if far:
+            assert {"compact": hard.sum() == 0, "stretched": 0 < hard.sum() < long_rows // 4, "mixed": 0 < hard.sum() < long_rows,
+                    "exploded": hard.sum() > topo.Lc // 2}[name], (name, int(hard.sum()), long_rows)
+        else:
+            assert {"compact": want.sum() == 0, "stretched": want.sum() > ct // 2, "mixed": 0 < want.sum() < ct,
+                    "exploded": want.sum() > ct // 2}[name]
+        check_close("local_edge_rows[%s, far %d]" % (name, far), got.cpu().numpy(), ref.cpu().numpy(), precision,
                     scale=3.0 if precision == "bf16x3" else 1.0)       # (two split-bf16 evaluations against each other)
-        # rows of edges longer than the cutoff are the MLP's own output, bit for bit -- and ONLY they: what a row holds depends
+        # rows the polynomials do not cover are the MLP's own output, bit for bit -- and ONLY they: what a row holds depends
         # on its own edge, not on the tile it shares (a neighbour molecule that stretches must not change this one's bits)
-        rows = torch.from_numpy(lens > cfg.cutoff)
+        rows = torch.from_numpy(hard)
         assert torch.equal(got[rows], ref[rows])
-        assert name == "stretched" or not torch.equal(got[~rows], ref[~rows])
+        assert bool(rows.all()) or not torch.equal(got[~rows], ref[~rows])
 
 
 @pytest.mark.parametrize("kind,mols,copies", [("drugs", 4, 3), ("qm9", 6, 4)])

@@ -280,6 +280,16 @@ def test_filter_polynomials_reproduce_the_networks(which):
         if typ == 0:
             ref = (a @ sd64["grad_global_dist_mlp.layers.0.weight"][:, 128:].T).numpy()
             assert np.abs(ph @ m["head_global.attr_poly_pk"][:, inv].T - ref).max() < 2e-6 * np.abs(ref).max()
+        else:
+            # ... and edge_attr itself BEYOND the cutoff (packing.fit_attr_far: the rows the GIN layers and the local head read for
+            # bonded atoms far apart at high sigma) against the ORACLE's encoder at lengths that are not fit nodes
+            cf, errf = packing.fit_attr_far(sd, cfg, typ)
+            assert errf < 1e-6
+            hi = packing.ATTR_FAR_FACTOR * cfg.cutoff
+            dfar = cfg.cutoff + torch.rand(257, 1, dtype=torch.float64, generator=torch.Generator().manual_seed(1)) * (hi - cfg.cutoff)
+            afar = O.mlp_edge_encoder(sd64, "edge_encoder_global", dfar, torch.full((257,), typ, dtype=torch.long)).numpy()
+            phf = packing.poly_features(2.0 * (dfar[:, 0].numpy() - cfg.cutoff) / (hi - cfg.cutoff) - 1.0, 32)
+            assert np.abs(phf @ cf[:, inv].T - afar).max() < 2e-6 * np.abs(afar).max()
 
 
 def _emulate_poly_mfma(c_nat, d, cutoff, plan, np16):
