@@ -384,6 +384,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the runs reported under `extra`")
     ap.add_argument("--no-traj", action="store_true")
+    ap.add_argument("--no-attr-far", action="store_true", help="local edges beyond the cutoff through the encoder MLP instead of their "
+                                                               "far polynomials (A/B runs)")
     ap.add_argument("--no-full-job", action="store_true", help="skip extra.full_job (one complete 5000-step job, ~40 s)")
     ap.add_argument("--no-gather-extra", action="store_true", help="skip extra.all_gather_world1")
     ap.add_argument("--no-qm9-extra", action="store_true", help="skip extra.configs1_qm9")
@@ -461,6 +463,7 @@ def main():
         m.precision = args.precision
         m.radius_poly = radius_poly or args.radius_poly
         m.poly_passes = args.poly_passes
+        m.attr_far_rows = not args.no_attr_far
         m.fused_front, m.front_split_graph = args.front != "unfused", args.front == "split"
         if args.serial:
             m.tuning["serial_branches"] = 1
