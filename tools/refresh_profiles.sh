@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerate the measurement records of a round (run on the GPU box via gpurun; results land in gpurun_out/profiles_new/ and
 # are copied into profiles/ by hand afterwards).  Two parts, each within one gpurun call:
-#   bash tools/refresh_profiles.sh r04 bench [precision]   the bench lines (default command first)
+#   bash tools/refresh_profiles.sh r04 bench [precision]   the bench lines (default command first; `default` = only it, `rest` = the others)
 #   bash tools/refresh_profiles.sh r04 prof  [precision]   rocprofv3 kernel stats of the default command, counter passes, step timeline
 R=${1:-r04}; part=${2:-bench}; PREC=${3:-f16x3}
 out=$GRAFT_REPO_ROOT/gpurun_out/profiles_new
@@ -10,8 +10,10 @@ cd $GRAFT_REPO_ROOT
 say() { echo "$(date +%T) $*"; }
 if [ $part = default ]; then
   say "default bench (drugs200)"; t0=$SECONDS; python bench.py --gpus 1 --steps 20 --warmup 5 2>$out/${R}_bench_default.err | tail -1 > $out/${R}_${PREC}_bench.json; say "default bench took $((SECONDS - t0)) s wall"
-elif [ $part = bench ]; then
+elif [ $part = bench ] || [ $part = rest ]; then
+  if [ $part = bench ]; then
   say "default bench (drugs200)"; t0=$SECONDS; python bench.py --gpus 1 --steps 20 --warmup 5 2>$out/${R}_bench_default.err | tail -1 > $out/${R}_${PREC}_bench.json; say "default bench took $((SECONDS - t0)) s wall"
+  fi
   say "drugs 8x128 + breakdown"; python bench.py --workload drugs --breakdown $out/${R}_${PREC}_breakdown.json --no-cpu-baseline 2>/dev/null | tail -1 > $out/${R}_bench_drugs_8x128.json
   say "8x128 unfused front"; python bench.py --workload drugs --front unfused --steps 500 --no-cpu-baseline --no-extra 2>/dev/null | tail -1 > $out/${R}_bench_drugs_8x128_unfused_front.json
   say "8x128 poly off"; python bench.py --workload drugs --radius-poly off --steps 300 --no-cpu-baseline --no-extra 2>/dev/null | tail -1 > $out/${R}_bench_poly_off.json
