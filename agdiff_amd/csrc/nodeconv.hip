@@ -111,6 +111,7 @@ struct NodeConvShape {
 #endif
 #ifndef AG_NODE_ABL
 #define AG_NODE_ABL 0       // timing experiments only (wrong results): 1 no x gathers, 2 no filter MFMAs, 4 no features, 8 no sums, 16 one coefficient read per group
+                            // (k_cfconv_quad: 1, 8 and 16 -- one read per tile -- only)
 #endif
 // PLAN (agdiff_params_t.poly_plan): 0 three passes for every term; 1 one pass for the high terms, whose coefficients the
 // host has bounded -- at NKT 1 two MFMAs per channel tile (hi x hi of all 32 terms, then both cross terms of terms 0..15 in
@@ -553,7 +554,10 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_quad(NodeConvA
 #pragma unroll
     for (int j = 0; j < GRP; ++j) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) xg[kb][j][r] = *reinterpret_cast<const float*>(xb + (size_t)xoff[r] + 64 * (GRP * g + j));
+      for (int r = 0; r < 4; ++r) {
+        if (AG_NODE_ABL & 1) xg[kb][j][r] = __uint_as_float(xoff[r] + (uint32_t)(GRP * g + j));
+        else xg[kb][j][r] = *reinterpret_cast<const float*>(xb + (size_t)xoff[r] + 64 * (GRP * g + j));
+      }
     }
   };
   auto fetch_first_groups = [&]() {
@@ -570,6 +574,11 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_quad(NodeConvA
     for (int j = 0; j < GRP; ++j) {
 #pragma unroll
       for (int t = 0; t < NKT; ++t) {
+        if ((AG_NODE_ABL & 16) && (j > 0 || C0 > 0)) {      // (timing experiment: one coefficient block read per tile)
+          w[j][t][0] = w[0][t][0];
+          w[j][t][1] = w[0][t][1];
+          continue;
+        }
         w[j][t][0] = base[(((C0 + j) * NKT + t) * 2) * 64];
         if (PLAN == 0 || t == 0) w[j][t][1] = base[(((C0 + j) * NKT + t) * 2 + 1) * 64];
       }
@@ -654,7 +663,13 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_quad(NodeConvA
 #pragma unroll
         for (int jj = 0; jj < GRP; ++jj) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[GRP * gg + jj] = fmaf(z[jj][r], xg[gg % XD][jj][r], acc[GRP * gg + jj]);
+          for (int r = 0; r < 4; ++r) {
+            if ((AG_NODE_ABL & 8) && r) {
+              asm volatile("" ::"v"(z[jj][r]), "v"(xg[gg % XD][jj][r]));
+              continue;
+            }
+            acc[GRP * gg + jj] = fmaf(z[jj][r], xg[gg % XD][jj][r], acc[GRP * gg + jj]);
+          }
           asm volatile("" : "+v"(acc[GRP * gg + jj]));
         }
       };
