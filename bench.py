@@ -408,6 +408,9 @@ def main():
     ap.add_argument("--serial", action="store_true", help="local and global branch on ONE stream (tune_serial_branches): per-kernel "
                     "stand-alone times under rocprofv3")
     ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL all-gather path even with one rank")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="rehearsal of the multi-rank path on a one-GPU box: every rank computes on cuda:0 and the ranks meet over "
+                         "gloo (RCCL refuses two ranks on one device); the line says so and its value is not a scaling figure")
     ap.add_argument("--job-steps", type=int, default=JOB_STEPS, help="denoising steps of one sampling job (5000; the "
                     "alanine dipeptide example runs 100)")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
@@ -441,6 +444,8 @@ def main():
 
     import torch
     import torch.distributed as dist
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
@@ -449,7 +454,10 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from agdiff_amd import _lib, driver, get_model, synth
     from agdiff_amd.dist import shard_of
@@ -937,6 +945,8 @@ def main():
         }
         if per_batch is not None:
             out["config"]["batches"] = per_batch
+        if args.rehearse_on_one_gpu:
+            out["config"]["rehearsal"] = "all %d ranks on ONE GPU, collectives over gloo: a run of the multi-rank code path, not a scaling figure" % world
         sys.stdout.flush()
         ctypes.CDLL(None).fflush(None)         # RCCL writes its banner through C stdio (block-buffered on a pipe):
         print(json.dumps(out), flush=True)     # push it out first, so that the JSON is the last line of stdout

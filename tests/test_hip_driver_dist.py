@@ -251,6 +251,32 @@ def test_all_gather_path_on_one_gpu_nccl_world1():
         dist.destroy_process_group()
 
 
+def test_bench_two_ranks_strong_scaling_rehearsal_on_one_gpu():
+    """The command the driver's SCALE run launches (python -m torch.distributed.run ... bench.py --gpus N), with two ranks,
+    as child processes: both compute on this box's one GPU and meet over gloo (--rehearse-on-one-gpu; RCCL refuses two ranks
+    on one device).  The sharded job -- global batches cut into per-rank graph ranges, one all-gather per step and batch --
+    runs through the real kernels and rank 0 prints one strong-scaling line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-extra", "--no-cpu-baseline", "--rehearse-on-one-gpu"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and d["config"]["conformers_total"] == 108874
+    nb = len(d["config"]["batches"])
+    assert d["config"]["all_gather_calls_rank0"] == 3 * nb          # one per step (1 warm-up + 2 timed) and global batch
+    assert "rehearsal" in d["config"]
+
+
 @pytest.mark.parametrize("kind,mols,copies,min_mean_deg", [("qm9", 40, 30, 14.0), ("large", 256, 1, 30.0)])
 def test_full_size_properties_other_configs(kind, mols, copies, min_mean_deg):
     """BASELINE.json configs[1] (QM9-shaped, uncapped) and configs[4]'s per-GPU share (200-atom molecules x 256,
