@@ -248,6 +248,9 @@ def test_cfconv_node_shapes_agree_bitwise(kind, mols, copies, mode, precision, p
         assert err <= {"f32": 2e-6, "f16x3": 6e-6, "bf16x3": 6e-5}[precision], (name, err)
 
 
+_ORACLE_RESULTS = {}        # oracle outputs shared by the parametrisations of one test (same inputs, same weights)
+
+
 @pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x3"])
 def test_sharper_first_layer_takes_64_terms_at_bench_scale(precision):
     """a feature_expansion layer 8 x sharper than the synthetic checkpoint's is not a 32-term polynomial
@@ -270,12 +273,15 @@ def test_sharper_first_layer_takes_64_terms_at_bench_scale(precision):
     g = torch.Generator().manual_seed(13)
     pos_init, noise = torch.randn(at.shape[0], 3, generator=g), torch.randn(3, at.shape[0], 3, generator=g)
     kw = dict(extend_order=False, n_steps=3, w_global=1.0, global_start_sigma=0.5, clip=1000.0)
-    nthr = torch.get_num_threads()
-    torch.set_num_threads(max(nthr, 16))
-    try:
-        ref, _ = O.langevin_dynamics_sample_diffusion(sd, cfg, at, pos_init, bi, bt, ba, b["num_graphs"], noise=noise, **kw)
-    finally:
-        torch.set_num_threads(nthr)
+    if "sharper_kt2" not in _ORACLE_RESULTS:          # (the oracle's three steps on 14.8 k atoms take ~35 s of CPU: once for the three modes)
+        nthr = torch.get_num_threads()
+        torch.set_num_threads(max(nthr, 16))
+        try:
+            _ORACLE_RESULTS["sharper_kt2"] = O.langevin_dynamics_sample_diffusion(sd, cfg, at, pos_init, bi, bt, ba, b["num_graphs"],
+                                                                                  noise=noise, **kw)[0]
+        finally:
+            torch.set_num_threads(nthr)
+    ref = _ORACLE_RESULTS["sharper_kt2"]
     got, _ = m.langevin_dynamics_sample_diffusion(at.cuda(), pos_init.cuda(), bi.cuda(), bt.cuda(), ba.cuda(),
                                                   b["num_graphs"], noise=noise.cuda(), **kw)
     pk, var, V = m.packed(), _variants(m._batch_cache[2]), _lib.DEFINES
