@@ -117,7 +117,7 @@ def shard_of(packed, rank, world):
 
 
 def sample_batch_sharded(model, packed, device, sampler_kwargs, save_traj=False, max_retry=2, log=print, group=None,
-                         pos_init=None, noise=None):
+                         pos_init=None, noise=None, topology=None):
     """driver.sample_batch for one packed batch sharded over the ranks of `group` by contiguous graph ranges
     (SURVEY §8e): every rank samples its range, the shards' positions (+ NaN flag) are all-gathered after every
     denoising step (StepAllGather), and the last gather is the job's result on every rank.  Molecules in which a NaN
@@ -150,11 +150,14 @@ def sample_batch_sharded(model, packed, device, sampler_kwargs, save_traj=False,
             try:
                 p0 = pos_init[lo:hi].to(device) if (first and pos_init is not None) else torch.randn(hi - lo, 3).to(device)
                 with _arithmetic(model, wide):
+                    # (`topology`: this rank's range of the whole batch, prepared ahead by driver.prepare_batch: first attempt only)
+                    extra = {"topology": topology} if (topology is not None and sub is packed) else {}
+                    topology = None
                     run = model.begin_sampling(T(mine["atom_type"]), p0, T(mine["bond_index"]), T(mine["bond_type"]),
                                                T(mine["batch"]), mine["num_graphs"], False, clip_local=clip_local,
                                                save_traj=save_traj, raise_on_nan=False,
                                                noise=(noise[:, lo:hi] if (first and noise is not None) else None),
-                                               **sampler_kwargs)
+                                               **extra, **sampler_kwargs)
                     run.on_step = lambda k, i, pos: gather(k, i, pos, run.ws.nan_flag)
                     run.advance(run.remaining())
                     _, traj = run.finish()

@@ -105,14 +105,32 @@ def pack_batch(mols, confs_of):
                 bond_type=np.concatenate(ts), batch=np.concatenate(bs), num_graphs=g_off, spans=spans)
 
 
+def prepare_batch(model, bmols, confs_of, rank=0, world=1):
+    """(packed batch, its BatchTopology on the host or None) -- for world > 1 the topology of THIS rank's graph range of the
+    batch (dist.shard_of), as sample_batch_sharded samples it.  Host work only (no GPU call): run_job calls it for the next
+    batch from a background thread.  None for models without prepare_topology (test stubs) or a rank without graphs."""
+    packed = pack_batch(bmols, confs_of)
+    if not hasattr(model, "prepare_topology"):
+        return packed, None
+    part = packed
+    if world > 1:
+        from .dist import shard_of
+        part = shard_of(packed, rank, world)[0]
+        if part is None:
+            return packed, None
+    return packed, model.prepare_topology(part["atom_type"], part["bond_index"], part["bond_type"], part["batch"], part["num_graphs"],
+                                          extend_order=False, device="cpu")
+
+
 def sample_batch(model, packed, device, sampler_kwargs, save_traj=False, max_retry=2, log=print, pos_init=None,
-                 noise=None):
+                 noise=None, topology=None):
     """test.py:143-181 for every molecule of a packed batch: a molecule in which a NaN appeared is sampled again
     (fresh pos_init) with clip_local=20, at most `max_retry` attempts in all, and dropped after that; the molecules
     packed with it keep their first result -- graphs are independent on the whole path, and the update kernel flags
     NaNs per graph (agdiff_ws_t.nan_flag).  Returns (pos [N,3] cpu, traj [steps,N,3] cpu or None, ok [num molecules]
     bool); rows of failed molecules are NaN.  `pos_init` [N,3] / `noise` [steps,N,3] replace the first attempt's
-    random draws (parity tests).  Models without begin_sampling (test stubs) take the reference's whole-batch retry."""
+    random draws (parity tests).  `topology`: the batch's BatchTopology prepared ahead (prepare_batch; first attempt only).
+    Models without begin_sampling (test stubs) take the reference's whole-batch retry."""
     import torch
     T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)
     spans = packed["spans"]
@@ -146,9 +164,11 @@ def sample_batch(model, packed, device, sampler_kwargs, save_traj=False, max_ret
         first = attempt == 0
         p0 = pos_init.to(device) if (first and pos_init is not None) else torch.randn(at.shape[0], 3).to(device)
         with _arithmetic(model, wide):
+            extra = {"topology": topology} if (topology is not None and sub is packed) else {}
             run = model.begin_sampling(at, p0, bi, bt, ba, sub["num_graphs"], False, clip_local=clip_local,
                                        save_traj=save_traj, raise_on_nan=False,
-                                       noise=(noise if first else None), **sampler_kwargs)
+                                       noise=(noise if first else None), **extra, **sampler_kwargs)
+            topology = None                    # (moved to the device and owned by the run now)
             run.advance(run.remaining())
             pos, traj = run.finish()
         pos = pos.cpu()
@@ -274,17 +294,34 @@ def run_job(model, mols, out_dir, confs_of, max_atoms, sampler_kwargs, device, s
         done = set(box[0])
     mols = [m for m in mols if m["index"] not in done]
     batches = plan_batches(mols, confs_of, sharded_capacity(max_atoms, world) if shard else max_atoms)
-    for bidx, bmols in enumerate(batches):
-        if not shard and bidx % world != rank:
-            continue
-        packed = pack_batch(bmols, confs_of)
+    mine = [bidx for bidx in range(len(batches)) if shard or bidx % world == rank]
+    # The next batch is packed -- and its topology built (seconds of numpy per 200 k atoms) -- in a background thread while the
+    # GPU samples the current one: the sampling loop spends its time inside library calls, which release the interpreter lock.
+    # (AGDIFF_PREPARE_INLINE=1: on the main thread, when its turn comes -- measurements, debugging)
+    from concurrent.futures import Future, ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=1)
+    prep = lambda bidx: prepare_batch(model, batches[bidx], confs_of, rank if shard else 0, world if shard else 1)
+    inline = os.environ.get("AGDIFF_PREPARE_INLINE", "0") not in ("", "0")
+
+    def submit(bidx):
+        if not inline:
+            return pool.submit(prep, bidx)
+        f = Future()
+        f.set_result(bidx)                 # (resolved below, when the batch's turn comes)
+        return f
+    fut = submit(mine[0]) if mine else None
+    for pos_in_mine, bidx in enumerate(mine):
+        bmols = batches[bidx]
+        packed, topology = prep(fut.result()) if inline else fut.result()
+        fut = submit(mine[pos_in_mine + 1]) if pos_in_mine + 1 < len(mine) else None
         if shard:
             from .dist import sample_batch_sharded
-            pos, traj, ok = sample_batch_sharded(model, packed, device, sampler_kwargs, save_traj=save_traj, log=log)
+            pos, traj, ok = sample_batch_sharded(model, packed, device, sampler_kwargs, save_traj=save_traj, log=log,
+                                                 topology=topology)
             if rank != 0:
                 continue
         else:
-            pos, traj, ok = sample_batch(model, packed, device, sampler_kwargs, save_traj=save_traj, log=log)
+            pos, traj, ok = sample_batch(model, packed, device, sampler_kwargs, save_traj=save_traj, log=log, topology=topology)
         if not ok.any():
             log("batch %d: every molecule failed twice (NaN); skipped: %s" % (bidx, [m["name"] for m in bmols]))
             continue
@@ -300,6 +337,7 @@ def run_job(model, mols, out_dir, confs_of, max_atoms, sampler_kwargs, device, s
         _save_npz_atomic(_batch_path(out_dir, bmols), out)
         log("rank %d: batch %d/%d (%d of %d molecules, %d conformers) saved" % (rank, bidx + 1, len(batches),
                                                                                int(ok.sum()), len(bmols), packed["num_graphs"]))
+    pool.shutdown(wait=True)
     if world > 1:
         dist.barrier()                       # every rank's batch files are on disk
     if SAMPLE_STATS["range_trips"]:

@@ -365,14 +365,25 @@ class DualEncoderEpsNetwork(nn.Module):
         self._packed_key = self._weights_key()
         return pk
 
-    def _batch(self, atom_type, bond_index, bond_type, batch, num_graphs, extend_order):
+    def prepare_topology(self, atom_type, bond_index, bond_type, batch, num_graphs, extend_order=False, device="cpu"):
+        """The static topology of a batch (BatchTopology: coalesced local edges, canonical list, quad tiles), built on the
+        host: what begin_sampling(..., topology=...) takes instead of building it itself.  No GPU call is made for
+        device="cpu", so the driver prepares the NEXT batch in a background thread while this one samples."""
+        return BatchTopology(atom_type, bond_index, bond_type, batch, num_graphs=num_graphs,
+                             extend_order=extend_order, order=self.config.edge_order, device=device,
+                             group_targets=getattr(self, "group_targets", None),
+                             radius_column=bool(self.tuning.get("group_radius_column", 1)))
+
+    def _batch(self, atom_type, bond_index, bond_type, batch, num_graphs, extend_order, topology=None):
         """Static topology + workspace of this call's batch (kept on the module afterwards so that
         tests and tools can inspect the device buffers; never reused across calls)."""
         key = None
-        topo = BatchTopology(atom_type, bond_index, bond_type, batch, num_graphs=num_graphs,
-                             extend_order=extend_order, order=self.config.edge_order, device=self._device(),
-                             group_targets=getattr(self, "group_targets", None),
-                             radius_column=bool(self.tuning.get("group_radius_column", 1)))
+        if topology is not None:
+            if topology.N != int(atom_type.shape[0]):
+                raise ValueError("topology was prepared for %d atoms, the batch has %d" % (topology.N, int(atom_type.shape[0])))
+            topo = topology.to(self._device())
+        else:
+            topo = self.prepare_topology(atom_type, bond_index, bond_type, batch, num_graphs, extend_order, device=self._device())
         ws = Workspace(topo)
         if self._packed is not None and topo.L:
             self._packed.ensure_local_types(topo.local_types)     # filter polynomials for this batch's local edge types
@@ -579,14 +590,15 @@ class LangevinRun:
     def __init__(self, model, atom_type, pos_init, bond_index, bond_type, batch, num_graphs, extend_order,
                  n_steps, step_lr, clip, clip_local, clip_pos, global_start_sigma, w_global, noise=None,
                  save_traj=True, skip_discarded_global=True, nan_check_every=64, step_indices=None, on_step=None,
-                 extend_radius=True, raise_on_nan=True, noise_mode="chunked", traj_overlap_min_bytes=16 << 20, **_ignored):
+                 extend_radius=True, raise_on_nan=True, noise_mode="chunked", traj_overlap_min_bytes=16 << 20, topology=None,
+                 **_ignored):
         self.model, self.lib = model, _lib.load()
         dev = model._device()
         self.sigmas = ((1.0 - model.alphas).sqrt() / model.alphas.sqrt()).detach().cpu()
         model.eval()
         with torch.no_grad():
             self.pk = model._renorm_embedding(atom_type)
-            self.topo, self.ws = model._batch(atom_type, bond_index, bond_type, batch, num_graphs, extend_order)
+            self.topo, self.ws = model._batch(atom_type, bond_index, bond_type, batch, num_graphs, extend_order, topology=topology)
             self.radius_flags = model._fwd_flags(self.topo, extend_radius, with_global=False)
             self._sampler_flag = _lib.DEFINES["AGDIFF_FWD_SAMPLER"]    # only radius edges' global scores are used (dualenc.py:516-518)
             self._stage0_done = False

@@ -191,15 +191,24 @@ class BatchTopology:
             loc_in_cand = np.bincount(dst[(src - gptr[ba[src]]) < m[dst]], minlength=N) if L else np.zeros(N, dtype=np.int64)
             rad_est = np.maximum(cand - loc_in_cand, 0)
             need_order = np.concatenate([need, ((rad_est + 3) // 4)[:, None]], axis=1)
+        # Consecutive graphs with the same need matrix -- the conformers of one molecule -- share one grouping: one look-up per
+        # run of such graphs, their quads written at once (a 200 k-atom batch has ~5,000 graphs of ~10 molecules).
         quad_tgt = []
-        for g in range(G):
-            # (conformers of one molecule share the grouping: cached by the molecule's need matrix)
-            idx = int(gptr[g]) + _group_order(need_order[gptr[g]:gptr[g + 1]], GT)
-            if idx.size % GT:
-                idx = np.concatenate([idx, np.full(GT - idx.size % GT, -1, dtype=idx.dtype)])
-            grp = np.full((idx.size // GT, 4), -1, dtype=np.int64)              # (always four entries per group: -1 = none)
-            grp[:, :GT] = idx.reshape(-1, GT)
-            quad_tgt.append(grp.reshape(-1))
+        size_change = np.flatnonzero(np.diff(counts)) + 1
+        for ga, gb in zip(np.concatenate([[0], size_change]), np.concatenate([size_change, [G]])):
+            n = int(counts[ga])
+            if n == 0:
+                continue
+            block = need_order[gptr[ga]:gptr[gb]].reshape(gb - ga, n, need_order.shape[1])
+            starts = np.concatenate([[0], np.flatnonzero(~(block[1:] == block[:-1]).all(axis=(1, 2))) + 1, [gb - ga]])
+            for sa, sb in zip(starts[:-1], starts[1:]):
+                idx = _group_order(block[sa], GT)
+                if idx.size % GT:
+                    idx = np.concatenate([idx, np.full(GT - idx.size % GT, -1, dtype=idx.dtype)])
+                grp = np.full((idx.size // GT, 4), -1, dtype=np.int64)          # (always four entries per group: -1 = none)
+                grp[:, :GT] = idx.reshape(-1, GT)
+                base = gptr[ga + sa:ga + sb].astype(np.int64)[:, None, None]
+                quad_tgt.append(np.where(grp[None] >= 0, grp[None] + base, -1).reshape(-1))
         quad_tgt = np.concatenate(quad_tgt).astype(np.int64) if quad_tgt else np.zeros(0, dtype=np.int64)
         Q = quad_tgt.size // 4
         qt = quad_tgt.reshape(Q, 4)
@@ -274,12 +283,32 @@ class BatchTopology:
             tm[int(ty) >> 6] |= 1 << (int(ty) & 63)
         for w in (0, 1):
             t.local_type_mask[w] = tm[w] - (1 << 64) if tm[w] >= (1 << 63) else tm[w]
-        for f in ("graph_ptr", "atom_type", "loc_src", "loc_dst", "loc_type", "loc_out_ptr", "loc_in_ptr", "loc_in_eid",
-                  "lc_src", "lc_dst", "lc_type", "lc_pos", "lc_mir", "loc_row", "loc_in_src",
-                  "loc_in_row", "lp_ptr", "lp_src", "lp_dst", "lp_type", "lp_row", "lc_ppos", "lc_pmir",
-                  "quad_tgt", "lt_ptr", "lt_src", "lt_type", "lc_tpos", "lc_tmir", "lcm_ptr"):
-            setattr(t, f, _lib.ptr(getattr(self, f)))
         self.struct = t
+        self._set_pointers()
+
+    _POINTER_FIELDS = ("graph_ptr", "atom_type", "loc_src", "loc_dst", "loc_type", "loc_out_ptr", "loc_in_ptr", "loc_in_eid",
+                       "lc_src", "lc_dst", "lc_type", "lc_pos", "lc_mir", "loc_row", "loc_in_src",
+                       "loc_in_row", "lp_ptr", "lp_src", "lp_dst", "lp_type", "lp_row", "lc_ppos", "lc_pmir",
+                       "quad_tgt", "lt_ptr", "lt_src", "lt_type", "lc_tpos", "lc_tmir", "lcm_ptr")
+
+    def _set_pointers(self):
+        for f in self._POINTER_FIELDS:
+            setattr(self.struct, f, _lib.ptr(getattr(self, f)))
+
+    def to(self, device):
+        """Move the index arrays to `device` (in place; returns self).  A topology is host work only -- numpy sorts and the
+        quad grouping -- so the driver builds the next batch's on the CPU in a background thread while the GPU samples the
+        current one (agdiff_amd/driver.py) and moves it over when its turn comes."""
+        import torch
+        device = torch.device(device)
+        if torch.device(self.device) == device:
+            return self
+        for name, v in list(vars(self).items()):
+            if isinstance(v, torch.Tensor):
+                setattr(self, name, v.to(device))
+        self.device = device
+        self._set_pointers()
+        return self
 
 
 class Workspace:
