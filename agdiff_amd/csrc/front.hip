@@ -33,6 +33,7 @@ struct FrontArgs {
   float* r_scale;
   const float* dist_union;   // agdiff_params_t.dist_union or null (then: one search per conv in dw[])
   int64_t rpad;
+  int32_t pad_rows;            // write the pad rows that complete a target's last 16-row radius tile
   const float* inv_r;          // [N * AGDIFF_RAD_STRIDE] global head output by radius row
   const float* dw[2 * AGDIFF_MAX_CONVS];
   int32_t n_scales;
@@ -436,7 +437,10 @@ __global__ void __launch_bounds__(AG_FRONT_THREADS) k_sampler_front(FrontArgs a)
     }
     const int cnt = rp0 - row0;
     if (lane == 0) a.rad_cnt[g0 + i] = cnt;
-    if (lane < ((cnt + AG_TW - 1) / AG_TW) * AG_TW - cnt) {     // pad rows: src = the target itself, length 0, scale 0
+    // pad rows (src = the target itself, length 0, scale 0) up to the end of the target's last 16-row tile: what k_cfconv_node
+    // reads.  k_cfconv_quad runs the rows from a target's count on with scale 0 itself (what they hold is older, finite data of
+    // the same molecule or the buffers' initial zeros), so on quads the 14 store instructions per target are not issued
+    if (a.pad_rows && lane < ((cnt + AG_TW - 1) / AG_TW) * AG_TW - cnt) {
       const int rp = rp0 + lane;
       a.rad_src[rp] = g0 + i;
       a.rad_len[rp] = 0.0f;
@@ -479,6 +483,7 @@ extern "C" int agdiff_sampler_front(const agdiff_params_t* p, const agdiff_topo_
   a.rad_len = ws->rad_len;
   a.r_scale = ws->r_scale;
   a.rpad = topo->num_nodes * (int64_t)AGDIFF_RAD_STRIDE;
+  a.pad_rows = !(topo->group_targets == 4 && p->tune_cfconv_quad_tiles >= 0);      // (agdiff_cfconv_node's choice of k_cfconv_quad)
   a.inv_r = ws->inv_r;
   for (int k = 0; k < p->num_convs; ++k) {
     a.dw[2 * k] = p->conv[k].dist_seg;

@@ -375,7 +375,10 @@ typedef struct agdiff_ws {
   /* CFConv by filter polynomials (agdiff_params_t.poly_kt > 0): the radius edges (type 0) of the dynamic graph by TARGET, in
    * AGDIFF_RAD_STRIDE rows per target (written by agdiff_graph_build next to the full list; sources ascending).  Rows
    * [rad_cnt[i], 16 ceil(rad_cnt[i] / 16)) of target i are pad rows (src = i, length 0, scale 0: agdiff_edge_scales_split
-   * writes them), rows beyond are never read: every 16-row tile belongs to ONE target. */
+   * writes them), rows beyond are never read by k_cfconv_node: every 16-row tile belongs to ONE target.  On quads
+   * (topo->group_targets == 4, p->tune_cfconv_quad_tiles >= 0: k_cfconv_quad) agdiff_sampler_front does NOT write the pad rows:
+   * that kernel runs rows [rad_cnt[i], 4 ceil(max over the quad / 4)) with scale 0 itself and only needs them to hold valid
+   * indices and finite numbers -- older rows of the same molecule, or the zeros the host allocated the buffers with. */
   int32_t* rad_cnt;          /* [N]  radius edges of target i (<= AGDIFF_RADIUS_CAP) */
   int32_t* rad_src;          /* [N * AGDIFF_RAD_STRIDE] */
   float*   rad_len;          /* [N * AGDIFF_RAD_STRIDE] */
