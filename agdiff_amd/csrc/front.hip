@@ -32,6 +32,8 @@ struct FrontArgs {
   float* rad_len;
   float* r_scale;
   const float* dist_union;   // agdiff_params_t.dist_union or null (then: one search per conv in dw[])
+  int32_t union_kinks;       // K, S of agdiff_params_t
+  int32_t union_segments;
   int64_t rpad;
   int32_t pad_rows;            // write the pad rows that complete a target's last 16-row radius tile
   const float* inv_r;          // [N * AGDIFF_RAD_STRIDE] global head output by radius row
@@ -103,13 +105,13 @@ __global__ void __launch_bounds__(AG_FRONT_THREADS) k_sampler_front(FrontArgs a)
   int* scan_c = reinterpret_cast<int*>(snew + 3 * nmax);
   uint32_t* radbits = reinterpret_cast<uint32_t*>(scan_c + nmax);
   uint32_t* locbits = radbits + nmax * words;
-  // the distance-weighting networks over their common segments (a.dist_union): 512 kinks + 385 x n_scales lines
+  // the distance-weighting networks over their common segments (a.dist_union): K kinks + S x n_scales lines
   float* skink = reinterpret_cast<float*>(locbits + nmax * words);
-  const float2* sline = reinterpret_cast<const float2*>(skink + 512);
+  const float2* sline = reinterpret_cast<const float2*>(skink + a.union_kinks);
   const bool by_union = a.dist_union != nullptr;
   __shared__ float red[3][AG_FRONT_THREADS / 64];
   __shared__ int nanw[AG_FRONT_THREADS / 64];
-  __shared__ float sseg[2 * AGDIFF_MAX_CONVS * 100];
+  float* sseg = skink;          // (without the union table: the per-conv tables, n_scales x 100 floats, in its place)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));     // lanes below mine
   auto bit = [&](const uint32_t* rows, int r, int c) -> bool { return (rows[r * words + (c >> 5)] >> (c & 31)) & 1u; };
@@ -124,15 +126,14 @@ __global__ void __launch_bounds__(AG_FRONT_THREADS) k_sampler_front(FrontArgs a)
   if ((a.do_graph || a.do_local) && !by_union)
     for (int i = threadIdx.x; i < a.n_scales * 100; i += blockDim.x) sseg[i] = a.dw[i / 100][i % 100];
   if ((a.do_graph || a.do_local) && by_union) {
-    const int words16 = (512 + 385 * 2 * a.n_scales) / 4;
+    const int words16 = (a.union_kinks + a.union_segments * 2 * a.n_scales + 3) / 4;
     ag_copy_lds<4>((lds_u32x4*)(ag_front_smem + (7 * nmax + 2 * nmax * words)), reinterpret_cast<const u32x4*>(a.dist_union), words16);
   }
-  // lw_cc(d) C(d) of every CFConv for one length: ONE search among the union of the networks' kinks (9 steps), then per conv
+  // lw_cc(d) C(d) of every CFConv for one length: ONE search among the union of the networks' kinks (log2 K steps), then per conv
   // the line its own table would have selected (the same floats: bit-identical to cf_dist_weight) and the sigmoid
   auto union_segment = [&](float d) -> int {
     int u = 0;
-#pragma unroll
-    for (int step = 256; step >= 1; step >>= 1) u += (skink[u + step - 1] <= d) ? step : 0;
+    for (int step = a.union_kinks >> 1; step >= 1; step >>= 1) u += (skink[u + step - 1] <= d) ? step : 0;
     return u;
   };
   auto scale_of = [&](int u, int cc, float d) -> float {
@@ -491,6 +492,11 @@ extern "C" int agdiff_sampler_front(const agdiff_params_t* p, const agdiff_topo_
   }
   a.n_scales = 2 * p->num_convs;
   a.dist_union = p->dist_union;
+  a.union_kinks = p->dist_union_kinks;
+  a.union_segments = p->dist_union_segments;
+  if (a.dist_union && (a.union_kinks < 2 || a.union_kinks > 512 || (a.union_kinks & (a.union_kinks - 1)) || a.union_segments < 1 ||
+                       a.union_segments > a.union_kinks))
+    return AGDIFF_ERR_ARG;
   a.cutoff = p->cutoff;
   a.r2 = cutoff * cutoff;
   a.smooth = p->smooth;
@@ -528,7 +534,8 @@ extern "C" int agdiff_sampler_front(const agdiff_params_t* p, const agdiff_topo_
   while (parts < 16 && 2 * parts * max_atoms <= bd) parts *= 2;
   a.parts = parts;
   const size_t smem = (size_t)(3 * nmax + 3 * nmax + nmax + 2 * nmax * a.words) * 4 +
-                      (a.dist_union ? (size_t)(512 + 385 * 2 * a.n_scales) * 4 : 0);
+                      (a.dist_union ? ((size_t)(a.union_kinks + a.union_segments * 2 * a.n_scales) * 4 + 15) / 16 * 16
+                                    : (size_t)a.n_scales * 100 * 4);
   if (smem > 48 * 1024) {
     static std::atomic<uint64_t> attr_done{0};
     // (the kernel also has ~6 KiB of static LDS: the dynamic part may not claim all 160 KiB)

@@ -399,26 +399,38 @@ def dist_segments(w1, b1, w2, b2):
     return np.concatenate([bp, alpha, beta, np.zeros(2)])
 
 
-def dist_union_table(segs):
-    """agdiff_params_t.dist_union from the per-conv tables (dist_segments, two per InteractionBlock, rounded to float32 as the
-    kernels read them): the union of all kinks ascending in [0..511] (+inf padded) and, for union segment u = number of
-    those kinks <= d, the line every conv's own table selects for such a d -- conv kinks <= d are exactly the conv's kinks
-    among the first u union kinks -- at [512 + (u * n + cc) * 2], cc = 2 k + (0 | 1), n = 2 num_convs."""
+def dist_union_table(segs, cutoff):
+    """(agdiff_params_t.dist_union, dist_union_kinks K, dist_union_segments S) from the per-conv tables (dist_segments, two per
+    InteractionBlock, rounded to float32 as the kernels read them): the union of all kinks that lie in (0, cutoff], ascending, in
+    [0..K-1] (K a power of two > their number, +inf padded) and, for union segment u = number of those kinks <= d (S = their
+    number + 1 segments), the line every conv's own table selects for a d in [0, cutoff] of that segment -- conv kinks <= d are
+    the conv's kinks <= 0 plus its kinks among the first u union kinks -- at [K + (u * n + cc) * 2], cc = 2 k + (0 | 1),
+    n = 2 num_convs.  Kinks outside (0, cutoff] cannot separate two lengths in [0, cutoff]; beyond the cutoff every scale is
+    multiplied by an envelope of exactly 0 (schnet.py:140-146), so any finite line serves there.  (The table sits in the LDS of
+    every workgroup of agdiff_sampler_front: 17 KiB instead of 39 for default-initialised networks, i.e. twice the workgroups
+    per CU.)"""
     tabs = [np.asarray(t, dtype=np.float64).astype(np.float32).reshape(2, 100) for t in segs]
     rows = [tabs[k][h] for k in range(len(tabs)) for h in (0, 1)]
     n = len(rows)
-    kinks = np.unique(np.concatenate([r[:32][np.isfinite(r[:32])] for r in rows])) if n else np.zeros(0, np.float32)
-    U = kinks.size
+    rc = np.float32(cutoff)
+    allk = np.concatenate([r[:32][np.isfinite(r[:32])] for r in rows]) if n else np.zeros(0, np.float32)
+    kinks = np.unique(allk[(allk > 0) & (allk <= rc)])
+    U = int(kinks.size)
     assert U <= 384
-    out = np.zeros(512 + 385 * 2 * n, dtype=np.float32)
-    out[:512] = np.inf
+    K = 2
+    while K <= U:
+        K *= 2
+    S = U + 1
+    out = np.zeros(K + S * 2 * n, dtype=np.float32)
+    out[:K] = np.inf
     out[:U] = kinks
-    for u in range(385):
+    for u in range(S):
+        upto = np.float32(0.0) if u == 0 else kinks[u - 1]
         for cc, r in enumerate(rows):
-            s_ = int(np.count_nonzero(r[:32] <= kinks[u - 1])) if (0 < u <= U) else (0 if u == 0 else int(np.count_nonzero(np.isfinite(r[:32]))))
-            out[512 + (u * n + cc) * 2] = r[32 + s_]
-            out[512 + (u * n + cc) * 2 + 1] = r[65 + s_]
-    return out
+            s_ = int(np.count_nonzero(r[:32] <= upto))
+            out[K + (u * n + cc) * 2] = r[32 + s_]
+            out[K + (u * n + cc) * 2 + 1] = r[65 + s_]
+    return out, K, S
 
 
 PRECISIONS = {"f32": 0, "bf16x3": 1, "f16x3": 2}
@@ -589,7 +601,8 @@ class PackedParams:
             arrays[n + "scale2_pk"] = pack_blocks(_np(sd, s + ".fc.2.weight"))
 
         # the DistanceWeightingNetworks of all CFConvs over their common segments (agdiff_params_t.dist_union)
-        arrays["dist_union"] = dist_union_table([arrays["conv%d.dist_seg" % k] for k in range(cfg.num_convs)])
+        arrays["dist_union"], self._union_kinks, self._union_segments = dist_union_table(
+            [arrays["conv%d.dist_seg" % k] for k in range(cfg.num_convs)], float(cfg.cutoff))
 
         # ---------------- GIN (gin.py:38-69, 112-148)
         for k in range(cfg.num_convs_local):
@@ -661,6 +674,7 @@ class PackedParams:
                   "ge_offset", "ge_emb", "schnet_emb", "gin_emb", "dist_union"):
             if f in offs:
                 setattr(prm, f, P(f))
+        prm.dist_union_kinks, prm.dist_union_segments = self._union_kinks, self._union_segments
         prm.edge_encoder = EDGE_ENCODERS[cfg.edge_encoder]
         prm.ge_coeff = scalars["ge_coeff"]
         for k in range(cfg.num_convs):

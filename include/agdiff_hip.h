@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 40
+#define AGDIFF_ABI_VERSION 41
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -152,11 +152,13 @@ typedef struct agdiff_params {
   const float* schnet_emb;   /* [100][128] encoder_global.embedding (max_norm renorm applied to used rows) */
   const float* gin_emb;      /* [100][128] encoder_local.node_emb */
   const int32_t* poly_type_slot; /* [100] or null: slot of an edge type in filt_poly_typed_pk, -1 = none */
-  const float* dist_union;   /* [512 + 385 * 2 * 2 num_convs] or null: the DistanceWeightingNetworks of all CFConvs (conv[k].dist_seg)
-                                over their COMMON segments: [0..511] the union of their kinks ascending (+inf padded; at most 384),
-                                then for union segment u = number of those kinks <= d and scale cc = 2 k + (0: conv1, 1: conv2)
-                                the line (alpha, beta) at [512 + (u * 2 num_convs + cc) * 2]: the same floats dist_seg selects
-                                for that d, found with ONE search instead of one per conv (agdiff_sampler_front) */
+  const float* dist_union;   /* [K + S * 2 * 2 num_convs] or null (K = dist_union_kinks, S = dist_union_segments below): the
+                                DistanceWeightingNetworks of all CFConvs (conv[k].dist_seg) over their COMMON segments on [0, cutoff]:
+                                [0..K-1] the union of their kinks in (0, cutoff] ascending (+inf padded; K a power of two > their
+                                number, at most 512), then for union segment u = number of those kinks <= d and scale
+                                cc = 2 k + (0: conv1, 1: conv2) the line (alpha, beta) at [K + (u * 2 num_convs + cc) * 2]: the same
+                                floats dist_seg selects for a d in [0, cutoff], found with ONE search instead of one per conv
+                                (agdiff_sampler_front; beyond the cutoff the envelope makes every scale exactly 0) */
   const float* attr_poly_typed_pk; /* [poly_num_slots + attr_poly_far_slots] x pk [8][1] or null: edge_attr itself (128 features) of a
                                 local edge of a slotted type as a polynomial in d on [0, cutoff] (agdiff_local_edge_rows); then, for
                                 the first attr_poly_far_slots slots, the same on [cutoff, attr_poly_far_hi] (below) */
@@ -234,6 +236,8 @@ typedef struct agdiff_params {
   int64_t tune_cfconv_four_min_quads; /* [8192] agdiff_cfconv_node at poly_kt 1: from this many quads on (two per wave of 256 x 16),
                                          16-wave workgroups at 128 VGPRs = four waves per SIMD, groups of two channel tiles;
                                          below, the 12-wave shape (more workgroups for the same quads); -1: never */
+  int32_t dist_union_kinks;    /* K: kink slots at the head of dist_union (a power of two in [2, 512]) */
+  int32_t dist_union_segments; /* S: segments (= kinks in (0, cutoff] + 1 <= K) whose lines follow */
 } agdiff_params_t;
 
 /* bits of agdiff_ws_t.variant_log: which kernel variants the launchers chose since the host last cleared it */

@@ -562,11 +562,13 @@ def test_distance_weighting_segments():
 
 
 def test_dist_union_table_selects_the_lines_of_the_per_conv_tables():
-    """agdiff_params_t.dist_union (packing.dist_union_table): for any length d the union segment u = number of union kinks
-    <= d carries, for every conv, exactly the (alpha, beta) floats that conv's own table (dist_segments: s = number of its
-    kinks <= d) selects -- so the fused front's ONE search gives bit-identical scales."""
+    """agdiff_params_t.dist_union (packing.dist_union_table): for any length d in [0, cutoff] the union segment u = number of
+    union kinks <= d carries, for every conv, exactly the (alpha, beta) floats that conv's own table (dist_segments: s = number
+    of its kinks <= d) selects -- so the fused front's ONE search gives bit-identical scales.  The union holds the kinks in
+    (0, cutoff] only: K slots (a power of two, +inf padded), S = their number + 1 segments."""
     from agdiff_amd.packing import dist_segments, dist_union_table
     rng = np.random.default_rng(3)
+    cutoff = 10.0
     segs = []
     for k in range(6):
         two = []
@@ -576,18 +578,33 @@ def test_dist_union_table_selects_the_lines_of_the_per_conv_tables():
             b1 = rng.normal(size=32) * 3.0
             if k == 2:
                 b1[:4] = -w1[:4] * 2.5                             # (coinciding kinks, also across convs below)
+            if k == 4:
+                b1[5], b1[6] = 0.0, -w1[6] * cutoff                # (a kink at exactly 0 and one at exactly the cutoff)
             two.append(dist_segments(w1, b1, rng.normal(size=32), float(rng.normal())))
         segs.append(np.concatenate(two))
     segs[3][:32] = segs[2][:32]                                    # conv1 of block 3 shares every kink with block 2's
-    tab = dist_union_table(segs)
+    tab, K, S = dist_union_table(segs, cutoff)
     n = 12
-    assert tab.shape[0] == 512 + 385 * 2 * n and np.all(np.diff(tab[:512][np.isfinite(tab[:512])]) > 0)
+    kinks = tab[:K]
+    fin = kinks[np.isfinite(kinks)]
+    assert K & (K - 1) == 0 and 2 <= K <= 512 and S == fin.size + 1 <= K and tab.shape[0] == K + S * 2 * n
+    assert np.all(np.diff(fin) > 0) and fin.min() > 0 and fin.max() <= np.float32(cutoff)
     rows = [np.asarray(segs[k], np.float64).astype(np.float32).reshape(2, 100)[h] for k in range(6) for h in (0, 1)]
-    kinks = tab[:512]
-    ds = np.concatenate([rng.uniform(-1.0, 12.0, 4000).astype(np.float32), kinks[np.isfinite(kinks)],
-                         np.nextafter(kinks[np.isfinite(kinks)], np.float32(-np.inf))])
+    every = np.concatenate([r[:32][np.isfinite(r[:32])] for r in rows])
+    assert fin.size == np.unique(every[(every > 0) & (every <= np.float32(cutoff))]).size < np.unique(every).size
+    ds = np.concatenate([rng.uniform(0.0, cutoff, 4000).astype(np.float32), fin, np.nextafter(fin, np.float32(-np.inf)),
+                         np.float32([0.0, cutoff])])
     for d in ds:
-        u = int(np.count_nonzero(kinks <= d))
+        # the kernel's search: steps K/2 .. 1 over the +inf padded slots
+        u, step = 0, K >> 1
+        while step >= 1:
+            u += step if kinks[u + step - 1] <= d else 0
+            step >>= 1
+        assert u == int(np.count_nonzero(kinks <= d)) < S
         for cc, r in enumerate(rows):
             s_ = int(np.count_nonzero(r[:32] <= d))
-            assert tab[512 + (u * n + cc) * 2] == r[32 + s_] and tab[512 + (u * n + cc) * 2 + 1] == r[65 + s_], (d, cc)
+            assert tab[K + (u * n + cc) * 2] == r[32 + s_] and tab[K + (u * n + cc) * 2 + 1] == r[65 + s_], (d, cc)
+    # beyond the cutoff the search still lands on a stored (finite) line: the envelope zeroes the scale there
+    for d in np.float32([cutoff * 1.0001, 50.0, 1e6]):
+        u = int(np.count_nonzero(kinks <= d))
+        assert u == S - 1 and np.isfinite(tab[K + u * n * 2: K + (u + 1) * n * 2]).all()
