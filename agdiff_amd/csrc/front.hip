@@ -414,8 +414,10 @@ __global__ void __launch_bounds__(AG_FRONT_THREADS) k_sampler_front(FrontArgs a)
         a.rad_src[rp] = g0 + j;
         a.rad_len[rp] = len;
         const float C = cf_envelope(len, a.cutoff, a.smooth);
-#ifdef AG_FRONT_ABL      // (timing experiment: the radius rows' scales without their evaluation -- wrong results)
-        for (int cc = 0; cc < a.n_scales; ++cc) a.r_scale[(size_t)cc * a.rpad + rp] = C;
+#if defined(AG_FRONT_ABL) && (AG_FRONT_ABL & 1)      // (timing experiments, wrong results: 1 the radius rows' scales without their evaluation,
+        for (int cc = 0; cc < a.n_scales; ++cc) a.r_scale[(size_t)cc * a.rpad + rp] = C;       //  2 only the first scale plane, 4 no canonical list)
+#elif defined(AG_FRONT_ABL) && (AG_FRONT_ABL & 2)
+        a.r_scale[rp] = scale_of(union_segment(len), 0, len) * C;
 #else
         if (by_union) {
           const int u = union_segment(len);
@@ -424,7 +426,11 @@ __global__ void __launch_bounds__(AG_FRONT_THREADS) k_sampler_front(FrontArgs a)
           for (int cc = 0; cc < a.n_scales; ++cc) a.r_scale[(size_t)cc * a.rpad + rp] = cf_dist_weight(sseg + cc * 100, len) * C;
         }
 #endif
+#if defined(AG_FRONT_ABL) && (AG_FRONT_ABL & 4)
+        if (false) {
+#else
         if (canon) {
+#endif
           const int cp = cp0 + __popcll(cmask & lt);
           a.c_len[cp] = len;
           a.c_src[cp] = g0 + j;

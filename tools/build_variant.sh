@@ -1,20 +1,17 @@
 #!/bin/bash
-# Build a variant of libagdiff_hip.so for same-box A/B runs:   bash tools/build_variant.sh <name> [extra hipcc flags]
-# (flags in $NODECONV_FLAGS go to nodeconv.hip only -- unset: the Makefile's scheduling strategy, empty: none --, $NODE_FLAGS to
-# node.hip, $EDGE_FLAGS to edge.hip)
-# -> _ab/lib_<name>.so (objects under _ab/build_<name>/; _ab/ is git-ignored but travels to the GPU box).
+# A variant of libagdiff_hip.so that differs in ONE translation unit (the other objects are the tree's):
+#   bash tools/build_variant.sh <file.hip> <name> [extra hipcc flags]   ->  _ab/lib_<name>.so     (AGDIFF_LIB=... selects it)
 set -e
 root=$(cd "$(dirname "$0")/.." && pwd)
-name=$1; shift
+src=$1; name=$2; shift 2
+base=${src%.hip}
+make -C "$root/agdiff_amd/csrc" > /dev/null
 mkdir -p "$root/_ab/build_$name"
 cd "$root/agdiff_amd/csrc"
-for f in graph front edge nodeconv node eval api; do
-  flags=""
-  [ $f = edge ] && flags="-fno-honor-nans $EDGE_FLAGS"
-  [ $f = nodeconv ] && flags="-fno-honor-nans -fno-slp-vectorize ${NODECONV_FLAGS--mllvm -amdgpu-sched-strategy=max-ilp}"
-  [ $f = node ] && flags="$NODE_FLAGS"
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -Wno-unused-function $flags "$@" -c $f.hip -o "$root/_ab/build_$name/$f.o" &
-done
-wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$root"/_ab/build_$name/*.o -o "$root/_ab/lib_$name.so"
+extra=""
+[ "$base" = nodeconv ] && extra="-fno-honor-nans -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=max-ilp"
+[ "$base" = edge ] && extra="-fno-honor-nans"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -Wno-unused-function $extra "$@" -c $src -o "$root/_ab/build_$name/$base.o"
+objs=$(ls _build/*.o | grep -v "/$base.o")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs "$root/_ab/build_$name/$base.o" -o "$root/_ab/lib_$name.so"
 echo "built _ab/lib_$name.so"
