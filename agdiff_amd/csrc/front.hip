@@ -36,6 +36,7 @@ struct FrontArgs {
   int32_t union_segments;
   int64_t rpad;
   int32_t pad_rows;            // write the pad rows that complete a target's last 16-row radius tile
+  const uint32_t* loc_bits;    // topo->loc_bits or null: [N][words] static local in-adjacency masks (bit j of row i: local edge j -> i)
   const float* inv_r;          // [N * AGDIFF_RAD_STRIDE] global head output by radius row
   const float* dw[2 * AGDIFF_MAX_CONVS];
   int32_t n_scales;
@@ -333,8 +334,15 @@ __global__ void __launch_bounds__(AG_FRONT_THREADS) k_sampler_front(FrontArgs a)
 
   // ================================================================== radius graph of step t + 1
   // static local in-adjacency of the molecule: the thread that owns target i sets its row
+  if (a.loc_bits) {          // (the masks are static: the host built them with the topology, a coalesced copy instead of a chain of
+                             // dependent index loads per target -- 15 % of the graph phase)
+    for (int k = threadIdx.x; k < n * words; k += blockDim.x) locbits[k] = a.loc_bits[(size_t)g0 * words + k];
+  } else
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     for (int w = 0; w < words; ++w) locbits[i * words + w] = 0u;
+#if defined(AG_FRONT_ABL) && (AG_FRONT_ABL & 8)       // (8: no local adjacency, 16: no scan of the canonical counts)
+    continue;
+#endif
     for (int k = a.loc_in_ptr[g0 + i]; k < a.loc_in_ptr[g0 + i + 1]; ++k) {
       const int j = a.loc_src[a.loc_in_eid[k]] - g0;
       locbits[i * words + (j >> 5)] |= 1u << (j & 31);
@@ -379,14 +387,32 @@ __global__ void __launch_bounds__(AG_FRONT_THREADS) k_sampler_front(FrontArgs a)
     wave_ctotal += cdeg;
   }
   __syncthreads();
-  for (int off = 1; off < n; off <<= 1) {          // inclusive scan of scan_c (n <= 512): Hillis-Steele in place
-    int vc[2], cnt = 0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x, ++cnt) vc[cnt] = scan_c[i] + (i >= off ? scan_c[i - off] : 0);
-    __syncthreads();
-    cnt = 0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x, ++cnt) scan_c[i] = vc[cnt];
-    __syncthreads();
+  // inclusive scan of scan_c (n <= 512) by ONE wave: eight consecutive counts per lane, a shuffle scan of the lanes' sums (the
+  // Hillis-Steele scan over the whole workgroup took two barriers per doubling: 13 % of the graph phase)
+#if !(defined(AG_FRONT_ABL) && (AG_FRONT_ABL & 16))
+  if (wave == 0) {
+    int run[8], sum = 0;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int idx = 8 * lane + t;
+      sum += (idx < n) ? scan_c[idx] : 0;
+      run[t] = sum;
+    }
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o);
+      incl += (lane >= o) ? up : 0;
+    }
+    const int excl = incl - sum;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int idx = 8 * lane + t;
+      if (idx < n) scan_c[idx] = run[t] + excl;
+    }
   }
+  __syncthreads();
+#endif
   __shared__ int cbase_s;
   if (threadIdx.x == 0) {
     cbase_s = atomicAdd(&a.canon_counter[a.parity], n ? scan_c[n - 1] : 0);
@@ -533,6 +559,7 @@ extern "C" int agdiff_sampler_front(const agdiff_params_t* p, const agdiff_topo_
   a.tpad = topo->num_local_tiles * (int64_t)AG_TW;
   a.nan_flag = ws->nan_flag;
   a.words = 2 * ((max_atoms + 63) / 64);
+  a.loc_bits = reinterpret_cast<const uint32_t*>(topo->loc_bits);       // (rows of 2 ceil(max_atoms_per_graph / 64) words, as a.words)
   const int nmax = a.words * 32;
   // threads per molecule and lanes per atom: as k_graph / k_langevin_update (node.hip, graph.hip)
   const int bd = topo->num_graphs >= 512 ? 512 : 1024;

@@ -259,6 +259,14 @@ class BatchTopology:
         self.lt_src = i32(np.where(real_t, src[np.maximum(eid_t, 0)], tgt_c) if L else np.zeros(16 * T))
         self.lt_type = i32(ltypes[tile_type_k][trow // 16] if T else np.zeros(0))     # every row of a tile carries the tile's type
         self.lt_real = real_t
+        # static local in-adjacency masks (agdiff_topo_t.loc_bits): bit (src - first atom of the molecule) of row dst
+        W = 2 * ((self.max_atoms + 63) // 64)
+        bits = np.zeros(N * W, dtype=np.uint32)
+        if L:
+            jl = src - gptr[ba[src]]
+            # (the local edges are unique, so every (row, word) sums DISTINCT powers of two: exact in float64, and a bincount)
+            bits = np.bincount(dst * W + (jl >> 5), weights=np.ldexp(1.0, (jl & 31).astype(np.int32)), minlength=N * W).astype(np.uint32)
+        self.loc_bits = torch.from_numpy(bits.view(np.int32)).to(device)
         self.lt_eid = eid_t
         self.lc_tpos = i32(tpos[lc_pos])
         self.lc_tmir = i32(np.where(lc_mir >= 0, tpos[np.maximum(lc_mir, 0)], -1))
@@ -289,7 +297,7 @@ class BatchTopology:
     _POINTER_FIELDS = ("graph_ptr", "atom_type", "loc_src", "loc_dst", "loc_type", "loc_out_ptr", "loc_in_ptr", "loc_in_eid",
                        "lc_src", "lc_dst", "lc_type", "lc_pos", "lc_mir", "loc_row", "loc_in_src",
                        "loc_in_row", "lp_ptr", "lp_src", "lp_dst", "lp_type", "lp_row", "lc_ppos", "lc_pmir",
-                       "quad_tgt", "lt_ptr", "lt_src", "lt_type", "lc_tpos", "lc_tmir", "lcm_ptr")
+                       "quad_tgt", "lt_ptr", "lt_src", "lt_type", "lc_tpos", "lc_tmir", "lcm_ptr", "loc_bits")
 
     def _set_pointers(self):
         for f in self._POINTER_FIELDS:

@@ -504,3 +504,17 @@ def test_fused_front_equals_the_unfused_loop(kind, mols, copies, precision):
     got_c = set(zip(ws.c_src.cpu().numpy()[live].tolist(), ws.c_dst.cpu().numpy()[live].tolist(),
                     ws.c_len.cpu().numpy()[live].tolist(), (ws.c_mir.cpu().numpy()[live] >= 0).tolist()))
     assert live.size == C and got_c == ref_c
+    # the local in-adjacency masks: copied from topo->loc_bits (host-built) or, without them, built in the kernel per step
+    assert topo.struct.loc_bits
+    with_bits = {k: getattr(ws, k).clone() for k in ("rad_cnt", "rad_src", "rad_len", "r_scale")}
+    keep, topo.struct.loc_bits = topo.struct.loc_bits, None
+    try:
+        for k in with_bits:
+            getattr(ws, k).fill_(0)
+        ws.canon_counter.zero_()
+        assert lib.agdiff_sampler_front(P, T, W, ctypes.byref(sa), 2, ctypes.c_float(cfg.cutoff), st) == 0
+        torch.cuda.synchronize()
+        for k in with_bits:
+            assert torch.equal(getattr(ws, k), with_bits[k]), k
+    finally:
+        topo.struct.loc_bits = keep

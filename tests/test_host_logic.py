@@ -608,3 +608,19 @@ def test_dist_union_table_selects_the_lines_of_the_per_conv_tables():
     for d in np.float32([cutoff * 1.0001, 50.0, 1e6]):
         u = int(np.count_nonzero(kinks <= d))
         assert u == S - 1 and np.isfinite(tab[K + u * n * 2: K + (u + 1) * n * 2]).all()
+
+
+def test_static_local_adjacency_masks():
+    """agdiff_topo_t.loc_bits: bit (src - first atom of the molecule) of row dst for every local edge, rows of
+    2 ceil(max atoms per molecule / 64) words -- what agdiff_sampler_front copies into LDS instead of walking the in-lists."""
+    from agdiff_amd import synth, topology
+    b = synth.make_packed_batch("drugs", 3, 4, seed=5)
+    tp = topology.BatchTopology(b["atom_type"], b["bond_index"], b["bond_type"], b["batch"], b["num_graphs"], device="cpu")
+    W = 2 * ((tp.max_atoms + 63) // 64)
+    bits = tp.loc_bits.numpy().view(np.uint32).reshape(tp.N, W)
+    src, dst, gp, ba = tp.loc_src.numpy(), tp.loc_dst.numpy(), tp.graph_ptr.numpy(), tp.batch64.numpy()
+    ref = np.zeros((tp.N, W), np.uint32)
+    for s_, d_ in zip(src, dst):
+        j = int(s_ - gp[ba[s_]])
+        ref[d_, j >> 5] |= np.uint32(1 << (j & 31))
+    assert np.array_equal(bits, ref) and int(np.unpackbits(bits.view(np.uint8)).sum()) == tp.L
