@@ -506,43 +506,40 @@ __global__ void __launch_bounds__(LDSW ? 1024 : 256, LDSW ? 1 : 2) k_gin_layer(G
     const u32x4* g2 = reinterpret_cast<const u32x4*>(a.gp.w2_pk);
     ag_copy_lds(L, g1, 32 * 128);
     ag_copy_lds(L + 32 * 128, g2, 32 * 128);
+    __syncthreads();
   }
   const int lane = ag_lane(), q = lane >> 4;
-  const int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const bool active = tile * AG_TW < a.n;
-  const int64_t node = tile * AG_TW + (lane & 15);
-  const bool valid = active && node < a.n;
-  const int64_t nd = valid ? node : 0;
-  const float* hin_self = a.emb ? a.emb + (size_t)a.atom_type[nd] * 128 : a.h_in + (size_t)nd * 128;
-
-  f32x4 m[8];
-#pragma unroll
-  for (int t = 0; t < 8; ++t) m[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 hself[8];
-  if (active) {
+  const int64_t tiles = (a.n + AG_TW - 1) / AG_TW;
+  // LDSW: PERSISTENT workgroups (at most one per CU: the launcher) -- the 128 KiB of weights are staged once and every wave
+  // walks its tiles without another barrier (768 one-round workgroups staged them three times per CU on 196 k atoms)
+  const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < tiles; tile += stride) {
+    const int64_t node = tile * AG_TW + (lane & 15);
+    const bool valid = node < a.n;
+    const int64_t nd = valid ? node : 0;
+    const float* hin_self = a.emb ? a.emb + (size_t)a.atom_type[nd] * 128 : a.h_in + (size_t)nd * 128;
+    f32x4 m[8], hself[8];
     ag_load_row<8, 0>(m, a.h_out + (size_t)nd * 128, q);
     ag_load_row<8, 0>(hself, hin_self, q);
-  }
-  if constexpr (LDSW) __syncthreads();
-  if (!active) return;
-  f32x4 y1[8];
-  ag_init_vec<8>(y1, a.gp.b1, q);
-  {
-    AgIn<MODE> mb[4];
-    ag_cvt_tiles<MODE, 4, 0>(m, mb);
-    AG_NODE_DENSE(false, 4, 8, 0, 0, mb, y1, a.gp.w1_pk, 0);
-  }
-  AG_FOR_TILE(y1, 8, ag_relu(v));
-  ag_init_vec<8>(m, a.gp.b2, q);
-  {
-    AgIn<MODE> yb[4];
-    ag_cvt_tiles<MODE, 4, 0>(y1, yb);
-    AG_NODE_DENSE(false, 4, 8, 0, 0, yb, m, a.gp.w2_pk, 32);
-  }
-  if (a.gp.relu_out) { AG_FOR_TILE(m, 8, ag_relu(v)); }
+    f32x4 y1[8];
+    ag_init_vec<8>(y1, a.gp.b1, q);
+    {
+      AgIn<MODE> mb[4];
+      ag_cvt_tiles<MODE, 4, 0>(m, mb);
+      AG_NODE_DENSE(false, 4, 8, 0, 0, mb, y1, a.gp.w1_pk, 0);
+    }
+    AG_FOR_TILE(y1, 8, ag_relu(v));
+    ag_init_vec<8>(m, a.gp.b2, q);
+    {
+      AgIn<MODE> yb[4];
+      ag_cvt_tiles<MODE, 4, 0>(y1, yb);
+      AG_NODE_DENSE(false, 4, 8, 0, 0, yb, m, a.gp.w2_pk, 32);
+    }
+    if (a.gp.relu_out) { AG_FOR_TILE(m, 8, ag_relu(v)); }
 #pragma unroll
-  for (int t = 0; t < 8; ++t) m[t] += hself[t];
-  if (valid) ag_store_row<8, 0>(m, a.h_out + (size_t)node * 128, q);
+    for (int t = 0; t < 8; ++t) m[t] += hself[t];
+    if (valid) ag_store_row<8, 0>(m, a.h_out + (size_t)node * 128, q);
+  }
 }
 
 // ------------------------------------------------------------------------------ Langevin update
@@ -1029,7 +1026,9 @@ extern "C" int agdiff_gin_encoder(const agdiff_params_t* p, const agdiff_topo_t*
   static std::atomic<uint64_t> attr_done{0};
   if (!ag_allow_big_lds(attr_done, (size_t)64 * 2048, k_gin_layer<AG_BF3, true>, k_gin_layer<AG_F32, true>, k_gin_layer<AG_H3, true>))
     return AGDIFF_ERR_LAUNCH;
-  const dim3 grid((unsigned)((tiles + waves - 1) / waves)), block(64 * waves);
+  int64_t wgs = (tiles + waves - 1) / waves;
+  if (ldsw && wgs > 256) wgs = 256;             // (persistent: one workgroup per CU walks its tiles with the weights resident)
+  const dim3 grid((unsigned)wgs), block(64 * waves);
   // ping-pong so that the final layer lands in ws->hl
   float* bufs[2] = {ws->hl, ws->hl2};
   int cur = (p->num_convs_local & 1) ? 0 : 1;   // layer 0 writes bufs[cur]; the last write must hit bufs[0]
