@@ -506,6 +506,60 @@ __global__ void __launch_bounds__(LDSW ? 1024 : 256, LDSW ? 1 : 2) k_gin_layer(G
     const u32x4* g2 = reinterpret_cast<const u32x4*>(a.gp.w2_pk);
     ag_copy_lds(L, g1, 32 * 128);
     ag_copy_lds(L + 32 * 128, g2, 32 * 128);
+  }
+  const int lane = ag_lane(), q = lane >> 4;
+  const int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const bool active = tile * AG_TW < a.n;
+  const int64_t node = tile * AG_TW + (lane & 15);
+  const bool valid = active && node < a.n;
+  const int64_t nd = valid ? node : 0;
+  const float* hin_self = a.emb ? a.emb + (size_t)a.atom_type[nd] * 128 : a.h_in + (size_t)nd * 128;
+
+  f32x4 m[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) m[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 hself[8];
+  if (active) {
+    ag_load_row<8, 0>(m, a.h_out + (size_t)nd * 128, q);
+    ag_load_row<8, 0>(hself, hin_self, q);
+  }
+  if constexpr (LDSW) __syncthreads();
+  if (!active) return;
+  f32x4 y1[8];
+  ag_init_vec<8>(y1, a.gp.b1, q);
+  {
+    AgIn<MODE> mb[4];
+    ag_cvt_tiles<MODE, 4, 0>(m, mb);
+    AG_NODE_DENSE(false, 4, 8, 0, 0, mb, y1, a.gp.w1_pk, 0);
+  }
+  AG_FOR_TILE(y1, 8, ag_relu(v));
+  ag_init_vec<8>(m, a.gp.b2, q);
+  {
+    AgIn<MODE> yb[4];
+    ag_cvt_tiles<MODE, 4, 0>(y1, yb);
+    AG_NODE_DENSE(false, 4, 8, 0, 0, yb, m, a.gp.w2_pk, 32);
+  }
+  if (a.gp.relu_out) { AG_FOR_TILE(m, 8, ag_relu(v)); }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) m[t] += hself[t];
+  if (valid) ag_store_row<8, 0>(m, a.h_out + (size_t)node * 128, q);
+}
+
+// The same layer with PERSISTENT workgroups (the launcher: more 16-wave rounds than CUs): the two matrices are staged once per CU
+// and every wave walks its tiles without another barrier -- 768 one-round workgroups staged the 128 KiB three times per CU on
+// 196 k atoms (288 -> 218 us in-step).  Its own kernel: with the loop around the one-round body the small-batch and exact-fp32
+// instantiations compiled to slower code (alanine dipeptide +28 %, exact fp32 on 47 k atoms +17 % per step).
+template <int MODE>
+__global__ void __launch_bounds__(1024, 1) k_gin_layer_persistent(GinArgs a) {
+  constexpr bool LDSW = true;
+  extern __shared__ u32x4 ag_gin_smem[];
+  lds_u32x4* L = (lds_u32x4*)ag_gin_smem;
+  constexpr int PF = (MODE == AG_F32) ? 3 : 10;
+  if constexpr (LDSW) {
+    const u32x4* g1 = reinterpret_cast<const u32x4*>(a.gp.w1_pk);
+    const u32x4* g2 = reinterpret_cast<const u32x4*>(a.gp.w2_pk);
+    ag_copy_lds(L, g1, 32 * 128);
+    ag_copy_lds(L + 32 * 128, g2, 32 * 128);
     __syncthreads();
   }
   const int lane = ag_lane(), q = lane >> 4;
@@ -1024,10 +1078,12 @@ extern "C" int agdiff_gin_encoder(const agdiff_params_t* p, const agdiff_topo_t*
   if (ldsw) ag_log_variant(ws, AGDIFF_VAR_GIN_LDSW);
   const size_t smem = ldsw ? (size_t)64 * 2048 : 0;
   static std::atomic<uint64_t> attr_done{0};
-  if (!ag_allow_big_lds(attr_done, (size_t)64 * 2048, k_gin_layer<AG_BF3, true>, k_gin_layer<AG_F32, true>, k_gin_layer<AG_H3, true>))
+  if (!ag_allow_big_lds(attr_done, (size_t)64 * 2048, k_gin_layer<AG_BF3, true>, k_gin_layer<AG_F32, true>, k_gin_layer<AG_H3, true>,
+                        k_gin_layer_persistent<AG_BF3>, k_gin_layer_persistent<AG_H3>))
     return AGDIFF_ERR_LAUNCH;
   int64_t wgs = (tiles + waves - 1) / waves;
-  if (ldsw && wgs > 256) wgs = 256;             // (persistent: one workgroup per CU walks its tiles with the weights resident)
+  const bool persistent = ldsw && wgs > 256 && p->precision_local != AG_F32;   // (one workgroup per CU walks its tiles, weights resident)
+  if (persistent) wgs = 256;
   const dim3 grid((unsigned)wgs), block(64 * waves);
   // ping-pong so that the final layer lands in ws->hl
   float* bufs[2] = {ws->hl, ws->hl2};
@@ -1049,10 +1105,12 @@ extern "C" int agdiff_gin_encoder(const agdiff_params_t* p, const agdiff_topo_t*
     k_gin_gather<<<dim3((unsigned)((((topo->num_nodes + 7) / 8) + 7) / 8 * 8)), dim3(256), 0, st>>>(a);   // grid: multiple of 8 (XCD ranges)
     AG_CHECK_LAUNCH();
     if (p->precision_local == AG_H3) {
-      if (ldsw) k_gin_layer<AG_H3, true><<<grid, block, smem, st>>>(a);
+      if (persistent) k_gin_layer_persistent<AG_H3><<<grid, block, smem, st>>>(a);
+      else if (ldsw) k_gin_layer<AG_H3, true><<<grid, block, smem, st>>>(a);
       else k_gin_layer<AG_H3, false><<<grid, block, 0, st>>>(a);
     } else if (p->precision_local == AG_BF3) {
-      if (ldsw) k_gin_layer<AG_BF3, true><<<grid, block, smem, st>>>(a);
+      if (persistent) k_gin_layer_persistent<AG_BF3><<<grid, block, smem, st>>>(a);
+      else if (ldsw) k_gin_layer<AG_BF3, true><<<grid, block, smem, st>>>(a);
       else k_gin_layer<AG_BF3, false><<<grid, block, 0, st>>>(a);
     } else {
       if (ldsw) k_gin_layer<AG_F32, true><<<grid, block, smem, st>>>(a);
