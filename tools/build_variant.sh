@@ -12,6 +12,6 @@ extra=""
 [ "$base" = nodeconv ] && extra="-fno-honor-nans -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=max-ilp"
 [ "$base" = edge ] && extra="-fno-honor-nans"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -Wno-unused-function $extra "$@" -c $src -o "$root/_ab/build_$name/$base.o"
-objs=$(ls _build/*.o | grep -v "/$base.o")
+objs=$(ls _build/*.o | grep -v -F "/$base.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs "$root/_ab/build_$name/$base.o" -o "$root/_ab/lib_$name.so"
 echo "built _ab/lib_$name.so"
