@@ -161,7 +161,13 @@ __global__ void __launch_bounds__(AG_FRONT_THREADS) k_sampler_front(FrontArgs a)
     const int was_bad = a.nan_flag[1 + g];       // quarantine of graphs that went NaN: see k_langevin_update (node.hip)
     float sx = 0.f, sy = 0.f, sz = 0.f;
     int bad = 0;
-    const int P = a.parts, part = threadIdx.x & (P - 1);
+    // lanes per atom: as many as the workgroup has for THIS molecule (a power of two <= 16; the launcher's a.parts is the value
+    // for the batch's largest molecule -- with it a 44-atom molecule in a batch that also holds a 181-atom one kept 468 of its 512
+    // threads idle while 44 walked their edge lists alone)
+    int P = 1;
+    while (P < 16 && 2 * P * n <= (int)blockDim.x) P *= 2;
+    if (P < a.parts) P = a.parts;
+    const int part = threadIdx.x & (P - 1);
     const int per_pass = blockDim.x / P;
     for (int base = 0; base < n; base += per_pass) {
       const int li = base + (int)(threadIdx.x / P);
