@@ -109,6 +109,9 @@ struct NodeConvShape {
 #ifndef AG_QUAD_STORE_NT
 #define AG_QUAD_STORE_NT 1
 #endif
+#ifndef AG_QUAD_DYNAMIC
+#define AG_QUAD_DYNAMIC 1      // k_cfconv_quad: a workgroup's quads dealt to its waves as they finish (0: quad p_begin + wave, + WAVES, ...)
+#endif
 #ifndef AG_NODE_ABL
 #define AG_NODE_ABL 0       // timing experiments only (wrong results): 1 no x gathers, 2 no filter MFMAs, 4 no features, 8 no sums, 16 one coefficient read per group
                             // (k_cfconv_quad: 1, 8 and 16 -- one read per tile -- only)
@@ -459,6 +462,14 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_quad(NodeConvA
   constexpr int NG = AG_CONV_NCH / GRP;
   ag_copy_lds(wl, reinterpret_cast<const u32x4*>(a.poly_rad), SET);
   if (a.lds_slots > 0) ag_copy_lds(wl + SET, reinterpret_cast<const u32x4*>(a.poly_typed), a.lds_slots * SET);
+#if AG_QUAD_DYNAMIC
+  // the workgroup's quads are DEALT to its waves as they finish (one LDS counter): a quad has 5 to 13 tiles, and with the static
+  // deal (quad p_begin + wave, + WAVES, ...) the slowest wave of a workgroup walked 18..35 % more tiles than the average one
+  // (counted on the default job's batches).  A quad's result does not depend on the wave that computes it.
+  typedef __attribute__((address_space(3))) int lds_ctr_t;
+  lds_ctr_t* next_quad = reinterpret_cast<lds_ctr_t*>(wl + (size_t)(1 + (a.lds_slots > 0 ? a.lds_slots : 0)) * SET) + WAVES * 32;
+  if (threadIdx.x == 0) *next_quad = WAVES;
+#endif
   __syncthreads();
   int lane = ag_lane();
   asm volatile("" : "+v"(lane));
@@ -627,7 +638,13 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_quad(NodeConvA
   AG_RQ_LOAD(c_, p, 0);
   bool have_pf = false;
   while (p < p_end) {
+#if AG_QUAD_DYNAMIC
+    int take = 0;
+    if (lane == 0) take = __hip_atomic_fetch_add(next_quad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const int pn = p_begin + __builtin_amdgcn_readfirstlane(take);
+#else
     const int pn = p + WAVES;
+#endif
     AG_RQ_DECL(x_);
     if (pn < p_end) AG_RQ_LOAD(x_, pn, cslot ^ 1);
     const int ntiles = c_nL + c_nR;
@@ -802,7 +819,7 @@ extern "C" int agdiff_cfconv_node(const agdiff_params_t* p, const agdiff_topo_t*
   a.qshift = topo->group_targets == 4 ? 0 : topo->group_targets == 2 ? 1 : 2;
   a.two_over_rc = 2.0f / p->cutoff;
   a.unscale = p->conv[k].filt_poly_unscale;
-  const size_t smem = (size_t)(1 + a.lds_slots) * set_bytes + 2048;       // (+ k_cfconv_quad's per-wave quad words)
+  const size_t smem = (size_t)(1 + a.lds_slots) * set_bytes + 2048 + 64;  // (+ k_cfconv_quad's per-wave quad words and its quad counter)
   // shape: four waves per SIMD pay from two quads per wave of a full grid on (below, 12-wave workgroups spread the quads wider)
   const int64_t four_min = p->tune_cfconv_four_min_quads ? p->tune_cfconv_four_min_quads : 8192;
   const bool four = p->poly_kt == 1 && four_min >= 0 && a.num_quads >= four_min;
