@@ -41,6 +41,7 @@ struct NodeConvArgs {
   const float* xs;            // [N][192]
   float* agg;                 // [N][192]
   int32_t n;                  // N
+  const int32_t* wg_ptr;      // topo->quad_wg_ptr (k_cfconv_quad on a grid of 256) or null
   int32_t num_quads;          // Q
   int32_t qshift;             // a local tile's rows of lane quarter q belong to the quad's (q >> qshift)-th target (GT = 4 >> qshift)
   float two_over_rc;
@@ -478,8 +479,10 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_quad(NodeConvA
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wg = (gridDim.x % 8 == 0) ? (int)((blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8) : (int)blockIdx.x;
   const int per_wg = (a.num_quads + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int p_begin = wg * per_wg;
-  const int p_end = (p_begin + per_wg < a.num_quads) ? p_begin + per_wg : a.num_quads;
+  // (the host's ranges of like tile counts where it made them, else equal quad counts)
+  const bool ranges = a.wg_ptr != nullptr && gridDim.x == 256;
+  const int p_begin = ranges ? a.wg_ptr[wg] : wg * per_wg;
+  const int p_end = ranges ? a.wg_ptr[wg + 1] : (p_begin + per_wg < a.num_quads) ? p_begin + per_wg : a.num_quads;
   const bool with_local = a.num_slots > 0;
 
   // a quad: nL local tiles from lt0 and nR radius tiles in scalars.  What differs by quarter -- the first radius row of the
@@ -815,6 +818,7 @@ extern "C" int agdiff_cfconv_node(const agdiff_params_t* p, const agdiff_topo_t*
   a.xs = ws->xs;
   a.agg = ws->agg;
   a.n = (int32_t)topo->num_nodes;
+  a.wg_ptr = topo->quad_wg_ptr;
   a.num_quads = (int32_t)topo->num_quads;
   a.qshift = topo->group_targets == 4 ? 0 : topo->group_targets == 2 ? 1 : 2;
   a.two_over_rc = 2.0f / p->cutoff;

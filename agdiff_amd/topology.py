@@ -184,13 +184,15 @@ class BatchTopology:
         # (models/common.py:217; AGDIFF_RADIUS_CAP), minus those that are local edges.  Only an ordering heuristic: the kernels
         # take the row counts of the graph that was built.
         need_order = need
-        if GT == 4 and radius_column:
+        rad_est = None
+        if GT == 4:
             li = np.arange(N) - gptr[ba]
             m = np.minimum(n_of_node, _lib.RADIUS_CAP)
             cand = np.where(li < m, m - 1, m)
             loc_in_cand = np.bincount(dst[(src - gptr[ba[src]]) < m[dst]], minlength=N) if L else np.zeros(N, dtype=np.int64)
             rad_est = np.maximum(cand - loc_in_cand, 0)
-            need_order = np.concatenate([need, ((rad_est + 3) // 4)[:, None]], axis=1)
+            if radius_column:
+                need_order = np.concatenate([need, ((rad_est + 3) // 4)[:, None]], axis=1)
         # Consecutive graphs with the same need matrix -- the conformers of one molecule -- share one grouping: one look-up per
         # run of such graphs, their quads written at once (a 200 k-atom batch has ~5,000 graphs of ~10 molecules).
         quad_tgt = []
@@ -216,6 +218,17 @@ class BatchTopology:
         nt_quad = qneed.sum(axis=1)
         lt_ptr = np.concatenate([[0], np.cumsum(nt_quad)])
         T = int(lt_ptr[-1])
+        # agdiff_topo_t.quad_wg_ptr: the quads cut into 256 contiguous ranges of like TILE counts (local tiles + the radius tiles a
+        # quad has while its molecule lies inside the cutoff) for k_cfconv_quad's 256 persistent workgroups: with equal QUAD counts
+        # the busiest workgroup of a default-job batch walked 4..12 % more tiles than the average one
+        if GT == 4 and Q >= 256:
+            rq = np.where(qt >= 0, rad_est[np.maximum(qt, 0)], 0).max(axis=1)
+            cost = np.cumsum(nt_quad + (rq + 3) // 4)
+            cuts = np.searchsorted(cost, cost[-1] * np.arange(1, 256) / 256.0, side="left") + 1
+            wg_ptr = np.concatenate([[0], np.minimum(cuts, Q), [Q]])
+            wg_ptr = np.maximum.accumulate(wg_ptr)
+        else:
+            wg_ptr = np.zeros(0, dtype=np.int64)
         # a target's in-edges of one type in order of source: position of every local edge inside its (target, type) list
         by_tts = np.lexsort((src, typ, dst)) if L else np.zeros(0, dtype=np.int64)
         rank_in = np.zeros(L, dtype=np.int64)
@@ -259,6 +272,7 @@ class BatchTopology:
         self.lt_src = i32(np.where(real_t, src[np.maximum(eid_t, 0)], tgt_c) if L else np.zeros(16 * T))
         self.lt_type = i32(ltypes[tile_type_k][trow // 16] if T else np.zeros(0))     # every row of a tile carries the tile's type
         self.lt_real = real_t
+        self.quad_wg_ptr = i32(wg_ptr) if wg_ptr.size else None
         # static local in-adjacency masks (agdiff_topo_t.loc_bits): bit (src - first atom of the molecule) of row dst
         W = 2 * ((self.max_atoms + 63) // 64)
         bits = np.zeros(N * W, dtype=np.uint32)
@@ -302,6 +316,7 @@ class BatchTopology:
     def _set_pointers(self):
         for f in self._POINTER_FIELDS:
             setattr(self.struct, f, _lib.ptr(getattr(self, f)))
+        self.struct.quad_wg_ptr = _lib.ptr(self.quad_wg_ptr) if self.quad_wg_ptr is not None else None
 
     def to(self, device):
         """Move the index arrays to `device` (in place; returns self).  A topology is host work only -- numpy sorts and the

@@ -322,6 +322,9 @@ typedef struct agdiff_topo {
   const int32_t* lt_type;    /* [16 T] (the same for the 16 rows of a tile) */
   const int32_t* lc_tpos;    /* [Lc]: quad-tile row of the canonical edge */
   const int32_t* lc_tmir;    /* [Lc]: ... of its mirror, or -1 */
+  const int32_t* quad_wg_ptr;/* [257] or null: workgroup w of agdiff_cfconv_node's 256 persistent workgroups (k_cfconv_quad) owns the quads
+                                [quad_wg_ptr[w], quad_wg_ptr[w+1]) -- contiguous ranges of like tile counts; null (or fewer workgroups):
+                                equal quad counts */
   const int32_t* loc_bits;   /* [N][W], W = 2 ceil(max_atoms_per_graph / 64) 32-bit words, or null: the static local in-adjacency of
                                 every atom as a bit mask over its molecule's atoms -- bit (j - graph_ptr[g]) of row i is set when
                                 the local edge j -> i exists.  agdiff_sampler_front copies a molecule's rows into LDS (the radius

@@ -624,3 +624,34 @@ def test_static_local_adjacency_masks():
         j = int(s_ - gp[ba[s_]])
         ref[d_, j >> 5] |= np.uint32(1 << (j & 31))
     assert np.array_equal(bits, ref) and int(np.unpackbits(bits.view(np.uint8)).sum()) == tp.L
+
+
+def test_workgroup_ranges_of_like_tile_counts():
+    """agdiff_topo_t.quad_wg_ptr: 256 contiguous quad ranges covering every quad once, cut so that the tiles a workgroup of
+    k_cfconv_quad walks (local tiles + the radius tiles of a compact molecule) are balanced better than by equal quad counts."""
+    from agdiff_amd import synth, topology
+    b = synth.make_packed_batch("drugs", 12, 40, seed=7)
+    tp = topology.BatchTopology(b["atom_type"], b["bond_index"], b["bond_type"], b["batch"], b["num_graphs"], device="cpu", group_targets=4)
+    assert tp.Q >= 256 and tp.quad_wg_ptr is not None
+    w = tp.quad_wg_ptr.numpy().astype(np.int64)
+    assert w.shape == (257,) and w[0] == 0 and w[-1] == tp.Q and np.all(np.diff(w) >= 0)
+    # estimated tiles per quad as the topology counts them
+    N, gp, ba = tp.N, tp.graph_ptr.numpy().astype(np.int64), tp.batch64.numpy()
+    n_of = np.diff(gp)[ba]
+    li = np.arange(N) - gp[ba]
+    m = np.minimum(n_of, 33)
+    cand = np.where(li < m, m - 1, m)
+    src, dst = tp.loc_src.numpy().astype(np.int64), tp.loc_dst.numpy().astype(np.int64)
+    cnt = cand - np.bincount(dst[(src - gp[ba[src]]) < m[dst]], minlength=N)
+    qt = tp.quad_tgt.numpy().astype(np.int64).reshape(-1, 4)
+    tiles = np.diff(tp.lt_ptr.numpy().astype(np.int64)) + ((np.where(qt >= 0, cnt[np.maximum(qt, 0)], 0).max(axis=1) + 3) // 4)
+    cs = np.concatenate([[0], np.cumsum(tiles)])
+    by_tiles = cs[w[1:]] - cs[w[:-1]]
+    per = (tp.Q + 255) // 256
+    eq = np.minimum(np.arange(257) * per, tp.Q)
+    by_quads = cs[eq[1:]] - cs[eq[:-1]]
+    # (a range ends at a quad boundary: within one quad's tiles of the mean, and never worse than equal quad counts)
+    assert by_tiles.max() - by_tiles.mean() <= tiles.max() and by_tiles.min() >= by_tiles.mean() - tiles.max()
+    assert by_tiles.max() <= by_quads.max()
+    small = topology.BatchTopology(b["atom_type"][:60], np.zeros((2, 0), np.int64), np.zeros(0, np.int64), np.zeros(60, np.int64), 1, device="cpu")
+    assert small.quad_wg_ptr is None
