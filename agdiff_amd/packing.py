@@ -795,8 +795,8 @@ class PackedParams:
     def ensure_local_types(self, types):
         """Give every local edge type of a batch (BatchTopology.local_types) a filter-polynomial slot, so that
         agdiff_cfconv_node needs no edge_attr for the local edges either (include/agdiff_hip.h: poly_num_slots).  Slots are
-        kept in order of first appearance (the first ones that fit stay LDS-resident in the kernel, later ones are read
-        from L2), fitted with the radius edges' number of terms (poly_kt).  A type whose fit misses POLY_TOL, or a type beyond
+        kept in order of first appearance, the types of one batch by expected row count (the first ones that fit stay
+        LDS-resident in the kernel, later ones are read from L2), fitted with the radius edges' number of terms (poly_kt).  A type whose fit misses POLY_TOL, or a type beyond
         AGDIFF_POLY_MAX_SLOTS, gets no slot: ITS edges go through the filter MLPs (agdiff_cfconv_local, in a "mixed" batch
         next to agdiff_cfconv_node's polynomial tiles for the slotted types); everything else keeps its polynomials.
         Returns True when every type of `types` has a slot."""
@@ -806,6 +806,11 @@ class PackedParams:
         new = [int(t) for t in types if int(t) not in self.local_slots and int(t) not in self.poly_refused_types]
         if not new:
             return not any(int(t) in self.poly_refused_types for t in types)
+        # (the kernel keeps the FIRST slots' sets in LDS -- five at 32 terms -- and reads later ones from L2: the types with the most
+        # rows first -- 3-hop, 2-hop, single, aromatic, double bonds -- so that with all six of GEOM-Drugs' types in one batch it is
+        # the triple bonds' set that comes from L2, not the 3-hop edges')
+        rank = {24: 0, 23: 1, 1: 2, 12: 3, 2: 4}
+        new.sort(key=lambda t: (rank.get(t, 5), t))
         prm = self.struct
         max_slots = _lib.DEFINES["AGDIFF_POLY_MAX_SLOTS"]
         kt = self.poly_kt
