@@ -118,8 +118,13 @@ def prepare_batch(model, bmols, confs_of, rank=0, world=1):
         part = shard_of(packed, rank, world)[0]
         if part is None:
             return packed, None
-    return packed, model.prepare_topology(part["atom_type"], part["bond_index"], part["bond_type"], part["batch"], part["num_graphs"],
-                                          extend_order=False, device="cpu")
+    try:
+        return packed, model.prepare_topology(part["atom_type"], part["bond_index"], part["bond_type"], part["batch"], part["num_graphs"],
+                                              extend_order=False, device="cpu")
+    except Exception:
+        # (a batch the topology refuses -- e.g. a molecule beyond the atom limit: the sampler builds it again and raises THERE, where
+        # sample_batch_sharded keeps a failing rank's collectives in step with the others)
+        return packed, None
 
 
 def sample_batch(model, packed, device, sampler_kwargs, save_traj=False, max_retry=2, log=print, pos_init=None,
@@ -310,6 +315,15 @@ def run_job(model, mols, out_dir, confs_of, max_atoms, sampler_kwargs, device, s
         f.set_result(bidx)                 # (resolved below, when the batch's turn comes)
         return f
     fut = submit(mine[0]) if mine else None
+    try:
+        return _run_job_batches(model, batches, mine, fut, submit, prep, inline, shard, device, sampler_kwargs, save_traj, log, out_dir, rank,
+                                world)
+    finally:
+        pool.shutdown(wait=True)
+
+
+def _run_job_batches(model, batches, mine, fut, submit, prep, inline, shard, device, sampler_kwargs, save_traj, log, out_dir, rank, world):
+    import torch.distributed as dist
     for pos_in_mine, bidx in enumerate(mine):
         bmols = batches[bidx]
         packed, topology = prep(fut.result()) if inline else fut.result()
@@ -337,7 +351,6 @@ def run_job(model, mols, out_dir, confs_of, max_atoms, sampler_kwargs, device, s
         _save_npz_atomic(_batch_path(out_dir, bmols), out)
         log("rank %d: batch %d/%d (%d of %d molecules, %d conformers) saved" % (rank, bidx + 1, len(batches),
                                                                                int(ok.sum()), len(bmols), packed["num_graphs"]))
-    pool.shutdown(wait=True)
     if world > 1:
         dist.barrier()                       # every rank's batch files are on disk
     if SAMPLE_STATS["range_trips"]:

@@ -308,3 +308,33 @@ def test_compat_install_aliases_the_reference_import_path():
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+def test_prepare_batch_leaves_a_refused_topology_to_the_sampler():
+    """driver.prepare_batch runs ahead of the sampler in a background thread: a batch whose topology cannot be built (a molecule
+    beyond the atom limit, ...) must not raise there -- on one rank of a sharded job that would leave the other ranks inside
+    their collectives -- but come back without a topology, so that the sampler builds it again and fails where failures are
+    kept in step (dist.sample_batch_sharded)."""
+    from agdiff_amd import driver
+
+    class Refuses:
+        def prepare_topology(self, *a, **k):
+            raise NotImplementedError("graphs with more than 512 atoms are not supported")
+
+    class Builds:
+        def prepare_topology(self, atom_type, *a, **k):
+            return ("topology of", int(np.asarray(atom_type).shape[0]))
+
+    rng = np.random.default_rng(0)
+    mols = []
+    for i in range(2):
+        n = 5 + i
+        mols.append(dict(atom_type=rng.integers(1, 9, n), edge_index=np.stack([np.arange(n - 1), np.arange(1, n)]),
+                         edge_type=np.ones(n - 1, dtype=np.int64), num_refs=1, name="m%d" % i, index=i))
+    confs = driver.num_confs("2")
+    packed, topo = driver.prepare_batch(Refuses(), mols, confs)
+    assert topo is None and packed["num_graphs"] == 4
+    packed, topo = driver.prepare_batch(Builds(), mols, confs)
+    assert topo == ("topology of", packed["atom_type"].shape[0])
+    packed, topo = driver.prepare_batch(object(), mols, confs)            # (test stubs without prepare_topology)
+    assert topo is None
