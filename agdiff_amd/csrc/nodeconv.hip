@@ -7,6 +7,15 @@
 
 #define AG_CONV_NCH 12          // 16-channel tiles of the 192 filter channels (conv1: 0..7, conv2: 8..11)
 
+#ifdef AG_QUAD_STAMPS      // (debug build: start / end clock of every workgroup of the last k_cfconv_quad launch -- tools/quad_stamps.py)
+__device__ unsigned long long ag_quad_stamp[2 * 256];
+extern "C" int agdiff_debug_quad_stamps(unsigned long long* out) {      // (reads the stamps and clears them for the next launch)
+  static unsigned long long zero[2 * 256];
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ag_quad_stamp), sizeof(ag_quad_stamp)) != hipSuccess) return AGDIFF_ERR_LAUNCH;
+  return hipMemcpyToSymbol(HIP_SYMBOL(ag_quad_stamp), zero, sizeof(zero)) == hipSuccess ? AGDIFF_OK : AGDIFF_ERR_LAUNCH;
+}
+#endif
+
 namespace {
 
 template <int I, int N, typename F>
@@ -471,6 +480,12 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_quad(NodeConvA
   lds_ctr_t* next_quad = reinterpret_cast<lds_ctr_t*>(wl + (size_t)(1 + (a.lds_slots > 0 ? a.lds_slots : 0)) * SET) + WAVES * 32;
   if (threadIdx.x == 0) *next_quad = WAVES;
 #endif
+  // edge type -> coefficient set, in LDS: a local tile's set is looked up when its features are made, by an LDS read.  (As a second,
+  // dependent global load in the tile's prefetch it had to wait for the type to arrive -- and with it, in order, for every gather
+  // in flight: a local tile cost 1.5 x a radius tile, tools/quad_stamps.py.)
+  typedef __attribute__((address_space(3))) int lds_tab_t;
+  lds_tab_t* tslot = reinterpret_cast<lds_tab_t*>(wl + (size_t)(1 + (a.lds_slots > 0 ? a.lds_slots : 0)) * SET) + WAVES * 32 + 16;
+  if (threadIdx.x < 100) tslot[threadIdx.x] = a.num_slots > 0 ? a.type_slot[threadIdx.x] : -1;
   __syncthreads();
   int lane = ag_lane();
   asm volatile("" : "+v"(lane));
@@ -513,7 +528,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_quad(NodeConvA
   // per-row inputs of the wave's NEXT tile: length and the two scales of row `col`, the tile's type slot (-1: radius rows),
   // whether the row is live, the sources of the lane's four rows 4 q .. 4 q + 3
   float pf_d = 0.f, pf_s1 = 0.f, pf_s2 = 0.f;
-  int pf_slot = -1;
+  int pf_slot = -1, pf_type = 0;
   bool pf_dead = false;
   int pf_src[4] = {0, 0, 0, 0};
   auto ldf = [](const float* base, uint32_t byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); };
@@ -525,9 +540,8 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_quad(NodeConvA
     const u32x4 s4 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.lt_src) + r16);
 #pragma unroll
     for (int r = 0; r < 4; ++r) pf_src[r] = (int)s4[r];
-    const int sl = ldi(a.type_slot, (uint32_t)ldi(a.lt_type, e4) * 4u);
-    pf_slot = sl < 0 ? -2 : sl;
-    pf_dead = sl < 0;
+    pf_type = ldi(a.lt_type, e4);          // (the same for the 16 rows of a tile; its set: resolve_slot, once it has landed)
+    pf_slot = -3;
     pf_d = ldf(a.lt_len, e4);
     pf_s1 = ldf(a.l_scale1, e4);
     pf_s2 = ldf(a.l_scale2, e4);
@@ -624,6 +638,12 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_quad(NodeConvA
     }
   };
   auto next_features = [&]() {
+    {   // a local tile's coefficient set (-2: its type has none -- the tile runs with scale 0)
+      const bool loc = pf_slot == -3;
+      const int sl = tslot[loc ? ((uint32_t)pf_type < 100u ? pf_type : 0) : 0];
+      pf_dead = loc ? sl < 0 : pf_dead;
+      pf_slot = loc ? (sl < 0 ? -2 : sl) : pf_slot;
+    }
     const float s1 = pf_dead ? 0.0f : pf_s1, s2 = pf_dead ? 0.0f : pf_s2;
     if constexpr (MIXED && AG_QUAD_FEATURES2) {
       ag_poly_features2_mixed<MODE>(pf_d, a.two_over_rc, q, ph1[0], s1, ph2[0], s2);
@@ -634,6 +654,9 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_quad(NodeConvA
   };
   float acc[AG_CONV_NCH];
 
+#ifdef AG_QUAD_STAMPS
+  if (threadIdx.x == 0 && gridDim.x <= 256) ag_quad_stamp[2 * blockIdx.x] = wall_clock64();
+#endif
   int p = p_begin + wave;
   if (p >= p_end) return;                       // (no barrier below)
   AG_RQ_DECL(c_);
@@ -743,6 +766,9 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_quad(NodeConvA
     c_nL = x_nL, c_lt0 = x_lt0, c_nR = x_nR;
     cslot ^= 1;
   }
+#ifdef AG_QUAD_STAMPS      // (the workgroup's LAST wave to pass here leaves the latest clock)
+  if (lane == 0 && gridDim.x <= 256) atomicMax(&ag_quad_stamp[2 * blockIdx.x + 1], (unsigned long long)wall_clock64());
+#endif
 #undef AG_RQ_DECL
 #undef AG_RQ_LOAD
 }
@@ -823,7 +849,7 @@ extern "C" int agdiff_cfconv_node(const agdiff_params_t* p, const agdiff_topo_t*
   a.qshift = topo->group_targets == 4 ? 0 : topo->group_targets == 2 ? 1 : 2;
   a.two_over_rc = 2.0f / p->cutoff;
   a.unscale = p->conv[k].filt_poly_unscale;
-  const size_t smem = (size_t)(1 + a.lds_slots) * set_bytes + 2048 + 64;  // (+ k_cfconv_quad's per-wave quad words and its quad counter)
+  const size_t smem = (size_t)(1 + a.lds_slots) * set_bytes + 2048 + 64 + 448;  // (+ k_cfconv_quad's per-wave quad words, quad counter, type table)
   // shape: four waves per SIMD pay from two quads per wave of a full grid on (below, 12-wave workgroups spread the quads wider)
   const int64_t four_min = p->tune_cfconv_four_min_quads ? p->tune_cfconv_four_min_quads : 8192;
   const bool four = p->poly_kt == 1 && four_min >= 0 && a.num_quads >= four_min;
