@@ -218,12 +218,13 @@ class BatchTopology:
         nt_quad = qneed.sum(axis=1)
         lt_ptr = np.concatenate([[0], np.cumsum(nt_quad)])
         T = int(lt_ptr[-1])
-        # agdiff_topo_t.quad_wg_ptr: the quads cut into 256 contiguous ranges of like TILE counts (local tiles + the radius tiles a
+        # agdiff_topo_t.quad_wg_ptr: the quads cut into 256 contiguous ranges of like TILE cost (local tiles + the radius tiles a
         # quad has while its molecule lies inside the cutoff) for k_cfconv_quad's 256 persistent workgroups: with equal QUAD counts
         # the busiest workgroup of a default-job batch walked 4..12 % more tiles than the average one
         if GT == 4 and Q >= 256:
             rq = np.where(qt >= 0, rad_est[np.maximum(qt, 0)], 0).max(axis=1)
-            cost = np.cumsum(nt_quad + (rq + 3) // 4)
+            # (a local tile takes about 1.2 x the time of a radius tile: tools/quad_stamps.py)
+            cost = np.cumsum(6 * nt_quad + 5 * ((rq + 3) // 4))
             cuts = np.searchsorted(cost, cost[-1] * np.arange(1, 256) / 256.0, side="left") + 1
             wg_ptr = np.concatenate([[0], np.minimum(cuts, Q), [Q]])
             wg_ptr = np.maximum.accumulate(wg_ptr)
