@@ -655,3 +655,24 @@ def test_workgroup_ranges_of_like_tile_counts():
     assert by_tiles.max() <= by_quads.max()
     small = topology.BatchTopology(b["atom_type"][:60], np.zeros((2, 0), np.int64), np.zeros(0, np.int64), np.zeros(60, np.int64), 1, device="cpu")
     assert small.quad_wg_ptr is None
+
+
+def test_topology_struct_points_at_its_own_tensors():
+    """Every pointer field of agdiff_topo_t holds the address of the BatchTopology tensor of the same name (BatchTopology.to
+    moves the tensors and re-points the struct: a field it forgot would keep pointing at the old device's memory)."""
+    import ctypes
+    from agdiff_amd import _lib, synth, topology
+    b = synth.make_packed_batch("drugs", 12, 40, seed=7)
+    tp = topology.BatchTopology(b["atom_type"], b["bond_index"], b["bond_type"], b["batch"], b["num_graphs"], device="cpu", group_targets=4)
+    checked = 0
+    for name, ctype in _lib.Topo._fields_:
+        if ctype is not ctypes.c_void_p:
+            continue
+        val = getattr(tp.struct, name)
+        t = getattr(tp, name, None)
+        assert t is not None or not val, name
+        if t is not None:
+            assert val == t.data_ptr(), name
+            checked += 1
+    assert checked >= 30 and tp.struct.quad_wg_ptr and tp.struct.loc_bits
+    assert tp.to("cpu") is tp                      # (same device: nothing moves)
