@@ -307,3 +307,58 @@ def test_bench_job_loop_world8_gloo():
     assert all(out[r][0] == 1 for r in range(8)), dict(out)
     assert len(set(out[r][2] for r in range(8))) == 1
     assert sum(out[r][1] for r in range(8)) == sum(2 * (2 + i) for i in range(6))
+
+
+def _run_job_shard_worker(rank, world, port, out, tmp):
+    """driver.run_job(shard=True): every rank prepares ITS graph range of the next batch in the background
+    (driver.prepare_batch(rank, world)) and hands the topology to the sampler of that range."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_driver_cpu import _FakeSampler, _mols
+    from agdiff_amd import driver
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=120))
+    try:
+        class Sampler(_FakeSampler):
+            def __init__(self):
+                super().__init__()
+                self.prepared, self.given = [], []
+
+            def prepare_topology(self, atom_type, bond_index, bond_type, batch, num_graphs, extend_order=False, device="cpu"):
+                import threading
+                tp = ("topology", int(np.asarray(atom_type).shape[0]), int(num_graphs), threading.current_thread() is threading.main_thread())
+                self.prepared.append(tp)
+                return tp
+
+            def begin_sampling(self, at, pos_init, bi, bt, batch, G, extend_order, topology=None, **kw):
+                self.given.append((topology, int(at.shape[0]), int(G)))
+                return super().begin_sampling(at, pos_init, bi, bt, batch, G, extend_order, **kw)
+
+        mols = _mols(5)
+        for i, m in enumerate(mols):
+            m["index"] = i
+        confs = driver.num_confs("2")
+        biggest = max(len(m["atom_type"]) * confs(m["num_refs"]) for m in mols)
+        model = Sampler()
+        res = driver.run_job(model, mols, os.path.join(tmp, "out"), confs, biggest, dict(n_steps=2), "cpu", rank=rank, world=world,
+                             shard=True, log=lambda *_: None)
+        good = len(model.prepared) >= 2 and not any(p[3] for p in model.prepared)          # several batches, none prepared on the main thread
+        # every sampler call got the topology prepared for exactly its range (atoms and graphs agree)
+        good = good and len(model.given) == len(model.prepared)
+        for (tp, n, g) in model.given:
+            good = good and tp is not None and tp[1] == n and tp[2] == g
+        if rank == 0:
+            good = good and all(("pos_gen_%d" % m["index"]) in res for m in mols)
+        else:
+            good = good and res is None
+        out[rank] = int(good)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_run_job_sharded_prepares_each_ranks_range_in_the_background_world2_gloo(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_run_job_shard_worker, args=(2, port, out, str(tmp_path)), nprocs=2, join=True)
+    assert out[0] == 1 and out[1] == 1
