@@ -126,7 +126,7 @@ def sample_batch_sharded(model, packed, device, sampler_kwargs, save_traj=False,
     Returns (pos [N,3] cpu, traj or None, ok [num molecules]) like driver.sample_batch; pos and ok are identical on all
     ranks, the trajectories [steps, N, 3] are gathered to rank 0 only (None elsewhere).  A rank that raises while the
     others sample keeps issuing its collectives, then every rank raises."""
-    from .driver import SAMPLE_STATS, _arithmetic, subset_batch
+    from .driver import SAMPLE_STATS, _arithmetic, _sort_results, subset_batch
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)
     spans = packed["spans"]
@@ -134,18 +134,21 @@ def sample_batch_sharded(model, packed, device, sampler_kwargs, save_traj=False,
     pos_out = torch.full((N, 3), float("nan"))
     traj_out = None
     ok = np.zeros(n_mol, dtype=bool)
-    todo, clip_local, wide = list(range(n_mol)), None, False
-    # collectives per attempt = steps LangevinRun will take (epsnet.py: len(step_indices) if given, else n_steps): a rank
+    # collectives per pass = steps LangevinRun will take (epsnet.py: len(step_indices) if given, else n_steps): a rank
     # without graphs must issue exactly as many gathers as the ranks that sample
     si = sampler_kwargs.get("step_indices")
     n_steps = len(si) if si is not None else int(sampler_kwargs.get("n_steps", 5000))
-    for attempt in range(max_retry):
+    # passes still to run, as in driver.sample_batch: (molecule slots, clip_local, split-bf16?, attempts counted); every rank
+    # takes the same decisions (the flags they rest on are gathered)
+    passes = [(list(range(n_mol)), None, False, 0)]
+    first = True
+    while passes:
+        todo, clip_local, wide, tries = passes.pop(0)
         sub = packed if len(todo) == n_mol else subset_batch(packed, todo)
         mine, (g0, g1), (lo, hi) = shard_of(sub, rank, world)
-        first = attempt == 0
         gather = StepAllGather(hi - lo, device, group)
         empty, zero = torch.zeros(0, 3, device=device), torch.zeros(1, dtype=torch.int32, device=device)
-        err, traj, bad_local, range_local = None, None, np.zeros(0, dtype=bool), 0
+        err, traj, bad_local, range_local = None, None, np.zeros(0, dtype=bool), []
         if mine is not None:
             try:
                 p0 = pos_init[lo:hi].to(device) if (first and pos_init is not None) else torch.randn(hi - lo, 3).to(device)
@@ -162,7 +165,7 @@ def sample_batch_sharded(model, packed, device, sampler_kwargs, save_traj=False,
                     run.advance(run.remaining())
                     _, traj = run.finish()
                 bad_local = run.nan_graphs().numpy()
-                range_local = len(getattr(run, "range_graphs", ()))
+                range_local = [g0 + int(g) for g in getattr(run, "range_graphs", ())]      # graph ids of `sub`
             except Exception as e:            # (AgdiffLimitError, out of memory, ...): the other ranks are inside the
                 err = e                       # per-step collectives -- keep this rank's count whole, fail together below
         # a rank without graphs (more ranks than graphs) or one that failed takes part in the collectives only
@@ -181,8 +184,9 @@ def sample_batch_sharded(model, packed, device, sampler_kwargs, save_traj=False,
         bad_all = [None] * world
         dist.all_gather_object(bad_all, (bad_local.tolist(), range_local), group=group)
         bad_graph = np.array([b for part, _ in bad_all for b in part], dtype=bool)
-        out_of_range = sum(r for _, r in bad_all)              # conformers that left the split-fp16 range, on any rank
-        SAMPLE_STATS["range_trips"] += out_of_range
+        out_of_range = sorted(g for _, r in bad_all for g in r)   # conformers that left the split-fp16 range, on any rank
+        SAMPLE_STATS["range_trips"] += len(out_of_range)
+        first = False
         if save_traj:                          # [steps, N_r, 3] per rank: to rank 0 only (it writes them)
             trajs = [None] * world if rank == 0 else None
             dist.gather_object(None if traj is None else torch.stack(traj).numpy(), trajs, dst=0, group=group)
@@ -190,27 +194,19 @@ def sample_batch_sharded(model, packed, device, sampler_kwargs, save_traj=False,
                 traj = torch.from_numpy(np.concatenate([x for x in trajs if x is not None], axis=1))
                 if traj_out is None:
                     traj_out = torch.full((traj.shape[0], N, 3), float("nan"))
-        failed, g_off = [], 0
-        for slot, (off_s, n, g) in zip(todo, sub["spans"]):
-            off, _, _ = spans[slot]
-            if bad_graph[g_off:g_off + g].any():
-                failed.append(slot)
-            else:
-                ok[slot] = True
-                pos_out[off:off + n * g] = pos[off_s:off_s + n * g]
-                if save_traj and rank == 0:
-                    traj_out[:, off:off + n * g] = traj[:, off_s:off_s + n * g]
-            g_off += g
-        todo = failed
-        if not todo:
-            break
-        clip_local = 20
-        if attempt + 1 < max_retry:
-            if out_of_range and not wide:                      # (the same decision on every rank: the counts were gathered)
-                wide = True
-                SAMPLE_STATS["bf16x3_retries"] += 1
+        nan_failed, range_failed = _sort_results(todo, sub["spans"], spans, bad_graph, out_of_range, wide, ok, pos_out, pos,
+                                                 traj_out if (save_traj and rank == 0) else None, traj if (save_traj and rank == 0) else None)
+        if range_failed:
+            SAMPLE_STATS["bf16x3_retries"] += 1
             if rank == 0:
-                log(("%d conformers left the split-fp16 range: retrying their molecules (%d of %d) in split-bf16 with local clipping."
-                     % (out_of_range, len(todo), len(sub["spans"]))) if (out_of_range and wide) else
-                    ("NaN in %d of %d molecules: retrying those with local clipping." % (len(todo), len(sub["spans"]))))
+                log("%d conformers left the split-fp16 range: sampling their molecules (%d of %d) again in split-bf16."
+                    % (len(out_of_range), len(range_failed), len(sub["spans"])))
+            passes.append((range_failed, clip_local, True, tries))
+        if nan_failed:
+            if tries + 1 < max_retry:
+                if rank == 0:
+                    log("NaN in %d of %d molecules: retrying those with local clipping." % (len(nan_failed), len(sub["spans"])))
+                passes.append((nan_failed, 20, wide, tries + 1))
+            else:
+                SAMPLE_STATS["dropped"] += len(nan_failed)
     return pos_out, traj_out, ok

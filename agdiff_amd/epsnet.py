@@ -18,7 +18,7 @@ from torch import nn
 
 from . import _lib
 from .packing import SPLIT_FP16_MAX_ERR, PackedParams
-from .topology import BatchTopology, Workspace
+from .topology import BatchTopology, Workspace, batch_fingerprint
 
 H_FIXED = 128
 
@@ -305,24 +305,35 @@ class DualEncoderEpsNetwork(nn.Module):
         return prec == "f16x3" or (prec == "bf16x3" and prec_l == "f16x3")
 
     def range_report(self, ws, batch=None):
-        """(name, max |x|, limit, graphs) of the first watched node tensor of workspace `ws` that has left the split-fp16 range,
-        or None.  NaNs are masked (they are the NaN flag's business, dualenc.py:539-541: a quarantined molecule must not blind
-        the watch for the others); `graphs` = the graphs (ids of `batch` [N]) that own the offending rows, or None without
-        `batch`.  One small device reduction per tensor and one host synchronisation: called where the NaN flag is polled."""
+        """(name, max |x|, limit, graphs) when a watched node tensor of workspace `ws` has left the split-fp16 range, else None:
+        `name` / `max |x|` / `limit` describe the first such tensor, `graphs` = the graphs (ids of `batch` [N]) that own an
+        offending row of ANY watched tensor (None without `batch`) -- so that one poll quarantines them all.  NaNs are masked
+        (they are the NaN flag's business, dualenc.py:539-541: a quarantined molecule must not blind the watch for the others):
+        the comparisons below are false for a NaN.  Byte-sized temporaries and one host synchronisation: called where the NaN
+        flag is polled."""
         if not self._uses_split_fp16():
             return None
         glob = (self._packed.precision if self._packed is not None else self.precision) == "f16x3"
         names = [n for n, _ in self.RANGE_LIMITS if glob or n == "hl"]
         lims = dict(self.RANGE_LIMITS)
-        mx = torch.stack([torch.nan_to_num(getattr(ws, n), nan=0.0).abs().max() for n in names]).cpu().tolist()
-        for n, v in zip(names, mx):
-            if not (v <= lims[n]):
-                graphs = None
-                if batch is not None:
-                    x = torch.nan_to_num(getattr(ws, n), nan=0.0).view(batch.shape[0], -1)
-                    graphs = torch.unique(batch[(x.abs() > lims[n]).any(dim=1)]).cpu().tolist()
-                return n, v, lims[n], graphs
-        return None
+        rows = None if batch is None else int(batch.shape[0])
+        over = []
+        for n in names:
+            x = getattr(ws, n)
+            o = (x > lims[n]) | (x < -lims[n])
+            over.append(o.view(rows, -1).any(dim=1) if rows else o.any().reshape(1))
+        hit = torch.stack([o.any() for o in over]).cpu().tolist()
+        if not any(hit):
+            return None
+        n = names[hit.index(True)]
+        v = float(torch.nan_to_num(getattr(ws, n), nan=0.0).abs().max())
+        graphs = None
+        if rows:
+            bad_rows = over[0]
+            for o in over[1:]:
+                bad_rows = bad_rows | o
+            graphs = torch.unique(batch[bad_rows]).cpu().tolist()
+        return n, v, lims[n], graphs
 
     def check_range(self, ws, batch=None):
         """Raise AgdiffRangeError (with .tensor, .value, .limit, .graphs) when range_report finds a violation."""
@@ -381,6 +392,14 @@ class DualEncoderEpsNetwork(nn.Module):
         if topology is not None:
             if topology.N != int(atom_type.shape[0]):
                 raise ValueError("topology was prepared for %d atoms, the batch has %d" % (topology.N, int(atom_type.shape[0])))
+            # ... and for THIS batch: same graphs, same bonds, same way of extending them, same grouping (a topology of another
+            # batch -- or of another rank's range -- with the same atom count would run with the wrong bonds and quads)
+            fp = batch_fingerprint(atom_type, bond_index, bond_type, batch, num_graphs, extend_order)
+            if fp != topology.fingerprint:
+                raise ValueError("topology was prepared for another batch (fingerprint %r, this batch %r)" % (topology.fingerprint, fp))
+            gt = getattr(self, "group_targets", None)
+            if gt is not None and int(gt) != topology.group_targets:
+                raise ValueError("topology was grouped for %d targets per wave, the model asks for %d" % (topology.group_targets, int(gt)))
             topo = topology.to(self._device())
         else:
             topo = self.prepare_topology(atom_type, bond_index, bond_type, batch, num_graphs, extend_order, device=self._device())

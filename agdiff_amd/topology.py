@@ -18,6 +18,38 @@ def _to_np(x):
     return np.asarray(x)
 
 
+def batch_fingerprint(atom_type, bond_index, bond_type, batch, num_graphs, extend_order):
+    """What a prepared BatchTopology is checked against when a sampler is handed one (epsnet._batch): atom count, graph count,
+    extend_order and two order-sensitive 64-bit sums over (atom_type, batch) and the bond list AS PASSED (wrapping int64
+    arithmetic: the same number from numpy arrays and from torch tensors on any device -- one small reduction, no copy of
+    the lists)."""
+    def wsum(cols, mults):
+        if hasattr(cols[0], "detach"):                       # torch (possibly on the GPU)
+            import torch
+            n = int(cols[0].reshape(-1).shape[0])
+            if n == 0:
+                return 0
+            acc = torch.zeros(n, dtype=torch.int64, device=cols[0].device)
+            for c, m in zip(cols, mults):
+                acc += c.reshape(-1).to(torch.int64) * m
+            acc = (acc + 12345) * torch.arange(1, n + 1, dtype=torch.int64, device=acc.device)
+            return int(acc.sum().item())
+        cols = [np.asarray(c).reshape(-1).astype(np.int64) for c in cols]
+        n = cols[0].shape[0]
+        if n == 0:
+            return 0
+        acc = np.zeros(n, dtype=np.int64)
+        with np.errstate(over="ignore"):
+            for c, m in zip(cols, mults):
+                acc += c * np.int64(m)
+            acc = (acc + np.int64(12345)) * np.arange(1, n + 1, dtype=np.int64)
+            return int(acc.sum(dtype=np.int64))
+    bi = bond_index.reshape(2, -1)
+    G = None if num_graphs is None else int(num_graphs)
+    return (int(atom_type.shape[0]), G, bool(extend_order), wsum([atom_type, batch], [1000003, 998244353]),
+            wsum([bi[0], bi[1], bond_type], [1000003, 998244353, 7919]))
+
+
 _GROUP_ORDER_CACHE = {}
 
 
@@ -54,6 +86,7 @@ class BatchTopology:
         bi = _to_np(bond_index).astype(np.int64).reshape(2, -1)
         bt = _to_np(bond_type).astype(np.int64).reshape(-1)
         ba = _to_np(batch).astype(np.int64)
+        self.fingerprint = batch_fingerprint(at, bi, bt, ba, num_graphs, extend_order)
         N = at.shape[0]
         if ba.shape[0] != N:
             raise ValueError("batch and atom_type disagree on the number of nodes")
@@ -383,7 +416,11 @@ class Workspace:
         ptiles = (Lp + TW - 1) // TW
         lchunk = _lib.load().agdiff_conv_chunk_tiles(Lp)
         self.rad_cnt = i32(N)
-        self.rad_src, self.rad_len = i32(N * RS), f32(N * RS)
+        # every row of target i starts out naming i itself as its source: k_cfconv_quad runs the rows between a target's count and
+        # its quad's tile end with scale 0 but still gathers x[src], and agdiff_sampler_front does not write them -- a row that was
+        # never written must not point at an atom of ANOTHER molecule (0 x a non-finite x of a diverging molecule is NaN)
+        self.rad_src = torch.arange(N, dtype=torch.int32, device=dev).repeat_interleave(RS)
+        self.rad_len = f32(N * RS)
         self.r_scale = f32(2 * _lib.DEFINES["AGDIFF_MAX_CONVS"] * N * RS)
         self.lt_len = f32(TW * topo.T)
         self.lt_scale = f32(2 * _lib.DEFINES["AGDIFF_MAX_CONVS"] * TW * topo.T)

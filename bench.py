@@ -113,6 +113,25 @@ def launcher_selftest(world, rank):
                           "local_rank_env": os.environ.get("LOCAL_RANK")}), flush=True)
 
 
+def collective_selfcheck(dist, torch, dev, rank, world, gloo=False):
+    """What the process group itself reports, from real collectives (`rccl_ranks` used to be the WORLD_SIZE
+    environment value): an all-reduce of ones (= ranks that took part), an all-gather of every rank's device index, the
+    backend's name.  Ranks of an RCCL group must sit on distinct devices (RCCL refuses two ranks on one GPU); the one-GPU
+    rehearsal over gloo is exempt."""
+    where = torch.device("cpu") if gloo else dev
+    ones = torch.ones(1, dtype=torch.int64, device=where)
+    dist.all_reduce(ones)
+    mine = torch.tensor([torch.cuda.current_device()], dtype=torch.int64, device=where)
+    devs = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(devs, mine)
+    devices = [int(d.item()) for d in devs]
+    rep = {"ranks": int(ones.item()), "world_size": dist.get_world_size(), "backend": dist.get_backend(),
+           "devices": devices, "distinct_devices": len(set(devices))}
+    if not gloo and rep["distinct_devices"] != world:
+        raise RuntimeError("the %d ranks sit on %d distinct devices %s" % (world, rep["distinct_devices"], devices))
+    return rep
+
+
 # ------------------------------------------------------------------------------------------ CPU baseline (oracle)
 def cpu_worker(kind, schedule, seed, mols, copies, threads, budget_s):
     """One CPU process of the baseline: the oracle (CPU port of the reference path) on `mols` x `copies`
@@ -454,10 +473,25 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if args.rehearse_on_one_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        try:
+            if args.rehearse_on_one_gpu:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            group_report = collective_selfcheck(dist, torch, dev, rank, world, gloo=args.rehearse_on_one_gpu)
+        except Exception as e:                      # RCCL could not form the group / a collective failed: say so, measure nothing
+            print("bench.py rank %d: the %d-rank %s group did not come up (%s: %s) -- MASTER_ADDR=%s MASTER_PORT=%s LOCAL_RANK=%d "
+                  "HSA_ENABLE_IPC_MODE_LEGACY=%s, %d GPU(s) visible; nothing was measured"
+                  % (rank, world, "gloo" if args.rehearse_on_one_gpu else "RCCL", type(e).__name__, e, os.environ.get("MASTER_ADDR"),
+                     os.environ.get("MASTER_PORT"), local_rank, os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), torch.cuda.device_count()),
+                  file=sys.stderr, flush=True)
+            sys.exit(3)
+        if group_report["ranks"] != args.gpus:
+            print("bench.py rank %d: --gpus %d but the group's all-reduce of ones gave %d" % (rank, args.gpus, group_report["ranks"]),
+                  file=sys.stderr, flush=True)
+            sys.exit(3)
+    else:
+        group_report = {"ranks": 1, "backend": None, "devices": [local_rank], "distinct_devices": 1}
 
     from agdiff_amd import _lib, driver, get_model, synth
     from agdiff_amd.dist import shard_of
@@ -932,7 +966,7 @@ def main():
             "value": value, "value_full_job": value_full_job, "unit": "conformers/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None,      # the reference publishes no number for this metric
-            "dtype": args.precision, "data": "synthetic", "rccl_ranks": world,
+            "dtype": args.precision, "data": "synthetic", "rccl_ranks": group_report["ranks"], "process_group": group_report,
             "config": {"workload": wl, "conformers_total": G_total, "parallelism": "dp%d" % world,
                        "all_gather_per_step": bool(use_dist), "all_gather_calls_rank0": int(gcalls[0]) if d200 else (gather.calls if use_dist else 0),
                        "trajectory_saved": save_traj, "nan_check_every": 64,

@@ -176,11 +176,41 @@ def test_molecules_that_leave_the_split_fp16_range_are_resampled_in_split_bf16()
     logs = []
     pos, _, ok = driver.sample_batch(m, packed, "cpu", dict(n_steps=2), log=logs.append)
     assert ok.all() and torch.isfinite(pos).all()
-    assert m.calls == [(8, None), (2, 20)] and m.modes == [("f16x3", None), ("bf16x3", "bf16x3")]
+    # (a molecule whose only fault was the range keeps the sampler settings -- no local clipping -- and its extra pass
+    # is not one of the max_retry attempts: test.py:143-181 clips only after a FloatingPointError)
+    assert m.calls == [(8, None), (2, None)] and m.modes == [("f16x3", None), ("bf16x3", "bf16x3")]
     assert (m.precision, m.precision_local) == ("f16x3", None)
     assert driver.SAMPLE_STATS["range_trips"] - before["range_trips"] == 2
     assert driver.SAMPLE_STATS["bf16x3_retries"] - before["bf16x3_retries"] == 1
     assert any("split-bf16" in l for l in logs)
+
+
+def test_a_range_trip_does_not_use_up_a_nan_attempt():
+    """molecule 1 leaves the split-fp16 range in the first pass, and in its split-bf16 pass a NaN appears: it still
+    gets its clipped retry (max_retry = 2 counts NaN attempts only), and a molecule that fails every attempt is counted as dropped."""
+    mols = _mols(3)
+    mols[1]["atom_type"] = mols[1]["atom_type"].copy()
+    mols[1]["atom_type"][:] = 9
+    packed = driver.pack_batch(mols, driver.num_confs("2"))
+
+    class _RangeThenNan(_RangeSampler):
+        def begin_sampling(self, *a, **kw):
+            run = _FakeSampler.begin_sampling(self, *a, **kw)
+            self.modes.append((self.precision, kw.get("clip_local")))
+            bad = run.nan_graphs()                                   # (the fake run: NaN while clip_local is None)
+            run.range_graphs = set(torch.nonzero(bad).view(-1).tolist()) if self.precision != "bf16x3" else set()
+            run.nan_graphs = lambda: bad
+            return run
+    m = _RangeThenNan(nan_type=9)
+    before = dict(driver.SAMPLE_STATS)
+    pos, _, ok = driver.sample_batch(m, packed, "cpu", dict(n_steps=2), log=lambda s: None)
+    assert m.modes == [("f16x3", None), ("bf16x3", None), ("bf16x3", 20)] and ok.all() and torch.isfinite(pos).all()
+    assert driver.SAMPLE_STATS["dropped"] == before["dropped"]
+    m2 = _RangeThenNan(nan_type=9)
+    run2 = m2.begin_sampling
+    m2.begin_sampling = lambda *a, **k: run2(*a, **dict(k, clip_local=None))        # clipping does not help either
+    pos, _, ok = driver.sample_batch(m2, packed, "cpu", dict(n_steps=2), log=lambda s: None)
+    assert ok.tolist() == [True, False, True] and driver.SAMPLE_STATS["dropped"] - before["dropped"] == 1
 
 
 def test_subset_batch_rebases():

@@ -676,3 +676,34 @@ def test_topology_struct_points_at_its_own_tensors():
             checked += 1
     assert checked >= 30 and tp.struct.quad_wg_ptr and tp.struct.loc_bits
     assert tp.to("cpu") is tp                      # (same device: nothing moves)
+
+
+def test_prepared_topology_is_tied_to_its_batch():
+    """a BatchTopology prepared ahead is only accepted for the batch it was built from -- same atoms, graphs, bonds
+    (as passed), extend_order -- not for any batch with the same atom count.  The fingerprint is the same number from numpy
+    arrays and from torch tensors."""
+    import torch
+    from agdiff_amd import synth, topology
+    b = synth.make_packed_batch("drugs", 3, 4, seed=1)
+    tp = topology.BatchTopology(b["atom_type"], b["bond_index"], b["bond_type"], b["batch"], b["num_graphs"], device="cpu")
+    tt = lambda x: torch.from_numpy(x)
+    fp = topology.batch_fingerprint(tt(b["atom_type"]), tt(b["bond_index"]), tt(b["bond_type"]), tt(b["batch"]), b["num_graphs"], False)
+    assert fp == tp.fingerprint
+    other = b["bond_type"].copy()
+    other[5] = 2 if other[5] != 2 else 1
+    swapped = b["bond_index"][:, ::-1].copy()                   # the same set of bonds in another order: another input
+    moved = b["batch"].copy()
+    edge = int(np.flatnonzero(np.diff(moved))[0]) + 1           # first atom of graph 1 ...
+    moved[edge] = moved[edge - 1]                               # ... now belongs to graph 0
+    for args in ((b["atom_type"], b["bond_index"], other, b["batch"], b["num_graphs"], False),
+                 (b["atom_type"], swapped, b["bond_type"], b["batch"], b["num_graphs"], False),
+                 (b["atom_type"], b["bond_index"], b["bond_type"], b["batch"], b["num_graphs"], True),
+                 (b["atom_type"], b["bond_index"], b["bond_type"], moved, b["num_graphs"], False)):
+        assert topology.batch_fingerprint(*args) != tp.fingerprint
+    from agdiff_amd import get_model, qm9_model_config
+    m = get_model(qm9_model_config())
+    with pytest.raises(ValueError, match="another batch"):
+        m._batch(tt(b["atom_type"]), tt(b["bond_index"]), tt(other), tt(b["batch"]), b["num_graphs"], False, topology=tp)
+    m.group_targets = 4 if tp.group_targets != 4 else 2
+    with pytest.raises(ValueError, match="targets per wave"):
+        m._batch(tt(b["atom_type"]), tt(b["bond_index"]), tt(b["bond_type"]), tt(b["batch"]), b["num_graphs"], False, topology=tp)
