@@ -234,43 +234,52 @@ def test_a_graph_that_goes_nan_mid_run_never_touches_its_neighbours(mode):
 def test_non_finite_node_features_of_one_molecule_never_reach_another_through_dead_quad_rows():
     """k_cfconv_quad runs the rows between a target's radius count and its quad's tile end with scale 0 but
     still gathers x[src]; rows the front kernel never wrote used to hold the workspace's zero init, i.e. NODE 0 -- an atom of
-    molecule 0.  Molecule 0 starts at finite but astronomically spread positions: its squared distances overflow, its local
-    rows' polynomial features are inf - inf, its aggregates and from block 1 on its xs are NaN during the FIRST forward, before
-    any update can quarantine it.  0 x NaN through such a dead row would poison every other molecule; now every row of a
-    target names the target itself until it is written (Workspace.rad_src).  The bystanders must end bit for bit where a run
-    with a tame molecule 0 puts them."""
-    from agdiff_amd import _lib, driver, get_model, qm9_model_config
+    molecule 0 -- and 0 x NaN through such a dead row poisons another molecule's aggregate.  Here node 0 carries an atom type
+    whose SchNet embedding row is NaN (a degenerate checkpoint): its h and xs are NaN in every forward, before and after the
+    update quarantines its molecule.  Every row of a target now names the target itself until it is written
+    (Workspace.rad_src): the bystanders end bit for bit where a batch with a tame molecule 0 puts them.  The same run with the
+    old zero init restored shows the hazard (so that this test cannot pass vacuously on a batch without dead rows)."""
+    from agdiff_amd import _lib, driver, get_model, qm9_model_config, synth
     from oracle import agdiff_oracle as O
     cfg = qm9_model_config(num_diffusion_timesteps=20, beta_end=2e-5)
     sd = O.synth_state_dict_for(cfg)
+    for k in list(sd):
+        if synth.canonical_key(k) == "encoder_global.embedding.weight":
+            sd[k] = sd[k].clone()
+            sd[k][17] = float("nan")
     m = get_model(cfg)
     m.group_targets = 4                                     # quads (and with them k_cfconv_quad) on a small batch
     m.load_state_dict({k: v.clone() for k, v in sd.items()})
     m = m.to("cuda:0").eval()
-    packed = driver.pack_batch(_three_molecules(seed=9), driver.num_confs("3"))
+    mols = _three_molecules(seed=9)
+    assert not any((mol["atom_type"] == 17).any() for mol in mols)
+    packed = driver.pack_batch(mols, driver.num_confs("3"))
     N, G, n_steps = packed["atom_type"].shape[0], packed["num_graphs"], 20
     gen = torch.Generator().manual_seed(5)
     pos_init, noise = torch.randn(N, 3, generator=gen), torch.randn(n_steps, N, 3, generator=gen)
     a = [t(packed[k]).cuda() for k in ("atom_type", "bond_index", "bond_type", "batch")]
     kw = dict(extend_order=False, n_steps=n_steps, w_global=1.0, global_start_sigma=0.5, clip=1000.0, raise_on_nan=False)
 
-    def run(p0):
-        r = m.begin_sampling(a[0], p0.cuda(), a[1], a[2], a[3], G, noise=noise.cuda(), **kw)
+    def run(at, old_init=False):
+        r = m.begin_sampling(at, pos_init.cuda(), a[1], a[2], a[3], G, noise=noise.cuda(), **kw)
+        if old_init:
+            r.ws.rad_src.zero_()
         r.advance(r.remaining())
         torch.cuda.synchronize()
         assert int(r.ws.variant_log.item()) & _lib.DEFINES["AGDIFF_VAR_CFCONV_NODE_QUAD"]
         return r.pos.cpu(), r.nan_graphs()
-    clean, cbad = run(pos_init)
+    clean, cbad = run(a[0])
     assert not cbad.any() and torch.isfinite(clean).all()
     ba = t(packed["batch"])
     off, n, g = packed["spans"][0]                          # molecule 0 = graphs 0 .. g - 1, node 0 included
-    wild = pos_init.clone()
-    wild[off:off + n * g] *= 1e22                           # finite; every squared distance inside the molecule is inf
-    assert torch.isfinite(wild * float(m.alphas.new_tensor(1.0))).all()
-    pos, bad = run(wild)
+    at_bad = a[0].clone()
+    at_bad[off:off + n * g:n] = 17                          # the first atom of each of its conformers
+    pos, bad = run(at_bad)
     assert bad[:g].all() and not bad[g:].any()
     keep = ba >= g
     assert torch.equal(pos[keep], clean[keep]) and torch.isfinite(pos).all()
+    _, bad_old = run(at_bad, old_init=True)
+    assert bad_old[g:].any(), "the fixture has no dead quad row that pointed at node 0: the check above proves nothing"
 
 
 def test_all_gather_path_on_one_gpu_nccl_world1():

@@ -181,7 +181,13 @@ def test_forward_other_mlp_act_matches_reference_golden(act, precision):
     at, bi, bt, ba = [t(g[k]) for k in ("atom_type", "bond_index", "bond_type", "batch")]
     out = m(at.cuda(), t(g["pos"]).cuda(), bi.cuda(), bt.cuda(), ba.cuda(), None, return_edges=True, extend_order=False)
     assert np.array_equal(out[2].cpu().numpy(), g["edge_index"]) and np.array_equal(out[3].cpu().numpy(), g["edge_type"])
-    check_close("mlp_act %s inv_g" % act, out[0].cpu().numpy(), g["edge_inv_global"], precision)
+    # sigmoid / softplus outputs do not centre at 0 (y ~ 0.5 resp. ~ 0.7): the last layer's dot product cancels (|sum w y| well
+    # below sum |w y|), so the split-bf16 rounding of y (2^-16 of y, not of the result) shows amplified in the normwise figure:
+    # 2.95e-5 / 2.26e-5 measured (profiles/r05_parity_errors.json) against 0.5..1.9e-5 for the centred activations.  The kernels
+    # are bitwise reproducible, so this is a property of the fixture, not noise; the gate for these two in split-bf16 is 6e-5
+    # (north_star: 1e-4), everything else keeps 3e-5.
+    wide = 2.0 if (precision == "bf16x3" and act in ("sigmoid", "softplus")) else 1.0
+    check_close("mlp_act %s inv_g" % act, out[0].cpu().numpy(), g["edge_inv_global"], precision, scale=wide)
     check_close("mlp_act %s inv_l" % act, out[1].cpu().numpy(), g["edge_inv_local"], precision)
     cfg2 = qm9_model_config(mlp_act=act, num_diffusion_timesteps=6, beta_end=2e-3)
     m2, sd2 = _gpu_model(cfg2, head_scale=1e-2, precision=precision)
@@ -473,6 +479,97 @@ def test_oracle_parity_at_natural_thresholds(precision, mode):
     assert bool(var & V["AGDIFF_VAR_HEAD_POLY"]) == (mode == "auto") and var & V["AGDIFF_VAR_NODE_LDSW"]
     check_close(tag + " traj", torch.stack(traj), o["ref_traj"], precision)
     check_close(tag + " pos", pos, o["ref_pos"], precision)
+
+
+def _with_triple_bonds(rng, n):
+    """synth.random_molecule with one SINGLE bond turned into a TRIPLE one (both directions) when it has a single bond between
+    two atoms that sit on no other multiple bond: a sixth local edge type (1, 2, 3, 12 + the 2- / 3-hop types 23, 24)."""
+    from agdiff_amd import synth
+    at, r, c, ty = synth.random_molecule(rng, n)
+    one = np.flatnonzero((ty == 1) & (r < c))
+    if one.size:
+        k = int(one[rng.integers(0, one.size)])
+        ty = ty.copy()
+        ty[(r == r[k]) & (c == c[k])] = 3
+        ty[(r == c[k]) & (c == r[k])] = 3
+    return at, r, c, ty
+
+
+def test_oracle_parity_of_molecules_sliced_out_of_a_product_shape_batch():
+    """ONE 196,608-atom-class Drugs-shaped batch at the library's own thresholds -- the 16-wave
+    k_cfconv_quad with host-cut workgroup ranges (quad_wg_ptr), six local edge types so that one coefficient set is read from
+    L2, LDS-shared node stage / GIN layer, side stream, fused front, polynomial head -- for forward(return_edges=True) and two
+    denoising steps with injected noise; graphs are independent (dualenc.py:142-251 touches no other graph's rows), so the
+    oracle is run on the conformers of five molecules SLICED OUT of the batch (first, middle, last, largest, smallest; first
+    and last conformer of each) and gated with check_close like every fixture.  Matches dualenc.py:142-251, 478-545."""
+    import os
+    from agdiff_amd import _lib, drugs_model_config, get_model, synth
+    from oracle import agdiff_oracle as O
+    assert not [k for k in os.environ if k.startswith("AGDIFF_")], "no AGDIFF_* overrides here"
+    cfg = drugs_model_config(num_diffusion_timesteps=40, beta_end=2e-5)
+    sd = O.synth_state_dict_for(cfg)
+    rng = np.random.default_rng(606)
+    copies, parts, node_off, g_off, spans = 128, [], 0, 0, []
+    while node_off < 196608:
+        n = synth.sample_n_atoms(rng, "drugs")
+        at1, r, c, ty = _with_triple_bonds(rng, n)
+        parts.append(synth.repeat_molecule(at1, r, c, ty, copies, node_off, g_off))
+        spans.append((node_off, n, g_off))
+        node_off += n * copies
+        g_off += copies
+    at = np.concatenate([p[0] for p in parts]); bi = np.stack([np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts])])
+    bt = np.concatenate([p[3] for p in parts]); ba = np.concatenate([p[4] for p in parts])
+    N, G = at.shape[0], g_off
+    assert N >= 196608 and set(np.unique(bt)) >= {1, 2, 3, 12, 23, 24}
+    gen = torch.Generator().manual_seed(17)
+    pos_init = torch.randn(N, 3, generator=gen)
+    noise = torch.randn(2, N, 3, generator=gen)
+    pos0 = pos_init * O.schedule_tensors(cfg)[2][-1]
+
+    m = get_model(cfg)
+    m.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+    m = m.to("cuda:0").eval()
+    assert m.tuning == {} and m.precision == "f16x3" and m.group_targets is None
+    dv = [t(x).cuda() for x in (at, bi, bt, ba)]
+    out = m(dv[0], pos0.cuda(), dv[1], dv[2], dv[3], None, return_edges=True, extend_order=False)
+    topo, ws = m._batch_cache[1], m._batch_cache[2]
+    V = _lib.DEFINES
+    var = int(ws.variant_log.item())
+    assert topo.Q >= 8192 and topo.quad_wg_ptr is not None and topo.group_targets == 4
+    for name in ("CFCONV_NODE", "CFCONV_NODE_LOCAL", "CFCONV_NODE_QUAD", "CFCONV_NODE_FOUR", "POLY_L2_SETS", "NODE_LDSW", "GIN_LDSW",
+                 "SIDE_STREAM", "ATTR_POLY"):
+        assert var & V["AGDIFF_VAR_" + name], (name, hex(var))
+    assert not var & (V["AGDIFF_VAR_CFCONV_FUSED"] | V["AGDIFF_VAR_CFCONV_LOCAL_MLP"])
+    inv_g, inv_l, ei, et, el, lm = [x.cpu() for x in out]
+    kw = dict(extend_order=False, n_steps=2, w_global=1.0, global_start_sigma=0.5, clip=1000.0)
+    pos, traj = m.langevin_dynamics_sample_diffusion(dv[0], pos_init.cuda(), dv[1], dv[2], dv[3], G, noise=noise.cuda(), **kw)
+    var = int(m._batch_cache[2].variant_log.item())
+    for name in ("CFCONV_NODE_QUAD", "CFCONV_NODE_FOUR", "POLY_L2_SETS", "HEAD_POLY", "FUSED_FRONT", "NODE_LDSW", "GIN_LDSW", "SIDE_STREAM"):
+        assert var & V["AGDIFF_VAR_" + name], (name, hex(var))
+    pos, traj = pos.cpu(), torch.stack(traj)
+
+    sizes = np.array([n for _, n, _ in spans])
+    picks = sorted({0, len(spans) // 2, len(spans) - 1, int(sizes.argmax()), int(sizes.argmin())})
+    gsel = np.array(sorted(g0 + k for _, _, g0 in (spans[i] for i in picks) for k in (0, copies - 1)))
+    node_sel = np.isin(ba, gsel)
+    new_id = np.cumsum(node_sel) - 1
+    esel = node_sel[bi[0]]
+    s_at, s_ba = t(at[node_sel]), t(np.searchsorted(gsel, ba[node_sel]))
+    s_bi, s_bt = t(new_id[bi[:, esel]]), t(bt[esel])
+    with torch.no_grad():
+        ref = O.forward(sd, cfg, s_at, pos0[node_sel], s_bi, s_bt, s_ba, extend_order=False)
+        rpos, rtraj = O.langevin_dynamics_sample_diffusion(sd, cfg, s_at, pos_init[node_sel], s_bi, s_bt, s_ba, len(gsel),
+                                                           noise=noise[:, node_sel], **kw)
+    keep = torch.from_numpy(node_sel)[ei[0]]                       # the batch's edges that belong to the sliced graphs, in order
+    got_ei = torch.from_numpy(new_id)[ei[:, keep]]
+    assert torch.equal(got_ei, ref[2]) and torch.equal(et[keep], ref[3]) and torch.equal(lm[keep], ref[5])     # bit-exact graph
+    assert float(np.bincount(ref[2][1].numpy()).mean()) > 30                                                  # at the 32-cap
+    tag = "product_shape"
+    check_close(tag + " edge_length", el[keep], ref[4], "f16x3")
+    check_close(tag + " inv_g", inv_g[keep], ref[0], "f16x3")
+    check_close(tag + " inv_l", inv_l[keep[lm]], ref[1], "f16x3")
+    check_close(tag + " traj", traj[:, node_sel], torch.stack(rtraj), "f16x3")
+    check_close(tag + " pos", pos[node_sel], rpos, "f16x3")
 
 
 def test_full_size_properties():
