@@ -2,9 +2,9 @@
 # Per-kernel average durations (rocprofv3 --kernel-trace --stats) of a short bench run in tree $1 (default .).
 # Usage: bash tools/kstats.sh <tree> <tag> [bench args]
 tree=$(cd "${1:-.}" && pwd); tag=$2; shift 2
-out=/tmp/kstats_$tag
+out=/tmp/kstats_$tag; rm -rf $out
 cd /tmp && export TMPDIR=/tmp
-(cd $tree && rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-traj --no-extra "$@" > /dev/null 2>&1)
+(cd $tree && timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-traj --no-extra "$@" > /dev/null 2>&1)
 python3 - <<PY
 import csv, glob
 for f in glob.glob("$out/*/*kernel_stats.csv"):
