@@ -127,6 +127,33 @@ def prepare_batch(model, bmols, confs_of, rank=0, world=1):
         return packed, None
 
 
+def _topology_options(model):
+    """What model.prepare_topology needs of the model (plain values: they travel to the worker process)."""
+    return dict(order=int(model.config.edge_order), group_targets=getattr(model, "group_targets", None),
+                radius_column=bool(getattr(model, "tuning", {}).get("group_radius_column", 1)))
+
+
+def _prepare_in_worker(bmols, confs, rank, world, topo_opts):
+    """prepare_batch in a worker PROCESS (run_job): the same packed batch and BatchTopology, built without the sampling
+    process's interpreter lock -- a background THREAD hid 0.3 s of a batch's 1-4 s of numpy, because every Python-level step of
+    the build waits for the launch loop's lock and vice versa.  Host work only: nothing here touches a GPU.  `confs`: conformers
+    per molecule of the batch (the callable of scripts/test.py:15-24 does not pickle)."""
+    from .topology import BatchTopology
+    it = iter(confs)
+    packed = pack_batch(bmols, lambda _num_refs: next(it))
+    part = packed
+    if world > 1:
+        from .dist import shard_of
+        part = shard_of(packed, rank, world)[0]
+        if part is None:
+            return packed, None
+    try:
+        return packed, BatchTopology(part["atom_type"], part["bond_index"], part["bond_type"], part["batch"], num_graphs=part["num_graphs"],
+                                     extend_order=False, device="cpu", **topo_opts)
+    except Exception:
+        return packed, None               # (the sampler builds it again and raises there: prepare_batch)
+
+
 def sample_batch(model, packed, device, sampler_kwargs, save_traj=False, max_retry=2, log=print, pos_init=None,
                  noise=None, topology=None):
     """test.py:143-181 for every molecule of a packed batch: a molecule in which a NaN appeared is sampled again
@@ -315,34 +342,77 @@ def run_job(model, mols, out_dir, confs_of, max_atoms, sampler_kwargs, device, s
     mols = [m for m in mols if m["index"] not in done]
     batches = plan_batches(mols, confs_of, sharded_capacity(max_atoms, world) if shard else max_atoms)
     mine = [bidx for bidx in range(len(batches)) if shard or bidx % world == rank]
-    # The next batch is packed -- and its topology built (seconds of numpy per 200 k atoms) -- in a background thread while the
-    # GPU samples the current one: the sampling loop spends its time inside library calls, which release the interpreter lock.
-    # (AGDIFF_PREPARE_INLINE=1: on the main thread, when its turn comes -- measurements, debugging)
+    # The next batch is packed -- and its topology built -- while the GPU samples the current one, in a background thread (the
+    # sampling loop spends its time inside library calls, which release the interpreter lock).  Measured on the MI355X box, four
+    # 196 k-atom batches x 600 steps (tools/job_wall.py, profiles/r06_job_wall.json): sampling + saving alone 10.13 s, preparation
+    # inline 11.3 s (0.29 s per batch), thread 10.8 s, worker process 11.8 s.
+    # AGDIFF_PREPARE=process: a worker PROCESS (agdiff_amd/prep_worker.py, a fresh interpreter started as a child; host work only)
+    # -- it shares nothing with the launch loop, but its reply (~100 MB of index arrays per batch) comes back through a pipe and a
+    # pickle, which costs the main thread more than the thread's lock contention on a host with fast cores; for hosts where the
+    # numpy build takes seconds per batch.  =inline: on the main thread, when the batch's turn comes (measurements, debugging).
     from concurrent.futures import Future, ThreadPoolExecutor
-    pool = ThreadPoolExecutor(max_workers=1)
     prep = lambda bidx: prepare_batch(model, batches[bidx], confs_of, rank if shard else 0, world if shard else 1)
-    inline = os.environ.get("AGDIFF_PREPARE_INLINE", "0") not in ("", "0")
+    how = os.environ.get("AGDIFF_PREPARE", "inline" if os.environ.get("AGDIFF_PREPARE_INLINE", "0") not in ("", "0") else "thread")
+    inline = how == "inline"
+    worker, pool = None, None
+    if how == "process" and hasattr(model, "prepare_topology") and hasattr(model, "config") and len(mine) > 1:
+        try:
+            from .prep_worker import Client
+            worker = Client()                         # (a child process: boots while the first batch is prepared here)
+        except Exception as e:                        # (no worker: the thread)
+            log("run_job: no worker process for the batch preparation (%s: %s); using a thread" % (type(e).__name__, e))
+    if worker is None:
+        pool = ThreadPoolExecutor(max_workers=1)
+    opts = _topology_options(model) if worker is not None else None
 
-    def submit(bidx):
-        if not inline:
-            return pool.submit(prep, bidx)
-        f = Future()
-        f.set_result(bidx)                 # (resolved below, when the batch's turn comes)
+    class _FromWorker:
+        on_main = False
+
+        def result(self):
+            return worker.result()
+
+    def submit(bidx, first=False):
+        if inline or (first and worker is not None):
+            f = Future()
+            f.set_result(bidx)                 # (resolved on the main thread, when the batch's turn comes)
+            f.on_main = True
+            return f
+        if worker is not None:
+            worker.submit(batches[bidx], [confs_of(m["num_refs"]) for m in batches[bidx]], rank if shard else 0, world if shard else 1, opts)
+            return _FromWorker()
+        f = pool.submit(prep, bidx)
+        f.on_main = False
         return f
-    fut = submit(mine[0]) if mine else None
+    fut = submit(mine[0], first=True) if mine else None
     try:
         return _run_job_batches(model, batches, mine, fut, submit, prep, inline, shard, device, sampler_kwargs, save_traj, log, out_dir, rank,
                                 world)
     finally:
-        pool.shutdown(wait=True)
+        if worker is not None:
+            worker.close()
+        if pool is not None:
+            pool.shutdown(wait=True)
 
 
 def _run_job_batches(model, batches, mine, fut, submit, prep, inline, shard, device, sampler_kwargs, save_traj, log, out_dir, rank, world):
     import torch.distributed as dist
     for pos_in_mine, bidx in enumerate(mine):
         bmols = batches[bidx]
-        packed, topology = prep(fut.result()) if inline else fut.result()
-        fut = submit(mine[pos_in_mine + 1]) if pos_in_mine + 1 < len(mine) else None
+        # (first this batch's reply, THEN the next request: the worker writes a reply of ~100 MB into a pipe nobody reads until here,
+        # and a request larger than the pipe's buffer sent before that would wait for a reader that is itself waiting)
+        try:
+            packed, topology = prep(fut.result()) if getattr(fut, "on_main", inline) else fut.result()
+        except Exception as e:                   # (a worker that died: this batch on the main thread)
+            log("run_job: the prepared batch did not arrive (%s: %s); preparing it here" % (type(e).__name__, e))
+            packed, topology = prep(bidx)
+        try:
+            fut = submit(mine[pos_in_mine + 1]) if pos_in_mine + 1 < len(mine) else None
+        except Exception as e:                   # (the worker's pipe is gone: the next batch on the main thread, when its turn comes)
+            log("run_job: the next batch could not be handed to the worker (%s: %s)" % (type(e).__name__, e))
+            from concurrent.futures import Future
+            fut = Future()
+            fut.set_result(mine[pos_in_mine + 1])
+            fut.on_main = True
         if shard:
             from .dist import sample_batch_sharded
             pos, traj, ok = sample_batch_sharded(model, packed, device, sampler_kwargs, save_traj=save_traj, log=log,

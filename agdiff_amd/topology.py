@@ -352,6 +352,34 @@ class BatchTopology:
             setattr(self.struct, f, _lib.ptr(getattr(self, f)))
         self.struct.quad_wg_ptr = _lib.ptr(self.quad_wg_ptr) if self.quad_wg_ptr is not None else None
 
+    # A topology prepared in a worker PROCESS (agdiff_amd/driver.py) comes back pickled: the ctypes struct (raw addresses) stays
+    # behind; its scalar fields travel as a dict and the pointers are taken again from the tensors on arrival.
+    def __getstate__(self):
+        import ctypes
+        st = dict(self.__dict__)
+        t = st.pop("struct")
+        scalars = {}
+        for name, ctype in _lib.Topo._fields_:
+            if ctype is ctypes.c_void_p:
+                continue
+            v = getattr(t, name)
+            scalars[name] = list(v) if hasattr(v, "__len__") else v
+        st["_struct_scalars"] = scalars
+        return st
+
+    def __setstate__(self, st):
+        scalars = st.pop("_struct_scalars")
+        self.__dict__.update(st)
+        t = _lib.Topo()
+        for name, v in scalars.items():
+            if isinstance(v, list):
+                for k, x in enumerate(v):
+                    getattr(t, name)[k] = x
+            else:
+                setattr(t, name, v)
+        self.struct = t
+        self._set_pointers()
+
     def to(self, device):
         """Move the index arrays to `device` (in place; returns self).  A topology is host work only -- numpy sorts and the
         quad grouping -- so the driver builds the next batch's on the CPU in a background thread while the GPU samples the

@@ -407,6 +407,8 @@ def main():
                                                                "far polynomials (A/B runs)")
     ap.add_argument("--no-full-job", action="store_true", help="skip extra.full_job (one complete 5000-step job, ~40 s)")
     ap.add_argument("--no-gather-extra", action="store_true", help="skip extra.all_gather_world1")
+    ap.add_argument("--end-to-end-batches", type=int, default=3,
+                    help="extra.end_to_end: driver.run_job over this many consecutive batches x all steps (0: skip; then three full jobs instead of two)")
     ap.add_argument("--no-qm9-extra", action="store_true", help="skip extra.configs1_qm9")
     ap.add_argument("--no-profile", action="store_true", help="no event pairs around the CFConv launches of the timed region")
     ap.add_argument("--breakdown", default=None, help="write per-op timings (ms) to this JSON file")
@@ -938,7 +940,7 @@ def main():
             # complete 5000-step jobs of three packed batches of different composition (fewest / median / most edges per step):
             # what a job delivers against what the 20 timed steps per batch extrapolate to
             order = sorted(range(len(per_batch)), key=lambda i_: per_batch[i_]["edges"])
-            picks = sorted(set([order[0], order[len(order) // 2], order[-1]]))
+            picks = sorted(set([order[0], order[-1]]) if args.end_to_end_batches > 0 else set([order[0], order[len(order) // 2], order[-1]]))
             jobs = [full_job(model, cfg, batches, confs_of, which=i_) for i_ in picks]
             ratio = sum(j["full_job_s"] for j in jobs) / sum(j["extrapolated_s"] for j in jobs)
             extra["full_job"] = max(jobs, key=lambda j: j["batch_atoms"])
@@ -946,6 +948,35 @@ def main():
                                   "note": "wall clock of begin_sampling .. finish() (trajectory D2H, NaN / range polls every 64 steps included) "
                                           "over the extrapolation from that batch's timed steps; value_full_job = value / ratio"}
             value_full_job = value / ratio
+            # ... and the job END TO END: agdiff_amd.driver.run_job -- the counterpart of scripts/test.py:116-176 --
+            # over the first consecutive batches of the job's plan, every batch all 5000 steps: planning, packing, the static topology
+            # of every batch (the first on the main thread, the next ones in the background while the GPU samples), host <-> device
+            # copies, NaN / range polls, the .npz of every batch and the merged file.  Wall clock against what the same batches' timed
+            # steps extrapolate to and against the full-job ratio above.
+            if args.end_to_end_batches > 0 and len(batches) >= args.end_to_end_batches:
+                import tempfile
+                nb = args.end_to_end_batches
+                use = [m_ for bm in batches[:nb] for m_ in bm]
+                kw_job = dict(n_steps=JOB_STEPS, step_lr=1e-6, clip=1000.0, global_start_sigma=0.5, w_global=1.0, skip_discarded_global=skip)
+                with tempfile.TemporaryDirectory() as d_:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    res_ = driver.run_job(model, use, d_, confs_of, args.max_atoms, kw_job, dev, log=lambda *_: None)
+                    torch.cuda.synchronize()
+                    wall = time.perf_counter() - t0
+                confs_ = sum(confs_of(m_["num_refs"]) for m_ in use)
+                got_ = sum(v.shape[0] for k_, v in res_.items() if k_.startswith("pos_gen_"))
+                planned = driver.plan_batches(use, confs_of, args.max_atoms)
+                same_plan = [sorted(m_["index"] for m_ in bm) for bm in planned] == [sorted(m_["index"] for m_ in bm) for bm in batches[:nb]]
+                extrap = sum(per_batch[i_]["ms_per_step"] for i_ in range(nb)) * JOB_STEPS / 1e3
+                extra["end_to_end"] = {
+                    "what": "driver.run_job over the first %d consecutive batches of the plan x %d steps each: plan, pack, topology (background thread), "
+                            "sample, polls, per-batch .npz + merged file; trajectories not saved (scripts/test.py default)" % (nb, JOB_STEPS),
+                    "batches": nb, "same_batches_as_the_plan": bool(same_plan), "conformers": int(confs_), "conformers_written": int(got_),
+                    "wall_s": wall, "conformers_per_s": confs_ / wall, "extrapolated_from_timed_steps_s": extrap,
+                    "wall_over_extrapolated": wall / extrap, "wall_over_full_job_rate": wall / (extrap * ratio),
+                    "note": "wall_over_full_job_rate = end-to-end wall clock over (these batches' extrapolation x the full-job ratio): what planning, "
+                            "packing, topology, saving cost on top of sampling"}
             # ... and the REFERENCE's schedule end to end on the restoring-force checkpoint: 2012 steps with the global branch on
             # a dense radius graph, 2988 local-only steps -- what a trained model's 5000-step job costs
             m5, cfg5 = make_model("default", weights="restoring")

@@ -368,3 +368,31 @@ def test_prepare_batch_leaves_a_refused_topology_to_the_sampler():
     assert topo == ("topology of", packed["atom_type"].shape[0])
     packed, topo = driver.prepare_batch(object(), mols, confs)            # (test stubs without prepare_topology)
     assert topo is None
+
+
+def test_preparation_worker_process_round_trip_and_fallback(tmp_path):
+    """run_job prepares the next batch in a worker PROCESS (agdiff_amd/prep_worker.py; its own module, not a
+    re-import of the caller's __main__).  The worker's packed batch equals pack_batch's, its BatchTopology arrives pickled with
+    the struct re-pointed at its own tensors; a worker that went away is survived (the batch is prepared on the main thread)."""
+    from agdiff_amd import topology
+    from agdiff_amd.prep_worker import Client
+    mols = _mols(3)
+    confs = driver.num_confs("2x")
+    counts = [confs(m["num_refs"]) for m in mols]
+    opts = dict(order=3, group_targets=None, radius_column=True)
+    w = Client()
+    try:
+        w.submit(mols, counts, 0, 1, opts)
+        packed, topo = w.result()
+        ref = driver.pack_batch(mols, confs)
+        assert all(np.array_equal(packed[k], ref[k]) for k in ("atom_type", "bond_index", "bond_type", "batch")) and packed["spans"] == ref["spans"]
+        here = topology.BatchTopology(ref["atom_type"], ref["bond_index"], ref["bond_type"], ref["batch"], ref["num_graphs"], device="cpu")
+        assert topo.fingerprint == here.fingerprint and topo.struct.num_quads == here.struct.num_quads
+        assert torch.equal(topo.quad_tgt, here.quad_tgt) and topo.struct.quad_tgt == topo.quad_tgt.data_ptr() != here.quad_tgt.data_ptr()
+        w.proc.kill()
+        w.proc.wait()
+        with pytest.raises(Exception):
+            w.submit(mols, counts, 0, 1, opts)
+            w.result()
+    finally:
+        w.close()

@@ -112,15 +112,26 @@ def test_topology_prepared_ahead_on_the_host_gives_the_same_samples(tmp_path, mo
     _, other = driver.prepare_batch(m, mols[:2], confs)
     with pytest.raises(ValueError):
         driver.sample_batch(m, packed, "cuda:0", kw, topology=other)
-    # the job loop: three batches of one molecule each, every preparation off the main thread, every molecule sampled
+    # the job loop: three batches of one molecule each.  AGDIFF_PREPARE=thread: every preparation off the main thread
     calls, orig = [], driver.prepare_batch
     monkeypatch.setattr(driver, "prepare_batch",
                         lambda *a, **k: (calls.append(threading.current_thread() is threading.main_thread()), orig(*a, **k))[1])
     smallest = max(len(x["atom_type"]) * confs(x["num_refs"]) for x in mols)
-    res = driver.run_job(m, mols, str(tmp_path), confs, smallest, kw, "cuda:0", log=lambda *_: None)
+    monkeypatch.setenv("AGDIFF_PREPARE", "thread")
+    res = driver.run_job(m, mols, str(tmp_path / "thread"), confs, smallest, kw, "cuda:0", log=lambda *_: None)
     assert calls == [False] * len(calls) and len(calls) >= 2
     for x in mols:
         g = res["pos_gen_%d" % x["index"]]
+        assert g.shape == (confs(x["num_refs"]), len(x["atom_type"]), 3) and np.isfinite(g).all()
+    # AGDIFF_PREPARE=process: a worker PROCESS prepares every batch but the first (which the main thread prepares while the worker
+    # boots); the topologies arrive pickled, are moved to the GPU and sampled: every molecule there, nothing fell back
+    calls.clear()
+    monkeypatch.setenv("AGDIFF_PREPARE", "process")
+    logs = []
+    res2 = driver.run_job(m, mols, str(tmp_path / "process"), confs, smallest, kw, "cuda:0", log=logs.append)
+    assert calls == [True] and not [l for l in logs if "did not arrive" in l or "no worker" in l], logs
+    for x in mols:
+        g = res2["pos_gen_%d" % x["index"]]
         assert g.shape == (confs(x["num_refs"]), len(x["atom_type"]), 3) and np.isfinite(g).all()
 
 
