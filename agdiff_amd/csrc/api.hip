@@ -412,3 +412,51 @@ extern "C" int agdiff_langevin_step(const agdiff_params_t* p, const agdiff_topo_
   AG_TRY(agdiff_score_forward(p, topo, ws, a->pos_in, (a->use_global ? AGDIFF_FWD_GLOBAL : 0) | AGDIFF_FWD_SAMPLER, stream));
   return agdiff_langevin_update(topo, ws, a, stream);
 }
+
+// ---- one denoising step as a replayable HIP graph (include/agdiff_hip.h: agdiff_step_graph_*)
+namespace {
+__global__ void k_bump_word(int32_t* p) {
+  if (threadIdx.x == 0) ++*p;
+}
+}  // namespace
+
+extern "C" int agdiff_step_graph_capture(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
+                                         const agdiff_step_args_t* host_step, const agdiff_step_args_t* step_table, int32_t* step_index,
+                                         int32_t front_mode, float cutoff, int32_t fwd_flags, void* stream, void** graph_out) {
+  if (!p || !topo || !ws || !host_step || !step_table || !step_index || !graph_out || !stream) return AGDIFF_ERR_ARG;
+  {
+    std::lock_guard<std::mutex> lock(g_prof.mu);       // (event pairs around the CFConv launches are not replayable: no graphs while
+    if (g_prof.on) return AGDIFF_ERR_ARG;              // agdiff_profile_cfconv is on)
+  }
+  hipStream_t st = (hipStream_t)stream;
+  *graph_out = nullptr;
+  if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) != hipSuccess) return AGDIFF_ERR_LAUNCH;
+  int rc = ag_sampler_front_table(p, topo, ws, host_step, step_table, step_index, front_mode, cutoff, stream);
+  if (rc == AGDIFF_OK) rc = agdiff_score_forward(p, topo, ws, host_step->pos_in, fwd_flags, stream);
+  if (rc == AGDIFF_OK) {
+    k_bump_word<<<1, 64, 0, st>>>(step_index);
+    if (hipGetLastError() != hipSuccess) rc = AGDIFF_ERR_LAUNCH;
+  }
+  hipGraph_t graph = nullptr;
+  const hipError_t ec = hipStreamEndCapture(st, &graph);
+  if (rc != AGDIFF_OK || ec != hipSuccess || !graph) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return rc != AGDIFF_OK ? rc : AGDIFF_ERR_LAUNCH;
+  }
+  hipGraphExec_t exec = nullptr;
+  const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (ei != hipSuccess || !exec) return AGDIFF_ERR_LAUNCH;
+  *graph_out = (void*)exec;
+  return AGDIFF_OK;
+}
+
+extern "C" int agdiff_step_graph_launch(void* graph, void* stream) {
+  if (!graph) return AGDIFF_ERR_ARG;
+  return hipGraphLaunch((hipGraphExec_t)graph, (hipStream_t)stream) == hipSuccess ? AGDIFF_OK : AGDIFF_ERR_LAUNCH;
+}
+
+extern "C" int agdiff_step_graph_destroy(void* graph) {
+  if (!graph) return AGDIFF_OK;
+  return hipGraphExecDestroy((hipGraphExec_t)graph) == hipSuccess ? AGDIFF_OK : AGDIFF_ERR_LAUNCH;
+}

@@ -672,6 +672,9 @@ static inline void ag_log_variant(const agdiff_ws_t* ws, int64_t bits) {
   if (ws && ws->variant_log) *ws->variant_log |= bits;
 }
 static inline int64_t ag_tune(int64_t v, int64_t dflt) { return v != 0 ? v : dflt; }
+// agdiff_sampler_front with the update's step read from a device table (front.hip; used by agdiff_step_graph_capture)
+int ag_sampler_front_table(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, const agdiff_step_args_t* s,
+                           const agdiff_step_args_t* step_table, const int32_t* step_index, int32_t mode, float cutoff, void* stream);
 // Host-side launch check
 #define AG_CHECK_LAUNCH()                                         \
   do {                                                            \

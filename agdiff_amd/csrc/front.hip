@@ -14,7 +14,9 @@
 namespace {
 
 struct FrontArgs {
-  agdiff_step_args_t s;        // the update's step (valid with do_update)
+  agdiff_step_args_t s;        // the update's step (valid with do_update) ...
+  const agdiff_step_args_t* step_table;   // ... or, when non-null, entry *step_index of this DEVICE table: a launch replayed from a
+  const int32_t* step_index;              // HIP graph (agdiff_step_graph_capture) takes its step from memory, not from its arguments
   int32_t do_update;
   int32_t do_graph;
   const int32_t* graph_ptr;
@@ -95,6 +97,7 @@ extern __shared__ uint32_t ag_front_smem[];
 
 #define AG_FRONT_THREADS 1024
 __global__ void __launch_bounds__(AG_FRONT_THREADS) k_sampler_front(FrontArgs a) {
+  const agdiff_step_args_t S = a.step_table ? a.step_table[*a.step_index] : a.s;
   const int g = blockIdx.x;
   const int g0 = a.graph_ptr[g];
   const int n = a.graph_ptr[g + 1] - g0;
@@ -123,7 +126,7 @@ __global__ void __launch_bounds__(AG_FRONT_THREADS) k_sampler_front(FrontArgs a)
     return k;
   };
 
-  for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) spos[i] = a.s.pos_in[3 * (size_t)g0 + i];
+  for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) spos[i] = S.pos_in[3 * (size_t)g0 + i];
   if ((a.do_graph || a.do_local) && !by_union)
     for (int i = threadIdx.x; i < a.n_scales * 100; i += blockDim.x) sseg[i] = a.dw[i / 100][i % 100];
   if ((a.do_graph || a.do_local) && by_union) {
@@ -144,7 +147,7 @@ __global__ void __launch_bounds__(AG_FRONT_THREADS) k_sampler_front(FrontArgs a)
 
   // ================================================================== update of step t
   if (a.do_update) {
-    const bool use_global = a.s.use_global != 0;
+    const bool use_global = S.use_global != 0;
     if (use_global) {
       // radius in-adjacency of the graph the global scores were computed on, from its stored rows
       for (int k = threadIdx.x; k < n * words; k += blockDim.x) radbits[k] = 0u;
@@ -228,7 +231,7 @@ __global__ void __launch_bounds__(AG_FRONT_THREADS) k_sampler_front(FrontArgs a)
         }
       }
       for (int o = P >> 1; o > 0; o >>= 1) { lx += __shfl_xor(lx, o); ly += __shfl_xor(ly, o); lz += __shfl_xor(lz, o); }
-      if (a.s.clip_local >= 0.0f) fr_clip3(lx, ly, lz, a.s.clip_local);
+      if (S.clip_local >= 0.0f) fr_clip3(lx, ly, lz, S.clip_local);
       float gx = 0.f, gy = 0.f, gz = 0.f;
       if (use_global) {
         if (on) {
@@ -256,13 +259,13 @@ __global__ void __launch_bounds__(AG_FRONT_THREADS) k_sampler_front(FrontArgs a)
           }
         }
         for (int o = P >> 1; o > 0; o >>= 1) { gx += __shfl_xor(gx, o); gy += __shfl_xor(gy, o); gz += __shfl_xor(gz, o); }
-        fr_clip3(gx, gy, gz, a.s.clip);
+        fr_clip3(gx, gy, gz, S.clip);
       }
       if (on && part == 0) {
-        const float ex = lx + gx * a.s.w_global, ey = ly + gy * a.s.w_global, ez = lz + gz * a.s.w_global;
-        const float nx = (px + (a.s.step_size * ex) / a.s.sigma) + a.s.noise[3 * i] * a.s.noise_scale;
-        const float ny = (py + (a.s.step_size * ey) / a.s.sigma) + a.s.noise[3 * i + 1] * a.s.noise_scale;
-        const float nz = (pz + (a.s.step_size * ez) / a.s.sigma) + a.s.noise[3 * i + 2] * a.s.noise_scale;
+        const float ex = lx + gx * S.w_global, ey = ly + gy * S.w_global, ez = lz + gz * S.w_global;
+        const float nx = (px + (S.step_size * ex) / S.sigma) + S.noise[3 * i] * S.noise_scale;
+        const float ny = (py + (S.step_size * ey) / S.sigma) + S.noise[3 * i + 1] * S.noise_scale;
+        const float nz = (pz + (S.step_size * ez) / S.sigma) + S.noise[3 * i + 2] * S.noise_scale;
         bad |= (nx != nx) | (ny != ny) | (nz != nz);
         sx += nx; sy += ny; sz += nz;
         snew[3 * li] = nx; snew[3 * li + 1] = ny; snew[3 * li + 2] = nz;
@@ -288,10 +291,10 @@ __global__ void __launch_bounds__(AG_FRONT_THREADS) k_sampler_front(FrontArgs a)
     for (int li = threadIdx.x; li < n; li += blockDim.x) {
       const int i = g0 + li;
       float x = snew[3 * li] - cx, y = snew[3 * li + 1] - cy, z = snew[3 * li + 2] - cz;
-      if (a.s.clip_pos >= 0.0f) {
-        x = fminf(fmaxf(x, -a.s.clip_pos), a.s.clip_pos);
-        y = fminf(fmaxf(y, -a.s.clip_pos), a.s.clip_pos);
-        z = fminf(fmaxf(z, -a.s.clip_pos), a.s.clip_pos);
+      if (S.clip_pos >= 0.0f) {
+        x = fminf(fmaxf(x, -S.clip_pos), S.clip_pos);
+        y = fminf(fmaxf(y, -S.clip_pos), S.clip_pos);
+        z = fminf(fmaxf(z, -S.clip_pos), S.clip_pos);
       }
       float tx = x, ty = y, tz = z;
       if (frozen) {          // placeholder: a centred straight chain, 1.5 apart (finite, no two atoms at one place)
@@ -299,8 +302,8 @@ __global__ void __launch_bounds__(AG_FRONT_THREADS) k_sampler_front(FrontArgs a)
         y = z = 0.0f;
         tx = ty = tz = __uint_as_float(0x7FC00000u);
       }
-      a.s.pos_out[3 * i] = x; a.s.pos_out[3 * i + 1] = y; a.s.pos_out[3 * i + 2] = z;
-      if (a.s.traj_out) { a.s.traj_out[3 * i] = tx; a.s.traj_out[3 * i + 1] = ty; a.s.traj_out[3 * i + 2] = tz; }
+      S.pos_out[3 * i] = x; S.pos_out[3 * i + 1] = y; S.pos_out[3 * i + 2] = z;
+      if (S.traj_out) { S.traj_out[3 * i] = tx; S.traj_out[3 * i + 1] = ty; S.traj_out[3 * i + 2] = tz; }
       snew[3 * li] = x; snew[3 * li + 1] = y; snew[3 * li + 2] = z;
     }
     __syncthreads();
@@ -490,8 +493,22 @@ __global__ void __launch_bounds__(AG_FRONT_THREADS) k_sampler_front(FrontArgs a)
 
 }  // namespace
 
+static int sampler_front_impl(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, const agdiff_step_args_t* s,
+                              const agdiff_step_args_t* step_table, const int32_t* step_index, int32_t mode, float cutoff, void* stream);
+
 extern "C" int agdiff_sampler_front(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
                                     const agdiff_step_args_t* s, int32_t mode, float cutoff, void* stream) {
+  return sampler_front_impl(p, topo, ws, s, nullptr, nullptr, mode, cutoff, stream);
+}
+
+// (internal, csrc/common.hpp: the front launch with its step taken from a device table -- agdiff_step_graph_capture, api.hip)
+int ag_sampler_front_table(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, const agdiff_step_args_t* s,
+                           const agdiff_step_args_t* step_table, const int32_t* step_index, int32_t mode, float cutoff, void* stream) {
+  return sampler_front_impl(p, topo, ws, s, step_table, step_index, mode, cutoff, stream);
+}
+
+static int sampler_front_impl(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, const agdiff_step_args_t* s,
+                              const agdiff_step_args_t* step_table, const int32_t* step_index, int32_t mode, float cutoff, void* stream) {
   if (!p || !topo || !ws || !(mode & 7)) return AGDIFF_ERR_ARG;
   const bool do_update = (mode & 1) != 0, do_graph = (mode & 2) != 0, do_local = (mode & 4) != 0 && topo->num_local > 0;
   if (do_local && (!topo->lcm_ptr || !topo->lc_src || !topo->lc_dst || !topo->lc_pos || !topo->lc_mir || !ws->l_len || !ws->lc_len))
@@ -507,6 +524,8 @@ extern "C" int agdiff_sampler_front(const agdiff_params_t* p, const agdiff_topo_
   if (topo->num_nodes * (int64_t)AGDIFF_RAD_STRIDE >= (1ll << 31)) return AGDIFF_ERR_LIMIT;
   FrontArgs a;
   a.s = *s;
+  a.step_table = step_table;
+  a.step_index = step_index;
   a.do_update = do_update ? 1 : 0;
   a.do_graph = do_graph ? 1 : 0;
   a.graph_ptr = topo->graph_ptr;

@@ -238,6 +238,13 @@ class DualEncoderEpsNetwork(nn.Module):
         # local edges LONGER than the cutoff take their edge_attr rows from a second polynomial per type on [cutoff, 10 cutoff]
         # (packing.fit_attr_far) instead of the encoder MLP; False keeps the MLP for them
         self.attr_far_rows = True
+        # The denoising loop's steps as replayed HIP graphs (include/agdiff_hip.h: agdiff_step_graph_capture): True, False, or "auto" (for
+        # batches of up to STEP_GRAPH_MAX_NODES atoms).  Bit-identical to the launch-by-launch loop (tests/test_hip_step_graphs.py) and
+        # NOT faster on this stack: one molecule x 100 conformers 0.327 / 0.335 ms per step replayed against 0.318 / 0.317 launched,
+        # alanine dipeptide 0.35 against 0.28 (profiles/r06_step_graphs.txt) -- a small batch's step is a chain of ~14 dependent
+        # dispatches at ~20 us each on the GPU side, which a replay issues one by one just the same; the host was never the bound.
+        # Hence off by default.
+        self.step_graphs = False
         self._packed = None
         self._packed_key = None
         self._batch_cache = None
@@ -298,6 +305,7 @@ class DualEncoderEpsNetwork(nn.Module):
     # AGDIFF (max_norm-10 embedding, BatchNorm'd CFConvs and GIN layers) sits two to three orders of magnitude below; what
     # trips the watch is a diverging run or a degenerate checkpoint, for which precision="bf16x3" has fp32's range.
     RANGE_LIMITS = (("h", 255.0), ("hl", 255.0), ("agg", 60000.0), ("xs", 60000.0))
+    STEP_GRAPH_MAX_NODES = 32768
 
     def _uses_split_fp16(self):
         p = self._packed
@@ -659,6 +667,18 @@ class LangevinRun:
         self.args = a
         self._nz, self._nz_base = None, 0
         self.global_steps = 0
+        # steps as HIP graphs (model.step_graphs): one graph per (global branch on / off, step parity); the front kernel of a replay
+        # reads its step from the device table below, the graph's last node moves the index on
+        sg = getattr(model, "step_graphs", "auto")
+        self._use_graphs = bool((sg is True or (sg == "auto" and N <= model.STEP_GRAPH_MAX_NODES)) and on_step is None and
+                                noise_mode == "chunked" and self.pk.poly_kt > 0 and getattr(model, "fused_front", True) and
+                                not getattr(model, "front_split_graph", False))
+        self._graphs, self._step_table, self._step_index, self._dev_index = {}, None, None, None
+        # (a capture needs a stream of its own: the legacy default stream, which torch hands out as the current one, cannot be captured)
+        self._gstream = torch.cuda.Stream(device=dev) if self._use_graphs else None
+        self.graph_steps = 0                   # steps that ran as graph replays (tests, bench)
+        if self._use_graphs and self.noise is not None:
+            self.noise = self.noise.to(dev, torch.float32).contiguous()       # (rows at fixed addresses for the step table)
         # per-step scalars of dualenc.py:515,532,536 for every step of the run, evaluated once in the reference's
         # fp32 tensor arithmetic (the loop then only touches Python floats)
         sig = self.sigmas[torch.as_tensor(self.steps, dtype=torch.long)] if len(self.steps) else self.sigmas[:0]
@@ -694,6 +714,16 @@ class LangevinRun:
         if self.noise_mode == "per_step":          # dualenc.py:529: noise = torch.randn_like(pos), one draw per step
             return torch.randn_like(self.pos)
         chunk = 128
+        if self._use_graphs:
+            # ONE buffer refilled in place (fixed row addresses for the step table).  Safe where _fill_args calls this: every launch
+            # that reads the rows of the chunk before is already enqueued on this stream
+            if self._nz is None:
+                self._nz = torch.empty((chunk, N, 3), dtype=torch.float32, device=dev)
+                self._nz_base, self._nz_origin = -chunk, k
+            if k >= self._nz_base + chunk:
+                self._nz_base = k
+                self._nz[:min(chunk, len(self.steps) - k)].normal_()
+            return self._nz[k - self._nz_base]
         if self._nz is None or k >= self._nz_base + self._nz.shape[0]:
             self._nz = torch.randn((min(chunk, len(self.steps) - k), N, 3), dtype=torch.float32, device=dev)
             self._nz_base = k
@@ -714,6 +744,59 @@ class LangevinRun:
         a.noise_scale = noise_scale
         a.use_global = 1 if use_global else 0
         return cur, bool(use_global or not self.skip_discarded)
+
+    def _build_step_table(self, first):
+        """The update's arguments of EVERY step of the run as a device array of agdiff_step_args_t (what _fill_args would put into
+        the launch arguments step by step), + the device index the graphs' front kernels read it at."""
+        a, N, dev = self.args, self.topo.N, self.pos.device
+        n = len(self.steps)
+        if self.noise is None:
+            self._noise_for(first, dev, N)                 # (allocates the buffer)
+        tab = (_lib.StepArgs * n)()
+        nz0 = self._nz.data_ptr() if self.noise is None else self.noise.data_ptr()
+        tr0 = self.traj.data_ptr() if self.traj is not None else 0
+        for k in range(n):
+            sig, step_size, noise_scale, use_global = self._sched[k]
+            e = tab[k]
+            e.pos_in, e.pos_out, e.scratch = a.pos_in, a.pos_out, a.scratch
+            row = ((k - self._nz_origin) % 128) if self.noise is None else k
+            e.noise = nz0 + row * N * 12
+            e.traj_out = (tr0 + k * N * 12) if tr0 else None
+            e.sigma, e.step_size, e.noise_scale = sig, step_size, noise_scale
+            e.w_global, e.clip, e.clip_local, e.clip_pos = a.w_global, a.clip, a.clip_local, a.clip_pos
+            e.use_global = 1 if use_global else 0
+        raw = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8)
+        self._step_table = raw.to(dev)
+        self._step_index = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._dev_index = None
+        self._table_first = first
+
+    def _step_graph(self, run_global, par, cached, cutoff):
+        """The replayable graph of one steady-state iteration [update of the step before | radius graph | local edges | forward]
+        for this (global branch, parity), captured on first use; None when the library refuses (then the run goes on without)."""
+        key = (run_global, par)
+        g = self._graphs.get(key)
+        if g is None:
+            V = _lib.DEFINES
+            mode = 1 | (2 if run_global else 0) | 4 | (par << 4)
+            flags = (run_global | self.radius_flags | self._sampler_flag | cached | V["AGDIFF_FWD_GRAPH_READY"] |
+                     (V["AGDIFF_FWD_PARITY"] if par else 0))
+            out = ctypes.c_void_p(0)
+            rc = self.lib.agdiff_step_graph_capture(ctypes.byref(self.pk.struct), ctypes.byref(self.topo.struct), ctypes.byref(self.ws.struct),
+                                                    ctypes.byref(self.args), _lib.ptr(self._step_table), _lib.ptr(self._step_index),
+                                                    mode, cutoff, flags, _lib.stream_ptr(), ctypes.byref(out))
+            if rc != 0 or not out.value:
+                self._use_graphs = False
+                return None
+            g = self._graphs[key] = out.value
+        return g
+
+    def __del__(self):
+        try:
+            for g in getattr(self, "_graphs", {}).values():
+                self.lib.agdiff_step_graph_destroy(ctypes.c_void_p(g))
+        except Exception:
+            pass
 
     def _advance_fused(self, end):
         """Steps k .. end - 1 with ONE launch between a step's global head and the next step's first CFConv: iteration k
@@ -739,16 +822,30 @@ class LangevinRun:
             # update(k - 1) | radius graph(k) | local edges(k)   (a carries step k - 1 when an update is due; its noise row
             # stays alive in `keep`).  With `front_split_graph` the graph phase is launched by the forward, after the fork.
             mode = (1 if k > first else 0) | (2 if (run_global and not pending) else 0) | 4 | (par << 4)
-            _lib.check(lib.agdiff_sampler_front(P, T, W, ctypes.byref(a), mode, cutoff, stream), "agdiff_sampler_front")
+            cached = V["AGDIFF_FWD_STAGE0_CACHED"] if (run_global and self._stage0_done) else 0
+            # steady state as ONE graph replay: the update of step k - 1 is due, node stage 0 is cached (every kernel has run once)
+            graph = None
+            if self._use_graphs and k > first + 1 and (cached or not run_global):
+                if self._step_table is None:
+                    self._build_step_table(first)
+                graph = self._step_graph(run_global, par, cached, cutoff)
+            if graph is not None:
+                if self._dev_index != k - 1:                # (the front kernel reads the table at the step whose update it does)
+                    self._step_index.fill_(k - 1)
+                _lib.check(lib.agdiff_step_graph_launch(ctypes.c_void_p(graph), stream), "agdiff_step_graph_launch")
+                self._dev_index = k
+                self.graph_steps += 1
+            else:
+                _lib.check(lib.agdiff_sampler_front(P, T, W, ctypes.byref(a), mode, cutoff, stream), "agdiff_sampler_front")
             if k > first:
                 self._traj_ready = k          # (the update of step k - 1 -- the launch above -- writes trajectory row k - 1)
             if k > first and self.on_step is not None:
                 self.on_step(k - 1, self.steps[k - 1], self.pos)
             self.global_steps += run_global
-            cached = V["AGDIFF_FWD_STAGE0_CACHED"] if (run_global and self._stage0_done) else 0
-            _lib.check(lib.agdiff_score_forward(P, T, W, self.pos_p, run_global | self.radius_flags | self._sampler_flag | cached |
-                                                V["AGDIFF_FWD_GRAPH_READY"] | (V["AGDIFF_FWD_PARITY"] if par else 0) |
-                                                (V["AGDIFF_FWD_GRAPH_PENDING"] if pending else 0), stream), "agdiff_score_forward")
+            if graph is None:
+                _lib.check(lib.agdiff_score_forward(P, T, W, self.pos_p, run_global | self.radius_flags | self._sampler_flag | cached |
+                                                    V["AGDIFF_FWD_GRAPH_READY"] | (V["AGDIFF_FWD_PARITY"] if par else 0) |
+                                                    (V["AGDIFF_FWD_GRAPH_PENDING"] if pending else 0), stream), "agdiff_score_forward")
             self._stage0_done = self._stage0_done or bool(run_global)
             keep = [self._fill_args(a, k, dev, N)[0]]
             a.use_global = 1 if self._sched[k][3] else 0
@@ -767,8 +864,17 @@ class LangevinRun:
     def advance(self, m):
         lib, a, pk, topo, ws = self.lib, self.args, self.pk, self.topo, self.ws
         dev, N = self.pos.device, topo.N
-        stream = _lib.stream_ptr()
         end = min(self.k + int(m), len(self.steps))
+        if self._gstream is not None and self._use_graphs and self._fused_front():
+            # the run's own stream (ordered after what the caller has enqueued; the caller's stream waits for it at the end)
+            outer = torch.cuda.current_stream(dev)
+            self._gstream.wait_stream(outer)
+            try:
+                with torch.cuda.stream(self._gstream), torch.no_grad():
+                    return self._advance_fused(end)
+            finally:
+                outer.wait_stream(self._gstream)
+        stream = _lib.stream_ptr()
         with torch.no_grad():
             if self._fused_front():
                 return self._advance_fused(end)

@@ -406,6 +406,8 @@ def main():
     ap.add_argument("--no-attr-far", action="store_true", help="local edges beyond the cutoff through the encoder MLP instead of their "
                                                                "far polynomials (A/B runs)")
     ap.add_argument("--no-full-job", action="store_true", help="skip extra.full_job (one complete 5000-step job, ~40 s)")
+    ap.add_argument("--step-graphs", choices=["auto", "on", "off"], default="off",
+                    help="the loop's steps as replayed HIP graphs (model.step_graphs; measured: no faster, profiles/r06_step_graphs.txt)")
     ap.add_argument("--no-gather-extra", action="store_true", help="skip extra.all_gather_world1")
     ap.add_argument("--end-to-end-batches", type=int, default=3,
                     help="extra.end_to_end: driver.run_job over this many consecutive batches x all steps (0: skip; then three full jobs instead of two)")
@@ -509,6 +511,7 @@ def main():
         m.poly_passes = args.poly_passes
         m.attr_far_rows = not args.no_attr_far
         m.fused_front, m.front_split_graph = args.front != "unfused", args.front == "split"
+        m.step_graphs = {"auto": "auto", "on": True, "off": False}[args.step_graphs]
         if args.serial:
             m.tuning["serial_branches"] = 1
         for kv in args.tune:

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 41
+#define AGDIFF_ABI_VERSION 42
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -611,6 +611,23 @@ int agdiff_score_forward(const agdiff_params_t* p, const agdiff_topo_t* topo, co
  * agdiff_graph_build_scaled inside the denoising loop (models/common.py:208-233 is rebuilt every step). */
 int agdiff_sampler_front(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
                          const agdiff_step_args_t* s, int32_t mode, float cutoff, void* stream);
+/* ONE denoising step of the loop above as a replayable HIP graph -- [agdiff_sampler_front(front_mode) | agdiff_score_forward(fwd_flags
+ * on host_step->pos_in) | step counter + 1], captured from `stream` (side stream of the local branch included) and instantiated:
+ * small batches (scripts/test.py:130-164 samples one molecule's 100..1000 conformers per call) are bound by the ~25 launches a step
+ * takes, a replay is one call.  What changes from step to step does not sit in kernel arguments: the front kernel reads the
+ * update's step from the DEVICE table `step_table` at index *step_index (the host fills the table for the whole run: noise and
+ * trajectory rows, sigma, step size, ...), and the last node of the graph increments *step_index.  `host_step` only carries what
+ * is the same for every step (pos_in / pos_out, and valid pointers for the argument checks).  One graph per (front_mode, fwd_flags)
+ * the loop alternates between (step parity, global branch on / off).  The kernels must have run once outside a capture (their
+ * function attributes, the side stream and its events are set up on first use).  *graph_out: opaque handle for
+ * agdiff_step_graph_launch / agdiff_step_graph_destroy. */
+int agdiff_step_graph_capture(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
+                              const agdiff_step_args_t* host_step /* [host] */, const agdiff_step_args_t* step_table,
+                              int32_t* step_index, int32_t front_mode, float cutoff, int32_t fwd_flags, void* stream,
+                              void** graph_out /* [host] */);
+int agdiff_step_graph_launch(void* graph /* [host] */, void* stream);
+int agdiff_step_graph_destroy(void* graph /* [host] */);
+
 /* The polynomial global head (agdiff_pair_head_poly) over the canonical radius list of agdiff_sampler_front (step parity as
  * there): results to ws->inv_r at the entry's radius row and its mirror's. */
 int agdiff_pair_head_poly_rows(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws, int32_t parity,
