@@ -968,15 +968,8 @@ __global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_pair_head_poly(Hea
       const float* ht = a.node_h + (size_t)t * 128;
       AgIn<MODE> sl[2];
       auto load_slice = [&](AgIn<MODE>& dst, int k) {
-#if defined(AG_HEADP_ABL) && (AG_HEADP_ABL & 1)       // (timing experiments, wrong results: 1 no gathers of h, 2 the target's row only)
-        const f32x4 p0 = {d, d + (float)k, d, d}, p1 = {d, d, d - (float)k, d};
-#elif defined(AG_HEADP_ABL) && (AG_HEADP_ABL & 2)
-        const f32x4 p0 = ag_ld4(ht + 32 * k + 4 * q) * d;
-        const f32x4 p1 = ag_ld4(ht + 32 * k + 16 + 4 * q) * d;
-#else
         const f32x4 p0 = ag_ld4(hs + 32 * k + 4 * q) * ag_ld4(ht + 32 * k + 4 * q);
         const f32x4 p1 = ag_ld4(hs + 32 * k + 16 + 4 * q) * ag_ld4(ht + 32 * k + 16 + 4 * q);
-#endif
         ag_cvt(p0, p1, dst);
       };
       load_slice(sl[0], 0);

@@ -349,9 +349,6 @@ __global__ void __launch_bounds__(AG_FRONT_THREADS) k_sampler_front(FrontArgs a)
   } else
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     for (int w = 0; w < words; ++w) locbits[i * words + w] = 0u;
-#if defined(AG_FRONT_ABL) && (AG_FRONT_ABL & 8)       // (8: no local adjacency, 16: no scan of the canonical counts)
-    continue;
-#endif
     for (int k = a.loc_in_ptr[g0 + i]; k < a.loc_in_ptr[g0 + i + 1]; ++k) {
       const int j = a.loc_src[a.loc_in_eid[k]] - g0;
       locbits[i * words + (j >> 5)] |= 1u << (j & 31);
@@ -398,7 +395,6 @@ __global__ void __launch_bounds__(AG_FRONT_THREADS) k_sampler_front(FrontArgs a)
   __syncthreads();
   // inclusive scan of scan_c (n <= 512) by ONE wave: eight consecutive counts per lane, a shuffle scan of the lanes' sums (the
   // Hillis-Steele scan over the whole workgroup took two barriers per doubling: 13 % of the graph phase)
-#if !(defined(AG_FRONT_ABL) && (AG_FRONT_ABL & 16))
   if (wave == 0) {
     int run[8], sum = 0;
 #pragma unroll
@@ -421,7 +417,6 @@ __global__ void __launch_bounds__(AG_FRONT_THREADS) k_sampler_front(FrontArgs a)
     }
   }
   __syncthreads();
-#endif
   __shared__ int cbase_s;
   if (threadIdx.x == 0) {
     cbase_s = atomicAdd(&a.canon_counter[a.parity], n ? scan_c[n - 1] : 0);
@@ -449,23 +444,13 @@ __global__ void __launch_bounds__(AG_FRONT_THREADS) k_sampler_front(FrontArgs a)
         a.rad_src[rp] = g0 + j;
         a.rad_len[rp] = len;
         const float C = cf_envelope(len, a.cutoff, a.smooth);
-#if defined(AG_FRONT_ABL) && (AG_FRONT_ABL & 1)      // (timing experiments, wrong results: 1 the radius rows' scales without their evaluation,
-        for (int cc = 0; cc < a.n_scales; ++cc) a.r_scale[(size_t)cc * a.rpad + rp] = C;       //  2 only the first scale plane, 4 no canonical list)
-#elif defined(AG_FRONT_ABL) && (AG_FRONT_ABL & 2)
-        a.r_scale[rp] = scale_of(union_segment(len), 0, len) * C;
-#else
         if (by_union) {
           const int u = union_segment(len);
           for (int cc = 0; cc < a.n_scales; ++cc) a.r_scale[(size_t)cc * a.rpad + rp] = scale_of(u, cc, len) * C;
         } else {
           for (int cc = 0; cc < a.n_scales; ++cc) a.r_scale[(size_t)cc * a.rpad + rp] = cf_dist_weight(sseg + cc * 100, len) * C;
         }
-#endif
-#if defined(AG_FRONT_ABL) && (AG_FRONT_ABL & 4)
-        if (false) {
-#else
         if (canon) {
-#endif
           const int cp = cp0 + __popcll(cmask & lt);
           a.c_len[cp] = len;
           a.c_src[cp] = g0 + j;

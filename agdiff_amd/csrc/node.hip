@@ -97,9 +97,7 @@ __global__ void __launch_bounds__(LDSW ? 1024 : 256, LDSW ? 1 : 2) k_schnet_node
   auto stage_in = [&](int dst_block, const float* src, int nblocks) {
     if constexpr (LDSW) {
       const u32x4* g = reinterpret_cast<const u32x4*>(src);
-#ifndef AG_NODE_NOCOPY      // (timing experiment: -DAG_NODE_NOCOPY leaves the weights unstaged -- wrong results)
       ag_copy_lds<4>(L + dst_block * 128, g, nblocks * 128);     // (4 deep: tile state is live across the later phases)
-#endif
     }
   };
   auto sync = [&]() {

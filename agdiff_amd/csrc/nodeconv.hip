@@ -122,10 +122,6 @@ struct NodeConvShape {
 #ifndef AG_QUAD_DYNAMIC
 #define AG_QUAD_DYNAMIC 1      // k_cfconv_quad: a workgroup's quads dealt to its waves as they finish (0: quad p_begin + wave, + WAVES, ...)
 #endif
-#ifndef AG_NODE_ABL
-#define AG_NODE_ABL 0       // timing experiments only (wrong results): 1 no x gathers, 2 no filter MFMAs, 4 no features, 8 no sums, 16 one coefficient read per group
-                            // (k_cfconv_quad: 1, 8 and 16 -- one read per tile -- only)
-#endif
 // PLAN (agdiff_params_t.poly_plan): 0 three passes for every term; 1 one pass for the high terms, whose coefficients the
 // host has bounded -- at NKT 1 two MFMAs per channel tile (hi x hi of all 32 terms, then both cross terms of terms 0..15 in
 // one instruction: ag_poly_features<.., true> / the mixed unit 1 of the blocks), at NKT 2 k-tile 1 by its hi x hi pass alone.
@@ -236,8 +232,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
     for (int j = 0; j < GRP; ++j) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (AG_NODE_ABL & 1) xg[kb][j][r] = __uint_as_float(xoff[r] + (uint32_t)(GRP * g + j));
-        else xg[kb][j][r] = *reinterpret_cast<const float*>(xb + (size_t)xoff[r] + 64 * (GRP * g + j));
+        xg[kb][j][r] = *reinterpret_cast<const float*>(xb + (size_t)xoff[r] + 64 * (GRP * g + j));
       }
     }
   };
@@ -256,11 +251,6 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
     for (int j = 0; j < CN; ++j) {
 #pragma unroll
       for (int t = 0; t < NKT; ++t) {
-        if ((AG_NODE_ABL & 16) && j > 0) {            // (timing experiment: one coefficient block read per group)
-          w[j][t][0] = w[0][t][0];
-          w[j][t][1] = w[0][t][1];
-          continue;
-        }
         w[j][t][0] = base[(((C0 + j) * NKT + t) * 2) * 64];
         if (PLAN == 0 || t == 0) w[j][t][1] = base[(((C0 + j) * NKT + t) * 2 + 1) * 64];
       }
@@ -278,13 +268,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
               continue;
             }
           }
-          if (AG_NODE_ABL & 2) {
-            if (t == 0 && part == 0) {
-              u32x4 pu;
-              __builtin_memcpy(&pu, &ph[0], 16);
-              z[j] = __builtin_bit_cast(f32x4, w[j][0][0]) * __uint_as_float(pu[0]);
-            }
-          } else if (t == 0 && part == 0) z[j] = ag_block_mma_first<MODE, true>(ph[0], w[j][0]);
+          if (t == 0 && part == 0) z[j] = ag_block_mma_first<MODE, true>(ph[0], w[j][0]);
           else ag_block_mma_part<MODE, true>(z[j], ph[t], w[j][t], part);
         }
       }
@@ -297,17 +281,8 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
   auto next_features = [&]() {
     const bool dead = with_local && pf_slot < -1;
     const float s1 = dead ? 0.0f : pf_s1, s2 = dead ? 0.0f : pf_s2;
-    if (AG_NODE_ABL & 4) {
-#pragma unroll
-      for (int t = 0; t < NKT; ++t) {
-        f32x4 v1[2] = {{pf_d, s1, pf_d, s1}, {s1, pf_d, s1, pf_d}}, v2[2] = {{pf_d, s2, pf_d, s2}, {s2, pf_d, s2, pf_d}};
-        __builtin_memcpy(&ph1[t], v1, 32);
-        __builtin_memcpy(&ph2[t], v2, 32);
-      }
-    } else {
-      ag_poly_features<MODE, NKT, MIXED>(pf_d, a.two_over_rc, q, ph1, s1);
-      ag_poly_features<MODE, NKT, MIXED>(pf_d, a.two_over_rc, q, ph2, s2);
-    }
+    ag_poly_features<MODE, NKT, MIXED>(pf_d, a.two_over_rc, q, ph1, s1);
+    ag_poly_features<MODE, NKT, MIXED>(pf_d, a.two_over_rc, q, ph2, s2);
   };
   float acc[AG_CONV_NCH], accL[AG_CONV_NCH];
   // the sums over the wave's quarters, once per target: quarter j of a reduce-scatter ends up with channel tile 4 g + j.
@@ -384,7 +359,6 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
         for (int jj = 0; jj < GRP; ++jj) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            if ((AG_NODE_ABL & 8) && r) continue;
             S[GRP * gg + jj] = fmaf(z[jj][r], xg[gg % XD][jj][r], S[GRP * gg + jj]);
           }
           // (pins the sum to this step: the optimiser otherwise sinks all 48 FMAs of a tile below its last MFMA -- nothing
@@ -583,8 +557,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_quad(NodeConvA
     for (int j = 0; j < GRP; ++j) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (AG_NODE_ABL & 1) xg[kb][j][r] = __uint_as_float(xoff[r] + (uint32_t)(GRP * g + j));
-        else xg[kb][j][r] = *reinterpret_cast<const float*>(xb + (size_t)xoff[r] + 64 * (GRP * g + j));
+        xg[kb][j][r] = *reinterpret_cast<const float*>(xb + (size_t)xoff[r] + 64 * (GRP * g + j));
       }
     }
   };
@@ -602,11 +575,6 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_quad(NodeConvA
     for (int j = 0; j < GRP; ++j) {
 #pragma unroll
       for (int t = 0; t < NKT; ++t) {
-        if ((AG_NODE_ABL & 16) && (j > 0 || C0 > 0)) {      // (timing experiment: one coefficient block read per tile)
-          w[j][t][0] = w[0][t][0];
-          w[j][t][1] = w[0][t][1];
-          continue;
-        }
         w[j][t][0] = base[(((C0 + j) * NKT + t) * 2) * 64];
         if (PLAN == 0 || t == 0) w[j][t][1] = base[(((C0 + j) * NKT + t) * 2 + 1) * 64];
       }
@@ -707,10 +675,6 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_quad(NodeConvA
         for (int jj = 0; jj < GRP; ++jj) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            if ((AG_NODE_ABL & 8) && r) {
-              asm volatile("" ::"v"(z[jj][r]), "v"(xg[gg % XD][jj][r]));
-              continue;
-            }
             acc[GRP * gg + jj] = fmaf(z[jj][r], xg[gg % XD][jj][r], acc[GRP * gg + jj]);
           }
           asm volatile("" : "+v"(acc[GRP * gg + jj]));

@@ -18,6 +18,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--out", default=None)
 ap.add_argument("--steps", type=int, default=60)
 ap.add_argument("--scales", default="1,2,5,8,16,40")
+ap.add_argument("--all-layers", default="1.5,2,3", help="every Linear weight of the edge encoder scaled by these factors")
+ap.add_argument("--default-init-seeds", default="0,1,2", help="PyTorch-default-initialised models (torch.manual_seed) -- no synthetic checkpoint")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 T = lambda x: torch.from_numpy(np.ascontiguousarray(x))
@@ -27,15 +29,26 @@ big = synth.make_packed_batch("drugs", 8, 128, seed=2021)
 pos_small = torch.randn(small["atom_type"].shape[0], 3, generator=torch.Generator().manual_seed(5)) * 2.0
 rows = []
 from agdiff_amd import _lib
-for scale in [float(x) for x in args.scales.split(",")]:
+cases = [("first_layer", float(x)) for x in args.scales.split(",") if x] + \
+        [("all_encoder_layers", float(x)) for x in args.all_layers.split(",") if x] + \
+        [("default_init", float(x)) for x in args.default_init_seeds.split(",") if x]
+for kind_, scale in cases:
     def build(precision):
+        if kind_ == "default_init":          # what nn.Linear / nn.Embedding give a freshly constructed model (the reference's own start)
+            torch.manual_seed(int(scale))
         m_ = get_model(cfg)
         m_.precision = precision
-        sd_ = synth.synth_state_dict(m_.state_dict())
-        for k in sd_:
-            if synth.canonical_key(k) == "edge_encoder_global.feature_expansion.weight":
-                sd_[k] = sd_[k] * scale
-        m_.load_state_dict(sd_)
+        if kind_ == "default_init":
+            sd_ = {k: v.clone() for k, v in m_.state_dict().items()}
+        else:
+            sd_ = synth.synth_state_dict(m_.state_dict())
+            for k in sd_:
+                ck = synth.canonical_key(k)
+                if kind_ == "first_layer" and ck == "edge_encoder_global.feature_expansion.weight":
+                    sd_[k] = sd_[k] * scale
+                if kind_ == "all_encoder_layers" and ck.startswith("edge_encoder_global.") and ck.endswith(".weight") and "bond_emb" not in ck:
+                    sd_[k] = sd_[k] * scale
+            m_.load_state_dict(sd_)
         return m_.to(dev).eval(), sd_
     at, bi, bt, ba = [T(small[k]) for k in ("atom_type", "bond_index", "bond_type", "batch")]
     precision = "f16x3"
@@ -49,7 +62,7 @@ for scale in [float(x) for x in args.scales.split(",")]:
         m.precision_local = "bf16x3"
         got = m(at.to(dev), pos_small.to(dev), bi.to(dev), bt.to(dev), ba.to(dev), None, return_edges=True, extend_order=False)
     pk = m.packed()
-    rec = {"first_layer_scale": scale, "precision": precision, "max_abs_reference_inv_g": float(ref[0].abs().max()),
+    rec = {"case": kind_, "first_layer_scale": scale if kind_ == "first_layer" else None, "scale_or_seed": scale, "precision": precision, "max_abs_reference_inv_g": float(ref[0].abs().max()),
            "poly_kt": int(pk.poly_kt), "terms": 32 * int(pk.poly_kt), "pass_plan": int(pk.poly_plan),
            "one_pass_bound_of_high_terms": max(pk.poly_high_bound.values()) if pk.poly_high_bound else None,
            "fit_errors": {str(k): float(v) for k, v in pk.poly_errors.items()},
@@ -60,13 +73,20 @@ for scale in [float(x) for x in args.scales.split(",")]:
     n = 10 + args.steps
     run = m.begin_sampling(at, pos_init, bi, bt, ba, big["num_graphs"], False, n_steps=n, step_lr=1e-6, clip=1000.0,
                            global_start_sigma=0.5, w_global=1.0, save_traj=False)
-    run.advance(10)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run.advance(args.steps)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / args.steps * 1e3
-    run.check_nan()
+    try:
+        run.advance(10)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run.advance(args.steps)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / args.steps * 1e3
+        run.check_nan()
+    except (FloatingPointError, _lib.AgdiffRangeError) as e:      # (the scaled network's own dynamics diverge: nothing to time)
+        rec.update(ms_per_step_8x128=None, conformers_per_s_8x128=0.0, path="sampler diverged (%s)" % type(e).__name__)
+        rows.append(rec)
+        print(json.dumps(rec), flush=True)
+        del run, m
+        continue
     rec.update(ms_per_step_8x128=ms, conformers_per_s_8x128=big["num_graphs"] / (ms * 5000 / 1e3),
                path="filter polynomials, %d terms" % (32 * pk.poly_kt) if pk.poly_kt else "filter MLPs (fit refused at 32 and 64 terms)")
     rows.append(rec)
@@ -74,7 +94,7 @@ for scale in [float(x) for x in args.scales.split(",")]:
     del run, m
 base = rows[0]["conformers_per_s_8x128"]
 for r in rows:
-    r["fraction_of_scale_1"] = r["conformers_per_s_8x128"] / base
+    r["fraction_of_scale_1"] = r["conformers_per_s_8x128"] / base          # (of the first row: the synthetic checkpoint as it is)
 if args.out:
     json.dump({"workload": "8 Drugs-shaped molecules x 128 conformers, saturated schedule, %d timed steps; parity: one forward of a 2 x 2 batch against the oracle (normwise)" % args.steps,
                "rows": rows}, open(args.out, "w"), indent=1)
