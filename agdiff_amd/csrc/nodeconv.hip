@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
   uint32_t xoff[4];
   auto set_xoff = [&]() {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) xoff[r] = ((uint32_t)pf_src[r] * 192u + (uint32_t)col) * 4u;
+    for (int r = 0; r < 4; ++r) xoff[r] = __umul24((uint32_t)pf_src[r], 768u) + (uint32_t)col * 4u;      // (v_mad_u32_u24: full rate.  N * 768 < 2^32: topology.py)
   };
   auto fetch_xg = [&](auto BUF, int g) {
     constexpr int kb = decltype(BUF)::value;
@@ -548,7 +548,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_quad(NodeConvA
   uint32_t xoff[4];
   auto set_xoff = [&]() {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) xoff[r] = ((uint32_t)pf_src[r] * 192u + (uint32_t)col) * 4u;
+    for (int r = 0; r < 4; ++r) xoff[r] = __umul24((uint32_t)pf_src[r], 768u) + (uint32_t)col * 4u;      // (v_mad_u32_u24: full rate.  N * 768 < 2^32: topology.py)
   };
   auto fetch_xg = [&](auto BUF, int g) {
     constexpr int kb = decltype(BUF)::value;
