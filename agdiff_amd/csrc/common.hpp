@@ -158,6 +158,16 @@ __device__ __forceinline__ void ag_head_act(f32x4 (&y)[NY], int act) {
     case AGDIFF_ACT_SOFTPLUS: AG_FOR_TILE(y, NT, ag_softplus(v)); break;
     case AGDIFF_ACT_LEAKY_RELU: AG_FOR_TILE(y, NT, (v > 0.0f ? v : 0.01f * v)); break;
     case AGDIFF_ACT_ELU: AG_FOR_TILE(y, NT, (v > 0.0f ? v : ag_exp2(v * 1.44269504088896340736f) - 1.0f)); break;
+    case AGDIFF_ACT_RELU6: AG_FOR_TILE(y, NT, fminf(fmaxf(v, 0.0f), 6.0f)); break;
+    case AGDIFF_ACT_HARDTANH: AG_FOR_TILE(y, NT, fminf(fmaxf(v, -1.0f), 1.0f)); break;
+    case AGDIFF_ACT_SELU:
+      AG_FOR_TILE(y, NT, 1.0507009873554804934f * (v > 0.0f ? v : 1.6732632423543772848f * (ag_exp2(v * 1.44269504088896340736f) - 1.0f)));
+      break;
+    case AGDIFF_ACT_MISH: AG_FOR_TILE(y, NT, v * ag_tanh(ag_softplus(v))); break;
+    case AGDIFF_ACT_HARDSWISH: AG_FOR_TILE(y, NT, v * fminf(fmaxf(v + 3.0f, 0.0f), 6.0f) * (1.0f / 6.0f)); break;
+    case AGDIFF_ACT_HARDSIGMOID: AG_FOR_TILE(y, NT, fminf(fmaxf(v + 3.0f, 0.0f), 6.0f) * (1.0f / 6.0f)); break;
+    case AGDIFF_ACT_SOFTSIGN: AG_FOR_TILE(y, NT, v * ag_rcp(1.0f + fabsf(v))); break;
+    case AGDIFF_ACT_LOGSIGMOID: AG_FOR_TILE(y, NT, -ag_softplus(-v)); break;
     default: AG_FOR_TILE(y, NT, ag_relu(v)); break;
   }
 }

@@ -118,7 +118,15 @@ typedef struct agdiff_gin_params {
 #define AGDIFF_ACT_SIGMOID 4
 #define AGDIFF_ACT_SOFTPLUS 5    /* beta 1, threshold 20 */
 #define AGDIFF_ACT_LEAKY_RELU 6  /* negative_slope 0.01 */
-#define AGDIFF_ACT_ELU 7         /* alpha 1 */
+#define AGDIFF_ACT_ELU 7         /* alpha 1 (F.celu with its default alpha is the same function) */
+#define AGDIFF_ACT_RELU6 8
+#define AGDIFF_ACT_HARDTANH 9    /* [-1, 1] */
+#define AGDIFF_ACT_SELU 10
+#define AGDIFF_ACT_MISH 11
+#define AGDIFF_ACT_HARDSWISH 12
+#define AGDIFF_ACT_HARDSIGMOID 13
+#define AGDIFF_ACT_SOFTSIGN 14
+#define AGDIFF_ACT_LOGSIGMOID 15
 typedef struct agdiff_head_params {
   const float* w1_pk;        /* pkk [8][8] layers.0 (256->128) */
   const float* b1;           /* [128] */

@@ -66,7 +66,8 @@ def test_forward_g3(case):
         assert np.abs(g["emb_rows_after"] - g["emb_rows_before"]).max() > 1e-3
 
 
-MLP_ACTS = ["gelu", "silu", "tanh", "sigmoid", "softplus", "leaky_relu", "elu"]
+MLP_ACTS = ["gelu", "silu", "tanh", "sigmoid", "softplus", "leaky_relu", "elu", "celu", "relu6", "hardtanh", "selu", "mish", "hardswish",
+            "hardsigmoid", "softsign", "logsigmoid"]
 
 
 @pytest.mark.parametrize("act", MLP_ACTS)
