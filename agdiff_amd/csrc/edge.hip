@@ -823,10 +823,12 @@ struct AttrPolyArgs {
 // length lies in [0, cutoff] -- or in (cutoff, far_hi] when its type has a far set -- and whose type has a slot is evaluated
 // here (features once, one masked MFMA round per coefficient set present in the tile); the other rows are flagged for the
 // encoder MLP (agdiff_local_edge_rows).
-#define AG_ATTRP_WAVES 8
+#ifndef AG_ATTRP_WAVES
+#define AG_ATTRP_WAVES 16        // (one 16-wave workgroup per CU: the kernel is bound by its row stores -- 0.055 ms without them, 0.135 with, at 8
+#endif                           // waves; twice the tiles in flight drain them 6 % faster: 0.127 ms for 417 MB on the 196 k-atom batch)
 #define AG_ATTRP_MAX_SLOTS 9         // 9 x 16 KiB of coefficients in LDS
 template <int MODE>
-__global__ void __launch_bounds__(64 * AG_ATTRP_WAVES, 2) k_edge_attr_poly(AttrPolyArgs a) {
+__global__ void __launch_bounds__(64 * AG_ATTRP_WAVES, AG_ATTRP_WAVES / 4) k_edge_attr_poly(AttrPolyArgs a) {
   extern __shared__ u32x4 ag_attrp_smem[];
   lds_u32x4* wl = (lds_u32x4*)ag_attrp_smem;
   __shared__ int wg_flagged;
@@ -1356,7 +1358,7 @@ extern "C" int agdiff_local_edge_rows(const agdiff_params_t* p, const agdiff_top
   a.far_hi = a.far_slots > 0 ? p->attr_poly_far_hi : p->cutoff;
   a.two_over_far = a.far_slots > 0 ? 2.0f / (p->attr_poly_far_hi - p->cutoff) : 0.0f;
   int64_t wgs = (ctiles + AG_ATTRP_WAVES - 1) / AG_ATTRP_WAVES;
-  if (wgs > 512) wgs = 512;
+  if (wgs > (AG_ATTRP_WAVES >= 16 ? 256 : 512)) wgs = AG_ATTRP_WAVES >= 16 ? 256 : 512;
   const size_t smem = (size_t)(p->poly_num_slots + a.far_slots) * 8 * 2048;
   static std::atomic<uint64_t> attr_done{0};
   if (!ag_allow_big_lds(attr_done, (size_t)AG_ATTRP_MAX_SLOTS * 8 * 2048, k_edge_attr_poly<AG_BF3>, k_edge_attr_poly<AG_F32>,

@@ -44,7 +44,7 @@ FLOP_PER_EDGE_CFCONV = 2 * (128 * 192 + 128 * 128 + 64 * 64)     # filter MLP of
 PEAK = {"f32": 157.3, "bf16x3": 2500.0, "f16x3": 2500.0}      # dense MFMA TFLOP/s (f32-input MFMA; bf16 MFMA), MI355X_MICROARCH.md
 HBM_PEAK_GBPS = 8000.0
 MFMA_PASSES = {"f32": 1, "bf16x3": 3, "f16x3": 3}        # MFMA FLOPs issued per algorithmic FLOP
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 
 def build_batch(kind, mols, copies, seed):
