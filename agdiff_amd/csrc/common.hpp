@@ -539,7 +539,8 @@ __device__ __forceinline__ float cf_envelope(float d, float cutoff, int smooth) 
 // Operand elements of the lane's edge for the NKT k-tiles of a d-polynomial (include/agdiff_hip.h: agdiff_params_t.poly_kt;
 // host mirror: agdiff_amd/packing.py poly_features): element j of quarter q in k-tile t is
 //   phi[8 (4 t + q) + j](x) = T_{8 (4 t + q)}(x) T_j(x),   x = 2 d / cutoff - 1 in [-1, 1].
-// T_0..T_8 by the three-term recurrence, T_16 .. T_56 from the product rule 2 T_a T_b = T_{a+b} + T_{|a-b|}: ~25 VALU
+// T_0..T_8 by the three-term recurrence, T_16 .. T_56 from the product rule 2 T_a T_b = T_{a+b} + T_{|a-b|}, T_64 .. T_120 (k-tiles
+// 2, 3) by the recurrence in steps of eight: ~25 VALU
 // instructions + the operand split per k-tile, instead of a 128-wide MLP chain per edge.
 // `gmask` (1 or 0) multiplies every element: edges outside the group being evaluated contribute nothing.
 // MIXED (agdiff_params_t.poly_plan 1 at one k-tile, split modes): o[0].lo is the operand of the SECOND of two passes instead
@@ -571,7 +572,7 @@ __device__ __forceinline__ void ag_poly_features(float d, float two_over_rc, int
     asm volatile("" : "+v"(sel));
     G[0] = gmask * sel;
   }
-  if constexpr (NKT == 2) {
+  if constexpr (NKT >= 2) {
     float g4 = fmaf(g2 + g2, g2, -1.0f);           // T32
     float g5 = fmaf(g4 + g4, t8, -g3);             // T40
     float g6 = fmaf(g3 + g3, g3, -1.0f);           // T48
@@ -583,6 +584,25 @@ __device__ __forceinline__ void ag_poly_features(float d, float two_over_rc, int
     sel = (q == 3) ? g7 : sel;
     asm volatile("" : "+v"(sel));
     G[1] = gmask * sel;
+    if constexpr (NKT >= 3) {                      // T64 .. T120: T_{8 (k + 1)} = 2 T_8 T_{8 k} - T_{8 (k - 1)}
+      const float t82 = t8 + t8;
+      float lo2 = g6, lo1 = g7;
+#pragma unroll
+      for (int t = 2; t < NKT; ++t) {
+        float h0 = fmaf(t82, lo1, -lo2);
+        float h1 = fmaf(t82, h0, -lo1);
+        float h2 = fmaf(t82, h1, -h0);
+        float h3 = fmaf(t82, h2, -h1);
+        asm volatile("" : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3));
+        float s_ = h0;
+        s_ = (q == 1) ? h1 : s_;
+        s_ = (q == 2) ? h2 : s_;
+        s_ = (q == 3) ? h3 : s_;
+        asm volatile("" : "+v"(s_));
+        G[t] = gmask * s_;
+        lo2 = h2, lo1 = h3;
+      }
+    }
   }
   if constexpr (MIXED) {
     float Gsel = (q & 1) ? t8 : 1.0f;                        // T_{8 (q & 1)}: the lane's own factor in quarters 0, 1

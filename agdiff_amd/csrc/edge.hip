@@ -1302,22 +1302,25 @@ int launch_pair_head_poly(const agdiff_params_t* p, const int32_t* n_edges_dev, 
   if (wgs > 256) wgs = 256;
   const size_t smem = (size_t)(48 + 8 * p->poly_kt) * 2048;
   static std::atomic<uint64_t> attr_done{0};
-  if (!ag_allow_big_lds(attr_done, (size_t)(48 + 8 * AGDIFF_POLY_MAX_KT) * 2048, k_pair_head_poly<AG_BF3, 1>,
-                        k_pair_head_poly<AG_BF3, 2>, k_pair_head_poly<AG_F32, 1>, k_pair_head_poly<AG_F32, 2>,
-                        k_pair_head_poly<AG_H3, 1>, k_pair_head_poly<AG_H3, 2>))
+#define AG_HEADP_KERNELS(M) k_pair_head_poly<M, 1>, k_pair_head_poly<M, 2>, k_pair_head_poly<M, 3>, k_pair_head_poly<M, 4>
+  if (!ag_allow_big_lds(attr_done, (size_t)(48 + 8 * AGDIFF_POLY_MAX_KT) * 2048, AG_HEADP_KERNELS(AG_BF3), AG_HEADP_KERNELS(AG_F32),
+                        AG_HEADP_KERNELS(AG_H3)))
     return AGDIFF_ERR_LAUNCH;
+#undef AG_HEADP_KERNELS
   const dim3 grid((unsigned)wgs), block(64 * AG_PERSIST_WAVES);
   hipStream_t st = (hipStream_t)stream;
-  if (p->precision == AG_H3) {
-    if (p->poly_kt == 1) k_pair_head_poly<AG_H3, 1><<<grid, block, smem, st>>>(a);
-    else k_pair_head_poly<AG_H3, 2><<<grid, block, smem, st>>>(a);
-  } else if (p->precision == AG_BF3) {
-    if (p->poly_kt == 1) k_pair_head_poly<AG_BF3, 1><<<grid, block, smem, st>>>(a);
-    else k_pair_head_poly<AG_BF3, 2><<<grid, block, smem, st>>>(a);
-  } else {
-    if (p->poly_kt == 1) k_pair_head_poly<AG_F32, 1><<<grid, block, smem, st>>>(a);
-    else k_pair_head_poly<AG_F32, 2><<<grid, block, smem, st>>>(a);
-  }
+  auto by_terms = [&](auto MODE_) {
+    constexpr int MODE = decltype(MODE_)::value;
+    switch (p->poly_kt) {
+      case 1: k_pair_head_poly<MODE, 1><<<grid, block, smem, st>>>(a); break;
+      case 2: k_pair_head_poly<MODE, 2><<<grid, block, smem, st>>>(a); break;
+      case 3: k_pair_head_poly<MODE, 3><<<grid, block, smem, st>>>(a); break;
+      default: k_pair_head_poly<MODE, 4><<<grid, block, smem, st>>>(a); break;
+    }
+  };
+  if (p->precision == AG_H3) by_terms(std::integral_constant<int, AG_H3>{});
+  else if (p->precision == AG_BF3) by_terms(std::integral_constant<int, AG_BF3>{});
+  else by_terms(std::integral_constant<int, AG_F32>{});
   AG_CHECK_LAUNCH();
   return AGDIFF_OK;
 }

@@ -93,12 +93,12 @@ struct NodeConvShape {
   static constexpr int GRP = AG_NODE_GRP;
 #else
   static_assert(!FOUR || NKT == 1, "four waves per SIMD: one k-tile");
-  static constexpr int GRP = FOUR ? 2 : 3;
+  static constexpr int GRP = (FOUR || NKT >= 3) ? 2 : 3;
 #endif
 #ifdef AG_NODECONV_WAVES
   static constexpr int WAVES = AG_NODECONV_WAVES;
 #else
-  static constexpr int WAVES = FOUR ? 16 : 12;
+  static constexpr int WAVES = FOUR ? 16 : NKT >= 3 ? 8 : 12;       // (three / four k-tiles: 256 registers per lane)
 #endif
 };
 #ifndef AG_NODE_XD
@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
   auto ldf = [](const float* base, uint32_t byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); };
   auto ldi = [](const int32_t* base, uint32_t byte_off) { return *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(base) + byte_off); };
   // (the radius rows are written by the front kernel and read once per launch: non-temporal, so that they do not evict x rows)
-  auto ldf_nt = [](const float* base, uint32_t byte_off) { return __builtin_nontemporal_load(reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off)); };
+  [[maybe_unused]] auto ldf_nt = [](const float* base, uint32_t byte_off) { return __builtin_nontemporal_load(reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off)); };
   auto prefetch_meta = [&](int rows, bool local) {
     const uint32_t e4 = (uint32_t)(rows + col) * 4u;
     const uint32_t r16 = (uint32_t)(rows + 4 * q) * 4u;
@@ -507,7 +507,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_quad(NodeConvA
   int pf_src[4] = {0, 0, 0, 0};
   auto ldf = [](const float* base, uint32_t byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); };
   auto ldi = [](const int32_t* base, uint32_t byte_off) { return *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(base) + byte_off); };
-  auto ldf_nt = [](const float* base, uint32_t byte_off) { return __builtin_nontemporal_load(reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off)); };
+  [[maybe_unused]] auto ldf_nt = [](const float* base, uint32_t byte_off) { return __builtin_nontemporal_load(reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off)); };
   auto prefetch_local = [&](int rows) {
     const uint32_t e4 = (uint32_t)(rows + col) * 4u;
     const uint32_t r16 = (uint32_t)(rows + 4 * q) * 4u;
@@ -786,7 +786,8 @@ extern "C" int agdiff_cfconv_node(const agdiff_params_t* p, const agdiff_topo_t*
   a.poly_typed = local ? p->conv[k].filt_poly_typed_pk : nullptr;
   a.type_slot = p->poly_type_slot;
   a.num_slots = local ? p->poly_num_slots : 0;
-  // coefficient sets in LDS: the radius edges' one, then as many typed ones as fit (5 of 24 KiB at poly_kt 1, 2 of 48 KiB at 2)
+  // coefficient sets in LDS: the radius edges' one, then as many typed ones as fit (5 of 24 KiB at poly_kt 1, 2 of 48 KiB at 2, 1 of 72 KiB
+  // at 3, none beside the radius set's 96 KiB at 4)
   const size_t set_bytes = (size_t)AG_CONV_NCH * p->poly_kt * 2048;
   int max_sets = (int)(((size_t)160 * 1024) / set_bytes);
   if (p->tune_poly_lds_sets > 0 && p->tune_poly_lds_sets < max_sets) max_sets = p->tune_poly_lds_sets;
@@ -823,10 +824,17 @@ extern "C" int agdiff_cfconv_node(const agdiff_params_t* p, const agdiff_topo_t*
                          (a.lds_slots < a.num_slots ? AGDIFF_VAR_POLY_L2_SETS : 0) | (four ? AGDIFF_VAR_CFCONV_NODE_FOUR : 0) |
                          (quad ? AGDIFF_VAR_CFCONV_NODE_QUAD : 0));
   const int plan = p->poly_plan;
-  if (p->precision == AG_H3)
-    return p->poly_kt == 1 ? launch_cfconv_node_t<AG_H3, 1>(a, plan, four, quad, smem, stream) : launch_cfconv_node_t<AG_H3, 2>(a, plan, four, quad, smem, stream);
-  if (p->precision == AG_BF3)
-    return p->poly_kt == 1 ? launch_cfconv_node_t<AG_BF3, 1>(a, plan, four, quad, smem, stream) : launch_cfconv_node_t<AG_BF3, 2>(a, plan, four, quad, smem, stream);
-  return p->poly_kt == 1 ? launch_cfconv_node_t<AG_F32, 1>(a, 0, four, quad, smem, stream) : launch_cfconv_node_t<AG_F32, 2>(a, 0, four, quad, smem, stream);
+  auto by_terms = [&](auto MODE_, int pl) {
+    constexpr int MODE = decltype(MODE_)::value;
+    switch (p->poly_kt) {
+      case 1: return launch_cfconv_node_t<MODE, 1>(a, pl, four, quad, smem, stream);
+      case 2: return launch_cfconv_node_t<MODE, 2>(a, pl, four, quad, smem, stream);
+      case 3: return launch_cfconv_node_t<MODE, 3>(a, pl, four, quad, smem, stream);
+      default: return launch_cfconv_node_t<MODE, 4>(a, pl, four, quad, smem, stream);
+    }
+  };
+  if (p->precision == AG_H3) return by_terms(std::integral_constant<int, AG_H3>{}, plan);
+  if (p->precision == AG_BF3) return by_terms(std::integral_constant<int, AG_BF3>{}, plan);
+  return by_terms(std::integral_constant<int, AG_F32>{}, 0);
 }
 

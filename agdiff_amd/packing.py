@@ -143,7 +143,7 @@ def fold_bn(W, b, sd, p, eps=1e-5):
 # (interpolation at Chebyshev nodes) and ACCEPTED ONLY IF they reproduce the networks on a dense grid to `POLY_TOL` of the
 # largest value; otherwise the kernels evaluate the MLPs for every edge as before (poly_kt = 0).
 POLY_TOL = 1e-6
-POLY_MAX_KT = 2
+POLY_MAX_KT = 4          # include/agdiff_hip.h AGDIFF_POLY_MAX_KT: 32 / 64 terms for smooth checkpoints, 96 / 128 before the filter MLPs
 
 
 def poly_feature_order(kt):
@@ -186,6 +186,8 @@ def poly_features(x, K):
     G.append(2 * G[4] * T8 - G[3])            # T40
     G.append(2 * G[3] * G[3] - 1)             # T48
     G.append(2 * G[6] * T8 - G[5])            # T56
+    while len(G) < K // 8:                    # T64 .. T120 (k-tiles 2, 3): the recurrence in steps of eight
+        G.append(2 * T8 * G[-1] - G[-2])
     return np.stack([G[f // 8] * T[f % 8] for f in range(K)], axis=-1)
 
 
@@ -351,7 +353,8 @@ def poly_high_weight(c_nat, kt):
     c_f = np.empty_like(np.asarray(c_nat, dtype=np.float64))
     c_f[:, poly_feature_order(kt)] = c_nat
     scale = np.abs(poly_features(np.linspace(-1.0, 1.0, 1025), K) @ c_f.T).max()
-    return float(np.abs(c_f[:, K // 2:]).sum(1).max() / max(scale, 1e-300))
+    high = 16 if kt == 1 else 32              # (the terms plan 1 gives one pass: f >= 16 at one k-tile, every k-tile but the first else)
+    return float(np.abs(c_f[:, high:]).sum(1).max() / max(scale, 1e-300))
 
 
 def mix_units(packed, kt):
@@ -448,8 +451,8 @@ class PackedParams:
                  poly_passes="auto", attr_far=True):
         """radius_poly: "auto" -- radius edges take their filters from d-polynomials when the fit is accepted
         (radius_polynomials above), and so do the local edges, per type (ensure_local_types); "off" -- every edge goes
-        through the encoder + filter MLPs; "radius" -- polynomials for the radius edges only; "kt2" -- as "auto" but
-        starting at 64 terms (the variants exist for tests and A/B runs).
+        through the encoder + filter MLPs; "radius" -- polynomials for the radius edges only; "kt2" / "kt3" / "kt4" -- as
+        "auto" but starting at 64 / 96 / 128 terms (the variants exist for tests and A/B runs).
         poly_passes: "auto" -- one pass over the high terms of the filter polynomials when their coefficients allow it
         (poly_pass_plan); "full" -- three passes for every term."""
         import torch
@@ -458,10 +461,10 @@ class PackedParams:
         if poly_passes not in ("auto", "full"):
             raise ValueError("poly_passes must be 'auto' or 'full'")
         self.poly_passes = poly_passes
-        if radius_poly not in ("auto", "off", "radius", "kt2"):
-            raise ValueError("radius_poly must be one of 'auto', 'off', 'radius', 'kt2'")
+        if radius_poly not in ("auto", "off", "radius", "kt2", "kt3", "kt4"):
+            raise ValueError("radius_poly must be one of 'auto', 'off', 'radius', 'kt2', 'kt3', 'kt4'")
         self.poly_kt, self._poly, self.poly_errors = (0, {}, {}) if radius_poly == "off" else \
-            radius_polynomials(sd, cfg, min_kt=2 if radius_poly == "kt2" else 1)
+            radius_polynomials(sd, cfg, min_kt=int(radius_poly[2]) if radius_poly.startswith("kt") else 1)
         # local edge types with filter polynomials (ensure_local_types): type -> slot, grown as batches bring new types
         self._sd, self._cfg, self._mode = sd, cfg, PRECISIONS.get(precision, 0)
         self.local_slots, self._typed_mats = {}, {}

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 42
+#define AGDIFF_ABI_VERSION 43
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -33,7 +33,8 @@ extern "C" {
 #define AGDIFF_TILE 16             /* edges / nodes per MFMA tile */
 #define AGDIFF_MAX_CHUNK_TILES 8   /* most tiles one wave walks per chunk in the fused CFConv kernel (128 edges) */
 #define AGDIFF_RMSD_MAX_ATOMS 256  /* most (heavy) atoms per conformer in agdiff_rmsd_matrix */
-#define AGDIFF_POLY_MAX_KT 2       /* most 32-term k-tiles of the radius-edge filter polynomial (degree 63) */
+#define AGDIFF_POLY_MAX_KT 4       /* most 32-term k-tiles of the radius-edge filter polynomial (degree 127): 1, 2 what smooth
+                                      checkpoints take; 3, 4 the rungs between them and the filter MLPs for sharp ones */
 #define AGDIFF_POLY_MAX_SLOTS 16   /* most local edge types with filter polynomials; the first sets that fit stay in LDS next to the
                                       radius edges' set (5 at poly_kt 1), the others are read from L2 by the tiles that meet them */
 #define AGDIFF_RAD_STRIDE 48       /* rows reserved per target in the radius-edge list (three 16-row tiles >= AGDIFF_RADIUS_CAP) */
@@ -205,7 +206,7 @@ typedef struct agdiff_params {
                                 quarter q in k-tile t is phi[8 (4 t + q) + j], and the packed blocks are ordered to match. */
   int32_t poly_plan;         /* passes of the split arithmetic over the filter polynomials' terms in agdiff_cfconv_node (0 when
                                 precision == 0).  0: every term three passes (hi hi, lo hi, hi lo).  1: the HIGH terms -- f >= 16
-                                at poly_kt 1, f >= 32 at poly_kt 2 -- take ONE pass (hi x hi): the host sets it only when
+                                at poly_kt 1, f >= 32 at poly_kt 2..4 -- take ONE pass (hi x hi): the host sets it only when
                                   fit error + eps1 * max_out sum_{high f} |c[out][f]| <= 1e-6 of the largest filter value
                                 for the radius set and the common local types (|phi_f| <= 1; eps1 = 1.5 * 2^-10 split-fp16, 2^-7 split-bf16: the
                                 two operand roundings of a single product), agdiff_amd/packing.py poly_pass_plan.
@@ -214,7 +215,8 @@ typedef struct agdiff_params {
                                   and, for lanes 32..63, the LO elements of lane - 32 (same row, terms 8 (q - 2) + j), and the
                                   kernel's second operand is [lo(phi_f), f < 16 | hi(phi_f), f < 16]: both cross terms of the
                                   low 16 terms in one K = 32 instruction.
-                                  poly_kt 2: k-tile 0 three passes, k-tile 1 one (unit 1 of its blocks is not read). */
+                                  poly_kt >= 2: k-tile 0 three passes, the others one (unit 1 of their blocks is not read);
+                                  the high terms are then f >= 32. */
   int32_t tune_cfconv_quad_tiles;    /* [0] agdiff_cfconv_node on quads (topo->group_targets == 4): radius rows in quad tiles too -- quarter k
                                         of a tile = four rows of the quad's k-th target, one set of sums per lane, no exchange between
                                         the quarters (k_cfconv_quad); -1: every target its own radius tiles (k_cfconv_node) */

@@ -4,6 +4,7 @@ against the one-list kernels that evaluate the filter MLPs for every edge.  `rad
   auto    radius edges and every local edge type from d-polynomials (the default the other test files run)
   radius  polynomials for the radius edges only, local edges through the filter MLPs on the padded local list
   kt2     64-term expansions (two k-tiles) for radius edges and local types alike
+  kt3/kt4 96 / 128 terms: the rungs a sharp checkpoint takes before the filter MLPs
   off     one list, every edge through the encoder + filter MLPs (rounds 1-2a product path)
 plus `auto-l2`: as auto with every local type's coefficient set read from L2 instead of LDS (tune_poly_lds_sets = 1: the
 path types beyond the LDS-resident sets take), and `auto-full` / `kt2-full`: three MFMA passes for every polynomial term
@@ -17,7 +18,7 @@ import torch
 from helpers import FORWARD_CASES, check_close, load_golden, sampler_case_cfg, sampler_case_kwargs, t
 
 pytestmark = pytest.mark.gpu
-MODES = ["auto", "radius", "kt2", "off"]
+MODES = ["auto", "radius", "kt2", "kt3", "kt4", "off"]
 
 
 def _model(cfg, mode, head_scale=1e-3, precision="f16x3"):
@@ -57,13 +58,13 @@ def _variants(ws):
 
 
 def _expect(pk, mode):
-    assert pk.poly_kt == {"auto": 1, "radius": 1, "kt2": 2, "off": 0}[mode]
-    want_slots = mode in ("auto", "kt2")
+    assert pk.poly_kt == {"auto": 1, "radius": 1, "kt2": 2, "kt3": 3, "kt4": 4, "off": 0}[mode]
+    want_slots = mode == "auto" or mode.startswith("kt")
     assert (pk.struct.poly_num_slots > 0) == want_slots, (mode, pk.struct.poly_num_slots, pk.poly_errors)
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x3"])
-@pytest.mark.parametrize("mode", MODES + ["auto-full", "kt2-full"])
+@pytest.mark.parametrize("mode", MODES + ["auto-full", "kt2-full", "kt3-full", "kt4-full"])
 @pytest.mark.parametrize("case", ["g3_forward_qm9_small", "g3_forward_drugs_capped"])
 def test_forward_every_filter_mode(case, mode, precision):
     g = load_golden(case)
@@ -105,11 +106,11 @@ def test_sampler_every_filter_mode(case, mode, precision):
     V, var = _lib.DEFINES, _variants(m._batch_cache[2])
     if "lowT" in case:        # the global branch ran: which CFConv did?
         assert bool(var & V["AGDIFF_VAR_CFCONV_NODE"]) == (mode != "off") and bool(var & V["AGDIFF_VAR_CFCONV_FUSED"]) == (mode == "off")
-        assert bool(var & V["AGDIFF_VAR_CFCONV_NODE_LOCAL"]) == (mode in ("auto", "kt2"))
+        assert bool(var & V["AGDIFF_VAR_CFCONV_NODE_LOCAL"]) == (mode == "auto" or mode.startswith("kt"))
         assert bool(var & V["AGDIFF_VAR_CFCONV_LOCAL_MLP"]) == (mode == "radius" or mixed)
         if mixed:
             assert 23 in m.packed().poly_refused_types and 23 not in m.packed().local_slots and m.packed().struct.poly_num_slots > 0
-        if mode != "kt2":     # (two-k-tile sets are 48 KiB: two typed ones fit next to the radius edges', the rest come from L2)
+        if not mode.startswith("kt"):     # (two-k-tile sets are 48 KiB: two typed ones fit next to the radius edges', the rest come from L2)
             assert bool(var & V["AGDIFF_VAR_POLY_L2_SETS"]) == l2
     check_close("poly[%s] traj[%s]" % (mode, case), torch.stack(traj).numpy(), g["traj"], precision)
     check_close("poly[%s] pos[%s]" % (mode, case), pos.cpu().numpy(), g["pos_final"], precision)
@@ -208,7 +209,8 @@ def test_node_cfconv_equals_one_list_kernel(kind, mols, copies, gt):
 
 @pytest.mark.parametrize("passes", ["auto", "full"])
 @pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x3"])
-@pytest.mark.parametrize("kind,mols,copies,mode", [("drugs", 3, 6, "auto"), ("qm9", 5, 9, "auto"), ("drugs", 2, 5, "kt2")])
+@pytest.mark.parametrize("kind,mols,copies,mode", [("drugs", 3, 6, "auto"), ("qm9", 5, 9, "auto"), ("drugs", 2, 5, "kt2"),
+                                                   ("drugs", 2, 5, "kt3")])
 def test_cfconv_node_shapes_agree_bitwise(kind, mols, copies, mode, precision, passes):
     """agdiff_cfconv_node has two shapes at one k-tile (csrc/nodeconv.hip NodeConvShape): 12-wave workgroups with groups of three
     channel tiles, and -- from tune_cfconv_four_min_quads quads on -- 16-wave workgroups at 128 VGPRs with groups of two (two
@@ -292,15 +294,53 @@ def test_sharper_first_layer_takes_64_terms_at_bench_scale(precision):
     check_close("sharper_first_layer_kt2 sampler", got.cpu().numpy(), ref.numpy(), precision)
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x3"])
+@pytest.mark.parametrize("kind,scale,terms", [("qm9", 40.0, 96), ("qm9", 100.0, 128), ("drugs", 32.0, 96)])
+def test_sharp_first_layer_takes_the_96_and_128_term_rungs(kind, scale, terms, precision):
+    """between the 64-term sets (first layer up to ~24 x the synthetic checkpoint's) and the filter MLPs there are
+    two more rungs -- 96 and 128 terms (k-tiles 2, 3: T_64 .. T_120 by the recurrence in steps of eight; 8-wave workgroups at 256
+    registers; 72- / 96-KiB sets, so one typed set or none stays in LDS and the others come from L2).  A first layer 32 .. 100 x
+    sharper is accepted there in mode `auto`, for the radius edges and every local type, and four denoising steps match the
+    oracle."""
+    from agdiff_amd import _lib, drugs_model_config, get_model, qm9_model_config, synth
+    from oracle import agdiff_oracle as O
+    cfg = (qm9_model_config if kind == "qm9" else drugs_model_config)(num_diffusion_timesteps=30, beta_end=2e-5)
+    sd = O.synth_state_dict_for(cfg)
+    for k in ("edge_encoder_global.feature_expansion.weight", "model_global.0.feature_expansion.weight"):
+        sd[k] = sd[k] * scale
+    m = get_model(cfg)
+    m.precision = precision
+    m.load_state_dict({k: v.clone() for k, v in sd.items()})
+    m = m.to("cuda:0").eval()
+    b = synth.make_packed_batch(kind, 3, 6, seed=17)
+    at, bi, bt, ba = [t(b[k]) for k in ("atom_type", "bond_index", "bond_type", "batch")]
+    g = torch.Generator().manual_seed(5)
+    pos_init, noise = torch.randn(at.shape[0], 3, generator=g), torch.randn(4, at.shape[0], 3, generator=g)
+    kw = dict(extend_order=False, n_steps=4, w_global=1.0, global_start_sigma=0.5, clip=1000.0)
+    key = ("rungs", kind, scale)
+    if key not in _ORACLE_RESULTS:
+        _ORACLE_RESULTS[key] = O.langevin_dynamics_sample_diffusion(sd, cfg, at, pos_init, bi, bt, ba, b["num_graphs"], noise=noise, **kw)[0]
+    ref = _ORACLE_RESULTS[key]
+    got, _ = m.langevin_dynamics_sample_diffusion(at.cuda(), pos_init.cuda(), bi.cuda(), bt.cuda(), ba.cuda(),
+                                                  b["num_graphs"], noise=noise.cuda(), **kw)
+    pk, var, V = m.packed(), _variants(m._batch_cache[2]), _lib.DEFINES
+    kt = terms // 32
+    assert pk.poly_kt == kt and pk.poly_errors[kt - 1] > 1e-6 >= pk.poly_errors[kt], pk.poly_errors
+    assert pk.struct.poly_num_slots == len(m._batch_cache[1].local_types) and not pk.poly_refused_types
+    assert var & V["AGDIFF_VAR_CFCONV_NODE_LOCAL"] and var & V["AGDIFF_VAR_HEAD_POLY"] and var & V["AGDIFF_VAR_POLY_L2_SETS"]
+    assert not var & (V["AGDIFF_VAR_CFCONV_LOCAL_MLP"] | V["AGDIFF_VAR_CFCONV_FUSED"])
+    check_close("sharp_first_layer_%d_terms[%s] sampler" % (terms, kind), got.cpu().numpy(), ref.numpy(), precision)
+
+
 def test_rejected_fit_falls_back_to_the_mlps():
-    """A first layer too sharp for 64 terms at 1e-6: the polynomials are refused at load time and every edge goes through
+    """A first layer too sharp for 128 terms at 1e-6: the polynomials are refused at load time and every edge goes through
     the encoder + filter MLPs; results still match the oracle."""
     from agdiff_amd import get_model, qm9_model_config, synth
     from oracle import agdiff_oracle as O
     cfg = qm9_model_config(num_diffusion_timesteps=30, beta_end=2e-5)
     sd = O.synth_state_dict_for(cfg)
     for k in ("edge_encoder_global.feature_expansion.weight", "model_global.0.feature_expansion.weight"):
-        sd[k] = sd[k] * 40.0
+        sd[k] = sd[k] * 400.0
     m = get_model(cfg)
     m.load_state_dict({k: v.clone() for k, v in sd.items()})
     m = m.to("cuda:0").eval()

@@ -381,13 +381,32 @@ def test_sharp_networks_need_more_terms_or_are_refused():
     sd = O.synth_state_dict_for(cfg)
     base = sd["edge_encoder_global.feature_expansion.weight"].clone()
     seen = set()
-    for scale in (1.0, 12.0, 40.0):
+    for scale in (1.0, 12.0, 40.0, 100.0, 400.0):
         sd["edge_encoder_global.feature_expansion.weight"] = base * scale
         kt, mats, errs = packing.radius_polynomials(sd, cfg)
         assert (kt == 0) == (min(errs.values()) > packing.POLY_TOL)
-        assert kt == 0 or errs[kt] <= packing.POLY_TOL
+        assert kt == 0 or (errs[kt] <= packing.POLY_TOL and all(errs[k] > packing.POLY_TOL for k in range(1, kt)))
+        assert kt == 0 or all(m.shape[1] == 32 * kt for m in mats.values())
         seen.add(kt)
-    assert 1 in seen and 0 in seen          # smooth weights: 32 terms; a 40x sharper first layer: refused
+    # smooth weights: 32 terms; 12 x: 64; 40 x: 96; 100 x: 128 (the two rungs of round 6); 400 x: refused -> the filter MLPs
+    assert seen == {1, 2, 3, 4, 0}, seen
+
+
+def test_polynomial_features_beyond_64_terms_span_the_chebyshev_basis():
+    """poly_features for K = 96, 128 (T_64 .. T_120 by the recurrence in steps of eight, as csrc/common.hpp ag_poly_features) are
+    the products T_{8 g} T_j they claim to be, and poly_basis_matrix maps them onto T_0 .. T_{K-1}."""
+    from agdiff_amd import packing
+    x = np.cos(np.linspace(0.0, np.pi, 257))
+    for K in (96, 128):
+        phi = packing.poly_features(x, K)
+        th = np.arccos(np.clip(x, -1, 1))
+        for f in (0, 7, 63, 64, 71, 95, K - 8, K - 1):
+            g, j = divmod(f, 8)
+            assert np.abs(phi[:, f] - np.cos(8 * g * th) * np.cos(j * th)).max() < 1e-9, (K, f)
+        cheb = np.stack([np.cos(n * th) for n in range(K)], axis=-1)
+        assert np.abs(cheb @ packing.poly_basis_matrix(K) - phi).max() < 1e-9
+        order = packing.poly_feature_order(K // 32)
+        assert sorted(order.tolist()) == list(range(K))
 
 
 def test_group_order_is_a_permutation_and_beats_the_plain_sort():
