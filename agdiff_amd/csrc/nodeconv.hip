@@ -87,7 +87,7 @@ struct NodeConvArgs {
 // Small launches (fewer than two quads per wave of a full grid: tune_cfconv_four_min_quads) keep the 12-wave shape: more
 // workgroups for the same quads (23 k atoms: even; 4 k atoms: 12 waves 3 % ahead).  -DAG_NODE_GRP / -DAG_NODECONV_WAVES force one
 // shape on every instantiation (A/B builds).
-template <int NKT, bool FOUR>
+template <int NKT, bool FOUR, int PLAN = 0>
 struct NodeConvShape {
 #ifdef AG_NODE_GRP
   static constexpr int GRP = AG_NODE_GRP;
@@ -99,6 +99,7 @@ struct NodeConvShape {
   static constexpr int WAVES = AG_NODECONV_WAVES;
 #else
   static constexpr int WAVES = FOUR ? 16 : NKT >= 3 ? 8 : 12;       // (three / four k-tiles: 256 registers per lane)
+  static_assert(PLAN >= 0 && PLAN <= 2, "poly_plan");
 #endif
 };
 #ifndef AG_NODE_XD
@@ -124,7 +125,11 @@ struct NodeConvShape {
 #endif
 // PLAN (agdiff_params_t.poly_plan): 0 three passes for every term; 1 one pass for the high terms, whose coefficients the
 // host has bounded -- at NKT 1 two MFMAs per channel tile (hi x hi of all 32 terms, then both cross terms of terms 0..15 in
-// one instruction: ag_poly_features<.., true> / the mixed unit 1 of the blocks), at NKT 2 k-tile 1 by its hi x hi pass alone.
+// one instruction: ag_poly_features<.., true> / the mixed unit 1 of the blocks), at NKT >= 2 every k-tile but the first by its hi x hi
+// pass alone; 2 (NKT >= 3: sharp networks, whose terms 32..63 still carry weight) the same from k-tile 2 on.
+// (k-tile t of a set takes all passes of the split arithmetic, or the hi x hi pass alone)
+__host__ __device__ constexpr bool ag_plan_full(int plan, int t) { return plan == 0 || t == 0 || (plan == 2 && t == 1); }
+
 template <int MODE, int NKT, int WAVES, int PLAN, int GRP>
 __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvArgs a) {
   static_assert(PLAN == 0 || MODE != AG_F32, "poly_plan needs a split mode");
@@ -252,12 +257,12 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvA
 #pragma unroll
       for (int t = 0; t < NKT; ++t) {
         w[j][t][0] = base[(((C0 + j) * NKT + t) * 2) * 64];
-        if (PLAN == 0 || t == 0) w[j][t][1] = base[(((C0 + j) * NKT + t) * 2 + 1) * 64];
+        if (ag_plan_full(PLAN, t)) w[j][t][1] = base[(((C0 + j) * NKT + t) * 2 + 1) * 64];
       }
     }
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
-      const int parts = (PLAN == 0) ? AgParts<MODE>::n : MIXED ? 2 : (t == 0) ? AgParts<MODE>::n : 1;
+      const int parts = MIXED ? 2 : ag_plan_full(PLAN, t) ? AgParts<MODE>::n : 1;
 #pragma unroll
       for (int part = 0; part < parts; ++part) {
 #pragma unroll
@@ -576,7 +581,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_quad(NodeConvA
 #pragma unroll
       for (int t = 0; t < NKT; ++t) {
         w[j][t][0] = base[(((C0 + j) * NKT + t) * 2) * 64];
-        if (PLAN == 0 || t == 0) w[j][t][1] = base[(((C0 + j) * NKT + t) * 2 + 1) * 64];
+        if (ag_plan_full(PLAN, t)) w[j][t][1] = base[(((C0 + j) * NKT + t) * 2 + 1) * 64];
       }
     }
   };
@@ -587,7 +592,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_quad(NodeConvA
     constexpr int C0 = GRP * decltype(GG)::value;
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
-      const int parts = (PLAN == 0) ? AgParts<MODE>::n : MIXED ? 2 : (t == 0) ? AgParts<MODE>::n : 1;
+      const int parts = MIXED ? 2 : ag_plan_full(PLAN, t) ? AgParts<MODE>::n : 1;
 #pragma unroll
       for (int part = 0; part < parts; ++part) {
 #pragma unroll
@@ -739,7 +744,7 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_quad(NodeConvA
 
 template <int MODE, int NKT, int PLAN, bool FOUR, bool QUAD>
 int launch_cfconv_node_s(const NodeConvArgs& a, size_t smem, void* stream) {
-  using Shape = NodeConvShape<NKT, FOUR>;
+  using Shape = NodeConvShape<NKT, FOUR, PLAN>;
   constexpr int WAVES = Shape::WAVES;
   static std::atomic<uint64_t> attr_done{0};
   auto kern = QUAD ? k_cfconv_quad<MODE, NKT, WAVES, PLAN, Shape::GRP> : k_cfconv_node<MODE, NKT, WAVES, PLAN, Shape::GRP>;
@@ -763,6 +768,9 @@ template <int MODE, int NKT>
 int launch_cfconv_node_t(const NodeConvArgs& a, int plan, bool four, bool quad, size_t smem, void* stream) {
   if constexpr (MODE != AG_F32) {
     if (plan == 1) return launch_cfconv_node_p<MODE, NKT, 1>(a, four, quad, smem, stream);
+    if constexpr (NKT >= 3) {
+      if (plan == 2) return launch_cfconv_node_p<MODE, NKT, 2>(a, four, quad, smem, stream);
+    }
   }
   return launch_cfconv_node_p<MODE, NKT, 0>(a, four, quad, smem, stream);
 }
@@ -772,7 +780,8 @@ extern "C" int agdiff_cfconv_node(const agdiff_params_t* p, const agdiff_topo_t*
                                   void* stream) {
   if (!p || !topo || !ws || k < 0 || k >= p->num_convs) return AGDIFF_ERR_ARG;
   if (p->poly_kt < 1 || p->poly_kt > AGDIFF_POLY_MAX_KT || !p->conv[k].filt_poly_pk) return AGDIFF_ERR_ARG;
-  if (p->poly_plan < 0 || p->poly_plan > 1 || (p->poly_plan && p->precision == AG_F32)) return AGDIFF_ERR_ARG;
+  if (p->poly_plan < 0 || p->poly_plan > 2 || (p->poly_plan && p->precision == AG_F32) || (p->poly_plan == 2 && p->poly_kt < 3))
+    return AGDIFF_ERR_ARG;
   if (!(p->conv[k].filt_poly_unscale > 0.0f)) return AGDIFF_ERR_ARG;
   if (!ws->rad_cnt || !ws->rad_src || !ws->rad_len || !ws->r_scale || !ws->xs || !ws->agg || !topo->quad_tgt ||
       topo->num_quads <= 0 || (topo->group_targets != 4 && topo->group_targets != 2 && topo->group_targets != 1))

@@ -346,14 +346,16 @@ POLY_COEF_TARGET = 128.0        # split-fp16: coefficients are stored times 2^S 
 POLY_COEF_LIMIT = 32768.0       # ... and a typed set must stay below this at the same S
 
 
-def poly_high_weight(c_nat, kt):
-    """max over outputs of sum_{high f} |c[out][f]| relative to the largest value the polynomials take on [0, cutoff]
-    (|phi_f| <= 1): c_nat [out, 32 kt] in natural packed column order (fit_type)."""
+def poly_high_weight(c_nat, kt, high=None):
+    """max over outputs of sum_{f >= high} |c[out][f]| relative to the largest value the polynomials take on [0, cutoff]
+    (|phi_f| <= 1): c_nat [out, 32 kt] in natural packed column order (fit_type).  `high`: the first term plan 1 gives one pass
+    (default: 16 at one k-tile, 32 else); 64 for plan 2."""
     K = 32 * kt
     c_f = np.empty_like(np.asarray(c_nat, dtype=np.float64))
     c_f[:, poly_feature_order(kt)] = c_nat
     scale = np.abs(poly_features(np.linspace(-1.0, 1.0, 1025), K) @ c_f.T).max()
-    high = 16 if kt == 1 else 32              # (the terms plan 1 gives one pass: f >= 16 at one k-tile, every k-tile but the first else)
+    if high is None:
+        high = 16 if kt == 1 else 32          # (the terms plan 1 gives one pass: f >= 16 at one k-tile, every k-tile but the first else)
     return float(np.abs(c_f[:, high:]).sum(1).max() / max(scale, 1e-300))
 
 
@@ -454,12 +456,12 @@ class PackedParams:
         through the encoder + filter MLPs; "radius" -- polynomials for the radius edges only; "kt2" / "kt3" / "kt4" -- as
         "auto" but starting at 64 / 96 / 128 terms (the variants exist for tests and A/B runs).
         poly_passes: "auto" -- one pass over the high terms of the filter polynomials when their coefficients allow it
-        (poly_pass_plan); "full" -- three passes for every term."""
+        (poly_pass_plan); "full" -- three passes for every term; "from64" -- as "auto" without plan 1 (tests of plan 2)."""
         import torch
         self.device = device
         self.attr_far = bool(attr_far)  # False keeps the encoder MLP for local edges beyond the cutoff (tests, A/B runs)
-        if poly_passes not in ("auto", "full"):
-            raise ValueError("poly_passes must be 'auto' or 'full'")
+        if poly_passes not in ("auto", "full", "from64"):
+            raise ValueError("poly_passes must be 'auto', 'full' or 'from64'")
         self.poly_passes = poly_passes
         if radius_poly not in ("auto", "off", "radius", "kt2", "kt3", "kt4"):
             raise ValueError("radius_poly must be one of 'auto', 'off', 'radius', 'kt2', 'kt3', 'kt4'")
@@ -717,36 +719,52 @@ class PackedParams:
         if self.poly_kt >= 1:
             self._pack_filter_sets()
 
+    def _bound(self, mats, plan):
+        """POLY_EPS1 x the weight of the terms `plan` gives one pass (1: f >= 16 at one k-tile, f >= 32 else; 2: f >= 64)."""
+        high = 64 if plan == 2 else None
+        return POLY_EPS1[self._mode] * max(poly_high_weight(mats["conv%d.filt_poly_pk" % k], self.poly_kt, high)
+                                           for k in range(self._cfg.num_convs))
+
     def _set_bound(self, name, mats):
+        """The one-pass bound of a set under the model's plan (kept in poly_high_bound)."""
         if name not in self.poly_high_bound:
-            self.poly_high_bound[name] = POLY_EPS1[self._mode] * max(poly_high_weight(mats["conv%d.filt_poly_pk" % k], self.poly_kt)
-                                                                      for k in range(self._cfg.num_convs))
+            self.poly_high_bound[name] = self._bound(mats, max(self.poly_pass_plan(), 1))
         return self.poly_high_bound[name]
 
     def poly_pass_plan(self):
-        """agdiff_params_t.poly_plan, decided ONCE per model: 1 when, for the radius set and for each of POLY_PLAN_TYPES whose
-        fit is accepted at all, fit error + POLY_EPS1[mode] * (weight of the high terms) <= POLY_TOL; self.poly_high_bound
-        records the second summand per set.  (Until round 4 the plan followed the types met so far and could flip mid-process.)"""
+        """agdiff_params_t.poly_plan, decided ONCE per model: the first of 1, 2 (2 only from three k-tiles on) for which the radius
+        set and each of POLY_PLAN_TYPES whose fit is accepted at all satisfy fit error + POLY_EPS1[mode] * (weight of the terms that
+        plan gives one pass) <= POLY_TOL, else 0; self.poly_high_bound records the second summand per set under the plan taken (under
+        plan 1 when none is).  (Until round 4 the plan followed the types met so far and could flip mid-process.)"""
         if self._plan_fixed is not None:
             return self._plan_fixed
         plan = 0
-        if self._mode in POLY_EPS1 and self.poly_kt >= 1 and self.poly_passes == "auto":
-            ok = self.poly_errors[self.poly_kt] + self._set_bound("radius", self._poly) <= POLY_TOL
-            if ok and self._typed_ok:
-                for t in POLY_PLAN_TYPES:
-                    if t in self.poly_refused_types:
-                        continue
-                    mats, err = fit_type(self._sd, self._cfg, t, self.poly_kt, False)
-                    if err <= POLY_TOL:
-                        ok = ok and err + self._set_bound("type%d" % t, mats) <= POLY_TOL
-            plan = 1 if ok else 0
+        if self._mode in POLY_EPS1 and self.poly_kt >= 1 and self.poly_passes != "full":
+            first = None
+            cands = (1, 2) if self.poly_kt >= 3 else (1,)
+            for cand in (cands[1:] if self.poly_passes == "from64" else cands):
+                bounds = {"radius": self._bound(self._poly, cand)}
+                ok = self.poly_errors[self.poly_kt] + bounds["radius"] <= POLY_TOL
+                if ok and self._typed_ok:
+                    for t in POLY_PLAN_TYPES:
+                        if t in self.poly_refused_types:
+                            continue
+                        mats, err = fit_type(self._sd, self._cfg, t, self.poly_kt, False)
+                        if err <= POLY_TOL:
+                            bounds["type%d" % t] = self._bound(mats, cand)
+                            ok = ok and err + bounds["type%d" % t] <= POLY_TOL
+                first = first or bounds
+                if ok:
+                    plan, first = cand, bounds
+                    break
+            self.poly_high_bound.update(first or {})
         self._plan_fixed = plan
         return plan
 
     def _type_fits_plan(self, t, mats, err):
         """Whether a local type's accepted fit can join the sets already packed: under plan 1 its own one-pass bound must hold,
         and in split-fp16 its coefficients must stay in range at the model's scale 2^S."""
-        if self.poly_pass_plan() == 1 and err + self._set_bound("type%d" % t, mats) > POLY_TOL:
+        if self.poly_pass_plan() >= 1 and err + self._set_bound("type%d" % t, mats) > POLY_TOL:
             return False
         if self._mode == 2:
             for k in range(self._cfg.num_convs):

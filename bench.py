@@ -44,6 +44,18 @@ FLOP_PER_EDGE_CFCONV = 2 * (128 * 192 + 128 * 128 + 64 * 64)     # filter MLP of
 PEAK = {"f32": 157.3, "bf16x3": 2500.0, "f16x3": 2500.0}      # dense MFMA TFLOP/s (f32-input MFMA; bf16 MFMA), MI355X_MICROARCH.md
 HBM_PEAK_GBPS = 8000.0
 MFMA_PASSES = {"f32": 1, "bf16x3": 3, "f16x3": 3}        # MFMA FLOPs issued per algorithmic FLOP
+
+
+def mfma_per_channel_tile(kt, plan, passes):
+    """MFMAs k_cfconv_quad issues per 16-channel tile of a 16-row tile (agdiff_params_t.poly_kt k-tiles, poly_plan): plan 0 every
+    k-tile all passes; plan 1 two instructions at one k-tile, else all passes for k-tile 0 and one for the others; plan 2 (three
+    k-tiles and more) all passes for k-tiles 0 and 1."""
+    if not plan:
+        return kt * passes
+    if plan == 1:
+        return 2 if kt == 1 else passes + (kt - 1)
+    return 2 * passes + (kt - 2)
+
 PROFILE_ROUND = "r06"
 
 
@@ -416,7 +428,7 @@ def main():
     ap.add_argument("--breakdown", default=None, help="write per-op timings (ms) to this JSON file")
     ap.add_argument("--seed", type=int, default=2021)
     ap.add_argument("--precision", default="f16x3", choices=["f32", "bf16x3", "f16x3"])
-    ap.add_argument("--radius-poly", default="auto", choices=["auto", "radius", "kt2", "off"],
+    ap.add_argument("--radius-poly", default="auto", choices=["auto", "radius", "kt2", "kt3", "kt4", "off"],
                     help="filter polynomials (agdiff_amd/packing.py): off = every edge through the encoder + filter MLPs")
     ap.add_argument("--poly-passes", default="auto", choices=["auto", "full"],
                     help="MFMA passes over the filter polynomials' high terms: auto = one when the host's bound allows it "
@@ -503,12 +515,12 @@ def main():
 
     # The measured path never touches oracle/: the synthetic checkpoint comes from the product-side closed-form
     # filler (agdiff_amd/synth.py; the oracle fills its own copy with the same function in the cpu_baseline leg).
-    def make_model(schedule, radius_poly=None, weights="filler"):
+    def make_model(schedule, radius_poly=None, weights="filler", poly_passes=None):
         cfg = make_cfg(kind, schedule)
         m = get_model(cfg)
         m.precision = args.precision
         m.radius_poly = radius_poly or args.radius_poly
-        m.poly_passes = args.poly_passes
+        m.poly_passes = poly_passes or args.poly_passes
         m.attr_far_rows = not args.no_attr_far
         m.fused_front, m.front_split_graph = args.front != "unfused", args.front == "split"
         m.step_graphs = {"auto": "auto", "on": True, "off": False}[args.step_graphs]
@@ -618,9 +630,17 @@ def main():
     ws, topo, pk = run.ws, run.topo, run.pk
     stream = _lib.stream_ptr()
     E = live_edges(run)
-    poly_info = {"mode": args.radius_poly, "poly_kt": pk.poly_kt, "local_type_slots": int(pk.struct.poly_num_slots),
+    # (edges whose CFConv filters come from the filter MLPs: all of them without polynomials, else the local edges of types without a
+    # coefficient set; E counts radius + local edges)
+    if pk.poly_kt == 0:
+        mlp_edges = E
+    else:
+        slotted = torch.tensor(sorted(pk.local_slots), dtype=torch.int32, device=topo.loc_type.device)
+        mlp_edges = int((~torch.isin(topo.loc_type, slotted)).sum().item()) if topo.L else 0
+    poly_info = {"mode": args.radius_poly, "poly_kt": pk.poly_kt, "terms": 32 * pk.poly_kt, "local_type_slots": int(pk.struct.poly_num_slots),
                  "pass_plan": int(pk.poly_plan), "one_pass_bound_of_high_terms": {k: float(v) for k, v in pk.poly_high_bound.items()},
-                 "cfconv_waves_per_simd": 4 if (int(ws.variant_log.item()) & _lib.DEFINES["AGDIFF_VAR_CFCONV_NODE_FOUR"]) else 3,
+                 "edges_through_filter_mlps_frac": mlp_edges / max(E, 1),
+                 "cfconv_waves_per_simd": 4 if (int(ws.variant_log.item()) & _lib.DEFINES["AGDIFF_VAR_CFCONV_NODE_FOUR"]) else (2 if pk.poly_kt >= 3 else 3),
                  "fit_errors_vs_float64_networks": {str(k): v for k, v in pk.poly_errors.items()}}
     roof = None
     P_, T_, W_ = ctypes.byref(pk.struct), ctypes.byref(topo.struct), ctypes.byref(ws.struct)
@@ -658,8 +678,8 @@ def main():
             # target's / a type's last tile are executed too and reported beside it, as is the reference-priced figure of rounds 1-3.
             tiles = pads_info["tiles_per_launch"] if pads_info else None
             # MFMAs per 16-channel tile and 16 rows: poly_kt k-tiles x passes; with the pass plan (agdiff_params_t.poly_plan 1) two
-            # at 32 terms (hi x hi of all terms + both cross terms of the low 16 in one instruction), 3 + 1 at 64
-            mfma_ct = pk.poly_kt * passes if not pk.poly_plan else (2 if pk.poly_kt == 1 else 4)
+            # at 32 terms (hi x hi of all terms + both cross terms of the low 16 in one instruction), 3 + 1 at 64 (mfma_per_channel_tile)
+            mfma_ct = mfma_per_channel_tile(pk.poly_kt, pk.poly_plan, passes)
             issued = prof_edges * 192 * 32 * 2 * mfma_ct / t_s / 1e12
             executed = issued * (pads_info["rows_executed"] / max(pads_info["rows_live"], 1) if pads_info else 1.0)
             kernel = ("%s<NKT=%d> (one launch per InteractionBlock: radius rows %s%s)"
@@ -868,7 +888,7 @@ def main():
                             "%d packed batches of <= %d atoms, every 4th timed (2 warm-up + 10 steps), saturated schedule" % (G_all, len(bq), args.max_atoms),
                 "value": Gl / (tms * JOB_STEPS / 1e3), "unit": "conformers/s", "ms_per_step_timed_batches": tms, "batches_timed": nb,
                 "cfconv_avg_launch_ms": (pms / pn) if pn else None,
-                "cfconv_mfma_frac": (pe * 192 * 32 * 2 * ((mq.packed().poly_kt * passes) if not mq.packed().poly_plan else (2 if mq.packed().poly_kt == 1 else 4))
+                "cfconv_mfma_frac": (pe * 192 * 32 * 2 * mfma_per_channel_tile(mq.packed().poly_kt, mq.packed().poly_plan, passes)
                                      / (pms * 1e-3) / 1e12 / PEAK[args.precision]) if pn else None}
 
     extra, value_full_job = None, None
@@ -914,6 +934,14 @@ def main():
             extra["filter_polynomials_64_terms"] = {"value": v, "unit": "conformers/s", "ms_per_step": ms4, "steps": Ke,
                                                     "batches": nb, "fraction_of_headline": v / value}
             del m4
+            # ... and the two rungs below it, with the pass plans the sharp checkpoints of tools/sharpness_sweep.py take there: 96 terms
+            # (first layer ~32 x sharper) one pass from term 64 on, 128 terms (~64 x) three passes for every term
+            for terms, rp, pp in ((96, "kt3", "from64"), (128, "kt4", "full")):
+                m5, cfg5 = make_model(args.schedule, radius_poly=rp, poly_passes=pp if args.poly_passes == "auto" else None)
+                v, ms5, gf5, nb = side_run(m5, cfg5, args.schedule, skip)
+                extra["filter_polynomials_%d_terms" % terms] = {"value": v, "unit": "conformers/s", "ms_per_step": ms5, "steps": Ke, "batches": nb,
+                                                                "pass_plan": int(m5.packed().poly_plan), "fraction_of_headline": v / value}
+                del m5
         if d200 and not use_dist and not args.no_gather_extra:
             # cost of north_star's per-step collective on this box: the same batches with a one-rank RCCL group and the
             # all-gather of [positions | NaN flag] issued after every step (what every rank of a multi-GPU run does)

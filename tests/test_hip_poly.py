@@ -8,7 +8,8 @@ against the one-list kernels that evaluate the filter MLPs for every edge.  `rad
   off     one list, every edge through the encoder + filter MLPs (rounds 1-2a product path)
 plus `auto-l2`: as auto with every local type's coefficient set read from L2 instead of LDS (tune_poly_lds_sets = 1: the
 path types beyond the LDS-resident sets take), and `auto-full` / `kt2-full`: three MFMA passes for every polynomial term
-(model.poly_passes = "full"; the other split-mode runs take one pass for the high terms: agdiff_params_t.poly_plan 1)."""
+(model.poly_passes = "full"; the other split-mode runs take one pass for the high terms: agdiff_params_t.poly_plan 1; `-from64`:
+plan 2, one pass from term 64 on)."""
 import ctypes
 
 import numpy as np
@@ -64,18 +65,19 @@ def _expect(pk, mode):
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x3"])
-@pytest.mark.parametrize("mode", MODES + ["auto-full", "kt2-full", "kt3-full", "kt4-full"])
+@pytest.mark.parametrize("mode", MODES + ["auto-full", "kt2-full", "kt3-full", "kt4-full", "kt3-from64", "kt4-from64"])
 @pytest.mark.parametrize("case", ["g3_forward_qm9_small", "g3_forward_drugs_capped"])
 def test_forward_every_filter_mode(case, mode, precision):
     g = load_golden(case)
-    full = mode.endswith("-full")
-    mode = mode[:-5] if full else mode
+    full, from64 = mode.endswith("-full"), mode.endswith("-from64")
+    mode = mode.split("-")[0] if (full or from64) else mode
     m = _model(FORWARD_CASES[case](), mode, precision=precision)
-    m.poly_passes = "full" if full else "auto"
+    m.poly_passes = "full" if full else "from64" if from64 else "auto"
     out = m(t(g["atom_type"]).cuda(), t(g["pos"]).cuda(), t(g["bond_index"]).cuda(), t(g["bond_type"]).cuda(),
             t(g["batch"]).cuda(), None, return_edges=True, extend_order=False)
     _expect(m.packed(), mode)
-    assert m.packed().struct.poly_plan == (1 if (mode != "off" and precision != "f32" and not full) else 0), m.packed().poly_high_bound
+    # (plan 2 -- one pass from term 64 on -- is what a sharp network takes at three / four k-tiles; forced here on the smooth one)
+    assert m.packed().struct.poly_plan == ((2 if from64 else 1) if (mode != "off" and precision != "f32" and not full) else 0), m.packed().poly_high_bound
     ws = m._batch_cache[2]
     assert np.array_equal(out[2].cpu().numpy(), g["edge_index"]) and np.array_equal(out[3].cpu().numpy(), g["edge_type"])
     if "schnet_out" in g:
@@ -294,20 +296,35 @@ def test_sharper_first_layer_takes_64_terms_at_bench_scale(precision):
     check_close("sharper_first_layer_kt2 sampler", got.cpu().numpy(), ref.numpy(), precision)
 
 
+def _sharpen(sd, scale, bounded):
+    """The encoder's first layer `scale` times sharper.  Plain: its weight times `scale` (the network's values grow with it).
+    Bounded: weight and bias times `scale`, the next layer's columns that read its outputs divided by it -- gelu(s u) / s: kinks
+    `scale` times sharper at unchanged magnitudes, the shape a trained network's sharp features would have."""
+    for e in ("edge_encoder_global", "model_global.0"):
+        sd[e + ".feature_expansion.weight"] = sd[e + ".feature_expansion.weight"] * scale
+        if bounded:
+            n = sd[e + ".feature_expansion.weight"].shape[0]
+            sd[e + ".feature_expansion.bias"] = sd[e + ".feature_expansion.bias"] * scale
+            w = sd[e + ".edge_feature_mlp.0.weight"].clone()
+            w[:, :n] = w[:, :n] / scale
+            sd[e + ".edge_feature_mlp.0.weight"] = w
+    return sd
+
+
 @pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x3"])
-@pytest.mark.parametrize("kind,scale,terms", [("qm9", 40.0, 96), ("qm9", 100.0, 128), ("drugs", 32.0, 96)])
+@pytest.mark.parametrize("kind,scale,terms", [("qm9", 40.0, 96), ("qm9", 100.0, 128), ("drugs", 32.0, 96), ("drugs-bounded", 32.0, 96),
+                                              ("drugs-bounded", 64.0, 128)])
 def test_sharp_first_layer_takes_the_96_and_128_term_rungs(kind, scale, terms, precision):
     """between the 64-term sets (first layer up to ~24 x the synthetic checkpoint's) and the filter MLPs there are
     two more rungs -- 96 and 128 terms (k-tiles 2, 3: T_64 .. T_120 by the recurrence in steps of eight; 8-wave workgroups at 256
     registers; 72- / 96-KiB sets, so one typed set or none stays in LDS and the others come from L2).  A first layer 32 .. 100 x
     sharper is accepted there in mode `auto`, for the radius edges and every local type, and four denoising steps match the
-    oracle."""
+    oracle -- with the plain scaling (whose values grow with the scale) and with the bounded one (_sharpen)."""
     from agdiff_amd import _lib, drugs_model_config, get_model, qm9_model_config, synth
     from oracle import agdiff_oracle as O
+    bounded, kind = kind.endswith("-bounded"), kind.split("-")[0]
     cfg = (qm9_model_config if kind == "qm9" else drugs_model_config)(num_diffusion_timesteps=30, beta_end=2e-5)
-    sd = O.synth_state_dict_for(cfg)
-    for k in ("edge_encoder_global.feature_expansion.weight", "model_global.0.feature_expansion.weight"):
-        sd[k] = sd[k] * scale
+    sd = _sharpen(O.synth_state_dict_for(cfg), scale, bounded)
     m = get_model(cfg)
     m.precision = precision
     m.load_state_dict({k: v.clone() for k, v in sd.items()})
@@ -317,7 +334,7 @@ def test_sharp_first_layer_takes_the_96_and_128_term_rungs(kind, scale, terms, p
     g = torch.Generator().manual_seed(5)
     pos_init, noise = torch.randn(at.shape[0], 3, generator=g), torch.randn(4, at.shape[0], 3, generator=g)
     kw = dict(extend_order=False, n_steps=4, w_global=1.0, global_start_sigma=0.5, clip=1000.0)
-    key = ("rungs", kind, scale)
+    key = ("rungs", kind, scale, bounded)
     if key not in _ORACLE_RESULTS:
         _ORACLE_RESULTS[key] = O.langevin_dynamics_sample_diffusion(sd, cfg, at, pos_init, bi, bt, ba, b["num_graphs"], noise=noise, **kw)[0]
     ref = _ORACLE_RESULTS[key]

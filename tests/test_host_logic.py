@@ -726,3 +726,40 @@ def test_prepared_topology_is_tied_to_its_batch():
     m.group_targets = 4 if tp.group_targets != 4 else 2
     with pytest.raises(ValueError, match="targets per wave"):
         m._batch(tt(b["atom_type"]), tt(b["bond_index"]), tt(b["bond_type"]), tt(b["batch"]), b["num_graphs"], False, topology=tp)
+
+
+def test_pass_plan_of_the_96_and_128_term_rungs():
+    """Three and four k-tiles (sharp first layers): plan 1 gives every term from 32 on one pass, plan 2 (new with these rungs) the
+    terms from 64 on; the host takes the first whose bound holds for the radius set and the common local types, and what it records
+    is that plan's bound.  Checked on the bounded-sharpness family (gelu(s u) / s: the first layer's weight and bias times s, the
+    next layer's columns that read it divided by s)."""
+    from agdiff_amd import drugs_model_config, packing
+    from oracle import agdiff_oracle as O
+    cfg = drugs_model_config()
+    seen = {}
+    for scale in (32.0, 64.0):
+        sd = O.synth_state_dict_for(cfg)
+        for e in ("edge_encoder_global", "model_global.0"):
+            n = sd[e + ".feature_expansion.weight"].shape[0]
+            sd[e + ".feature_expansion.weight"] = sd[e + ".feature_expansion.weight"] * scale
+            sd[e + ".feature_expansion.bias"] = sd[e + ".feature_expansion.bias"] * scale
+            w = sd[e + ".edge_feature_mlp.0.weight"].clone()
+            w[:, :n] = w[:, :n] / scale
+            sd[e + ".edge_feature_mlp.0.weight"] = w
+        pk = packing.PackedParams(sd, cfg, "cpu", "f16x3")
+        kt = pk.poly_kt
+        assert kt == {32.0: 3, 64.0: 4}[scale], pk.poly_errors
+        b1, b2 = pk._bound(pk._poly, 1), pk._bound(pk._poly, 2)
+        assert b2 < b1                                                   # (fewer terms in one pass)
+        ok1, ok2 = pk.poly_errors[kt] + b1 <= packing.POLY_TOL, pk.poly_errors[kt] + b2 <= packing.POLY_TOL
+        assert pk.poly_plan in (0, 1, 2) and pk.struct.poly_plan == pk.poly_plan
+        if pk.poly_plan == 1:
+            assert ok1 and pk.poly_high_bound["radius"] == b1
+        elif pk.poly_plan == 2:
+            assert not (ok1 and all(pk.poly_errors.get("type%d" % t, 0) + pk._bound(packing.fit_type(sd, cfg, t, kt, False)[0], 1) <= packing.POLY_TOL
+                                    for t in packing.POLY_PLAN_TYPES)) and ok2 and pk.poly_high_bound["radius"] == b2
+        else:
+            assert not ok2 or pk.poly_high_bound["radius"] == b1
+        seen[scale] = pk.poly_plan
+        assert packing.PackedParams(sd, cfg, "cpu", "f16x3", poly_passes="full").poly_plan == 0
+    assert 2 in seen.values(), seen          # (at these scales the terms 32..63 are too heavy for plan 1: plan 2 is what the rungs run on)

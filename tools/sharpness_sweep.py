@@ -17,7 +17,9 @@ from helpers import rel_err
 ap = argparse.ArgumentParser()
 ap.add_argument("--out", default=None)
 ap.add_argument("--steps", type=int, default=60)
-ap.add_argument("--scales", default="1,2,5,8,16,40")
+ap.add_argument("--scales", default="1,2,5,8,16,24,32,40")
+ap.add_argument("--bounded", default="16,32,64,128", help="first layer (weight and bias) times s, its outputs' columns of the next layer divided by s: "
+                "gelu(s u) / s -- kinks s times sharper at unchanged magnitudes (the plain first-layer scaling also blows the network's values up)")
 ap.add_argument("--all-layers", default="1.5,2,3", help="every Linear weight of the edge encoder scaled by these factors")
 ap.add_argument("--default-init-seeds", default="0,1,2", help="PyTorch-default-initialised models (torch.manual_seed) -- no synthetic checkpoint")
 args = ap.parse_args()
@@ -30,6 +32,7 @@ pos_small = torch.randn(small["atom_type"].shape[0], 3, generator=torch.Generato
 rows = []
 from agdiff_amd import _lib
 cases = [("first_layer", float(x)) for x in args.scales.split(",") if x] + \
+        [("first_layer_bounded", float(x)) for x in args.bounded.split(",") if x] + \
         [("all_encoder_layers", float(x)) for x in args.all_layers.split(",") if x] + \
         [("default_init", float(x)) for x in args.default_init_seeds.split(",") if x]
 for kind_, scale in cases:
@@ -46,6 +49,12 @@ for kind_, scale in cases:
                 ck = synth.canonical_key(k)
                 if kind_ == "first_layer" and ck == "edge_encoder_global.feature_expansion.weight":
                     sd_[k] = sd_[k] * scale
+                if kind_ == "first_layer_bounded" and ck in ("edge_encoder_global.feature_expansion.weight", "edge_encoder_global.feature_expansion.bias"):
+                    sd_[k] = sd_[k] * scale
+                if kind_ == "first_layer_bounded" and ck == "edge_encoder_global.edge_feature_mlp.0.weight":
+                    w_ = sd_[k].clone()
+                    w_[:, :cfg.hidden_dim] = w_[:, :cfg.hidden_dim] / scale          # (the columns that read the first layer's outputs)
+                    sd_[k] = w_
                 if kind_ == "all_encoder_layers" and ck.startswith("edge_encoder_global.") and ck.endswith(".weight") and "bond_emb" not in ck:
                     sd_[k] = sd_[k] * scale
             m_.load_state_dict(sd_)
@@ -88,7 +97,7 @@ for kind_, scale in cases:
         del run, m
         continue
     rec.update(ms_per_step_8x128=ms, conformers_per_s_8x128=big["num_graphs"] / (ms * 5000 / 1e3),
-               path="filter polynomials, %d terms" % (32 * pk.poly_kt) if pk.poly_kt else "filter MLPs (fit refused at 32 and 64 terms)")
+               path="filter polynomials, %d terms" % (32 * pk.poly_kt) if pk.poly_kt else "filter MLPs (fit refused at 32 .. 128 terms)")
     rows.append(rec)
     print(json.dumps(rec), flush=True)
     del run, m
