@@ -99,7 +99,7 @@ struct NodeConvShape {
   static constexpr int WAVES = AG_NODECONV_WAVES;
 #else
   static constexpr int WAVES = FOUR ? 16 : NKT >= 3 ? 8 : 12;       // (three / four k-tiles: 256 registers per lane)
-  static_assert(PLAN >= 0 && PLAN <= 2, "poly_plan");
+  static_assert(PLAN >= 0 && PLAN <= 3, "poly_plan");
 #endif
 };
 #ifndef AG_NODE_XD
@@ -126,9 +126,9 @@ struct NodeConvShape {
 // PLAN (agdiff_params_t.poly_plan): 0 three passes for every term; 1 one pass for the high terms, whose coefficients the
 // host has bounded -- at NKT 1 two MFMAs per channel tile (hi x hi of all 32 terms, then both cross terms of terms 0..15 in
 // one instruction: ag_poly_features<.., true> / the mixed unit 1 of the blocks), at NKT >= 2 every k-tile but the first by its hi x hi
-// pass alone; 2 (NKT >= 3: sharp networks, whose terms 32..63 still carry weight) the same from k-tile 2 on.
+// pass alone; 2 (NKT >= 3) / 3 (NKT 4): the same from k-tile 2 / 3 on -- sharp networks, whose terms 32..63 (..95) still carry weight.
 // (k-tile t of a set takes all passes of the split arithmetic, or the hi x hi pass alone)
-__host__ __device__ constexpr bool ag_plan_full(int plan, int t) { return plan == 0 || t == 0 || (plan == 2 && t == 1); }
+__host__ __device__ constexpr bool ag_plan_full(int plan, int t) { return plan == 0 || t < plan; }
 
 template <int MODE, int NKT, int WAVES, int PLAN, int GRP>
 __global__ void __launch_bounds__(64 * WAVES, WAVES / 4) k_cfconv_node(NodeConvArgs a) {
@@ -771,6 +771,9 @@ int launch_cfconv_node_t(const NodeConvArgs& a, int plan, bool four, bool quad, 
     if constexpr (NKT >= 3) {
       if (plan == 2) return launch_cfconv_node_p<MODE, NKT, 2>(a, four, quad, smem, stream);
     }
+    if constexpr (NKT >= 4) {
+      if (plan == 3) return launch_cfconv_node_p<MODE, NKT, 3>(a, four, quad, smem, stream);
+    }
   }
   return launch_cfconv_node_p<MODE, NKT, 0>(a, four, quad, smem, stream);
 }
@@ -780,7 +783,7 @@ extern "C" int agdiff_cfconv_node(const agdiff_params_t* p, const agdiff_topo_t*
                                   void* stream) {
   if (!p || !topo || !ws || k < 0 || k >= p->num_convs) return AGDIFF_ERR_ARG;
   if (p->poly_kt < 1 || p->poly_kt > AGDIFF_POLY_MAX_KT || !p->conv[k].filt_poly_pk) return AGDIFF_ERR_ARG;
-  if (p->poly_plan < 0 || p->poly_plan > 2 || (p->poly_plan && p->precision == AG_F32) || (p->poly_plan == 2 && p->poly_kt < 3))
+  if (p->poly_plan < 0 || p->poly_plan > 3 || (p->poly_plan && p->precision == AG_F32) || (p->poly_plan >= 2 && p->poly_kt <= p->poly_plan))
     return AGDIFF_ERR_ARG;
   if (!(p->conv[k].filt_poly_unscale > 0.0f)) return AGDIFF_ERR_ARG;
   if (!ws->rad_cnt || !ws->rad_src || !ws->rad_len || !ws->r_scale || !ws->xs || !ws->agg || !topo->quad_tgt ||

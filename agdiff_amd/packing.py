@@ -349,7 +349,7 @@ POLY_COEF_LIMIT = 32768.0       # ... and a typed set must stay below this at th
 def poly_high_weight(c_nat, kt, high=None):
     """max over outputs of sum_{f >= high} |c[out][f]| relative to the largest value the polynomials take on [0, cutoff]
     (|phi_f| <= 1): c_nat [out, 32 kt] in natural packed column order (fit_type).  `high`: the first term plan 1 gives one pass
-    (default: 16 at one k-tile, 32 else); 64 for plan 2."""
+    (default: 16 at one k-tile, 32 else); 64 / 96 for plans 2 / 3."""
     K = 32 * kt
     c_f = np.empty_like(np.asarray(c_nat, dtype=np.float64))
     c_f[:, poly_feature_order(kt)] = c_nat
@@ -456,12 +456,13 @@ class PackedParams:
         through the encoder + filter MLPs; "radius" -- polynomials for the radius edges only; "kt2" / "kt3" / "kt4" -- as
         "auto" but starting at 64 / 96 / 128 terms (the variants exist for tests and A/B runs).
         poly_passes: "auto" -- one pass over the high terms of the filter polynomials when their coefficients allow it
-        (poly_pass_plan); "full" -- three passes for every term; "from64" -- as "auto" without plan 1 (tests of plan 2)."""
+        (poly_pass_plan); "full" -- three passes for every term; "from64" / "from96" -- as "auto" without plan 1 / plans 1, 2 (tests and
+        A/B runs of plans 2 and 3)."""
         import torch
         self.device = device
         self.attr_far = bool(attr_far)  # False keeps the encoder MLP for local edges beyond the cutoff (tests, A/B runs)
-        if poly_passes not in ("auto", "full", "from64"):
-            raise ValueError("poly_passes must be 'auto', 'full' or 'from64'")
+        if poly_passes not in ("auto", "full", "from64", "from96"):
+            raise ValueError("poly_passes must be 'auto', 'full', 'from64' or 'from96'")
         self.poly_passes = poly_passes
         if radius_poly not in ("auto", "off", "radius", "kt2", "kt3", "kt4"):
             raise ValueError("radius_poly must be one of 'auto', 'off', 'radius', 'kt2', 'kt3', 'kt4'")
@@ -720,8 +721,8 @@ class PackedParams:
             self._pack_filter_sets()
 
     def _bound(self, mats, plan):
-        """POLY_EPS1 x the weight of the terms `plan` gives one pass (1: f >= 16 at one k-tile, f >= 32 else; 2: f >= 64)."""
-        high = 64 if plan == 2 else None
+        """POLY_EPS1 x the weight of the terms `plan` gives one pass (1: f >= 16 at one k-tile, f >= 32 else; 2: f >= 64; 3: f >= 96)."""
+        high = 32 * plan if plan >= 2 else None
         return POLY_EPS1[self._mode] * max(poly_high_weight(mats["conv%d.filt_poly_pk" % k], self.poly_kt, high)
                                            for k in range(self._cfg.num_convs))
 
@@ -732,7 +733,7 @@ class PackedParams:
         return self.poly_high_bound[name]
 
     def poly_pass_plan(self):
-        """agdiff_params_t.poly_plan, decided ONCE per model: the first of 1, 2 (2 only from three k-tiles on) for which the radius
+        """agdiff_params_t.poly_plan, decided ONCE per model: the first of 1, 2, 3 (p < poly_kt: one pass from k-tile p on) for which the radius
         set and each of POLY_PLAN_TYPES whose fit is accepted at all satisfy fit error + POLY_EPS1[mode] * (weight of the terms that
         plan gives one pass) <= POLY_TOL, else 0; self.poly_high_bound records the second summand per set under the plan taken (under
         plan 1 when none is).  (Until round 4 the plan followed the types met so far and could flip mid-process.)"""
@@ -741,8 +742,8 @@ class PackedParams:
         plan = 0
         if self._mode in POLY_EPS1 and self.poly_kt >= 1 and self.poly_passes != "full":
             first = None
-            cands = (1, 2) if self.poly_kt >= 3 else (1,)
-            for cand in (cands[1:] if self.poly_passes == "from64" else cands):
+            cands = tuple(range(1, max(self.poly_kt, 2)))            # (plan p: one pass from k-tile p on -- p < poly_kt)
+            for cand in cands[{"from64": 1, "from96": 2}.get(self.poly_passes, 0):]:
                 bounds = {"radius": self._bound(self._poly, cand)}
                 ok = self.poly_errors[self.poly_kt] + bounds["radius"] <= POLY_TOL
                 if ok and self._typed_ok:

@@ -48,13 +48,13 @@ MFMA_PASSES = {"f32": 1, "bf16x3": 3, "f16x3": 3}        # MFMA FLOPs issued per
 
 def mfma_per_channel_tile(kt, plan, passes):
     """MFMAs k_cfconv_quad issues per 16-channel tile of a 16-row tile (agdiff_params_t.poly_kt k-tiles, poly_plan): plan 0 every
-    k-tile all passes; plan 1 two instructions at one k-tile, else all passes for k-tile 0 and one for the others; plan 2 (three
-    k-tiles and more) all passes for k-tiles 0 and 1."""
+    k-tile all passes; plan 1 two instructions at one k-tile; else plan p all passes for k-tiles 0 .. p - 1
+    and one for the others."""
     if not plan:
         return kt * passes
-    if plan == 1:
-        return 2 if kt == 1 else passes + (kt - 1)
-    return 2 * passes + (kt - 2)
+    if plan == 1 and kt == 1:
+        return 2
+    return plan * passes + (kt - plan)
 
 PROFILE_ROUND = "r06"
 
@@ -430,7 +430,7 @@ def main():
     ap.add_argument("--precision", default="f16x3", choices=["f32", "bf16x3", "f16x3"])
     ap.add_argument("--radius-poly", default="auto", choices=["auto", "radius", "kt2", "kt3", "kt4", "off"],
                     help="filter polynomials (agdiff_amd/packing.py): off = every edge through the encoder + filter MLPs")
-    ap.add_argument("--poly-passes", default="auto", choices=["auto", "full"],
+    ap.add_argument("--poly-passes", default="auto", choices=["auto", "full", "from64", "from96"],
                     help="MFMA passes over the filter polynomials' high terms: auto = one when the host's bound allows it "
                          "(agdiff_params_t.poly_plan), full = three for every term (A/B runs)")
     ap.add_argument("--group-targets", type=int, default=None, choices=[1, 2, 4],
@@ -935,8 +935,8 @@ def main():
                                                     "batches": nb, "fraction_of_headline": v / value}
             del m4
             # ... and the two rungs below it, with the pass plans the sharp checkpoints of tools/sharpness_sweep.py take there: 96 terms
-            # (first layer ~32 x sharper) one pass from term 64 on, 128 terms (~64 x) three passes for every term
-            for terms, rp, pp in ((96, "kt3", "from64"), (128, "kt4", "full")):
+            # (first layer ~32 x sharper) one pass from term 64 on, 128 terms (~64 x) one pass from term 96 on
+            for terms, rp, pp in ((96, "kt3", "from64"), (128, "kt4", "from96")):
                 m5, cfg5 = make_model(args.schedule, radius_poly=rp, poly_passes=pp if args.poly_passes == "auto" else None)
                 v, ms5, gf5, nb = side_run(m5, cfg5, args.schedule, skip)
                 extra["filter_polynomials_%d_terms" % terms] = {"value": v, "unit": "conformers/s", "ms_per_step": ms5, "steps": Ke, "batches": nb,

@@ -217,8 +217,8 @@ typedef struct agdiff_params {
                                   low 16 terms in one K = 32 instruction.
                                   poly_kt >= 2: k-tile 0 three passes, the others one (unit 1 of their blocks is not read);
                                   the high terms are then f >= 32.
-                                2 (poly_kt >= 3 only): k-tiles 0 and 1 three passes, the others one -- the high terms are
-                                f >= 64: sharp networks whose terms 32..63 still carry too much weight for plan 1. */
+                                2 (poly_kt >= 3) / 3 (poly_kt 4): k-tiles 0..1 / 0..2 three passes, the others one -- the high terms
+                                are f >= 64 / 96: sharp networks whose terms 32..63 (..95) still carry too much weight for plan 1. */
   int32_t tune_cfconv_quad_tiles;    /* [0] agdiff_cfconv_node on quads (topo->group_targets == 4): radius rows in quad tiles too -- quarter k
                                         of a tile = four rows of the quad's k-th target, one set of sums per lane, no exchange between
                                         the quarters (k_cfconv_quad); -1: every target its own radius tiles (k_cfconv_node) */

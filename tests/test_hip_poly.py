@@ -8,8 +8,8 @@ against the one-list kernels that evaluate the filter MLPs for every edge.  `rad
   off     one list, every edge through the encoder + filter MLPs (rounds 1-2a product path)
 plus `auto-l2`: as auto with every local type's coefficient set read from L2 instead of LDS (tune_poly_lds_sets = 1: the
 path types beyond the LDS-resident sets take), and `auto-full` / `kt2-full`: three MFMA passes for every polynomial term
-(model.poly_passes = "full"; the other split-mode runs take one pass for the high terms: agdiff_params_t.poly_plan 1; `-from64`:
-plan 2, one pass from term 64 on)."""
+(model.poly_passes = "full"; the other split-mode runs take one pass for the high terms: agdiff_params_t.poly_plan 1; `-from64` / `-from96`:
+plans 2 / 3, one pass from term 64 / 96 on)."""
 import ctypes
 
 import numpy as np
@@ -65,19 +65,20 @@ def _expect(pk, mode):
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x3"])
-@pytest.mark.parametrize("mode", MODES + ["auto-full", "kt2-full", "kt3-full", "kt4-full", "kt3-from64", "kt4-from64"])
+@pytest.mark.parametrize("mode", MODES + ["auto-full", "kt2-full", "kt3-full", "kt4-full", "kt3-from64", "kt4-from64", "kt4-from96"])
 @pytest.mark.parametrize("case", ["g3_forward_qm9_small", "g3_forward_drugs_capped"])
 def test_forward_every_filter_mode(case, mode, precision):
     g = load_golden(case)
-    full, from64 = mode.endswith("-full"), mode.endswith("-from64")
-    mode = mode.split("-")[0] if (full or from64) else mode
+    full, later = mode.endswith("-full"), {"from64": 2, "from96": 3}.get(mode.split("-")[-1], 0)
+    passes = mode.split("-")[-1] if (full or later) else "auto"
+    mode = mode.split("-")[0]
     m = _model(FORWARD_CASES[case](), mode, precision=precision)
-    m.poly_passes = "full" if full else "from64" if from64 else "auto"
+    m.poly_passes = passes
     out = m(t(g["atom_type"]).cuda(), t(g["pos"]).cuda(), t(g["bond_index"]).cuda(), t(g["bond_type"]).cuda(),
             t(g["batch"]).cuda(), None, return_edges=True, extend_order=False)
     _expect(m.packed(), mode)
-    # (plan 2 -- one pass from term 64 on -- is what a sharp network takes at three / four k-tiles; forced here on the smooth one)
-    assert m.packed().struct.poly_plan == ((2 if from64 else 1) if (mode != "off" and precision != "f32" and not full) else 0), m.packed().poly_high_bound
+    # (plans 2, 3 -- one pass from term 64 / 96 on -- are what a sharp network takes at three / four k-tiles; forced here on the smooth one)
+    assert m.packed().struct.poly_plan == ((later or 1) if (mode != "off" and precision != "f32" and not full) else 0), m.packed().poly_high_bound
     ws = m._batch_cache[2]
     assert np.array_equal(out[2].cpu().numpy(), g["edge_index"]) and np.array_equal(out[3].cpu().numpy(), g["edge_type"])
     if "schnet_out" in g:

@@ -729,15 +729,15 @@ def test_prepared_topology_is_tied_to_its_batch():
 
 
 def test_pass_plan_of_the_96_and_128_term_rungs():
-    """Three and four k-tiles (sharp first layers): plan 1 gives every term from 32 on one pass, plan 2 (new with these rungs) the
-    terms from 64 on; the host takes the first whose bound holds for the radius set and the common local types, and what it records
+    """Three and four k-tiles (sharp first layers): plan 1 gives every term from 32 on one pass, plans 2 and 3 (new with these
+    rungs) the terms from 64 / 96 on; the host takes the first whose bound holds for the radius set and the common local types, and what it records
     is that plan's bound.  Checked on the bounded-sharpness family (gelu(s u) / s: the first layer's weight and bias times s, the
     next layer's columns that read it divided by s)."""
     from agdiff_amd import drugs_model_config, packing
     from oracle import agdiff_oracle as O
     cfg = drugs_model_config()
     seen = {}
-    for scale in (32.0, 64.0):
+    for precision, scale in (("f16x3", 32.0), ("f16x3", 64.0), ("bf16x3", 32.0), ("bf16x3", 64.0)):
         sd = O.synth_state_dict_for(cfg)
         for e in ("edge_encoder_global", "model_global.0"):
             n = sd[e + ".feature_expansion.weight"].shape[0]
@@ -746,20 +746,21 @@ def test_pass_plan_of_the_96_and_128_term_rungs():
             w = sd[e + ".edge_feature_mlp.0.weight"].clone()
             w[:, :n] = w[:, :n] / scale
             sd[e + ".edge_feature_mlp.0.weight"] = w
-        pk = packing.PackedParams(sd, cfg, "cpu", "f16x3")
+        pk = packing.PackedParams(sd, cfg, "cpu", precision)
         kt = pk.poly_kt
         assert kt == {32.0: 3, 64.0: 4}[scale], pk.poly_errors
-        b1, b2 = pk._bound(pk._poly, 1), pk._bound(pk._poly, 2)
-        assert b2 < b1                                                   # (fewer terms in one pass)
-        ok1, ok2 = pk.poly_errors[kt] + b1 <= packing.POLY_TOL, pk.poly_errors[kt] + b2 <= packing.POLY_TOL
-        assert pk.poly_plan in (0, 1, 2) and pk.struct.poly_plan == pk.poly_plan
-        if pk.poly_plan == 1:
-            assert ok1 and pk.poly_high_bound["radius"] == b1
-        elif pk.poly_plan == 2:
-            assert not (ok1 and all(pk.poly_errors.get("type%d" % t, 0) + pk._bound(packing.fit_type(sd, cfg, t, kt, False)[0], 1) <= packing.POLY_TOL
-                                    for t in packing.POLY_PLAN_TYPES)) and ok2 and pk.poly_high_bound["radius"] == b2
-        else:
-            assert not ok2 or pk.poly_high_bound["radius"] == b1
-        seen[scale] = pk.poly_plan
-        assert packing.PackedParams(sd, cfg, "cpu", "f16x3", poly_passes="full").poly_plan == 0
-    assert 2 in seen.values(), seen          # (at these scales the terms 32..63 are too heavy for plan 1: plan 2 is what the rungs run on)
+        bounds = {p: pk._bound(pk._poly, p) for p in range(1, kt)}
+        assert all(bounds[p + 1] < bounds[p] for p in range(1, kt - 1))                 # (fewer terms in one pass)
+        plan = pk.poly_plan
+        assert 0 <= plan < kt and pk.struct.poly_plan == plan
+        if plan:
+            assert pk.poly_errors[kt] + bounds[plan] <= packing.POLY_TOL and pk.poly_high_bound["radius"] == bounds[plan]
+
+        def fits(p):        # (the radius set and every common local type under plan p)
+            sets = [(pk.poly_errors[kt], pk._poly)] + [packing.fit_type(sd, cfg, t, kt, False)[::-1] for t in packing.POLY_PLAN_TYPES]
+            return all(err > packing.POLY_TOL or err + pk._bound(m, p) <= packing.POLY_TOL for err, m in sets)
+        assert not any(fits(p) for p in range(1, plan or kt))                          # (no earlier plan would have done)
+        seen[precision, scale] = pk.poly_plan
+        assert packing.PackedParams(sd, cfg, "cpu", precision, poly_passes="full").poly_plan == 0
+    # (split-bf16 rounds an operand to 8 bits instead of 11: the terms 32..63, and at 128 terms 64..95 too, are then too heavy for one pass)
+    assert seen == {("f16x3", 32.0): 1, ("f16x3", 64.0): 2, ("bf16x3", 32.0): 2, ("bf16x3", 64.0): 3}, seen
