@@ -240,11 +240,13 @@ int local_branch(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdi
   if (split && split_ready && hipEventRecord(split_ready, (hipStream_t)stream) != hipSuccess) return AGDIFF_ERR_LAUNCH;
   AG_TRY(agdiff_gin_encoder(p, topo, ws, canon ? 1 : 0, stream));
   if (topo->num_local > 0) {
+    agdiff_head_params_t hl = p->head_local;       // (the hidden layer's range flags go to this workspace)
+    hl.range_rows = ws->range_rows;
     if (canon)
-      AG_TRY(agdiff_pair_head(&p->head_local, ws->num_local_canon, ctiles, topo->lc_src, topo->lc_dst, ws->hl, nullptr,
+      AG_TRY(agdiff_pair_head(&hl, ws->num_local_canon, ctiles, topo->lc_src, topo->lc_dst, ws->hl, nullptr,
                               ws->l_attr_rows, topo->lc_pos, topo->lc_mir, ws->l_inv, stream));
     else
-      AG_TRY(agdiff_pair_head(&p->head_local, ws->num_local, ltiles, topo->loc_src, topo->loc_dst, ws->hl, nullptr,
+      AG_TRY(agdiff_pair_head(&hl, ws->num_local, ltiles, topo->loc_src, topo->loc_dst, ws->hl, nullptr,
                               ws->l_attr_rows, nullptr, nullptr, ws->l_inv, stream));
   }
   return AGDIFF_OK;
@@ -280,11 +282,13 @@ int global_back(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdif
       AG_TRY(agdiff_cfconv_fused(p, topo, ws, k, stream));
     }
   }
+  agdiff_head_params_t hg = p->head_global;
+  hg.range_rows = ws->range_rows;
   if (flags & AGDIFF_FWD_GRAPH_GIVEN) {
-    AG_TRY(agdiff_pair_head(&p->head_global, ws->num_edges, etiles, ws->e_src, ws->e_dst, ws->h, ws->e_attr, nullptr,
+    AG_TRY(agdiff_pair_head(&hg, ws->num_edges, etiles, ws->e_src, ws->e_dst, ws->h, ws->e_attr, nullptr,
                             nullptr, nullptr, ws->e_inv_global, stream));
   } else {
-    AG_TRY(agdiff_pair_head(&p->head_global, ws->num_canon, etiles, ws->c_src, ws->c_dst, ws->h, ws->e_attr, nullptr,
+    AG_TRY(agdiff_pair_head(&hg, ws->num_canon, etiles, ws->c_src, ws->c_dst, ws->h, ws->e_attr, nullptr,
                             ws->c_pos, ws->c_mir, ws->e_inv_global, stream));
   }
   return AGDIFF_OK;
@@ -346,11 +350,16 @@ int global_back_split(const agdiff_params_t* p, const agdiff_topo_t* topo, const
     ag_log_variant(ws, AGDIFF_VAR_HEAD_POLY);
     if (flags & AGDIFF_FWD_GRAPH_READY)       // segmented canonical list, results by radius row (ws->inv_r)
       AG_TRY(agdiff_pair_head_poly_rows(p, topo, ws, (flags & AGDIFF_FWD_PARITY) ? 1 : 0, stream));
-    else
-      AG_TRY(agdiff_pair_head_poly(p, ws->num_canon, etiles, ws->c_src, ws->c_dst, ws->c_len, ws->h, ws->c_pos, ws->c_mir,
+    else {
+      agdiff_params_t pp = *p;                      // (the hidden layer's range flags go to this workspace)
+      pp.head_global.range_rows = ws->range_rows;
+      AG_TRY(agdiff_pair_head_poly(&pp, ws->num_canon, etiles, ws->c_src, ws->c_dst, ws->c_len, ws->h, ws->c_pos, ws->c_mir,
                                    ws->e_inv_global, stream));
+    }
   } else {
-    AG_TRY(agdiff_pair_head(&p->head_global, ws->num_canon, etiles, ws->c_src, ws->c_dst, ws->h, ws->e_attr, nullptr,
+    agdiff_head_params_t hg = p->head_global;
+    hg.range_rows = ws->range_rows;
+    AG_TRY(agdiff_pair_head(&hg, ws->num_canon, etiles, ws->c_src, ws->c_dst, ws->h, ws->e_attr, nullptr,
                             ws->c_pos, ws->c_mir, ws->e_inv_global, stream));
   }
   return AGDIFF_OK;

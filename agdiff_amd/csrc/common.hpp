@@ -294,6 +294,25 @@ __device__ __forceinline__ void ag_cvt_tiles(const f32x4 (&a)[NA], AgIn<MODE> (&
   for (int t = 0; t < NK; ++t) ag_cvt(a[A0 + 2 * t], a[A0 + 2 * t + 1], o[t]);
 }
 
+// Split-fp16 operands saturate at 65504 (ag_cvt_pair).  Activations that depend on the state and that no workspace tensor shows (hidden
+// layers of the node stage, the GIN layers, the heads) are tracked where they are converted: the largest magnitude a lane has seen, and
+// one flag per node for the launch's caller (agdiff_ws_t.range_rows) when it reaches the edge of the range.  Nothing in the other modes.
+template <int MODE, int N, int NA>
+__device__ __forceinline__ float ag_absmax(const f32x4 (&a)[NA], float mx) {
+  static_assert(N <= NA, "tile range");
+  if constexpr (MODE == AG_H3) {
+#pragma unroll
+    for (int t = 0; t < N; ++t) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(a[t][0]), fabsf(a[t][1]))), fmaxf(fabsf(a[t][2]), fabsf(a[t][3])));
+  }
+  return mx;
+}
+template <int MODE>
+__device__ __forceinline__ void ag_report_range(float mx, int32_t* rows, int64_t row, bool live) {
+  if constexpr (MODE == AG_H3) {
+    if (rows && live && mx >= 65000.0f) rows[row] = 1;
+  }
+}
+
 // one weight block (2 x 16 B per lane, already in registers) applied to one k-tile
 template <int MODE, bool FLIP>
 __device__ __forceinline__ void ag_block_mma(f32x4& o, const AgIn<MODE>& x, const u32x4 (&w)[2]) {

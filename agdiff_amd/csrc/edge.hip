@@ -751,6 +751,7 @@ __global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_pair_head(HeadArgs
     ag_init_vec<4>(y2, a.hp.b2, q);
     {
       AgIn<MODE> y1b[4];
+      ag_report_range<MODE>(ag_absmax<MODE, 8>(y1, 0.0f), a.hp.range_rows, s, valid);      // (the hidden layer as an operand: common.hpp)
       ag_cvt_tiles<MODE, 4, 0>(y1, y1b);
       ag_dense_lds<MODE, false, false, 4, 4, 0, 0>(y1b, y2, ag_lds_base(lw2, lane), 0);
     }
@@ -991,6 +992,7 @@ __global__ void __launch_bounds__(64 * AG_PERSIST_WAVES, 4) k_pair_head_poly(Hea
     ag_init_vec<4>(y2, a.hp.b2, q);
     {
       AgIn<MODE> y1b[4];
+      ag_report_range<MODE>(ag_absmax<MODE, 8>(y1, 0.0f), a.hp.range_rows, s, valid);      // (the hidden layer as an operand: common.hpp)
       ag_cvt_tiles<MODE, 4, 0>(y1, y1b);
       ag_dense_lds<MODE, false, false, 4, 4, 0, 0>(y1b, y2, ag_lds_base(lw2, lane), 0);
     }
@@ -1258,14 +1260,14 @@ namespace {
 int launch_pair_head_poly(const agdiff_params_t* p, const int32_t* n_edges_dev, int64_t max_tiles,
                           const int32_t* src, const int32_t* dst, const float* len, const float* node_h,
                           const int32_t* pos_index, const int32_t* mir_index, float* out, const int32_t* seg_tile_live,
-                          void* stream);
+                          int32_t* range_rows, void* stream);
 }
 
 extern "C" int agdiff_pair_head_poly(const agdiff_params_t* p, const int32_t* n_edges_dev, int64_t max_tiles,
                                      const int32_t* src, const int32_t* dst, const float* len, const float* node_h,
                                      const int32_t* pos_index, const int32_t* mir_index, float* out, void* stream) {
   if (!n_edges_dev) return AGDIFF_ERR_ARG;
-  return launch_pair_head_poly(p, n_edges_dev, max_tiles, src, dst, len, node_h, pos_index, mir_index, out, nullptr, stream);
+  return launch_pair_head_poly(p, n_edges_dev, max_tiles, src, dst, len, node_h, pos_index, mir_index, out, nullptr, nullptr, stream);
 }
 
 extern "C" int agdiff_pair_head_poly_rows(const agdiff_params_t* p, const agdiff_topo_t* topo, const agdiff_ws_t* ws,
@@ -1273,20 +1275,21 @@ extern "C" int agdiff_pair_head_poly_rows(const agdiff_params_t* p, const agdiff
   if (!p || !topo || !ws || !ws->canon_counter || !ws->inv_r) return AGDIFF_ERR_ARG;
   const int64_t tiles = (topo->max_edges - topo->num_local + AG_TW - 1) / AG_TW + 1;
   return launch_pair_head_poly(p, ws->canon_counter + (parity & 1), tiles, ws->c_src, ws->c_dst, ws->c_len, ws->h, ws->c_pos,
-                               ws->c_mir, ws->inv_r, nullptr, stream);
+                               ws->c_mir, ws->inv_r, nullptr, ws->range_rows, stream);
 }
 
 namespace {
 int launch_pair_head_poly(const agdiff_params_t* p, const int32_t* n_edges_dev, int64_t max_tiles,
                           const int32_t* src, const int32_t* dst, const float* len, const float* node_h,
                           const int32_t* pos_index, const int32_t* mir_index, float* out, const int32_t* seg_tile_live,
-                          void* stream) {
+                          int32_t* range_rows, void* stream) {
   if (!p || !src || !dst || !len || !node_h || !out || max_tiles < 0 || (!pos_index != !mir_index))
     return AGDIFF_ERR_ARG;
   if (p->poly_kt < 1 || p->poly_kt > AGDIFF_POLY_MAX_KT || !p->head_global.attr_poly_pk) return AGDIFF_ERR_ARG;
   if (max_tiles == 0) return AGDIFF_OK;
   HeadPolyArgs a;
   a.hp = p->head_global;
+  if (range_rows) a.hp.range_rows = range_rows;
   a.seg_tile_live = seg_tile_live;
   a.n_dev = n_edges_dev;
   a.src = src;

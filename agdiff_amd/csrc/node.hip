@@ -27,6 +27,7 @@ struct NodeStageArgs {
   const float* agg2;
   const float* agg_first2;
   int32_t chunk_edges2;
+  int32_t* range_rows;         // agdiff_ws_t.range_rows (split-fp16: hidden activations at the edge of fp16's range)
 };
 
 // The aggregate of one node from one CFConv pass (edge.hip): agg[node] holds the part of the node's edge list that lies
@@ -158,6 +159,7 @@ __global__ void __launch_bounds__(LDSW ? 1024 : 256, LDSW ? 1 : 2) k_schnet_node
       }
       // InteractionBlock.act in base 2: act.beta log2(e) rides in lin2, ln 2 and the -ln 2 shift in lin (packing.py)
       AG_FOR_TILE(u, 16, ag_ssp_base2(v));
+      ag_report_range<MODE>(ag_absmax<MODE, 16>(u, 0.0f), a.range_rows, nd, valid);      // (hidden activations as operands: common.hpp)
       ag_cvt_tiles<MODE, 8, 0>(u, ub);
       ag_init_vec<8>(xc, a.prev.lin_b, q);
       AG_NODE_DENSE(false, 8, 4, 0, 0, ub, xc, a.prev.lin_pk, 48);                             // output tiles 0..3
@@ -172,6 +174,7 @@ __global__ void __launch_bounds__(LDSW ? 1024 : 256, LDSW ? 1 : 2) k_schnet_node
       ag_init_vec<4>(g1, a.prev.gate1_b, q);
       {
         AgIn<MODE> xb[4];
+        ag_report_range<MODE>(ag_absmax<MODE, 8>(xc, 0.0f), a.range_rows, nd, valid);        // (the gate below only shrinks it)
         ag_cvt_tiles<MODE, 4, 0>(xc, xb);
         AG_NODE_DENSE(false, 4, 4, 0, 0, xb, g1, a.prev.gate1_pk, 32);
       }
@@ -199,6 +202,7 @@ __global__ void __launch_bounds__(LDSW ? 1024 : 256, LDSW ? 1 : 2) k_schnet_node
       for (int t = 0; t < 8; ++t) s2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       {
         AgIn<MODE> sb[1];
+        ag_report_range<MODE>(ag_absmax<MODE, 2>(s1, 0.0f), a.range_rows, nd, valid);
         ag_cvt_tiles<MODE, 1, 0>(s1, sb);
         AG_NODE_DENSE(false, 1, 8, 0, 0, sb, s2, a.prev.scale2_pk, 4);
       }
@@ -350,6 +354,7 @@ __global__ void __launch_bounds__(256, 2) k_schnet_node_stage_split(NodeStageArg
     for (int i = 0; i < 4; ++i) AG_SPLIT_STEP(8 + i, u4[2 + (i & 1)], gk[4 + (i >> 1)]);
     {
       AG_FOR_TILE(u4, 4, ag_ssp_base2(v));
+      ag_report_range<MODE>(ag_absmax<MODE, 4>(u4, 0.0f), a.range_rows, nd, valid);
       AgIn<MODE> k0, k1;
       ag_cvt(u4[0], u4[1], k0);
       ag_cvt(u4[2], u4[3], k1);
@@ -363,6 +368,7 @@ __global__ void __launch_bounds__(256, 2) k_schnet_node_stage_split(NodeStageArg
     for (int i = 0; i < 16; ++i) AG_SPLIT_STEP(12 + i, xc2[i >> 3], ub[i & 7]);
     {
       AgIn<MODE> k0;
+      ag_report_range<MODE>(ag_absmax<MODE, 2>(xc2, 0.0f), a.range_rows, nd, valid);
       ag_cvt(xc2[0], xc2[1], k0);
       ag_xch_put<MODE>(xch, 8 + w, k0, lane);
       __syncthreads();
@@ -394,6 +400,7 @@ __global__ void __launch_bounds__(256, 2) k_schnet_node_stage_split(NodeStageArg
 #pragma unroll
     for (int i = 0; i < 4; ++i) AG_SPLIT_STEP(32 + i, s1[0], xb[i]);
     AG_FOR_TILE(s1, 1, ag_relu(v));
+    ag_report_range<MODE>(ag_absmax<MODE, 2>(s1, 0.0f), a.range_rows, nd, valid);
     ag_cvt(s1[0], s1[1], sb[0]);
 #pragma unroll
     for (int i = 0; i < 2; ++i) AG_SPLIT_STEP(36 + i, s2[i], sb[0]);
@@ -438,6 +445,7 @@ struct GinArgs {
   const float* h_in;
   float* h_out;
   int64_t n;
+  int32_t* range_rows;         // agdiff_ws_t.range_rows
 };
 
 // GINEConv message sum (gin.py:57-63): m_i = sum_{e: dst = i} relu(h_src(e) + edge_attr_e) + (1 + eps) h_i, written to
@@ -534,6 +542,7 @@ __global__ void __launch_bounds__(LDSW ? 1024 : 256, LDSW ? 1 : 2) k_gin_layer(G
   ag_init_vec<8>(m, a.gp.b2, q);
   {
     AgIn<MODE> yb[4];
+    ag_report_range<MODE>(ag_absmax<MODE, 8>(y1, 0.0f), a.range_rows, nd, valid);
     ag_cvt_tiles<MODE, 4, 0>(y1, yb);
     AG_NODE_DENSE(false, 4, 8, 0, 0, yb, m, a.gp.w2_pk, 32);
   }
@@ -584,6 +593,7 @@ __global__ void __launch_bounds__(1024, 1) k_gin_layer_persistent(GinArgs a) {
     ag_init_vec<8>(m, a.gp.b2, q);
     {
       AgIn<MODE> yb[4];
+      ag_report_range<MODE>(ag_absmax<MODE, 8>(y1, 0.0f), a.range_rows, nd, valid);
       ag_cvt_tiles<MODE, 4, 0>(y1, yb);
       AG_NODE_DENSE(false, 4, 8, 0, 0, yb, m, a.gp.w2_pk, 32);
     }
@@ -1007,6 +1017,7 @@ extern "C" int agdiff_schnet_node_stage_split(const agdiff_params_t* p, const ag
   a.agg2 = nullptr;
   a.agg_first2 = nullptr;
   a.chunk_edges2 = 1;
+  a.range_rows = ws->range_rows;
   // Stage 0 (embedding + block 0's lin1) does not depend on the positions: split bit 2 makes stage 0 write its outputs to
   // the cache ws->h0 / ws->xs0 instead of ws->h / ws->xs, bit 1 makes stage 1 take block 0's input h from that cache.
   if ((split & 4) && k == 0 && ws->h0 && ws->xs0) {
@@ -1099,6 +1110,7 @@ extern "C" int agdiff_gin_encoder(const agdiff_params_t* p, const agdiff_topo_t*
     a.h_in = in;
     a.h_out = bufs[cur];
     a.n = topo->num_nodes;
+    a.range_rows = ws->range_rows;
     hipStream_t st = (hipStream_t)stream;
     k_gin_gather<<<dim3((unsigned)((((topo->num_nodes + 7) / 8) + 7) / 8 * 8)), dim3(256), 0, st>>>(a);   // grid: multiple of 8 (XCD ranges)
     AG_CHECK_LAUNCH();

@@ -313,9 +313,10 @@ class DualEncoderEpsNetwork(nn.Module):
         return prec == "f16x3" or (prec == "bf16x3" and prec_l == "f16x3")
 
     def range_report(self, ws, batch=None):
-        """(name, max |x|, limit, graphs) when a watched node tensor of workspace `ws` has left the split-fp16 range, else None:
-        `name` / `max |x|` / `limit` describe the first such tensor, `graphs` = the graphs (ids of `batch` [N]) that own an
-        offending row of ANY watched tensor (None without `batch`) -- so that one poll quarantines them all.  NaNs are masked
+        """(name, max |x|, limit, graphs) when a watched node tensor of workspace `ws` has left the split-fp16 range -- or a kernel
+        has flagged a node whose hidden activations did (ws.range_rows: node stage, GIN layers, pair heads; the flags are cleared
+        here) --, else None: `name` / `max |x|` / `limit` describe the first such tensor, `graphs` = the graphs (ids of `batch` [N])
+        that own an offending row of ANY of them (None without `batch`) -- so that one poll quarantines them all.  NaNs are masked
         (they are the NaN flag's business, dualenc.py:539-541: a quarantined molecule must not blind the watch for the others):
         the comparisons below are false for a NaN.  Byte-sized temporaries and one host synchronisation: called where the NaN
         flag is polled."""
@@ -330,28 +331,34 @@ class DualEncoderEpsNetwork(nn.Module):
             x = getattr(ws, n)
             o = (x > lims[n]) | (x < -lims[n])
             over.append(o.view(rows, -1).any(dim=1) if rows else o.any().reshape(1))
+        flagged = ws.range_rows != 0
+        names, over = names + ["hidden activations"], over + [flagged if rows else flagged.any().reshape(1)]
         hit = torch.stack([o.any() for o in over]).cpu().tolist()
         if not any(hit):
             return None
         n = names[hit.index(True)]
-        v = float(torch.nan_to_num(getattr(ws, n), nan=0.0).abs().max())
+        if hit[-1]:
+            ws.range_rows.zero_()
+        v = float(torch.nan_to_num(getattr(ws, n), nan=0.0).abs().max()) if n in lims else 65000.0
         graphs = None
         if rows:
             bad_rows = over[0]
             for o in over[1:]:
                 bad_rows = bad_rows | o
             graphs = torch.unique(batch[bad_rows]).cpu().tolist()
-        return n, v, lims[n], graphs
+        return n, v, lims.get(n, 65000.0), graphs
 
     def check_range(self, ws, batch=None):
         """Raise AgdiffRangeError (with .tensor, .value, .limit, .graphs) when range_report finds a violation."""
         rep = self.range_report(ws, batch)
         if rep is not None:
             n, v, lim, graphs = rep
+            what = ("max |%s| = %.3g exceeds %.0f" % (n, v, lim)) if n in dict(self.RANGE_LIMITS) else \
+                "a hidden activation of the node stage, the GIN layers or the pair heads reached %.0f" % lim
             e = _lib.AgdiffRangeError(
-                "max |%s| = %.3g exceeds %.0f: outside the range in which the split-fp16 arithmetic mode is valid (fp16 "
+                "%s: outside the range in which the split-fp16 arithmetic mode is valid (fp16 "
                 "operands saturate at 65504; the pair heads multiply two node features) -- set model.precision = 'bf16x3' "
-                "(agdiff_amd.driver re-samples the affected molecules that way by itself)" % (n, v, lim))
+                "(agdiff_amd.driver re-samples the affected molecules that way by itself)" % what)
             e.tensor, e.value, e.limit, e.graphs = n, v, lim, graphs
             raise e
 
@@ -436,7 +443,7 @@ class DualEncoderEpsNetwork(nn.Module):
                                                 self._fwd_flags(topo, extend_radius), _lib.stream_ptr()),
                        "agdiff_score_forward")
             E = int(ws.num_edges.item())
-            self.check_range(ws)
+            self.check_range(ws, topo.batch64)
             perm = ws.ref2dst[:E].long()                     # reference (row, col)-sorted order
             inv_g = ws.e_inv_global[:E][perm].unsqueeze(-1)
             inv_l = ws.l_inv[:topo.L].clone().unsqueeze(-1)
@@ -654,6 +661,7 @@ class LangevinRun:
         self.k = 0
         self.range_graphs = set()              # graphs taken out of the run because they left the split-fp16 range (check_nan)
         self.ws.nan_flag.zero_()
+        self.ws.range_rows.zero_()
         self._quarantine_non_finite_input()
         self.pos_p = _lib.ptr(self.pos)
         a = _lib.StepArgs()

@@ -437,6 +437,7 @@ class Workspace:
         self.agg_first = f32(chunks * 192)
         self.hl, self.hl2 = f32(N * 128), f32(N * 128)
         self.nan_flag = i32(1 + G)
+        self.range_rows = i32(N)           # agdiff_ws_t.range_rows: per-node flags of the split-fp16 kernels' hidden activations
         self.scratch = f32(N * 3)
         # CFConv by filter polynomials: radius rows by target (agdiff_ws_t.rad_*), local quad tiles (lt_*), padded local list
         RS = _lib.DEFINES["AGDIFF_RAD_STRIDE"]

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 43
+#define AGDIFF_ABI_VERSION 44
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -141,6 +141,8 @@ typedef struct agdiff_head_params {
                                 getattr(F, name); configs/*.yml: relu) */
   int32_t precision;         /* as agdiff_params_t.precision, or 2 (split-fp16: only with attr_rows) */
   int32_t pad0;
+  int32_t* range_rows;       /* as agdiff_ws_t.range_rows (the head's hidden layer; an edge flags its source node), or null.
+                                agdiff_score_forward passes the workspace's */
 } agdiff_head_params_t;
 
 typedef struct agdiff_params {
@@ -395,6 +397,12 @@ typedef struct agdiff_ws {
   float*   hl2;              /* [N][128] (pong) */
   int32_t* nan_flag;         /* [1 + G]: [0] set to 1 when any position becomes NaN, [1 + g] when one of graph g does
                                 (sticky: the host clears them when a sampling job starts) */
+  int32_t* range_rows;       /* [N] or null.  Split-fp16 operands saturate at 65504: the kernels that convert activations which
+                                depend on the STATE and which no tensor of the workspace shows (hidden layers of the node stage, the
+                                GIN layers, the pair heads) set range_rows[node] = 1 when such a value of that node (of an edge's
+                                source node) reaches 65000.  The node's results are then not to be trusted in this mode: the caller
+                                polls the flags with the NaN flag, clears them and runs the owning molecules in split-bf16
+                                (agdiff_amd/epsnet.py range_report).  Never written in the other modes. */
   /* CFConv by filter polynomials (agdiff_params_t.poly_kt > 0): the radius edges (type 0) of the dynamic graph by TARGET, in
    * AGDIFF_RAD_STRIDE rows per target (written by agdiff_graph_build next to the full list; sources ascending).  Rows
    * [rad_cnt[i], 16 ceil(rad_cnt[i] / 16)) of target i are pad rows (src = i, length 0, scale 0: agdiff_edge_scales_split

@@ -980,3 +980,46 @@ def test_split_fp16_range_watch_raises_instead_of_returning_saturated_results():
     m.precision_local = "bf16x3"
     out = m(at, pos, bi, bt, ba, None, return_edges=True, extend_order=False)
     assert bool(torch.isfinite(out[0]).all()) and float(out[0].abs().max()) > 100.0
+
+
+def test_hidden_activations_beyond_fp16_range_are_reported_not_saturated():
+    """Found in round 6 with tools/sharp_modes_probe.py: the same filler with a first encoder layer 24 x sharper keeps every WATCHED
+    node tensor inside the split-fp16 range (max |h| = 203 <= 255) while the global head's hidden layer -- 128 products h_i h_j of
+    up to 4e4 each -- passes 65504 and saturates as an operand of the next layer: the split-fp16 scores came back finite and 4 %
+    off (exact-fp32 mode: 6e-6, split-bf16: 2e-4 against the oracle).  The kernels that convert state-dependent hidden activations
+    (node stage, GIN layers, pair heads) now flag the node (agdiff_ws_t.range_rows) and forward raises AgdiffRangeError; the flags
+    are cleared by the poll; split-bf16 on the same weights agrees with the exact-fp32 mode."""
+    from agdiff_amd import _lib, drugs_model_config, get_model, synth
+    cfg = drugs_model_config(beta_end=2e-5)
+    b = synth.make_packed_batch("drugs", 2, 2, seed=77)
+    at, bi, bt, ba = [t(b[k]).cuda() for k in ("atom_type", "bond_index", "bond_type", "batch")]
+    pos = (torch.randn(at.shape[0], 3, generator=torch.Generator().manual_seed(5)) * 2.0).cuda()
+
+    def model(precision, scale):
+        m = get_model(cfg)
+        m.precision = precision
+        sd = synth.synth_state_dict(m.state_dict())
+        for k in sd:
+            if synth.canonical_key(k) == "edge_encoder_global.feature_expansion.weight":
+                sd[k] = sd[k] * scale
+        m.load_state_dict(sd)
+        return m.to("cuda:0").eval()
+    m = model("f16x3", 24.0)
+    with pytest.raises(_lib.AgdiffRangeError) as e:
+        m(at, pos, bi, bt, ba, None, return_edges=True, extend_order=False)
+    assert e.value.tensor == "hidden activations" and "hidden activation" in str(e.value) and "bf16x3" in str(e.value)
+    ws = m._batch_cache[2]
+    assert float(ws.h.abs().max()) < 255.0 and float(ws.agg.abs().max()) < 60000.0        # (no watched tensor shows it)
+    assert int(ws.range_rows.sum()) == 0 and m.range_report(ws, ba) is None                # (cleared by the poll that reported them)
+    assert sorted(e.value.graphs) == sorted(set(e.value.graphs)) and set(e.value.graphs) <= set(range(int(b["num_graphs"])))
+    ref = model("f32", 24.0)(at, pos, bi, bt, ba, None, return_edges=True, extend_order=False)
+    mb = model("bf16x3", 24.0)
+    got = mb(at, pos, bi, bt, ba, None, return_edges=True, extend_order=False)
+    err = float((got[0] - ref[0]).abs().max() / ref[0].abs().max())
+    assert err < 1e-3, err
+    # a scale at which nothing leaves the range: no flag, no exception, and the split-fp16 result is the accurate one
+    m16 = model("f16x3", 16.0)
+    got16 = m16(at, pos, bi, bt, ba, None, return_edges=True, extend_order=False)
+    ref16 = model("f32", 16.0)(at, pos, bi, bt, ba, None, return_edges=True, extend_order=False)
+    assert int(m16._batch_cache[2].range_rows.sum()) == 0
+    assert float((got16[0] - ref16[0]).abs().max() / ref16[0].abs().max()) < 2e-5
