@@ -466,6 +466,13 @@ def main():
         launcher_selftest(world, rank)
         return
 
+    # From here on this process measures.  Its stdout carries ONE line, the JSON record: whatever libraries print there (RCCL's
+    # version banner comes through C stdio when a process group forms) goes to stderr instead -- file descriptor 1 is pointed at
+    # stderr and the record is written to a duplicate of the original taken first.
+    sys.stdout.flush()
+    record_fd = os.dup(1)
+    os.dup2(2, 1)
+
     JOB_STEPS = args.job_steps
     d200 = args.workload == "drugs200"
     K = args.steps if args.steps is not None else (10 if d200 else 1000)
@@ -1044,8 +1051,8 @@ def main():
         if args.rehearse_on_one_gpu:
             out["config"]["rehearsal"] = "all %d ranks on ONE GPU, collectives over gloo: a run of the multi-rank code path, not a scaling figure" % world
         sys.stdout.flush()
-        ctypes.CDLL(None).fflush(None)         # RCCL writes its banner through C stdio (block-buffered on a pipe):
-        print(json.dumps(out), flush=True)     # push it out first, so that the JSON is the last line of stdout
+        ctypes.CDLL(None).fflush(None)         # (C stdio of the libraries: block-buffered on a pipe)
+        os.write(record_fd, (json.dumps(out) + "\n").encode())       # the one line of this process's stdout
 
 
 if __name__ == "__main__":
