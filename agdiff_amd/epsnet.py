@@ -284,8 +284,10 @@ class DualEncoderEpsNetwork(nn.Module):
                     r = rep[branch]
                     if r["err"] > SPLIT_FP16_MAX_ERR or r["clipped"]:
                         import warnings
-                        warnings.warn("agdiff_amd: the %s branch's weights do not fit split-fp16 (%s: normwise error %.2g%s); "
-                                      "that branch runs in split-bf16" % (branch, r["worst"], r["err"], ", clipped" if r["clipped"] else ""))
+                        why = ("activations of the edge encoder / filter networks reach %.3g" % r["activations"]) if r.get("activations") else \
+                            "%s: normwise error %.2g%s" % (r["worst"], r["err"], ", clipped" if r["clipped"] else "")
+                        warnings.warn("agdiff_amd: the %s branch's weights do not fit split-fp16 (%s); "
+                                      "that branch runs in split-bf16" % (branch, why))
                         if branch == "global":
                             prec, prec_l = "bf16x3", (prec_l or pk.precision_local)
                         else:

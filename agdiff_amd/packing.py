@@ -127,6 +127,7 @@ def split_fp16_error(W):
 # split-fp16 is taken for a branch only while every matrix it packs keeps this normwise accuracy (2^-19: an eighth of what the
 # mode gives O(1) weights, ~10 x better than split-bf16's 2^-16) and nothing is clipped; otherwise the branch runs in split-bf16
 SPLIT_FP16_MAX_ERR = 2.0 ** -19
+SPLIT_FP16_ACT_LIMIT = 60000.0       # activations that become split-fp16 operands (encoder_activation_max; fp16 saturates at 65504)
 
 
 def fold_bn(W, b, sd, p, eps=1e-5):
@@ -244,6 +245,37 @@ def _edge_attr_fn(sd, e, typ):
         h = F.linear(F.gelu(F.linear(torch.cat([x, b], 1), W0, b0)), W2, b2)
         return F.linear(F.gelu(F.linear(torch.cat([h, b], 1), C0, c0)), C2, c2)
     return fn
+
+
+def encoder_activation_max(sd, cfg, types=(0, 1, 2, 3, 12, 23, 24), far=10.0):
+    """Largest magnitude any activation of the MLP edge encoder (edge.py:84-103) and of the CFConv filter networks behind it
+    (schnet.py:169-179) takes as an MFMA operand, over lengths in [0, far x cutoff] and the common edge types: these depend on the
+    length and the type alone, so their range is a property of the checkpoint and is checked when it is packed (the split-fp16 mode
+    saturates operands at 65504; the state-dependent activations are flagged by the kernels: agdiff_ws_t.range_rows).  float64."""
+    import torch
+    import torch.nn.functional as F
+    e = "edge_encoder_global"
+    g = lambda k: sd[k].detach().cpu().double()
+    few, feb = g(e + ".feature_expansion.weight"), g(e + ".feature_expansion.bias")
+    W0, b0, W2, b2 = g(e + ".edge_feature_mlp.0.weight"), g(e + ".edge_feature_mlp.0.bias"), g(e + ".edge_feature_mlp.2.weight"), g(e + ".edge_feature_mlp.2.bias")
+    C0, c0, C2, c2 = g(e + ".combination_mlp.0.weight"), g(e + ".combination_mlp.0.bias"), g(e + ".combination_mlp.2.weight"), g(e + ".combination_mlp.2.bias")
+    d = torch.linspace(0.0, float(far) * float(cfg.cutoff), 1025, dtype=torch.float64).view(-1, 1)
+    x = F.gelu(F.linear(d, few, feb))
+    worst = float(x.abs().max())
+    LN2 = float(np.log(2.0))
+    for typ in types:
+        emb = g(e + ".bond_emb.weight")[int(typ)].expand(d.shape[0], -1)
+        h1 = F.gelu(F.linear(torch.cat([x, emb], 1), W0, b0))
+        h2 = F.linear(h1, W2, b2)
+        h3 = F.gelu(F.linear(torch.cat([h2, emb], 1), C0, c0))
+        attr = F.linear(h3, C2, c2)
+        worst = max(worst, float(h1.abs().max()), float(h3.abs().max()), float(attr.abs().max()))
+        for k in range(cfg.num_convs):
+            for conv in ("conv1", "conv2"):
+                p = "encoder_global.interactions.%d.%s" % (k, conv)
+                sp = F.softplus(g(p + ".nn.1.beta") * F.linear(attr, g(p + ".nn.0.weight"), g(p + ".nn.0.bias"))) - LN2
+                worst = max(worst, float(sp.abs().max()))
+    return worst
 
 
 def _poly_targets(sd, cfg, typ, with_head):
@@ -536,6 +568,15 @@ class PackedParams:
             scalars["ge_coeff"] = -0.5 / float(off[1] - off[0]) ** 2    # (offset[1]-offset[0]).item() ** 2
         else:
             self._pack_mlp_edge_encoder(sd, e, arrays, pack_blocks)
+            if mode == 2:       # (activations that depend on the length and the type alone: their range is the checkpoint's)
+                key = (_poly_weights_digest(sd, cfg), float(cfg.cutoff), int(cfg.num_convs), "activation_max")
+                if key not in _FIT_CACHE:
+                    _FIT_CACHE[key] = encoder_activation_max(sd, cfg)
+                amax = _FIT_CACHE[key]
+                self.encoder_activation_max = amax
+                if not amax < SPLIT_FP16_ACT_LIMIT:
+                    r = self.split_fp16_report["global"]
+                    r["clipped"], r["activations"] = True, amax
         arrays["schnet_emb"] = _np(sd, "encoder_global.embedding.weight")
         arrays["gin_emb"] = _np(sd, "encoder_local.node_emb.weight")
         self._pack_rest(sd, cfg, device, mode, arrays, scalars, pack_blocks)

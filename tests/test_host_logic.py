@@ -764,3 +764,24 @@ def test_pass_plan_of_the_96_and_128_term_rungs():
         assert packing.PackedParams(sd, cfg, "cpu", precision, poly_passes="full").poly_plan == 0
     # (split-bf16 rounds an operand to 8 bits instead of 11: the terms 32..63, and at 128 terms 64..95 too, are then too heavy for one pass)
     assert seen == {("f16x3", 32.0): 1, ("f16x3", 64.0): 2, ("bf16x3", 32.0): 2, ("bf16x3", 64.0): 3}, seen
+
+
+def test_length_only_activations_beyond_fp16_range_send_the_branch_to_split_bf16():
+    """The MLP edge encoder's and the filter networks' activations depend on an edge's length and type alone: their range is a
+    property of the checkpoint.  When one of them would saturate as a split-fp16 operand (65504) the pack-time report says so --
+    DualEncoderEpsNetwork.packed() then packs the global branch in split-bf16, as for weights the mode cannot hold -- although every
+    MATRIX of the checkpoint fits the mode."""
+    from agdiff_amd import drugs_model_config, packing
+    from oracle import agdiff_oracle as O
+    cfg = drugs_model_config()
+    sd = O.synth_state_dict_for(cfg)
+    pk = packing.PackedParams(sd, cfg, "cpu", "f16x3")
+    rep = pk.split_fp16_report["global"]
+    assert pk.encoder_activation_max < 1e3 and not rep["clipped"] and rep["err"] <= packing.SPLIT_FP16_MAX_ERR
+    assert abs(packing.encoder_activation_max(sd, cfg) - pk.encoder_activation_max) < 1e-9
+    sd["edge_encoder_global.feature_expansion.weight"] = sd["edge_encoder_global.feature_expansion.weight"] * 3000.0
+    pk = packing.PackedParams(sd, cfg, "cpu", "f16x3", radius_poly="off")
+    rep = pk.split_fp16_report["global"]
+    assert pk.encoder_activation_max > packing.SPLIT_FP16_ACT_LIMIT and rep["clipped"] and rep["activations"] == pk.encoder_activation_max
+    assert rep["err"] <= packing.SPLIT_FP16_MAX_ERR            # (no matrix is the problem)
+    assert not hasattr(packing.PackedParams(sd, cfg, "cpu", "bf16x3", radius_poly="off"), "encoder_activation_max")
