@@ -168,6 +168,9 @@ __device__ __forceinline__ void ag_head_act(f32x4 (&y)[NY], int act) {
     case AGDIFF_ACT_HARDSIGMOID: AG_FOR_TILE(y, NT, fminf(fmaxf(v + 3.0f, 0.0f), 6.0f) * (1.0f / 6.0f)); break;
     case AGDIFF_ACT_SOFTSIGN: AG_FOR_TILE(y, NT, v * ag_rcp(1.0f + fabsf(v))); break;
     case AGDIFF_ACT_LOGSIGMOID: AG_FOR_TILE(y, NT, -ag_softplus(-v)); break;
+    case AGDIFF_ACT_HARDSHRINK: AG_FOR_TILE(y, NT, fabsf(v) > 0.5f ? v : 0.0f); break;
+    case AGDIFF_ACT_SOFTSHRINK: AG_FOR_TILE(y, NT, v > 0.5f ? v - 0.5f : v < -0.5f ? v + 0.5f : 0.0f); break;
+    case AGDIFF_ACT_RRELU: AG_FOR_TILE(y, NT, v >= 0.0f ? v : v * ((1.0f / 8.0f + 1.0f / 3.0f) / 2.0f)); break;
     default: AG_FOR_TILE(y, NT, ag_relu(v)); break;
   }
 }

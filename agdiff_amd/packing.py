@@ -473,7 +473,8 @@ def dist_union_table(segs, cutoff):
 PRECISIONS = {"f32": 0, "bf16x3": 1, "f16x3": 2}
 # config.mlp_act (models/common.py:62-66: getattr(F, name)) -> agdiff_head_params_t.act (include/agdiff_hip.h AGDIFF_ACT_*)
 HEAD_ACTS = {"relu": 0, "gelu": 1, "silu": 2, "tanh": 3, "sigmoid": 4, "softplus": 5, "leaky_relu": 6, "elu": 7, "celu": 7, "relu6": 8,
-             "hardtanh": 9, "selu": 10, "mish": 11, "hardswish": 12, "hardsigmoid": 13, "softsign": 14, "logsigmoid": 15}
+             "hardtanh": 9, "selu": 10, "mish": 11, "hardswish": 12, "hardsigmoid": 13, "softsign": 14, "logsigmoid": 15, "hardshrink": 16,
+             "softshrink": 17, "rrelu": 18}
 LOCAL_PRECISIONS = {"f32": 0, "bf16x3": 1, "f16x3": 2}      # agdiff_params_t.precision_local
 EDGE_ENCODERS = {"mlp": 0, "gaussian": 1}       # agdiff_params_t.edge_encoder
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 44
+#define AGDIFF_ABI_VERSION 45
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -128,6 +128,9 @@ typedef struct agdiff_gin_params {
 #define AGDIFF_ACT_HARDSIGMOID 13
 #define AGDIFF_ACT_SOFTSIGN 14
 #define AGDIFF_ACT_LOGSIGMOID 15
+#define AGDIFF_ACT_HARDSHRINK 16  /* lambd 0.5 */
+#define AGDIFF_ACT_SOFTSHRINK 17  /* lambd 0.5 */
+#define AGDIFF_ACT_RRELU 18       /* as evaluated (training=False): negative slope (1/8 + 1/3) / 2 */
 typedef struct agdiff_head_params {
   const float* w1_pk;        /* pkk [8][8] layers.0 (256->128) */
   const float* b1;           /* [128] */

@@ -322,7 +322,7 @@ def g_mlp_act():
     """config.mlp_act other than relu (models/common.py:62-66 builds the heads' MultiLayerPerceptron with getattr(F, name)):
     one small forward per activation the HIP heads implement."""
     for act in ("gelu", "silu", "tanh", "sigmoid", "softplus", "leaky_relu", "elu", "celu", "relu6", "hardtanh", "selu", "mish", "hardswish",
-                "hardsigmoid", "softsign", "logsigmoid"):
+                "hardsigmoid", "softsign", "logsigmoid", "hardshrink", "softshrink", "rrelu"):
         cfg = qm9_model_config(mlp_act=act)
         m = build_ref(cfg, head_scale=1.0)
         b, pos = small_batch("qm9", 51, 2, 2, 1.5)

@@ -168,7 +168,7 @@ def test_trajectory_copied_while_sampling_equals_the_copy_at_the_end():
 
 
 MLP_ACTS = ["gelu", "silu", "tanh", "sigmoid", "softplus", "leaky_relu", "elu", "celu", "relu6", "hardtanh", "selu", "mish", "hardswish",
-            "hardsigmoid", "softsign", "logsigmoid"]
+            "hardsigmoid", "softsign", "logsigmoid", "hardshrink", "softshrink", "rrelu"]
 
 
 # (round 5's seven activations in all three modes; round 6's nine in the two split modes -- the exact-fp32 mode shares the

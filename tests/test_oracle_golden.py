@@ -67,7 +67,7 @@ def test_forward_g3(case):
 
 
 MLP_ACTS = ["gelu", "silu", "tanh", "sigmoid", "softplus", "leaky_relu", "elu", "celu", "relu6", "hardtanh", "selu", "mish", "hardswish",
-            "hardsigmoid", "softsign", "logsigmoid"]
+            "hardsigmoid", "softsign", "logsigmoid", "hardshrink", "softshrink", "rrelu"]
 
 
 @pytest.mark.parametrize("act", MLP_ACTS)
