@@ -459,7 +459,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world == 1:
         # no launcher around us: become one.  Nothing above this line has touched a GPU.
-        sys.exit(spawn_ranks(args.gpus, sys.argv[1:], selftest=args.launcher_selftest))
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:], selftest=args.launcher_selftest or args.rehearse_on_one_gpu))    # (a rehearsal puts every rank on GPU 0)
     if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.launcher_selftest:
