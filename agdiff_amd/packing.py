@@ -569,15 +569,18 @@ class PackedParams:
             scalars["ge_coeff"] = -0.5 / float(off[1] - off[0]) ** 2    # (offset[1]-offset[0]).item() ** 2
         else:
             self._pack_mlp_edge_encoder(sd, e, arrays, pack_blocks)
-            if mode == 2:       # (activations that depend on the length and the type alone: their range is the checkpoint's)
+            if mode == 2 or lmode == 2:       # (activations that depend on the length and the type alone: their range is the checkpoint's;
+                # the local branch's kernels read the encoder's rows as operands too)
                 key = (_poly_weights_digest(sd, cfg), float(cfg.cutoff), int(cfg.num_convs), "activation_max")
                 if key not in _FIT_CACHE:
                     _FIT_CACHE[key] = encoder_activation_max(sd, cfg)
                 amax = _FIT_CACHE[key]
                 self.encoder_activation_max = amax
                 if not amax < SPLIT_FP16_ACT_LIMIT:
-                    r = self.split_fp16_report["global"]
-                    r["clipped"], r["activations"] = True, amax
+                    for branch, on in (("global", mode == 2), ("local", lmode == 2)):
+                        if on:
+                            self.split_fp16_report[branch]["clipped"] = True
+                            self.split_fp16_report[branch]["activations"] = amax
         arrays["schnet_emb"] = _np(sd, "encoder_global.embedding.weight")
         arrays["gin_emb"] = _np(sd, "encoder_local.node_emb.weight")
         self._pack_rest(sd, cfg, device, mode, arrays, scalars, pack_blocks)

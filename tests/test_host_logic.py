@@ -784,4 +784,8 @@ def test_length_only_activations_beyond_fp16_range_send_the_branch_to_split_bf16
     rep = pk.split_fp16_report["global"]
     assert pk.encoder_activation_max > packing.SPLIT_FP16_ACT_LIMIT and rep["clipped"] and rep["activations"] == pk.encoder_activation_max
     assert rep["err"] <= packing.SPLIT_FP16_MAX_ERR            # (no matrix is the problem)
-    assert not hasattr(packing.PackedParams(sd, cfg, "cpu", "bf16x3", radius_poly="off"), "encoder_activation_max")
+    # split-bf16 global branch next to a split-fp16 local one (the default pairing after a fallback): the local kernels read the
+    # encoder's rows as operands too -- that branch is reported; with both in split-bf16 nothing is checked
+    pk = packing.PackedParams(sd, cfg, "cpu", "bf16x3", radius_poly="off")
+    assert pk.precision_local == "f16x3" and pk.split_fp16_report["local"]["clipped"] and not pk.split_fp16_report["global"]["clipped"]
+    assert not hasattr(packing.PackedParams(sd, cfg, "cpu", "bf16x3", radius_poly="off", precision_local="bf16x3"), "encoder_activation_max")
