@@ -309,10 +309,13 @@ __device__ __forceinline__ float ag_absmax(const f32x4 (&a)[NA], float mx) {
   }
   return mx;
 }
+// (`limit`: 65000 for a value that becomes an operand itself; 255 for a node state the pair heads multiply with another one, 60000
+// for the aggregates and CFConv inputs -- the figures of the host's tensor watch, agdiff_amd/epsnet.py RANGE_LIMITS: checked where
+// a kernel stores such a row, the flag is sticky between two polls where the tensor only shows its last state)
 template <int MODE>
-__device__ __forceinline__ void ag_report_range(float mx, int32_t* rows, int64_t row, bool live) {
+__device__ __forceinline__ void ag_report_range(float mx, int32_t* rows, int64_t row, bool live, float limit = 65000.0f) {
   if constexpr (MODE == AG_H3) {
-    if (rows && live && mx >= 65000.0f) rows[row] = 1;
+    if (rows && live && mx >= limit) rows[row] = 1;
   }
 }
 

@@ -214,6 +214,7 @@ __global__ void __launch_bounds__(LDSW ? 1024 : 256, LDSW ? 1 : 2) k_schnet_node
     }
   }
   if (!active) return;                     // no barrier below this point
+  ag_report_range<MODE>(ag_absmax<MODE, 8>(hv, 0.0f), a.range_rows, nd, valid, 255.0f);       // (the node state: the heads multiply two of them)
   if (valid) ag_store_row<8, 0>(hv, a.h + (size_t)node * 128, q);
   if (a.prep) {
     f32x4 xo[12];
@@ -224,6 +225,7 @@ __global__ void __launch_bounds__(LDSW ? 1024 : 256, LDSW ? 1 : 2) k_schnet_node
       AG_NODE_DENSE(false, 4, 12, 0, 0, hb, xo, a.next.lin1_pk, 12);
     }
     AG_FOR_TILE(xo, 12, ag_lrelu(v));
+    ag_report_range<MODE>(ag_absmax<MODE, 12>(xo, 0.0f), a.range_rows, nd, valid, 60000.0f);
     if (valid) ag_store_row<12, 0>(xo, a.xs + (size_t)node * 192, q);
   }
 }
@@ -410,6 +412,7 @@ __global__ void __launch_bounds__(256, 2) k_schnet_node_stage_split(NodeStageArg
       for (int r = 0; r < 4; ++r) hv2[j][r] = hv2[j][r] + xc2[j][r] * ag_sigmoid(s2[j][r]);
       if (valid) ag_st4(a.h + (size_t)node * 128 + 16 * (2 * w + j) + 4 * q, hv2[j]);
     }
+    ag_report_range<MODE>(ag_absmax<MODE, 2>(hv2, 0.0f), a.range_rows, nd, valid, 255.0f);
     if constexpr (PREP) {
       AgIn<MODE> k0;
       ag_cvt(hv2[0], hv2[1], k0);
@@ -426,6 +429,7 @@ __global__ void __launch_bounds__(256, 2) k_schnet_node_stage_split(NodeStageArg
 #undef AG_SPLIT_STEP
   if (PREP) {
     AG_FOR_TILE(xo3, 3, ag_lrelu(v));
+    ag_report_range<MODE>(ag_absmax<MODE, 3>(xo3, 0.0f), a.range_rows, nd, valid, 60000.0f);
     if (valid) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) ag_st4(a.xs + (size_t)node * 192 + 16 * (3 * w + j) + 4 * q, xo3[j]);
@@ -549,6 +553,7 @@ __global__ void __launch_bounds__(LDSW ? 1024 : 256, LDSW ? 1 : 2) k_gin_layer(G
   if (a.gp.relu_out) { AG_FOR_TILE(m, 8, ag_relu(v)); }
 #pragma unroll
   for (int t = 0; t < 8; ++t) m[t] += hself[t];
+  ag_report_range<MODE>(ag_absmax<MODE, 8>(m, 0.0f), a.range_rows, nd, valid, 255.0f);
   if (valid) ag_store_row<8, 0>(m, a.h_out + (size_t)node * 128, q);
 }
 
@@ -600,6 +605,7 @@ __global__ void __launch_bounds__(1024, 1) k_gin_layer_persistent(GinArgs a) {
     if (a.gp.relu_out) { AG_FOR_TILE(m, 8, ag_relu(v)); }
 #pragma unroll
     for (int t = 0; t < 8; ++t) m[t] += hself[t];
+    ag_report_range<MODE>(ag_absmax<MODE, 8>(m, 0.0f), a.range_rows, nd, valid, 255.0f);
     if (valid) ag_store_row<8, 0>(m, a.h_out + (size_t)node * 128, q);
   }
 }

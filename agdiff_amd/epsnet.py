@@ -316,8 +316,8 @@ class DualEncoderEpsNetwork(nn.Module):
 
     def range_report(self, ws, batch=None):
         """(name, max |x|, limit, graphs) when a watched node tensor of workspace `ws` has left the split-fp16 range -- or a kernel
-        has flagged a node whose hidden activations did (ws.range_rows: node stage, GIN layers, pair heads; the flags are cleared
-        here) --, else None: `name` / `max |x|` / `limit` describe the first such tensor, `graphs` = the graphs (ids of `batch` [N])
+        has flagged a node whose hidden activations did, or whose state / CFConv input did when it was stored (ws.range_rows: node
+        stage, GIN layers, pair heads; sticky between two polls, cleared here) --, else None: `name` / `max |x|` / `limit` describe the first such tensor, `graphs` = the graphs (ids of `batch` [N])
         that own an offending row of ANY of them (None without `batch`) -- so that one poll quarantines them all.  NaNs are masked
         (they are the NaN flag's business, dualenc.py:539-541: a quarantined molecule must not blind the watch for the others):
         the comparisons below are false for a NaN.  Byte-sized temporaries and one host synchronisation: called where the NaN

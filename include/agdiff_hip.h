@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AGDIFF_ABI_VERSION 45
+#define AGDIFF_ABI_VERSION 46
 #define AGDIFF_HIDDEN 128          /* config.hidden_dim; InteractionBlock.lin hard-codes 256 = 2*128 (schnet.py:190) */
 #define AGDIFF_MAX_CONVS 8         /* >= config.num_convs (6) */
 #define AGDIFF_MAX_CONVS_LOCAL 8   /* >= config.num_convs_local (4) */
@@ -403,7 +403,10 @@ typedef struct agdiff_ws {
   int32_t* range_rows;       /* [N] or null.  Split-fp16 operands saturate at 65504: the kernels that convert activations which
                                 depend on the STATE and which no tensor of the workspace shows (hidden layers of the node stage, the
                                 GIN layers, the pair heads) set range_rows[node] = 1 when such a value of that node (of an edge's
-                                source node) reaches 65000.  The node's results are then not to be trusted in this mode: the caller
+                                source node) reaches 65000 -- and, where they store them, when a node state (|h|, |hl| >= 255: the
+                                heads multiply two) or a CFConv input (|xs| >= 60000) leaves the range the host's tensor watch
+                                polls, so that an excursion between two polls is not lost.  The node's results are then not to be
+                                trusted in this mode: the caller
                                 polls the flags with the NaN flag, clears them and runs the owning molecules in split-bf16
                                 (agdiff_amd/epsnet.py range_report).  Never written in the other modes. */
   /* CFConv by filter polynomials (agdiff_params_t.poly_kt > 0): the radius edges (type 0) of the dynamic graph by TARGET, in
