@@ -158,6 +158,42 @@ def test_node_stage_block0_vs_reference_modules(case, precision):
     check_close("node_stage1 xs[%s]" % case, ws.xs.view(-1, 192), xs1.float(), precision)
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_node_stage_flags_the_rows_it_takes_out_of_the_split_fp16_range(precision):
+    """agdiff_ws_t.range_rows (round 6): in the split-fp16 mode the node stage flags a node whose hidden activations reach 65000
+    or whose new state |h| passes 255 (the heads multiply two states) WHERE it computes them -- sticky until the host's poll clears
+    it, whatever the tensors show by then.  Aggregates blown up for two nodes: exactly those two are flagged; the other modes
+    (fp32's exponent range) write no flag; a second, tame launch leaves the flags standing."""
+    case = STAGE_CASES[0]
+    g, cfg, sd, m, lib, topo, ws, (P, Tp, Wp, st) = _setup(case, precision)
+    blk = "encoder_global.interactions.0"
+    h0 = t(g["schnet_h0"]).double()
+    assert lib.agdiff_schnet_node_stage(P, Tp, Wp, 0, st) == 0
+    agg_ref = _agg_ref(sd, cfg, blk, g, _xs_ref(sd, blk, h0)).float().cuda()
+    ws.agg_first.zero_()
+    ws.range_rows.zero_()
+    ws.agg.view(-1, 192)[: topo.N].copy_(agg_ref)
+    assert lib.agdiff_schnet_node_stage(P, Tp, Wp, 1, st) == 0
+    torch.cuda.synchronize()
+    assert int(ws.range_rows.sum()) == 0                                  # (the reference's aggregates: nothing near the range)
+    hot = [1, topo.N - 2]
+    big = agg_ref.clone()
+    big[hot] *= 1e7
+    ws.agg.view(-1, 192)[: topo.N].copy_(big)
+    assert lib.agdiff_schnet_node_stage(P, Tp, Wp, 1, st) == 0
+    torch.cuda.synchronize()
+    flagged = torch.nonzero(ws.range_rows[: topo.N]).flatten().cpu().tolist()
+    assert flagged == (hot if precision == "f16x3" else []), (precision, flagged)
+    ws.agg.view(-1, 192)[: topo.N].copy_(agg_ref)                         # a tame launch afterwards: the flags stay
+    assert lib.agdiff_schnet_node_stage(P, Tp, Wp, 1, st) == 0
+    torch.cuda.synchronize()
+    assert torch.nonzero(ws.range_rows[: topo.N]).flatten().cpu().tolist() == flagged
+    if precision == "f16x3":                                              # ... until the poll reports the owning graphs and clears them
+        ba = t(g["batch"]).cuda()
+        rep = m.range_report(ws, ba)
+        assert rep is not None and sorted(rep[3]) == sorted(set(int(ba[i]) for i in hot)) and int(ws.range_rows.sum()) == 0
+
+
 @pytest.mark.parametrize("layout", ["by_batch_size", "quad_tiles", "quads_per_target"])
 @pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("case", STAGE_CASES[:2])
