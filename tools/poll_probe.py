@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Ad-hoc (GPU box): what the sampler's polls cost on a small batch (1 molecule x 100 conformers, 1044 steps, a poll every 64):
+the trajectory landing / sending and the NaN + range poll of LangevinRun.check_nan, timed separately.   python tools/poll_probe.py"""
 import sys, time, json
 sys.path.insert(0, '.')
 import numpy as np, torch
