@@ -100,10 +100,32 @@ def spawn_ranks(n, argv, selftest=False):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL across processes)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, cwd=ROOT,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode())
+    # a rank that dies leaves the others waiting in a collective for ever: watch all of them, and when one exits non-zero stop
+    # the rest (torchrun does the same for the driver's launches)
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while any(p.poll() is None for p in procs):
+        failed = next(((r, p.returncode) for r, p in enumerate(procs) if p.poll() not in (None, 0)), None)
+        if failed is not None:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.2)
+    for p in procs:
+        try:
+            p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    reader.join(timeout=30)
+    codes = [p.returncode for p in procs]
+    sys.stdout.write((out0[0] if out0 else b"").decode())
     sys.stdout.flush()
+    if failed is not None:
+        print("bench.py --gpus %d: rank %d exited with code %s; the other ranks were stopped" % (n, failed[0], failed[1]), file=sys.stderr)
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad:
         print("bench.py --gpus %d: rank(s) failed: %s" % (n, bad), file=sys.stderr)
@@ -115,6 +137,8 @@ def launcher_selftest(world, rank):
     """Wiring check of spawn_ranks on CPU (tests/test_dist_cpu.py): the ranks meet over gloo, rank 0 prints one JSON line."""
     import torch
     import torch.distributed as dist
+    if os.environ.get("AGDIFF_SELFTEST_FAIL_RANK") == str(rank):       # (test hook: a rank that dies before its first collective)
+        sys.exit(7)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     x = torch.tensor([rank + 1], dtype=torch.int64)
     dist.all_reduce(x)

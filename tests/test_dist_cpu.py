@@ -209,6 +209,13 @@ def test_bench_launcher_spawns_ranks_and_fails_cleanly():
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads(out.stdout.strip().splitlines()[-1])
     assert rec == {"selftest": True, "rccl_ranks": 3, "sum_of_ranks": 6, "local_rank_env": "0"}
+    # a rank that dies before its first collective would leave the others waiting for ever: the launcher stops them and fails
+    import time
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--launcher-selftest"],
+                         capture_output=True, text=True, timeout=200, env=dict(env, AGDIFF_SELFTEST_FAIL_RANK="1"))
+    assert out.returncode == 1 and "rank 1 exited with code 7" in out.stderr and out.stdout.strip() == "", (out.returncode, out.stderr[-800:])
+    assert time.time() - t0 < 150
     if torch.cuda.device_count() < 2:
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                              capture_output=True, text=True, timeout=300, env=env)
